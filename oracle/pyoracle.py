@@ -1,0 +1,223 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY -- "parity unpinned" (see oracle/suhmo_oracle.h).  May be
+imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; the
+product package suhmo_amd never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class OrPhys(C.Structure):
+    _fields_ = [("A", C.c_double), ("omega", C.c_double), ("nu", C.c_double),
+                ("cutOffbr", C.c_double), ("maxOffbr", C.c_double),
+                ("rho_w_g", C.c_double), ("grav", C.c_double),
+                ("cutOffB", C.c_int), ("use_NL", C.c_int), ("use_mask_gradients", C.c_int)]
+
+
+class OrBC(C.Structure):
+    _fields_ = [("type", (C.c_int * 2) * 2), ("value", (C.c_double * 2) * 2),
+                ("periodic", C.c_int * 2)]
+
+
+class OrSolverParams(C.Structure):
+    _fields_ = [("num_smooth", C.c_int), ("num_bottom", C.c_int), ("max_iter", C.c_int),
+                ("iter_min", C.c_int), ("imin", C.c_int), ("eps", C.c_double),
+                ("hang", C.c_double), ("norm_thresh", C.c_double),
+                ("bcoeff_otf", C.c_int), ("max_depth", C.c_int)]
+
+
+F_PHI, F_RHS, F_ACOEF, F_B, F_PI, F_ZB, F_MASK, F_BX, F_BY, F_LAMBDA, F_RES, F_LPHI, F_NL, F_DNL = range(14)
+F_PHIOLD, F_CORR = 14, 15
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("suhmo_oracle.c", "level_shim.c", "suhmo_oracle.h", "level_shim.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        dp = C.POINTER(C.c_double)
+        L.or_level_create.restype = C.c_void_p
+        L.or_level_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                      C.POINTER(OrBC), C.POINTER(OrPhys), C.c_double, C.c_double, C.c_int]
+        L.or_level_destroy.argtypes = [C.c_void_p]
+        L.or_level_num_depths.argtypes = [C.c_void_p]
+        L.or_level_num_boxes.argtypes = [C.c_void_p]
+        L.or_level_set.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int]
+        L.or_level_get.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int]
+        for name in ("or_level_exchange",):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.or_level_bc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        for name in ("or_level_reset_lambda", "or_level_nonlinear", "or_level_residual",
+                     "or_level_restrict_residual", "or_level_restrict_r",
+                     "or_level_update_operator", "or_level_average_operator"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int]
+        L.or_level_gsrb.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.or_level_apply_op.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.or_level_prolong_increment.argtypes = [C.c_void_p, C.c_int, dp]
+        L.or_level_build_mg_coefficients.argtypes = [C.c_void_p]
+        L.or_level_norm.restype = C.c_double
+        L.or_level_norm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.or_level_vcycle.argtypes = [C.c_void_p, C.POINTER(OrSolverParams)]
+        L.or_level_solve.restype = C.c_int
+        L.or_level_solve.argtypes = [C.c_void_p, C.POINTER(OrSolverParams), dp]
+        L.or_prolong2_global.argtypes = [dp, dp, C.c_int, C.c_int]
+        L.or_divergence_global.argtypes = [dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.or_difterm_global.argtypes = [dp, dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.or_getflux_global.argtypes = [dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def make_phys(p):
+    return OrPhys(p["A"], p["omega"], p["nu"], p["cutOffbr"], p["maxOffbr"],
+                  p.get("rho_w_g", 9800.0), p.get("grav", 9.8),
+                  int(p.get("cutOffB", 0)), int(p.get("use_NL", 1)), int(p.get("use_mask_gradients", 0)))
+
+
+def make_bc(bc):
+    b = OrBC()
+    for d in range(2):
+        for s in range(2):
+            b.type[d][s] = int(bc["type"][d][s])
+            b.value[d][s] = float(bc["value"][d][s])
+        b.periodic[d] = int(bc["periodic"][d])
+    return b
+
+
+def make_solver_params(sp):
+    return OrSolverParams(sp.get("num_smooth", 4), sp.get("num_bottom", 16), sp.get("max_iter", 100),
+                          sp.get("iter_min", 2), sp.get("imin", 5), sp.get("eps", 1e-7),
+                          sp.get("hang", 0.01), sp.get("norm_thresh", 1e-7),
+                          int(sp.get("bcoeff_otf", 1)), sp.get("max_depth", -1))
+
+
+class OracleLevel:
+    """One AMR level of nx x ny cells split into boxes of at most max_box^2 cells."""
+
+    def __init__(self, nx, ny, dx, dy, bc, phys, alpha=0.0, beta=-1.0, max_box=64, nthreads=1):
+        self.nx, self.ny, self.dx, self.dy = nx, ny, dx, dy
+        self._bc, self._ph = make_bc(bc), make_phys(phys)
+        self.h = lib().or_level_create(nx, ny, dx, dy, max_box, C.byref(self._bc), C.byref(self._ph),
+                                       alpha, beta, nthreads)
+        self.ndepth = lib().or_level_num_depths(self.h)
+        self.nbox = lib().or_level_num_boxes(self.h)
+
+    def close(self):
+        if self.h:
+            lib().or_level_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def shape(self, field, depth=0, ghosted=False):
+        nx, ny = self.nx >> depth, self.ny >> depth
+        if field == F_BX:
+            return (ny, nx + 1)
+        if field == F_BY:
+            return (ny + 1, nx)
+        return (ny + 2, nx + 2) if ghosted else (ny, nx)
+
+    def set(self, field, arr, depth=0, ghosted=False):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        assert a.shape == self.shape(field, depth, ghosted), (a.shape, self.shape(field, depth, ghosted))
+        lib().or_level_set(self.h, depth, field, _dp(a), int(ghosted))
+
+    def get(self, field, depth=0, ghosted=False):
+        out = np.zeros(self.shape(field, depth, ghosted), dtype=np.float64)
+        lib().or_level_get(self.h, depth, field, _dp(out), int(ghosted))
+        return out
+
+    def set_inputs(self, f):
+        """f: dict from suhmo_amd.synthetic (phi, rhs, aCoef valid; B, Pi, zb, mask ghosted)."""
+        self.set(F_PHI, f["phi"])
+        self.set(F_RHS, f["rhs"])
+        self.set(F_ACOEF, f["aCoef"])
+        for k, fid in (("B", F_B), ("Pi", F_PI), ("zb", F_ZB), ("mask", F_MASK)):
+            self.set(fid, f[k], ghosted=True)
+        if "bx" in f:
+            self.set(F_BX, f["bx"])
+            self.set(F_BY, f["by"])
+
+    # restated methods
+    def exchange(self, field, depth=0): lib().or_level_exchange(self.h, depth, field)
+    def bc(self, field, homogeneous, depth=0): lib().or_level_bc(self.h, depth, field, int(homogeneous))
+    def reset_lambda(self, depth=0): lib().or_level_reset_lambda(self.h, depth)
+    def nonlinear(self, depth=0): lib().or_level_nonlinear(self.h, depth)
+    def gsrb(self, sweeps=1, depth=0): lib().or_level_gsrb(self.h, depth, sweeps)
+    def apply_op(self, homogeneous=False, depth=0): lib().or_level_apply_op(self.h, depth, int(homogeneous))
+    def residual(self, depth=0): lib().or_level_residual(self.h, depth)
+    def restrict_residual(self, depth=0): lib().or_level_restrict_residual(self.h, depth)
+    def restrict_r(self, depth=0): lib().or_level_restrict_r(self.h, depth)
+    def update_operator(self, depth=0): lib().or_level_update_operator(self.h, depth)
+    def average_operator(self, depth): lib().or_level_average_operator(self.h, depth)
+    def build_mg_coefficients(self): lib().or_level_build_mg_coefficients(self.h)
+    def norm(self, field, ord=0, depth=0): return lib().or_level_norm(self.h, depth, field, ord)
+
+    def prolong_increment(self, coarse_corr, depth=0):
+        a = np.ascontiguousarray(coarse_corr, dtype=np.float64)
+        lib().or_level_prolong_increment(self.h, depth, _dp(a))
+
+    def vcycle(self, sp):
+        s = make_solver_params(sp)
+        lib().or_level_vcycle(self.h, C.byref(s))
+
+    def solve(self, sp):
+        s = make_solver_params(sp)
+        hist = np.zeros(s.max_iter + 2)
+        n = lib().or_level_solve(self.h, C.byref(s), _dp(hist))
+        return n, hist[: n + 1]
+
+
+def prolong2(fine, coarse_ghosted):
+    f = np.ascontiguousarray(fine, dtype=np.float64).copy()
+    c = np.ascontiguousarray(coarse_ghosted, dtype=np.float64)
+    ny, nx = f.shape
+    assert c.shape == (ny // 2 + 2, nx // 2 + 2)
+    lib().or_prolong2_global(_dp(f), _dp(c), nx, ny)
+    return f
+
+
+def divergence(ux, uy, dx, dy, div0=None):
+    ny, nx = uy.shape[0] - 1, ux.shape[1] - 1
+    d = np.zeros((ny, nx)) if div0 is None else np.ascontiguousarray(div0, dtype=np.float64).copy()
+    lib().or_divergence_global(_dp(np.ascontiguousarray(ux)), _dp(np.ascontiguousarray(uy)), _dp(d), nx, ny, dx, dy)
+    return d
+
+
+def difterm(phi_ghosted, dxf, dyf, dx, dy):
+    ny, nx = phi_ghosted.shape[0] - 2, phi_ghosted.shape[1] - 2
+    out = np.zeros((ny, nx))
+    lib().or_difterm_global(_dp(np.ascontiguousarray(phi_ghosted)), _dp(np.ascontiguousarray(dxf)),
+                            _dp(np.ascontiguousarray(dyf)), _dp(out), nx, ny, dx, dy)
+    return out
+
+
+def getflux(phi_ghosted, bface, direction, beta, dx_dir, ref=1):
+    ny, nx = phi_ghosted.shape[0] - 2, phi_ghosted.shape[1] - 2
+    out = np.zeros_like(bface)
+    lib().or_getflux_global(_dp(np.ascontiguousarray(phi_ghosted)), _dp(np.ascontiguousarray(bface)), _dp(out),
+                            nx, ny, direction, beta, dx_dir, ref)
+    return out

@@ -1,0 +1,122 @@
+/*
+ * suhmo_oracle.h -- TEST INFRASTRUCTURE ONLY (not product code).
+ *
+ * CPU restatement, in plain C, of the per-box Chombo-Fortran kernels on SUHMO's
+ * nonlinear variable-coefficient Poisson (hydraulic head) solve.  Every function
+ * cites the reference file:line (relative to the SUHMO checkout) it follows, keeps
+ * the reference's loop order and expression association, and is compiled with
+ * -ffp-contract=off so that the HIP kernels can be compared against it bit for bit.
+ *
+ * PARITY STATUS: "parity unpinned".  The reference ships no kernel-level golden
+ * vectors or unit tests for this path and cannot be compiled here (it needs an
+ * un-vendored Chombo fork); this restatement is pinned only by reference-free
+ * known-answer tests (tests/test_oracle_*.py) and the hand-computed fixture under
+ * tests/golden/.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * Array convention = Chombo FArrayBox: column-major, i fastest, box
+ * [lo0:hi0] x [lo1:hi1], component slowest.
+ */
+#ifndef SUHMO_ORACLE_H
+#define SUHMO_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OrFab {
+    double *p;
+    int lo0, lo1, hi0, hi1; /* inclusive index box of the allocation */
+    int ncomp;
+} OrFab;
+
+typedef struct OrBox {
+    int lo0, lo1, hi0, hi1; /* inclusive */
+} OrBox;
+
+/* physics constants reaching the kernels (suhmo_params.cpp:51-74; the .ChF files
+ * hard-code 1000.0*9.8 and 9.8, AmrHydroF.ChF:45-52,103,217).  `grav` is a field so
+ * that a gfortran build without real-8 promotion (single-precision literal 9.8
+ * widened to double = 9.80000019073486328125) can be reproduced; default 9.8. */
+typedef struct OrPhys {
+    double A;          /* suhmo.A          */
+    double omega;      /* turbulentParam   */
+    double nu;         /* WaterViscosity   */
+    double cutOffbr;   /* suhmo.cutOffbr   */
+    double maxOffbr;   /* suhmo.maxOffbr   */
+    double rho_w_g;    /* 1000.0*9.8 = 9800.0 */
+    double grav;       /* 9.8 */
+    int    cutOffB;    /* solver.cut_solve_outside_domain */
+    int    use_NL;     /* solver.use_NL */
+    int    use_mask_gradients; /* solver.use_mask_for_gradients */
+} OrPhys;
+
+static inline double *or_at(const OrFab *f, int i, int j, int n)
+{
+    long nx = (long)(f->hi0 - f->lo0 + 1);
+    long ny = (long)(f->hi1 - f->lo1 + 1);
+    return f->p + ((long)(i - f->lo0) + nx * ((long)(j - f->lo1) + ny * (long)n));
+}
+
+/* src/VCAMRNonLinearPoissonOpF.ChF:46-168 */
+void or_gsrbhelmholtzvcnl2d(OrFab *phi, const OrFab *rhs, OrBox region, const double dx[2],
+                            double alpha, const OrFab *aCoef, double beta,
+                            const OrFab *bCoef0, const OrFab *bCoef1,
+                            const OrFab *nlfunc, const OrFab *nlDfunc,
+                            const OrFab *lambda, int redBlack);
+/* src/VCAMRNonLinearPoissonOpF.ChF:201-284 */
+void or_vcnlcomputeop2d(OrFab *lofphi, const OrFab *phi, double alpha, const OrFab *aCoef,
+                        double beta, const OrFab *bCoef0, const OrFab *bCoef1,
+                        const OrFab *nlfunc, OrBox region, const double dx[2]);
+/* src/VCAMRNonLinearPoissonOpF.ChF:320-406 */
+void or_vcnlcomputeres2d(OrFab *res, const OrFab *phi, const OrFab *rhs, double alpha,
+                         const OrFab *aCoef, double beta, const OrFab *bCoef0,
+                         const OrFab *bCoef1, const OrFab *nlfunc, OrBox region,
+                         const double dx[2]);
+/* src/VCAMRNonLinearPoissonOpF.ChF:419-449 (and AMRNonLinearPoissonOpF.ChF:491-522) */
+void or_restrictvcnl(OrFab *phiCoarse, const OrFab *phiFine, OrBox region);
+/* src/VCAMRNonLinearPoissonOpF.ChF:480-561 */
+void or_restrictresvcnl2d(OrFab *res, const OrFab *phi, const OrFab *rhs, double alpha,
+                          const OrFab *aCoef, double beta, const OrFab *bCoef0,
+                          const OrFab *bCoef1, const OrFab *nlfunc, OrBox region,
+                          const double dx[2]);
+/* src/VCAMRNonLinearPoissonOpF.ChF:574-601 */
+void or_sumfacesnl(OrFab *lhs, double beta, const OrFab *bCoefs, OrBox box, int dir,
+                   double scale);
+/* src/AMRNonLinearPoissonOpF.ChF:607-632 */
+void or_prolongnl(OrFab *phi, const OrFab *coarse, OrBox region, int m);
+/* src/AMRNonLinearPoissonOpF.ChF:646-709 */
+void or_prolong_2_nl(OrFab *phi, const OrFab *coarse, OrBox region, int m);
+/* src/AMRNonLinearPoissonOpF.ChF:711-741 */
+void or_newgetfluxnl(OrFab *flux, const OrFab *phi, OrBox box, double beta_dx, int idir);
+/* src/VCAMRNonLinearPoissonOp.cpp:792-841 (C++ BoxIterator loop) */
+void or_vc_getflux(OrFab *flux, const OrFab *phi, const OrFab *bCoefDir, OrBox facebox,
+                   int dir, double beta, double dx_dir, int ref);
+/* src/AmrHydroF.ChF:23-68 */
+void or_computenonlinearterms(const OrFab *phi, const OrFab *aB, const OrFab *IM,
+                              const OrFab *aPi, const OrFab *aZb, OrBox region,
+                              OrFab *nlfunc, OrFab *dnlfunc, const OrPhys *ph);
+/* src/AmrHydroF.ChF:81-112 */
+void or_computere(const OrFab *aB, const OrFab *agradH, OrBox region, OrFab *Re,
+                  const OrPhys *ph);
+/* src/AmrHydroF.ChF:199-231 */
+void or_computebcoeff(const OrFab *aB, const OrFab *aRe, OrBox region, OrFab *Bcoeff,
+                      const OrFab *IMec, const OrPhys *ph);
+/* src/AmrHydroF.ChF:289-343 */
+void or_computedifterm2d(const OrFab *phi, OrBox region, const double dx[2], OrFab *Dterm,
+                         const OrFab *Dcoef0, const OrFab *Dcoef1);
+/* util/GradientF.ChF:30-85, normal branch 57-70 (dir == edgeDir) */
+void or_newmacgrad(OrFab *edgeGrad, const OrFab *mask, const OrFab *phi, OrBox edgeGrid,
+                   const double dx[2], int dir, int hasMask);
+/* util/ExtrapBCF.ChF:7-31 / 39-61 / 69-93 */
+void or_simpleextrapbc(OrFab *phi, OrBox bcbox, int dir, int hiLo);
+void or_simplecopybc(OrFab *phi, OrBox bcbox, int dir, int hiLo);
+void or_nullbc(OrFab *phi, OrBox bcbox, int dir, int hiLo);
+/* util/DivergenceF.ChF:23-57 */
+void or_divergence(const OrFab *uEdge, OrFab *div, OrBox gridInt, double dx, int idir);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,86 @@
+"""Deterministic synthetic inputs for the head-solve hot path.
+
+Formulas follow the reference's initial-condition code so that the fields have the
+magnitudes the kernels see in production:
+  * geometry / ice thickness / overburden: SqrtIBC::initializeData
+    (src/SqrtIBC.cpp:219-262), SHMIP-A domain (exec/A_SHMIP/A3/input.hydro:2)
+  * ice mask: SqrtIBC::setup_iceMask (src/SqrtIBC.cpp:145-167)
+  * physics constants: exec/A_SHMIP/A3/input.hydro:15-36, src/suhmo_params.cpp:51-53
+All arrays are float64, C order [j][i] (i fastest).  "ghosted" arrays carry one ghost
+layer: shape (ny+2, nx+2), cell (i,j) at [j+1, i+1].
+"""
+import numpy as np
+
+RHO_I, RHO_W, GRAV = 910.0, 1000.0, 9.8
+
+A3_PHYS = dict(A=5e-25, omega=1e-3, nu=1.787e-6, cutOffbr=0.0, maxOffbr=1.0e4,
+               rho_w_g=9800.0, grav=9.8, cutOffB=0, use_NL=1, use_mask_gradients=0)
+
+# bc.lo_bc = 0 1 / bc.hi_bc = 1 1, all values 0 (exec/A_SHMIP/A3/input.hydro:8-13)
+A3_BC = dict(type=[[0, 1], [1, 1]], value=[[0.0, 0.0], [0.0, 0.0]], periodic=[0, 0])
+# exec/1_convergence_distributed/256x64/input.hydro:8-13,76: y periodic
+CONV_BC = dict(type=[[0, 1], [1, 1]], value=[[0.0, 0.0], [0.0, 0.0]], periodic=[0, 1])
+
+SOLVER_DEFAULT = dict(num_smooth=4, num_bottom=16, max_iter=100, iter_min=2, imin=5,
+                      eps=1e-7, hang=0.01, norm_thresh=1e-7, bcoeff_otf=1, max_depth=-1)
+
+
+def shmip_fields(nx, ny, lx=1.0e5, ly=2.0e4, vary_B=True, seed=12345, ice_height=5000.0,
+                 slope=0.0, gap_init=0.01, source=5.79e-9, j0=0, ny_total=None):
+    """K-bench inputs.  j0 / ny_total select a strip of rows [j0, j0+ny) of a taller
+    domain (used by the multi-GPU weak-scaling bench; random phi is seeded per row
+    block so any partition sees the same global field)."""
+    ny_total = ny if ny_total is None else ny_total
+    dx, dy = lx / nx, ly / ny_total
+    i = np.arange(-1, nx + 1, dtype=np.float64)
+    j = np.arange(j0 - 1, j0 + ny + 1, dtype=np.float64)
+    x = (i + 0.5) * dx
+    y = (j + 0.5) * dy
+    X, Y = np.meshgrid(x, y)  # (ny+2, nx+2)
+    zb = slope * X
+    H = np.maximum(6.0 * (np.sqrt(np.maximum(X + ice_height, 0.0)) - np.sqrt(ice_height)) + 1.0, 0.0)
+    Pi = np.maximum(RHO_I * GRAV * H, 0.0)
+    mask = np.where(Pi > 0.0, 1.0, -1.0)
+    B = np.full_like(X, gap_init)
+    if vary_B:
+        B = B * (1.0 + 0.5 * np.sin(2.0 * np.pi * X / 1.0e4) * np.cos(2.0 * np.pi * Y / 5.0e3))
+    # random perturbation of the head, reproducible per global row
+    phi = np.empty((ny, nx))
+    r = 0
+    while r < ny:
+        blk_id, off = divmod(j0 + r, 64)
+        blk = np.random.default_rng([seed, blk_id]).uniform(-1.0, 1.0, size=(64, nx))
+        n = min(64 - off, ny - r)
+        phi[r:r + n] = blk[off:off + n]
+        r += n
+    phi = 101325.0 / (RHO_W * GRAV) + zb[1:-1, 1:-1] + 1.0e-3 * phi
+    return dict(nx=nx, ny=ny, dx=dx, dy=dy,
+                phi=phi, rhs=np.full((ny, nx), source), aCoef=np.zeros((ny, nx)),
+                B=np.ascontiguousarray(B), Pi=np.ascontiguousarray(Pi),
+                zb=np.ascontiguousarray(zb), mask=np.ascontiguousarray(mask))
+
+
+def random_fields(nx, ny, dx=3.0, dy=2.0, seed=7, with_mask_holes=True):
+    """Adversarial inputs for kernel parity: random coefficients of realistic magnitude,
+    some masked-out cells (mask < 0), gap heights on both sides of cutOffbr / maxOffbr
+    so that every branch of COMPUTENONLINEARTERMS (src/AmrHydroF.ChF:40-62) is taken."""
+    rng = np.random.default_rng(seed)
+    g = (ny + 2, nx + 2)
+    B = rng.uniform(0.002, 0.05, size=g)
+    Pi = rng.uniform(1.0e5, 1.3e7, size=g)
+    zb = rng.uniform(0.0, 50.0, size=g)
+    mask = np.ones(g)
+    if with_mask_holes:
+        mask[rng.uniform(size=g) < 0.1] = -1.0
+    phi = rng.uniform(5.0, 900.0, size=(ny, nx))
+    rhs = rng.uniform(-1e-5, 1e-5, size=(ny, nx))
+    aCoef = rng.uniform(0.0, 1.0, size=(ny, nx))
+    bx = -rng.uniform(0.05, 1.0, size=(ny, nx + 1))
+    by = -rng.uniform(0.05, 1.0, size=(ny + 1, nx))
+    return dict(nx=nx, ny=ny, dx=dx, dy=dy, phi=phi, rhs=rhs, aCoef=aCoef, B=B, Pi=Pi, zb=zb,
+                mask=mask, bx=bx, by=by)
+
+
+RANDOM_PHYS = dict(A=5e-25, omega=1e-3, nu=1.787e-6, cutOffbr=0.01, maxOffbr=0.03,
+                   rho_w_g=9800.0, grav=9.8, cutOffB=1, use_NL=1, use_mask_gradients=1)
+RANDOM_BC = dict(type=[[0, 1], [1, 0]], value=[[3.0, -0.02], [0.01, 7.0]], periodic=[0, 0])
