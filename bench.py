@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- head-solve hot path on MI355X.
+
+One "step" = one FAS multigrid V-cycle of the hydraulic-head solve (4 pre + 4 post
+nonlinear GSRB sweeps per depth, bottom relaxes, restrict/prolong, on-the-fly bCoef
+update) on a 4096 x 4096 single level with 64^2 boxes, SHMIP-A synthetic inputs
+(SURVEY.md 8d "K-bench").  N > 1: weak scaling, every rank holds a 4096 x 4096 strip of
+a 4096 x (4096 N) level, strips coupled by halo exchange over RCCL.
+
+Prints ONE JSON line (rank 0).  `value` = V-cycles/s of the whole job; the GSRB
+cell-update rate and the roofline of the dominant kernel (the GSRB sweep at depth 0,
+72 algorithmic bytes per cell per sweep) ride along, plus the CPU baseline (the oracle's
+un-fused box-by-box restatement of the reference path, timed on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+BYTES_PER_CELL_SWEEP = 72.0    # phi r+w, rhs, bx, by, B, Pi, zb, mask
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=4096, help="cells per side of one rank's strip")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--sweeps-only", type=int, default=0, help="also time this many bare GSRB sweeps")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+
+    import numpy as np
+    from suhmo_amd import capi, level, synthetic as sy
+
+    n = args.n
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+    assert capi.lib().suhmo_device_count() > 0, "no GPU visible: the product path has no CPU fallback"
+
+    ny_global = n * world
+    f = sy.shmip_fields(n, n, j0=rank * n, ny_total=ny_global)
+    G = level.HipLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64, j0=rank * n,
+                       ny_global=ny_global, device=local_rank)
+    G.set_inputs(f)
+    if world > 1:
+        from suhmo_amd import multigpu
+        multigpu.attach(G, dist, rank, world)
+    G.build_mg_coefficients()
+    sp = dict(sy.SOLVER_DEFAULT)
+
+    def sync():
+        G.synchronize()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        G.vcycle(sp)
+    sync()
+    G.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        G.vcycle(sp)
+    sync()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    gsrb_ms, gsrb_launches, gsrb_cells = G.profile_read()
+    G.profile(False)
+
+    sweeps_depth0 = 2 * sp["num_smooth"]
+    cells = n * n
+    ms_per_step = 1e3 * elapsed / args.steps
+    vps = args.steps / elapsed
+    # GSRB sweeps at every depth: 8 per depth + bottom, geometric in cells
+    ndepth = G.ndepth
+    updates_per_vcycle = sum((cells >> (2 * d)) * (sp["num_bottom"] if d == ndepth - 1 else sweeps_depth0)
+                             for d in range(ndepth))
+    sweep_ms = gsrb_ms / max(gsrb_launches, 1)
+    achieved = BYTES_PER_CELL_SWEEP * cells / (sweep_ms * 1e-3) / 1e9 if gsrb_launches else 0.0
+
+    extra = {}
+    if args.sweeps_only:
+        sync()
+        G.profile(True)
+        t0 = time.perf_counter()
+        G.gsrb(args.sweeps_only)
+        sync()
+        dt = time.perf_counter() - t0
+        ms, nl, _ = G.profile_read()
+        G.profile(False)
+        extra["bare_gsrb"] = {"sweeps": args.sweeps_only, "wall_ms_per_sweep": 1e3 * dt / args.sweeps_only,
+                              "event_ms_per_sweep": ms / max(nl, 1),
+                              "cell_updates_per_s": cells * args.sweeps_only / dt}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        cpu = cpu_baseline(sy, n if n <= 4096 else 4096, sp)
+
+    if rank == 0:
+        out = {
+            "metric": "multigrid V-cycles/s (FAS head solve) + GSRB cell-updates/s; achieved HBM GB/s vs peak",
+            "value": vps * 1.0, "unit": "V-cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "SHMIP-A head solve, %dx%d cells per GPU, single AMR level, 64x64 boxes, "
+                                   "%d MG depths, 4+4 GSRB sweeps per depth, %d bottom (BASELINE north_star: 4096^2 single-level)"
+                                   % (n, n, ndepth, sp["num_bottom"]),
+                       "global_cells": [n, ny_global], "partition": "row strips, 1 per GPU" if world > 1 else "none"},
+            "gsrb_cell_updates_per_s": updates_per_vcycle * vps * world,
+            "gsrb_depth0_cell_updates_per_s_kernel": cells / (sweep_ms * 1e-3) * world if gsrb_launches else None,
+            "roofline": {"bound": "hbm", "kernel": "GSRB sweep (red+black) at depth 0", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_cell_sweep": BYTES_PER_CELL_SWEEP,
+                         "avg_sweep_ms": sweep_ms, "sweeps_timed": gsrb_launches},
+            "cpu_baseline": cpu,
+        }
+        out.update(extra)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sy, n, sp):
+    """The oracle's restatement of the reference CPU path (un-fused levelGSRB etc. over 64^2
+    boxes, OpenMP over boxes), same workload, bounded sample: 1 warm-up + 2 timed V-cycles."""
+    from oracle import pyoracle as po
+    cores = len(os.sched_getaffinity(0))
+    f = sy.shmip_fields(n, n)
+    O = po.OracleLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64, nthreads=cores)
+    O.set_inputs(f)
+    O.build_mg_coefficients()
+    O.vcycle(sp)
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        O.vcycle(sp)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.gsrb(2)
+    dts = time.perf_counter() - t0
+    O.close()
+    return {"value": reps / dt, "unit": "V-cycles/s", "cores": cores, "kind": "port",
+            "sample": "%d V-cycles of the same %dx%d workload (after 1 warm-up), CPU restatement of the "
+                      "reference path (oracle level shim, 64^2 boxes, OpenMP over boxes)" % (reps, n, n),
+            "gsrb_cell_updates_per_s": 2 * n * n / dts}
+
+
+if __name__ == "__main__":
+    main()

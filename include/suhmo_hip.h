@@ -1,0 +1,195 @@
+/*
+ * suhmo_hip.h -- C-ABI of the MI355X-native hydraulic-head solve (libsuhmo_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of EnnaDelfen/SUHMO: the per-timestep nonlinear
+ * variable-coefficient Poisson (FAS multigrid) solve for hydraulic head,
+ *   VCAMRNonLinearPoissonOp + AMRNonLinearPoissonOp + the AmrHydro callbacks they invoke.
+ * Plain C: opaque handle, pointers and sizes, int return codes (0 = ok, <0 = error, text
+ * via suhmo_last_error()), no exceptions, caller-provided HIP stream (NULL = default
+ * stream).  All data fp64.  Citations are file:line in the SUHMO checkout.
+ *
+ * The reference calls its Fortran kernels once per box (<= 64x64 cells).  This ABI is
+ * level-batched: one call works on a whole AMR level / multigrid depth that lives in HBM
+ * as a "level canvas" (see DESIGN.md): the level's boxes (Chombo DisjointBoxLayout) are
+ * registered once, box data (FArrayBox::dataPtr) is scattered into / gathered from the
+ * canvas with suhmo_level_put_box / get_box, and every operator method of the reference
+ * has one entry point below.
+ *
+ * Array conventions: "global" arrays are row-major [j][i] (i fastest) = Fortran a(i,j);
+ * a box fab is Fortran order a(lo0:hi0, lo1:hi1) exactly as Chombo's CHF_FRA passes it.
+ */
+#ifndef SUHMO_HIP_H
+#define SUHMO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct suhmo_level suhmo_level_t;
+typedef void *suhmo_stream_t; /* hipStream_t */
+
+/* physics constants reaching the kernels: suhmo_params.cpp:51-74; the literals 1000.0*9.8
+ * and 9.8 are hard-coded in src/AmrHydroF.ChF:45-52,103,217 */
+typedef struct suhmo_phys {
+    double A, omega, nu, cutOffbr, maxOffbr;
+    double rho_w_g; /* 9800.0 */
+    double grav;    /* 9.8    */
+    int cutOffB;            /* solver.cut_solve_outside_domain (src/AmrHydro.cpp:872) */
+    int use_NL;             /* solver.use_NL (:877) */
+    int use_mask_gradients; /* solver.use_mask_for_gradients (:873) */
+} suhmo_phys_t;
+
+/* bc.lo_bc/hi_bc (0 Dirichlet, 1 Neumann), x.lo_dirich_val ..., AmrHydro.is_periodic
+ * (src/AmrHydro.cpp:99-155, mixBCValues :248-309); index [dir][side] */
+typedef struct suhmo_bc {
+    int    type[2][2];
+    double value[2][2];
+    int    periodic[2];
+} suhmo_bc_t;
+
+/* AMRMultiGrid::setSolverParameters as called at src/AmrHydro.cpp:737-762 */
+typedef struct suhmo_solver_params {
+    int    num_smooth, num_bottom, max_iter, iter_min, imin;
+    double eps, hang, norm_thresh;
+    int    bcoeff_otf;  /* solver.bcoeff_otf: UpdateOperator/AverageOperator each V-cycle */
+    int    max_depth;   /* -1: as deep as MGnewOp's rule allows */
+} suhmo_solver_params_t;
+
+/* one level (or, multi-GPU, this rank's strip of rows of it) */
+typedef struct suhmo_level_desc {
+    int nx, ny;          /* cells of the strip held by this process */
+    int j0, ny_global;   /* first global row of the strip, rows of the whole level */
+    double dx, dy;
+    int nbox;            /* boxes of the DisjointBoxLayout that lie in this strip */
+    const int *boxes;    /* nbox x {lo0, lo1, hi0, hi1}, global cell indices; may be NULL:
+                            then the strip is split into max_box x max_box boxes */
+    int max_box;         /* AmrHydro.max_box_size (used when boxes == NULL), e.g. 64 */
+    double alpha, beta;  /* 0, -1 at src/AmrHydro.cpp:713-714 */
+    suhmo_bc_t bc;
+    suhmo_phys_t phys;
+    int device;          /* HIP device ordinal */
+    int halo_rows;       /* ghost rows kept on the strip's y sides (>= 1) */
+} suhmo_level_desc_t;
+
+/* field ids (same numbering as the test oracle) */
+enum {
+    SUHMO_F_PHI = 0, SUHMO_F_RHS, SUHMO_F_ACOEF, SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB,
+    SUHMO_F_MASK, SUHMO_F_BX, SUHMO_F_BY, SUHMO_F_LAMBDA, SUHMO_F_RES, SUHMO_F_LPHI,
+    SUHMO_F_NL, SUHMO_F_DNL, SUHMO_F_PHIOLD, SUHMO_F_CORR, SUHMO_F_GRADX, SUHMO_F_GRADY,
+    SUHMO_F_RE, SUHMO_F_COUNT
+};
+
+const char *suhmo_last_error(void);
+int suhmo_device_count(void);
+
+/* VCAMRNonLinearPoissonOpFactory::define + MGnewOp/AMRnewOp
+ * (src/VCAMRNonLinearPoissonOp.cpp:877-953, 1016-1286): allocates the level canvas for
+ * depth 0 and every multigrid depth allowed by coarsenable(2^d * s_maxCoarse) (:1053). */
+int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t *desc);
+int suhmo_level_destroy(suhmo_level_t *L);
+int suhmo_level_num_depths(const suhmo_level_t *L);
+int suhmo_level_synchronize(suhmo_level_t *L, suhmo_stream_t s);
+
+/* LevelData<FArrayBox> / LevelData<FluxBox> traffic, box by box (DataIterator order =
+ * index into desc.boxes).  `fab` is a host pointer to Fortran-order data over
+ * [flo0:fhi0] x [flo1:fhi1] (the FArrayBox box of that grid at this depth, ghosts
+ * included; for face fields the face-centred box).  put copies the VALID cells (faces) of
+ * box `ibox` and, if with_domain_ghosts != 0, those ghost cells of the fab that lie outside
+ * the problem domain (caller-owned data for B / iceMask); interior ghost cells are never
+ * copied (they duplicate a neighbour's valid cells).  get fills valid cells plus all ghost
+ * cells of the fab from the canvas (= what exchange + BC would have produced). */
+int suhmo_level_put_box(suhmo_level_t *L, int depth, int field, int ibox, const double *fab,
+                        int flo0, int flo1, int fhi0, int fhi1, int with_domain_ghosts,
+                        suhmo_stream_t s);
+int suhmo_level_get_box(suhmo_level_t *L, int depth, int field, int ibox, double *fab,
+                        int flo0, int flo1, int fhi0, int fhi1, suhmo_stream_t s);
+/* whole-strip variants: cell fields ny x nx (ghosted: (ny+2) x (nx+2)); BX ny x (nx+1);
+ * BY (ny+1) x nx.  `on_device` != 0: src/dst is a device pointer. */
+int suhmo_level_set_field(suhmo_level_t *L, int depth, int field, const double *src,
+                          int ghosted, int on_device, suhmo_stream_t s);
+int suhmo_level_get_field(suhmo_level_t *L, int depth, int field, double *dst,
+                          int ghosted, int on_device, suhmo_stream_t s);
+/* raw device view of a field canvas (for zero-copy callers): base pointer, pitch in
+ * doubles, offset of cell (0,0) */
+int suhmo_level_field_view(suhmo_level_t *L, int depth, int field, double **base,
+                           long *pitch, long *origin);
+
+/* --- operator methods; each replaces the named reference method for a whole level --- */
+/* AMRNonLinearPoissonOp::relax -> VCAMRNonLinearPoissonOp::levelGSRB x sweeps
+ * (src/AMRNonLinearPoissonOp.cpp:707-750, src/VCAMRNonLinearPoissonOp.cpp:654-760), kernel
+ * GSRBHELMHOLTZVCNL2D (src/VCAMRNonLinearPoissonOpF.ChF:46-168) with COMPUTENONLINEARTERMS
+ * (src/AmrHydroF.ChF:23-68), SUMFACESNL (:574-601) and mixBCValues fused in. */
+int suhmo_level_gsrb(suhmo_level_t *L, int depth, int sweeps, suhmo_stream_t s);
+/* applyOpI / applyOpNoBoundary (src/VCAMRNonLinearPoissonOp.cpp:273-345), VCNLCOMPUTEOP2D */
+int suhmo_level_apply_op(suhmo_level_t *L, int depth, int homogeneous, suhmo_stream_t s);
+/* residualI (:98-167), VCNLCOMPUTERES2D */
+int suhmo_level_residual(suhmo_level_t *L, int depth, suhmo_stream_t s);
+/* restrictResidual (:384-460), RESTRICTRESVCNL2D: RES[depth+1] */
+int suhmo_level_restrict_residual(suhmo_level_t *L, int depth, suhmo_stream_t s);
+/* restrictR (:347-372), RESTRICTVCNL: PHI[depth+1] */
+int suhmo_level_restrict_r(suhmo_level_t *L, int depth, suhmo_stream_t s);
+/* prolongIncrement (src/AMRNonLinearPoissonOp.cpp:856-886), PROLONGNL:
+ * PHI[depth] += P(CORR[depth+1]) */
+int suhmo_level_prolong_increment(suhmo_level_t *L, int depth, suhmo_stream_t s);
+/* AMRProlongS_2's kernel PROLONG_2_NL (src/AMRNonLinearPoissonOpF.ChF:646-709):
+ * PHI[depth] += bilinear(CORR[depth+1], ghosted) */
+int suhmo_level_prolong_bilinear(suhmo_level_t *L, int depth, suhmo_stream_t s);
+/* UpdateOperator (src/VCAMRNonLinearPoissonOp.cpp:34-64) = AmrHydro::WFlx_level
+ * (src/AmrHydro.cpp:1415-1539): NEWMACGRAD, EdgeToCell, ExtrapGhostCells, COMPUTERE,
+ * CellToEdge, setup_iceMask_EC, COMPUTEBCOEFF -> BX, BY of `depth` */
+int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_stream_t s);
+/* AverageOperator (:66-95): BX,BY[depth] <- CoarseAverageFace(BX,BY[0], 2^depth) */
+int suhmo_level_average_operator(suhmo_level_t *L, int depth, suhmo_stream_t s);
+/* MGnewOp coefficient coarsening (:1096-1173) for every depth > 0 */
+int suhmo_level_build_mg_coefficients(suhmo_level_t *L, suhmo_stream_t s);
+/* stand-alone pieces for parity of a2 / a9 / a16 / a19 / a10 */
+int suhmo_level_nonlinear(suhmo_level_t *L, int depth, suhmo_stream_t s);     /* NL, DNL */
+int suhmo_level_compute_lambda(suhmo_level_t *L, int depth, suhmo_stream_t s);/* LAMBDA  */
+int suhmo_level_fill_ghosts(suhmo_level_t *L, int depth, int field, int homogeneous,
+                            suhmo_stream_t s);   /* exchange (periodic wrap) + mixBCValues */
+/* DIVERGENCE (util/DivergenceF.ChF:23-57): dst_field += d(BX)/dx + d(BY)/dy */
+int suhmo_level_divergence(suhmo_level_t *L, int depth, int dst_field, suhmo_stream_t s);
+/* getFlux (src/VCAMRNonLinearPoissonOp.cpp:792-841) on all faces of direction dir into
+ * device/host array `flux` shaped like BX/BY */
+int suhmo_level_get_flux(suhmo_level_t *L, int depth, int dir, int ref, double *flux_host,
+                         suhmo_stream_t s);
+/* norm over valid cells (AMRNonLinearPoissonOp::norm, :660-666): ord 0 max-abs, 2 l2 */
+int suhmo_level_norm(suhmo_level_t *L, int depth, int field, int ord, double *out,
+                     suhmo_stream_t s);
+/* LevelDataOps vector ops (:629-688): dst = a*x + b*y ; dst += scale*x ; set value */
+int suhmo_level_axby(suhmo_level_t *L, int depth, int dst, int x, int y, double a, double b,
+                     suhmo_stream_t s);
+int suhmo_level_set_value(suhmo_level_t *L, int depth, int field, double v, suhmo_stream_t s);
+
+/* one FAS V-cycle on PHI/RHS of depth 0, and the AMRMultiGrid::solve loop
+ * (src/AmrHydro.cpp:766).  hist (length max_iter+1, may be NULL) gets residual norms. */
+int suhmo_level_vcycle(suhmo_level_t *L, const suhmo_solver_params_t *sp, suhmo_stream_t s);
+int suhmo_level_solve(suhmo_level_t *L, const suhmo_solver_params_t *sp, int *iters,
+                      double *hist, suhmo_stream_t s);
+
+/* multi-GPU strips: pack the `rows` owned rows next to side (0 = y-lo, 1 = y-hi) of a
+ * field into a contiguous device buffer (rows x nx doubles) / unpack a neighbour's rows
+ * into the ghost rows of that side.  The transport (RCCL send/recv) belongs to the host. */
+int suhmo_level_pack_rows(suhmo_level_t *L, int depth, int field, int side, int rows,
+                          double *dev_buf, suhmo_stream_t s);
+int suhmo_level_unpack_rows(suhmo_level_t *L, int depth, int field, int side, int rows,
+                            const double *dev_buf, suhmo_stream_t s);
+/* hook called by the V-cycle driver wherever the reference calls LevelData::exchange on a
+ * field whose strip ghost rows must come from another rank; NULL = single process. */
+typedef int (*suhmo_exchange_fn)(void *user, suhmo_level_t *L, int depth, int field,
+                                 suhmo_stream_t s);
+typedef int (*suhmo_allreduce_max_fn)(void *user, double *value);
+int suhmo_level_set_hooks(suhmo_level_t *L, suhmo_exchange_fn ex, suhmo_allreduce_max_fn ar,
+                          void *user);
+
+/* timing helper: average device time (ms) of the GSRB sweep kernel launches since the
+ * last reset, measured with HIP events on the launch stream */
+int suhmo_level_profile_reset(suhmo_level_t *L);
+int suhmo_level_profile_enable(suhmo_level_t *L, int on);
+int suhmo_level_profile_read(suhmo_level_t *L, suhmo_stream_t s, double *gsrb_ms_total,
+                             long *gsrb_launches, long *gsrb_cells);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,116 @@
+"""ctypes binding of libsuhmo_hip.so (the C-ABI declared in include/suhmo_hip.h).
+
+There is NO fallback: if the HIP library is missing or no GPU is visible, calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libsuhmo_hip.so")
+_LIB = None
+
+
+class SuhmoError(RuntimeError):
+    pass
+
+
+class Phys(C.Structure):
+    _fields_ = [("A", C.c_double), ("omega", C.c_double), ("nu", C.c_double),
+                ("cutOffbr", C.c_double), ("maxOffbr", C.c_double),
+                ("rho_w_g", C.c_double), ("grav", C.c_double),
+                ("cutOffB", C.c_int), ("use_NL", C.c_int), ("use_mask_gradients", C.c_int)]
+
+
+class BC(C.Structure):
+    _fields_ = [("type", (C.c_int * 2) * 2), ("value", (C.c_double * 2) * 2), ("periodic", C.c_int * 2)]
+
+
+class SolverParams(C.Structure):
+    _fields_ = [("num_smooth", C.c_int), ("num_bottom", C.c_int), ("max_iter", C.c_int),
+                ("iter_min", C.c_int), ("imin", C.c_int), ("eps", C.c_double), ("hang", C.c_double),
+                ("norm_thresh", C.c_double), ("bcoeff_otf", C.c_int), ("max_depth", C.c_int)]
+
+
+class LevelDesc(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("j0", C.c_int), ("ny_global", C.c_int),
+                ("dx", C.c_double), ("dy", C.c_double), ("nbox", C.c_int), ("boxes", C.POINTER(C.c_int)),
+                ("max_box", C.c_int), ("alpha", C.c_double), ("beta", C.c_double),
+                ("bc", BC), ("phys", Phys), ("device", C.c_int), ("halo_rows", C.c_int)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
+
+# every symbol include/suhmo_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "suhmo_last_error", "suhmo_device_count", "suhmo_level_create", "suhmo_level_destroy",
+    "suhmo_level_num_depths", "suhmo_level_synchronize", "suhmo_level_put_box", "suhmo_level_get_box",
+    "suhmo_level_set_field", "suhmo_level_get_field", "suhmo_level_field_view", "suhmo_level_gsrb",
+    "suhmo_level_apply_op", "suhmo_level_residual", "suhmo_level_restrict_residual",
+    "suhmo_level_restrict_r", "suhmo_level_prolong_increment", "suhmo_level_prolong_bilinear",
+    "suhmo_level_update_operator", "suhmo_level_average_operator", "suhmo_level_build_mg_coefficients",
+    "suhmo_level_nonlinear", "suhmo_level_compute_lambda", "suhmo_level_fill_ghosts",
+    "suhmo_level_divergence", "suhmo_level_get_flux", "suhmo_level_norm", "suhmo_level_axby",
+    "suhmo_level_set_value", "suhmo_level_vcycle", "suhmo_level_solve", "suhmo_level_pack_rows",
+    "suhmo_level_unpack_rows", "suhmo_level_set_hooks", "suhmo_level_profile_reset",
+    "suhmo_level_profile_enable", "suhmo_level_profile_read",
+]
+
+
+def build(force=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "suhmo_hip.h"))
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-C", CSRC, "-B", "libsuhmo_hip.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise SuhmoError("libsuhmo_hip.so not built (%s); run __graft_entry__.build(). "
+                         "There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    dp, vp, ci = C.POINTER(C.c_double), C.c_void_p, C.c_int
+    L.suhmo_last_error.restype = C.c_char_p
+    L.suhmo_level_create.argtypes = [C.POINTER(vp), C.POINTER(LevelDesc)]
+    L.suhmo_level_destroy.argtypes = [vp]
+    L.suhmo_level_num_depths.argtypes = [vp]
+    L.suhmo_level_synchronize.argtypes = [vp, vp]
+    L.suhmo_level_put_box.argtypes = [vp, ci, ci, ci, dp, ci, ci, ci, ci, ci, vp]
+    L.suhmo_level_get_box.argtypes = [vp, ci, ci, ci, dp, ci, ci, ci, ci, vp]
+    L.suhmo_level_set_field.argtypes = [vp, ci, ci, vp, ci, ci, vp]
+    L.suhmo_level_get_field.argtypes = [vp, ci, ci, vp, ci, ci, vp]
+    L.suhmo_level_field_view.argtypes = [vp, ci, ci, C.POINTER(vp), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    L.suhmo_level_gsrb.argtypes = [vp, ci, ci, vp]
+    L.suhmo_level_apply_op.argtypes = [vp, ci, ci, vp]
+    for n in ("residual", "restrict_residual", "restrict_r", "prolong_increment", "prolong_bilinear",
+              "update_operator", "average_operator", "nonlinear", "compute_lambda"):
+        getattr(L, "suhmo_level_" + n).argtypes = [vp, ci, vp]
+    L.suhmo_level_build_mg_coefficients.argtypes = [vp, vp]
+    L.suhmo_level_fill_ghosts.argtypes = [vp, ci, ci, ci, vp]
+    L.suhmo_level_divergence.argtypes = [vp, ci, ci, vp]
+    L.suhmo_level_get_flux.argtypes = [vp, ci, ci, ci, dp, vp]
+    L.suhmo_level_norm.argtypes = [vp, ci, ci, ci, dp, vp]
+    L.suhmo_level_axby.argtypes = [vp, ci, ci, ci, ci, C.c_double, C.c_double, vp]
+    L.suhmo_level_set_value.argtypes = [vp, ci, ci, C.c_double, vp]
+    L.suhmo_level_vcycle.argtypes = [vp, C.POINTER(SolverParams), vp]
+    L.suhmo_level_solve.argtypes = [vp, C.POINTER(SolverParams), C.POINTER(ci), dp, vp]
+    L.suhmo_level_pack_rows.argtypes = [vp, ci, ci, ci, ci, vp, vp]
+    L.suhmo_level_unpack_rows.argtypes = [vp, ci, ci, ci, ci, vp, vp]
+    L.suhmo_level_set_hooks.argtypes = [vp, EXCHANGE_FN, ALLREDUCE_FN, vp]
+    L.suhmo_level_profile_reset.argtypes = [vp]
+    L.suhmo_level_profile_enable.argtypes = [vp, ci]
+    L.suhmo_level_profile_read.argtypes = [vp, vp, dp, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    _LIB = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise SuhmoError("libsuhmo_hip: rc=%d: %s" % (rc, lib().suhmo_last_error().decode()))

@@ -1,0 +1,149 @@
+// suhmo_common.h -- internal types shared by the HIP translation units of libsuhmo_hip.so.
+// gfx950 (MI355X) only; compiled with -ffp-contract=off so that every kernel reproduces
+// the reference's Fortran expression association bit for bit ("Parity").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/suhmo_hip.h"
+
+#define SUHMO_XOFF 16      // column of cell i = 0 in a canvas row (128-byte aligned)
+#define SUHMO_MAXDEPTH 16
+
+// Level canvas geometry + boundary description of one multigrid depth, passed by value to
+// kernels.  Canvas element of cell/face (i,j): (j + gy) * P + XOFF + i.  Every field of a
+// depth (cell-centred, x-faces, y-faces) uses the same canvas shape.
+struct DV {
+    int nx, ny;        // cells of this strip at this depth
+    int P;             // pitch in doubles (multiple of 16)
+    int gy;            // ghost rows below / above
+    int rows;          // ny + 2*gy
+    int j0, nyg;       // global row of local j = 0; rows of the whole level (colour parity, faces)
+    double dx, dy;     // cell size
+    double rdx, rdy;   // one/(dx*dx), one/(dy*dy)   (src/VCAMRNonLinearPoissonOpF.ChF:110)
+    double fdx, fdy;   // one/dx, one/dy             (util/GradientF.ChF:57)
+    double alpha, beta;
+    int bct[2][2];     // [dir][side] 0 Dirichlet, 1 Neumann
+    double two_v[2][2];// 2.0*value               (DiriBC order 1: 2*value - near)
+    double neu[2][2];  // (sign*dx)*value         (NeumBC: near + sign*dx*value)
+    int per[2];        // periodic
+    int ext[2];        // y side is a rank boundary: ghost rows hold exchanged data
+};
+
+struct FP { double *f[SUHMO_F_COUNT]; };
+
+__host__ __device__ __forceinline__ int cidx(const DV &v, int i, int j)
+{
+    return (j + v.gy) * v.P + SUHMO_XOFF + i;
+}
+
+// ---- neighbour values of phi with the physical BC / periodic wrap applied on the fly ----
+// mixBCValues (src/AmrHydro.cpp:248-309): ghost = 2*value - near (Dirichlet, order 1) or
+// near + sign*dx*value (Neumann); the ghost depends only on the adjacent interior cell, so
+// it is recomputed from registers instead of being stored between colour passes.
+__device__ __forceinline__ double phiW(const DV &v, const double *__restrict__ p, int idx, int i, double c, bool homog)
+{
+    if (i > 0) return p[idx - 1];
+    if (v.per[0]) return p[idx + v.nx - 1];
+    if (v.bct[0][0] == 0) return (homog ? 0.0 : v.two_v[0][0]) - c;
+    return homog ? c : c + v.neu[0][0];
+}
+__device__ __forceinline__ double phiE(const DV &v, const double *__restrict__ p, int idx, int i, double c, bool homog)
+{
+    if (i < v.nx - 1) return p[idx + 1];
+    if (v.per[0]) return p[idx - (v.nx - 1)];
+    if (v.bct[0][1] == 0) return (homog ? 0.0 : v.two_v[0][1]) - c;
+    return homog ? c : c + v.neu[0][1];
+}
+__device__ __forceinline__ double phiS(const DV &v, const double *__restrict__ p, int idx, int j, double c, bool homog)
+{
+    if (j > 0 || v.ext[0]) return p[idx - v.P];
+    if (v.per[1]) return p[idx + (v.ny - 1) * v.P];
+    if (v.bct[1][0] == 0) return (homog ? 0.0 : v.two_v[1][0]) - c;
+    return homog ? c : c + v.neu[1][0];
+}
+__device__ __forceinline__ double phiN(const DV &v, const double *__restrict__ p, int idx, int j, double c, bool homog)
+{
+    if (j < v.ny - 1 || v.ext[1]) return p[idx + v.P];
+    if (v.per[1]) return p[idx - (v.ny - 1) * v.P];
+    if (v.bct[1][1] == 0) return (homog ? 0.0 : v.two_v[1][1]) - c;
+    return homog ? c : c + v.neu[1][1];
+}
+
+// COMPUTENONLINEARTERMS, src/AmrHydroF.ChF:38-65
+__device__ __forceinline__ void nl_terms(const suhmo_phys_t &ph, double phi, double B, double Pi,
+                                         double zb, double mask, double &nl, double &dnl)
+{
+    if (!ph.use_NL || mask < 0.0) { nl = 0.0; dnl = 0.0; return; }
+    double N = Pi - ph.rho_w_g * (phi - zb);
+    nl = -ph.A * B * N * N * N;
+    dnl = 3.0 * ph.A * B * 1000.0 * ph.grav * N * N;
+    if (ph.cutOffbr > B) {
+        nl = nl * (1.0 - (ph.cutOffbr - B) / ph.cutOffbr);
+        dnl = dnl * B / ph.cutOffbr;
+    }
+    if (ph.maxOffbr < B) {
+        nl = nl * (1.0 - (ph.maxOffbr - B) / ph.maxOffbr);
+        dnl = dnl * B / ph.maxOffbr;
+    }
+}
+
+// L(phi) at one cell, src/VCAMRNonLinearPoissonOpF.ChF:130-152 / 257-279.  `aterm` is
+// alpha*aCoef(i,j) (or alpha alone when alpha == 0 and aCoef is not read).
+__device__ __forceinline__ double lofphi_cell(const DV &v, double aterm, double c, double e, double w,
+                                              double n, double s, double bxE, double bxW, double byN,
+                                              double byS, double nl)
+{
+    return aterm * c
+           - v.beta * (bxE * (e - c) * v.rdx - bxW * (c - w) * v.rdx
+                       + byN * (n - c) * v.rdy - byS * (c - s) * v.rdy)
+           + nl;
+}
+
+// lambda, resetLambda + SUMFACESNL (src/VCAMRNonLinearPoissonOp.cpp:517-528, ...OpF.ChF:591-598)
+__device__ __forceinline__ double lambda_cell(const DV &v, double aterm, double bxE, double bxW,
+                                              double byN, double byS)
+{
+    double lam = aterm;
+    lam = lam + v.rdx * v.beta * (bxE + bxW);
+    lam = lam + v.rdy * v.beta * (byN + byS);
+    return lam;
+}
+
+struct Depth {
+    DV v;
+    FP fp;
+    size_t elems;      // doubles per canvas
+    int nbox;
+};
+
+struct ProfEv { hipEvent_t a, b; long cells; };
+
+struct suhmo_level {
+    int ndepth;
+    Depth d[SUHMO_MAXDEPTH];
+    suhmo_level_desc_t desc;
+    std::vector<int> boxes;     // nbox x 4, global indices, depth 0
+    suhmo_phys_t ph;
+    int device;
+    double *scratch;            // reduction scratch (device)
+    double *hscratch;           // pinned host scratch
+    size_t scratch_elems;
+    suhmo_exchange_fn ex;
+    suhmo_allreduce_max_fn ar;
+    void *user;
+    int prof_on;
+    std::vector<ProfEv> prof;
+    int gsrb_variant;           // kernel selection (see suhmo_gsrb.hip)
+};
+
+void suhmo_set_error(const char *fmt, ...);
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    suhmo_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return -2; } } while (0)
+#define ARG(cond) do { if (!(cond)) { suhmo_set_error("%s:%d bad argument: %s", __FILE__, __LINE__, #cond); return -1; } } while (0)
+
+double *suhmo_field(suhmo_level *L, int depth, int field);   // lazily allocates
+int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, hipStream_t st);   // suhmo_gsrb.hip

@@ -1,0 +1,85 @@
+// suhmo_fas.hip -- FAS multigrid V-cycle and solve loop on the device-resident level.
+//
+// Stands in for Chombo's AMRFASMultiGrid<LevelData<FArrayBox>>::solve as driven by
+// AmrHydro::SolveForHead_nl (src/AmrHydro.cpp:665-769).  The cycle driver itself lives in
+// the un-vendored Chombo fork; the ordering below is the reconstruction documented in
+// SURVEY.md Appendix D (UNPINNED) from the reference's operator overrides:
+//   UpdateOperator / AverageOperator   src/VCAMRNonLinearPoissonOp.cpp:32-95
+//   relax                              src/AMRNonLinearPoissonOp.cpp:707-750
+//   restrictResidual / restrictR       src/VCAMRNonLinearPoissonOp.cpp:347-460
+//   applyOpMg                          src/VCAMRNonLinearPoissonOp.cpp:211-231
+//   prolongIncrement                   src/AMRNonLinearPoissonOp.cpp:856-886
+// Single AMR level in this round; all work stays on `st`, the only host round trip is the
+// 8-byte residual norm per V-cycle in the solve loop.
+#include "suhmo_common.h"
+
+static int eff_depths(const suhmo_level *L, const suhmo_solver_params_t *sp)
+{
+    int nd = L->ndepth;
+    if (sp->max_depth >= 0 && sp->max_depth + 1 < nd) nd = sp->max_depth + 1;
+    return nd;
+}
+
+static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, int nd, suhmo_stream_t s)
+{
+    int rc;
+    if (dep == nd - 1) return suhmo_level_gsrb(L, dep, sp->num_bottom, s);        // bottom relaxes
+    Depth &C = L->d[dep + 1];
+    if ((rc = suhmo_level_gsrb(L, dep, sp->num_smooth, s))) return rc;            // pre-smooth
+    if ((rc = suhmo_level_restrict_residual(L, dep, s))) return rc;               // RES[dep+1]
+    if ((rc = suhmo_level_restrict_r(L, dep, s))) return rc;                      // PHI[dep+1]
+    HIPCHK(hipMemcpyAsync(C.fp.f[SUHMO_F_PHIOLD], C.fp.f[SUHMO_F_PHI], C.elems * sizeof(double),
+                          hipMemcpyDeviceToDevice, (hipStream_t)s));
+    if ((rc = suhmo_level_apply_op(L, dep + 1, 0, s))) return rc;                 // LPHI = L_c(R phi)
+    if ((rc = suhmo_level_axby(L, dep + 1, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
+    if ((rc = fas_cycle(L, dep + 1, sp, nd, s))) return rc;
+    if ((rc = suhmo_level_axby(L, dep + 1, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) return rc;
+    if ((rc = suhmo_level_prolong_increment(L, dep, s))) return rc;
+    return suhmo_level_gsrb(L, dep, sp->num_smooth, s);                           // post-smooth
+}
+
+extern "C" int suhmo_level_vcycle(suhmo_level_t *L, const suhmo_solver_params_t *sp, suhmo_stream_t s)
+{
+    ARG(L && sp);
+    HIPCHK(hipSetDevice(L->device));
+    int nd = eff_depths(L, sp), rc;
+    if (sp->bcoeff_otf) {
+        if ((rc = suhmo_level_update_operator(L, 0, s))) return rc;
+        for (int k = 1; k < nd; k++)
+            if ((rc = suhmo_level_average_operator(L, k, s))) return rc;
+    }
+    return fas_cycle(L, 0, sp, nd, s);
+}
+
+extern "C" int suhmo_level_solve(suhmo_level_t *L, const suhmo_solver_params_t *sp, int *iters, double *hist, suhmo_stream_t s)
+{
+    ARG(L && sp);
+    HIPCHK(hipSetDevice(L->device));
+    int rc;
+    double rnorm = 0.0;
+    if ((rc = suhmo_level_residual(L, 0, s))) return rc;
+    if ((rc = suhmo_level_norm(L, 0, SUHMO_F_RES, 0, &rnorm, s))) return rc;
+    double initial_rnorm = rnorm, norm_last = 2.0 * initial_rnorm;
+    int iter = 0;
+    if (hist) hist[0] = rnorm;
+    bool goNorm = rnorm > sp->norm_thresh;
+    bool goRedu = rnorm > sp->eps * initial_rnorm;
+    bool goIter = iter < sp->max_iter;
+    bool goHang = iter < sp->imin || rnorm < (1.0 - sp->hang) * norm_last;
+    bool goMin = iter < sp->iter_min;
+    while (goMin || (goIter && goRedu && goHang && goNorm)) {
+        norm_last = rnorm;
+        if ((rc = suhmo_level_vcycle(L, sp, s))) return rc;
+        if ((rc = suhmo_level_residual(L, 0, s))) return rc;
+        if ((rc = suhmo_level_norm(L, 0, SUHMO_F_RES, 0, &rnorm, s))) return rc;
+        iter++;
+        if (hist) hist[iter] = rnorm;
+        goNorm = rnorm > sp->norm_thresh;
+        goRedu = rnorm > sp->eps * initial_rnorm;
+        goIter = iter < sp->max_iter;
+        goHang = iter < sp->imin || rnorm < (1.0 - sp->hang) * norm_last;
+        goMin = iter < sp->iter_min;
+    }
+    if (iters) *iters = iter;
+    return 0;
+}

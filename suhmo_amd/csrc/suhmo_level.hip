@@ -1,0 +1,931 @@
+// suhmo_level.hip -- level canvas management, LevelData traffic and every operator
+// kernel except the GSRB relaxation (suhmo_gsrb.hip) and the FAS driver (suhmo_fas.hip).
+// gfx950 only.  Reference citations: file:line in the SUHMO checkout.
+#include "suhmo_common.h"
+#include <cstdarg>
+#include <cmath>
+
+static thread_local char g_err[512] = "";
+void suhmo_set_error(const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char *suhmo_last_error(void) { return g_err; }
+extern "C" int suhmo_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------ level lifecycle
+static bool boxes_coarsenable(const std::vector<int> &b, int r)
+{
+    for (size_t k = 0; k < b.size(); k += 4)
+        if (b[k] % r || b[k + 1] % r || (b[k + 2] + 1) % r || (b[k + 3] + 1) % r) return false;
+    return true;
+}
+
+static void make_dv(DV &v, const suhmo_level_desc_t &d, int depth)
+{
+    int c = 1 << depth;
+    memset(&v, 0, sizeof(v));
+    v.nx = d.nx / c; v.ny = d.ny / c;
+    v.gy = d.halo_rows < 1 ? 1 : d.halo_rows;
+    v.rows = v.ny + 2 * v.gy;
+    v.P = ((v.nx + 2 * SUHMO_XOFF + 15) / 16) * 16;
+    v.j0 = d.j0 / c; v.nyg = d.ny_global / c;
+    v.dx = d.dx * c; v.dy = d.dy * c;
+    v.rdx = 1.0 / (v.dx * v.dx); v.rdy = 1.0 / (v.dy * v.dy);
+    v.fdx = 1.0 / v.dx; v.fdy = 1.0 / v.dy;
+    v.alpha = d.alpha; v.beta = d.beta;
+    for (int dir = 0; dir < 2; dir++) {
+        v.per[dir] = d.bc.periodic[dir];
+        for (int s = 0; s < 2; s++) {
+            v.bct[dir][s] = d.bc.type[dir][s];
+            v.two_v[dir][s] = 2.0 * d.bc.value[dir][s];
+            double isign = s == 0 ? -1.0 : 1.0;
+            v.neu[dir][s] = isign * (dir == 0 ? v.dx : v.dy) * d.bc.value[dir][s];
+        }
+    }
+    bool whole = (d.j0 == 0 && d.ny == d.ny_global);
+    v.ext[0] = (!whole) && (d.j0 > 0 || d.bc.periodic[1]);
+    v.ext[1] = (!whole) && (d.j0 + d.ny < d.ny_global || d.bc.periodic[1]);
+}
+
+double *suhmo_field(suhmo_level *L, int depth, int field)
+{
+    Depth &D = L->d[depth];
+    if (!D.fp.f[field]) {
+        double *p = nullptr;
+        if (hipMalloc(&p, D.elems * sizeof(double)) != hipSuccess) return nullptr;
+        (void)hipMemset(p, 0, D.elems * sizeof(double));
+        D.fp.f[field] = p;
+    }
+    return D.fp.f[field];
+}
+
+extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t *desc)
+{
+    ARG(out && desc);
+    ARG(desc->nx >= 2 && desc->ny >= 2 && desc->dx > 0 && desc->dy > 0);
+    ARG(desc->ny_global >= desc->ny && desc->j0 >= 0 && desc->j0 + desc->ny <= desc->ny_global);
+    ARG((long)(desc->nx + 64) * (long)(desc->ny + 2 * (desc->halo_rows < 1 ? 1 : desc->halo_rows)) < (1L << 31));
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { suhmo_set_error("no HIP device: the product path has no CPU fallback"); return -3; }
+    ARG(desc->device >= 0 && desc->device < ndev);
+    HIPCHK(hipSetDevice(desc->device));
+    suhmo_level *L = new suhmo_level();
+    L->desc = *desc; L->ph = desc->phys; L->device = desc->device;
+    L->ex = nullptr; L->ar = nullptr; L->user = nullptr; L->prof_on = 0; L->gsrb_variant = -1;
+    if (desc->boxes && desc->nbox > 0) {
+        L->boxes.assign(desc->boxes, desc->boxes + 4 * (size_t)desc->nbox);
+    } else {
+        int mb = desc->max_box > 0 ? desc->max_box : 64;
+        for (int bj = 0; bj * mb < desc->ny; bj++)
+            for (int bi = 0; bi * mb < desc->nx; bi++) {
+                int lo0 = bi * mb, lo1 = desc->j0 + bj * mb;
+                int hi0 = std::min(lo0 + mb, desc->nx) - 1, hi1 = std::min(lo1 + mb, desc->j0 + desc->ny) - 1;
+                int b[4] = {lo0, lo1, hi0, hi1};
+                L->boxes.insert(L->boxes.end(), b, b + 4);
+            }
+    }
+    L->desc.boxes = nullptr;
+    L->desc.nbox = (int)(L->boxes.size() / 4);
+    // boxes must tile the strip exactly
+    {
+        long cells = 0;
+        for (size_t k = 0; k < L->boxes.size(); k += 4) {
+            const int *b = &L->boxes[k];
+            if (b[0] < 0 || b[2] >= desc->nx || b[1] < desc->j0 || b[3] >= desc->j0 + desc->ny || b[0] > b[2] || b[1] > b[3]) {
+                suhmo_set_error("box %zu outside the strip", k / 4); delete L; return -1;
+            }
+            cells += (long)(b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+        }
+        if (cells != (long)desc->nx * desc->ny) { suhmo_set_error("boxes do not tile the level"); delete L; return -1; }
+    }
+    // MGnewOp depth rule (src/VCAMRNonLinearPoissonOp.cpp:1044-1060; s_maxCoarse = 2)
+    L->ndepth = 1;
+    for (int dep = 1; dep < SUHMO_MAXDEPTH; dep++) {
+        if (!boxes_coarsenable(L->boxes, (1 << dep) * 2)) break;
+        if ((desc->j0 % (1 << dep)) || (desc->ny_global % (1 << dep))) break;
+        L->ndepth = dep + 1;
+    }
+    static const int eager[] = {SUHMO_F_PHI, SUHMO_F_RHS, SUHMO_F_ACOEF, SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB,
+                                SUHMO_F_MASK, SUHMO_F_BX, SUHMO_F_BY, SUHMO_F_RES, SUHMO_F_LPHI};
+    for (int dep = 0; dep < L->ndepth; dep++) {
+        Depth &D = L->d[dep];
+        make_dv(D.v, L->desc, dep);
+        D.elems = (size_t)D.v.P * (size_t)(D.v.rows + 1);
+        D.nbox = L->desc.nbox;
+        memset(&D.fp, 0, sizeof(D.fp));
+        for (int f : eager) {
+            if (dep == 0 && f == SUHMO_F_LPHI) continue;       // lazily (only tests / AMR use it at depth 0)
+            if (!suhmo_field(L, dep, f)) { suhmo_set_error("hipMalloc failed (depth %d field %d)", dep, f); delete L; return -2; }
+        }
+        if (dep > 0) { suhmo_field(L, dep, SUHMO_F_PHIOLD); suhmo_field(L, dep, SUHMO_F_CORR); }
+    }
+    L->scratch_elems = 8192;
+    HIPCHK(hipMalloc(&L->scratch, L->scratch_elems * sizeof(double)));
+    HIPCHK(hipHostMalloc(&L->hscratch, 64 * sizeof(double)));
+    *out = L;
+    return 0;
+}
+
+extern "C" int suhmo_level_destroy(suhmo_level_t *L)
+{
+    if (!L) return 0;
+    (void)hipSetDevice(L->device);
+    (void)hipDeviceSynchronize();
+    for (int dep = 0; dep < L->ndepth; dep++)
+        for (int f = 0; f < SUHMO_F_COUNT; f++)
+            if (L->d[dep].fp.f[f]) (void)hipFree(L->d[dep].fp.f[f]);
+    for (auto &pe : L->prof) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    (void)hipFree(L->scratch);
+    (void)hipHostFree(L->hscratch);
+    delete L;
+    return 0;
+}
+
+extern "C" int suhmo_level_num_depths(const suhmo_level_t *L) { return L ? L->ndepth : -1; }
+extern "C" int suhmo_level_synchronize(suhmo_level_t *L, suhmo_stream_t s)
+{
+    ARG(L);
+    HIPCHK(hipStreamSynchronize((hipStream_t)s));
+    return 0;
+}
+extern "C" int suhmo_level_set_hooks(suhmo_level_t *L, suhmo_exchange_fn ex, suhmo_allreduce_max_fn ar, void *user)
+{
+    ARG(L);
+    L->ex = ex; L->ar = ar; L->user = user;
+    return 0;
+}
+
+// ------------------------------------------------------------------ LevelData traffic
+static bool is_face(int f) { return f == SUHMO_F_BX || f == SUHMO_F_BY; }
+#define CHECK_DF(L, depth, field) ARG(L); ARG(depth >= 0 && depth < L->ndepth); ARG(field >= 0 && field < SUHMO_F_COUNT)
+
+extern "C" int suhmo_level_field_view(suhmo_level_t *L, int depth, int field, double **base, long *pitch, long *origin)
+{
+    CHECK_DF(L, depth, field);
+    double *p = suhmo_field(L, depth, field);
+    if (!p) { suhmo_set_error("field allocation failed"); return -2; }
+    if (base) *base = p;
+    if (pitch) *pitch = L->d[depth].v.P;
+    if (origin) *origin = cidx(L->d[depth].v, 0, 0);
+    return 0;
+}
+
+static int copy2d(suhmo_level *L, int depth, int field, double *host, long hpitch, int i0, int j0, int ni, int nj,
+                  bool to_canvas, bool on_device, hipStream_t st)
+{
+    if (ni <= 0 || nj <= 0) return 0;
+    double *p = suhmo_field(L, depth, field);
+    if (!p) { suhmo_set_error("field allocation failed"); return -2; }
+    const DV &v = L->d[depth].v;
+    double *c = p + cidx(v, i0, j0);
+    hipMemcpyKind kind = to_canvas ? (on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice)
+                                   : (on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
+    if (to_canvas)
+        HIPCHK(hipMemcpy2DAsync(c, (size_t)v.P * 8, host, (size_t)hpitch * 8, (size_t)ni * 8, nj, kind, st));
+    else
+        HIPCHK(hipMemcpy2DAsync(host, (size_t)hpitch * 8, c, (size_t)v.P * 8, (size_t)ni * 8, nj, kind, st));
+    return 0;
+}
+
+static int field_io(suhmo_level *L, int depth, int field, double *buf, int ghosted, int on_device, bool set, hipStream_t st)
+{
+    const DV &v = L->d[depth].v;
+    int rc;
+    if (field == SUHMO_F_BX) rc = copy2d(L, depth, field, buf, v.nx + 1, 0, 0, v.nx + 1, v.ny, set, on_device, st);
+    else if (field == SUHMO_F_BY) rc = copy2d(L, depth, field, buf, v.nx, 0, 0, v.nx, v.ny + 1, set, on_device, st);
+    else if (ghosted) rc = copy2d(L, depth, field, buf, v.nx + 2, -1, -1, v.nx + 2, v.ny + 2, set, on_device, st);
+    else rc = copy2d(L, depth, field, buf, v.nx, 0, 0, v.nx, v.ny, set, on_device, st);
+    if (rc) return rc;
+    if (!on_device) HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int suhmo_level_set_field(suhmo_level_t *L, int depth, int field, const double *src, int ghosted,
+                                     int on_device, suhmo_stream_t s)
+{
+    CHECK_DF(L, depth, field); ARG(src);
+    HIPCHK(hipSetDevice(L->device));
+    return field_io(L, depth, field, (double *)src, ghosted, on_device, true, (hipStream_t)s);
+}
+extern "C" int suhmo_level_get_field(suhmo_level_t *L, int depth, int field, double *dst, int ghosted,
+                                     int on_device, suhmo_stream_t s)
+{
+    CHECK_DF(L, depth, field); ARG(dst);
+    HIPCHK(hipSetDevice(L->device));
+    return field_io(L, depth, field, dst, ghosted, on_device, false, (hipStream_t)s);
+}
+
+// valid region of box ibox at `depth`, in strip-local indices; faces: surroundingNodes
+static void box_region(const suhmo_level *L, int depth, int field, int ibox, int r[4])
+{
+    const int *b = &L->boxes[4 * (size_t)ibox];
+    int c = 1 << depth;
+    r[0] = b[0] / c; r[1] = b[1] / c - L->d[depth].v.j0; r[2] = (b[2] + 1) / c - 1; r[3] = (b[3] + 1) / c - 1 - L->d[depth].v.j0;
+    if (field == SUHMO_F_BX) r[2] += 1;
+    if (field == SUHMO_F_BY) r[3] += 1;
+}
+
+extern "C" int suhmo_level_put_box(suhmo_level_t *L, int depth, int field, int ibox, const double *fab,
+                                   int flo0, int flo1, int fhi0, int fhi1, int with_domain_ghosts, suhmo_stream_t s)
+{
+    CHECK_DF(L, depth, field); ARG(fab); ARG(ibox >= 0 && ibox < L->desc.nbox);
+    HIPCHK(hipSetDevice(L->device));
+    hipStream_t st = (hipStream_t)s;
+    const DV &v = L->d[depth].v;
+    int r[4]; box_region(L, depth, field, ibox, r);
+    int j0 = v.j0;                         // fab indices are global: local j = global j - j0
+    long fp = fhi0 - flo0 + 1;
+    ARG(flo0 <= r[0] && fhi0 >= r[2] && flo1 - j0 <= r[1] && fhi1 - j0 >= r[3]);
+    double *h = (double *)fab;
+    int rc = copy2d(L, depth, field, h + (long)(r[1] + j0 - flo1) * fp + (r[0] - flo0), fp, r[0], r[1],
+                    r[2] - r[0] + 1, r[3] - r[1] + 1, true, false, st);
+    if (rc) return rc;
+    if (with_domain_ghosts && !is_face(field)) {
+        // ghost strips of the fab that fall outside the problem domain (1 layer)
+        if (r[0] == 0 && flo0 <= -1)
+            rc |= copy2d(L, depth, field, h + (long)(r[1] + j0 - flo1) * fp + (-1 - flo0), fp, -1, r[1], 1, r[3] - r[1] + 1, true, false, st);
+        if (r[2] == v.nx - 1 && fhi0 >= v.nx)
+            rc |= copy2d(L, depth, field, h + (long)(r[1] + j0 - flo1) * fp + (v.nx - flo0), fp, v.nx, r[1], 1, r[3] - r[1] + 1, true, false, st);
+        if (r[1] + j0 == 0 && flo1 <= -1)
+            rc |= copy2d(L, depth, field, h + (long)(-1 - flo1) * fp + (r[0] - flo0), fp, r[0], -1 - j0, r[2] - r[0] + 1, 1, true, false, st);
+        if (r[3] + j0 == v.nyg - 1 && fhi1 >= v.nyg)
+            rc |= copy2d(L, depth, field, h + (long)(v.nyg - flo1) * fp + (r[0] - flo0), fp, r[0], v.nyg - j0, r[2] - r[0] + 1, 1, true, false, st);
+        if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int suhmo_level_get_box(suhmo_level_t *L, int depth, int field, int ibox, double *fab,
+                                   int flo0, int flo1, int fhi0, int fhi1, suhmo_stream_t s)
+{
+    CHECK_DF(L, depth, field); ARG(fab); ARG(ibox >= 0 && ibox < L->desc.nbox);
+    HIPCHK(hipSetDevice(L->device));
+    hipStream_t st = (hipStream_t)s;
+    const DV &v = L->d[depth].v;
+    int j0 = v.j0;
+    long fp = fhi0 - flo0 + 1;
+    // clip the fab box to the stored canvas region (1 ghost layer in x, gy rows in y)
+    int lo0 = std::max(flo0, -1), hi0 = std::min(fhi0, v.nx + (field == SUHMO_F_BX ? 0 : 0));
+    int lo1 = std::max(flo1 - j0, -v.gy), hi1 = std::min(fhi1 - j0, v.ny + v.gy - 1);
+    int rc = copy2d(L, depth, field, fab + (long)(lo1 + j0 - flo1) * fp + (lo0 - flo0), fp, lo0, lo1,
+                    hi0 - lo0 + 1, hi1 - lo1 + 1, false, false, st);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// ------------------------------------------------------------------ kernels
+#define BLK2D dim3(64, 4)
+static inline dim3 grid2d(int nx, int ny) { return dim3((nx + 63) / 64, (ny + 3) / 4); }
+
+// exchange (periodic wrap) + mixBCValues into the stored ghost ring of a cell field
+// (src/AmrHydro.cpp:248-309).  One thread per perimeter cell.
+__global__ void k_fill_ghosts(DV v, double *__restrict__ p, int homog)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 2 * v.ny) {                       // x sides
+        int side = t / v.ny, j = t % v.ny;
+        int i = side ? v.nx - 1 : 0;
+        int idx = cidx(v, i, j);
+        double c = p[idx];
+        if (side) p[idx + 1] = phiE(v, p, idx, i, c, homog); else p[idx - 1] = phiW(v, p, idx, i, c, homog);
+        return;
+    }
+    t -= 2 * v.ny;
+    if (t < 2 * v.nx) {                       // y sides
+        int side = t / v.nx, i = t % v.nx;
+        if (v.ext[side]) return;              // rank boundary: ghost rows hold exchanged data
+        int j = side ? v.ny - 1 : 0;
+        int idx = cidx(v, i, j);
+        double c = p[idx];
+        if (side) p[idx + v.P] = phiN(v, p, idx, j, c, homog); else p[idx - v.P] = phiS(v, p, idx, j, c, homog);
+    }
+}
+
+extern "C" int suhmo_level_fill_ghosts(suhmo_level_t *L, int depth, int field, int homogeneous, suhmo_stream_t s)
+{
+    CHECK_DF(L, depth, field); ARG(!is_face(field));
+    HIPCHK(hipSetDevice(L->device));
+    const DV &v = L->d[depth].v;
+    double *p = suhmo_field(L, depth, field);
+    int n = 2 * v.ny + 2 * v.nx;
+    hipLaunchKernelGGL(k_fill_ghosts, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, v, p, homogeneous);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// VCNLCOMPUTEOP2D / VCNLCOMPUTERES2D with BC, NL fused.  MODE 0: LPHI = L(phi); 1: RES = rhs - L(phi)
+template <bool HAS_ALPHA, int MODE>
+__global__ __launch_bounds__(256) void k_apply(DV v, FP fp, suhmo_phys_t ph, int homog)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || j >= v.ny) return;
+    const double *__restrict__ phi = fp.f[SUHMO_F_PHI];
+    int idx = cidx(v, i, j);
+    double c = phi[idx];
+    double e = phiE(v, phi, idx, i, c, homog), w = phiW(v, phi, idx, i, c, homog);
+    double n = phiN(v, phi, idx, j, c, homog), s = phiS(v, phi, idx, j, c, homog);
+    double bxW = fp.f[SUHMO_F_BX][idx], bxE = fp.f[SUHMO_F_BX][idx + 1];
+    double byS = fp.f[SUHMO_F_BY][idx], byN = fp.f[SUHMO_F_BY][idx + v.P];
+    double nl, dnl;
+    nl_terms(ph, c, fp.f[SUHMO_F_B][idx], fp.f[SUHMO_F_PI][idx], fp.f[SUHMO_F_ZB][idx], fp.f[SUHMO_F_MASK][idx], nl, dnl);
+    double aterm = HAS_ALPHA ? v.alpha * fp.f[SUHMO_F_ACOEF][idx] : v.alpha;
+    double lofphi = lofphi_cell(v, aterm, c, e, w, n, s, bxE, bxW, byN, byS, nl);
+    if (MODE == 0) fp.f[SUHMO_F_LPHI][idx] = lofphi;
+    else fp.f[SUHMO_F_RES][idx] = fp.f[SUHMO_F_RHS][idx] - lofphi;
+}
+
+static int exchange_if_needed(suhmo_level *L, int depth, int field, hipStream_t st)
+{
+    const DV &v = L->d[depth].v;
+    if (L->ex && (v.ext[0] || v.ext[1])) return L->ex(L->user, L, depth, field, (suhmo_stream_t)st);
+    return 0;
+}
+
+extern "C" int suhmo_level_apply_op(suhmo_level_t *L, int depth, int homogeneous, suhmo_stream_t s)
+{
+    ARG(L); ARG(depth >= 0 && depth < L->ndepth);
+    HIPCHK(hipSetDevice(L->device));
+    Depth &D = L->d[depth];
+    if (!suhmo_field(L, depth, SUHMO_F_LPHI)) return -2;
+    int rc = exchange_if_needed(L, depth, SUHMO_F_PHI, (hipStream_t)s); if (rc) return rc;
+    if (D.v.alpha != 0.0) hipLaunchKernelGGL((k_apply<true, 0>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, L->ph, homogeneous);
+    else hipLaunchKernelGGL((k_apply<false, 0>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, L->ph, homogeneous);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int suhmo_level_residual(suhmo_level_t *L, int depth, suhmo_stream_t s)
+{
+    ARG(L); ARG(depth >= 0 && depth < L->ndepth);
+    HIPCHK(hipSetDevice(L->device));
+    Depth &D = L->d[depth];
+    int rc = exchange_if_needed(L, depth, SUHMO_F_PHI, (hipStream_t)s); if (rc) return rc;
+    if (D.v.alpha != 0.0) hipLaunchKernelGGL((k_apply<true, 1>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, L->ph, 0);
+    else hipLaunchKernelGGL((k_apply<false, 1>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, L->ph, 0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// COMPUTENONLINEARTERMS / lambda as stand-alone kernels (parity of a2, a9)
+__global__ void k_nonlinear(DV v, FP fp, suhmo_phys_t ph)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || j >= v.ny) return;
+    int idx = cidx(v, i, j);
+    double nl, dnl;
+    nl_terms(ph, fp.f[SUHMO_F_PHI][idx], fp.f[SUHMO_F_B][idx], fp.f[SUHMO_F_PI][idx], fp.f[SUHMO_F_ZB][idx], fp.f[SUHMO_F_MASK][idx], nl, dnl);
+    fp.f[SUHMO_F_NL][idx] = nl; fp.f[SUHMO_F_DNL][idx] = dnl;
+}
+__global__ void k_lambda(DV v, FP fp)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || j >= v.ny) return;
+    int idx = cidx(v, i, j);
+    double aterm = fp.f[SUHMO_F_ACOEF][idx] * v.alpha;
+    fp.f[SUHMO_F_LAMBDA][idx] = lambda_cell(v, aterm, fp.f[SUHMO_F_BX][idx + 1], fp.f[SUHMO_F_BX][idx],
+                                            fp.f[SUHMO_F_BY][idx + v.P], fp.f[SUHMO_F_BY][idx]);
+}
+extern "C" int suhmo_level_nonlinear(suhmo_level_t *L, int depth, suhmo_stream_t s)
+{
+    ARG(L); ARG(depth >= 0 && depth < L->ndepth);
+    HIPCHK(hipSetDevice(L->device));
+    Depth &D = L->d[depth];
+    if (!suhmo_field(L, depth, SUHMO_F_NL) || !suhmo_field(L, depth, SUHMO_F_DNL)) return -2;
+    hipLaunchKernelGGL(k_nonlinear, grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, L->ph);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int suhmo_level_compute_lambda(suhmo_level_t *L, int depth, suhmo_stream_t s)
+{
+    ARG(L); ARG(depth >= 0 && depth < L->ndepth);
+    HIPCHK(hipSetDevice(L->device));
+    Depth &D = L->d[depth];
+    if (!suhmo_field(L, depth, SUHMO_F_LAMBDA)) return -2;
+    hipLaunchKernelGGL(k_lambda, grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int suhmo_level_gsrb(suhmo_level_t *L, int depth, int sweeps, suhmo_stream_t s)
+{
+    ARG(L); ARG(depth >= 0 && depth < L->ndepth); ARG(sweeps >= 0);
+    HIPCHK(hipSetDevice(L->device));
+    int rc = suhmo_launch_gsrb(L, depth, sweeps, (hipStream_t)s);
+    if (rc) return rc;
+    // levelGSRB leaves the ghosts with the HOMOGENEOUS BC applied (:757-759)
+    if (sweeps > 0) return suhmo_level_fill_ghosts(L, depth, SUHMO_F_PHI, 1, s);
+    return 0;
+}
+
+// RESTRICTRESVCNL2D (src/VCAMRNonLinearPoissonOpF.ChF:516-558) fused with BC + NL: one thread
+// per coarse cell; the four fine contributions are accumulated in the reference's loop order
+// (2I,2J), (2I+1,2J), (2I,2J+1), (2I+1,2J+1) onto a zero-initialised coarse value.
+template <bool HAS_ALPHA>
+__global__ __launch_bounds__(256) void k_restrict_residual(DV v, FP fp, DV vc, double *__restrict__ resC, suhmo_phys_t ph)
+{
+    int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y * blockDim.y + threadIdx.y;
+    if (I >= vc.nx || J >= vc.ny) return;
+    const double *__restrict__ phi = fp.f[SUHMO_F_PHI];
+    double acc = 0.0;
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            int i = 2 * I + a, j = 2 * J + b;
+            int idx = cidx(v, i, j);
+            double c = phi[idx];
+            double e = phiE(v, phi, idx, i, c, false), w = phiW(v, phi, idx, i, c, false);
+            double n = phiN(v, phi, idx, j, c, false), s = phiS(v, phi, idx, j, c, false);
+            double bxW = fp.f[SUHMO_F_BX][idx], bxE = fp.f[SUHMO_F_BX][idx + 1];
+            double byS = fp.f[SUHMO_F_BY][idx], byN = fp.f[SUHMO_F_BY][idx + v.P];
+            double nl, dnl;
+            nl_terms(ph, c, fp.f[SUHMO_F_B][idx], fp.f[SUHMO_F_PI][idx], fp.f[SUHMO_F_ZB][idx], fp.f[SUHMO_F_MASK][idx], nl, dnl);
+            double aterm = HAS_ALPHA ? v.alpha * fp.f[SUHMO_F_ACOEF][idx] : v.alpha;
+            double lofphi = lofphi_cell(v, aterm, c, e, w, n, s, bxE, bxW, byN, byS, nl);
+            acc = acc + (fp.f[SUHMO_F_RHS][idx] - lofphi) / 4.0;
+        }
+    resC[cidx(vc, I, J)] = acc;
+}
+
+extern "C" int suhmo_level_restrict_residual(suhmo_level_t *L, int depth, suhmo_stream_t s)
+{
+    ARG(L); ARG(depth >= 0 && depth + 1 < L->ndepth);
+    HIPCHK(hipSetDevice(L->device));
+    Depth &D = L->d[depth], &C = L->d[depth + 1];
+    int rc = exchange_if_needed(L, depth, SUHMO_F_PHI, (hipStream_t)s); if (rc) return rc;
+    if (D.v.alpha != 0.0) hipLaunchKernelGGL(k_restrict_residual<true>, grid2d(C.v.nx, C.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, C.v, C.fp.f[SUHMO_F_RES], L->ph);
+    else hipLaunchKernelGGL(k_restrict_residual<false>, grid2d(C.v.nx, C.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, C.v, C.fp.f[SUHMO_F_RES], L->ph);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// RESTRICTVCNL (src/VCAMRNonLinearPoissonOpF.ChF:432-446)
+__global__ void k_restrict_r(DV v, const double *__restrict__ f, DV vc, double *__restrict__ c)
+{
+    int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y * blockDim.y + threadIdx.y;
+    if (I >= vc.nx || J >= vc.ny) return;
+    int idx = cidx(v, 2 * I, 2 * J);
+    double acc = 0.0;
+    acc = acc + f[idx] / 4.0;
+    acc = acc + f[idx + 1] / 4.0;
+    acc = acc + f[idx + v.P] / 4.0;
+    acc = acc + f[idx + v.P + 1] / 4.0;
+    c[cidx(vc, I, J)] = acc;
+}
+extern "C" int suhmo_level_restrict_r(suhmo_level_t *L, int depth, suhmo_stream_t s)
+{
+    ARG(L); ARG(depth >= 0 && depth + 1 < L->ndepth);
+    HIPCHK(hipSetDevice(L->device));
+    Depth &D = L->d[depth], &C = L->d[depth + 1];
+    hipLaunchKernelGGL(k_restrict_r, grid2d(C.v.nx, C.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp.f[SUHMO_F_PHI], C.v, C.fp.f[SUHMO_F_PHI]);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// PROLONGNL (src/AMRNonLinearPoissonOpF.ChF:617-628), m = 2
+__global__ void k_prolong(DV v, double *__restrict__ phi, DV vc, const double *__restrict__ c)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || j >= v.ny) return;
+    int idx = cidx(v, i, j);
+    phi[idx] = phi[idx] + c[cidx(vc, i / 2, j / 2)];
+}
+extern "C" int suhmo_level_prolong_increment(suhmo_level_t *L, int depth, suhmo_stream_t s)
+{
+    ARG(L); ARG(depth >= 0 && depth + 1 < L->ndepth);
+    HIPCHK(hipSetDevice(L->device));
+    Depth &D = L->d[depth], &C = L->d[depth + 1];
+    hipLaunchKernelGGL(k_prolong, grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp.f[SUHMO_F_PHI], C.v, C.fp.f[SUHMO_F_CORR]);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// PROLONG_2_NL (src/AMRNonLinearPoissonOpF.ChF:660-705), coarse data read with its stored ghosts
+__global__ void k_prolong2(DV v, double *__restrict__ phi, DV vc, const double *__restrict__ c)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || j >= v.ny) return;
+    const double den = 1.0 / 16.0, fx1 = 3.0 * den, fx2 = 9.0 * den, f0 = 1.0 * den;
+    int ic = i / 2, jc = j / 2, o1 = 2 * (i % 2) - 1, o2 = 2 * (j % 2) - 1;
+    int idx = cidx(v, i, j), cc = cidx(vc, ic, jc);
+    double p = phi[idx];
+    p = p + fx2 * c[cc] + f0 * c[cc + o1 + o2 * vc.P];
+    p = p + fx1 * (c[cc + o1] + c[cc + o2 * vc.P]);
+    phi[idx] = p;
+}
+extern "C" int suhmo_level_prolong_bilinear(suhmo_level_t *L, int depth, suhmo_stream_t s)
+{
+    ARG(L); ARG(depth >= 0 && depth + 1 < L->ndepth);
+    HIPCHK(hipSetDevice(L->device));
+    Depth &D = L->d[depth], &C = L->d[depth + 1];
+    hipLaunchKernelGGL(k_prolong2, grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp.f[SUHMO_F_PHI], C.v, C.fp.f[SUHMO_F_CORR]);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ bCoef update (WFlx_level)
+// step 1: cell-centred gradient = EdgeToCell(NEWMACGRAD) (util/Gradient.cpp:96-127, :623;
+// util/GradientF.ChF:57-70)
+__global__ __launch_bounds__(256) void k_gradcc(DV v, FP fp, int hasMask)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || j >= v.ny) return;
+    const double *__restrict__ phi = fp.f[SUHMO_F_PHI];
+    int idx = cidx(v, i, j);
+    double c = phi[idx];
+    double e = phiE(v, phi, idx, i, c, false), w = phiW(v, phi, idx, i, c, false);
+    double n = phiN(v, phi, idx, j, c, false), s = phiS(v, phi, idx, j, c, false);
+    double gW = v.fdx * (c - w), gE = v.fdx * (e - c), gS = v.fdy * (c - s), gN = v.fdy * (n - c);
+    if (hasMask) {
+        const double *__restrict__ m = fp.f[SUHMO_F_MASK];
+        bool mc = m[idx] < 1e-6;
+        if (mc || m[idx - 1] < 1e-6) gW = 0.0;
+        if (mc || m[idx + 1] < 1e-6) gE = 0.0;
+        if (mc || m[idx - v.P] < 1e-6) gS = 0.0;
+        if (mc || m[idx + v.P] < 1e-6) gN = 0.0;
+    }
+    fp.f[SUHMO_F_GRADX][idx] = 0.5 * (gW + gE);
+    fp.f[SUHMO_F_GRADY][idx] = 0.5 * (gS + gN);
+}
+// step 2: ghosts of the gradient: exchange (periodic wrap) + ExtrapGhostCells
+// (src/AmrHydro.cpp:1490-1491, util/ExtrapGhostCells.cpp:94-180, util/ExtrapBCF.ChF:21-29)
+__global__ void k_grad_ghosts(DV v, double *__restrict__ gx, double *__restrict__ gy)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double *g2[2] = {gx, gy};
+    if (t < 2 * v.ny) {
+        int side = t / v.ny, j = t % v.ny;
+        for (int c = 0; c < 2; c++) {
+            double *g = g2[c];
+            if (side == 0) { int idx = cidx(v, 0, j); g[idx - 1] = v.per[0] ? g[idx + v.nx - 1] : 2.0 * g[idx] - g[idx + 1]; }
+            else { int idx = cidx(v, v.nx - 1, j); g[idx + 1] = v.per[0] ? g[idx - (v.nx - 1)] : 2.0 * g[idx] - g[idx - 1]; }
+        }
+        return;
+    }
+    t -= 2 * v.ny;
+    if (t < 2 * v.nx) {
+        int side = t / v.nx, i = t % v.nx;
+        if (v.ext[side]) return;
+        for (int c = 0; c < 2; c++) {
+            double *g = g2[c];
+            if (side == 0) { int idx = cidx(v, i, 0); g[idx - v.P] = v.per[1] ? g[idx + (v.ny - 1) * v.P] : 2.0 * g[idx] - g[idx + v.P]; }
+            else { int idx = cidx(v, i, v.ny - 1); g[idx + v.P] = v.per[1] ? g[idx - (v.ny - 1) * v.P] : 2.0 * g[idx] - g[idx - v.P]; }
+        }
+    }
+}
+// step 3: COMPUTERE on the ghosted box (src/AmrHydro.cpp:1495-1505, src/AmrHydroF.ChF:92-109)
+__global__ __launch_bounds__(256) void k_re(DV v, FP fp, suhmo_phys_t ph)
+{
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1, j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+    if (i > v.nx || j > v.ny) return;
+    bool xo = (i < 0 || i >= v.nx), yo = (j < 0 || j >= v.ny);
+    if (xo && yo) return;                                      // corner ghosts are never read
+    int idx = cidx(v, i, j);
+    double gx = fp.f[SUHMO_F_GRADX][idx], gy = fp.f[SUHMO_F_GRADY][idx], B = fp.f[SUHMO_F_B][idx];
+    double sg = sqrt(gx * gx + gy * gy);
+    double discr = 1.0 + 4.0 * ph.omega * (B * B * B * ph.grav * sg) / (12.0 * ph.nu * ph.nu);
+    fp.f[SUHMO_F_RE][idx] = (-1.0 + sqrt(discr)) / (2.0 * ph.omega);
+}
+// step 4: CellToEdge(Re), CellToEdge(B), setup_iceMask_EC, COMPUTEBCOEFF
+// (src/AmrHydro.cpp:1512-1537, src/HydroIBC.cpp:139-184, src/AmrHydroF.ChF:212-228)
+__device__ __forceinline__ double bcoef_face(const suhmo_phys_t &ph, double Rc, double Rm, double Bc, double Bm,
+                                             double mc, double mm, bool dom_edge)
+{
+    double Ref = 0.5 * (Rc + Rm), Bf = 0.5 * (Bc + Bm);
+    double mec;
+    if (fabs(mc - mm) < 1e-10) mec = (mc > 0.0) ? 1.0 : -1.0; else mec = 0.0;
+    if (dom_edge) mec = 0.0;
+    double num_q = -(Bf * Bf * Bf * ph.grav);
+    double denom_q = 12.0 * ph.nu * (1.0 + ph.omega * Ref);
+    if (mec < 0.0 && ph.cutOffB > 0) return 0.0;
+    return num_q / denom_q;
+}
+__global__ __launch_bounds__(256) void k_bcoef_faces(DV v, FP fp, suhmo_phys_t ph)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > v.nx || j > v.ny) return;
+    int idx = cidx(v, i, j);
+    const double *__restrict__ Re = fp.f[SUHMO_F_RE], *__restrict__ B = fp.f[SUHMO_F_B], *__restrict__ m = fp.f[SUHMO_F_MASK];
+    if (j < v.ny)   // x-face (i,j) between cells (i-1,j) and (i,j)
+        fp.f[SUHMO_F_BX][idx] = bcoef_face(ph, Re[idx], Re[idx - 1], B[idx], B[idx - 1], m[idx], m[idx - 1], i == 0 || i == v.nx);
+    if (i < v.nx) { // y-face (i,j) between cells (i,j-1) and (i,j)
+        int jg = j + v.j0;
+        fp.f[SUHMO_F_BY][idx] = bcoef_face(ph, Re[idx], Re[idx - v.P], B[idx], B[idx - v.P], m[idx], m[idx - v.P], jg == 0 || jg == v.nyg);
+    }
+}
+
+extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_stream_t s)
+{
+    ARG(L); ARG(depth >= 0 && depth < L->ndepth);
+    HIPCHK(hipSetDevice(L->device));
+    hipStream_t st = (hipStream_t)s;
+    Depth &D = L->d[depth];
+    if (!suhmo_field(L, depth, SUHMO_F_GRADX) || !suhmo_field(L, depth, SUHMO_F_GRADY) || !suhmo_field(L, depth, SUHMO_F_RE)) return -2;
+    int rc = exchange_if_needed(L, depth, SUHMO_F_PHI, st); if (rc) return rc;
+    hipLaunchKernelGGL(k_gradcc, grid2d(D.v.nx, D.v.ny), BLK2D, 0, st, D.v, D.fp, L->ph.use_mask_gradients);
+    rc = exchange_if_needed(L, depth, SUHMO_F_GRADX, st); if (rc) return rc;
+    rc = exchange_if_needed(L, depth, SUHMO_F_GRADY, st); if (rc) return rc;
+    int n = 2 * D.v.ny + 2 * D.v.nx;
+    hipLaunchKernelGGL(k_grad_ghosts, dim3((n + 255) / 256), dim3(256), 0, st, D.v, D.fp.f[SUHMO_F_GRADX], D.fp.f[SUHMO_F_GRADY]);
+    hipLaunchKernelGGL(k_re, grid2d(D.v.nx + 2, D.v.ny + 2), BLK2D, 0, st, D.v, D.fp, L->ph);
+    hipLaunchKernelGGL(k_bcoef_faces, grid2d(D.v.nx + 1, D.v.ny + 1), BLK2D, 0, st, D.v, D.fp, L->ph);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// AverageOperator: CoarseAverageFace(bCoef[0] -> bCoef[depth], ratio r = 2^depth), sequential
+// sum of the r collinear fine faces divided by r  (src/VCAMRNonLinearPoissonOp.cpp:66-95)
+__global__ void k_average_faces(DV vf, const double *__restrict__ bxf, const double *__restrict__ byf,
+                                DV vc, double *__restrict__ bxc, double *__restrict__ byc, int r)
+{
+    int ic = blockIdx.x * blockDim.x + threadIdx.x, jc = blockIdx.y * blockDim.y + threadIdx.y;
+    if (ic > vc.nx || jc > vc.ny) return;
+    if (jc < vc.ny) {
+        double sm = 0.0;
+        int base = cidx(vf, ic * r, jc * r);
+        for (int k = 0; k < r; k++) sm = sm + bxf[base + k * vf.P];
+        bxc[cidx(vc, ic, jc)] = sm / (double)r;
+    }
+    if (ic < vc.nx) {
+        double sm = 0.0;
+        int base = cidx(vf, ic * r, jc * r);
+        for (int k = 0; k < r; k++) sm = sm + byf[base + k];
+        byc[cidx(vc, ic, jc)] = sm / (double)r;
+    }
+}
+extern "C" int suhmo_level_average_operator(suhmo_level_t *L, int depth, suhmo_stream_t s)
+{
+    ARG(L); ARG(depth >= 0 && depth < L->ndepth);
+    if (depth == 0) return 0;
+    HIPCHK(hipSetDevice(L->device));
+    Depth &F = L->d[0], &C = L->d[depth];
+    hipLaunchKernelGGL(k_average_faces, grid2d(C.v.nx + 1, C.v.ny + 1), BLK2D, 0, (hipStream_t)s, F.v, F.fp.f[SUHMO_F_BX], F.fp.f[SUHMO_F_BY],
+                       C.v, C.fp.f[SUHMO_F_BX], C.fp.f[SUHMO_F_BY], 1 << depth);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// MGnewOp coefficient coarsening: CoarseAverage (arithmetic) of aCoef, B, Pi, zb, iceMask from
+// depth 0 with ratio r: sequential sum (ii fastest) * 1/r^2 (src/VCAMRNonLinearPoissonOp.cpp:1116-1138)
+__global__ void k_average_cells(DV vf, const double *__restrict__ f, DV vc, double *__restrict__ c, int r)
+{
+    int ic = blockIdx.x * blockDim.x + threadIdx.x, jc = blockIdx.y * blockDim.y + threadIdx.y;
+    if (ic >= vc.nx || jc >= vc.ny) return;
+    double sm = 0.0;
+    int base = cidx(vf, ic * r, jc * r);
+    for (int jj = 0; jj < r; jj++)
+        for (int ii = 0; ii < r; ii++) sm = sm + f[base + jj * vf.P + ii];
+    c[cidx(vc, ic, jc)] = sm * (1.0 / (double)(r * r));
+}
+// ghosts of coarse B / Pi / zb / mask: periodic wrap or Neumann copy (NeumBCForB :1309-1341)
+__global__ void k_coef_ghosts(DV v, double *__restrict__ p)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 2 * v.ny) {
+        int side = t / v.ny, j = t % v.ny;
+        if (side == 0) { int idx = cidx(v, 0, j); p[idx - 1] = v.per[0] ? p[idx + v.nx - 1] : p[idx]; }
+        else { int idx = cidx(v, v.nx - 1, j); p[idx + 1] = v.per[0] ? p[idx - (v.nx - 1)] : p[idx]; }
+        return;
+    }
+    t -= 2 * v.ny;
+    if (t < 2 * v.nx) {
+        int side = t / v.nx, i = t % v.nx;
+        if (v.ext[side]) return;
+        if (side == 0) { int idx = cidx(v, i, 0); p[idx - v.P] = v.per[1] ? p[idx + (v.ny - 1) * v.P] : p[idx]; }
+        else { int idx = cidx(v, i, v.ny - 1); p[idx + v.P] = v.per[1] ? p[idx - (v.ny - 1) * v.P] : p[idx]; }
+    }
+}
+extern "C" int suhmo_level_build_mg_coefficients(suhmo_level_t *L, suhmo_stream_t s)
+{
+    ARG(L);
+    HIPCHK(hipSetDevice(L->device));
+    hipStream_t st = (hipStream_t)s;
+    static const int fields[5] = {SUHMO_F_ACOEF, SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB, SUHMO_F_MASK};
+    Depth &F = L->d[0];
+    for (int dep = 1; dep < L->ndepth; dep++) {
+        Depth &C = L->d[dep];
+        for (int q = 0; q < 5; q++) {
+            hipLaunchKernelGGL(k_average_cells, grid2d(C.v.nx, C.v.ny), BLK2D, 0, st, F.v, F.fp.f[fields[q]], C.v, C.fp.f[fields[q]], 1 << dep);
+            if (q > 0) {
+                int n = 2 * C.v.ny + 2 * C.v.nx;
+                hipLaunchKernelGGL(k_coef_ghosts, dim3((n + 255) / 256), dim3(256), 0, st, C.v, C.fp.f[fields[q]]);
+            }
+        }
+        int rc = suhmo_level_average_operator(L, dep, s);
+        if (rc) return rc;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ small operators
+// DIVERGENCE (util/DivergenceF.ChF:38-54), called for dir 0 then dir 1
+__global__ void k_divergence(DV v, const double *__restrict__ ux, const double *__restrict__ uy, double *__restrict__ div)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || j >= v.ny) return;
+    int idx = cidx(v, i, j);
+    double d = div[idx];
+    d = d + v.fdx * (ux[idx + 1] - ux[idx]);
+    d = d + v.fdy * (uy[idx + v.P] - uy[idx]);
+    div[idx] = d;
+}
+extern "C" int suhmo_level_divergence(suhmo_level_t *L, int depth, int dst_field, suhmo_stream_t s)
+{
+    CHECK_DF(L, depth, dst_field); ARG(!is_face(dst_field));
+    HIPCHK(hipSetDevice(L->device));
+    Depth &D = L->d[depth];
+    double *dst = suhmo_field(L, depth, dst_field);
+    hipLaunchKernelGGL(k_divergence, grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp.f[SUHMO_F_BX], D.fp.f[SUHMO_F_BY], dst);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// getFlux (src/VCAMRNonLinearPoissonOp.cpp:820-840): F = -b * ((phi_hi - phi_lo) * (beta*ref/dx))
+__global__ void k_getflux(DV v, FP fp, int dir, double scale, double *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    int nxf = dir == 0 ? v.nx + 1 : v.nx, nyf = dir == 0 ? v.ny : v.ny + 1;
+    if (i >= nxf || j >= nyf) return;
+    const double *__restrict__ phi = fp.f[SUHMO_F_PHI];
+    int idx = cidx(v, i, j);
+    double phihi = phi[idx], philo = dir == 0 ? phi[idx - 1] : phi[idx - v.P];   // stored ghosts
+    double gradphi = (phihi - philo) * scale;
+    out[(size_t)j * nxf + i] = -fp.f[dir == 0 ? SUHMO_F_BX : SUHMO_F_BY][idx] * gradphi;
+}
+extern "C" int suhmo_level_get_flux(suhmo_level_t *L, int depth, int dir, int ref, double *flux_host, suhmo_stream_t s)
+{
+    ARG(L); ARG(depth >= 0 && depth < L->ndepth); ARG(dir == 0 || dir == 1); ARG(flux_host);
+    HIPCHK(hipSetDevice(L->device));
+    hipStream_t st = (hipStream_t)s;
+    Depth &D = L->d[depth];
+    int rc = suhmo_level_fill_ghosts(L, depth, SUHMO_F_PHI, 0, s); if (rc) return rc;
+    int nxf = dir == 0 ? D.v.nx + 1 : D.v.nx, nyf = dir == 0 ? D.v.ny : D.v.ny + 1;
+    double *tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, (size_t)nxf * nyf * 8));
+    double scale = D.v.beta * ref / (dir == 0 ? D.v.dx : D.v.dy);
+    hipLaunchKernelGGL(k_getflux, grid2d(nxf, nyf), BLK2D, 0, st, D.v, D.fp, dir, scale, tmp);
+    HIPCHK(hipMemcpyAsync(flux_host, tmp, (size_t)nxf * nyf * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipFree(tmp));
+    return 0;
+}
+
+// LevelDataOps::axby / setVal on valid cells
+__global__ void k_axby(DV v, double *__restrict__ dst, const double *__restrict__ x, const double *__restrict__ y, double a, double b)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || j >= v.ny) return;
+    int idx = cidx(v, i, j);
+    dst[idx] = a * x[idx] + b * y[idx];
+}
+__global__ void k_setval(DV v, double *__restrict__ dst, double val)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || j >= v.ny) return;
+    dst[cidx(v, i, j)] = val;
+}
+extern "C" int suhmo_level_axby(suhmo_level_t *L, int depth, int dst, int x, int y, double a, double b, suhmo_stream_t s)
+{
+    CHECK_DF(L, depth, dst); CHECK_DF(L, depth, x); CHECK_DF(L, depth, y);
+    HIPCHK(hipSetDevice(L->device));
+    Depth &D = L->d[depth];
+    double *pd = suhmo_field(L, depth, dst), *px = suhmo_field(L, depth, x), *py = suhmo_field(L, depth, y);
+    hipLaunchKernelGGL(k_axby, grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, pd, px, py, a, b);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int suhmo_level_set_value(suhmo_level_t *L, int depth, int field, double val, suhmo_stream_t s)
+{
+    CHECK_DF(L, depth, field);
+    HIPCHK(hipSetDevice(L->device));
+    Depth &D = L->d[depth];
+    hipLaunchKernelGGL(k_setval, grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, suhmo_field(L, depth, field), val);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// norms over valid cells.  ord 0: max |x| (exact, order independent).  ord 2: sqrt(sum x^2),
+// two-stage deterministic reduction (fixed partial order; differs from the serial CPU sum
+// by rounding only).
+__global__ __launch_bounds__(256) void k_norm_partial(DV v, const double *__restrict__ x, int ord, double *__restrict__ partial)
+{
+    __shared__ double sm[256];
+    int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    double acc = 0.0;
+    for (int j = blockIdx.y * blockDim.y + threadIdx.y; j < v.ny; j += gridDim.y * blockDim.y)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.nx; i += gridDim.x * blockDim.x) {
+            double val = x[cidx(v, i, j)];
+            if (ord == 0) acc = fmax(acc, fabs(val)); else acc += val * val;
+        }
+    sm[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sm[tid] = ord == 0 ? fmax(sm[tid], sm[tid + s]) : sm[tid] + sm[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = sm[0];
+}
+__global__ void k_norm_final(const double *__restrict__ partial, int n, int ord, double *__restrict__ out)
+{
+    __shared__ double sm[256];
+    int tid = threadIdx.x;
+    double acc = 0.0;
+    for (int k = tid; k < n; k += 256) acc = ord == 0 ? fmax(acc, partial[k]) : acc + partial[k];
+    sm[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sm[tid] = ord == 0 ? fmax(sm[tid], sm[tid + s]) : sm[tid] + sm[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = ord == 0 ? sm[0] : sm[0];
+}
+extern "C" int suhmo_level_norm(suhmo_level_t *L, int depth, int field, int ord, double *out, suhmo_stream_t s)
+{
+    CHECK_DF(L, depth, field); ARG(out); ARG(ord == 0 || ord == 2);
+    HIPCHK(hipSetDevice(L->device));
+    hipStream_t st = (hipStream_t)s;
+    Depth &D = L->d[depth];
+    dim3 grd(std::min((D.v.nx + 63) / 64, 32), std::min((D.v.ny + 3) / 4, 128));
+    int np = grd.x * grd.y;
+    hipLaunchKernelGGL(k_norm_partial, grd, BLK2D, 0, st, D.v, suhmo_field(L, depth, field), ord, L->scratch + 1);
+    hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, st, L->scratch + 1, np, ord, L->scratch);
+    HIPCHK(hipMemcpyAsync(L->hscratch, L->scratch, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double r = L->hscratch[0];
+    if (ord == 2) r = sqrt(r);
+    if (L->ar && ord == 0) { int rc = L->ar(L->user, &r); if (rc) return rc; }
+    *out = r;
+    return 0;
+}
+
+// ------------------------------------------------------------------ multi-GPU strip halos
+__global__ void k_pack_rows(DV v, const double *__restrict__ p, int jstart, int rows, double *__restrict__ buf)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || r >= rows) return;
+    buf[(size_t)r * v.nx + i] = p[cidx(v, i, jstart + r)];
+}
+__global__ void k_unpack_rows(DV v, double *__restrict__ p, int jstart, int rows, const double *__restrict__ buf)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || r >= rows) return;
+    p[cidx(v, i, jstart + r)] = buf[(size_t)r * v.nx + i];
+}
+extern "C" int suhmo_level_pack_rows(suhmo_level_t *L, int depth, int field, int side, int rows, double *dev_buf, suhmo_stream_t s)
+{
+    CHECK_DF(L, depth, field); ARG(dev_buf); ARG(side == 0 || side == 1);
+    const DV &v = L->d[depth].v;
+    ARG(rows >= 1 && rows <= v.gy && rows <= v.ny);
+    HIPCHK(hipSetDevice(L->device));
+    int jstart = side == 0 ? 0 : v.ny - rows;     // owned rows next to that side, ascending j
+    hipLaunchKernelGGL(k_pack_rows, grid2d(v.nx, rows), BLK2D, 0, (hipStream_t)s, v, suhmo_field(L, depth, field), jstart, rows, dev_buf);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int suhmo_level_unpack_rows(suhmo_level_t *L, int depth, int field, int side, int rows, const double *dev_buf, suhmo_stream_t s)
+{
+    CHECK_DF(L, depth, field); ARG(dev_buf); ARG(side == 0 || side == 1);
+    const DV &v = L->d[depth].v;
+    ARG(rows >= 1 && rows <= v.gy);
+    HIPCHK(hipSetDevice(L->device));
+    int jstart = side == 0 ? -rows : v.ny;        // ghost rows of that side, ascending j
+    hipLaunchKernelGGL(k_unpack_rows, grid2d(v.nx, rows), BLK2D, 0, (hipStream_t)s, v, suhmo_field(L, depth, field), jstart, rows, dev_buf);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ profiling helper
+extern "C" int suhmo_level_profile_enable(suhmo_level_t *L, int on) { ARG(L); L->prof_on = on; return 0; }
+extern "C" int suhmo_level_profile_reset(suhmo_level_t *L)
+{
+    ARG(L);
+    for (auto &pe : L->prof) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    L->prof.clear();
+    return 0;
+}
+extern "C" int suhmo_level_profile_read(suhmo_level_t *L, suhmo_stream_t s, double *ms_total, long *launches, long *cells)
+{
+    ARG(L);
+    HIPCHK(hipStreamSynchronize((hipStream_t)s));
+    double tot = 0.0; long n = 0, c = 0;
+    for (auto &pe : L->prof) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, pe.a, pe.b));
+        tot += ms; n++; c += pe.cells;
+    }
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = n;
+    if (cells) *cells = c;
+    return 0;
+}

@@ -1,0 +1,175 @@
+"""Host-side handle on one device-resident level: a thin Python mirror of the operator
+interface the reference exposes through VCAMRNonLinearPoissonOp / AMRNonLinearPoissonOp
+(src/VCAMRNonLinearPoissonOp.H:50-141, src/AMRNonLinearPoissonOp.H:138-460), calling the
+C-ABI one level at a time.  Method names follow the reference's (levelGSRB -> gsrb /
+relax, applyOpI -> apply_op, residualI -> residual, restrictResidual, restrictR,
+prolongIncrement, UpdateOperator, AverageOperator, AMRNorm -> norm)."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check
+
+F_PHI, F_RHS, F_ACOEF, F_B, F_PI, F_ZB, F_MASK, F_BX, F_BY, F_LAMBDA, F_RES, F_LPHI, F_NL, F_DNL, \
+    F_PHIOLD, F_CORR, F_GRADX, F_GRADY, F_RE = range(19)
+
+
+def _phys(p):
+    return capi.Phys(p["A"], p["omega"], p["nu"], p["cutOffbr"], p["maxOffbr"], p.get("rho_w_g", 9800.0),
+                     p.get("grav", 9.8), int(p.get("cutOffB", 0)), int(p.get("use_NL", 1)),
+                     int(p.get("use_mask_gradients", 0)))
+
+
+def _bc(bc):
+    b = capi.BC()
+    for d in range(2):
+        for s in range(2):
+            b.type[d][s] = int(bc["type"][d][s])
+            b.value[d][s] = float(bc["value"][d][s])
+        b.periodic[d] = int(bc["periodic"][d])
+    return b
+
+
+def solver_params(sp):
+    return capi.SolverParams(sp.get("num_smooth", 4), sp.get("num_bottom", 16), sp.get("max_iter", 100),
+                             sp.get("iter_min", 2), sp.get("imin", 5), sp.get("eps", 1e-7), sp.get("hang", 0.01),
+                             sp.get("norm_thresh", 1e-7), int(sp.get("bcoeff_otf", 1)), sp.get("max_depth", -1))
+
+
+class HipLevel:
+    """One AMR level (or this rank's strip of rows of it) resident in HBM."""
+
+    def __init__(self, nx, ny, dx, dy, bc, phys, alpha=0.0, beta=-1.0, max_box=64, boxes=None,
+                 j0=0, ny_global=None, device=0, halo_rows=1, stream=None):
+        self.nx, self.ny, self.dx, self.dy = nx, ny, dx, dy
+        self.j0, self.ny_global = j0, (ny if ny_global is None else ny_global)
+        self.stream = C.c_void_p(stream) if stream else C.c_void_p(0)
+        d = capi.LevelDesc()
+        d.nx, d.ny, d.j0, d.ny_global, d.dx, d.dy = nx, ny, j0, self.ny_global, dx, dy
+        self._boxes = None
+        if boxes is not None:
+            self._boxes = (C.c_int * (4 * len(boxes)))(*[int(x) for b in boxes for x in b])
+            d.nbox, d.boxes = len(boxes), C.cast(self._boxes, C.POINTER(C.c_int))
+        else:
+            d.nbox, d.boxes = 0, None
+        d.max_box, d.alpha, d.beta = max_box, alpha, beta
+        d.bc, d.phys, d.device, d.halo_rows = _bc(bc), _phys(phys), device, halo_rows
+        self._desc = d
+        h = C.c_void_p()
+        check(capi.lib().suhmo_level_create(C.byref(h), C.byref(d)))
+        self.h = h
+        self.ndepth = capi.lib().suhmo_level_num_depths(h)
+        self._hooks = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib().suhmo_level_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- data movement
+    def shape(self, field, depth=0, ghosted=False):
+        nx, ny = self.nx >> depth, self.ny >> depth
+        if field == F_BX:
+            return (ny, nx + 1)
+        if field == F_BY:
+            return (ny + 1, nx)
+        return (ny + 2, nx + 2) if ghosted else (ny, nx)
+
+    def set(self, field, arr, depth=0, ghosted=False):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        assert a.shape == self.shape(field, depth, ghosted), (a.shape, self.shape(field, depth, ghosted))
+        check(capi.lib().suhmo_level_set_field(self.h, depth, field, a.ctypes.data, int(ghosted), 0, self.stream))
+
+    def get(self, field, depth=0, ghosted=False):
+        out = np.zeros(self.shape(field, depth, ghosted), dtype=np.float64)
+        check(capi.lib().suhmo_level_get_field(self.h, depth, field, out.ctypes.data, int(ghosted), 0, self.stream))
+        return out
+
+    def set_device(self, field, dev_ptr, depth=0, ghosted=False):
+        check(capi.lib().suhmo_level_set_field(self.h, depth, field, C.c_void_p(dev_ptr), int(ghosted), 1, self.stream))
+
+    def put_box(self, field, ibox, fab, lo, hi, depth=0, with_domain_ghosts=False):
+        a = np.ascontiguousarray(fab, dtype=np.float64)
+        check(capi.lib().suhmo_level_put_box(self.h, depth, field, ibox, a.ctypes.data_as(C.POINTER(C.c_double)),
+                                             lo[0], lo[1], hi[0], hi[1], int(with_domain_ghosts), self.stream))
+
+    def get_box(self, field, ibox, lo, hi, depth=0):
+        out = np.zeros((hi[1] - lo[1] + 1, hi[0] - lo[0] + 1))
+        check(capi.lib().suhmo_level_get_box(self.h, depth, field, ibox, out.ctypes.data_as(C.POINTER(C.c_double)),
+                                             lo[0], lo[1], hi[0], hi[1], self.stream))
+        return out
+
+    def set_inputs(self, f):
+        self.set(F_PHI, f["phi"])
+        self.set(F_RHS, f["rhs"])
+        self.set(F_ACOEF, f["aCoef"])
+        for k, fid in (("B", F_B), ("Pi", F_PI), ("zb", F_ZB), ("mask", F_MASK)):
+            self.set(fid, f[k], ghosted=True)
+        if "bx" in f:
+            self.set(F_BX, f["bx"])
+            self.set(F_BY, f["by"])
+
+    # ---- operator methods (reference names in the module docstring)
+    def _call(self, name, *args):
+        check(getattr(capi.lib(), "suhmo_level_" + name)(self.h, *args, self.stream))
+
+    def gsrb(self, sweeps=1, depth=0): self._call("gsrb", depth, sweeps)
+    relax = gsrb
+    def apply_op(self, homogeneous=False, depth=0): self._call("apply_op", depth, int(homogeneous))
+    def residual(self, depth=0): self._call("residual", depth)
+    def restrict_residual(self, depth=0): self._call("restrict_residual", depth)
+    def restrict_r(self, depth=0): self._call("restrict_r", depth)
+    def prolong_increment(self, depth=0): self._call("prolong_increment", depth)
+    def prolong_bilinear(self, depth=0): self._call("prolong_bilinear", depth)
+    def update_operator(self, depth=0): self._call("update_operator", depth)
+    def average_operator(self, depth): self._call("average_operator", depth)
+    def build_mg_coefficients(self): check(capi.lib().suhmo_level_build_mg_coefficients(self.h, self.stream))
+    def nonlinear(self, depth=0): self._call("nonlinear", depth)
+    def compute_lambda(self, depth=0): self._call("compute_lambda", depth)
+    def fill_ghosts(self, field, homogeneous=False, depth=0): self._call("fill_ghosts", depth, field, int(homogeneous))
+    def divergence(self, dst_field, depth=0): self._call("divergence", depth, dst_field)
+    def axby(self, dst, x, y, a, b, depth=0): self._call("axby", depth, dst, x, y, float(a), float(b))
+    def set_value(self, field, v, depth=0): self._call("set_value", depth, field, float(v))
+
+    def get_flux(self, direction, ref=1, depth=0):
+        out = np.zeros(self.shape(F_BX if direction == 0 else F_BY, depth))
+        check(capi.lib().suhmo_level_get_flux(self.h, depth, direction, ref,
+                                              out.ctypes.data_as(C.POINTER(C.c_double)), self.stream))
+        return out
+
+    def norm(self, field, ord=0, depth=0):
+        r = C.c_double()
+        check(capi.lib().suhmo_level_norm(self.h, depth, field, ord, C.byref(r), self.stream))
+        return r.value
+
+    def vcycle(self, sp):
+        s = solver_params(sp)
+        check(capi.lib().suhmo_level_vcycle(self.h, C.byref(s), self.stream))
+
+    def solve(self, sp):
+        s = solver_params(sp)
+        hist = np.zeros(s.max_iter + 2)
+        n = C.c_int()
+        check(capi.lib().suhmo_level_solve(self.h, C.byref(s), C.byref(n), hist.ctypes.data_as(C.POINTER(C.c_double)),
+                                           self.stream))
+        return n.value, hist[: n.value + 1]
+
+    def synchronize(self):
+        check(capi.lib().suhmo_level_synchronize(self.h, self.stream))
+
+    # ---- profiling of the relax kernel (HIP events on the launch stream)
+    def profile(self, on=True):
+        check(capi.lib().suhmo_level_profile_reset(self.h))
+        check(capi.lib().suhmo_level_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        ms, n, c = C.c_double(), C.c_long(), C.c_long()
+        check(capi.lib().suhmo_level_profile_read(self.h, self.stream, C.byref(ms), C.byref(n), C.byref(c)))
+        return ms.value, n.value, c.value

@@ -1,0 +1,215 @@
+"""Parity tests proper: every HIP operator is driven through the C-ABI (libsuhmo_hip.so)
+and compared with the CPU oracle on the same seeded inputs.  Bar: BITWISE equality for
+every fp64 field (both sides are compiled with FP contraction off and follow the
+reference's expression association); the only tolerance is on the l2 norm, whose
+summation order differs (1e-12 relative, stated below)."""
+import numpy as np
+import pytest
+
+from suhmo_amd import synthetic as sy
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from suhmo_amd import capi, level
+    assert capi.lib().suhmo_device_count() > 0, "no GPU visible: the product path has no fallback"
+    return level
+
+
+def pair(oracle, hip, f, bc, ph, alpha=0.0, beta=-1.0, max_box=16):
+    O = oracle.OracleLevel(f["nx"], f["ny"], f["dx"], f["dy"], bc, ph, alpha, beta, max_box, 2)
+    G = hip.HipLevel(f["nx"], f["ny"], f["dx"], f["dy"], bc, ph, alpha, beta, max_box)
+    O.set_inputs(f)
+    G.set_inputs(f)
+    return O, G
+
+
+CASES = [
+    ("random-mixedbc", lambda: sy.random_fields(48, 32), sy.RANDOM_BC, sy.RANDOM_PHYS, 0.7, -1.0, 16),
+    ("random-yperiodic", lambda: sy.random_fields(64, 32, seed=3), sy.CONV_BC, sy.RANDOM_PHYS, 0.0, -1.0, 16),
+    ("random-allperiodic", lambda: sy.random_fields(32, 32, seed=5),
+     dict(type=[[0, 0], [0, 0]], value=[[0, 0], [0, 0]], periodic=[1, 1]), sy.RANDOM_PHYS, 0.25, -1.0, 8),
+    ("ragged-odd", lambda: sy.random_fields(50, 34, seed=9), sy.RANDOM_BC, sy.RANDOM_PHYS, 0.0, -1.0, 64),
+    ("shmip-a3", lambda: sy.shmip_fields(128, 64), sy.A3_BC, sy.A3_PHYS, 0.0, -1.0, 64),
+    ("no-nl", lambda: sy.random_fields(32, 16, seed=2), sy.A3_BC, dict(sy.RANDOM_PHYS, use_NL=0), 0.0, -1.0, 16),
+]
+IDS = [c[0] for c in CASES]
+
+
+def prep(oracle, hip, case, need_b=True):
+    _, mk, bc, ph, alpha, beta, mb = case
+    f = mk()
+    O, G = pair(oracle, hip, f, bc, ph, alpha, beta, mb)
+    if need_b and "bx" not in f:
+        O.update_operator()
+        G.update_operator()
+    return f, O, G
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_nonlinear_and_lambda(oracle, hip, case):
+    f, O, G = prep(oracle, hip, case)
+    O.nonlinear(); G.nonlinear()
+    O.reset_lambda(); G.compute_lambda()
+    assert np.array_equal(G.get(hip.F_NL), O.get(oracle.F_NL))
+    assert np.array_equal(G.get(hip.F_DNL), O.get(oracle.F_DNL))
+    assert np.array_equal(G.get(hip.F_LAMBDA), O.get(oracle.F_LAMBDA))
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_apply_and_residual(oracle, hip, case):
+    f, O, G = prep(oracle, hip, case)
+    for homog in (False, True):
+        O.apply_op(homog); G.apply_op(homog)
+        assert np.array_equal(G.get(hip.F_LPHI), O.get(oracle.F_LPHI))
+    O.residual(); G.residual()
+    assert np.array_equal(G.get(hip.F_RES), O.get(oracle.F_RES))
+    assert G.norm(hip.F_RES, 0) == O.norm(oracle.F_RES, 0)
+    assert abs(G.norm(hip.F_RES, 2) - O.norm(oracle.F_RES, 2)) <= 1e-12 * O.norm(oracle.F_RES, 2)
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+@pytest.mark.parametrize("sweeps", [1, 4])
+def test_gsrb(oracle, hip, case, sweeps):
+    f, O, G = prep(oracle, hip, case)
+    O.gsrb(sweeps); G.gsrb(sweeps)
+    assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI))
+    # ghosts are left with the HOMOGENEOUS BC applied (VCAMRNonLinearPoissonOp.cpp:757-759)
+    go, gg = O.get(oracle.F_PHI, ghosted=True), G.get(hip.F_PHI, ghosted=True)
+    bc = case[2]
+    if not bc["periodic"][0]:
+        assert np.array_equal(gg[1:-1, 0], go[1:-1, 0]) and np.array_equal(gg[1:-1, -1], go[1:-1, -1])
+    if not bc["periodic"][1]:
+        assert np.array_equal(gg[0, 1:-1], go[0, 1:-1]) and np.array_equal(gg[-1, 1:-1], go[-1, 1:-1])
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_restrict_prolong(oracle, hip, case):
+    f, O, G = prep(oracle, hip, case)
+    if O.ndepth < 2:
+        pytest.skip("boxes not coarsenable")
+    assert G.ndepth == O.ndepth
+    O.build_mg_coefficients(); G.build_mg_coefficients()
+    for fid in (oracle.F_ACOEF, oracle.F_B, oracle.F_PI, oracle.F_ZB, oracle.F_MASK, oracle.F_BX, oracle.F_BY):
+        for d in range(1, O.ndepth):
+            assert np.array_equal(G.get(fid, depth=d), O.get(fid, depth=d)), (fid, d)
+    O.restrict_residual(); G.restrict_residual()
+    assert np.array_equal(G.get(hip.F_RES, depth=1), O.get(oracle.F_RES, depth=1))
+    O.restrict_r(); G.restrict_r()
+    assert np.array_equal(G.get(hip.F_PHI, depth=1), O.get(oracle.F_PHI, depth=1))
+    rng = np.random.default_rng(1)
+    corr = rng.normal(size=O.shape(oracle.F_PHI, 1))
+    O.prolong_increment(corr)
+    G.set(hip.F_CORR, corr, depth=1); G.prolong_increment()
+    assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI))
+    # PROLONG_2_NL with a ghosted coarse correction
+    cg = rng.normal(size=O.shape(oracle.F_PHI, 1, ghosted=True))
+    fine0 = G.get(hip.F_PHI)
+    G.set(hip.F_CORR, cg, depth=1, ghosted=True); G.prolong_bilinear()
+    assert np.array_equal(G.get(hip.F_PHI), oracle.prolong2(fine0, cg))
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_update_and_average_operator(oracle, hip, case):
+    _, mk, bc, ph, alpha, beta, mb = case
+    f = mk()
+    O, G = pair(oracle, hip, f, bc, ph, alpha, beta, mb)
+    O.update_operator(); G.update_operator()
+    assert np.array_equal(G.get(hip.F_BX), O.get(oracle.F_BX))
+    assert np.array_equal(G.get(hip.F_BY), O.get(oracle.F_BY))
+    for d in range(1, O.ndepth):
+        O.average_operator(d); G.average_operator(d)
+        assert np.array_equal(G.get(hip.F_BX, depth=d), O.get(oracle.F_BX, depth=d))
+        assert np.array_equal(G.get(hip.F_BY, depth=d), O.get(oracle.F_BY, depth=d))
+
+
+def test_divergence_flux_axby(oracle, hip):
+    f = sy.random_fields(40, 24, seed=4)
+    O, G = pair(oracle, hip, f, sy.RANDOM_BC, sy.RANDOM_PHYS)
+    d0 = np.random.default_rng(0).normal(size=(24, 40))
+    G.set(hip.F_LPHI, d0)
+    G.divergence(hip.F_LPHI)
+    assert np.array_equal(G.get(hip.F_LPHI), oracle.divergence(f["bx"], f["by"], f["dx"], f["dy"], d0))
+    O.bc(oracle.F_PHI, False)
+    pg = O.get(oracle.F_PHI, ghosted=True)
+    for direction, b, h in ((0, f["bx"], f["dx"]), (1, f["by"], f["dy"])):
+        assert np.array_equal(G.get_flux(direction, ref=2), oracle.getflux(pg, b, direction, -1.0, h, 2))
+    G.axby(hip.F_RES, hip.F_PHI, hip.F_RHS, 1.0, -1.0)
+    assert np.array_equal(G.get(hip.F_RES), f["phi"] - f["rhs"])
+
+
+def test_box_traffic_roundtrip(oracle, hip):
+    # LevelData<FArrayBox> drop-in: scatter per-box fabs (1 ghost), gather them back with ghosts
+    nx, ny, mb = 32, 16, 8
+    f = sy.random_fields(nx, ny, seed=8)
+    boxes = [(bi * mb, bj * mb, bi * mb + mb - 1, bj * mb + mb - 1) for bj in range(ny // mb) for bi in range(nx // mb)]
+    G = hip.HipLevel(nx, ny, f["dx"], f["dy"], sy.RANDOM_BC, sy.RANDOM_PHYS, boxes=boxes)
+    Bg = f["B"]
+    for k, (l0, l1, h0, h1) in enumerate(boxes):
+        fab = np.full((mb + 2, mb + 2), np.nan)           # stale interior ghosts must be ignored
+        fab[1:-1, 1:-1] = f["phi"][l1:h1 + 1, l0:h0 + 1]
+        G.put_box(hip.F_PHI, k, fab, (l0 - 1, l1 - 1), (h0 + 1, h1 + 1))
+        G.put_box(hip.F_B, k, Bg[l1:h1 + 3, l0:h0 + 3], (l0 - 1, l1 - 1), (h0 + 1, h1 + 1), with_domain_ghosts=True)
+    assert np.array_equal(G.get(hip.F_PHI), f["phi"])
+    gb = G.get(hip.F_B, ghosted=True)
+    assert np.array_equal(gb[1:-1, :], Bg[1:-1, :]) and np.array_equal(gb[:, 1:-1], Bg[:, 1:-1])
+    G.fill_ghosts(hip.F_PHI, False)
+    O = oracle.OracleLevel(nx, ny, f["dx"], f["dy"], sy.RANDOM_BC, sy.RANDOM_PHYS, 0.0, -1.0, mb, 1)
+    O.set_inputs(f); O.exchange(oracle.F_PHI); O.bc(oracle.F_PHI, False)
+    og = O.get(oracle.F_PHI, ghosted=True)
+    l0, l1, h0, h1 = boxes[0]
+    fab = G.get_box(hip.F_PHI, 0, (l0 - 1, l1 - 1), (h0 + 1, h1 + 1))
+    assert np.array_equal(fab[1:, 1:][:-1, :-1], f["phi"][l1:h1 + 1, l0:h0 + 1])
+    assert np.array_equal(fab[1:-1, 0], og[1:mb + 1, 0])          # x-lo domain ghosts (Dirichlet)
+    assert np.array_equal(fab[1:-1, -1], f["phi"][l1:h1 + 1, h0 + 1])  # interior ghost = neighbour's valid cells
+
+
+SOLVE_CASES = [
+    ("shmip-a3", lambda: sy.shmip_fields(128, 64), sy.A3_BC, sy.A3_PHYS, 0.0, -1.0, 64),
+    ("conv-yperiodic", lambda: sy.shmip_fields(256, 64, lx=8.0e4), sy.CONV_BC, dict(sy.A3_PHYS, A=2.5e-25), 0.0, -1.0, 32),
+]
+
+
+@pytest.mark.parametrize("case", SOLVE_CASES, ids=[c[0] for c in SOLVE_CASES])
+def test_vcycle_and_solve(oracle, hip, case):
+    _, mk, bc, ph, alpha, beta, mb = case
+    f = mk()
+    f.pop("bx", None); f.pop("by", None)
+    O, G = pair(oracle, hip, f, bc, ph, alpha, beta, mb)
+    O.build_mg_coefficients(); G.build_mg_coefficients()
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-10, norm_thresh=1e-13, max_iter=6, imin=6)
+    O.vcycle(sp); G.vcycle(sp)
+    assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI))      # one V-cycle: bitwise
+    no, ho = O.solve(sp)
+    ng, hg = G.solve(sp)
+    assert ng == no
+    assert np.array_equal(hg, ho)
+    assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI))      # converged head: bitwise
+
+
+def test_full_size_properties(hip):
+    """BASELINE size (4096^2): size-independent properties instead of the (slow) oracle:
+    GSRB fixed point, residual == rhs - applyOp, restriction of a constant, idempotent
+    operator update."""
+    n = 4096
+    f = sy.shmip_fields(n, n)
+    G = hip.HipLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS)
+    G.set_inputs(f)
+    G.update_operator()
+    bx1 = G.get(hip.F_BX)
+    G.update_operator()
+    assert np.array_equal(bx1, G.get(hip.F_BX))
+    G.apply_op()
+    lphi = G.get(hip.F_LPHI)
+    G.residual()
+    assert np.array_equal(G.get(hip.F_RES), f["rhs"] - lphi)
+    G.set(hip.F_RHS, lphi)                       # rhs = L(phi)  ->  fixed point of the relaxation
+    G.gsrb(2)
+    out = G.get(hip.F_PHI)
+    assert np.max(np.abs(out - f["phi"]) / np.abs(f["phi"])) < 1e-11
+    G.set(hip.F_PHI, np.full((n, n), 2.5))
+    G.restrict_r()
+    assert np.all(G.get(hip.F_PHI, depth=1) == 2.5)
+    assert G.ndepth == 6
