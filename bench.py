@@ -99,7 +99,10 @@ def main():
     ndepth = G.ndepth
     updates_per_vcycle = sum((cells >> (2 * d)) * (sp["num_bottom"] if d == ndepth - 1 else sweeps_depth0)
                              for d in range(ndepth))
-    sweep_ms = gsrb_ms / max(gsrb_launches, 1)
+    # profile_read: device time over all depth-0 relax launches in the timed region and the
+    # cell-updates they performed (a K-sweep fused launch counts K sweeps)
+    sweeps_timed = gsrb_cells / cells
+    sweep_ms = gsrb_ms / max(sweeps_timed, 1)
     achieved = BYTES_PER_CELL_SWEEP * cells / (sweep_ms * 1e-3) / 1e9 if gsrb_launches else 0.0
 
     extra = {}
@@ -110,10 +113,10 @@ def main():
         G.gsrb(args.sweeps_only)
         sync()
         dt = time.perf_counter() - t0
-        ms, nl, _ = G.profile_read()
+        ms, nl, nc = G.profile_read()
         G.profile(False)
         extra["bare_gsrb"] = {"sweeps": args.sweeps_only, "wall_ms_per_sweep": 1e3 * dt / args.sweeps_only,
-                              "event_ms_per_sweep": ms / max(nl, 1),
+                              "event_ms_per_sweep": ms / max(nc / cells, 1),
                               "cell_updates_per_s": cells * args.sweeps_only / dt}
 
     cpu = None
@@ -135,7 +138,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "GSRB sweep (red+black) at depth 0", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_cell_sweep": BYTES_PER_CELL_SWEEP,
-                         "avg_sweep_ms": sweep_ms, "sweeps_timed": gsrb_launches},
+                         "avg_sweep_ms": sweep_ms, "sweeps_timed": sweeps_timed, "launches_timed": gsrb_launches},
             "cpu_baseline": cpu,
         }
         out.update(extra)
@@ -144,11 +147,30 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (the
+    GPU box exposes all host CPUs in the mask but grants a 16-core share per GPU)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            n = min(n, max(1, int(int(q[0]) / int(q[1]))))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return min(n, int(os.environ.get("SUHMO_CPU_CORES", "16")))
+
+
 def cpu_baseline(sy, n, sp):
     """The oracle's restatement of the reference CPU path (un-fused levelGSRB etc. over 64^2
     boxes, OpenMP over boxes), same workload, bounded sample: 1 warm-up + 2 timed V-cycles."""
     from oracle import pyoracle as po
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     f = sy.shmip_fields(n, n)
     O = po.OracleLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64, nthreads=cores)
     O.set_inputs(f)

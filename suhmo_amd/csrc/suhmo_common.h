@@ -118,6 +118,7 @@ struct Depth {
     FP fp;
     size_t elems;      // doubles per canvas
     int nbox;
+    double *phi_alt;   // second phi canvas: the fused GSRB kernel writes out of place (ping-pong)
 };
 
 struct ProfEv { hipEvent_t a, b; long cells; };
@@ -137,7 +138,9 @@ struct suhmo_level {
     void *user;
     int prof_on;
     std::vector<ProfEv> prof;
-    int gsrb_variant;           // kernel selection (see suhmo_gsrb.hip)
+    int gsrb_variant;           // kernel selection (see suhmo_gsrb.hip); env SUHMO_GSRB_VARIANT
+    long fused_min_cells;       // auto mode: use the fused kernel from this many cells (env SUHMO_FUSED_MIN_CELLS)
+    int fused_hc;               // rows per chunk of the fused kernel (0 = auto); env SUHMO_FUSED_HC
 };
 
 void suhmo_set_error(const char *fmt, ...);

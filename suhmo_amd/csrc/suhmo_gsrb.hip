@@ -2,15 +2,27 @@
 //
 // Replaces VCAMRNonLinearPoissonOp::levelGSRB (src/VCAMRNonLinearPoissonOp.cpp:654-760):
 //   per colour pass: exchange -> mixBCValues -> NonLinear_level -> GSRBHELMHOLTZVCNL2D
-// with one fused kernel per colour pass over the whole level canvas: the physical BC is
-// evaluated on the fly (common.h phiW/E/S/N), the nonlinear term and its derivative
-// (COMPUTENONLINEARTERMS) and the relaxation coefficient lambda (SUMFACESNL) are
-// recomputed in registers, so per sweep only phi, rhs, bx, by, B, Pi, zb, mask stream
-// through HBM.  Colour rule: cell (i,j) is updated in pass p iff (i + j_global + p) is even
-// (src/VCAMRNonLinearPoissonOpF.ChF:121-129).
+// The physical BC is evaluated on the fly, the nonlinear term and its derivative
+// (COMPUTENONLINEARTERMS, src/AmrHydroF.ChF:23-68) and the relaxation coefficient lambda
+// (SUMFACESNL, ...OpF.ChF:574-601) are recomputed in registers, so per sweep only phi, rhs,
+// bx, by, B, Pi, zb, mask stream through HBM (72 B per cell per sweep).
+// Colour rule: cell (i,j) is updated in pass p iff (i + j_global + p) is even
+// (src/VCAMRNonLinearPoissonOpF.ChF:121-129).  GSRB is colour-Jacobi, so the result does not
+// depend on the box decomposition: the kernels work on the whole level canvas.
+//
+// Two kernels:
+//   k_gsrb_pass_simple   one launch per colour pass, one thread per active cell (small /
+//                        odd-sized depths; also the structural reference for the fused one)
+//   k_gsrb_fused<K>      K full sweeps (2K colour passes) in ONE pass over HBM: each
+//                        workgroup owns a column strip x row chunk and marches down the rows
+//                        with a (2K+3)-row ring of phi in LDS; row r-m is advanced from
+//                        half-sweep m-1 to m while row r+1 is being prefetched, and row r-2K
+//                        (all 2K half-sweeps done) is streamed out.  Halos of 2K cells are
+//                        recomputed redundantly, output goes to a second phi buffer (ping-
+//                        pong) so no workgroup ever reads a neighbour's updated cell.
 #include "suhmo_common.h"
 
-// ---- variant 0: one thread per active-colour cell (reference kernel for the others) ----
+// ---- variant 0: one thread per active-colour cell ----
 template <bool HAS_ALPHA>
 __global__ __launch_bounds__(256) void k_gsrb_pass_simple(DV v, FP fp, suhmo_phys_t ph, int pass)
 {
@@ -36,7 +48,7 @@ __global__ __launch_bounds__(256) void k_gsrb_pass_simple(DV v, FP fp, suhmo_phy
     phi[idx] = c + (fp.f[SUHMO_F_RHS][idx] - lofphi) / denom; // :156
 }
 
-static int launch_simple(suhmo_level *L, int depth, int pass, hipStream_t st)
+static void launch_simple(suhmo_level *L, int depth, int pass, hipStream_t st)
 {
     Depth &D = L->d[depth];
     dim3 blk(64, 4), grd(((D.v.nx + 1) / 2 + 63) / 64, (D.v.ny + 3) / 4);
@@ -44,31 +56,253 @@ static int launch_simple(suhmo_level *L, int depth, int pass, hipStream_t st)
         hipLaunchKernelGGL(k_gsrb_pass_simple<true>, grd, blk, 0, st, D.v, D.fp, L->ph, pass);
     else
         hipLaunchKernelGGL(k_gsrb_pass_simple<false>, grd, blk, 0, st, D.v, D.fp, L->ph, pass);
+}
+
+// ---- variant 1: K sweeps fused, streaming over rows ----
+struct FusedGeom {
+    int W;        // owned columns per strip (even)
+    int Hc;       // owned rows per chunk
+    int nstrips, nchunks, ntiles;
+    int ylo, yhi; // rows that exist for loading / computing (strip-local j, inclusive)
+    int wrap_y;   // rows outside [0, ny) are periodic images (single-rank periodic y)
+};
+
+struct RowCoef {          // per-thread coefficients of its column pair in one row
+    double rhs[2], B[2], Pi[2], zb[2], mask[2], a[2], byS[2], byN[2];
+    double bx0, bx1, bx2;
+};
+#define CP2(d, s, f) d.f[0] = s.f[0]; d.f[1] = s.f[1]
+template <bool HAS_ALPHA>
+__device__ __forceinline__ void copy_coef(RowCoef &d, const RowCoef &s)
+{
+    CP2(d, s, rhs); CP2(d, s, B); CP2(d, s, Pi); CP2(d, s, zb); CP2(d, s, mask);
+    if (HAS_ALPHA) { CP2(d, s, a); }
+    CP2(d, s, byS); CP2(d, s, byN);
+    d.bx0 = s.bx0; d.bx1 = s.bx1; d.bx2 = s.bx2;
+}
+
+template <int K, bool HAS_ALPHA>
+__global__ __launch_bounds__(256, 2) void k_gsrb_fused(DV v, FP fp, const double *__restrict__ pin,
+                                                       double *__restrict__ pout, suhmo_phys_t ph, FusedGeom g)
+{
+    constexpr int NT = 256, LW = 2 * NT, R = 2 * K + 3;
+    __shared__ double lds[R * LW];
+
+    // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs; give every XCD a
+    // contiguous range of tiles (adjacent chunks of one strip share 2K halo rows in its L2).
+    int b = blockIdx.x, q = g.ntiles / 8, rem = g.ntiles % 8, xcd = b % 8;
+    int tile = xcd * q + (xcd < rem ? xcd : rem) + b / 8;
+    int strip = tile / g.nchunks, chunk = tile % g.nchunks;
+
+    const int t = threadIdx.x;
+    const int c0 = strip * g.W;
+    const int xl = 2 * t;                      // position of the pair's first cell in an LDS row
+    const int i0 = c0 - 2 * K + xl;            // its global column (even)
+    const bool in_row = xl < g.W + 4 * K;
+    int im = i0;
+    if (v.per[0]) { if (im < 0) im += v.nx; else if (im >= v.nx) im -= v.nx; }
+    const bool cval = in_row && im >= 0 && im < v.nx;                 // pair lies in the domain
+    const int cend = (c0 + g.W < v.nx) ? c0 + g.W : v.nx;
+    const bool own = cval && i0 >= c0 && i0 < cend;
+
+    const int jA = chunk * g.Hc;
+    const int jB = (jA + g.Hc < v.ny) ? jA + g.Hc : v.ny;
+    const int jmin = (jA - 2 * K > g.ylo) ? jA - 2 * K : g.ylo;
+    const int jmax = (jB - 1 + 2 * K < g.yhi) ? jB - 1 + 2 * K : g.yhi;
+
+    const double *__restrict__ f_rhs = fp.f[SUHMO_F_RHS], *__restrict__ f_B = fp.f[SUHMO_F_B];
+    const double *__restrict__ f_Pi = fp.f[SUHMO_F_PI], *__restrict__ f_zb = fp.f[SUHMO_F_ZB];
+    const double *__restrict__ f_mask = fp.f[SUHMO_F_MASK], *__restrict__ f_a = fp.f[SUHMO_F_ACOEF];
+    const double *__restrict__ f_bx = fp.f[SUHMO_F_BX], *__restrict__ f_by = fp.f[SUHMO_F_BY];
+
+    auto wrapj = [&](int j) { if (g.wrap_y) { if (j < 0) j += v.ny; else if (j >= v.ny) j -= v.ny; } return j; };
+    auto ld2 = [&](const double *__restrict__ p, int idx) { return *reinterpret_cast<const double2 *>(p + idx); };
+
+    // coefficient ring as NAMED variables (an indexed array ends up in scratch memory):
+    // cf0 = row r (being prefetched), cfM = row r-M
+    RowCoef cf0, cf1, cf2, cf3, cf4;
+    double2 pnext = make_double2(0.0, 0.0);
+
+    int sr = 0;                            // LDS ring slot of row r
+    for (int r = jmin - 1; r <= jB - 1 + 2 * K; r++) {
+        // ---- 1. prefetch: phi of row r+1, coefficients of row r (both first used in step r+1)
+        bool lphi = cval && (r + 1 >= jmin) && (r + 1 <= jmax);
+        if (lphi) pnext = ld2(pin, cidx(v, im, wrapj(r + 1)));
+        bool lcf = cval && (r >= jmin) && (r <= jmax);
+        if (lcf) {
+            int idx = cidx(v, im, wrapj(r));
+#define LD2(dst, p, ix) { double2 t_ = ld2(p, ix); dst[0] = t_.x; dst[1] = t_.y; }
+            LD2(cf0.rhs, f_rhs, idx); LD2(cf0.B, f_B, idx); LD2(cf0.Pi, f_Pi, idx);
+            LD2(cf0.zb, f_zb, idx); LD2(cf0.mask, f_mask, idx);
+            if (HAS_ALPHA) LD2(cf0.a, f_a, idx);
+            LD2(cf0.byS, f_by, idx); LD2(cf0.byN, f_by, idx + v.P);
+            double2 bxp = ld2(f_bx, idx);
+            cf0.bx0 = bxp.x; cf0.bx1 = bxp.y; cf0.bx2 = f_bx[idx + 2];
+        }
+        __syncthreads();                   // row r (written at the end of step r-1) is visible
+
+        // ---- 2. advance row r-m from half-sweep m-1 to m, m = 1..2K
+        auto advance = [&](const int m, const RowCoef &q) {
+            const int j = r - m;
+            if (cval && j >= jmin && j <= jmax) {
+                const int pass = (m - 1) & 1;
+                const int a = (j + v.j0 + pass) & 1;          // which cell of the pair has this colour
+                const int x = xl + a, i = im + a;
+                const int s0 = (sr - m + 2 * R) % R, sN = (s0 + 1) % R, sS = (s0 + R - 1) % R;
+                const double *row = lds + s0 * LW;
+                double c = row[x];
+                double w = row[x > 0 ? x - 1 : 0], e = row[x < LW - 1 ? x + 1 : LW - 1];
+                double n = lds[sN * LW + x], s = lds[sS * LW + x];
+                if (!v.per[0]) {                               // mixBCValues on the fly
+                    if (i == 0) w = (v.bct[0][0] == 0) ? v.two_v[0][0] - c : c + v.neu[0][0];
+                    if (i == v.nx - 1) e = (v.bct[0][1] == 0) ? v.two_v[0][1] - c : c + v.neu[0][1];
+                }
+                if (!v.per[1]) {
+                    if (j == 0 && !v.ext[0]) s = (v.bct[1][0] == 0) ? v.two_v[1][0] - c : c + v.neu[1][0];
+                    if (j == v.ny - 1 && !v.ext[1]) n = (v.bct[1][1] == 0) ? v.two_v[1][1] - c : c + v.neu[1][1];
+                }
+                double B = a ? q.B[1] : q.B[0], Pi = a ? q.Pi[1] : q.Pi[0], zb = a ? q.zb[1] : q.zb[0];
+                double mk = a ? q.mask[1] : q.mask[0], rhs = a ? q.rhs[1] : q.rhs[0];
+                double bxW = a ? q.bx1 : q.bx0, bxE = a ? q.bx2 : q.bx1;
+                double byS = a ? q.byS[1] : q.byS[0], byN = a ? q.byN[1] : q.byN[0];
+                double nl, dnl;
+                nl_terms(ph, c, B, Pi, zb, mk, nl, dnl);
+                double aterm = HAS_ALPHA ? v.alpha * (a ? q.a[1] : q.a[0]) : v.alpha;
+                double lofphi = lofphi_cell(v, aterm, c, e, w, n, s, bxE, bxW, byN, byS, nl);
+                double lam = lambda_cell(v, aterm, bxE, bxW, byN, byS);
+                double denom = 1.0e-16 + lam + dnl;
+                lds[s0 * LW + x] = c + (rhs - lofphi) / denom;
+            }
+        };
+        advance(1, cf1);
+        __syncthreads();
+        advance(2, cf2);
+        if constexpr (K >= 2) {
+            __syncthreads();
+            advance(3, cf3);
+            __syncthreads();
+            advance(4, cf4);
+        }
+
+        // ---- 3. row r-2K has all 2K half-sweeps: stream it out (own pair, written by this thread)
+        {
+            const int jo = r - 2 * K;
+            if (own && jo >= jA && jo < jB) {
+                const int so = (sr - 2 * K + 2 * R) % R;
+                double2 o = make_double2(lds[so * LW + xl], lds[so * LW + xl + 1]);
+                *reinterpret_cast<double2 *>(pout + cidx(v, i0, jo)) = o;
+            }
+        }
+        // ---- 4. row r+1 enters the ring (its slot held row r-2K-2: no longer read), rotate
+        sr = (sr + 1) % R;
+        if (in_row) { lds[sr * LW + xl] = pnext.x; lds[sr * LW + xl + 1] = pnext.y; }
+        if constexpr (K >= 2) { copy_coef<HAS_ALPHA>(cf4, cf3); copy_coef<HAS_ALPHA>(cf3, cf2); }
+        copy_coef<HAS_ALPHA>(cf2, cf1);
+        copy_coef<HAS_ALPHA>(cf1, cf0);
+    }
+}
+
+static bool fused_ok(const suhmo_level *L, const Depth &D, int K)
+{
+    const DV &v = D.v;
+    if (v.nx % 2 || v.nx < 64 || v.ny < 4 * K + 4) return false;
+    if ((v.ext[0] || v.ext[1]) && v.gy < 2 * K) return false;
+    if (v.per[1] && !(v.ext[0] || v.ext[1]) && v.ny < 4 * K) return false;
+    return true;
+}
+
+template <int K>
+static int launch_fused(suhmo_level *L, int depth, hipStream_t st)
+{
+    Depth &D = L->d[depth];
+    const DV &v = D.v;
+    if (!D.phi_alt) {
+        HIPCHK(hipMalloc(&D.phi_alt, D.elems * sizeof(double)));
+        HIPCHK(hipMemsetAsync(D.phi_alt, 0, D.elems * sizeof(double), st));
+    }
+    FusedGeom g;
+    const int maxW = 512 - 4 * K;
+    g.nstrips = (v.nx + maxW - 1) / maxW;
+    g.W = 2 * ((v.nx + 2 * g.nstrips - 1) / (2 * g.nstrips));
+    g.nstrips = (v.nx + g.W - 1) / g.W;
+    // rows per chunk: all tiles resident in ONE round (tiles <= workgroup slots of the chip;
+    // a partial second round costs a full one), but never shorter than 16K rows so that the
+    // 4K-row pipeline fill stays small; measured on MI355X: profiles/r01_b_hc_sweep.log
+    {
+        static int slots_k[3] = {0, 0, 0};
+        if (!slots_k[K]) {
+            int nb = 0, ncu = 0, dev = 0;
+            HIPCHK(hipGetDevice(&dev));
+            HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gsrb_fused<K, false>, 256, 0));
+            slots_k[K] = (nb > 0 ? nb : 1) * (ncu > 0 ? ncu : 256);
+        }
+        int nch = slots_k[K] / g.nstrips;
+        if (nch < 1) nch = 1;
+        g.Hc = (v.ny + nch - 1) / nch;
+    }
+    if (L->fused_hc > 0) g.Hc = L->fused_hc;
+    if (g.Hc < 16 * K) g.Hc = 16 * K;
+    if (g.Hc > v.ny) g.Hc = v.ny;
+    g.nchunks = (v.ny + g.Hc - 1) / g.Hc;
+    g.ntiles = g.nstrips * g.nchunks;
+    bool selfper = v.per[1] && !(v.ext[0] || v.ext[1]);
+    g.wrap_y = selfper;
+    g.ylo = (v.ext[0] || selfper) ? -2 * K : 0;
+    g.yhi = (v.ext[1] || selfper) ? v.ny - 1 + 2 * K : v.ny - 1;
+    const double *pin = D.fp.f[SUHMO_F_PHI];
+    if (v.alpha != 0.0)
+        hipLaunchKernelGGL((k_gsrb_fused<K, true>), dim3(g.ntiles), dim3(256), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+    else
+        hipLaunchKernelGGL((k_gsrb_fused<K, false>), dim3(g.ntiles), dim3(256), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+    std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
     return 0;
 }
 
 int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, hipStream_t st)
 {
     Depth &D = L->d[depth];
-    for (int it = 0; it < sweeps; it++) {
+    int variant = L->gsrb_variant;       // -1 auto, 0 simple, 1 fused K=1, 2 fused K=2
+    if (variant < 0) {
+        // the streaming kernel pays ~(Hc + 4K) serial row steps per workgroup: below ~2M cells
+        // (cache-resident depths) two plain colour-pass launches are faster
+        // (profiles/r01_c_vcycle_trace.txt)
+        variant = ((long)D.v.nx * D.v.ny >= (long)L->fused_min_cells) ? 2 : 0;
+    }
+    int it = 0;
+    while (it < sweeps) {
+        int K = 0;                       // sweeps done by the next launch group (0 = simple path, 1 sweep)
+        if (variant >= 2 && sweeps - it >= 2 && fused_ok(L, D, 2)) K = 2;
+        else if (variant >= 1 && fused_ok(L, D, 1)) K = 1;
         ProfEv pe{};
         bool prof = L->prof_on && depth == 0;
         if (prof) {
             HIPCHK(hipEventCreate(&pe.a)); HIPCHK(hipEventCreate(&pe.b));
             HIPCHK(hipEventRecord(pe.a, st));
         }
-        for (int pass = 0; pass < 2; pass++) {
+        if (K == 0) {
+            for (int pass = 0; pass < 2; pass++) {
+                if (L->ex && (D.v.ext[0] || D.v.ext[1])) {
+                    int rc = L->ex(L->user, L, depth, SUHMO_F_PHI, (suhmo_stream_t)st);
+                    if (rc) return rc;
+                }
+                launch_simple(L, depth, pass, st);
+            }
+        } else {
             if (L->ex && (D.v.ext[0] || D.v.ext[1])) {
                 int rc = L->ex(L->user, L, depth, SUHMO_F_PHI, (suhmo_stream_t)st);
                 if (rc) return rc;
             }
-            launch_simple(L, depth, pass, st);
+            int rc = (K == 2) ? launch_fused<2>(L, depth, st) : launch_fused<1>(L, depth, st);
+            if (rc) return rc;
         }
+        int done = K == 0 ? 1 : K;
         if (prof) {
             HIPCHK(hipEventRecord(pe.b, st));
-            pe.cells = (long)D.v.nx * D.v.ny;
+            pe.cells = (long)D.v.nx * D.v.ny * done;
             L->prof.push_back(pe);
         }
+        it += done;
     }
     HIPCHK(hipGetLastError());
     return 0;

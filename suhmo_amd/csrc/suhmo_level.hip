@@ -78,7 +78,11 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     HIPCHK(hipSetDevice(desc->device));
     suhmo_level *L = new suhmo_level();
     L->desc = *desc; L->ph = desc->phys; L->device = desc->device;
-    L->ex = nullptr; L->ar = nullptr; L->user = nullptr; L->prof_on = 0; L->gsrb_variant = -1;
+    L->ex = nullptr; L->ar = nullptr; L->user = nullptr; L->prof_on = 0; L->gsrb_variant = -1; L->fused_hc = 0;
+    if (const char *e = getenv("SUHMO_GSRB_VARIANT")) L->gsrb_variant = atoi(e);
+    if (const char *e = getenv("SUHMO_FUSED_HC")) L->fused_hc = atoi(e);
+    L->fused_min_cells = 2000000;
+    if (const char *e = getenv("SUHMO_FUSED_MIN_CELLS")) L->fused_min_cells = atol(e);
     if (desc->boxes && desc->nbox > 0) {
         L->boxes.assign(desc->boxes, desc->boxes + 4 * (size_t)desc->nbox);
     } else {
@@ -120,6 +124,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
         D.elems = (size_t)D.v.P * (size_t)(D.v.rows + 1);
         D.nbox = L->desc.nbox;
         memset(&D.fp, 0, sizeof(D.fp));
+        D.phi_alt = nullptr;
         for (int f : eager) {
             if (dep == 0 && f == SUHMO_F_LPHI) continue;       // lazily (only tests / AMR use it at depth 0)
             if (!suhmo_field(L, dep, f)) { suhmo_set_error("hipMalloc failed (depth %d field %d)", dep, f); delete L; return -2; }
@@ -141,6 +146,8 @@ extern "C" int suhmo_level_destroy(suhmo_level_t *L)
     for (int dep = 0; dep < L->ndepth; dep++)
         for (int f = 0; f < SUHMO_F_COUNT; f++)
             if (L->d[dep].fp.f[f]) (void)hipFree(L->d[dep].fp.f[f]);
+    for (int dep = 0; dep < L->ndepth; dep++)
+        if (L->d[dep].phi_alt) (void)hipFree(L->d[dep].phi_alt);
     for (auto &pe : L->prof) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     (void)hipFree(L->scratch);
     (void)hipHostFree(L->hscratch);

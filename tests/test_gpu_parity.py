@@ -85,6 +85,29 @@ def test_gsrb(oracle, hip, case, sweeps):
         assert np.array_equal(gg[0, 1:-1], go[0, 1:-1]) and np.array_equal(gg[-1, 1:-1], go[-1, 1:-1])
 
 
+FUSED_CASES = [
+    ("wide-3strips", lambda: sy.random_fields(1100, 48, seed=21), sy.RANDOM_BC, sy.RANDOM_PHYS, 0.7, -1.0, 2048),
+    ("allperiodic", lambda: sy.random_fields(128, 96, seed=22),
+     dict(type=[[0, 0], [0, 0]], value=[[0, 0], [0, 0]], periodic=[1, 1]), sy.RANDOM_PHYS, 0.0, -1.0, 32),
+    ("yperiodic-tall", lambda: sy.random_fields(64, 200, seed=23), sy.CONV_BC, sy.RANDOM_PHYS, 0.0, -1.0, 8),
+    ("shmip-512", lambda: sy.shmip_fields(512, 256), sy.A3_BC, sy.A3_PHYS, 0.0, -1.0, 64),
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
+@pytest.mark.parametrize("variant,hc", [(0, 0), (1, 0), (1, 16), (2, 0), (2, 32)])
+@pytest.mark.parametrize("sweeps", [1, 2, 5])
+def test_gsrb_fused_variants(oracle, hip, case, variant, hc, sweeps, monkeypatch):
+    """every relaxation kernel variant (two-pass, fused red+black, two sweeps fused; several
+    chunk heights = many workgroup seams) gives the oracle's phi bit for bit"""
+    monkeypatch.setenv("SUHMO_GSRB_VARIANT", str(variant))
+    monkeypatch.setenv("SUHMO_FUSED_HC", str(hc))
+    f, O, G = prep(oracle, hip, case)
+    O.gsrb(sweeps); G.gsrb(sweeps)
+    a, b = G.get(hip.F_PHI), O.get(oracle.F_PHI)
+    assert np.array_equal(a, b), "mismatch at %s" % (np.argwhere(a != b)[:5],)
+
+
 @pytest.mark.parametrize("case", CASES, ids=IDS)
 def test_restrict_prolong(oracle, hip, case):
     f, O, G = prep(oracle, hip, case)
