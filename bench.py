@@ -58,7 +58,7 @@ def main():
     ny_global = n * world
     f = sy.shmip_fields(n, n, j0=rank * n, ny_total=ny_global)
     G = level.HipLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64, j0=rank * n,
-                       ny_global=ny_global, device=local_rank)
+                       ny_global=ny_global, device=local_rank, halo_rows=4 if world > 1 else 1)
     G.set_inputs(f)
     if world > 1:
         from suhmo_amd import multigpu
@@ -120,7 +120,7 @@ def main():
                               "cell_updates_per_s": cells * args.sweeps_only / dt}
 
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(sy, n if n <= 4096 else 4096, sp)
 
     if rank == 0:

@@ -168,7 +168,7 @@ int suhmo_level_solve(suhmo_level_t *L, const suhmo_solver_params_t *sp, int *it
                       double *hist, suhmo_stream_t s);
 
 /* multi-GPU strips: pack the `rows` owned rows next to side (0 = y-lo, 1 = y-hi) of a
- * field into a contiguous device buffer (rows x nx doubles) / unpack a neighbour's rows
+ * field into a contiguous device buffer (rows x (nx+1) doubles) / unpack a neighbour's rows
  * into the ghost rows of that side.  The transport (RCCL send/recv) belongs to the host. */
 int suhmo_level_pack_rows(suhmo_level_t *L, int depth, int field, int side, int rows,
                           double *dev_buf, suhmo_stream_t s);
@@ -181,6 +181,12 @@ typedef int (*suhmo_exchange_fn)(void *user, suhmo_level_t *L, int depth, int fi
 typedef int (*suhmo_allreduce_max_fn)(void *user, double *value);
 int suhmo_level_set_hooks(suhmo_level_t *L, suhmo_exchange_fn ex, suhmo_allreduce_max_fn ar,
                           void *user);
+/* LevelData::exchange of one field across the strip's rank boundaries (calls the hook; a
+ * no-op for a single-process level).  Used by the host after it loads coefficient fields. */
+int suhmo_level_exchange(suhmo_level_t *L, int depth, int field, suhmo_stream_t s);
+/* rows of ghost data kept per y side / 1 if the side is a rank boundary */
+int suhmo_level_halo_info(const suhmo_level_t *L, int depth, int *halo_rows, int *ext_lo, int *ext_hi,
+                          int *nx, int *ny);
 
 /* timing helper: average device time (ms) of the GSRB sweep kernel launches since the
  * last reset, measured with HIP events on the launch stream */

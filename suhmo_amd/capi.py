@@ -54,7 +54,7 @@ SYMBOLS = [
     "suhmo_level_nonlinear", "suhmo_level_compute_lambda", "suhmo_level_fill_ghosts",
     "suhmo_level_divergence", "suhmo_level_get_flux", "suhmo_level_norm", "suhmo_level_axby",
     "suhmo_level_set_value", "suhmo_level_vcycle", "suhmo_level_solve", "suhmo_level_pack_rows",
-    "suhmo_level_unpack_rows", "suhmo_level_set_hooks", "suhmo_level_profile_reset",
+    "suhmo_level_unpack_rows", "suhmo_level_set_hooks", "suhmo_level_exchange", "suhmo_level_halo_info", "suhmo_level_profile_reset",
     "suhmo_level_profile_enable", "suhmo_level_profile_read",
 ]
 
@@ -104,6 +104,8 @@ def lib():
     L.suhmo_level_pack_rows.argtypes = [vp, ci, ci, ci, ci, vp, vp]
     L.suhmo_level_unpack_rows.argtypes = [vp, ci, ci, ci, ci, vp, vp]
     L.suhmo_level_set_hooks.argtypes = [vp, EXCHANGE_FN, ALLREDUCE_FN, vp]
+    L.suhmo_level_exchange.argtypes = [vp, ci, ci, vp]
+    L.suhmo_level_halo_info.argtypes = [vp, ci] + [C.POINTER(ci)] * 5
     L.suhmo_level_profile_reset.argtypes = [vp]
     L.suhmo_level_profile_enable.argtypes = [vp, ci]
     L.suhmo_level_profile_read.argtypes = [vp, vp, dp, C.POINTER(C.c_long), C.POINTER(C.c_long)]

@@ -32,6 +32,7 @@ static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, i
                           hipMemcpyDeviceToDevice, (hipStream_t)s));
     if ((rc = suhmo_level_apply_op(L, dep + 1, 0, s))) return rc;                 // LPHI = L_c(R phi)
     if ((rc = suhmo_level_axby(L, dep + 1, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
+    if ((rc = suhmo_level_exchange(L, dep + 1, SUHMO_F_RHS, s))) return rc;   // strips: rhs halo rows for the fused relax
     if ((rc = fas_cycle(L, dep + 1, sp, nd, s))) return rc;
     if ((rc = suhmo_level_axby(L, dep + 1, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) return rc;
     if ((rc = suhmo_level_prolong_increment(L, dep, s))) return rc;

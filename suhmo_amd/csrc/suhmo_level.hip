@@ -169,6 +169,28 @@ extern "C" int suhmo_level_set_hooks(suhmo_level_t *L, suhmo_exchange_fn ex, suh
     return 0;
 }
 
+extern "C" int suhmo_level_exchange(suhmo_level_t *L, int depth, int field, suhmo_stream_t s)
+{
+    ARG(L); ARG(depth >= 0 && depth < L->ndepth); ARG(field >= 0 && field < SUHMO_F_COUNT);
+    const DV &v = L->d[depth].v;
+    if (L->ex && (v.ext[0] || v.ext[1])) {
+        if (!suhmo_field(L, depth, field)) return -2;
+        return L->ex(L->user, L, depth, field, s);
+    }
+    return 0;
+}
+extern "C" int suhmo_level_halo_info(const suhmo_level_t *L, int depth, int *halo_rows, int *ext_lo, int *ext_hi, int *nx, int *ny)
+{
+    ARG(L); ARG(depth >= 0 && depth < L->ndepth);
+    const DV &v = L->d[depth].v;
+    if (halo_rows) *halo_rows = v.gy;
+    if (ext_lo) *ext_lo = v.ext[0];
+    if (ext_hi) *ext_hi = v.ext[1];
+    if (nx) *nx = v.nx;
+    if (ny) *ny = v.ny;
+    return 0;
+}
+
 // ------------------------------------------------------------------ LevelData traffic
 static bool is_face(int f) { return f == SUHMO_F_BX || f == SUHMO_F_BY; }
 #define CHECK_DF(L, depth, field) ARG(L); ARG(depth >= 0 && depth < L->ndepth); ARG(field >= 0 && field < SUHMO_F_COUNT)
@@ -647,6 +669,9 @@ extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_st
     hipLaunchKernelGGL(k_re, grid2d(D.v.nx + 2, D.v.ny + 2), BLK2D, 0, st, D.v, D.fp, L->ph);
     hipLaunchKernelGGL(k_bcoef_faces, grid2d(D.v.nx + 1, D.v.ny + 1), BLK2D, 0, st, D.v, D.fp, L->ph);
     HIPCHK(hipGetLastError());
+    // strips: the fused relaxation recomputes halo rows, so it needs the coefficients there too
+    rc = exchange_if_needed(L, depth, SUHMO_F_BX, st); if (rc) return rc;
+    rc = exchange_if_needed(L, depth, SUHMO_F_BY, st); if (rc) return rc;
     return 0;
 }
 
@@ -679,6 +704,8 @@ extern "C" int suhmo_level_average_operator(suhmo_level_t *L, int depth, suhmo_s
     hipLaunchKernelGGL(k_average_faces, grid2d(C.v.nx + 1, C.v.ny + 1), BLK2D, 0, (hipStream_t)s, F.v, F.fp.f[SUHMO_F_BX], F.fp.f[SUHMO_F_BY],
                        C.v, C.fp.f[SUHMO_F_BX], C.fp.f[SUHMO_F_BY], 1 << depth);
     HIPCHK(hipGetLastError());
+    int rc = exchange_if_needed(L, depth, SUHMO_F_BX, (hipStream_t)s); if (rc) return rc;
+    rc = exchange_if_needed(L, depth, SUHMO_F_BY, (hipStream_t)s); if (rc) return rc;
     return 0;
 }
 
@@ -730,6 +757,7 @@ extern "C" int suhmo_level_build_mg_coefficients(suhmo_level_t *L, suhmo_stream_
         }
         int rc = suhmo_level_average_operator(L, dep, s);
         if (rc) return rc;
+        for (int q = 0; q < 5; q++) { rc = exchange_if_needed(L, dep, fields[q], st); if (rc) return rc; }
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -877,17 +905,18 @@ extern "C" int suhmo_level_norm(suhmo_level_t *L, int depth, int field, int ord,
 }
 
 // ------------------------------------------------------------------ multi-GPU strip halos
+// rows are shipped (nx + 1) wide so that x-face fields (nx + 1 faces per row) travel whole
 __global__ void k_pack_rows(DV v, const double *__restrict__ p, int jstart, int rows, double *__restrict__ buf)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y * blockDim.y + threadIdx.y;
-    if (i >= v.nx || r >= rows) return;
-    buf[(size_t)r * v.nx + i] = p[cidx(v, i, jstart + r)];
+    if (i > v.nx || r >= rows) return;
+    buf[(size_t)r * (v.nx + 1) + i] = p[cidx(v, i, jstart + r)];
 }
 __global__ void k_unpack_rows(DV v, double *__restrict__ p, int jstart, int rows, const double *__restrict__ buf)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y * blockDim.y + threadIdx.y;
-    if (i >= v.nx || r >= rows) return;
-    p[cidx(v, i, jstart + r)] = buf[(size_t)r * v.nx + i];
+    if (i > v.nx || r >= rows) return;
+    p[cidx(v, i, jstart + r)] = buf[(size_t)r * (v.nx + 1) + i];
 }
 extern "C" int suhmo_level_pack_rows(suhmo_level_t *L, int depth, int field, int side, int rows, double *dev_buf, suhmo_stream_t s)
 {
@@ -896,7 +925,10 @@ extern "C" int suhmo_level_pack_rows(suhmo_level_t *L, int depth, int field, int
     ARG(rows >= 1 && rows <= v.gy && rows <= v.ny);
     HIPCHK(hipSetDevice(L->device));
     int jstart = side == 0 ? 0 : v.ny - rows;     // owned rows next to that side, ascending j
-    hipLaunchKernelGGL(k_pack_rows, grid2d(v.nx, rows), BLK2D, 0, (hipStream_t)s, v, suhmo_field(L, depth, field), jstart, rows, dev_buf);
+    // y-faces: face row 0 of this strip IS face row ny of the lower neighbour (both own it), so
+    // the rows the lower neighbour lacks start at face row 1
+    if (field == SUHMO_F_BY && side == 0) jstart = 1;
+    hipLaunchKernelGGL(k_pack_rows, grid2d(v.nx + 1, rows), BLK2D, 0, (hipStream_t)s, v, suhmo_field(L, depth, field), jstart, rows, dev_buf);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -907,7 +939,8 @@ extern "C" int suhmo_level_unpack_rows(suhmo_level_t *L, int depth, int field, i
     ARG(rows >= 1 && rows <= v.gy);
     HIPCHK(hipSetDevice(L->device));
     int jstart = side == 0 ? -rows : v.ny;        // ghost rows of that side, ascending j
-    hipLaunchKernelGGL(k_unpack_rows, grid2d(v.nx, rows), BLK2D, 0, (hipStream_t)s, v, suhmo_field(L, depth, field), jstart, rows, dev_buf);
+    if (field == SUHMO_F_BY && side == 1) jstart = v.ny + 1;   // face row ny is owned (see pack)
+    hipLaunchKernelGGL(k_unpack_rows, grid2d(v.nx + 1, rows), BLK2D, 0, (hipStream_t)s, v, suhmo_field(L, depth, field), jstart, rows, dev_buf);
     HIPCHK(hipGetLastError());
     return 0;
 }

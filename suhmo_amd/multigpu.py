@@ -1,0 +1,168 @@
+"""Row-strip partition of one level across processes (one process per GPU).
+
+The reference partitions a level's boxes over MPI ranks and couples them only through
+LevelData::exchange (src/VCAMRNonLinearPoissonOp.cpp:47,124,304,405,692,751).  Here every
+rank owns a strip of rows; the library calls the exchange hook wherever the reference
+exchanges a field, the hook packs the strip's edge rows on the device
+(suhmo_level_pack_rows), hands them to a transport, and unpacks the neighbour's rows into
+the ghost rows.  Transports:
+  * TorchDistTransport -- torch.distributed P2P (backend "nccl" = RCCL over xGMI on the
+    GPU box, "gloo" in CPU tests); tensors are plain device buffers, plumbing only.
+  * ThreadTransport    -- N "ranks" as threads of one process (tests on a 1-GPU box).
+No collective is on the data path except the 8-byte MAX all-reduce of the residual norm.
+"""
+import ctypes as C
+import threading
+
+from . import capi
+from .capi import check
+
+
+class StripExchanger:
+    """Owns the hook closures for one level (keep a reference alive as long as the level)."""
+
+    def __init__(self, level, transport, rank, world, periodic_y):
+        self.level, self.tr, self.rank, self.world = level, transport, rank, world
+        self.lo = rank - 1 if rank > 0 else (world - 1 if periodic_y else None)
+        self.hi = rank + 1 if rank < world - 1 else (0 if periodic_y else None)
+        self._bufs = {}
+        self._ex = capi.EXCHANGE_FN(self._exchange)
+        self._ar = capi.ALLREDUCE_FN(self._allreduce)
+        check(capi.lib().suhmo_level_set_hooks(level.h, self._ex, self._ar, None))
+        self.calls = 0
+
+    def _geom(self, depth):
+        g = [C.c_int() for _ in range(5)]
+        check(capi.lib().suhmo_level_halo_info(self.level.h, depth, *[C.byref(x) for x in g]))
+        rows, _, _, nx, ny = [x.value for x in g]
+        return min(rows, ny), nx
+
+    def _exchange(self, user, L, depth, field, stream):
+        try:
+            rows, nx = self._geom(depth)
+            n = rows * (nx + 1)
+            key = (depth, field)
+            if key not in self._bufs:
+                self._bufs[key] = [self.tr.alloc(n) for _ in range(4)]   # send lo/hi, recv lo/hi
+            slo, shi, rlo, rhi = self._bufs[key]
+            lib, h, st = capi.lib(), self.level.h, C.c_void_p(stream)
+            if self.lo is not None:
+                check(lib.suhmo_level_pack_rows(h, depth, field, 0, rows, C.c_void_p(self.tr.ptr(slo)), st))
+            if self.hi is not None:
+                check(lib.suhmo_level_pack_rows(h, depth, field, 1, rows, C.c_void_p(self.tr.ptr(shi)), st))
+            self.tr.sendrecv(self.rank, self.lo, self.hi, slo, shi, rlo, rhi, (depth, field, self.calls))
+            if self.lo is not None:
+                check(lib.suhmo_level_unpack_rows(h, depth, field, 0, rows, C.c_void_p(self.tr.ptr(rlo)), st))
+            if self.hi is not None:
+                check(lib.suhmo_level_unpack_rows(h, depth, field, 1, rows, C.c_void_p(self.tr.ptr(rhi)), st))
+            self.calls += 1
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return -9
+
+    def _allreduce(self, user, pval):
+        try:
+            pval[0] = self.tr.allreduce_max(self.rank, float(pval[0]))
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return -9
+
+    def exchange_static(self):
+        """halo rows of the caller-provided coefficient fields (depth 0)"""
+        from . import level as lv
+        for f in (lv.F_RHS, lv.F_ACOEF, lv.F_B, lv.F_PI, lv.F_ZB, lv.F_MASK, lv.F_BX, lv.F_BY):
+            check(capi.lib().suhmo_level_exchange(self.level.h, 0, f, self.level.stream))
+
+
+class TorchDistTransport:
+    """torch.distributed point-to-point; buffers are torch tensors on `device`."""
+
+    def __init__(self, dist, device):
+        import torch
+        self.torch, self.dist, self.device = torch, dist, device
+
+    def alloc(self, n):
+        return self.torch.empty(n, dtype=self.torch.float64, device=self.device)
+
+    def ptr(self, t):
+        return t.data_ptr()
+
+    def sendrecv(self, rank, lo, hi, slo, shi, rlo, rhi, tag):
+        d, ops = self.dist, []
+        # order matters when lo == hi (2 ranks, periodic): to-hi before to-lo, from-lo before from-hi
+        if hi is not None:
+            ops.append(d.P2POp(d.isend, shi, hi))
+        if lo is not None:
+            ops.append(d.P2POp(d.isend, slo, lo))
+        if lo is not None:
+            ops.append(d.P2POp(d.irecv, rlo, lo))
+        if hi is not None:
+            ops.append(d.P2POp(d.irecv, rhi, hi))
+        if ops:
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+
+    def allreduce_max(self, rank, v):
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+class ThreadTransport:
+    """N ranks = N threads of one process sharing one GPU (test harness).  Buffers are raw
+    device allocations made through torch-free HIP calls of the library's own canvases: we
+    borrow pinned staging through ctypes hipMalloc."""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.box = {}
+        self.vals = [0.0] * world
+        self._hip = C.CDLL("libamdhip64.so")
+        self._hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self._hip.hipDeviceSynchronize.argtypes = []
+
+    def alloc(self, n):
+        p = C.c_void_p()
+        assert self._hip.hipMalloc(C.byref(p), n * 8) == 0
+        return (p.value, n)
+
+    def ptr(self, b):
+        return b[0]
+
+    def sendrecv(self, rank, lo, hi, slo, shi, rlo, rhi, tag):
+        self._hip.hipDeviceSynchronize()
+        self.box[(rank, "lo")] = slo
+        self.box[(rank, "hi")] = shi
+        self.barrier.wait()
+        if lo is not None:   # my lo ghosts <- lo neighbour's top rows
+            src = self.box[(lo, "hi")]
+            assert self._hip.hipMemcpy(C.c_void_p(rlo[0]), C.c_void_p(src[0]), rlo[1] * 8, 3) == 0
+        if hi is not None:
+            src = self.box[(hi, "lo")]
+            assert self._hip.hipMemcpy(C.c_void_p(rhi[0]), C.c_void_p(src[0]), rhi[1] * 8, 3) == 0
+        self._hip.hipDeviceSynchronize()
+        self.barrier.wait()
+
+    def allreduce_max(self, rank, v):
+        self.vals[rank] = v
+        self.barrier.wait()
+        m = max(self.vals)
+        self.barrier.wait()
+        return m
+
+
+def attach(level, dist, rank, world, periodic_y=False):
+    """bench.py / production entry: couple this rank's strip to its neighbours over
+    torch.distributed (nccl backend = RCCL).  Returns the exchanger (keep it alive)."""
+    import torch
+    tr = TorchDistTransport(dist, torch.device("cuda", torch.cuda.current_device()))
+    ex = StripExchanger(level, tr, rank, world, periodic_y)
+    level._exchanger = ex
+    ex.exchange_static()
+    return ex

@@ -1,0 +1,140 @@
+"""Multi-rank path on a 1-GPU box: the level is cut into row strips, each strip is driven by
+its own thread ("rank") through the same C-ABI + exchange hooks bench.py uses with RCCL,
+and the gathered result must equal the single-level result (and hence the oracle) BIT FOR
+BIT -- GSRB is colour-Jacobi, so the partition must not change a single bit."""
+import threading
+
+import numpy as np
+import pytest
+
+from suhmo_amd import synthetic as sy
+
+pytestmark = pytest.mark.gpu
+
+
+def split_fields(f, j0, ny):
+    s = dict(nx=f["nx"], ny=ny, dx=f["dx"], dy=f["dy"])
+    for k in ("phi", "rhs", "aCoef"):
+        s[k] = f[k][j0:j0 + ny]
+    for k in ("B", "Pi", "zb", "mask"):
+        s[k] = f[k][j0:j0 + ny + 2]
+    if "bx" in f:
+        s["bx"] = f["bx"][j0:j0 + ny]
+        s["by"] = f["by"][j0:j0 + ny + 1]
+    return s
+
+
+def wrap_ghosts(f, bc):
+    """periodic directions: caller-side ghost data must be the periodic image (what Chombo's
+    exchange would have put there), otherwise 'one box' and 'several ranks' see different input"""
+    for k in ("B", "Pi", "zb", "mask"):
+        a = f[k]
+        if bc["periodic"][1]:
+            a[0, :], a[-1, :] = a[-2, :].copy(), a[1, :].copy()
+        if bc["periodic"][0]:
+            a[:, 0], a[:, -1] = a[:, -2].copy(), a[:, 1].copy()
+    if "by" in f and bc["periodic"][1]:
+        f["by"][-1, :] = f["by"][0, :]        # the same physical face
+    if "bx" in f and bc["periodic"][0]:
+        f["bx"][:, -1] = f["bx"][:, 0]
+    return f
+
+
+def run_strips(world, f, bc, ph, alpha, beta, body, halo=4, max_box=32):
+    """body(level, rank) runs on every rank-thread; returns list of per-rank results"""
+    from suhmo_amd import level, multigpu
+    ny_tot = f["ny"]
+    assert ny_tot % world == 0
+    ny = ny_tot // world
+    tr = multigpu.ThreadTransport(world)
+    out, err = [None] * world, []
+
+    def worker(rank):
+        try:
+            j0 = rank * ny
+            G = level.HipLevel(f["nx"], ny, f["dx"], f["dy"], bc, ph, alpha, beta, max_box, j0=j0,
+                               ny_global=ny_tot, halo_rows=halo)
+            G.set_inputs(split_fields(f, j0, ny))
+            ex = multigpu.StripExchanger(G, tr, rank, world, bool(bc["periodic"][1]))
+            ex.exchange_static()
+            out[rank] = body(G, rank)
+            G.synchronize()
+        except Exception as e:  # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            err.append(e)
+            tr.barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not err, err
+    return out
+
+
+def single(f, bc, ph, alpha, beta, body, max_box=32):
+    from suhmo_amd import level
+    G = level.HipLevel(f["nx"], f["ny"], f["dx"], f["dy"], bc, ph, alpha, beta, max_box)
+    G.set_inputs(f)
+    return body(G, 0)
+
+
+CASES = [
+    ("random-2ranks", lambda: sy.random_fields(128, 128, seed=31), sy.RANDOM_BC, sy.RANDOM_PHYS, 0.5, -1.0, 2),
+    ("random-yperiodic-2ranks", lambda: sy.random_fields(128, 128, seed=32), sy.CONV_BC, sy.RANDOM_PHYS, 0.0, -1.0, 2),
+    ("random-3ranks", lambda: sy.random_fields(192, 192, seed=33), sy.RANDOM_BC, sy.RANDOM_PHYS, 0.0, -1.0, 3),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_strips_gsrb_and_operators(case, variant, monkeypatch):
+    from suhmo_amd import level as lv
+    monkeypatch.setenv("SUHMO_GSRB_VARIANT", str(variant))
+    monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "1")
+    _, mk, bc, ph, alpha, beta, world = case
+    f = wrap_ghosts(mk(), bc)
+
+    def body(G, rank):
+        G.gsrb(3)
+        phi = G.get(lv.F_PHI)
+        G.residual()
+        res = G.get(lv.F_RES)
+        G.update_operator()
+        return phi, res, G.get(lv.F_BX), G.get(lv.F_BY), G.norm(lv.F_RES, 0)
+
+    ref = single(f, bc, ph, alpha, beta, body)
+    parts = run_strips(world, f, bc, ph, alpha, beta, body)
+    assert np.array_equal(np.vstack([p[0] for p in parts]), ref[0])
+    assert np.array_equal(np.vstack([p[1] for p in parts]), ref[1])
+    assert np.array_equal(np.vstack([p[2] for p in parts]), ref[2])
+    by = np.vstack([p[3][:-1] for p in parts] + [parts[-1][3][-1:]])
+    assert np.array_equal(by, ref[3])
+    assert all(p[4] == ref[4] for p in parts)       # MAX all-reduce of the norm
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_strips_vcycle_and_solve(world, oracle):
+    from suhmo_amd import level as lv
+    f = sy.shmip_fields(256, 256)
+    bc, ph = sy.A3_BC, sy.A3_PHYS
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-10, norm_thresh=1e-13, max_iter=4, imin=4)
+
+    def body(G, rank):
+        G.build_mg_coefficients()
+        G.vcycle(sp)
+        p1 = G.get(lv.F_PHI)
+        n, hist = G.solve(sp)
+        return p1, G.get(lv.F_PHI), n, hist, G.ndepth
+
+    parts = run_strips(world, f, bc, ph, 0.0, -1.0, body, max_box=64)
+    O = oracle.OracleLevel(256, 256, f["dx"], f["dy"], bc, ph, 0.0, -1.0, 64, 4)
+    O.set_inputs(f)
+    O.build_mg_coefficients()
+    assert parts[0][4] == O.ndepth
+    O.vcycle(sp)
+    assert np.array_equal(np.vstack([p[0] for p in parts]), O.get(oracle.F_PHI))
+    n, hist = O.solve(sp)
+    assert all(p[2] == n for p in parts)
+    assert np.array_equal(parts[0][3], hist)
+    assert np.array_equal(np.vstack([p[1] for p in parts]), O.get(oracle.F_PHI))
