@@ -1,0 +1,214 @@
+// VCAMRNonLinearPoissonOpHIP.cpp -- see the header.  Plain C++ (g++), links libsuhmo_hip.so.
+#include "VCAMRNonLinearPoissonOpHIP.H"
+#include <cmath>
+#include <string>
+
+namespace suhmo_host {
+
+static void chk(int rc, const char *what)
+{
+    if (rc != 0) {
+        std::string m = std::string(what) + ": " + suhmo_last_error();
+        MayDay::Error(m.c_str());       // the reference's error channel (process abort)
+    }
+}
+
+HeadSolverParameters::HeadSolverParameters(int a_cur_step, bool a_bcoeff_otf)
+{
+    num_smooth = 4; num_bottom = 16; max_iter = 100; iter_min = 2; imin = 5;      // AmrHydro.cpp:737-743,762
+    eps = 1.0e-7; hang = 0.01; norm_thresh = 1.0e-7;
+    if (a_cur_step < 50) { num_bottom = 10; eps = 1.0e-10; hang = 0.0001; imin = 20; }  // :744-754
+    bcoeff_otf = a_bcoeff_otf ? 1 : 0; max_depth = -1;
+}
+
+VCAMRNonLinearPoissonOpHIPFactory::VCAMRNonLinearPoissonOpHIPFactory() : m_level(nullptr), m_update_operator(true) {}
+VCAMRNonLinearPoissonOpHIPFactory::~VCAMRNonLinearPoissonOpHIPFactory() { if (m_level) suhmo_level_destroy(m_level); }
+
+void VCAMRNonLinearPoissonOpHIPFactory::define(const ProblemDomain &a_dom, const DisjointBoxLayout &a_grids,
+                                               const RealVect &a_dx, const suhmo_bc_t &a_bc, const Real &a_alpha,
+                                               const LevelData<FArrayBox> &a_aCoef, const Real &a_beta,
+                                               const LevelData<FluxBox> &a_bCoef, const suhmo_phys_t &a_phys,
+                                               const LevelData<FArrayBox> &a_B, const LevelData<FArrayBox> &a_Pi,
+                                               const LevelData<FArrayBox> &a_zb, const LevelData<FArrayBox> &a_iceMask,
+                                               bool a_update_operator, int a_device)
+{
+    if (m_level) { suhmo_level_destroy(m_level); m_level = nullptr; m_ops.clear(); m_grids.clear(); }
+    suhmo_level_desc_t d;
+    d.nx = a_dom.dom.size(0); d.ny = a_dom.dom.size(1); d.j0 = 0; d.ny_global = d.ny;
+    d.dx = a_dx[0]; d.dy = a_dx[1];
+    std::vector<int> boxes;
+    for (int k = 0; k < a_grids.size(); k++) { const Box &b = a_grids[k]; boxes.insert(boxes.end(), {b.lo[0], b.lo[1], b.hi[0], b.hi[1]}); }
+    d.nbox = a_grids.size(); d.boxes = boxes.data(); d.max_box = 0;
+    d.alpha = a_alpha; d.beta = a_beta; d.bc = a_bc; d.phys = a_phys; d.device = a_device; d.halo_rows = 1;
+    chk(suhmo_level_create(&m_level, &d), "VCAMRNonLinearPoissonOpHIPFactory::define");
+    m_update_operator = a_update_operator;
+    int nd = suhmo_level_num_depths(m_level);
+    for (int dep = 0; dep < nd; dep++) m_grids.push_back(dep == 0 ? a_grids : a_grids.coarsened(1 << dep));
+    m_ops.resize(nd);
+    for (int dep = 0; dep < nd; dep++) m_ops[dep].reset(new VCAMRNonLinearPoissonOpHIP(this, dep));
+    VCAMRNonLinearPoissonOpHIP &op0 = *m_ops[0];
+    op0.put(SUHMO_F_ACOEF, a_aCoef, 0);
+    op0.put(SUHMO_F_B, a_B, 0, true); op0.put(SUHMO_F_PI, a_Pi, 0, true);
+    op0.put(SUHMO_F_ZB, a_zb, 0, true); op0.put(SUHMO_F_MASK, a_iceMask, 0, true);
+    for (int k = 0; k < a_bCoef.size(); k++)
+        for (int dir = 0; dir < 2; dir++) {
+            const FArrayBox &f = a_bCoef[k][dir];
+            chk(suhmo_level_put_box(m_level, 0, dir == 0 ? SUHMO_F_BX : SUHMO_F_BY, k, f.dataPtr(), f.box().lo[0], f.box().lo[1],
+                                    f.box().hi[0], f.box().hi[1], 0, nullptr), "put bCoef");
+        }
+    chk(suhmo_level_build_mg_coefficients(m_level, nullptr), "MGnewOp coefficient coarsening");
+}
+
+int VCAMRNonLinearPoissonOpHIPFactory::numDepths() const { return m_level ? suhmo_level_num_depths(m_level) : 0; }
+
+VCAMRNonLinearPoissonOpHIP *VCAMRNonLinearPoissonOpHIPFactory::MGnewOp(const ProblemDomain &, int a_depth, bool)
+{
+    if (a_depth < 0 || a_depth >= numDepths()) return nullptr;      // !coarsenable(2^depth * s_maxCoarse)
+    return m_ops[a_depth].get();
+}
+
+int VCAMRNonLinearPoissonOpHIPFactory::solve(LevelData<FArrayBox> &a_phi, const LevelData<FArrayBox> &a_rhs,
+                                             const HeadSolverParameters &a_sp, std::vector<Real> *a_hist)
+{
+    VCAMRNonLinearPoissonOpHIP &op = *m_ops[0];
+    op.put(SUHMO_F_PHI, a_phi, 0);
+    op.put(SUHMO_F_RHS, a_rhs, 0);
+    std::vector<Real> hist(a_sp.max_iter + 2, 0.0);
+    int iters = 0;
+    chk(suhmo_level_solve(m_level, &a_sp, &iters, hist.data(), nullptr), "AMRFASMultiGrid::solve");
+    op.get(SUHMO_F_PHI, a_phi, 0);
+    if (a_hist) a_hist->assign(hist.begin(), hist.begin() + iters + 1);
+    return iters;
+}
+
+// ---------------------------------------------------------------- operator
+void VCAMRNonLinearPoissonOpHIP::put(int field, const LevelData<FArrayBox> &ld, int depth, bool domainGhosts)
+{
+    for (int k = 0; k < ld.size(); k++) {
+        const FArrayBox &f = ld[k];
+        chk(suhmo_level_put_box(m_factory->m_level, depth, field, k, f.dataPtr(), f.box().lo[0], f.box().lo[1],
+                                f.box().hi[0], f.box().hi[1], domainGhosts ? 1 : 0, nullptr), "put_box");
+    }
+}
+void VCAMRNonLinearPoissonOpHIP::get(int field, LevelData<FArrayBox> &ld, int depth)
+{
+    for (int k = 0; k < ld.size(); k++) {
+        FArrayBox &f = ld[k];
+        chk(suhmo_level_get_box(m_factory->m_level, depth, field, k, f.dataPtr(), f.box().lo[0], f.box().lo[1],
+                                f.box().hi[0], f.box().hi[1], nullptr), "get_box");
+    }
+}
+
+void VCAMRNonLinearPoissonOpHIP::levelGSRB(LevelData<FArrayBox> &a_phi, const LevelData<FArrayBox> &a_rhs, int, int, int a_depth)
+{
+    put(SUHMO_F_PHI, a_phi, a_depth); put(SUHMO_F_RHS, a_rhs, a_depth);
+    chk(suhmo_level_gsrb(m_factory->m_level, a_depth, 1, nullptr), "levelGSRB");
+    get(SUHMO_F_PHI, a_phi, a_depth);
+}
+void VCAMRNonLinearPoissonOpHIP::relax(LevelData<FArrayBox> &a_e, const LevelData<FArrayBox> &a_residual, int a_iterations, int, int a_depth)
+{
+    put(SUHMO_F_PHI, a_e, a_depth); put(SUHMO_F_RHS, a_residual, a_depth);
+    chk(suhmo_level_gsrb(m_factory->m_level, a_depth, a_iterations, nullptr), "relax");   // s_relaxMode 1 only
+    get(SUHMO_F_PHI, a_e, a_depth);
+}
+void VCAMRNonLinearPoissonOpHIP::applyOpI(LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_phi, bool a_homogeneous)
+{
+    put(SUHMO_F_PHI, a_phi, m_depth);
+    chk(suhmo_level_apply_op(m_factory->m_level, m_depth, a_homogeneous ? 1 : 0, nullptr), "applyOpI");
+    get(SUHMO_F_LPHI, a_lhs, m_depth);
+    // the reference leaves phi's ghosts filled (it const-casts a_phi, :278); mirror that
+    chk(suhmo_level_fill_ghosts(m_factory->m_level, m_depth, SUHMO_F_PHI, a_homogeneous ? 1 : 0, nullptr), "BC");
+    get(SUHMO_F_PHI, const_cast<LevelData<FArrayBox> &>(a_phi), m_depth);
+}
+void VCAMRNonLinearPoissonOpHIP::applyOpMg(LevelData<FArrayBox> &a_lhs, LevelData<FArrayBox> &a_phi, LevelData<FArrayBox> *a_phiCoarse, bool a_homogeneous)
+{
+    if (a_phiCoarse != nullptr) MayDay::Abort("VCAMRNonLinearPoissonOpHIP::applyOpMg: coarse-fine interpolation not built yet");
+    applyOpI(a_lhs, a_phi, a_homogeneous);
+}
+void VCAMRNonLinearPoissonOpHIP::residualI(LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_phi,
+                                           const LevelData<FArrayBox> &a_rhs, bool a_homogeneous)
+{
+    if (a_homogeneous) MayDay::Abort("VCAMRNonLinearPoissonOp::residualI homogeneous");            // :107-109
+    put(SUHMO_F_PHI, a_phi, m_depth); put(SUHMO_F_RHS, a_rhs, m_depth);
+    chk(suhmo_level_residual(m_factory->m_level, m_depth, nullptr), "residualI");
+    get(SUHMO_F_RES, a_lhs, m_depth);
+}
+void VCAMRNonLinearPoissonOpHIP::restrictResidual(LevelData<FArrayBox> &a_resCoarse, LevelData<FArrayBox> &a_phiFine,
+                                                  const LevelData<FArrayBox> *a_phiCoarse, const LevelData<FArrayBox> &a_rhsFine, bool homogeneous)
+{
+    if (homogeneous) MayDay::Abort("VCAMRNonLinearPoissonOp::restrictResidual homogeneous");       // :391-393
+    if (a_phiCoarse != nullptr) MayDay::Abort("VCAMRNonLinearPoissonOpHIP::restrictResidual: coarse-fine interpolation not built yet");
+    put(SUHMO_F_PHI, a_phiFine, m_depth); put(SUHMO_F_RHS, a_rhsFine, m_depth);
+    chk(suhmo_level_restrict_residual(m_factory->m_level, m_depth, nullptr), "restrictResidual");
+    get(SUHMO_F_RES, a_resCoarse, m_depth + 1);
+}
+void VCAMRNonLinearPoissonOpHIP::restrictR(LevelData<FArrayBox> &a_phiCoarse, const LevelData<FArrayBox> &a_phiFine)
+{
+    put(SUHMO_F_PHI, a_phiFine, m_depth);
+    for (int k = 0; k < a_phiCoarse.size(); k++) a_phiCoarse[k].setVal(0.0);                      // :365
+    chk(suhmo_level_restrict_r(m_factory->m_level, m_depth, nullptr), "restrictR");
+    // valid cells only (the coarse ghosts stay zero as in the reference)
+    LevelData<FArrayBox> tmp(a_phiCoarse.disjointBoxLayout(), 1, 0);
+    get(SUHMO_F_PHI, tmp, m_depth + 1);
+    for (int k = 0; k < tmp.size(); k++) {
+        const Box &b = tmp[k].box();
+        for (int j = b.lo[1]; j <= b.hi[1]; j++) for (int i = b.lo[0]; i <= b.hi[0]; i++) a_phiCoarse[k](i, j) = tmp[k](i, j);
+    }
+}
+void VCAMRNonLinearPoissonOpHIP::prolongIncrement(LevelData<FArrayBox> &a_phiThisLevel, const LevelData<FArrayBox> &a_correctCoarse)
+{
+    put(SUHMO_F_PHI, a_phiThisLevel, m_depth); put(SUHMO_F_CORR, a_correctCoarse, m_depth + 1);
+    chk(suhmo_level_prolong_increment(m_factory->m_level, m_depth, nullptr), "prolongIncrement");
+    LevelData<FArrayBox> tmp(a_phiThisLevel.disjointBoxLayout(), 1, 0);
+    get(SUHMO_F_PHI, tmp, m_depth);
+    for (int k = 0; k < tmp.size(); k++) {
+        const Box &b = tmp[k].box();
+        for (int j = b.lo[1]; j <= b.hi[1]; j++) for (int i = b.lo[0]; i <= b.hi[0]; i++) a_phiThisLevel[k](i, j) = tmp[k](i, j);
+    }
+}
+void VCAMRNonLinearPoissonOpHIP::UpdateOperator(const LevelData<FArrayBox> &a_phi, const LevelData<FArrayBox> *a_phicoarsePtr, int a_depth, int, bool a_homogeneous)
+{
+    if (a_homogeneous) MayDay::Abort("VCAMRNonLinearPoissonOp::UpdateOperator homogeneous");       // :42-44
+    if (a_phicoarsePtr != nullptr) MayDay::Abort("VCAMRNonLinearPoissonOpHIP::UpdateOperator: coarser AMR level not built yet");
+    put(SUHMO_F_PHI, a_phi, a_depth);
+    chk(suhmo_level_update_operator(m_factory->m_level, a_depth, nullptr), "UpdateOperator");
+}
+void VCAMRNonLinearPoissonOpHIP::AverageOperator(const VCAMRNonLinearPoissonOpHIP &, int a_depth)
+{
+    chk(suhmo_level_average_operator(m_factory->m_level, a_depth, nullptr), "AverageOperator");
+}
+void VCAMRNonLinearPoissonOpHIP::getBCoef(LevelData<FluxBox> &a_bCoef)
+{
+    for (int k = 0; k < a_bCoef.size(); k++)
+        for (int dir = 0; dir < 2; dir++) {
+            FArrayBox &f = a_bCoef[k][dir];
+            chk(suhmo_level_get_box(m_factory->m_level, m_depth, dir == 0 ? SUHMO_F_BX : SUHMO_F_BY, k, f.dataPtr(), f.box().lo[0],
+                                    f.box().lo[1], f.box().hi[0], f.box().hi[1], nullptr), "get bCoef");
+        }
+}
+Real VCAMRNonLinearPoissonOpHIP::norm(const LevelData<FArrayBox> &a_x, int a_ord)
+{
+    put(SUHMO_F_RES, a_x, m_depth);
+    double r = 0.0;
+    chk(suhmo_level_norm(m_factory->m_level, m_depth, SUHMO_F_RES, a_ord, &r, nullptr), "norm");
+    return r;
+}
+void VCAMRNonLinearPoissonOpHIP::create(LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_rhs)
+{ a_lhs.define(a_rhs.disjointBoxLayout(), 1, a_rhs.ghost()); }
+void VCAMRNonLinearPoissonOpHIP::createCoarser(LevelData<FArrayBox> &a_coarse, const LevelData<FArrayBox> &a_fine, bool)
+{ a_coarse.define(m_factory->m_grids[m_depth + 1], 1, a_fine.ghost()); }                          // AMRNL...cpp:753-766
+void VCAMRNonLinearPoissonOpHIP::assign(LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_rhs)
+{ axby(a_lhs, a_rhs, a_rhs, 1.0, 0.0); }
+void VCAMRNonLinearPoissonOpHIP::incr(LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_x, Real a_scale)
+{ axby(a_lhs, a_lhs, a_x, 1.0, a_scale); }
+void VCAMRNonLinearPoissonOpHIP::axby(LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_x, const LevelData<FArrayBox> &a_y, Real a, Real b)
+{
+    for (int k = 0; k < a_lhs.size(); k++) {
+        const Box &v = a_lhs.disjointBoxLayout()[k];
+        for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++)
+            a_lhs[k](i, j) = (b == 0.0) ? a * a_x[k](i, j) : a * a_x[k](i, j) + b * a_y[k](i, j);
+    }
+}
+void VCAMRNonLinearPoissonOpHIP::setToZero(LevelData<FArrayBox> &a_lhs) { for (int k = 0; k < a_lhs.size(); k++) a_lhs[k].setVal(0.0); }
+
+} // namespace suhmo_host

@@ -1,0 +1,145 @@
+// test_mirror.cpp -- drives the C++ host mirror (suhmo_amd/host) exactly the way Chombo's
+// multigrid drives VCAMRNonLinearPoissonOp (MGnewOp, relax, restrictResidual, restrictR,
+// applyOpMg, prolongIncrement, UpdateOperator, AverageOperator, norm, solve) on box-decomposed
+// LevelData, and checks every result BITWISE against the CPU oracle (test infrastructure).
+// Built and run by tests/test_gpu_host_mirror.py on the GPU box.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../suhmo_amd/host/VCAMRNonLinearPoissonOpHIP.H"
+#include "../../oracle/level_shim.h"
+
+using namespace suhmo_host;
+
+static int g_fail = 0;
+#define CHECK(cond, msg) do { if (!(cond)) { printf("FAIL: %s\n", msg); g_fail++; } else printf("ok:   %s\n", msg); } while (0)
+
+static double hashv(int k, double a, double b) { return a + (b - a) * (double)(((unsigned)k * 2654435761u) % 1000003u) / 1000003.0; }
+
+// LevelData (valid cells) <-> global row-major array
+static std::vector<double> to_global(const LevelData<FArrayBox> &ld, int nx, int ny, int g)
+{
+    std::vector<double> a((size_t)(nx + 2 * g) * (ny + 2 * g), 0.0);
+    for (int k = 0; k < ld.size(); k++) {
+        const Box &v = ld.disjointBoxLayout()[k];
+        Box b = v;
+        if (g) { if (v.lo[0] == 0) b.lo[0] -= 1; if (v.hi[0] == nx - 1) b.hi[0] += 1; if (v.lo[1] == 0) b.lo[1] -= 1; if (v.hi[1] == ny - 1) b.hi[1] += 1; }
+        for (int j = b.lo[1]; j <= b.hi[1]; j++)
+            for (int i = b.lo[0]; i <= b.hi[0]; i++)
+                if ((i >= 0 && i < nx) || (j >= 0 && j < ny))       // no corner ghosts
+                    a[(size_t)(j + g) * (nx + 2 * g) + (i + g)] = ld[k](i, j);
+    }
+    return a;
+}
+static bool same_valid(const LevelData<FArrayBox> &ld, const std::vector<double> &glob, int nx)
+{
+    for (int k = 0; k < ld.size(); k++) {
+        const Box &v = ld.disjointBoxLayout()[k];
+        for (int j = v.lo[1]; j <= v.hi[1]; j++)
+            for (int i = v.lo[0]; i <= v.hi[0]; i++) {
+                double a = ld[k](i, j), b = glob[(size_t)j * nx + i];
+                if (memcmp(&a, &b, 8) != 0) { printf("   mismatch at (%d,%d): %.17g vs %.17g\n", i, j, a, b); return false; }
+            }
+    }
+    return true;
+}
+
+int main()
+{
+    const int nx = 128, ny = 64, mb = 32;
+    const double dxv = 781.25, dyv = 312.5;
+    ProblemDomain dom; dom.dom = Box(0, 0, nx - 1, ny - 1); dom.periodic[0] = false; dom.periodic[1] = false;
+    std::vector<Box> bx;
+    for (int bj = 0; bj < ny / mb; bj++) for (int bi = 0; bi < nx / mb; bi++) bx.push_back(Box(bi * mb, bj * mb, bi * mb + mb - 1, bj * mb + mb - 1));
+    DisjointBoxLayout grids(bx, dom);
+    RealVect dx; dx[0] = dxv; dx[1] = dyv;
+
+    suhmo_bc_t bc; memset(&bc, 0, sizeof(bc));
+    bc.type[0][0] = 0; bc.type[0][1] = 1; bc.type[1][0] = 1; bc.type[1][1] = 1;       // A-suite BCs
+    suhmo_phys_t ph = {5e-25, 1e-3, 1.787e-6, 0.0, 1.0e4, 9800.0, 9.8, 0, 1, 0};
+
+    LevelData<FArrayBox> phi(grids, 1, 1), rhs(grids, 1, 0), aCoef(grids, 1, 0), B(grids, 1, 1), Pi(grids, 1, 1), zb(grids, 1, 1), mask(grids, 1, 1);
+    LevelData<FluxBox> bCoef(grids, 1, 0);
+    for (int k = 0; k < grids.size(); k++) {
+        const Box g = grids[k].grown(1);
+        for (int j = g.lo[1]; j <= g.hi[1]; j++)
+            for (int i = g.lo[0]; i <= g.hi[0]; i++) {
+                double x = (i + 0.5) * dxv;
+                double H = 6.0 * (std::sqrt(x + 5000.0) - std::sqrt(5000.0)) + 1.0; if (H < 0) H = 0;
+                B[k](i, j) = 0.01 * (1.0 + 0.4 * std::sin(0.37 * i) * std::cos(0.23 * j));
+                Pi[k](i, j) = 910.0 * 9.8 * H; zb[k](i, j) = 0.0; mask[k](i, j) = 1.0;
+                phi[k](i, j) = 101325.0 / 9800.0 + 1e-3 * hashv(i * 1000 + j, -1.0, 1.0);
+            }
+        const Box &v = grids[k];
+        for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++) { rhs[k](i, j) = 5.79e-9; aCoef[k](i, j) = 0.0; }
+    }
+
+    // ---- oracle twin
+    OrBC obc; memcpy(&obc, &bc, sizeof(obc));
+    OrPhys oph; memcpy(&oph, &ph, sizeof(oph));
+    OrLevel *O = or_level_create(nx, ny, dxv, dyv, mb, &obc, &oph, 0.0, -1.0, 2);
+    { auto g = to_global(phi, nx, ny, 0); or_level_set(O, 0, OR_F_PHI, g.data(), 0); }
+    { auto g = to_global(rhs, nx, ny, 0); or_level_set(O, 0, OR_F_RHS, g.data(), 0); }
+    { auto g = to_global(aCoef, nx, ny, 0); or_level_set(O, 0, OR_F_ACOEF, g.data(), 0); }
+    { auto g = to_global(B, nx, ny, 1); or_level_set(O, 0, OR_F_B, g.data(), 1); }
+    { auto g = to_global(Pi, nx, ny, 1); or_level_set(O, 0, OR_F_PI, g.data(), 1); }
+    { auto g = to_global(zb, nx, ny, 1); or_level_set(O, 0, OR_F_ZB, g.data(), 1); }
+    { auto g = to_global(mask, nx, ny, 1); or_level_set(O, 0, OR_F_MASK, g.data(), 1); }
+
+    // ---- factory / operators, as AmrHydro::SolveForHead_nl + AMRFASMultiGrid::define do
+    VCAMRNonLinearPoissonOpHIPFactory fac;
+    fac.define(dom, grids, dx, bc, 0.0, aCoef, -1.0, bCoef, ph, B, Pi, zb, mask, true);
+    CHECK(fac.numDepths() == or_level_num_depths(O), "MGnewOp depth rule: coarsenable(2^d * s_maxCoarse)");
+    CHECK(fac.MGnewOp(dom, fac.numDepths()) == nullptr, "MGnewOp returns NULL past the coarsest depth");
+    VCAMRNonLinearPoissonOpHIP *op = fac.AMRnewOp(dom);
+    VCAMRNonLinearPoissonOpHIP *opC = fac.MGnewOp(dom, 1);
+    std::vector<double> og((size_t)nx * ny), ogc((size_t)nx * ny / 4);
+
+    op->UpdateOperator(phi, nullptr, 0, 0, false);
+    or_level_update_operator(O, 0);
+    or_level_build_mg_coefficients(O);
+    opC->AverageOperator(*op, 1);
+
+    op->relax(phi, rhs, 4, 0, 0);
+    or_level_gsrb(O, 0, 4); or_level_get(O, 0, OR_F_PHI, og.data(), 0);
+    CHECK(same_valid(phi, og, nx), "relax(4) == oracle levelGSRB x4 (bitwise)");
+
+    LevelData<FArrayBox> res, resC, phiC, LphiC;
+    op->create(res, rhs); op->createCoarser(resC, rhs, false); op->createCoarser(phiC, phi, true); opC->create(LphiC, resC);
+    op->residualI(res, phi, rhs, false);
+    or_level_residual(O, 0); or_level_get(O, 0, OR_F_RES, og.data(), 0);
+    CHECK(same_valid(res, og, nx), "residualI == oracle");
+    CHECK(op->norm(res, 0) == or_level_norm(O, 0, OR_F_RES, 0), "norm(res, 0) == oracle max-norm");
+
+    op->restrictResidual(resC, phi, nullptr, rhs, false);
+    or_level_restrict_residual(O, 0); or_level_get(O, 1, OR_F_RES, ogc.data(), 0);
+    CHECK(same_valid(resC, ogc, nx / 2), "restrictResidual == oracle");
+    op->restrictR(phiC, phi);
+    or_level_restrict_r(O, 0); or_level_get(O, 1, OR_F_PHI, ogc.data(), 0);
+    CHECK(same_valid(phiC, ogc, nx / 2), "restrictR == oracle");
+    opC->applyOpMg(LphiC, phiC, nullptr, false);
+    or_level_apply_op(O, 1, 0); or_level_get(O, 1, OR_F_LPHI, ogc.data(), 0);
+    CHECK(same_valid(LphiC, ogc, nx / 2), "applyOpMg on depth 1 == oracle");
+
+    // prolongIncrement with the restricted phi as 'correction'
+    { auto g = to_global(phiC, nx / 2, ny / 2, 0); or_level_prolong_increment(O, 0, g.data()); }
+    op->prolongIncrement(phi, phiC);
+    or_level_get(O, 0, OR_F_PHI, og.data(), 0);
+    CHECK(same_valid(phi, og, nx), "prolongIncrement == oracle");
+
+    // whole solve, parameters of SolveForHead_nl for m_cur_step >= 50
+    HeadSolverParameters sp(100, true);
+    OrSolverParams osp; memcpy(&osp, static_cast<suhmo_solver_params_t *>(&sp), sizeof(osp));
+    std::vector<double> hist, ohist(sp.max_iter + 2);
+    int n = fac.solve(phi, rhs, sp, &hist);
+    int on = or_level_solve(O, &osp, ohist.data());
+    or_level_get(O, 0, OR_F_PHI, og.data(), 0);
+    CHECK(n == on, "solve: same number of V-cycles as the oracle");
+    CHECK(same_valid(phi, og, nx), "solve: converged head == oracle (bitwise)");
+    printf("V-cycles %d, residual %.3e -> %.3e\n", n, hist.front(), hist.back());
+
+    or_level_destroy(O);
+    printf(g_fail ? "RESULT: FAIL (%d)\n" : "RESULT: PASS\n", g_fail);
+    return g_fail ? 1 : 0;
+}
