@@ -37,3 +37,37 @@ def test_host_mirror_matches_oracle():
     out = p.stdout.decode()
     print(out)
     assert p.returncode == 0 and "RESULT: PASS" in out, out
+
+
+EXE_B2 = os.path.join(ROOT, "tests", "host_cpp", "test_b2")
+
+
+def build_b2():
+    from suhmo_amd import capi
+    capi.build()
+    csrc = os.path.join(ROOT, "suhmo_amd", "csrc")
+    o = os.path.join(ROOT, "tests", "host_cpp", "suhmo_oracle.o")
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-ffp-contract=off", "-c", os.path.join(ROOT, "oracle", "suhmo_oracle.c"), "-o", o])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", os.path.join(ROOT, "tests", "host_cpp", "test_b2.cpp"), o,
+                           "-L" + csrc, "-lsuhmo_hip", "-Wl,-rpath," + csrc, "-lm", "-o", EXE_B2])
+
+
+def test_b2_symbols_exported_cpu():
+    """every per-box Fortran-ABI symbol of include/suhmo_chf.h is exported (link check, no GPU)"""
+    import re
+    build_b2()
+    hdr = open(os.path.join(ROOT, "include", "suhmo_chf.h")).read()
+    names = set(re.findall(r"^void ([a-z_0-9]+_)\(", hdr, flags=re.M))
+    assert len(names) == 18, names
+    out = subprocess.check_output(["nm", "-D", os.path.join(ROOT, "suhmo_amd", "csrc", "libsuhmo_hip.so")]).decode()
+    for n in names:
+        assert re.search(r" T %s$" % n, out, flags=re.M), n
+
+
+@pytest.mark.gpu
+def test_b2_per_box_kernels_match_oracle():
+    build_b2()
+    p = subprocess.run([EXE_B2], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = p.stdout.decode()
+    print(out)
+    assert p.returncode == 0 and "RESULT: PASS" in out, out
