@@ -140,6 +140,8 @@ struct suhmo_level {
     std::vector<ProfEv> prof;
     int gsrb_variant;           // kernel selection (see suhmo_gsrb.hip); env SUHMO_GSRB_VARIANT
     long fused_min_cells;       // auto mode: use the fused kernel from this many cells (env SUHMO_FUSED_MIN_CELLS)
+    int bcoef_fused;            // single-kernel WFlx_level (env SUHMO_BCOEF_FUSED, default 1)
+    int fused_nt;               // threads per workgroup of the fused kernel: 256 or 64 (env SUHMO_FUSED_NT)
     int fused_hc;               // rows per chunk of the fused kernel (0 = auto); env SUHMO_FUSED_HC
 };
 
@@ -149,4 +151,5 @@ void suhmo_set_error(const char *fmt, ...);
 #define ARG(cond) do { if (!(cond)) { suhmo_set_error("%s:%d bad argument: %s", __FILE__, __LINE__, #cond); return -1; } } while (0)
 
 double *suhmo_field(suhmo_level *L, int depth, int field);   // lazily allocates
+int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st);      // suhmo_level.hip
 int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, hipStream_t st);   // suhmo_gsrb.hip

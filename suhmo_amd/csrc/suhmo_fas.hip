@@ -46,8 +46,7 @@ extern "C" int suhmo_level_vcycle(suhmo_level_t *L, const suhmo_solver_params_t 
     int nd = eff_depths(L, sp), rc;
     if (sp->bcoeff_otf) {
         if ((rc = suhmo_level_update_operator(L, 0, s))) return rc;
-        for (int k = 1; k < nd; k++)
-            if ((rc = suhmo_level_average_operator(L, k, s))) return rc;
+        if ((rc = suhmo_average_operator_all(L, nd, (hipStream_t)s))) return rc;   // AverageOperator on every depth > 0
     }
     return fas_cycle(L, 0, sp, nd, s);
 }

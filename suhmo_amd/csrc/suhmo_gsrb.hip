@@ -81,11 +81,11 @@ __device__ __forceinline__ void copy_coef(RowCoef &d, const RowCoef &s)
     d.bx0 = s.bx0; d.bx1 = s.bx1; d.bx2 = s.bx2;
 }
 
-template <int K, bool HAS_ALPHA>
-__global__ __launch_bounds__(256, 2) void k_gsrb_fused(DV v, FP fp, const double *__restrict__ pin,
-                                                       double *__restrict__ pout, suhmo_phys_t ph, FusedGeom g)
+template <int K, bool HAS_ALPHA, int NT>
+__global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__restrict__ pin,
+                                                   double *__restrict__ pout, suhmo_phys_t ph, FusedGeom g)
 {
-    constexpr int NT = 256, LW = 2 * NT, R = 2 * K + 3;
+    constexpr int LW = 2 * NT, R = 2 * K + 3;
     __shared__ double lds[R * LW];
 
     // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs; give every XCD a
@@ -211,7 +211,7 @@ static bool fused_ok(const suhmo_level *L, const Depth &D, int K)
     return true;
 }
 
-template <int K>
+template <int K, int NT>
 static int launch_fused(suhmo_level *L, int depth, hipStream_t st)
 {
     Depth &D = L->d[depth];
@@ -221,7 +221,7 @@ static int launch_fused(suhmo_level *L, int depth, hipStream_t st)
         HIPCHK(hipMemsetAsync(D.phi_alt, 0, D.elems * sizeof(double), st));
     }
     FusedGeom g;
-    const int maxW = 512 - 4 * K;
+    const int maxW = 2 * NT - 4 * K;
     g.nstrips = (v.nx + maxW - 1) / maxW;
     g.W = 2 * ((v.nx + 2 * g.nstrips - 1) / (2 * g.nstrips));
     g.nstrips = (v.nx + g.W - 1) / g.W;
@@ -229,12 +229,12 @@ static int launch_fused(suhmo_level *L, int depth, hipStream_t st)
     // a partial second round costs a full one), but never shorter than 16K rows so that the
     // 4K-row pipeline fill stays small; measured on MI355X: profiles/r01_b_hc_sweep.log
     {
-        static int slots_k[3] = {0, 0, 0};
+        static int slots_k[3] = {0, 0, 0};     // per (K, NT) instantiation
         if (!slots_k[K]) {
             int nb = 0, ncu = 0, dev = 0;
             HIPCHK(hipGetDevice(&dev));
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gsrb_fused<K, false>, 256, 0));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gsrb_fused<K, false, NT>, NT, 0));
             slots_k[K] = (nb > 0 ? nb : 1) * (ncu > 0 ? ncu : 256);
         }
         int nch = slots_k[K] / g.nstrips;
@@ -252,9 +252,9 @@ static int launch_fused(suhmo_level *L, int depth, hipStream_t st)
     g.yhi = (v.ext[1] || selfper) ? v.ny - 1 + 2 * K : v.ny - 1;
     const double *pin = D.fp.f[SUHMO_F_PHI];
     if (v.alpha != 0.0)
-        hipLaunchKernelGGL((k_gsrb_fused<K, true>), dim3(g.ntiles), dim3(256), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+        hipLaunchKernelGGL((k_gsrb_fused<K, true, NT>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
     else
-        hipLaunchKernelGGL((k_gsrb_fused<K, false>), dim3(g.ntiles), dim3(256), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+        hipLaunchKernelGGL((k_gsrb_fused<K, false, NT>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
     std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
     return 0;
 }
@@ -293,7 +293,9 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, hipStream_t st)
                 int rc = L->ex(L->user, L, depth, SUHMO_F_PHI, (suhmo_stream_t)st);
                 if (rc) return rc;
             }
-            int rc = (K == 2) ? launch_fused<2>(L, depth, st) : launch_fused<1>(L, depth, st);
+            int rc;
+            if (L->fused_nt == 64) rc = (K == 2) ? launch_fused<2, 64>(L, depth, st) : launch_fused<1, 64>(L, depth, st);
+            else rc = (K == 2) ? launch_fused<2, 256>(L, depth, st) : launch_fused<1, 256>(L, depth, st);
             if (rc) return rc;
         }
         int done = K == 0 ? 1 : K;

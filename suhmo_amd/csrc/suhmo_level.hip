@@ -81,6 +81,10 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     L->ex = nullptr; L->ar = nullptr; L->user = nullptr; L->prof_on = 0; L->gsrb_variant = -1; L->fused_hc = 0;
     if (const char *e = getenv("SUHMO_GSRB_VARIANT")) L->gsrb_variant = atoi(e);
     if (const char *e = getenv("SUHMO_FUSED_HC")) L->fused_hc = atoi(e);
+    L->bcoef_fused = 1;
+    if (const char *e = getenv("SUHMO_BCOEF_FUSED")) L->bcoef_fused = atoi(e);
+    L->fused_nt = 256;
+    if (const char *e = getenv("SUHMO_FUSED_NT")) L->fused_nt = atoi(e);
     L->fused_min_cells = 2000000;
     if (const char *e = getenv("SUHMO_FUSED_MIN_CELLS")) L->fused_min_cells = atol(e);
     if (desc->boxes && desc->nbox > 0) {
@@ -653,21 +657,162 @@ __global__ __launch_bounds__(256) void k_bcoef_faces(DV v, FP fp, suhmo_phys_t p
     }
 }
 
+// ---- fused WFlx_level: one kernel = steps 1-4 above on a tile staged in LDS.
+// A block of 64 x 4 threads owns BT_X x BT_Y = 62 x 30 cells.  phi tile (halo 2, 66 x 34) and
+// the B / mask tiles (halo 1) are loaded up front (one exposure to HBM latency); then
+// cell-centred gradient on the Re range (halo 1 = 64 x 32: one lane per column, 8 rows per
+// thread, in registers) -> ghost gradients by linear extrapolation (periodic images and
+// exchanged halo rows are ordinary cells) -> Re (LDS, aliasing the dead phi tile) -> the
+// tile's W and S faces (+ the domain's E / N faces in the last tile column / row).
+// Every value comes from the same expressions as the four-kernel path (bitwise equal); halo
+// cells are recomputed instead of stored, so HBM sees phi, B, mask once and bx, by once.
+#define BT_X 62
+#define BT_Y 30
+__global__ __launch_bounds__(256) void k_bcoef_fused(DV v, FP fp, suhmo_phys_t ph, int hasMask)
+{
+    constexpr int PW = BT_X + 4, PH = BT_Y + 4;     // phi tile: cells [i0-2, i0+BT_X+1] x [j0-2, j0+BT_Y+1]
+    constexpr int RW = BT_X + 2, RH = BT_Y + 2;     // Re tile:  cells [i0-1, i0+BT_X]   x [j0-1, j0+BT_Y]
+    constexpr int NK = RH / 4;
+    __shared__ double sphi[PW * PH], sB[RW * RH], sM[RW * RH];
+    double *sre = sphi;                              // phi is dead once the gradients exist
+    const int i0 = blockIdx.x * BT_X, j0 = blockIdx.y * BT_Y;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const double *__restrict__ phi = fp.f[SUHMO_F_PHI], *__restrict__ Bf = fp.f[SUHMO_F_B], *__restrict__ mk = fp.f[SUHMO_F_MASK];
+    double *__restrict__ bxo = fp.f[SUHMO_F_BX], *__restrict__ byo = fp.f[SUHMO_F_BY];
+    const bool halo_lo = v.ext[0], halo_hi = v.ext[1], selfper_y = v.per[1] && !halo_lo && !halo_hi;
+    // a cell "exists" (has its own phi) inside the domain, as a periodic image, or in an exchanged halo row
+    auto xin = [&](int i) { return (i >= 0 && i < v.nx) || v.per[0]; };
+    auto yin = [&](int j) { return (j >= 0 && j < v.ny) || selfper_y || (j < 0 && halo_lo && j >= -v.gy) || (j >= v.ny && halo_hi && j < v.ny + v.gy); };
+    auto wrapx = [&](int i) { return v.per[0] ? (i < 0 ? i + v.nx : (i >= v.nx ? i - v.nx : i)) : i; };
+    auto wrapy = [&](int j) { return selfper_y ? (j < 0 ? j + v.ny : (j >= v.ny ? j - v.ny : j)) : j; };
+
+    // ---- phi tile.  Cells that do not exist get the physical-BC ghost of their interior
+    // neighbour (only the first ghost layer is used: face gradient of the boundary cell).
+    for (int lj = ty; lj < PH; lj += 4) {
+        const int j = j0 - 2 + lj;
+        const bool yi = yin(j);
+        for (int li = tx; li < PW; li += 64) {
+            const int i = i0 - 2 + li;
+            const bool xi = xin(i);
+            double val = 0.0;
+            if (xi && yi) val = phi[cidx(v, wrapx(i), wrapy(j))];
+            else if (yi && (i == -1 || i == v.nx)) {
+                int ic = i < 0 ? 0 : v.nx - 1, idx = cidx(v, ic, wrapy(j));
+                double c = phi[idx];
+                val = i < 0 ? phiW(v, phi, idx, ic, c, false) : phiE(v, phi, idx, ic, c, false);
+            } else if (xi && (j == -1 || j == v.ny)) {
+                int jc = j < 0 ? 0 : v.ny - 1, idx = cidx(v, wrapx(i), jc);
+                double c = phi[idx];
+                val = j < 0 ? phiS(v, phi, idx, jc, c, false) : phiN(v, phi, idx, jc, c, false);
+            }
+            sphi[lj * PW + li] = val;
+        }
+    }
+    // ---- B and mask on the Re range (stored ghosts included: caller data, src/AmrHydro.cpp:686-701)
+    const int i = i0 - 1 + tx;
+    const bool xi = xin(i);
+    double Br[NK];
+    bool hasB[NK];
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const int lj = ty + 4 * k, j = j0 - 1 + lj;
+        hasB[k] = i >= -1 && i <= v.nx && j >= -v.gy && j <= v.ny + v.gy - 1 && !((i < 0 || i >= v.nx) && (j < 0 || j >= v.ny));
+        double b = 0.0, m = 0.0;
+        if (hasB[k]) { int idx = cidx(v, i, j); b = Bf[idx]; m = mk[idx]; }
+        Br[k] = b;
+        sB[lj * RW + tx] = b; sM[lj * RW + tx] = m;
+    }
+    __syncthreads();
+    // cell-centred gradient of the cell at phi-tile position p (k_gradcc); (gi, gj) = its indices
+    auto gradcc = [&](int p, int gi, int gj, double &gx, double &gy) {
+        double c = sphi[p], w = sphi[p - 1], e = sphi[p + 1], s = sphi[p - PW], n = sphi[p + PW];
+        double gW = v.fdx * (c - w), gE = v.fdx * (e - c), gS = v.fdy * (c - s), gN = v.fdy * (n - c);
+        if (hasMask) {
+            int idx = cidx(v, wrapx(gi), wrapy(gj));
+            bool mc = mk[idx] < 1e-6;
+            if (mc || mk[idx - 1] < 1e-6) gW = 0.0;
+            if (mc || mk[idx + 1] < 1e-6) gE = 0.0;
+            if (mc || mk[idx - v.P] < 1e-6) gS = 0.0;
+            if (mc || mk[idx + v.P] < 1e-6) gN = 0.0;
+        }
+        gx = 0.5 * (gW + gE); gy = 0.5 * (gS + gN);
+    };
+    double rer[NK];
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const int lj = ty + 4 * k, j = j0 - 1 + lj;
+        const bool yi = yin(j);
+        const int p = (lj + 1) * PW + (tx + 1);
+        double gx = 0.0, gy = 0.0;
+        if (xi && yi) {
+            gradcc(p, i, j, gx, gy);
+        } else if (xi != yi) {
+            // first ghost layer on a non-periodic domain side: linear extrapolation of the two
+            // interior neighbours' gradients (k_grad_ghosts, util/ExtrapBCF.ChF:21-29)
+            int d = 0, di = 0, dj = 0;
+            if (!xi && (i == -1 || i == v.nx)) { di = i < 0 ? 1 : -1; d = di; }
+            else if (!yi && (j == -1 || j == v.ny)) { dj = j < 0 ? 1 : -1; d = dj * PW; }
+            if (d != 0) {
+                double g1x, g1y, g2x, g2y;
+                gradcc(p + d, i + di, j + dj, g1x, g1y);
+                gradcc(p + 2 * d, i + 2 * di, j + 2 * dj, g2x, g2y);
+                gx = 2.0 * g1x - g2x; gy = 2.0 * g1y - g2y;
+            }
+        }
+        // Re on the (ghosted) range (k_re)
+        double re = 0.0;
+        if (hasB[k]) {
+            double B = Br[k];
+            double sg = sqrt(gx * gx + gy * gy);
+            double discr = 1.0 + 4.0 * ph.omega * (B * B * B * ph.grav * sg) / (12.0 * ph.nu * ph.nu);
+            re = (-1.0 + sqrt(discr)) / (2.0 * ph.omega);
+        }
+        rer[k] = re;
+    }
+    __syncthreads();                                 // every lane is done reading the phi tile
+#pragma unroll
+    for (int k = 0; k < NK; k++) sre[(ty + 4 * k) * RW + tx] = rer[k];
+    __syncthreads();
+    // ---- faces (k_bcoef_faces): lane tx >= 1 owns cell column i (its W and S faces); the last tile
+    // column / row also owns the domain's E / N faces
+    const int nxt = (i0 + BT_X >= v.nx) ? v.nx - i0 + 1 : BT_X, nyt = (j0 + BT_Y >= v.ny) ? v.ny - j0 + 1 : BT_Y;
+    const int fx = tx - 1;                           // face column index inside the tile
+    if (fx >= 0 && fx < nxt) {
+        for (int fy = ty; fy < nyt; fy += 4) {
+            const int j = j0 + fy, idx = cidx(v, i, j), r = (fy + 1) * RW + tx;
+            if (j < v.ny)
+                bxo[idx] = bcoef_face(ph, sre[r], sre[r - 1], sB[r], sB[r - 1], sM[r], sM[r - 1], i == 0 || i == v.nx);
+            if (i < v.nx) {
+                int jg = j + v.j0;
+                byo[idx] = bcoef_face(ph, sre[r], sre[r - RW], sB[r], sB[r - RW], sM[r], sM[r - RW], jg == 0 || jg == v.nyg);
+            }
+        }
+    }
+}
+
 extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_stream_t s)
 {
     ARG(L); ARG(depth >= 0 && depth < L->ndepth);
     HIPCHK(hipSetDevice(L->device));
     hipStream_t st = (hipStream_t)s;
     Depth &D = L->d[depth];
-    if (!suhmo_field(L, depth, SUHMO_F_GRADX) || !suhmo_field(L, depth, SUHMO_F_GRADY) || !suhmo_field(L, depth, SUHMO_F_RE)) return -2;
     int rc = exchange_if_needed(L, depth, SUHMO_F_PHI, st); if (rc) return rc;
-    hipLaunchKernelGGL(k_gradcc, grid2d(D.v.nx, D.v.ny), BLK2D, 0, st, D.v, D.fp, L->ph.use_mask_gradients);
-    rc = exchange_if_needed(L, depth, SUHMO_F_GRADX, st); if (rc) return rc;
-    rc = exchange_if_needed(L, depth, SUHMO_F_GRADY, st); if (rc) return rc;
-    int n = 2 * D.v.ny + 2 * D.v.nx;
-    hipLaunchKernelGGL(k_grad_ghosts, dim3((n + 255) / 256), dim3(256), 0, st, D.v, D.fp.f[SUHMO_F_GRADX], D.fp.f[SUHMO_F_GRADY]);
-    hipLaunchKernelGGL(k_re, grid2d(D.v.nx + 2, D.v.ny + 2), BLK2D, 0, st, D.v, D.fp, L->ph);
-    hipLaunchKernelGGL(k_bcoef_faces, grid2d(D.v.nx + 1, D.v.ny + 1), BLK2D, 0, st, D.v, D.fp, L->ph);
+    // fused single-kernel path: needs >= 3 cells per direction (extrapolation sources inside every
+    // edge tile) and, on rank boundaries, 2 exchanged phi rows for the halo-row gradient
+    bool fused = L->bcoef_fused && D.v.nx >= 4 && D.v.ny >= 4 && (!(D.v.ext[0] || D.v.ext[1]) || (D.v.gy >= 2 && D.v.ny >= 2));
+    if (fused) {
+        dim3 grd((D.v.nx + BT_X - 1) / BT_X, (D.v.ny + BT_Y - 1) / BT_Y);   // the last tile column / row also owns the E / N faces
+        hipLaunchKernelGGL(k_bcoef_fused, grd, dim3(64, 4), 0, st, D.v, D.fp, L->ph, L->ph.use_mask_gradients);
+    } else {
+        if (!suhmo_field(L, depth, SUHMO_F_GRADX) || !suhmo_field(L, depth, SUHMO_F_GRADY) || !suhmo_field(L, depth, SUHMO_F_RE)) return -2;
+        hipLaunchKernelGGL(k_gradcc, grid2d(D.v.nx, D.v.ny), BLK2D, 0, st, D.v, D.fp, L->ph.use_mask_gradients);
+        rc = exchange_if_needed(L, depth, SUHMO_F_GRADX, st); if (rc) return rc;
+        rc = exchange_if_needed(L, depth, SUHMO_F_GRADY, st); if (rc) return rc;
+        int n = 2 * D.v.ny + 2 * D.v.nx;
+        hipLaunchKernelGGL(k_grad_ghosts, dim3((n + 255) / 256), dim3(256), 0, st, D.v, D.fp.f[SUHMO_F_GRADX], D.fp.f[SUHMO_F_GRADY]);
+        hipLaunchKernelGGL(k_re, grid2d(D.v.nx + 2, D.v.ny + 2), BLK2D, 0, st, D.v, D.fp, L->ph);
+        hipLaunchKernelGGL(k_bcoef_faces, grid2d(D.v.nx + 1, D.v.ny + 1), BLK2D, 0, st, D.v, D.fp, L->ph);
+    }
     HIPCHK(hipGetLastError());
     // strips: the fused relaxation recomputes halo rows, so it needs the coefficients there too
     rc = exchange_if_needed(L, depth, SUHMO_F_BX, st); if (rc) return rc;
@@ -695,6 +840,55 @@ __global__ void k_average_faces(DV vf, const double *__restrict__ bxf, const dou
         byc[cidx(vc, ic, jc)] = sm / (double)r;
     }
 }
+// All depths of AverageOperator in ONE pass over the depth-0 faces (the V-cycle refreshes every
+// depth right after UpdateOperator).  The reference's arithmetic is a sequential sum of the
+// r = 2^d collinear fine faces divided by r; the running sum of the first r/2 faces of a group IS
+// the (unscaled) depth d-1 sum, so one walk over 2^(nd-1) faces yields every depth bit for bit.
+struct AvgOut { double *bx[SUHMO_MAXDEPTH], *by[SUHMO_MAXDEPTH]; int P[SUHMO_MAXDEPTH]; int gy[SUHMO_MAXDEPTH]; };
+// x-faces: thread = (even fine column i, block of R = 2^(nd-1) rows); walks the rows
+__global__ __launch_bounds__(256) void k_average_faces_x_all(DV vf, const double *__restrict__ bxf, AvgOut o, int nd)
+{
+    const int R = 1 << (nd - 1);
+    int ih = blockIdx.x * blockDim.x + threadIdx.x;      // i = 2 * ih
+    int jb = blockIdx.y * blockDim.y + threadIdx.y;
+    int i = 2 * ih;
+    if (i > vf.nx || jb * R >= vf.ny) return;
+    double sum[SUHMO_MAXDEPTH];
+    const int base = cidx(vf, i, jb * R);
+    for (int k = 0; k < R; k++) {
+        double f = bxf[base + k * vf.P];
+#pragma unroll
+        for (int d = 1; d < SUHMO_MAXDEPTH; d++) {
+            if (d >= nd) break;
+            const int r = 1 << d;
+            if ((i & (r - 1)) != 0) break;               // column not on depth d's face grid (nor deeper)
+            sum[d] = ((k & (r - 1)) == 0) ? 0.0 + f : sum[d] + f;
+            if ((k & (r - 1)) == r - 1)
+                o.bx[d][((jb * R + k) / r + o.gy[d]) * o.P[d] + SUHMO_XOFF + i / r] = sum[d] / (double)r;
+        }
+    }
+}
+// y-faces: one wave walks 64 consecutive columns of one even fine row; lane l = column
+__global__ __launch_bounds__(256) void k_average_faces_y_all(DV vf, const double *__restrict__ byf, AvgOut o, int nd)
+{
+    const int lane = threadIdx.x & 63;
+    int i = blockIdx.x * 64 + lane;
+    int j = 2 * (blockIdx.y * (blockDim.x / 64) + (threadIdx.x >> 6));
+    if (j > vf.ny) return;                                // whole wave leaves together
+    double f = (i < vf.nx) ? byf[cidx(vf, i, j)] : 0.0;
+    double run = 0.0 + f;                                 // depth-0 "sum" of a single face
+    for (int d = 1; d < nd; d++) {
+        const int r = 1 << d;
+        if ((j & (r - 1)) != 0) break;                    // row not on depth d's face grid
+        // sequential continuation: (((run + f[l + r/2]) + f[l + r/2 + 1]) + ... + f[l + r - 1])
+        double acc = run;
+        for (int k = r / 2; k < r; k++) acc = acc + __shfl(f, (lane + k) & 63);
+        run = acc;                                        // valid on lanes with (lane % r) == 0
+        if ((lane & (r - 1)) == 0 && i < vf.nx)
+            o.by[d][(j / r + o.gy[d]) * o.P[d] + SUHMO_XOFF + i / r] = run / (double)r;
+    }
+}
+
 extern "C" int suhmo_level_average_operator(suhmo_level_t *L, int depth, suhmo_stream_t s)
 {
     ARG(L); ARG(depth >= 0 && depth < L->ndepth);
@@ -706,6 +900,29 @@ extern "C" int suhmo_level_average_operator(suhmo_level_t *L, int depth, suhmo_s
     HIPCHK(hipGetLastError());
     int rc = exchange_if_needed(L, depth, SUHMO_F_BX, (hipStream_t)s); if (rc) return rc;
     rc = exchange_if_needed(L, depth, SUHMO_F_BY, (hipStream_t)s); if (rc) return rc;
+    return 0;
+}
+
+int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st)
+{
+    Depth &F = L->d[0];
+    if (nd < 2) return 0;
+    if (nd > 7 || F.v.nx % (1 << (nd - 1)) || F.v.ny % (1 << (nd - 1))) {     // generic fallback
+        for (int k = 1; k < nd; k++) { int rc = suhmo_level_average_operator(L, k, (suhmo_stream_t)st); if (rc) return rc; }
+        return 0;
+    }
+    AvgOut o;
+    for (int d = 0; d < nd; d++) { o.bx[d] = L->d[d].fp.f[SUHMO_F_BX]; o.by[d] = L->d[d].fp.f[SUHMO_F_BY]; o.P[d] = L->d[d].v.P; o.gy[d] = L->d[d].v.gy; }
+    const int R = 1 << (nd - 1);
+    dim3 gx((F.v.nx / 2 + 1 + 63) / 64, (F.v.ny / R + 3) / 4);
+    hipLaunchKernelGGL(k_average_faces_x_all, gx, dim3(64, 4), 0, st, F.v, F.fp.f[SUHMO_F_BX], o, nd);
+    dim3 gy((F.v.nx + 63) / 64, (F.v.ny / 2 + 1 + 3) / 4);
+    hipLaunchKernelGGL(k_average_faces_y_all, gy, dim3(256), 0, st, F.v, F.fp.f[SUHMO_F_BY], o, nd);
+    HIPCHK(hipGetLastError());
+    for (int k = 1; k < nd; k++) {
+        int rc = exchange_if_needed(L, k, SUHMO_F_BX, st); if (rc) return rc;
+        rc = exchange_if_needed(L, k, SUHMO_F_BY, st); if (rc) return rc;
+    }
     return 0;
 }
 
