@@ -118,6 +118,7 @@ struct Depth {
     FP fp;
     size_t elems;      // doubles per canvas
     int nbox;
+    int prolong_pending; // the next fused relax adds P(phi_c - phi_c,old) while loading phi (FAS prolongIncrement)
     double *phi_alt;   // second phi canvas: the fused GSRB kernel writes out of place (ping-pong)
 };
 
@@ -152,4 +153,6 @@ void suhmo_set_error(const char *fmt, ...);
 
 double *suhmo_field(suhmo_level *L, int depth, int field);   // lazily allocates
 int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st);      // suhmo_level.hip
+int suhmo_restrict_both(suhmo_level *L, int depth, hipStream_t st);                 // suhmo_level.hip
+bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps);           // suhmo_gsrb.hip
 int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, hipStream_t st);   // suhmo_gsrb.hip

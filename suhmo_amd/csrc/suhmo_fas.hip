@@ -26,16 +26,19 @@ static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, i
     if (dep == nd - 1) return suhmo_level_gsrb(L, dep, sp->num_bottom, s);        // bottom relaxes
     Depth &C = L->d[dep + 1];
     if ((rc = suhmo_level_gsrb(L, dep, sp->num_smooth, s))) return rc;            // pre-smooth
-    if ((rc = suhmo_level_restrict_residual(L, dep, s))) return rc;               // RES[dep+1]
-    if ((rc = suhmo_level_restrict_r(L, dep, s))) return rc;                      // PHI[dep+1]
+    if ((rc = suhmo_restrict_both(L, dep, (hipStream_t)s))) return rc;            // RES[dep+1] and PHI[dep+1] = R(phi)
     HIPCHK(hipMemcpyAsync(C.fp.f[SUHMO_F_PHIOLD], C.fp.f[SUHMO_F_PHI], C.elems * sizeof(double),
                           hipMemcpyDeviceToDevice, (hipStream_t)s));
     if ((rc = suhmo_level_apply_op(L, dep + 1, 0, s))) return rc;                 // LPHI = L_c(R phi)
     if ((rc = suhmo_level_axby(L, dep + 1, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
     if ((rc = suhmo_level_exchange(L, dep + 1, SUHMO_F_RHS, s))) return rc;   // strips: rhs halo rows for the fused relax
     if ((rc = fas_cycle(L, dep + 1, sp, nd, s))) return rc;
-    if ((rc = suhmo_level_axby(L, dep + 1, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) return rc;
-    if ((rc = suhmo_level_prolong_increment(L, dep, s))) return rc;
+    if (suhmo_gsrb_can_fuse_prolong(L, dep, sp->num_smooth)) {
+        L->d[dep].prolong_pending = 1;      // phi += P(phi_c - phi_c,old) happens inside the first post-smoothing pass
+    } else {
+        if ((rc = suhmo_level_axby(L, dep + 1, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) return rc;
+        if ((rc = suhmo_level_prolong_increment(L, dep, s))) return rc;
+    }
     return suhmo_level_gsrb(L, dep, sp->num_smooth, s);                           // post-smooth
 }
 

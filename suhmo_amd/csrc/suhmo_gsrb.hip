@@ -65,6 +65,9 @@ struct FusedGeom {
     int nstrips, nchunks, ntiles;
     int ylo, yhi; // rows that exist for loading / computing (strip-local j, inclusive)
     int wrap_y;   // rows outside [0, ny) are periodic images (single-rank periodic y)
+    // FAS prolongIncrement fused into the load of phi (PROLONGNL, AMRNonLinearPoissonOpF.ChF:619-627):
+    // phi(i,j) += phi_c(i/2,j/2) - phi_c_old(i/2,j/2)
+    const double *pc, *pco; int Pc, gyc;
 };
 
 struct RowCoef {          // per-thread coefficients of its column pair in one row
@@ -127,7 +130,15 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
     for (int r = jmin - 1; r <= jB - 1 + 2 * K; r++) {
         // ---- 1. prefetch: phi of row r+1, coefficients of row r (both first used in step r+1)
         bool lphi = cval && (r + 1 >= jmin) && (r + 1 <= jmax);
-        if (lphi) pnext = ld2(pin, cidx(v, im, wrapj(r + 1)));
+        if (lphi) {
+            const int jr = wrapj(r + 1);
+            pnext = ld2(pin, cidx(v, im, jr));
+            if (g.pc) {
+                const int ic = ((jr >> 1) + g.gyc) * g.Pc + SUHMO_XOFF + (im >> 1);
+                const double corr = 1.0 * g.pc[ic] + (-1.0) * g.pco[ic];      // axby(1, -1), then PROLONGNL
+                pnext.x = pnext.x + corr; pnext.y = pnext.y + corr;
+            }
+        }
         bool lcf = cval && (r >= jmin) && (r <= jmax);
         if (lcf) {
             int idx = cidx(v, im, wrapj(r));
@@ -251,6 +262,12 @@ static int launch_fused(suhmo_level *L, int depth, hipStream_t st)
     g.ylo = (v.ext[0] || selfper) ? -2 * K : 0;
     g.yhi = (v.ext[1] || selfper) ? v.ny - 1 + 2 * K : v.ny - 1;
     const double *pin = D.fp.f[SUHMO_F_PHI];
+    g.pc = g.pco = nullptr; g.Pc = g.gyc = 0;
+    if (D.prolong_pending) {
+        Depth &C = L->d[depth + 1];
+        g.pc = C.fp.f[SUHMO_F_PHI]; g.pco = C.fp.f[SUHMO_F_PHIOLD]; g.Pc = C.v.P; g.gyc = C.v.gy;
+        D.prolong_pending = 0;
+    }
     if (v.alpha != 0.0)
         hipLaunchKernelGGL((k_gsrb_fused<K, true, NT>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
     else
@@ -259,9 +276,8 @@ static int launch_fused(suhmo_level *L, int depth, hipStream_t st)
     return 0;
 }
 
-int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, hipStream_t st)
+static int pick_variant(const suhmo_level *L, const Depth &D)
 {
-    Depth &D = L->d[depth];
     int variant = L->gsrb_variant;       // -1 auto, 0 simple, 1 fused K=1, 2 fused K=2
     if (variant < 0) {
         // the streaming kernel pays ~(Hc + 4K) serial row steps per workgroup: below ~2M cells
@@ -269,11 +285,29 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, hipStream_t st)
         // (profiles/r01_c_vcycle_trace.txt)
         variant = ((long)D.v.nx * D.v.ny >= (long)L->fused_min_cells) ? 2 : 0;
     }
+    return variant;
+}
+static int pick_K(const suhmo_level *L, const Depth &D, int variant, int remaining)
+{
+    if (variant >= 2 && remaining >= 2 && fused_ok(L, D, 2)) return 2;
+    if (variant >= 1 && fused_ok(L, D, 1)) return 1;
+    return 0;
+}
+bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps)
+{
+    Depth &D = L->d[depth];
+    if (sweeps < 1 || depth + 1 >= L->ndepth || D.v.ext[0] || D.v.ext[1]) return false;
+    return pick_K(L, D, pick_variant(L, D), sweeps) > 0;
+}
+
+int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, hipStream_t st)
+{
+    Depth &D = L->d[depth];
+    int variant = pick_variant(L, D);
     int it = 0;
     while (it < sweeps) {
-        int K = 0;                       // sweeps done by the next launch group (0 = simple path, 1 sweep)
-        if (variant >= 2 && sweeps - it >= 2 && fused_ok(L, D, 2)) K = 2;
-        else if (variant >= 1 && fused_ok(L, D, 1)) K = 1;
+        int K = pick_K(L, D, variant, sweeps - it);   // sweeps done by the next launch (0 = simple path, 1 sweep)
+        if (K == 0 && D.prolong_pending) { suhmo_set_error("internal: prolong_pending without a fused relax"); return -4; }
         ProfEv pe{};
         bool prof = L->prof_on && depth == 0;
         if (prof) {

@@ -128,7 +128,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
         D.elems = (size_t)D.v.P * (size_t)(D.v.rows + 1);
         D.nbox = L->desc.nbox;
         memset(&D.fp, 0, sizeof(D.fp));
-        D.phi_alt = nullptr;
+        D.phi_alt = nullptr; D.prolong_pending = 0;
         for (int f : eager) {
             if (dep == 0 && f == SUHMO_F_LPHI) continue;       // lazily (only tests / AMR use it at depth 0)
             if (!suhmo_field(L, dep, f)) { suhmo_set_error("hipMalloc failed (depth %d field %d)", dep, f); delete L; return -2; }
@@ -464,12 +464,12 @@ extern "C" int suhmo_level_gsrb(suhmo_level_t *L, int depth, int sweeps, suhmo_s
 // per coarse cell; the four fine contributions are accumulated in the reference's loop order
 // (2I,2J), (2I+1,2J), (2I,2J+1), (2I+1,2J+1) onto a zero-initialised coarse value.
 template <bool HAS_ALPHA>
-__global__ __launch_bounds__(256) void k_restrict_residual(DV v, FP fp, DV vc, double *__restrict__ resC, suhmo_phys_t ph)
+__global__ __launch_bounds__(256) void k_restrict_residual(DV v, FP fp, DV vc, double *__restrict__ resC, double *__restrict__ phiC, suhmo_phys_t ph)
 {
     int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y * blockDim.y + threadIdx.y;
     if (I >= vc.nx || J >= vc.ny) return;
     const double *__restrict__ phi = fp.f[SUHMO_F_PHI];
-    double acc = 0.0;
+    double acc = 0.0, accp = 0.0;      // accp: RESTRICTVCNL of phi (restrictR), same visiting order
 #pragma unroll
     for (int b = 0; b < 2; b++)
 #pragma unroll
@@ -486,21 +486,30 @@ __global__ __launch_bounds__(256) void k_restrict_residual(DV v, FP fp, DV vc, d
             double aterm = HAS_ALPHA ? v.alpha * fp.f[SUHMO_F_ACOEF][idx] : v.alpha;
             double lofphi = lofphi_cell(v, aterm, c, e, w, n, s, bxE, bxW, byN, byS, nl);
             acc = acc + (fp.f[SUHMO_F_RHS][idx] - lofphi) / 4.0;
+            accp = accp + c / 4.0;
         }
     resC[cidx(vc, I, J)] = acc;
+    if (phiC) phiC[cidx(vc, I, J)] = accp;
 }
 
+static int restrict_residual_impl(suhmo_level *L, int depth, bool also_phi, hipStream_t st)
+{
+    Depth &D = L->d[depth], &C = L->d[depth + 1];
+    int rc = exchange_if_needed(L, depth, SUHMO_F_PHI, st); if (rc) return rc;
+    double *phiC = also_phi ? C.fp.f[SUHMO_F_PHI] : nullptr;
+    if (D.v.alpha != 0.0) hipLaunchKernelGGL(k_restrict_residual<true>, grid2d(C.v.nx, C.v.ny), BLK2D, 0, st, D.v, D.fp, C.v, C.fp.f[SUHMO_F_RES], phiC, L->ph);
+    else hipLaunchKernelGGL(k_restrict_residual<false>, grid2d(C.v.nx, C.v.ny), BLK2D, 0, st, D.v, D.fp, C.v, C.fp.f[SUHMO_F_RES], phiC, L->ph);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 extern "C" int suhmo_level_restrict_residual(suhmo_level_t *L, int depth, suhmo_stream_t s)
 {
     ARG(L); ARG(depth >= 0 && depth + 1 < L->ndepth);
     HIPCHK(hipSetDevice(L->device));
-    Depth &D = L->d[depth], &C = L->d[depth + 1];
-    int rc = exchange_if_needed(L, depth, SUHMO_F_PHI, (hipStream_t)s); if (rc) return rc;
-    if (D.v.alpha != 0.0) hipLaunchKernelGGL(k_restrict_residual<true>, grid2d(C.v.nx, C.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, C.v, C.fp.f[SUHMO_F_RES], L->ph);
-    else hipLaunchKernelGGL(k_restrict_residual<false>, grid2d(C.v.nx, C.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, C.v, C.fp.f[SUHMO_F_RES], L->ph);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return restrict_residual_impl(L, depth, false, (hipStream_t)s);
 }
+// restrictResidual + restrictR of the FAS cycle in one pass over the fine level
+int suhmo_restrict_both(suhmo_level *L, int depth, hipStream_t st) { return restrict_residual_impl(L, depth, true, st); }
 
 // RESTRICTVCNL (src/VCAMRNonLinearPoissonOpF.ChF:432-446)
 __global__ void k_restrict_r(DV v, const double *__restrict__ f, DV vc, double *__restrict__ c)
