@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=4096, help="cells per side of one rank's strip")
+    ap.add_argument("--cells", dest="n", type=int, default=4096, help="cells per side of one rank strip")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--sweeps-only", type=int, default=0, help="also time this many bare GSRB sweeps")
     args = ap.parse_args()
@@ -51,8 +51,10 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        ndev = torch.cuda.device_count()
+        local_rank = local_rank % max(ndev, 1)          # rehearsal: several ranks may share one GPU (gloo only)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("SUHMO_DIST_BACKEND", "nccl"))
     assert capi.lib().suhmo_device_count() > 0, "no GPU visible: the product path has no CPU fallback"
 
     ny_global = n * world

@@ -176,8 +176,8 @@ int suhmo_level_unpack_rows(suhmo_level_t *L, int depth, int field, int side, in
                             const double *dev_buf, suhmo_stream_t s);
 /* hook called by the V-cycle driver wherever the reference calls LevelData::exchange on a
  * field whose strip ghost rows must come from another rank; NULL = single process. */
-typedef int (*suhmo_exchange_fn)(void *user, suhmo_level_t *L, int depth, int field,
-                                 suhmo_stream_t s);
+typedef int (*suhmo_exchange_fn)(void *user, suhmo_level_t *L, int depth, const int *fields,
+                                 int nfields, suhmo_stream_t s);   /* several fields = one message per neighbour */
 typedef int (*suhmo_allreduce_max_fn)(void *user, double *value);
 int suhmo_level_set_hooks(suhmo_level_t *L, suhmo_exchange_fn ex, suhmo_allreduce_max_fn ar,
                           void *user);

@@ -40,7 +40,7 @@ class LevelDesc(C.Structure):
                 ("bc", BC), ("phys", Phys), ("device", C.c_int), ("halo_rows", C.c_int)]
 
 
-EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
 
 # every symbol include/suhmo_hip.h declares (tests check the library exports all of them)

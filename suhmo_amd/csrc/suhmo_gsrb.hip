@@ -21,14 +21,17 @@
 //                        recomputed redundantly, output goes to a second phi buffer (ping-
 //                        pong) so no workgroup ever reads a neighbour's updated cell.
 #include "suhmo_common.h"
+#include <type_traits>
 
 // ---- variant 0: one thread per active-colour cell ----
 template <bool HAS_ALPHA>
-__global__ __launch_bounds__(256) void k_gsrb_pass_simple(DV v, FP fp, suhmo_phys_t ph, int pass)
+__global__ __launch_bounds__(256) void k_gsrb_pass_simple(DV v, FP fp, suhmo_phys_t ph, int pass, int jlo, int jhi)
 {
-    int j = blockIdx.y * blockDim.y + threadIdx.y;
+    // rows [jlo, jhi]: the strip's own rows plus, on rank boundaries, the halo rows that are
+    // still fresh enough to be advanced redundantly (one exchange then feeds several passes)
+    int j = jlo + (int)(blockIdx.y * blockDim.y + threadIdx.y);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= v.ny) return;
+    if (j > jhi) return;
     int i = 2 * t + ((j + v.j0 + pass) & 1);
     if (i >= v.nx) return;
     double *__restrict__ phi = fp.f[SUHMO_F_PHI];
@@ -48,14 +51,15 @@ __global__ __launch_bounds__(256) void k_gsrb_pass_simple(DV v, FP fp, suhmo_phy
     phi[idx] = c + (fp.f[SUHMO_F_RHS][idx] - lofphi) / denom; // :156
 }
 
-static void launch_simple(suhmo_level *L, int depth, int pass, hipStream_t st)
+static void launch_simple(suhmo_level *L, int depth, int pass, int ext_rows, hipStream_t st)
 {
     Depth &D = L->d[depth];
-    dim3 blk(64, 4), grd(((D.v.nx + 1) / 2 + 63) / 64, (D.v.ny + 3) / 4);
+    int jlo = D.v.ext[0] ? -ext_rows : 0, jhi = D.v.ny - 1 + (D.v.ext[1] ? ext_rows : 0);
+    dim3 blk(64, 4), grd(((D.v.nx + 1) / 2 + 63) / 64, (jhi - jlo + 1 + 3) / 4);
     if (D.v.alpha != 0.0)
-        hipLaunchKernelGGL(k_gsrb_pass_simple<true>, grd, blk, 0, st, D.v, D.fp, L->ph, pass);
+        hipLaunchKernelGGL(k_gsrb_pass_simple<true>, grd, blk, 0, st, D.v, D.fp, L->ph, pass, jlo, jhi);
     else
-        hipLaunchKernelGGL(k_gsrb_pass_simple<false>, grd, blk, 0, st, D.v, D.fp, L->ph, pass);
+        hipLaunchKernelGGL(k_gsrb_pass_simple<false>, grd, blk, 0, st, D.v, D.fp, L->ph, pass, jlo, jhi);
 }
 
 // ---- variant 1: K sweeps fused, streaming over rows ----
@@ -124,6 +128,9 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
     // coefficient ring as NAMED variables (an indexed array ends up in scratch memory):
     // cf0 = row r (being prefetched), cfM = row r-M
     RowCoef cf0, cf1, cf2, cf3, cf4;
+    // physical-BC sides this tile can touch (uniform): skip the per-lane boundary tests elsewhere
+    const bool xbc = !v.per[0] && (c0 - 2 * K <= 0 || c0 + g.W + 2 * K >= v.nx);
+    const bool ybc = !v.per[1] && (jmin <= 0 || jmax >= v.ny - 1);
     double2 pnext = make_double2(0.0, 0.0);
 
     int sr = 0;                            // LDS ring slot of row r
@@ -153,36 +160,41 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
         __syncthreads();                   // row r (written at the end of step r-1) is visible
 
         // ---- 2. advance row r-m from half-sweep m-1 to m, m = 1..2K
+        // One half-sweep of row r-m.  The colour offset `a` (which cell of the pair is updated)
+        // depends only on the row, so it is WAVE-UNIFORM: branch on it once (scalar branch) and
+        // address the pair's coefficients statically instead of selecting per lane.
+        auto advance_a = [&](const int m, const RowCoef &q, auto a_tag) {
+            constexpr int a = decltype(a_tag)::value;
+            const int j = r - m;
+            const int x = xl + a, i = im + a;
+            const int s0 = (sr - m + 2 * R) % R, sN = (s0 + 1) % R, sS = (s0 + R - 1) % R;
+            const double *row = lds + s0 * LW;
+            double c = row[x];
+            double w = row[(a == 0 && xl == 0) ? 0 : x - 1], e = row[(a == 1 && xl == LW - 2) ? LW - 1 : x + 1];
+            double n = lds[sN * LW + x], s = lds[sS * LW + x];
+            if (xbc) {                                         // mixBCValues on the fly (strip touches a BC side)
+                if (i == 0) w = (v.bct[0][0] == 0) ? v.two_v[0][0] - c : c + v.neu[0][0];
+                if (i == v.nx - 1) e = (v.bct[0][1] == 0) ? v.two_v[0][1] - c : c + v.neu[0][1];
+            }
+            if (ybc) {
+                if (j == 0 && !v.ext[0]) s = (v.bct[1][0] == 0) ? v.two_v[1][0] - c : c + v.neu[1][0];
+                if (j == v.ny - 1 && !v.ext[1]) n = (v.bct[1][1] == 0) ? v.two_v[1][1] - c : c + v.neu[1][1];
+            }
+            double nl, dnl;
+            nl_terms(ph, c, q.B[a], q.Pi[a], q.zb[a], q.mask[a], nl, dnl);
+            const double bxW = a ? q.bx1 : q.bx0, bxE = a ? q.bx2 : q.bx1;
+            double aterm = HAS_ALPHA ? v.alpha * q.a[a] : v.alpha;
+            double lofphi = lofphi_cell(v, aterm, c, e, w, n, s, bxE, bxW, q.byN[a], q.byS[a], nl);
+            double lam = lambda_cell(v, aterm, bxE, bxW, q.byN[a], q.byS[a]);
+            double denom = 1.0e-16 + lam + dnl;
+            lds[s0 * LW + x] = c + (q.rhs[a] - lofphi) / denom;
+        };
         auto advance = [&](const int m, const RowCoef &q) {
             const int j = r - m;
-            if (cval && j >= jmin && j <= jmax) {
-                const int pass = (m - 1) & 1;
-                const int a = (j + v.j0 + pass) & 1;          // which cell of the pair has this colour
-                const int x = xl + a, i = im + a;
-                const int s0 = (sr - m + 2 * R) % R, sN = (s0 + 1) % R, sS = (s0 + R - 1) % R;
-                const double *row = lds + s0 * LW;
-                double c = row[x];
-                double w = row[x > 0 ? x - 1 : 0], e = row[x < LW - 1 ? x + 1 : LW - 1];
-                double n = lds[sN * LW + x], s = lds[sS * LW + x];
-                if (!v.per[0]) {                               // mixBCValues on the fly
-                    if (i == 0) w = (v.bct[0][0] == 0) ? v.two_v[0][0] - c : c + v.neu[0][0];
-                    if (i == v.nx - 1) e = (v.bct[0][1] == 0) ? v.two_v[0][1] - c : c + v.neu[0][1];
-                }
-                if (!v.per[1]) {
-                    if (j == 0 && !v.ext[0]) s = (v.bct[1][0] == 0) ? v.two_v[1][0] - c : c + v.neu[1][0];
-                    if (j == v.ny - 1 && !v.ext[1]) n = (v.bct[1][1] == 0) ? v.two_v[1][1] - c : c + v.neu[1][1];
-                }
-                double B = a ? q.B[1] : q.B[0], Pi = a ? q.Pi[1] : q.Pi[0], zb = a ? q.zb[1] : q.zb[0];
-                double mk = a ? q.mask[1] : q.mask[0], rhs = a ? q.rhs[1] : q.rhs[0];
-                double bxW = a ? q.bx1 : q.bx0, bxE = a ? q.bx2 : q.bx1;
-                double byS = a ? q.byS[1] : q.byS[0], byN = a ? q.byN[1] : q.byN[0];
-                double nl, dnl;
-                nl_terms(ph, c, B, Pi, zb, mk, nl, dnl);
-                double aterm = HAS_ALPHA ? v.alpha * (a ? q.a[1] : q.a[0]) : v.alpha;
-                double lofphi = lofphi_cell(v, aterm, c, e, w, n, s, bxE, bxW, byN, byS, nl);
-                double lam = lambda_cell(v, aterm, bxE, bxW, byN, byS);
-                double denom = 1.0e-16 + lam + dnl;
-                lds[s0 * LW + x] = c + (rhs - lofphi) / denom;
+            if (j >= jmin && j <= jmax) {                      // uniform
+                const int a = (j + v.j0 + ((m - 1) & 1)) & 1;  // uniform: colour offset of this row
+                if (a) { if (cval) advance_a(m, q, std::integral_constant<int, 1>()); }
+                else   { if (cval) advance_a(m, q, std::integral_constant<int, 0>()); }
             }
         };
         advance(1, cf1);
@@ -304,6 +316,10 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, hipStream_t st)
 {
     Depth &D = L->d[depth];
     int variant = pick_variant(L, D);
+    const bool ext = L->ex && (D.v.ext[0] || D.v.ext[1]);
+    const int phi_field = SUHMO_F_PHI;
+    const int halo = D.v.gy < D.v.ny ? D.v.gy : D.v.ny;   // halo rows that hold real neighbour data
+    int fresh = 0;       // colour passes the current halo contents still allow (simple path)
     int it = 0;
     while (it < sweeps) {
         int K = pick_K(L, D, variant, sweeps - it);   // sweeps done by the next launch (0 = simple path, 1 sweep)
@@ -316,16 +332,20 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, hipStream_t st)
         }
         if (K == 0) {
             for (int pass = 0; pass < 2; pass++) {
-                if (L->ex && (D.v.ext[0] || D.v.ext[1])) {
-                    int rc = L->ex(L->user, L, depth, SUHMO_F_PHI, (suhmo_stream_t)st);
+                if (ext && fresh == 0) {
+                    int rc = L->ex(L->user, L, depth, &phi_field, 1, (suhmo_stream_t)st);
                     if (rc) return rc;
+                    fresh = halo;
                 }
-                launch_simple(L, depth, pass, st);
+                // with `fresh` valid halo rows this pass may also advance fresh-1 of them
+                launch_simple(L, depth, pass, ext ? fresh - 1 : 0, st);
+                if (ext) fresh--;
             }
         } else {
-            if (L->ex && (D.v.ext[0] || D.v.ext[1])) {
-                int rc = L->ex(L->user, L, depth, SUHMO_F_PHI, (suhmo_stream_t)st);
+            if (ext) {
+                int rc = L->ex(L->user, L, depth, &phi_field, 1, (suhmo_stream_t)st);
                 if (rc) return rc;
+                fresh = 0;
             }
             int rc;
             if (L->fused_nt == 64) rc = (K == 2) ? launch_fused<2, 64>(L, depth, st) : launch_fused<1, 64>(L, depth, st);

@@ -4,6 +4,7 @@
 #include "suhmo_common.h"
 #include <cstdarg>
 #include <cmath>
+#include <initializer_list>
 
 static thread_local char g_err[512] = "";
 void suhmo_set_error(const char *fmt, ...)
@@ -179,7 +180,7 @@ extern "C" int suhmo_level_exchange(suhmo_level_t *L, int depth, int field, suhm
     const DV &v = L->d[depth].v;
     if (L->ex && (v.ext[0] || v.ext[1])) {
         if (!suhmo_field(L, depth, field)) return -2;
-        return L->ex(L->user, L, depth, field, s);
+        return L->ex(L->user, L, depth, &field, 1, s);
     }
     return 0;
 }
@@ -377,12 +378,14 @@ __global__ __launch_bounds__(256) void k_apply(DV v, FP fp, suhmo_phys_t ph, int
     else fp.f[SUHMO_F_RES][idx] = fp.f[SUHMO_F_RHS][idx] - lofphi;
 }
 
-static int exchange_if_needed(suhmo_level *L, int depth, int field, hipStream_t st)
+static int exchange_fields(suhmo_level *L, int depth, std::initializer_list<int> fields, hipStream_t st)
 {
     const DV &v = L->d[depth].v;
-    if (L->ex && (v.ext[0] || v.ext[1])) return L->ex(L->user, L, depth, field, (suhmo_stream_t)st);
-    return 0;
+    if (!(L->ex && (v.ext[0] || v.ext[1]))) return 0;
+    for (int f : fields) if (!suhmo_field(L, depth, f)) return -2;
+    return L->ex(L->user, L, depth, fields.begin(), (int)fields.size(), (suhmo_stream_t)st);
 }
+static int exchange_if_needed(suhmo_level *L, int depth, int field, hipStream_t st) { return exchange_fields(L, depth, {field}, st); }
 
 extern "C" int suhmo_level_apply_op(suhmo_level_t *L, int depth, int homogeneous, suhmo_stream_t s)
 {
@@ -815,8 +818,7 @@ extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_st
     } else {
         if (!suhmo_field(L, depth, SUHMO_F_GRADX) || !suhmo_field(L, depth, SUHMO_F_GRADY) || !suhmo_field(L, depth, SUHMO_F_RE)) return -2;
         hipLaunchKernelGGL(k_gradcc, grid2d(D.v.nx, D.v.ny), BLK2D, 0, st, D.v, D.fp, L->ph.use_mask_gradients);
-        rc = exchange_if_needed(L, depth, SUHMO_F_GRADX, st); if (rc) return rc;
-        rc = exchange_if_needed(L, depth, SUHMO_F_GRADY, st); if (rc) return rc;
+        rc = exchange_fields(L, depth, {SUHMO_F_GRADX, SUHMO_F_GRADY}, st); if (rc) return rc;
         int n = 2 * D.v.ny + 2 * D.v.nx;
         hipLaunchKernelGGL(k_grad_ghosts, dim3((n + 255) / 256), dim3(256), 0, st, D.v, D.fp.f[SUHMO_F_GRADX], D.fp.f[SUHMO_F_GRADY]);
         hipLaunchKernelGGL(k_re, grid2d(D.v.nx + 2, D.v.ny + 2), BLK2D, 0, st, D.v, D.fp, L->ph);
@@ -824,8 +826,7 @@ extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_st
     }
     HIPCHK(hipGetLastError());
     // strips: the fused relaxation recomputes halo rows, so it needs the coefficients there too
-    rc = exchange_if_needed(L, depth, SUHMO_F_BX, st); if (rc) return rc;
-    rc = exchange_if_needed(L, depth, SUHMO_F_BY, st); if (rc) return rc;
+    rc = exchange_fields(L, depth, {SUHMO_F_BX, SUHMO_F_BY}, st); if (rc) return rc;
     return 0;
 }
 
@@ -907,8 +908,7 @@ extern "C" int suhmo_level_average_operator(suhmo_level_t *L, int depth, suhmo_s
     hipLaunchKernelGGL(k_average_faces, grid2d(C.v.nx + 1, C.v.ny + 1), BLK2D, 0, (hipStream_t)s, F.v, F.fp.f[SUHMO_F_BX], F.fp.f[SUHMO_F_BY],
                        C.v, C.fp.f[SUHMO_F_BX], C.fp.f[SUHMO_F_BY], 1 << depth);
     HIPCHK(hipGetLastError());
-    int rc = exchange_if_needed(L, depth, SUHMO_F_BX, (hipStream_t)s); if (rc) return rc;
-    rc = exchange_if_needed(L, depth, SUHMO_F_BY, (hipStream_t)s); if (rc) return rc;
+    int rc = exchange_fields(L, depth, {SUHMO_F_BX, SUHMO_F_BY}, (hipStream_t)s); if (rc) return rc;
     return 0;
 }
 
@@ -929,8 +929,7 @@ int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st)
     hipLaunchKernelGGL(k_average_faces_y_all, gy, dim3(256), 0, st, F.v, F.fp.f[SUHMO_F_BY], o, nd);
     HIPCHK(hipGetLastError());
     for (int k = 1; k < nd; k++) {
-        int rc = exchange_if_needed(L, k, SUHMO_F_BX, st); if (rc) return rc;
-        rc = exchange_if_needed(L, k, SUHMO_F_BY, st); if (rc) return rc;
+        int rc = exchange_fields(L, k, {SUHMO_F_BX, SUHMO_F_BY}, st); if (rc) return rc;
     }
     return 0;
 }
@@ -983,7 +982,7 @@ extern "C" int suhmo_level_build_mg_coefficients(suhmo_level_t *L, suhmo_stream_
         }
         int rc = suhmo_level_average_operator(L, dep, s);
         if (rc) return rc;
-        for (int q = 0; q < 5; q++) { rc = exchange_if_needed(L, dep, fields[q], st); if (rc) return rc; }
+        rc = exchange_fields(L, dep, {SUHMO_F_ACOEF, SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB, SUHMO_F_MASK}, st); if (rc) return rc;
     }
     HIPCHK(hipGetLastError());
     return 0;

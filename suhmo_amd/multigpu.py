@@ -37,27 +37,32 @@ class StripExchanger:
         rows, _, _, nx, ny = [x.value for x in g]
         return min(rows, ny), nx
 
-    def _exchange(self, user, L, depth, field, stream):
+    def _exchange(self, user, L, depth, pfields, nfields, stream):
         try:
+            fields = tuple(pfields[k] for k in range(nfields))
             rows, nx = self._geom(depth)
-            n = rows * (nx + 1)
-            key = (depth, field)
+            n = rows * (nx + 1)                      # doubles per field and side
+            key = (depth, fields)
             if key not in self._bufs:
-                self._bufs[key] = [self.tr.alloc(n) for _ in range(4)]   # send lo/hi, recv lo/hi
+                self._bufs[key] = [self.tr.alloc(n * nfields) for _ in range(4)]   # send lo/hi, recv lo/hi
             slo, shi, rlo, rhi = self._bufs[key]
             lib, h, st = capi.lib(), self.level.h, C.c_void_p(stream)
-            if self.lo is not None:
-                check(lib.suhmo_level_pack_rows(h, depth, field, 0, rows, C.c_void_p(self.tr.ptr(slo)), st))
-            if self.hi is not None:
-                check(lib.suhmo_level_pack_rows(h, depth, field, 1, rows, C.c_void_p(self.tr.ptr(shi)), st))
-            self.tr.sendrecv(self.rank, self.lo, self.hi, slo, shi, rlo, rhi, (depth, field, self.calls))
-            if self.lo is not None:
-                check(lib.suhmo_level_unpack_rows(h, depth, field, 0, rows, C.c_void_p(self.tr.ptr(rlo)), st))
-            if self.hi is not None:
-                check(lib.suhmo_level_unpack_rows(h, depth, field, 1, rows, C.c_void_p(self.tr.ptr(rhi)), st))
+            for q, f in enumerate(fields):
+                off = q * n * 8
+                if self.lo is not None:
+                    check(lib.suhmo_level_pack_rows(h, depth, f, 0, rows, C.c_void_p(self.tr.ptr(slo) + off), st))
+                if self.hi is not None:
+                    check(lib.suhmo_level_pack_rows(h, depth, f, 1, rows, C.c_void_p(self.tr.ptr(shi) + off), st))
+            self.tr.sendrecv(self.rank, self.lo, self.hi, slo, shi, rlo, rhi, key)
+            for q, f in enumerate(fields):
+                off = q * n * 8
+                if self.lo is not None:
+                    check(lib.suhmo_level_unpack_rows(h, depth, f, 0, rows, C.c_void_p(self.tr.ptr(rlo) + off), st))
+                if self.hi is not None:
+                    check(lib.suhmo_level_unpack_rows(h, depth, f, 1, rows, C.c_void_p(self.tr.ptr(rhi) + off), st))
             self.calls += 1
             return 0
-        except Exception as e:  # never let an exception cross the C boundary
+        except Exception:  # never let an exception cross the C boundary
             import traceback
             traceback.print_exc()
             return -9
@@ -74,8 +79,12 @@ class StripExchanger:
     def exchange_static(self):
         """halo rows of the caller-provided coefficient fields (depth 0)"""
         from . import level as lv
-        for f in (lv.F_RHS, lv.F_ACOEF, lv.F_B, lv.F_PI, lv.F_ZB, lv.F_MASK, lv.F_BX, lv.F_BY):
-            check(capi.lib().suhmo_level_exchange(self.level.h, 0, f, self.level.stream))
+        fields = (lv.F_RHS, lv.F_ACOEF, lv.F_B, lv.F_PI, lv.F_ZB, lv.F_MASK, lv.F_BX, lv.F_BY)
+        arr = (C.c_int * len(fields))(*fields)
+        st = self.level.stream.value or 0
+        rc = self._exchange(None, None, 0, arr, len(fields), st)
+        if rc:
+            raise capi.SuhmoError("exchange of the coefficient halos failed")
 
 
 class TorchDistTransport:
@@ -84,6 +93,7 @@ class TorchDistTransport:
     def __init__(self, dist, device):
         import torch
         self.torch, self.dist, self.device = torch, dist, device
+        self._ops = {}
 
     def alloc(self, n):
         return self.torch.empty(n, dtype=self.torch.float64, device=self.device)
@@ -92,18 +102,22 @@ class TorchDistTransport:
         return t.data_ptr()
 
     def sendrecv(self, rank, lo, hi, slo, shi, rlo, rhi, tag):
-        d, ops = self.dist, []
-        # order matters when lo == hi (2 ranks, periodic): to-hi before to-lo, from-lo before from-hi
-        if hi is not None:
-            ops.append(d.P2POp(d.isend, shi, hi))
-        if lo is not None:
-            ops.append(d.P2POp(d.isend, slo, lo))
-        if lo is not None:
-            ops.append(d.P2POp(d.irecv, rlo, lo))
-        if hi is not None:
-            ops.append(d.P2POp(d.irecv, rhi, hi))
+        ops = self._ops.get(tag) if tag is not None else None
+        if ops is None:
+            d, ops = self.dist, []
+            # order matters when lo == hi (2 ranks, periodic): to-hi before to-lo, from-lo before from-hi
+            if hi is not None:
+                ops.append(d.P2POp(d.isend, shi, hi))
+            if lo is not None:
+                ops.append(d.P2POp(d.isend, slo, lo))
+            if lo is not None:
+                ops.append(d.P2POp(d.irecv, rlo, lo))
+            if hi is not None:
+                ops.append(d.P2POp(d.irecv, rhi, hi))
+            if tag is not None:
+                self._ops[tag] = ops      # buffers are fixed per (depth, fields): build the op list once
         if ops:
-            for w in d.batch_isend_irecv(ops):
+            for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
 
     def allreduce_max(self, rank, v):

@@ -28,7 +28,7 @@ def main():
     n = 7
     slo, shi = torch.full((n,), 10.0 * rank + 1, dtype=torch.float64), torch.full((n,), 10.0 * rank + 2, dtype=torch.float64)
     rlo, rhi = torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
-    tr.sendrecv(rank, lo, hi, slo, shi, rlo, rhi, 0)
+    tr.sendrecv(rank, lo, hi, slo, shi, rlo, rhi, "t1")
     if lo is not None:
         assert torch.all(rlo == 10.0 * lo + 2), (rank, rlo)      # lo neighbour's TOP rows
     if hi is not None:
@@ -51,7 +51,7 @@ def main():
             pg = npref.fill_ghosts(phi, dict(bc, periodic=[bc["periodic"][0], 0]), f["dx"], f["dy"])
             # rank boundaries: ghost rows come from the neighbours (exchange before each pass)
             rlo, rhi = torch.zeros(nx, dtype=torch.float64), torch.zeros(nx, dtype=torch.float64)
-            tr.sendrecv(rank, lo, hi, torch.from_numpy(phi[0].copy()), torch.from_numpy(phi[-1].copy()), rlo, rhi, 0)
+            tr.sendrecv(rank, lo, hi, torch.from_numpy(phi[0].copy()), torch.from_numpy(phi[-1].copy()), rlo, rhi, None)
             if lo is not None:
                 pg[0, 1:-1] = rlo.numpy()
             if hi is not None:
