@@ -107,6 +107,17 @@ def main():
     sweep_ms = gsrb_ms / max(sweeps_timed, 1)
     achieved = BYTES_PER_CELL_SWEEP * cells / (sweep_ms * 1e-3) / 1e9 if gsrb_launches else 0.0
 
+    # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc cannot run inside this process:
+    # collected with tools/pmc_any.sh on the same workload, corrected as MI355X_MICROARCH.md prescribes, committed)
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_gsrb.json")
+    if gsrb_launches and os.path.exists(pmc):
+        pj = json.load(open(pmc))
+        if pj.get("cells") == cells and abs(sweeps_timed / gsrb_launches - pj.get("sweeps_per_launch", 0)) < 1e-9:
+            traffic, traffic_src = pj["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic_gsrb.json"
+    launch_ms = gsrb_ms / max(gsrb_launches, 1)
+    alg_bytes_launch = BYTES_PER_CELL_SWEEP * cells * sweeps_timed / max(gsrb_launches, 1)
+
     extra = {}
     if args.sweeps_only:
         sync()
@@ -139,7 +150,9 @@ def main():
             "gsrb_depth0_cell_updates_per_s_kernel": cells / (sweep_ms * 1e-3) * world if gsrb_launches else None,
             "roofline": {"bound": "hbm", "kernel": "GSRB sweep (red+black) at depth 0", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_cell_sweep": BYTES_PER_CELL_SWEEP,
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": launch_ms,
+                         "algorithmic_bytes_per_cell_sweep": BYTES_PER_CELL_SWEEP,
                          "avg_sweep_ms": sweep_ms, "sweeps_timed": sweeps_timed, "launches_timed": gsrb_launches},
             "cpu_baseline": cpu,
         }

@@ -76,7 +76,11 @@ enum {
     SUHMO_F_PHI = 0, SUHMO_F_RHS, SUHMO_F_ACOEF, SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB,
     SUHMO_F_MASK, SUHMO_F_BX, SUHMO_F_BY, SUHMO_F_LAMBDA, SUHMO_F_RES, SUHMO_F_LPHI,
     SUHMO_F_NL, SUHMO_F_DNL, SUHMO_F_PHIOLD, SUHMO_F_CORR, SUHMO_F_GRADX, SUHMO_F_GRADY,
-    SUHMO_F_RE, SUHMO_F_COUNT
+    SUHMO_F_RE,
+    /* fields of the caller of the solve (suhmo_level_timestep): melt rate, water pressure, water
+     * flux on x / y faces, lagged head, channelisation degree */
+    SUHMO_F_MR, SUHMO_F_PW, SUHMO_F_QWX, SUHMO_F_QWY, SUHMO_F_HLAG, SUHMO_F_CD,
+    SUHMO_F_COUNT
 };
 
 const char *suhmo_last_error(void);
@@ -167,6 +171,26 @@ int suhmo_level_vcycle(suhmo_level_t *L, const suhmo_solver_params_t *sp, suhmo_
 int suhmo_level_solve(suhmo_level_t *L, const suhmo_solver_params_t *sp, int *iters,
                       double *hist, suhmo_stream_t s);
 
+/* ---- the caller of the solve ("next rows" of the hot path): one AmrHydro::timeStepFAS
+ * (src/AmrHydro.cpp:2254-3460) for a single level with distributed water input and the explicit
+ * gap-height update: Picard loop { lagged Re / Qw / melt rate -> RHS_h (:2920-3079) ->
+ * SolveForHead_nl (:3119) -> convergence test (:3169-3228) } then CalcRHS_gapHeightFAS (:2069-2171)
+ * + forward Euler (:3394-3408).  PHI holds the head, B the gap height (both updated in place). */
+typedef struct suhmo_model_params {
+    double rho_i, rho_w, gravity;      /* suhmo_params.cpp:51-53 */
+    double G, L, ct, cw;               /* suhmo.GeoFlux, LatHeat, ct, cw */
+    double ub0, ub1;                   /* suhmo.SlidingVelocity */
+    double br, lr;                     /* suhmo.br, suhmo.lr */
+    double diffFactor;                 /* suhmo.diffFactor (must be 0 in this build) */
+    double distributed_input;          /* suhmo.distributed_input */
+    double eps_picard;                 /* solver.eps_PicardIte */
+    int basal_friction, use_mask_rhs_b;
+} suhmo_model_params_t;
+/* cur_step = AmrHydro::m_cur_step after its increment (1 for the first step): selects the solver
+ * parameters and the Picard stopping rule.  picard_iters / vcycles: totals of this step. */
+int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t *mp, double dt, int cur_step,
+                         int *picard_iters, int *vcycles, suhmo_stream_t s);
+
 /* multi-GPU strips: pack the `rows` owned rows next to side (0 = y-lo, 1 = y-hi) of a
  * field into a contiguous device buffer (rows x (nx+1) doubles) / unpack a neighbour's rows
  * into the ghost rows of that side.  The transport (RCCL send/recv) belongs to the host. */
@@ -187,6 +211,20 @@ int suhmo_level_exchange(suhmo_level_t *L, int depth, int field, suhmo_stream_t 
 /* rows of ghost data kept per y side / 1 if the side is a rank boundary */
 int suhmo_level_halo_info(const suhmo_level_t *L, int depth, int *halo_rows, int *ext_lo, int *ext_hi,
                           int *nx, int *ny);
+
+/* Native transport for those hooks: RCCL send/recv + 1-element MAX all-reduce enqueued on the caller's
+ * stream (suhmo_amd/csrc/suhmo_rccl.hip); stands where the reference has MPI under LevelData::exchange
+ * (src/VCAMRNonLinearPoissonOp.cpp:692) and under norm() (src/AMRNonLinearPoissonOp.cpp:1222-1264).
+ *   suhmo_rccl_load       dlopen librccl (path NULL/"" = "librccl.so"); no link-time dependency
+ *   suhmo_rccl_unique_id  128-byte ncclUniqueId, made on one rank, distributed by the host (MPI_Bcast, ...)
+ *   suhmo_level_attach_rccl  COLLECTIVE: ranks 0..world-1 own the strips in ascending j0; installs the hooks
+ *   suhmo_level_rccl_exchanges  messages sent so far by this level (diagnostics) */
+int suhmo_rccl_load(const char *librccl_path);
+int suhmo_rccl_unique_id(void *id128);
+int suhmo_level_attach_rccl(suhmo_level_t *L, const void *id128, int rank, int world, int periodic_y,
+                            suhmo_stream_t s);
+int suhmo_level_detach_rccl(suhmo_level_t *L);
+long suhmo_level_rccl_exchanges(const suhmo_level_t *L);
 
 /* timing helper: average device time (ms) of the GSRB sweep kernel launches since the
  * last reset, measured with HIP events on the launch stream */

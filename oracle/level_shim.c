@@ -1,5 +1,5 @@
 /*
- * level_shim.c -- TEST INFRASTRUCTURE ONLY.  See level_shim.h.  "parity unpinned".
+ * level_shim.c -- TEST INFRASTRUCTURE ONLY.  See level_shim.h (parity status: suhmo_oracle.h).
  *
  * Restates, on a minimal box/LevelData stand-in, the C++ orchestration of the
  * reference's head solve.  Citations are relative to the SUHMO checkout.  Pieces

@@ -1,5 +1,6 @@
 /*
- * level_shim.h -- TEST INFRASTRUCTURE ONLY (not product code).  "parity unpinned".
+ * level_shim.h -- TEST INFRASTRUCTURE ONLY (not product code).  Parity status: suhmo_oracle.h
+ * (pinned end-to-end by the reference's SHMIP A result tables; no kernel-level vectors).
  *
  * A minimal stand-in for the Chombo containers the reference's hot path runs on
  * (DisjointBoxLayout / LevelData<FArrayBox> / LevelData<FluxBox> / Copier::exchange /

@@ -1,6 +1,7 @@
 """ctypes binding of the CPU oracle (oracle/liboracle.so).
 
-TEST INFRASTRUCTURE ONLY -- "parity unpinned" (see oracle/suhmo_oracle.h).  May be
+TEST INFRASTRUCTURE ONLY -- pinned end-to-end by the reference's SHMIP A tables, no kernel-level vectors
+(see oracle/suhmo_oracle.h).  May be
 imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; the
 product package suhmo_amd never imports it.
 """
@@ -26,6 +27,14 @@ class OrBC(C.Structure):
                 ("periodic", C.c_int * 2)]
 
 
+class OrModelParams(C.Structure):
+    _fields_ = [("rho_i", C.c_double), ("rho_w", C.c_double), ("gravity", C.c_double), ("G", C.c_double),
+                ("L", C.c_double), ("ct", C.c_double), ("cw", C.c_double), ("ub0", C.c_double), ("ub1", C.c_double),
+                ("br", C.c_double), ("lr", C.c_double), ("diffFactor", C.c_double),
+                ("distributed_input", C.c_double), ("eps_picard", C.c_double),
+                ("basal_friction", C.c_int), ("use_mask_rhs_b", C.c_int)]
+
+
 class OrSolverParams(C.Structure):
     _fields_ = [("num_smooth", C.c_int), ("num_bottom", C.c_int), ("max_iter", C.c_int),
                 ("iter_min", C.c_int), ("imin", C.c_int), ("eps", C.c_double),
@@ -39,7 +48,7 @@ F_PHIOLD, F_CORR = 14, 15
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("suhmo_oracle.c", "level_shim.c", "suhmo_oracle.h", "level_shim.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("suhmo_oracle.c", "level_shim.c", "time_loop.c", "suhmo_oracle.h", "level_shim.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -77,6 +86,14 @@ def lib():
         L.or_level_vcycle.argtypes = [C.c_void_p, C.POINTER(OrSolverParams)]
         L.or_level_solve.restype = C.c_int
         L.or_level_solve.argtypes = [C.c_void_p, C.POINTER(OrSolverParams), dp]
+        L.or_model_create.restype = C.c_void_p
+        L.or_model_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(OrBC),
+                                      C.POINTER(OrPhys), C.POINTER(OrModelParams)]
+        L.or_model_destroy.argtypes = [C.c_void_p]
+        L.or_model_field.restype = dp
+        L.or_model_field.argtypes = [C.c_void_p, C.c_int]
+        L.or_model_timestep.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.or_model_step_index.argtypes = [C.c_void_p]
         L.or_prolong2_global.argtypes = [dp, dp, C.c_int, C.c_int]
         L.or_divergence_global.argtypes = [dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double]
         L.or_difterm_global.argtypes = [dp, dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double]
@@ -221,3 +238,53 @@ def getflux(phi_ghosted, bface, direction, beta, dx_dir, ref=1):
     lib().or_getflux_global(_dp(np.ascontiguousarray(phi_ghosted)), _dp(np.ascontiguousarray(bface)), _dp(out),
                             nx, ny, direction, beta, dx_dir, ref)
     return out
+
+
+# ---- time loop ("next rows"): one AmrHydro::timeStepFAS per call
+OM_H, OM_B, OM_BOLD, OM_PI, OM_ZB, OM_MASK, OM_MR, OM_PW, OM_SRC, OM_RHSH, OM_CD, OM_GRADX, OM_GRADY, OM_RE, OM_HLAG = range(15)
+OM_QWX, OM_QWY = 100, 101
+
+
+def make_model_params(m):
+    return OrModelParams(m["rho_i"], m["rho_w"], m["gravity"], m["G"], m["L"], m["ct"], m["cw"], m["ub"][0], m["ub"][1],
+                         m["br"], m["lr"], m["diffFactor"], m["distributed_input"], m["eps_picard"],
+                         int(m["basal_friction"]), int(m.get("use_mask_rhs_b", 0)))
+
+
+class OracleModel:
+    """Hydrology time loop on one level: head (Picard + FAS solve) and gap height (forward Euler)."""
+
+    def __init__(self, nx, ny, dx, dy, bc, phys, model, max_box=64, nthreads=1):
+        self.level = OracleLevel(nx, ny, dx, dy, bc, phys, 0.0, -1.0, max_box, nthreads)
+        self.nx, self.ny = nx, ny
+        self._mp = make_model_params(model)
+        self.h = lib().or_model_create(self.level.h, nx, ny, dx, dy, C.byref(self.level._bc), C.byref(self.level._ph),
+                                       C.byref(self._mp))
+
+    def field(self, fid):
+        """numpy VIEW of a model array (ghosted cells (ny+2, nx+2); QWX (ny, nx+1); QWY (ny+1, nx))"""
+        p = lib().or_model_field(self.h, fid)
+        shape = {OM_QWX: (self.ny, self.nx + 1), OM_QWY: (self.ny + 1, self.nx)}.get(fid, (self.ny + 2, self.nx + 2))
+        return np.ctypeslib.as_array(p, shape=shape)
+
+    def set_state(self, f):
+        """f: dict with ghosted arrays head, B, Pi, zb, mask"""
+        for k, fid in (("head", OM_H), ("B", OM_B), ("Pi", OM_PI), ("zb", OM_ZB), ("mask", OM_MASK)):
+            self.field(fid)[:] = f[k]
+        L = self.level
+        L.set(F_ACOEF, np.zeros((self.ny, self.nx)))
+        for k, fid in (("Pi", F_PI), ("zb", F_ZB), ("mask", F_MASK), ("B", F_B)):
+            L.set(fid, f[k], ghosted=True)
+
+    def timestep(self, dt):
+        pi, nv = C.c_int(), C.c_int()
+        rc = lib().or_model_timestep(self.h, dt, C.byref(pi), C.byref(nv))
+        if rc:
+            raise RuntimeError("Picard loop did not converge (> 100 iterations)")
+        return pi.value, nv.value
+
+    def close(self):
+        if self.h:
+            lib().or_model_destroy(self.h)
+            self.h = None
+            self.level.close()

@@ -1,6 +1,6 @@
 /*
  * suhmo_oracle.c -- TEST INFRASTRUCTURE ONLY.  See suhmo_oracle.h.
- * "parity unpinned": no reference golden vectors exist for these kernels.
+ * Parity status: suhmo_oracle.h (no kernel-level reference vectors exist; pinned end-to-end).
  *
  * Each function restates the 2D (CH_SPACEDIM == 2), ncomp-general arm of one
  * Chombo-Fortran subroutine of the reference, same loop nest order (component

@@ -1,0 +1,315 @@
+/*
+ * time_loop.c -- TEST INFRASTRUCTURE ONLY ("next rows" of SURVEY.md 8f: the caller of the
+ * head solve).  CPU restatement of one AmrHydro::timeStepFAS (src/AmrHydro.cpp:2254-3460) for a
+ * single AMR level without moulins (n_moulins < 0: distributed input) and with the explicit
+ * gap-height update (solver.use_ImplDiff = false):
+ *   [I]   ghosts of h and b, copy into old                         :2360-2445
+ *   [II]  Picard loop: lagged quantities -> RHS_h -> SolveForHead_nl -> convergence test
+ *                                                                   :2477-3235
+ *   [III] re-evaluate Re, Qw, melt rate with the new head; gap-height RHS; forward Euler
+ *                                                                   :3238-3421
+ * All fields live in GLOBAL ghosted arrays ((ny+2) x (nx+2), cell (i,j) at [(j+1)*(nx+2)+i+1]):
+ * every operation here is pointwise or a fixed stencil, so (as for the solve itself) the box
+ * decomposition does not change a bit; the head solve goes through the level shim
+ * (or_level_solve), i.e. the un-fused box-by-box path.
+ * Diffusive term (suhmo.diffFactor): the reference multiplies COMPUTEDIFTERM2D by DiffFactor
+ * (:3071, :2145); with DiffFactor = 0 (SHMIP A) it contributes +-0 and is skipped here.
+ */
+#include "level_shim.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct OrModelParams {
+    double rho_i, rho_w, gravity;       /* suhmo_params.cpp:51-53 */
+    double G, L, ct, cw;                /* GeoFlux, LatHeat, ct, cw */
+    double ub0, ub1;                    /* SlidingVelocity */
+    double br, lr;                      /* bump height / spacing */
+    double diffFactor;
+    double distributed_input;
+    double eps_picard;                  /* solver.eps_PicardIte */
+    int basal_friction;
+    int use_mask_rhs_b;
+} OrModelParams;
+
+enum { OM_H = 0, OM_B, OM_BOLD, OM_PI, OM_ZB, OM_MASK, OM_MR, OM_PW, OM_SRC, OM_RHSH, OM_CD,
+       OM_GRADX, OM_GRADY, OM_RE, OM_HLAG, OM_NCELL, OM_QWX = 100, OM_QWY = 101 };
+
+typedef struct OrModel {
+    OrLevel *L;
+    int nx, ny;
+    double dx, dy;
+    OrBC bc;
+    OrPhys ph;
+    OrModelParams mp;
+    double *c[OM_NCELL];                /* ghosted cell arrays */
+    double *gxf, *gyf, *zxf, *zyf;      /* face gradients of h and zb */
+    double *bxf, *byf, *rxf, *ryf;      /* B_ec, Re_ec */
+    double *qx, *qy;                    /* Qw_ec */
+    double *t1x, *t1y, *t2x, *t2y;      /* Qw*gradH, Qw*gradZb on faces */
+    int cur_step;
+    double time;
+} OrModel;
+
+#define NXG (M->nx + 2)
+#define CC(a, i, j) (a)[(size_t)((j) + 1) * NXG + ((i) + 1)]
+#define FX(a, i, j) (a)[(size_t)(j) * (M->nx + 1) + (i)]      /* x-faces: ny x (nx+1) */
+#define FY(a, i, j) (a)[(size_t)(j) * M->nx + (i)]            /* y-faces: (ny+1) x nx */
+
+OrModel *or_model_create(OrLevel *L, int nx, int ny, double dx, double dy, const OrBC *bc, const OrPhys *ph,
+                         const OrModelParams *mp)
+{
+    OrModel *M = (OrModel *)calloc(1, sizeof(OrModel));
+    M->L = L; M->nx = nx; M->ny = ny; M->dx = dx; M->dy = dy; M->bc = *bc; M->ph = *ph; M->mp = *mp;
+    size_t nc = (size_t)(nx + 2) * (ny + 2), nfx = (size_t)(nx + 1) * ny, nfy = (size_t)nx * (ny + 1);
+    for (int f = 0; f < OM_NCELL; f++) M->c[f] = (double *)calloc(nc, sizeof(double));
+    double **fxs[] = {&M->gxf, &M->zxf, &M->bxf, &M->rxf, &M->qx, &M->t1x, &M->t2x};
+    double **fys[] = {&M->gyf, &M->zyf, &M->byf, &M->ryf, &M->qy, &M->t1y, &M->t2y};
+    for (int k = 0; k < 7; k++) { *fxs[k] = (double *)calloc(nfx, sizeof(double)); *fys[k] = (double *)calloc(nfy, sizeof(double)); }
+    return M;
+}
+void or_model_destroy(OrModel *M)
+{
+    if (!M) return;
+    for (int f = 0; f < OM_NCELL; f++) free(M->c[f]);
+    free(M->gxf); free(M->gyf); free(M->zxf); free(M->zyf); free(M->bxf); free(M->byf); free(M->rxf); free(M->ryf);
+    free(M->qx); free(M->qy); free(M->t1x); free(M->t1y); free(M->t2x); free(M->t2y);
+    free(M);
+}
+double *or_model_field(OrModel *M, int id)
+{
+    if (id == OM_QWX) return M->qx;
+    if (id == OM_QWY) return M->qy;
+    return (id >= 0 && id < OM_NCELL) ? M->c[id] : NULL;
+}
+int or_model_step_index(const OrModel *M) { return M->cur_step; }
+
+/* exchange (periodic wrap) of a ghosted global array */
+static void wrap_ghosts(OrModel *M, double *a)
+{
+    if (M->bc.periodic[0]) for (int j = 0; j < M->ny; j++) { CC(a, -1, j) = CC(a, M->nx - 1, j); CC(a, M->nx, j) = CC(a, 0, j); }
+    if (M->bc.periodic[1]) for (int i = 0; i < M->nx; i++) { CC(a, i, -1) = CC(a, i, M->ny - 1); CC(a, i, M->ny) = CC(a, i, 0); }
+}
+/* exchange + mixBCValues (src/AmrHydro.cpp:248-309) */
+static void head_ghosts(OrModel *M, double *h)
+{
+    wrap_ghosts(M, h);
+    for (int dir = 0; dir < 2; dir++) {
+        if (M->bc.periodic[dir]) continue;
+        int n = dir == 0 ? M->ny : M->nx;
+        for (int side = 0; side < 2; side++) {
+            double isign = side == 0 ? -1.0 : 1.0, value = M->bc.value[dir][side];
+            for (int t = 0; t < n; t++) {
+                int ig, jg, in, jn;
+                if (dir == 0) { ig = side ? M->nx : -1; in = side ? M->nx - 1 : 0; jg = jn = t; }
+                else { jg = side ? M->ny : -1; jn = side ? M->ny - 1 : 0; ig = in = t; }
+                double nearVal = CC(h, in, jn);
+                if (M->bc.type[dir][side] == 0) CC(h, ig, jg) = 2.0 * value - nearVal;
+                else CC(h, ig, jg) = nearVal + isign * (dir == 0 ? M->dx : M->dy) * value;
+            }
+        }
+    }
+}
+/* exchange + CopyGhostCells (util/ExtrapGhostCells.cpp:182-269): ghost = nearest interior cell */
+static void copy_ghosts(OrModel *M, double *a)
+{
+    wrap_ghosts(M, a);
+    if (!M->bc.periodic[0]) for (int j = -1; j <= M->ny; j++) { CC(a, -1, j) = CC(a, 0, j); CC(a, M->nx, j) = CC(a, M->nx - 1, j); }
+    if (!M->bc.periodic[1]) for (int i = -1; i <= M->nx; i++) { CC(a, i, -1) = CC(a, i, 0); CC(a, i, M->ny) = CC(a, i, M->ny - 1); }
+}
+/* exchange + ExtrapGhostCells (:94-180): ghost = 2*near - far */
+static void extrap_ghosts(OrModel *M, double *a)
+{
+    wrap_ghosts(M, a);
+    if (!M->bc.periodic[0]) for (int j = -1; j <= M->ny; j++) {
+        CC(a, -1, j) = 2.0 * CC(a, 0, j) - CC(a, 1, j); CC(a, M->nx, j) = 2.0 * CC(a, M->nx - 1, j) - CC(a, M->nx - 2, j); }
+    if (!M->bc.periodic[1]) for (int i = -1; i <= M->nx; i++) {
+        CC(a, i, -1) = 2.0 * CC(a, i, 0) - CC(a, i, 1); CC(a, i, M->ny) = 2.0 * CC(a, i, M->ny - 1) - CC(a, i, M->ny - 2); }
+}
+
+/* Gradient::compGradientMAC, normal branch of NEWMACGRAD (util/GradientF.ChF:57-70) */
+static void mac_grad(OrModel *M, const double *phi, double *gx, double *gy)
+{
+    const double *mask = M->c[OM_MASK];
+    int hm = M->ph.use_mask_gradients;
+    double f0 = 1.0 / M->dx, f1 = 1.0 / M->dy;
+    for (int j = 0; j < M->ny; j++)
+        for (int i = 0; i <= M->nx; i++) {
+            double v = f0 * (CC(phi, i, j) - CC(phi, i - 1, j));
+            if (hm && ((CC(mask, i, j) < 1e-6) || (CC(mask, i - 1, j) < 1e-6))) v = 0.0;
+            FX(gx, i, j) = v;
+        }
+    for (int j = 0; j <= M->ny; j++)
+        for (int i = 0; i < M->nx; i++) {
+            double v = f1 * (CC(phi, i, j) - CC(phi, i, j - 1));
+            if (hm && ((CC(mask, i, j) < 1e-6) || (CC(mask, i, j - 1) < 1e-6))) v = 0.0;
+            FY(gy, i, j) = v;
+        }
+}
+/* CellToEdge [Chombo]: face = half*(cell(i) + cell(i-e)) on the valid faces */
+static void cell_to_edge(OrModel *M, const double *c, double *fx, double *fy)
+{
+    for (int j = 0; j < M->ny; j++) for (int i = 0; i <= M->nx; i++) FX(fx, i, j) = 0.5 * (CC(c, i, j) + CC(c, i - 1, j));
+    for (int j = 0; j <= M->ny; j++) for (int i = 0; i < M->nx; i++) FY(fy, i, j) = 0.5 * (CC(c, i, j) + CC(c, i, j - 1));
+}
+
+/* compute_grad_head (:1610-1674) / evaluate_Re_quadratic (:1711-1778) / evaluate_Qw_ec (:1677-1709) */
+static void grad_re_qw(OrModel *M)
+{
+    double *h = M->c[OM_H], *B = M->c[OM_B], *gx = M->c[OM_GRADX], *gy = M->c[OM_GRADY], *Re = M->c[OM_RE];
+    mac_grad(M, h, M->gxf, M->gyf);
+    for (int j = 0; j < M->ny; j++)
+        for (int i = 0; i < M->nx; i++) {              /* EdgeToCell */
+            CC(gx, i, j) = 0.5 * (FX(M->gxf, i, j) + FX(M->gxf, i + 1, j));
+            CC(gy, i, j) = 0.5 * (FY(M->gyf, i, j) + FY(M->gyf, i, j + 1));
+        }
+    extrap_ghosts(M, gx); extrap_ghosts(M, gy);
+    for (int j = -1; j <= M->ny; j++)
+        for (int i = -1; i <= M->nx; i++) {            /* COMPUTERE on the ghosted box, AmrHydroF.ChF:92-109 */
+            double s = sqrt(CC(gx, i, j) * CC(gx, i, j) + CC(gy, i, j) * CC(gy, i, j));
+            double b = CC(B, i, j);
+            double discr = 1.0 + 4.0 * M->ph.omega * (b * b * b * M->ph.grav * s) / (12.0 * M->ph.nu * M->ph.nu);
+            CC(Re, i, j) = (-1.0 + sqrt(discr)) / (2.0 * M->ph.omega);
+        }
+    cell_to_edge(M, Re, M->rxf, M->ryf);
+    /* COMPUTEQW, AmrHydroF.ChF:137-150 */
+    for (int j = 0; j < M->ny; j++) for (int i = 0; i <= M->nx; i++) {
+        double b = FX(M->bxf, i, j);
+        double num_q = -(b * b * b * M->ph.grav * FX(M->gxf, i, j));
+        double denom_q = 12.0 * M->ph.nu * (1.0 + M->ph.omega * FX(M->rxf, i, j));
+        FX(M->qx, i, j) = num_q / denom_q;
+    }
+    for (int j = 0; j <= M->ny; j++) for (int i = 0; i < M->nx; i++) {
+        double b = FY(M->byf, i, j);
+        double num_q = -(b * b * b * M->ph.grav * FY(M->gyf, i, j));
+        double denom_q = 12.0 * M->ph.nu * (1.0 + M->ph.omega * FY(M->ryf, i, j));
+        FY(M->qy, i, j) = num_q / denom_q;
+    }
+}
+
+/* COMPUTESCAPROD + EdgeToCell + Calc_meltingRate (:2954-2979, :2174-2252) on valid cells */
+static void melting_rate(OrModel *M)
+{
+    const OrModelParams *p = &M->mp;
+    double *h = M->c[OM_H], *zb = M->c[OM_ZB], *Pw = M->c[OM_PW], *Pi = M->c[OM_PI], *B = M->c[OM_B], *mR = M->c[OM_MR], *IM = M->c[OM_MASK];
+    for (int j = 0; j < M->ny; j++) for (int i = 0; i <= M->nx; i++) {
+        FX(M->t1x, i, j) = FX(M->qx, i, j) * FX(M->gxf, i, j); FX(M->t2x, i, j) = FX(M->qx, i, j) * FX(M->zxf, i, j); }
+    for (int j = 0; j <= M->ny; j++) for (int i = 0; i < M->nx; i++) {
+        FY(M->t1y, i, j) = FY(M->qy, i, j) * FY(M->gyf, i, j); FY(M->t2y, i, j) = FY(M->qy, i, j) * FY(M->zyf, i, j); }
+    for (int j = 0; j < M->ny; j++)
+        for (int i = 0; i < M->nx; i++) {
+            double t0 = 0.5 * (FX(M->t1x, i, j) + FX(M->t1x, i + 1, j)), t1 = 0.5 * (FY(M->t1y, i, j) + FY(M->t1y, i, j + 1));
+            double u0 = 0.5 * (FX(M->t2x, i, j) + FX(M->t2x, i + 1, j)), u1 = 0.5 * (FY(M->t2y, i, j) + FY(M->t2y, i, j + 1));
+            CC(Pw, i, j) = p->gravity * p->rho_w * (CC(h, i, j) - CC(zb, i, j));                     /* :2215 */
+            double sca_prod = 0.0;
+            if (p->basal_friction) sca_prod = 20. * 20. * p->ub0 * fabs(CC(Pi, i, j) - CC(Pw, i, j)) * p->ub0;   /* :2220 */
+            double abs_QPw = t0 + t1 - (u0 + u1);                                                   /* :2225 */
+            if ((abs_QPw < 0) && (CC(B, i, j) < 1e-6)) abs_QPw = 0.0;
+            double m = p->G + sca_prod - p->rho_w * p->gravity * (t0 + t1)
+                       + p->ct * p->cw * p->rho_w * p->rho_w * p->gravity * abs_QPw;                  /* :2231-2234 */
+            m = m / p->L;
+            m = fmax(m, 0.0);
+            if (CC(IM, i, j) < 0.0) m = 0.0;
+            CC(mR, i, j) = m;
+        }
+}
+
+static double max_valid(OrModel *M, const double *a)
+{
+    double m = -1e300;
+    for (int j = 0; j < M->ny; j++) for (int i = 0; i < M->nx; i++) if (CC(a, i, j) > m) m = CC(a, i, j);
+    return m;
+}
+
+/* one timestep; returns 0, or -1 if the Picard loop exceeds 100 iterations (:3190-3195) */
+int or_model_timestep(OrModel *M, double dt, int *picard_iters, int *vcycles_total)
+{
+    const OrModelParams *p = &M->mp;
+    int nx = M->nx, ny = M->ny;
+    double *h = M->c[OM_H], *B = M->c[OM_B], *Bold = M->c[OM_BOLD], *IM = M->c[OM_MASK], *src = M->c[OM_SRC];
+    double *rhs = M->c[OM_RHSH], *mR = M->c[OM_MR], *hl = M->c[OM_HLAG], *Pi = M->c[OM_PI], *Pw = M->c[OM_PW], *CD = M->c[OM_CD];
+    size_t nc = (size_t)(nx + 2) * (ny + 2);
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)nx * ny);
+    M->cur_step += 1;                                                        /* :2259 */
+    /* [I] :2360-2445 */
+    head_ghosts(M, h); copy_ghosts(M, B);
+    memcpy(Bold, B, nc * sizeof(double));
+    mac_grad(M, M->c[OM_ZB], M->zxf, M->zyf);                                /* compute_grad_zb_ec :1577-1608 (zb is static) */
+    OrSolverParams sp;                                                       /* SolveForHead_nl :737-762 */
+    sp.num_smooth = 4; sp.num_bottom = 16; sp.max_iter = 100; sp.iter_min = 2; sp.imin = 5;
+    sp.eps = 1.0e-7; sp.hang = 0.01; sp.norm_thresh = 1.0e-7; sp.bcoeff_otf = 1; sp.max_depth = -1;
+    if (M->cur_step < 50) { sp.num_bottom = 10; sp.eps = 1.0e-10; sp.hang = 0.0001; sp.imin = 20; }
+    int converged = 0, ite_idx = 0, cur_picard = 0, nv = 0;
+    while (!converged) {                                                     /* [II] :2477 */
+        head_ghosts(M, h); copy_ghosts(M, B);
+        memcpy(hl, h, nc * sizeof(double));
+        cell_to_edge(M, B, M->bxf, M->byf);
+        grad_re_qw(M);
+        for (int j = -1; j <= ny; j++) for (int i = -1; i <= nx; i++)       /* distributed input :2865-2877 */
+            CC(src, i, j) = (CC(IM, i, j) > 0.0) ? p->distributed_input : 0.0;
+        melting_rate(M);
+        double rho_coef = (1.0 / p->rho_w - 1.0 / p->rho_i);                 /* :3023 */
+        {   /* diagnosis knob (tools/run_shmip_a.py --head-melt-coef, DESIGN.md "end-to-end pin"): scales the melt
+             * term of RHS_h; unset = the reference's source as it is */
+            const char *e = getenv("SUHMO_ORACLE_HEAD_MELT_COEF");
+            if (e) rho_coef *= atof(e);
+        }
+        double ub_norm = sqrt(p->ub0 * p->ub0 + p->ub1 * p->ub1);            /* magVel, SqrtIBC.cpp:280-281 */
+        for (int j = 0; j < ny; j++)
+            for (int i = 0; i < nx; i++) {                                   /* :3044-3077 */
+                double r = CC(mR, i, j) * rho_coef;
+                if (CC(B, i, j) < p->br) r -= ub_norm * (p->br - CC(B, i, j)) / p->lr;
+                r += CC(src, i, j);
+                if (CC(IM, i, j) < 0.0) r = 0.0;
+                CC(rhs, i, j) = r;
+            }
+        /* SolveForHead_nl: fields into the operator (factory define), solve */
+        for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) tmp[(size_t)j * nx + i] = CC(h, i, j);
+        or_level_set(M->L, 0, OR_F_PHI, tmp, 0);
+        for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) tmp[(size_t)j * nx + i] = CC(rhs, i, j);
+        or_level_set(M->L, 0, OR_F_RHS, tmp, 0);
+        or_level_set(M->L, 0, OR_F_B, B, 1);
+        or_level_build_mg_coefficients(M->L);
+        nv += or_level_solve(M->L, &sp, NULL);
+        or_level_get(M->L, 0, OR_F_PHI, tmp, 0);
+        for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) CC(h, i, j) = tmp[(size_t)j * nx + i];
+        head_ghosts(M, h);                                                   /* :3157-3165 */
+        double maxHead = max_valid(M, h), res = 0.0;                         /* :3169-3185 */
+        for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) {
+            double d = fabs((CC(hl, i, j) - CC(h, i, j)) / maxHead);
+            if (d > res) res = d;
+        }
+        if (ite_idx > 100) { free(tmp); return -1; }
+        if (M->cur_step < 2) { if (res < 0.05 && cur_picard > 2) converged = 1; }
+        else if (M->cur_step < 50) { if (res < 0.05) converged = 1; }
+        else { if (res < p->eps_picard) converged = 1; }
+        ite_idx++; cur_picard++;
+    }
+    /* [III] :3238-3421 */
+    grad_re_qw(M);                                    /* evaluate_Re_quadratic(lev, true) + evaluate_Qw_ec with the lagged B_ec */
+    melting_rate(M);
+    {
+        double ub_norm = sqrt(p->ub0 * p->ub0 + p->ub1 * p->ub1);
+        for (int j = 0; j < ny; j++)
+            for (int i = 0; i < nx; i++) {            /* CalcRHS_gapHeightFAS :2069-2171 */
+                double b = CC(B, i, j);
+                double RHS = CC(mR, i, j) * (1.0 / p->rho_i), RHS_A = RHS, RHS_B = 0.0;
+                if ((CC(IM, i, j) < 0.0) && p->use_mask_rhs_b) { RHS = 0.0; CC(CD, i, j) = 0.0; }
+                else {
+                    if (b < p->br) { RHS += ub_norm * (p->br - b) / p->lr; RHS_B = ub_norm * (p->br - b) / p->lr; }
+                    double PimPw = CC(Pi, i, j) - CC(Pw, i, j), AbsPimPw = fabs(PimPw);
+                    if (M->ph.cutOffbr > b) RHS -= M->ph.A * (AbsPimPw * AbsPimPw) * PimPw * b * (1.0 - (M->ph.cutOffbr - b) / M->ph.cutOffbr);
+                    else if (M->ph.maxOffbr < b) RHS -= M->ph.A * (AbsPimPw * AbsPimPw) * PimPw * b * (1.0 - (M->ph.maxOffbr - b) / M->ph.maxOffbr);
+                    else RHS -= M->ph.A * (AbsPimPw * AbsPimPw) * PimPw * b;
+                    CC(CD, i, j) = RHS_A / (RHS_A + RHS_B);
+                }
+                CC(B, i, j) = RHS * dt + CC(Bold, i, j);     /* forward Euler :3406 */
+            }
+    }
+    copy_ghosts(M, B);                                /* :3419-3420 */
+    M->time += dt;
+    if (picard_iters) *picard_iters = ite_idx;
+    if (vcycles_total) *vcycles_total = nv;
+    free(tmp);
+    return 0;
+}

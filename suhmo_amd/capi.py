@@ -33,6 +33,14 @@ class SolverParams(C.Structure):
                 ("norm_thresh", C.c_double), ("bcoeff_otf", C.c_int), ("max_depth", C.c_int)]
 
 
+class ModelParams(C.Structure):
+    _fields_ = [("rho_i", C.c_double), ("rho_w", C.c_double), ("gravity", C.c_double), ("G", C.c_double),
+                ("L", C.c_double), ("ct", C.c_double), ("cw", C.c_double), ("ub0", C.c_double), ("ub1", C.c_double),
+                ("br", C.c_double), ("lr", C.c_double), ("diffFactor", C.c_double),
+                ("distributed_input", C.c_double), ("eps_picard", C.c_double),
+                ("basal_friction", C.c_int), ("use_mask_rhs_b", C.c_int)]
+
+
 class LevelDesc(C.Structure):
     _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("j0", C.c_int), ("ny_global", C.c_int),
                 ("dx", C.c_double), ("dy", C.c_double), ("nbox", C.c_int), ("boxes", C.POINTER(C.c_int)),
@@ -55,7 +63,9 @@ SYMBOLS = [
     "suhmo_level_divergence", "suhmo_level_get_flux", "suhmo_level_norm", "suhmo_level_axby",
     "suhmo_level_set_value", "suhmo_level_vcycle", "suhmo_level_solve", "suhmo_level_pack_rows",
     "suhmo_level_unpack_rows", "suhmo_level_set_hooks", "suhmo_level_exchange", "suhmo_level_halo_info", "suhmo_level_profile_reset",
-    "suhmo_level_profile_enable", "suhmo_level_profile_read",
+    "suhmo_level_profile_enable", "suhmo_level_profile_read", "suhmo_level_timestep",
+    "suhmo_rccl_load", "suhmo_rccl_unique_id", "suhmo_level_attach_rccl", "suhmo_level_detach_rccl",
+    "suhmo_level_rccl_exchanges",
 ]
 
 
@@ -106,6 +116,13 @@ def lib():
     L.suhmo_level_set_hooks.argtypes = [vp, EXCHANGE_FN, ALLREDUCE_FN, vp]
     L.suhmo_level_exchange.argtypes = [vp, ci, ci, vp]
     L.suhmo_level_halo_info.argtypes = [vp, ci] + [C.POINTER(ci)] * 5
+    L.suhmo_level_timestep.argtypes = [vp, C.POINTER(ModelParams), C.c_double, ci, C.POINTER(ci), C.POINTER(ci), vp]
+    L.suhmo_rccl_load.argtypes = [C.c_char_p]
+    L.suhmo_rccl_unique_id.argtypes = [vp]
+    L.suhmo_level_attach_rccl.argtypes = [vp, vp, ci, ci, ci, vp]
+    L.suhmo_level_detach_rccl.argtypes = [vp]
+    L.suhmo_level_rccl_exchanges.argtypes = [vp]
+    L.suhmo_level_rccl_exchanges.restype = C.c_long
     L.suhmo_level_profile_reset.argtypes = [vp]
     L.suhmo_level_profile_enable.argtypes = [vp, ci]
     L.suhmo_level_profile_read.argtypes = [vp, vp, dp, C.POINTER(C.c_long), C.POINTER(C.c_long)]

@@ -137,6 +137,7 @@ struct suhmo_level {
     suhmo_exchange_fn ex;
     suhmo_allreduce_max_fn ar;
     void *user;
+    void *rccl;                 // native transport state (suhmo_rccl.hip), owned by the level
     int prof_on;
     std::vector<ProfEv> prof;
     int gsrb_variant;           // kernel selection (see suhmo_gsrb.hip); env SUHMO_GSRB_VARIANT

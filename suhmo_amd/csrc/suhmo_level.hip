@@ -148,6 +148,7 @@ extern "C" int suhmo_level_destroy(suhmo_level_t *L)
     if (!L) return 0;
     (void)hipSetDevice(L->device);
     (void)hipDeviceSynchronize();
+    if (L->rccl) (void)suhmo_level_detach_rccl(L);
     for (int dep = 0; dep < L->ndepth; dep++)
         for (int f = 0; f < SUHMO_F_COUNT; f++)
             if (L->d[dep].fp.f[f]) (void)hipFree(L->d[dep].fp.f[f]);
@@ -197,7 +198,7 @@ extern "C" int suhmo_level_halo_info(const suhmo_level_t *L, int depth, int *hal
 }
 
 // ------------------------------------------------------------------ LevelData traffic
-static bool is_face(int f) { return f == SUHMO_F_BX || f == SUHMO_F_BY; }
+static bool is_face(int f) { return f == SUHMO_F_BX || f == SUHMO_F_BY || f == SUHMO_F_QWX || f == SUHMO_F_QWY; }
 #define CHECK_DF(L, depth, field) ARG(L); ARG(depth >= 0 && depth < L->ndepth); ARG(field >= 0 && field < SUHMO_F_COUNT)
 
 extern "C" int suhmo_level_field_view(suhmo_level_t *L, int depth, int field, double **base, long *pitch, long *origin)
@@ -232,8 +233,8 @@ static int field_io(suhmo_level *L, int depth, int field, double *buf, int ghost
 {
     const DV &v = L->d[depth].v;
     int rc;
-    if (field == SUHMO_F_BX) rc = copy2d(L, depth, field, buf, v.nx + 1, 0, 0, v.nx + 1, v.ny, set, on_device, st);
-    else if (field == SUHMO_F_BY) rc = copy2d(L, depth, field, buf, v.nx, 0, 0, v.nx, v.ny + 1, set, on_device, st);
+    if (field == SUHMO_F_BX || field == SUHMO_F_QWX) rc = copy2d(L, depth, field, buf, v.nx + 1, 0, 0, v.nx + 1, v.ny, set, on_device, st);
+    else if (field == SUHMO_F_BY || field == SUHMO_F_QWY) rc = copy2d(L, depth, field, buf, v.nx, 0, 0, v.nx, v.ny + 1, set, on_device, st);
     else if (ghosted) rc = copy2d(L, depth, field, buf, v.nx + 2, -1, -1, v.nx + 2, v.ny + 2, set, on_device, st);
     else rc = copy2d(L, depth, field, buf, v.nx, 0, 0, v.nx, v.ny, set, on_device, st);
     if (rc) return rc;
@@ -262,8 +263,8 @@ static void box_region(const suhmo_level *L, int depth, int field, int ibox, int
     const int *b = &L->boxes[4 * (size_t)ibox];
     int c = 1 << depth;
     r[0] = b[0] / c; r[1] = b[1] / c - L->d[depth].v.j0; r[2] = (b[2] + 1) / c - 1; r[3] = (b[3] + 1) / c - 1 - L->d[depth].v.j0;
-    if (field == SUHMO_F_BX) r[2] += 1;
-    if (field == SUHMO_F_BY) r[3] += 1;
+    if (field == SUHMO_F_BX || field == SUHMO_F_QWX) r[2] += 1;
+    if (field == SUHMO_F_BY || field == SUHMO_F_QWY) r[3] += 1;
 }
 
 extern "C" int suhmo_level_put_box(suhmo_level_t *L, int depth, int field, int ibox, const double *fab,
@@ -830,6 +831,20 @@ extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_st
     return 0;
 }
 
+// grad h (cell centred, extrapolated ghosts) and Re on the ghosted level, for the time step
+// (suhmo_step.hip): the un-fused steps 1-3 above
+int suhmo_grad_re(suhmo_level *L, int depth, hipStream_t st)
+{
+    Depth &D = L->d[depth];
+    if (!suhmo_field(L, depth, SUHMO_F_GRADX) || !suhmo_field(L, depth, SUHMO_F_GRADY) || !suhmo_field(L, depth, SUHMO_F_RE)) return -2;
+    hipLaunchKernelGGL(k_gradcc, grid2d(D.v.nx, D.v.ny), BLK2D, 0, st, D.v, D.fp, L->ph.use_mask_gradients);
+    int n = 2 * D.v.ny + 2 * D.v.nx;
+    hipLaunchKernelGGL(k_grad_ghosts, dim3((n + 255) / 256), dim3(256), 0, st, D.v, D.fp.f[SUHMO_F_GRADX], D.fp.f[SUHMO_F_GRADY]);
+    hipLaunchKernelGGL(k_re, grid2d(D.v.nx + 2, D.v.ny + 2), BLK2D, 0, st, D.v, D.fp, L->ph);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // AverageOperator: CoarseAverageFace(bCoef[0] -> bCoef[depth], ratio r = 2^depth), sequential
 // sum of the r collinear fine faces divided by r  (src/VCAMRNonLinearPoissonOp.cpp:66-95)
 __global__ void k_average_faces(DV vf, const double *__restrict__ bxf, const double *__restrict__ byf,
@@ -963,6 +978,17 @@ __global__ void k_coef_ghosts(DV v, double *__restrict__ p)
         if (side == 0) { int idx = cidx(v, i, 0); p[idx - v.P] = v.per[1] ? p[idx + (v.ny - 1) * v.P] : p[idx]; }
         else { int idx = cidx(v, i, v.ny - 1); p[idx + v.P] = v.per[1] ? p[idx - (v.ny - 1) * v.P] : p[idx]; }
     }
+}
+// exchange + CopyGhostCells of a cell field (util/ExtrapGhostCells.cpp:182-269)
+int suhmo_copy_ghosts(suhmo_level *L, int depth, int field, hipStream_t st)
+{
+    Depth &D = L->d[depth];
+    double *p = suhmo_field(L, depth, field);
+    if (!p) return -2;
+    int n = 2 * D.v.ny + 2 * D.v.nx;
+    hipLaunchKernelGGL(k_coef_ghosts, dim3((n + 255) / 256), dim3(256), 0, st, D.v, p);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 extern "C" int suhmo_level_build_mg_coefficients(suhmo_level_t *L, suhmo_stream_t s)
 {

@@ -1,0 +1,211 @@
+// suhmo_rccl.hip -- native strip-halo transport: RCCL point-to-point over xGMI, enqueued on the
+// same HIP stream as the kernels (no host round trip per exchange).
+//
+// Replaces, for a level cut into row strips (one process per GPU), what the reference does with
+// LevelData::exchange over MPI (src/VCAMRNonLinearPoissonOp.cpp:47,124,304,405,692,751) and the
+// MPI_Allreduce inside norm() (src/AMRNonLinearPoissonOp.cpp:1222-1264): per exchange
+//   1 pack kernel (all fields, both sides) -> ncclGroup{send hi, send lo, recv lo, recv hi} -> 1 unpack kernel.
+// librccl is NOT a link dependency: it is dlopen'ed (the copy PyTorch already loaded, when the host is
+// Python), so a single-GPU user never needs it.  The communicator is created from an id the host
+// distributes (torch.distributed broadcast in suhmo_amd/multigpu.py; MPI_Bcast in a Chombo build).
+#include "suhmo_common.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+struct Fns {
+    void *dl = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+} g;
+
+constexpr int MAXF = 8;           // fields per message
+struct Strip {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, lo = -1, hi = -1;
+    hipStream_t st = nullptr;     // stream of the norm all-reduce (the hook carries none)
+    double *buf[SUHMO_MAXDEPTH][4] = {};   // send lo, send hi, recv lo, recv hi
+    double *dscalar = nullptr;
+    long exchanges = 0;
+};
+struct PackList { double *p[MAXF]; int pack_lo[MAXF], pack_hi[MAXF], unpack_lo[MAXF], unpack_hi[MAXF]; int n; };
+
+#define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { \
+    suhmo_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #x, g.GetErrorString ? g.GetErrorString(r_) : "rccl error"); return -7; } } while (0)
+
+// rows travel (nx + 1) wide (x-face rows whole); z = 2 * field + side
+__global__ void k_pack_multi(DV v, PackList pl, int rows, double *__restrict__ blo, double *__restrict__ bhi)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y * blockDim.y + threadIdx.y;
+    int q = blockIdx.z >> 1, side = blockIdx.z & 1;
+    double *b = side ? bhi : blo;
+    if (i > v.nx || r >= rows || !b) return;
+    int j = (side ? pl.pack_hi[q] : pl.pack_lo[q]) + r;
+    b[((size_t)q * rows + r) * (v.nx + 1) + i] = pl.p[q][cidx(v, i, j)];
+}
+__global__ void k_unpack_multi(DV v, PackList pl, int rows, const double *__restrict__ blo, const double *__restrict__ bhi)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y * blockDim.y + threadIdx.y;
+    int q = blockIdx.z >> 1, side = blockIdx.z & 1;
+    const double *b = side ? bhi : blo;
+    if (i > v.nx || r >= rows || !b) return;
+    int j = (side ? pl.unpack_hi[q] : pl.unpack_lo[q]) + r;
+    pl.p[q][cidx(v, i, j)] = b[((size_t)q * rows + r) * (v.nx + 1) + i];
+}
+
+int exchange_hook(void *user, suhmo_level_t *L, int depth, const int *fields, int nfields, suhmo_stream_t s)
+{
+    Strip *S = (Strip *)user;
+    hipStream_t st = (hipStream_t)s;
+    const DV &v = L->d[depth].v;
+    const int rows = v.gy < v.ny ? v.gy : v.ny;
+    const size_t n = (size_t)rows * (v.nx + 1);
+    double **B = S->buf[depth];
+    for (int f0 = 0; f0 < nfields; f0 += MAXF) {
+        PackList pl;
+        pl.n = nfields - f0 < MAXF ? nfields - f0 : MAXF;
+        for (int q = 0; q < pl.n; q++) {
+            int f = fields[f0 + q];
+            pl.p[q] = suhmo_field(L, depth, f);
+            if (!pl.p[q]) { suhmo_set_error("field allocation failed"); return -2; }
+            // owned rows next to each side / ghost rows of each side, ascending j.  y-faces: face row 0 of
+            // a strip IS face row ny of the lower neighbour (both own it): the rows the lower neighbour
+            // lacks start at face row 1 and land from face row ny + 1 (as suhmo_level_pack/unpack_rows)
+            pl.pack_lo[q] = f == SUHMO_F_BY ? 1 : 0;
+            pl.pack_hi[q] = v.ny - rows;
+            pl.unpack_lo[q] = -rows;
+            pl.unpack_hi[q] = f == SUHMO_F_BY ? v.ny + 1 : v.ny;
+        }
+        dim3 blk(64, 4), grd((v.nx + 1 + 63) / 64, (rows + 3) / 4, 2 * pl.n);
+        hipLaunchKernelGGL(k_pack_multi, grd, blk, 0, st, v, pl, rows, S->lo >= 0 ? B[0] : nullptr, S->hi >= 0 ? B[1] : nullptr);
+        HIPCHK(hipGetLastError());
+        const size_t cnt = n * pl.n;
+        // order matters when lo == hi (2 ranks, periodic; or a rank that is its own neighbour):
+        // to-hi before to-lo, from-lo before from-hi
+        NCCLCHK(g.GroupStart());
+        if (S->hi >= 0) NCCLCHK(g.Send(B[1], cnt, ncclFloat64, S->hi, S->comm, st));
+        if (S->lo >= 0) NCCLCHK(g.Send(B[0], cnt, ncclFloat64, S->lo, S->comm, st));
+        if (S->lo >= 0) NCCLCHK(g.Recv(B[2], cnt, ncclFloat64, S->lo, S->comm, st));
+        if (S->hi >= 0) NCCLCHK(g.Recv(B[3], cnt, ncclFloat64, S->hi, S->comm, st));
+        NCCLCHK(g.GroupEnd());
+        hipLaunchKernelGGL(k_unpack_multi, grd, blk, 0, st, v, pl, rows, S->lo >= 0 ? B[2] : nullptr, S->hi >= 0 ? B[3] : nullptr);
+        HIPCHK(hipGetLastError());
+        S->exchanges++;
+    }
+    return 0;
+}
+
+int allreduce_hook(void *user, double *value)
+{
+    Strip *S = (Strip *)user;
+    HIPCHK(hipMemcpyAsync(S->dscalar, value, sizeof(double), hipMemcpyHostToDevice, S->st));
+    NCCLCHK(g.AllReduce(S->dscalar, S->dscalar, 1, ncclFloat64, ncclMax, S->comm, S->st));
+    HIPCHK(hipMemcpyAsync(value, S->dscalar, sizeof(double), hipMemcpyDeviceToHost, S->st));
+    HIPCHK(hipStreamSynchronize(S->st));
+    return 0;
+}
+}  // namespace
+
+// RCCL must sit on the SAME HIP runtime instance as this library (streams and buffers cross the call): a
+// process can hold two (ROCm's and the copy PyTorch ships, whichever was mapped first serves us).  With no
+// explicit path, take the librccl that lives next to the libamdhip64 this library is bound to.
+extern "C" int suhmo_rccl_load(const char *path)
+{
+    if (g.dl) return 0;
+    void *dl = nullptr;
+    std::string tried;
+    if (path && path[0]) { dl = dlopen(path, RTLD_NOW | RTLD_GLOBAL); tried = path; }
+    else {
+        Dl_info info;
+        std::string dir;
+        if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+            dir = info.dli_fname;
+            size_t k = dir.rfind('/');
+            dir = k == std::string::npos ? std::string() : dir.substr(0, k + 1);
+        }
+        const char *names[] = {"librccl.so", "librccl.so.1"};
+        for (int pass = 0; pass < 2 && !dl; pass++)
+            for (const char *nm : names) {
+                std::string cand = (pass == 0 ? dir : std::string()) + nm;
+                if (pass == 0 && dir.empty()) continue;
+                dl = dlopen(cand.c_str(), RTLD_NOW | RTLD_GLOBAL);
+                tried += cand + " ";
+                if (dl) break;
+            }
+    }
+    if (!dl) { suhmo_set_error("dlopen(%s) failed: %s", tried.c_str(), dlerror()); return -7; }
+#define SYM(field, name) do { g.field = (decltype(g.field))dlsym(dl, name); \
+    if (!g.field) { suhmo_set_error("librccl lacks %s", name); return -7; } } while (0)
+    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+    SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
+    SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g.dl = dl;
+    return 0;
+}
+
+extern "C" int suhmo_rccl_unique_id(void *id128)
+{
+    ARG(id128);
+    if (!g.dl) { suhmo_set_error("suhmo_rccl_load first"); return -7; }
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    NCCLCHK(g.GetUniqueId((ncclUniqueId *)id128));
+    return 0;
+}
+
+extern "C" int suhmo_level_detach_rccl(suhmo_level_t *L)
+{
+    ARG(L);
+    Strip *S = (Strip *)L->rccl;
+    if (!S) return 0;
+    (void)hipSetDevice(L->device);
+    (void)hipDeviceSynchronize();
+    for (int d = 0; d < SUHMO_MAXDEPTH; d++) for (int k = 0; k < 4; k++) if (S->buf[d][k]) (void)hipFree(S->buf[d][k]);
+    if (S->dscalar) (void)hipFree(S->dscalar);
+    if (S->comm && g.CommDestroy) (void)g.CommDestroy(S->comm);
+    if (L->user == S) { L->ex = nullptr; L->ar = nullptr; L->user = nullptr; }
+    delete S;
+    L->rccl = nullptr;
+    return 0;
+}
+
+// collective over the `world` ranks that own the strips of this level (rank r owns rows [j0, j0 + ny),
+// strips ordered by rank); periodic_y: the first and last strip are neighbours
+extern "C" int suhmo_level_attach_rccl(suhmo_level_t *L, const void *id128, int rank, int world, int periodic_y, suhmo_stream_t s)
+{
+    ARG(L && id128); ARG(world >= 1 && rank >= 0 && rank < world);
+    if (!g.dl) { suhmo_set_error("suhmo_rccl_load first"); return -7; }
+    if (L->rccl) { suhmo_set_error("level already attached"); return -1; }
+    HIPCHK(hipSetDevice(L->device));
+    Strip *S = new Strip;
+    S->rank = rank; S->world = world; S->st = (hipStream_t)s;
+    S->lo = rank > 0 ? rank - 1 : (periodic_y ? world - 1 : -1);
+    S->hi = rank < world - 1 ? rank + 1 : (periodic_y ? 0 : -1);
+    L->rccl = S;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = g.CommInitRank(&S->comm, world, id, rank);
+    if (r != ncclSuccess) { suhmo_set_error("ncclCommInitRank -> %s", g.GetErrorString(r)); S->comm = nullptr; suhmo_level_detach_rccl(L); return -7; }
+    for (int d = 0; d < L->ndepth; d++) {
+        const DV &v = L->d[d].v;
+        int rows = v.gy < v.ny ? v.gy : v.ny;
+        size_t cap = (size_t)MAXF * rows * (v.nx + 1) * sizeof(double);
+        for (int k = 0; k < 4; k++)
+            if (hipMalloc(&S->buf[d][k], cap) != hipSuccess) { suhmo_set_error("halo buffer allocation failed"); suhmo_level_detach_rccl(L); return -2; }
+    }
+    if (hipMalloc(&S->dscalar, sizeof(double)) != hipSuccess) { suhmo_level_detach_rccl(L); return -2; }
+    L->ex = exchange_hook; L->ar = allreduce_hook; L->user = S;
+    return 0;
+}
+
+extern "C" long suhmo_level_rccl_exchanges(const suhmo_level_t *L)
+{
+    return (L && L->rccl) ? ((Strip *)L->rccl)->exchanges : -1;
+}

@@ -1,0 +1,226 @@
+// suhmo_step.hip -- the caller of the head solve, device resident: one AmrHydro::timeStepFAS
+// (src/AmrHydro.cpp:2254-3460) for a single level, distributed water input (n_moulins < 0),
+// explicit gap-height update (solver.use_ImplDiff = false).  "Next rows" of SURVEY.md 8(f).
+//
+//   [II]  Picard loop (:2477-3235): ghosts of h and b -> grad h (compute_grad_head :1610-1674) ->
+//         Re (evaluate_Re_quadratic :1711-1778) -> Qw on faces (evaluate_Qw_ec :1677-1709, COMPUTEQW)
+//         -> Qw.grad(h), Qw.grad(zb) (COMPUTESCAPROD + EdgeToCell :2954-2979) -> melt rate
+//         (Calc_meltingRate :2174-2252) -> RHS_h (:3031-3078) -> SolveForHead_nl -> Picard test
+//   [III] the same chain with the new head, CalcRHS_gapHeightFAS (:2069-2171), forward Euler (:3406)
+// Head = PHI, gap height = B: both stay in HBM across Picard iterations and timesteps; per step
+// the host sees two scalars per Picard iteration (max head, max relative change).
+// The diffusive term (suhmo.diffFactor, COMPUTEDIFTERM2D) is not built: diffFactor must be 0.
+#include "suhmo_common.h"
+#include <cmath>
+
+// Qw on x- and y-faces: B_ec, Re_ec by CellToEdge (half*(cell + lower cell)), grad h by NEWMACGRAD
+// with the physical BC applied on the fly, COMPUTEQW (src/AmrHydroF.ChF:137-150)
+__device__ __forceinline__ double face_grad(const DV &v, const double *__restrict__ phi, const double *__restrict__ mk,
+                                            int i, int j, int dir, int hasMask)
+{
+    // face (i,j) of direction dir lies between cell (i,j) and (i-1,j) / (i,j-1)
+    double hi, lo;
+    if (dir == 0) {
+        if (i < v.nx) { int idx = cidx(v, i, j); hi = phi[idx]; lo = phiW(v, phi, idx, i, hi, false); }
+        else { int idx = cidx(v, v.nx - 1, j); lo = phi[idx]; hi = phiE(v, phi, idx, v.nx - 1, lo, false); }
+    } else {
+        if (j < v.ny) { int idx = cidx(v, i, j); hi = phi[idx]; lo = phiS(v, phi, idx, j, hi, false); }
+        else { int idx = cidx(v, i, v.ny - 1); lo = phi[idx]; hi = phiN(v, phi, idx, v.ny - 1, lo, false); }
+    }
+    double g = (dir == 0 ? v.fdx : v.fdy) * (hi - lo);
+    if (hasMask) {
+        int idx = cidx(v, i, j), idm = dir == 0 ? idx - 1 : idx - v.P;
+        if (mk[idx] < 1e-6 || mk[idm] < 1e-6) g = 0.0;
+    }
+    return g;
+}
+// gradient of the bed on a face: plain stored ghosts (zb is caller data over the ghosted level)
+__device__ __forceinline__ double face_grad_zb(const DV &v, const double *__restrict__ zb, const double *__restrict__ mk,
+                                               int i, int j, int dir, int hasMask)
+{
+    int idx = cidx(v, i, j), idm = dir == 0 ? idx - 1 : idx - v.P;
+    double g = (dir == 0 ? v.fdx : v.fdy) * (zb[idx] - zb[idm]);
+    if (hasMask && (mk[idx] < 1e-6 || mk[idm] < 1e-6)) g = 0.0;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void k_qw_faces(DV v, FP fp, suhmo_phys_t ph)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > v.nx || j > v.ny) return;
+    const double *__restrict__ phi = fp.f[SUHMO_F_PHI], *__restrict__ B = fp.f[SUHMO_F_B], *__restrict__ Re = fp.f[SUHMO_F_RE];
+    const double *__restrict__ mk = fp.f[SUHMO_F_MASK];
+    int idx = cidx(v, i, j);
+    if (j < v.ny) {
+        double b = 0.5 * (B[idx] + B[idx - 1]), re = 0.5 * (Re[idx] + Re[idx - 1]);
+        double g = face_grad(v, phi, mk, i, j, 0, ph.use_mask_gradients);
+        double num_q = -(b * b * b * ph.grav * g);
+        double denom_q = 12.0 * ph.nu * (1.0 + ph.omega * re);
+        fp.f[SUHMO_F_QWX][idx] = num_q / denom_q;
+    }
+    if (i < v.nx) {
+        double b = 0.5 * (B[idx] + B[idx - v.P]), re = 0.5 * (Re[idx] + Re[idx - v.P]);
+        double g = face_grad(v, phi, mk, i, j, 1, ph.use_mask_gradients);
+        double num_q = -(b * b * b * ph.grav * g);
+        double denom_q = 12.0 * ph.nu * (1.0 + ph.omega * re);
+        fp.f[SUHMO_F_QWY][idx] = num_q / denom_q;
+    }
+}
+
+// MODE 0: melt rate + RHS_h (Picard iteration).  MODE 1: melt rate + gap-height RHS + forward Euler.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_melt(DV v, FP fp, suhmo_phys_t ph, suhmo_model_params_t mp, double dt)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || j >= v.ny) return;
+    const double *__restrict__ phi = fp.f[SUHMO_F_PHI], *__restrict__ zb = fp.f[SUHMO_F_ZB], *__restrict__ mk = fp.f[SUHMO_F_MASK];
+    const double *__restrict__ qx = fp.f[SUHMO_F_QWX], *__restrict__ qy = fp.f[SUHMO_F_QWY];
+    const int idx = cidx(v, i, j), hm = ph.use_mask_gradients;
+    // COMPUTESCAPROD on the four faces of the cell, EdgeToCell
+    double t1w = qx[idx] * face_grad(v, phi, mk, i, j, 0, hm), t1e = qx[idx + 1] * face_grad(v, phi, mk, i + 1, j, 0, hm);
+    double t1s = qy[idx] * face_grad(v, phi, mk, i, j, 1, hm), t1n = qy[idx + v.P] * face_grad(v, phi, mk, i, j + 1, 1, hm);
+    double t2w = qx[idx] * face_grad_zb(v, zb, mk, i, j, 0, hm), t2e = qx[idx + 1] * face_grad_zb(v, zb, mk, i + 1, j, 0, hm);
+    double t2s = qy[idx] * face_grad_zb(v, zb, mk, i, j, 1, hm), t2n = qy[idx + v.P] * face_grad_zb(v, zb, mk, i, j + 1, 1, hm);
+    double t0 = 0.5 * (t1w + t1e), t1 = 0.5 * (t1s + t1n), u0 = 0.5 * (t2w + t2e), u1 = 0.5 * (t2s + t2n);
+    // Calc_meltingRate (src/AmrHydro.cpp:2210-2244)
+    const double h = phi[idx], b = fp.f[SUHMO_F_B][idx], Pi = fp.f[SUHMO_F_PI][idx], im = mk[idx];
+    double Pw = mp.gravity * mp.rho_w * (h - zb[idx]);
+    double sca_prod = 0.0;
+    if (mp.basal_friction) sca_prod = 20. * 20. * mp.ub0 * fabs(Pi - Pw) * mp.ub0;
+    double abs_QPw = t0 + t1 - (u0 + u1);
+    if ((abs_QPw < 0) && (b < 1e-6)) abs_QPw = 0.0;
+    double m = mp.G + sca_prod - mp.rho_w * mp.gravity * (t0 + t1) + mp.ct * mp.cw * mp.rho_w * mp.rho_w * mp.gravity * abs_QPw;
+    m = m / mp.L;
+    m = fmax(m, 0.0);
+    if (im < 0.0) m = 0.0;
+    fp.f[SUHMO_F_MR][idx] = m;
+    fp.f[SUHMO_F_PW][idx] = Pw;
+    const double ub_norm = sqrt(mp.ub0 * mp.ub0 + mp.ub1 * mp.ub1);
+    if (MODE == 0) {                                           // RHS_h, :3044-3077
+        double rho_coef = (1.0 / mp.rho_w - 1.0 / mp.rho_i);
+        double r = m * rho_coef;
+        if (b < mp.br) r -= ub_norm * (mp.br - b) / mp.lr;
+        r += (im > 0.0) ? mp.distributed_input : 0.0;          // distributed input where there is ice, :2871-2875
+        if (im < 0.0) r = 0.0;
+        fp.f[SUHMO_F_RHS][idx] = r;
+    } else {                                                   // CalcRHS_gapHeightFAS :2113-2168 + forward Euler :3406
+        double RHS = m * (1.0 / mp.rho_i), RHS_A = RHS, RHS_B = 0.0, cd = 0.0;
+        if ((im < 0.0) && mp.use_mask_rhs_b) { RHS = 0.0; }
+        else {
+            if (b < mp.br) { RHS += ub_norm * (mp.br - b) / mp.lr; RHS_B = ub_norm * (mp.br - b) / mp.lr; }
+            double PimPw = Pi - Pw, AbsPimPw = fabs(PimPw);
+            if (ph.cutOffbr > b) RHS -= ph.A * (AbsPimPw * AbsPimPw) * PimPw * b * (1.0 - (ph.cutOffbr - b) / ph.cutOffbr);
+            else if (ph.maxOffbr < b) RHS -= ph.A * (AbsPimPw * AbsPimPw) * PimPw * b * (1.0 - (ph.maxOffbr - b) / ph.maxOffbr);
+            else RHS -= ph.A * (AbsPimPw * AbsPimPw) * PimPw * b;
+            cd = RHS_A / (RHS_A + RHS_B);
+        }
+        fp.f[SUHMO_F_CD][idx] = cd;
+        fp.f[SUHMO_F_B][idx] = RHS * dt + b;                   // old b == b: the gap height is untouched during [II]
+    }
+}
+
+// max over valid cells (signed) and max |(a - b) / s|: Picard convergence test, :3169-3185
+__global__ __launch_bounds__(256) void k_picard_partial(DV v, const double *__restrict__ h, const double *__restrict__ hl,
+                                                        double scale, int mode, double *__restrict__ partial)
+{
+    __shared__ double sm[256];
+    int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    double acc = mode == 0 ? -1.0e300 : 0.0;
+    for (int j = blockIdx.y * blockDim.y + threadIdx.y; j < v.ny; j += gridDim.y * blockDim.y)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.nx; i += gridDim.x * blockDim.x) {
+            int idx = cidx(v, i, j);
+            double val = mode == 0 ? h[idx] : fabs((hl[idx] - h[idx]) / scale);
+            acc = fmax(acc, val);
+        }
+    sm[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = fmax(sm[tid], sm[tid + s]); __syncthreads(); }
+    if (tid == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = sm[0];
+}
+__global__ void k_max_final(const double *__restrict__ partial, int n, double *__restrict__ out)
+{
+    __shared__ double sm[256];
+    int tid = threadIdx.x;
+    double acc = -1.0e300;
+    for (int k = tid; k < n; k += 256) acc = fmax(acc, partial[k]);
+    sm[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = fmax(sm[tid], sm[tid + s]); __syncthreads(); }
+    if (tid == 0) out[0] = sm[0];
+}
+static int reduce_max(suhmo_level *L, const double *h, const double *hl, double scale, int mode, double *out, hipStream_t st)
+{
+    Depth &D = L->d[0];
+    dim3 grd(std::min((D.v.nx + 63) / 64, 32), std::min((D.v.ny + 3) / 4, 128));
+    hipLaunchKernelGGL(k_picard_partial, grd, dim3(64, 4), 0, st, D.v, h, hl, scale, mode, L->scratch + 1);
+    hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, st, L->scratch + 1, (int)(grd.x * grd.y), L->scratch);
+    HIPCHK(hipMemcpyAsync(L->hscratch, L->scratch, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *out = L->hscratch[0];
+    return 0;
+}
+
+// grad h (cell centred, ghosted) and Re on the ghosted level: reuses the WFlx_level kernels of
+// suhmo_level.hip (identical arithmetic: NEWMACGRAD + EdgeToCell + ExtrapGhostCells + COMPUTERE)
+int suhmo_grad_re(suhmo_level *L, int depth, hipStream_t st);      // suhmo_level.hip
+int suhmo_copy_ghosts(suhmo_level *L, int depth, int field, hipStream_t st);
+
+static int lagged_chain(suhmo_level *L, hipStream_t st)
+{
+    Depth &D = L->d[0];
+    int rc = suhmo_grad_re(L, 0, st); if (rc) return rc;
+    hipLaunchKernelGGL(k_qw_faces, dim3((D.v.nx + 1 + 63) / 64, (D.v.ny + 1 + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, L->ph);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t *mp, double dt, int cur_step,
+                                    int *picard_iters, int *vcycles, suhmo_stream_t s)
+{
+    ARG(L && mp); ARG(dt > 0 && cur_step >= 1);
+    if (mp->diffFactor != 0.0) { suhmo_set_error("suhmo.diffFactor != 0: the diffusive term is not built"); return -5; }
+    Depth &D = L->d[0];
+    if (D.v.ext[0] || D.v.ext[1]) { suhmo_set_error("timestep on a rank strip is not built yet"); return -5; }
+    HIPCHK(hipSetDevice(L->device));
+    hipStream_t st = (hipStream_t)s;
+    static const int need[] = {SUHMO_F_MR, SUHMO_F_PW, SUHMO_F_QWX, SUHMO_F_QWY, SUHMO_F_HLAG, SUHMO_F_CD,
+                               SUHMO_F_GRADX, SUHMO_F_GRADY, SUHMO_F_RE};
+    for (int f : need) if (!suhmo_field(L, 0, f)) { suhmo_set_error("field allocation failed"); return -2; }
+    int rc;
+    // [I] ghosts of b (exchange + CopyGhostCells, :2385,:2429); ghosts of h are evaluated on the fly
+    if ((rc = suhmo_copy_ghosts(L, 0, SUHMO_F_B, st))) return rc;
+    // MGnewOp coarsening of B (+ static Pi, zb, mask, aCoef): once per step, b does not change in [II]
+    if ((rc = suhmo_level_build_mg_coefficients(L, s))) return rc;
+    suhmo_solver_params_t sp;                                      // SolveForHead_nl, :737-762
+    sp.num_smooth = 4; sp.num_bottom = 16; sp.max_iter = 100; sp.iter_min = 2; sp.imin = 5;
+    sp.eps = 1.0e-7; sp.hang = 0.01; sp.norm_thresh = 1.0e-7; sp.bcoeff_otf = 1; sp.max_depth = -1;
+    if (cur_step < 50) { sp.num_bottom = 10; sp.eps = 1.0e-10; sp.hang = 0.0001; sp.imin = 20; }
+    const dim3 blk(64, 4), grd((D.v.nx + 63) / 64, (D.v.ny + 3) / 4);
+    bool converged = false;
+    int ite_idx = 0, cur_picard = 0, nv = 0;
+    while (!converged) {                                           // [II]
+        HIPCHK(hipMemcpyAsync(D.fp.f[SUHMO_F_HLAG], D.fp.f[SUHMO_F_PHI], D.elems * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if ((rc = lagged_chain(L, st))) return rc;
+        hipLaunchKernelGGL(k_melt<0>, grd, blk, 0, st, D.v, D.fp, L->ph, *mp, dt);
+        HIPCHK(hipGetLastError());
+        int it = 0;
+        if ((rc = suhmo_level_solve(L, &sp, &it, nullptr, s))) return rc;
+        nv += it;
+        double maxHead = 0.0, res = 0.0;
+        if ((rc = reduce_max(L, D.fp.f[SUHMO_F_PHI], nullptr, 1.0, 0, &maxHead, st))) return rc;
+        if ((rc = reduce_max(L, D.fp.f[SUHMO_F_PHI], D.fp.f[SUHMO_F_HLAG], maxHead, 1, &res, st))) return rc;
+        if (ite_idx > 100) { suhmo_set_error("does not converge (Picard iterations > 100)"); return -6; }   // :3190-3195
+        if (cur_step < 2) { if (res < 0.05 && cur_picard > 2) converged = true; }
+        else if (cur_step < 50) { if (res < 0.05) converged = true; }
+        else { if (res < mp->eps_picard) converged = true; }
+        ite_idx++; cur_picard++;
+    }
+    // [III]
+    if ((rc = lagged_chain(L, st))) return rc;
+    hipLaunchKernelGGL(k_melt<1>, grd, blk, 0, st, D.v, D.fp, L->ph, *mp, dt);
+    HIPCHK(hipGetLastError());
+    if ((rc = suhmo_copy_ghosts(L, 0, SUHMO_F_B, st))) return rc;  // :3419-3420
+    if (picard_iters) *picard_iters = ite_idx;
+    if (vcycles) *vcycles = nv;
+    return 0;
+}

@@ -12,7 +12,7 @@ from . import capi
 from .capi import check
 
 F_PHI, F_RHS, F_ACOEF, F_B, F_PI, F_ZB, F_MASK, F_BX, F_BY, F_LAMBDA, F_RES, F_LPHI, F_NL, F_DNL, \
-    F_PHIOLD, F_CORR, F_GRADX, F_GRADY, F_RE = range(19)
+    F_PHIOLD, F_CORR, F_GRADX, F_GRADY, F_RE, F_MR, F_PW, F_QWX, F_QWY, F_HLAG, F_CD = range(25)
 
 
 def _phys(p):
@@ -76,9 +76,9 @@ class HipLevel:
     # ---- data movement
     def shape(self, field, depth=0, ghosted=False):
         nx, ny = self.nx >> depth, self.ny >> depth
-        if field == F_BX:
+        if field in (F_BX, F_QWX):
             return (ny, nx + 1)
-        if field == F_BY:
+        if field in (F_BY, F_QWY):
             return (ny + 1, nx)
         return (ny + 2, nx + 2) if ghosted else (ny, nx)
 

@@ -1,0 +1,57 @@
+"""Host-side handle on the hydrology time loop of one device-resident level: the single-level
+subset of AmrHydro::timeStepFAS (src/AmrHydro.cpp:2254-3460) the C-ABI exposes as
+suhmo_level_timestep.  Head = F_PHI and gap height = F_B stay in HBM from step to step."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi, level as lv
+from . import synthetic as sy
+from .capi import check
+
+
+def model_params(m):
+    ub = m.get("ub", (0.0, 0.0))
+    return capi.ModelParams(m["rho_i"], m["rho_w"], m["gravity"], m["G"], m["L"], m["ct"], m["cw"], ub[0], ub[1],
+                            m["br"], m["lr"], m.get("diffFactor", 0.0), m["distributed_input"], m["eps_picard"],
+                            int(m.get("basal_friction", 1)), int(m.get("use_mask_rhs_b", 0)))
+
+
+class HipModel:
+    FIELDS = dict(head=lv.F_PHI, B=lv.F_B, Pi=lv.F_PI, zb=lv.F_ZB, mask=lv.F_MASK, mR=lv.F_MR, Pw=lv.F_PW,
+                  qwx=lv.F_QWX, qwy=lv.F_QWY, cd=lv.F_CD, rhs_h=lv.F_RHS, Re=lv.F_RE)
+
+    def __init__(self, nx, ny, dx, dy, bc, phys, model, max_box=64, device=0):
+        self.level = lv.HipLevel(nx, ny, dx, dy, bc, phys, alpha=0.0, beta=-1.0, max_box=max_box, device=device)
+        self.nx, self.ny, self.dx, self.dy = nx, ny, dx, dy
+        self.model = dict(model)
+        self._mp = model_params(model)
+        self.cur_step = 0
+
+    def set_state(self, f):
+        """f: dict with ghosted (ny+2, nx+2) arrays head, B, Pi, zb, mask"""
+        L = self.level
+        L.set(lv.F_PHI, f["head"][1:-1, 1:-1])
+        L.set(lv.F_ACOEF, np.zeros((self.ny, self.nx)))
+        for k, fid in (("B", lv.F_B), ("Pi", lv.F_PI), ("zb", lv.F_ZB), ("mask", lv.F_MASK)):
+            L.set(fid, f[k], ghosted=True)
+
+    def timestep(self, dt):
+        self.cur_step += 1                                         # src/AmrHydro.cpp:2259
+        pi, nv = C.c_int(), C.c_int()
+        check(capi.lib().suhmo_level_timestep(self.level.h, C.byref(self._mp), float(dt), self.cur_step,
+                                              C.byref(pi), C.byref(nv), self.level.stream))
+        return pi.value, nv.value
+
+    def get(self, name, ghosted=False):
+        return self.level.get(self.FIELDS[name], ghosted=ghosted)
+
+    def postproc_table(self):
+        """SHMIP cross-section table (src/AmrHydro.cpp:3647-4102) from the device-resident state"""
+        mask = self.get("mask")
+        src = np.where(mask > 0.0, self.model["distributed_input"], 0.0)
+        return sy.shmip_postproc_table(self.dx, self.dy, self.get("qwx"), self.get("cd", ghosted=True), src,
+                                       self.get("mR"), self.get("Pw"), self.get("Pi"), mask, self.model["rho_w"])
+
+    def close(self):
+        self.level.close()

@@ -6,12 +6,16 @@ rank owns a strip of rows; the library calls the exchange hook wherever the refe
 exchanges a field, the hook packs the strip's edge rows on the device
 (suhmo_level_pack_rows), hands them to a transport, and unpacks the neighbour's rows into
 the ghost rows.  Transports:
+  * native RCCL (attach_rccl, the default on the "nccl" backend) -- pack, ncclSend/ncclRecv and unpack are
+    enqueued by the library itself on the kernels' stream (suhmo_amd/csrc/suhmo_rccl.hip); Python only
+    distributes the communicator id once.  No host round trip per exchange.
   * TorchDistTransport -- torch.distributed P2P (backend "nccl" = RCCL over xGMI on the
     GPU box, "gloo" in CPU tests); tensors are plain device buffers, plumbing only.
   * ThreadTransport    -- N "ranks" as threads of one process (tests on a 1-GPU box).
 No collective is on the data path except the 8-byte MAX all-reduce of the residual norm.
 """
 import ctypes as C
+import os
 import threading
 
 from . import capi
@@ -171,10 +175,43 @@ class ThreadTransport:
         return m
 
 
+STATIC_FIELDS = (1, 2, 3, 4, 5, 6, 7, 8)    # RHS, ACOEF, B, PI, ZB, MASK, BX, BY: caller-provided at depth 0
+
+
+def attach_rccl(level, rank, world, periodic_y=False, dist=None, unique_id=None):
+    """Native transport.  The 128-byte communicator id is made on rank 0 and broadcast with
+    torch.distributed (any backend) unless the caller passes it."""
+    lib = capi.lib()
+    # librccl: the one next to the HIP runtime this library is bound to (see suhmo_rccl_load); SUHMO_LIBRCCL overrides
+    path = os.environ.get("SUHMO_LIBRCCL")
+    check(lib.suhmo_rccl_load(path.encode() if path else None))
+    if unique_id is None:
+        idbuf = (C.c_char * 128)()
+        if rank == 0:
+            check(lib.suhmo_rccl_unique_id(C.cast(idbuf, C.c_void_p)))
+        unique_id = bytes(idbuf)
+        if world > 1:
+            import torch                      # already loaded by the caller that made `dist`
+            t = torch.tensor(list(unique_id), dtype=torch.uint8)
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = t.to(dev)
+            dist.broadcast(t, 0)
+            unique_id = bytes(t.cpu().tolist())
+    idarr = (C.c_char * 128).from_buffer_copy(unique_id)
+    check(lib.suhmo_level_attach_rccl(level.h, C.cast(idarr, C.c_void_p), rank, world, int(periodic_y), level.stream))
+    for f in STATIC_FIELDS:
+        check(lib.suhmo_level_exchange(level.h, 0, f, level.stream))
+    level._exchanger = "rccl"
+    return level
+
+
 def attach(level, dist, rank, world, periodic_y=False):
-    """bench.py / production entry: couple this rank's strip to its neighbours over
-    torch.distributed (nccl backend = RCCL).  Returns the exchanger (keep it alive)."""
+    """bench.py / production entry: couple this rank's strip to its neighbours.  Backend "nccl":
+    the native RCCL transport (SUHMO_TRANSPORT=torch forces the torch.distributed P2P one);
+    other backends (gloo in CPU-side tests): torch.distributed P2P.  Returns the exchanger."""
     import torch
+    if dist.get_backend() == "nccl" and os.environ.get("SUHMO_TRANSPORT", "rccl") != "torch":
+        return attach_rccl(level, rank, world, periodic_y, dist)
     tr = TorchDistTransport(dist, torch.device("cuda", torch.cuda.current_device()))
     ex = StripExchanger(level, tr, rank, world, periodic_y)
     level._exchanger = ex

@@ -84,3 +84,58 @@ def random_fields(nx, ny, dx=3.0, dy=2.0, seed=7, with_mask_holes=True):
 RANDOM_PHYS = dict(A=5e-25, omega=1e-3, nu=1.787e-6, cutOffbr=0.01, maxOffbr=0.03,
                    rho_w_g=9800.0, grav=9.8, cutOffB=1, use_NL=1, use_mask_gradients=1)
 RANDOM_BC = dict(type=[[0, 1], [1, 0]], value=[[3.0, -0.02], [0.01, 7.0]], periodic=[0, 0])
+
+
+# ---- whole-model inputs (the caller of the head solve): SHMIP suite A
+# exec/A_SHMIP/A3/input.hydro:15-60, src/suhmo_params.cpp:51-106
+A3_MODEL = dict(rho_i=910.0, rho_w=1000.0, gravity=9.8, G=0.0, L=3.34e5, ct=7.5e-8, cw=4.22e3, ub=(1.0e-6, 0.0),
+                br=0.1, lr=2.0, diffFactor=0.0, distributed_input=5.79e-9, eps_picard=1.0e-4, basal_friction=1,
+                use_mask_rhs_b=0, dt=3600.0, max_step=10000, nx=320, ny=64, lx=1.0e5, ly=2.0e4)
+
+
+# exec/A_SHMIP/A{1..6}/input.hydro:41 -- the suite-A cases differ in the distributed input only
+SHMIP_A_INPUT = dict(A1=7.93e-11, A2=1.59e-9, A3=5.79e-9, A4=2.5e-8, A5=4.5e-8, A6=5.79e-7)
+
+
+def shmip_a_model(case):
+    return dict(A3_MODEL, distributed_input=SHMIP_A_INPUT[case])
+
+
+def shmip_initial_state(nx, ny, lx=1.0e5, ly=2.0e4, ice_height=5000.0, slope=0.0, gap_init=0.01):
+    """SqrtIBC::initializeData (src/SqrtIBC.cpp:219-262) evaluated over the ghosted level:
+    zb = slope x, H = max(6(sqrt(x+IceHeight)-sqrt(IceHeight))+1, 0), Pi = rho_i g H,
+    B = GapInit (1e-16 where Pi < 2), head = 101325/(rho_w g) + zb; mask: SqrtIBC::setup_iceMask."""
+    dx, dy = lx / nx, ly / ny
+    i = np.arange(-1, nx + 1, dtype=np.float64)
+    j = np.arange(-1, ny + 1, dtype=np.float64)
+    X, _ = np.meshgrid((i + 0.5) * dx, (j + 0.5) * dy)
+    zb = slope * X
+    H = np.maximum(6.0 * (np.sqrt(X + ice_height) - np.sqrt(ice_height)) + 1.0, 0.0)
+    Pi = np.maximum(RHO_I * GRAV * H, 0.0)
+    B = np.where(Pi < 2.0, 1.0e-16, gap_init)
+    head = 101325.0 * (1.0 / (RHO_W * GRAV)) + zb
+    mask = np.where(Pi > 0.0, 1.0, -1.0)
+    return dict(nx=nx, ny=ny, dx=dx, dy=dy, head=head, B=B, Pi=Pi, zb=zb, mask=mask)
+
+
+def shmip_postproc_table(dx, dy, qwx, cd, src, mR, Pw, Pi, mask, rho_w=1000.0):
+    """The SHMIP cross-section table of AmrHydro::timeStepFAS (src/AmrHydro.cpp:3647-4102), columns of
+    exec/*_SHMIP/*/results/postproc.dat: x[km], Ylength, discharge, dischargeEFF, dischargeINEFF,
+    recharge(ext), recharge(melt), mean effective pressure [MPa].  cell arrays are VALID cells (ny, nx),
+    cd is ghosted (ny+2, nx+2) (channelisation degree, domain ghosts as stored), qwx is (ny, nx+1)."""
+    ny, nx = mR.shape
+    cd_ec = 0.5 * (cd[1:-1, 1:] + cd[1:-1, :-1])                       # CellToEdge, x-faces
+    q_tot = (qwx * dy).sum(axis=0)
+    q_chan = (qwx * dy * cd_ec).sum(axis=0)
+    q_dist = (qwx * dy * (1.0 - cd_ec)).sum(axis=0)
+    ice = mask > 0.0
+    ext = np.where(ice, src * dy * dx, 0.0).sum(axis=0)
+    mr = np.where(ice, (mR / rho_w) * dy * dx, 0.0).sum(axis=0)
+    ylen = np.where(ice, dy, 0.0).sum(axis=0)
+    ok = ice & (Pi > 0.0)
+    avp = np.where(ok, Pi - Pw, 0.0).sum(axis=0)
+    cnt = ok.sum(axis=0)
+    ext = np.cumsum(ext[::-1])[::-1]
+    mr = np.cumsum(mr[::-1])[::-1]
+    x = (np.arange(nx) + 0.5) * dx / 1e3
+    return np.stack([x, ylen, -q_tot[:nx], -q_chan[:nx], -q_dist[:nx], ext, mr, avp / np.maximum(cnt, 1.0) / 1e6], axis=1)

@@ -1,0 +1,52 @@
+"""The native RCCL transport (suhmo_amd/csrc/suhmo_rccl.hip) on a 1-GPU box: a strip that is its OWN
+periodic neighbour (world = 1, lo = hi = rank 0) sends its edge rows to itself through
+ncclSend/ncclRecv.  A level of ny rows declared as the lower strip of a 2 ny periodic domain then sees,
+in its ghost rows, exactly the periodic image -- so every result must equal the whole periodic level of
+ny rows BIT FOR BIT.  (Pack/unpack kernels, message layout, send/recv order when lo == hi, the stream
+ordering with the relax kernels and the MAX all-reduce are all on this path; only the peer differs on
+a real multi-GPU node.)"""
+import numpy as np
+import pytest
+
+from suhmo_amd import synthetic as sy
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(nx, ny, f, ph, halo):
+    from suhmo_amd import level, multigpu
+    bc = sy.CONV_BC
+    W = level.HipLevel(nx, ny, f["dx"], f["dy"], bc, ph, 0.0, -1.0, 32)
+    W.set_inputs(f)
+    S = level.HipLevel(nx, ny, f["dx"], f["dy"], bc, ph, 0.0, -1.0, 32, j0=0, ny_global=2 * ny, halo_rows=halo)
+    S.set_inputs(f)
+    multigpu.attach_rccl(S, 0, 1, periodic_y=True)
+    return W, S
+
+
+@pytest.mark.parametrize("nx,ny,variant", [(64, 32, "simple"), (2048, 1024, "fused")])
+def test_self_neighbour_vcycle_bitwise(nx, ny, variant, monkeypatch):
+    from suhmo_amd import capi
+    from suhmo_amd.level import F_PHI, F_RES, F_BX, F_BY
+    from test_gpu_strips import wrap_ghosts
+    if variant == "fused":
+        monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "100000")
+    f = wrap_ghosts(sy.shmip_fields(nx, ny, ly=2.0e4 * ny / nx * 5), sy.CONV_BC)
+    W, S = make_pair(nx, ny, f, sy.A3_PHYS, 4)
+    sp = dict(sy.SOLVER_DEFAULT)
+    for L in (W, S):
+        L.build_mg_coefficients()
+        L.vcycle(sp)
+        L.vcycle(sp)
+        L.residual()
+    assert capi.lib().suhmo_level_rccl_exchanges(S.h) > 10
+    for fid in (F_PHI, F_RES, F_BX):
+        assert np.array_equal(W.get(fid), S.get(fid)), fid
+    assert np.array_equal(W.get(F_BY)[:-1], S.get(F_BY)[:-1])
+    assert W.norm(F_RES, 0) == S.norm(F_RES, 0)          # goes through the ncclAllReduce(MAX) hook
+    n1, h1 = W.solve(dict(sp, max_iter=6))
+    n2, h2 = S.solve(dict(sp, max_iter=6))
+    assert n1 == n2 and np.array_equal(h1, h2)
+    assert np.array_equal(W.get(F_PHI), S.get(F_PHI))
+    W.close()
+    S.close()

@@ -1,0 +1,108 @@
+"""The caller of the head solve on the GPU (suhmo_level_timestep: Picard loop, melt rate, RHS assembly,
+gap-height update) against the oracle's time loop on the same inputs: BITWISE over several steps, and the
+whole SHMIP A3 run (10002 steps) against the reference's committed result table."""
+import os
+
+import numpy as np
+import pytest
+
+from suhmo_amd import synthetic as sy
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def hipmodel():
+    from suhmo_amd import capi, model
+    assert capi.lib().suhmo_device_count() > 0, "no GPU visible: the product path has no fallback"
+    return model
+
+
+def perturbed_state(nx, ny, seed, mask_holes=False, ly=2.0e4):
+    st = sy.shmip_initial_state(nx, ny, ly=ly)
+    rng = np.random.default_rng(seed)
+    st["B"] = st["B"] * rng.uniform(0.5, 12.0, size=st["B"].shape)     # both sides of br = 0.1
+    st["head"] = st["head"] + rng.uniform(0.0, 30.0, size=st["head"].shape)
+    st["zb"] = st["zb"] + rng.uniform(0.0, 2.0, size=st["zb"].shape)
+    if mask_holes:
+        st["mask"][rng.uniform(size=st["mask"].shape) < 0.05] = -1.0
+    return st
+
+
+CASES = [
+    ("a3-32x16", 32, 16, sy.A3_BC, sy.A3_PHYS, dict(), False, 3),
+    ("a3-128x32-perturbed", 128, 32, sy.A3_BC, sy.A3_PHYS, dict(), False, 3),
+    ("yperiodic-mask", 64, 32, sy.CONV_BC, dict(sy.A3_PHYS, use_mask_gradients=1, cutOffbr=0.02, maxOffbr=0.08, cutOffB=1),
+     dict(use_mask_rhs_b=1, G=0.05), True, 2),
+    ("dirichlet-values", 48, 16, dict(type=[[0, 0], [1, 1]], value=[[2.0, 900.0], [0.0, 0.0]], periodic=[0, 0]),
+     sy.A3_PHYS, dict(basal_friction=0), False, 2),
+]
+
+
+@pytest.mark.parametrize("name,nx,ny,bc,ph,mpo,holes,nsteps", CASES, ids=[c[0] for c in CASES])
+def test_timestep_bitwise(oracle, hipmodel, name, nx, ny, bc, ph, mpo, holes, nsteps):
+    m = dict(sy.A3_MODEL, **mpo)
+    st = sy.shmip_initial_state(nx, ny) if name == "a3-32x16" else perturbed_state(nx, ny, 11, holes)
+    O = oracle.OracleModel(nx, ny, st["dx"], st["dy"], bc, ph, m, max_box=16, nthreads=2)
+    G = hipmodel.HipModel(nx, ny, st["dx"], st["dy"], bc, ph, m, max_box=16)
+    O.set_state(st)
+    G.set_state(st)
+    v = lambda a: np.array(a)[1:-1, 1:-1]
+    for k in range(nsteps):
+        po, vo = O.timestep(m["dt"])
+        pg, vg = G.timestep(m["dt"])
+        assert (po, vo) == (pg, vg), (k, po, vo, pg, vg)
+        for nm, fid in (("head", oracle.OM_H), ("B", oracle.OM_B), ("mR", oracle.OM_MR), ("Pw", oracle.OM_PW),
+                        ("cd", oracle.OM_CD), ("rhs_h", oracle.OM_RHSH)):
+            a, b = v(O.field(fid)), G.get(nm)
+            assert np.array_equal(a, b, equal_nan=True), (name, k, nm, float(np.nanmax(np.abs(a - b))))   # cd = 0/0 where nothing opens the gap
+        for nm, fid in (("qwx", oracle.OM_QWX), ("qwy", oracle.OM_QWY)):
+            a, b = np.array(O.field(fid)), G.get(nm)
+            assert np.array_equal(a, b, equal_nan=True), (name, k, nm, float(np.nanmax(np.abs(a - b))))   # cd = 0/0 where nothing opens the gap
+        # ghosts of the gap height after the step (CopyGhostCells): edges, corners are never read
+        a, b = np.array(O.field(oracle.OM_B)), G.get("B", ghosted=True)
+        assert np.array_equal(a[1:-1, :], b[1:-1, :]) and np.array_equal(a[:, 1:-1], b[:, 1:-1])
+        assert np.all(np.isfinite(b))
+    O.close()
+    G.close()
+
+
+def test_timestep_refuses_what_is_not_built(hipmodel):
+    from suhmo_amd import capi
+    st = sy.shmip_initial_state(32, 16)
+    G = hipmodel.HipModel(32, 16, st["dx"], st["dy"], sy.A3_BC, sy.A3_PHYS, dict(sy.A3_MODEL, diffFactor=1.0))
+    G.set_state(st)
+    with pytest.raises(capi.SuhmoError):
+        G.timestep(3600.0)
+    G.close()
+
+
+@pytest.mark.parametrize("case", ["A1", "A2", "A3", "A4", "A5", "A6"])
+def test_shmip_a_full_run(hipmodel, case):
+    """exec/A_SHMIP/A<k>: 320 x 64, dt = 1 h, 10000 + 2 steps, all on the device.  Gates:
+    (1) same Picard-iteration and V-cycle totals as the oracle's committed run, and table == the oracle's
+        (tests/golden/shmip_A<k>_oracle_run_table.dat, written with 10 significant digits) to 1e-9 relative:
+        the GPU path stays on the oracle's trajectory for 10002 steps;
+    (2) table vs the REFERENCE's committed result (exec/A_SHMIP/A<k>/results/postproc.dat): the tolerances of
+        test_oracle_timeloop.ASIS_TOL (the tables were written without the melt term of RHS_h; the oracle with
+        that one term off matches them to print precision -- test_oracle_pinned_by_reference_results)."""
+    import json
+    from test_oracle_timeloop import check_against_reference
+    m = sy.shmip_a_model(case)
+    st = sy.shmip_initial_state(m["nx"], m["ny"], m["lx"], m["ly"])
+    G = hipmodel.HipModel(m["nx"], m["ny"], st["dx"], st["dy"], sy.A3_BC, sy.A3_PHYS, m, max_box=64)
+    G.set_state(st)
+    tot_p = tot_v = 0
+    for k in range(m["max_step"] + 2):
+        p, nv = G.timestep(m["dt"])
+        tot_p += p
+        tot_v += nv
+    table = G.postproc_table()
+    G.close()
+    orc = np.loadtxt(os.path.join(GOLD, "shmip_%s_oracle_run_table.dat" % case))
+    run = json.load(open(os.path.join(GOLD, "shmip_%s_oracle_run.json" % case)))
+    assert (tot_p, tot_v) == (run["picard_total"], run["vcycles_total"])
+    scale = np.max(np.abs(orc), axis=0)
+    assert np.all(np.abs(table - orc) <= 1e-9 * scale), np.max(np.abs(table - orc) / scale, axis=0)
+    check_against_reference(table, case, "run")
