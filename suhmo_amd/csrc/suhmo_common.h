@@ -120,6 +120,7 @@ struct Depth {
     int nbox;
     int prolong_pending; // the next fused relax adds P(phi_c - phi_c,old) while loading phi (FAS prolongIncrement)
     double *phi_alt;   // second phi canvas: the fused GSRB kernel writes out of place (ping-pong)
+    int phi_fresh;     // strips: halo rows of phi (each rank-boundary side) that hold the neighbour's CURRENT values
 };
 
 struct ProfEv { hipEvent_t a, b; long cells; };
@@ -137,6 +138,8 @@ struct suhmo_level {
     suhmo_exchange_fn ex;
     suhmo_allreduce_max_fn ar;
     void *user;
+    int (*ex_begin)(void *user);                       // optional: open / close a batch of exchanges that
+    int (*ex_end)(void *user, suhmo_stream_t s);        // travel as ONE message group (native transport)
     void *rccl;                 // native transport state (suhmo_rccl.hip), owned by the level
     int prof_on;
     std::vector<ProfEv> prof;
@@ -156,4 +159,6 @@ double *suhmo_field(suhmo_level *L, int depth, int field);   // lazily allocates
 int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st);      // suhmo_level.hip
 int suhmo_restrict_both(suhmo_level *L, int depth, hipStream_t st);                 // suhmo_level.hip
 bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps);           // suhmo_gsrb.hip
-int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, hipStream_t st);   // suhmo_gsrb.hip
+int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream_t st);   // suhmo_gsrb.hip; tail = halo rows worth keeping valid at exit
+int suhmo_ensure_phi_halo(suhmo_level *L, int depth, int need, hipStream_t st);      // suhmo_level.hip
+static inline int suhmo_halo_rows(const DV &v) { return v.gy < v.ny ? v.gy : v.ny; }

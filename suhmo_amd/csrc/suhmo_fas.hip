@@ -20,12 +20,22 @@ static int eff_depths(const suhmo_level *L, const suhmo_solver_params_t *sp)
     return nd;
 }
 
+// relax() of the operator: levelGSRB sweeps, then the homogeneous-BC ghost fill levelGSRB ends with
+// (src/VCAMRNonLinearPoissonOp.cpp:757-759).  `tail`: halo rows (strips) worth keeping valid for the next reader.
+static int relax(suhmo_level *L, int dep, int sweeps, int tail, suhmo_stream_t s)
+{
+    int rc = suhmo_launch_gsrb(L, dep, sweeps, tail, (hipStream_t)s);
+    if (rc) return rc;
+    if (sweeps > 0) return suhmo_level_fill_ghosts(L, dep, SUHMO_F_PHI, 1, s);
+    return 0;
+}
+
 static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, int nd, suhmo_stream_t s)
 {
     int rc;
-    if (dep == nd - 1) return suhmo_level_gsrb(L, dep, sp->num_bottom, s);        // bottom relaxes
+    if (dep == nd - 1) return relax(L, dep, sp->num_bottom, 0, s);                // bottom relaxes
     Depth &C = L->d[dep + 1];
-    if ((rc = suhmo_level_gsrb(L, dep, sp->num_smooth, s))) return rc;            // pre-smooth
+    if ((rc = relax(L, dep, sp->num_smooth, 1, s))) return rc;                    // pre-smooth (the restriction reads 1 halo row)
     if ((rc = suhmo_restrict_both(L, dep, (hipStream_t)s))) return rc;            // RES[dep+1] and PHI[dep+1] = R(phi)
     HIPCHK(hipMemcpyAsync(C.fp.f[SUHMO_F_PHIOLD], C.fp.f[SUHMO_F_PHI], C.elems * sizeof(double),
                           hipMemcpyDeviceToDevice, (hipStream_t)s));
@@ -39,7 +49,7 @@ static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, i
         if ((rc = suhmo_level_axby(L, dep + 1, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) return rc;
         if ((rc = suhmo_level_prolong_increment(L, dep, s))) return rc;
     }
-    return suhmo_level_gsrb(L, dep, sp->num_smooth, s);                           // post-smooth
+    return relax(L, dep, sp->num_smooth, dep == 0 ? 2 : 0, s);                    // post-smooth (depth 0: UpdateOperator of the next cycle reads 2)
 }
 
 extern "C" int suhmo_level_vcycle(suhmo_level_t *L, const suhmo_solver_params_t *sp, suhmo_stream_t s)

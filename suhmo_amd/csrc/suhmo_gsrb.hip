@@ -68,6 +68,8 @@ struct FusedGeom {
     int Hc;       // owned rows per chunk
     int nstrips, nchunks, ntiles;
     int ylo, yhi; // rows that exist for loading / computing (strip-local j, inclusive)
+    int jbeg, jend; // rows written: [jbeg, jend) = the strip's rows plus, on rank boundaries, the halo rows that
+                    // stay valid after this launch (advanced redundantly so the next launch needs no exchange)
     int wrap_y;   // rows outside [0, ny) are periodic images (single-rank periodic y)
     // FAS prolongIncrement fused into the load of phi (PROLONGNL, AMRNonLinearPoissonOpF.ChF:619-627):
     // phi(i,j) += phi_c(i/2,j/2) - phi_c_old(i/2,j/2)
@@ -112,8 +114,8 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
     const int cend = (c0 + g.W < v.nx) ? c0 + g.W : v.nx;
     const bool own = cval && i0 >= c0 && i0 < cend;
 
-    const int jA = chunk * g.Hc;
-    const int jB = (jA + g.Hc < v.ny) ? jA + g.Hc : v.ny;
+    const int jA = g.jbeg + chunk * g.Hc;
+    const int jB = (jA + g.Hc < g.jend) ? jA + g.Hc : g.jend;
     const int jmin = (jA - 2 * K > g.ylo) ? jA - 2 * K : g.ylo;
     const int jmax = (jB - 1 + 2 * K < g.yhi) ? jB - 1 + 2 * K : g.yhi;
 
@@ -235,7 +237,7 @@ static bool fused_ok(const suhmo_level *L, const Depth &D, int K)
 }
 
 template <int K, int NT>
-static int launch_fused(suhmo_level *L, int depth, hipStream_t st)
+static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st)
 {
     Depth &D = L->d[depth];
     const DV &v = D.v;
@@ -260,19 +262,22 @@ static int launch_fused(suhmo_level *L, int depth, hipStream_t st)
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gsrb_fused<K, false, NT>, NT, 0));
             slots_k[K] = (nb > 0 ? nb : 1) * (ncu > 0 ? ncu : 256);
         }
+        g.jbeg = v.ext[0] ? -ext_rows : 0;
+        g.jend = v.ny + (v.ext[1] ? ext_rows : 0);
+        const int nrows = g.jend - g.jbeg;
         int nch = slots_k[K] / g.nstrips;
         if (nch < 1) nch = 1;
-        g.Hc = (v.ny + nch - 1) / nch;
+        g.Hc = (nrows + nch - 1) / nch;
+        if (L->fused_hc > 0) g.Hc = L->fused_hc;
+        if (g.Hc < 16 * K) g.Hc = 16 * K;
+        if (g.Hc > nrows) g.Hc = nrows;
+        g.nchunks = (nrows + g.Hc - 1) / g.Hc;
     }
-    if (L->fused_hc > 0) g.Hc = L->fused_hc;
-    if (g.Hc < 16 * K) g.Hc = 16 * K;
-    if (g.Hc > v.ny) g.Hc = v.ny;
-    g.nchunks = (v.ny + g.Hc - 1) / g.Hc;
     g.ntiles = g.nstrips * g.nchunks;
     bool selfper = v.per[1] && !(v.ext[0] || v.ext[1]);
     g.wrap_y = selfper;
-    g.ylo = (v.ext[0] || selfper) ? -2 * K : 0;
-    g.yhi = (v.ext[1] || selfper) ? v.ny - 1 + 2 * K : v.ny - 1;
+    g.ylo = v.ext[0] ? g.jbeg - 2 * K : (selfper ? -2 * K : 0);
+    g.yhi = v.ext[1] ? g.jend - 1 + 2 * K : (selfper ? v.ny - 1 + 2 * K : v.ny - 1);
     const double *pin = D.fp.f[SUHMO_F_PHI];
     g.pc = g.pco = nullptr; g.Pc = g.gyc = 0;
     if (D.prolong_pending) {
@@ -312,14 +317,16 @@ bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps)
     return pick_K(L, D, pick_variant(L, D), sweeps) > 0;
 }
 
-int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, hipStream_t st)
+int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream_t st)
 {
     Depth &D = L->d[depth];
     int variant = pick_variant(L, D);
     const bool ext = L->ex && (D.v.ext[0] || D.v.ext[1]);
-    const int phi_field = SUHMO_F_PHI;
-    const int halo = D.v.gy < D.v.ny ? D.v.gy : D.v.ny;   // halo rows that hold real neighbour data
-    int fresh = 0;       // colour passes the current halo contents still allow (simple path)
+    // Strips: F = halo rows of phi that hold current neighbour values (Depth::phi_fresh).  A colour pass
+    // needs 1, a K-sweep launch 2K; each launch also advances, redundantly, as many of the remaining halo
+    // rows as the work still to come (rest of these sweeps + `tail` rows for the next reader) can use, so
+    // one exchange of halo_rows rows feeds up to halo_rows colour passes.
+    int F = ext ? D.phi_fresh : 0;
     int it = 0;
     while (it < sweeps) {
         int K = pick_K(L, D, variant, sweeps - it);   // sweeps done by the next launch (0 = simple path, 1 sweep)
@@ -332,25 +339,28 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, hipStream_t st)
         }
         if (K == 0) {
             for (int pass = 0; pass < 2; pass++) {
-                if (ext && fresh == 0) {
-                    int rc = L->ex(L->user, L, depth, &phi_field, 1, (suhmo_stream_t)st);
-                    if (rc) return rc;
-                    fresh = halo;
+                if (ext && F < 1) {
+                    int rc = suhmo_ensure_phi_halo(L, depth, 1, st); if (rc) return rc;
+                    F = D.phi_fresh;
                 }
-                // with `fresh` valid halo rows this pass may also advance fresh-1 of them
-                launch_simple(L, depth, pass, ext ? fresh - 1 : 0, st);
-                if (ext) fresh--;
+                int want = 2 * (sweeps - it) - (pass + 1) + tail;          // halo rows the work after this pass can use
+                int E = ext ? (F - 1 < want ? F - 1 : want) : 0;
+                launch_simple(L, depth, pass, E, st);
+                if (ext) { F = E; D.phi_fresh = F; }
             }
         } else {
-            if (ext) {
-                int rc = L->ex(L->user, L, depth, &phi_field, 1, (suhmo_stream_t)st);
-                if (rc) return rc;
-                fresh = 0;
+            if (ext && F < 2 * K) {
+                int rc = suhmo_ensure_phi_halo(L, depth, 2 * K, st); if (rc) return rc;
+                F = D.phi_fresh;
+                if (F < 2 * K) { suhmo_set_error("internal: halo shallower than 2K"); return -4; }
             }
+            int want = 2 * (sweeps - it - K) + tail;
+            int E = ext ? (F - 2 * K < want ? F - 2 * K : want) : 0;
             int rc;
-            if (L->fused_nt == 64) rc = (K == 2) ? launch_fused<2, 64>(L, depth, st) : launch_fused<1, 64>(L, depth, st);
-            else rc = (K == 2) ? launch_fused<2, 256>(L, depth, st) : launch_fused<1, 256>(L, depth, st);
+            if (L->fused_nt == 64) rc = (K == 2) ? launch_fused<2, 64>(L, depth, E, st) : launch_fused<1, 64>(L, depth, E, st);
+            else rc = (K == 2) ? launch_fused<2, 256>(L, depth, E, st) : launch_fused<1, 256>(L, depth, E, st);
             if (rc) return rc;
+            if (ext) { F = E; D.phi_fresh = F; }
         }
         int done = K == 0 ? 1 : K;
         if (prof) {

@@ -129,7 +129,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
         D.elems = (size_t)D.v.P * (size_t)(D.v.rows + 1);
         D.nbox = L->desc.nbox;
         memset(&D.fp, 0, sizeof(D.fp));
-        D.phi_alt = nullptr; D.prolong_pending = 0;
+        D.phi_alt = nullptr; D.prolong_pending = 0; D.phi_fresh = 0;
         for (int f : eager) {
             if (dep == 0 && f == SUHMO_F_LPHI) continue;       // lazily (only tests / AMR use it at depth 0)
             if (!suhmo_field(L, dep, f)) { suhmo_set_error("hipMalloc failed (depth %d field %d)", dep, f); delete L; return -2; }
@@ -181,7 +181,9 @@ extern "C" int suhmo_level_exchange(suhmo_level_t *L, int depth, int field, suhm
     const DV &v = L->d[depth].v;
     if (L->ex && (v.ext[0] || v.ext[1])) {
         if (!suhmo_field(L, depth, field)) return -2;
-        return L->ex(L->user, L, depth, &field, 1, s);
+        int rc = L->ex(L->user, L, depth, &field, 1, s);
+        if (!rc && field == SUHMO_F_PHI) L->d[depth].phi_fresh = suhmo_halo_rows(v);
+        return rc;
     }
     return 0;
 }
@@ -198,6 +200,7 @@ extern "C" int suhmo_level_halo_info(const suhmo_level_t *L, int depth, int *hal
 }
 
 // ------------------------------------------------------------------ LevelData traffic
+static inline void phi_changed(suhmo_level *L, int depth) { L->d[depth].phi_fresh = 0; }   // see suhmo_ensure_phi_halo
 static bool is_face(int f) { return f == SUHMO_F_BX || f == SUHMO_F_BY || f == SUHMO_F_QWX || f == SUHMO_F_QWY; }
 #define CHECK_DF(L, depth, field) ARG(L); ARG(depth >= 0 && depth < L->ndepth); ARG(field >= 0 && field < SUHMO_F_COUNT)
 
@@ -247,6 +250,7 @@ extern "C" int suhmo_level_set_field(suhmo_level_t *L, int depth, int field, con
 {
     CHECK_DF(L, depth, field); ARG(src);
     HIPCHK(hipSetDevice(L->device));
+    if (field == SUHMO_F_PHI) phi_changed(L, depth);
     return field_io(L, depth, field, (double *)src, ghosted, on_device, true, (hipStream_t)s);
 }
 extern "C" int suhmo_level_get_field(suhmo_level_t *L, int depth, int field, double *dst, int ghosted,
@@ -274,6 +278,7 @@ extern "C" int suhmo_level_put_box(suhmo_level_t *L, int depth, int field, int i
     HIPCHK(hipSetDevice(L->device));
     hipStream_t st = (hipStream_t)s;
     const DV &v = L->d[depth].v;
+    if (field == SUHMO_F_PHI) phi_changed(L, depth);
     int r[4]; box_region(L, depth, field, ibox, r);
     int j0 = v.j0;                         // fab indices are global: local j = global j - j0
     long fp = fhi0 - flo0 + 1;
@@ -384,9 +389,21 @@ static int exchange_fields(suhmo_level *L, int depth, std::initializer_list<int>
     const DV &v = L->d[depth].v;
     if (!(L->ex && (v.ext[0] || v.ext[1]))) return 0;
     for (int f : fields) if (!suhmo_field(L, depth, f)) return -2;
-    return L->ex(L->user, L, depth, fields.begin(), (int)fields.size(), (suhmo_stream_t)st);
+    int rc = L->ex(L->user, L, depth, fields.begin(), (int)fields.size(), (suhmo_stream_t)st);
+    if (!rc) for (int f : fields) if (f == SUHMO_F_PHI) L->d[depth].phi_fresh = suhmo_halo_rows(v);
+    return rc;
 }
-static int exchange_if_needed(suhmo_level *L, int depth, int field, hipStream_t st) { return exchange_fields(L, depth, {field}, st); }
+// strips: make sure `need` halo rows of phi hold the neighbours' current values.  Every kernel that
+// changes phi lowers Depth::phi_fresh (a colour pass that also advances the halo rows redundantly loses
+// one row, a K-sweep fused launch 2K), so an exchange happens only when the stencil about to run would
+// reach stale rows -- LevelData::exchange of the reference (src/VCAMRNonLinearPoissonOp.cpp:47,124,304,405,692)
+int suhmo_ensure_phi_halo(suhmo_level *L, int depth, int need, hipStream_t st)
+{
+    Depth &D = L->d[depth];
+    if (!(L->ex && (D.v.ext[0] || D.v.ext[1]))) return 0;
+    if (D.phi_fresh >= need) return 0;
+    return exchange_fields(L, depth, {SUHMO_F_PHI}, st);
+}
 
 extern "C" int suhmo_level_apply_op(suhmo_level_t *L, int depth, int homogeneous, suhmo_stream_t s)
 {
@@ -394,7 +411,7 @@ extern "C" int suhmo_level_apply_op(suhmo_level_t *L, int depth, int homogeneous
     HIPCHK(hipSetDevice(L->device));
     Depth &D = L->d[depth];
     if (!suhmo_field(L, depth, SUHMO_F_LPHI)) return -2;
-    int rc = exchange_if_needed(L, depth, SUHMO_F_PHI, (hipStream_t)s); if (rc) return rc;
+    int rc = suhmo_ensure_phi_halo(L, depth, 1, (hipStream_t)s); if (rc) return rc;
     if (D.v.alpha != 0.0) hipLaunchKernelGGL((k_apply<true, 0>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, L->ph, homogeneous);
     else hipLaunchKernelGGL((k_apply<false, 0>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, L->ph, homogeneous);
     HIPCHK(hipGetLastError());
@@ -406,7 +423,7 @@ extern "C" int suhmo_level_residual(suhmo_level_t *L, int depth, suhmo_stream_t 
     ARG(L); ARG(depth >= 0 && depth < L->ndepth);
     HIPCHK(hipSetDevice(L->device));
     Depth &D = L->d[depth];
-    int rc = exchange_if_needed(L, depth, SUHMO_F_PHI, (hipStream_t)s); if (rc) return rc;
+    int rc = suhmo_ensure_phi_halo(L, depth, 1, (hipStream_t)s); if (rc) return rc;
     if (D.v.alpha != 0.0) hipLaunchKernelGGL((k_apply<true, 1>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, L->ph, 0);
     else hipLaunchKernelGGL((k_apply<false, 1>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, L->ph, 0);
     HIPCHK(hipGetLastError());
@@ -457,7 +474,7 @@ extern "C" int suhmo_level_gsrb(suhmo_level_t *L, int depth, int sweeps, suhmo_s
 {
     ARG(L); ARG(depth >= 0 && depth < L->ndepth); ARG(sweeps >= 0);
     HIPCHK(hipSetDevice(L->device));
-    int rc = suhmo_launch_gsrb(L, depth, sweeps, (hipStream_t)s);
+    int rc = suhmo_launch_gsrb(L, depth, sweeps, 0, (hipStream_t)s);
     if (rc) return rc;
     // levelGSRB leaves the ghosts with the HOMOGENEOUS BC applied (:757-759)
     if (sweeps > 0) return suhmo_level_fill_ghosts(L, depth, SUHMO_F_PHI, 1, s);
@@ -499,7 +516,8 @@ __global__ __launch_bounds__(256) void k_restrict_residual(DV v, FP fp, DV vc, d
 static int restrict_residual_impl(suhmo_level *L, int depth, bool also_phi, hipStream_t st)
 {
     Depth &D = L->d[depth], &C = L->d[depth + 1];
-    int rc = exchange_if_needed(L, depth, SUHMO_F_PHI, st); if (rc) return rc;
+    int rc = suhmo_ensure_phi_halo(L, depth, 1, st); if (rc) return rc;
+    if (also_phi) phi_changed(L, depth + 1);
     double *phiC = also_phi ? C.fp.f[SUHMO_F_PHI] : nullptr;
     if (D.v.alpha != 0.0) hipLaunchKernelGGL(k_restrict_residual<true>, grid2d(C.v.nx, C.v.ny), BLK2D, 0, st, D.v, D.fp, C.v, C.fp.f[SUHMO_F_RES], phiC, L->ph);
     else hipLaunchKernelGGL(k_restrict_residual<false>, grid2d(C.v.nx, C.v.ny), BLK2D, 0, st, D.v, D.fp, C.v, C.fp.f[SUHMO_F_RES], phiC, L->ph);
@@ -533,6 +551,7 @@ extern "C" int suhmo_level_restrict_r(suhmo_level_t *L, int depth, suhmo_stream_
     ARG(L); ARG(depth >= 0 && depth + 1 < L->ndepth);
     HIPCHK(hipSetDevice(L->device));
     Depth &D = L->d[depth], &C = L->d[depth + 1];
+    phi_changed(L, depth + 1);
     hipLaunchKernelGGL(k_restrict_r, grid2d(C.v.nx, C.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp.f[SUHMO_F_PHI], C.v, C.fp.f[SUHMO_F_PHI]);
     HIPCHK(hipGetLastError());
     return 0;
@@ -551,6 +570,7 @@ extern "C" int suhmo_level_prolong_increment(suhmo_level_t *L, int depth, suhmo_
     ARG(L); ARG(depth >= 0 && depth + 1 < L->ndepth);
     HIPCHK(hipSetDevice(L->device));
     Depth &D = L->d[depth], &C = L->d[depth + 1];
+    phi_changed(L, depth);
     hipLaunchKernelGGL(k_prolong, grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp.f[SUHMO_F_PHI], C.v, C.fp.f[SUHMO_F_CORR]);
     HIPCHK(hipGetLastError());
     return 0;
@@ -574,6 +594,7 @@ extern "C" int suhmo_level_prolong_bilinear(suhmo_level_t *L, int depth, suhmo_s
     ARG(L); ARG(depth >= 0 && depth + 1 < L->ndepth);
     HIPCHK(hipSetDevice(L->device));
     Depth &D = L->d[depth], &C = L->d[depth + 1];
+    phi_changed(L, depth);
     hipLaunchKernelGGL(k_prolong2, grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp.f[SUHMO_F_PHI], C.v, C.fp.f[SUHMO_F_CORR]);
     HIPCHK(hipGetLastError());
     return 0;
@@ -809,10 +830,10 @@ extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_st
     HIPCHK(hipSetDevice(L->device));
     hipStream_t st = (hipStream_t)s;
     Depth &D = L->d[depth];
-    int rc = exchange_if_needed(L, depth, SUHMO_F_PHI, st); if (rc) return rc;
     // fused single-kernel path: needs >= 3 cells per direction (extrapolation sources inside every
     // edge tile) and, on rank boundaries, 2 exchanged phi rows for the halo-row gradient
     bool fused = L->bcoef_fused && D.v.nx >= 4 && D.v.ny >= 4 && (!(D.v.ext[0] || D.v.ext[1]) || (D.v.gy >= 2 && D.v.ny >= 2));
+    int rc = suhmo_ensure_phi_halo(L, depth, fused ? 2 : 1, st); if (rc) return rc;
     if (fused) {
         dim3 grd((D.v.nx + BT_X - 1) / BT_X, (D.v.ny + BT_Y - 1) / BT_Y);   // the last tile column / row also owns the E / N faces
         hipLaunchKernelGGL(k_bcoef_fused, grd, dim3(64, 4), 0, st, D.v, D.fp, L->ph, L->ph.use_mask_gradients);
@@ -1087,6 +1108,7 @@ extern "C" int suhmo_level_axby(suhmo_level_t *L, int depth, int dst, int x, int
     HIPCHK(hipSetDevice(L->device));
     Depth &D = L->d[depth];
     double *pd = suhmo_field(L, depth, dst), *px = suhmo_field(L, depth, x), *py = suhmo_field(L, depth, y);
+    if (dst == SUHMO_F_PHI) phi_changed(L, depth);
     hipLaunchKernelGGL(k_axby, grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, pd, px, py, a, b);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1096,6 +1118,7 @@ extern "C" int suhmo_level_set_value(suhmo_level_t *L, int depth, int field, dou
     CHECK_DF(L, depth, field);
     HIPCHK(hipSetDevice(L->device));
     Depth &D = L->d[depth];
+    if (field == SUHMO_F_PHI) phi_changed(L, depth);
     hipLaunchKernelGGL(k_setval, grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, suhmo_field(L, depth, field), val);
     HIPCHK(hipGetLastError());
     return 0;

@@ -24,15 +24,15 @@ def make_pair(nx, ny, f, ph, halo):
     return W, S
 
 
-@pytest.mark.parametrize("nx,ny,variant", [(64, 32, "simple"), (2048, 1024, "fused")])
-def test_self_neighbour_vcycle_bitwise(nx, ny, variant, monkeypatch):
+@pytest.mark.parametrize("nx,ny,variant,halo", [(64, 32, "simple", 4), (2048, 1024, "fused", 4), (128, 64, "simple", 16), (2048, 1024, "fused", 16)])
+def test_self_neighbour_vcycle_bitwise(nx, ny, variant, halo, monkeypatch):
     from suhmo_amd import capi
     from suhmo_amd.level import F_PHI, F_RES, F_BX, F_BY
     from test_gpu_strips import wrap_ghosts
     if variant == "fused":
         monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "100000")
     f = wrap_ghosts(sy.shmip_fields(nx, ny, ly=2.0e4 * ny / nx * 5), sy.CONV_BC)
-    W, S = make_pair(nx, ny, f, sy.A3_PHYS, 4)
+    W, S = make_pair(nx, ny, f, sy.A3_PHYS, halo)
     sp = dict(sy.SOLVER_DEFAULT)
     for L in (W, S):
         L.build_mg_coefficients()

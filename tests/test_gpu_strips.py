@@ -88,7 +88,8 @@ CASES = [
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 @pytest.mark.parametrize("variant", [0, 1, 2])
-def test_strips_gsrb_and_operators(case, variant, monkeypatch):
+@pytest.mark.parametrize("halo", [4, 9, 16])
+def test_strips_gsrb_and_operators(case, variant, halo, monkeypatch):
     from suhmo_amd import level as lv
     monkeypatch.setenv("SUHMO_GSRB_VARIANT", str(variant))
     monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "1")
@@ -104,7 +105,7 @@ def test_strips_gsrb_and_operators(case, variant, monkeypatch):
         return phi, res, G.get(lv.F_BX), G.get(lv.F_BY), G.norm(lv.F_RES, 0)
 
     ref = single(f, bc, ph, alpha, beta, body)
-    parts = run_strips(world, f, bc, ph, alpha, beta, body)
+    parts = run_strips(world, f, bc, ph, alpha, beta, body, halo=halo)
     assert np.array_equal(np.vstack([p[0] for p in parts]), ref[0])
     assert np.array_equal(np.vstack([p[1] for p in parts]), ref[1])
     assert np.array_equal(np.vstack([p[2] for p in parts]), ref[2])
@@ -113,9 +114,11 @@ def test_strips_gsrb_and_operators(case, variant, monkeypatch):
     assert all(p[4] == ref[4] for p in parts)       # MAX all-reduce of the norm
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_strips_vcycle_and_solve(world, oracle):
+@pytest.mark.parametrize("world,halo,fused", [(2, 4, 0), (4, 4, 0), (2, 16, 0), (4, 9, 0), (2, 16, 1), (4, 12, 1)])
+def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
     from suhmo_amd import level as lv
+    if fused:
+        monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "4000")     # fused K=2 launches down to 64 x 64 strips
     f = sy.shmip_fields(256, 256)
     bc, ph = sy.A3_BC, sy.A3_PHYS
     sp = dict(sy.SOLVER_DEFAULT, eps=1e-10, norm_thresh=1e-13, max_iter=4, imin=4)
@@ -127,7 +130,7 @@ def test_strips_vcycle_and_solve(world, oracle):
         n, hist = G.solve(sp)
         return p1, G.get(lv.F_PHI), n, hist, G.ndepth
 
-    parts = run_strips(world, f, bc, ph, 0.0, -1.0, body, max_box=64)
+    parts = run_strips(world, f, bc, ph, 0.0, -1.0, body, halo=halo, max_box=64)
     O = oracle.OracleLevel(256, 256, f["dx"], f["dy"], bc, ph, 0.0, -1.0, 64, 4)
     O.set_inputs(f)
     O.build_mg_coefficients()
