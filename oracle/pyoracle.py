@@ -94,6 +94,20 @@ def lib():
         L.or_model_field.argtypes = [C.c_void_p, C.c_int]
         L.or_model_timestep.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.or_model_step_index.argtypes = [C.c_void_p]
+        L.or_amr2_create.restype = C.c_void_p
+        L.or_amr2_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(OrBC), C.POINTER(OrPhys),
+                                     C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.or_amr2_destroy.argtypes = [C.c_void_p]
+        L.or_amr2_fine_io.argtypes = [C.c_void_p, C.c_int, dp, C.c_int, C.c_int]
+        for name in ("or_amr2_cf_interp_phi", "or_amr2_fine_residual", "or_amr2_fine_update_operator"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.or_amr2_fine_gsrb.argtypes = [C.c_void_p, C.c_int]
+        L.or_amr2_fine_apply_op.argtypes = [C.c_void_p, C.c_int]
+        L.or_amr2_residual.restype = C.c_double
+        L.or_amr2_residual.argtypes = [C.c_void_p]
+        L.or_amr2_vcycle.argtypes = [C.c_void_p, C.POINTER(OrSolverParams)]
+        L.or_amr2_solve.restype = C.c_int
+        L.or_amr2_solve.argtypes = [C.c_void_p, C.POINTER(OrSolverParams), dp]
         L.or_prolong2_global.argtypes = [dp, dp, C.c_int, C.c_int]
         L.or_divergence_global.argtypes = [dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double]
         L.or_difterm_global.argtypes = [dp, dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double]
@@ -288,3 +302,62 @@ class OracleModel:
             lib().or_model_destroy(self.h)
             self.h = None
             self.level.close()
+
+
+class OracleAmr2:
+    """Base level + one fine patch (coarse index box ci0..ci1 x cj0..cj1, refined by 2): oracle/amr2.c"""
+
+    def __init__(self, nxc, nyc, dxc, dyc, bc, phys, patch, alpha=0.0, beta=-1.0, max_box=64, nthreads=1):
+        self.coarse = OracleLevel(nxc, nyc, dxc, dyc, bc, phys, alpha, beta, max_box, nthreads)
+        self.patch = tuple(int(v) for v in patch)
+        ci0, cj0, ci1, cj1 = self.patch
+        self.nxp, self.nyp = 2 * (ci1 - ci0 + 1), 2 * (cj1 - cj0 + 1)
+        self.h = lib().or_amr2_create(self.coarse.h, nxc, nyc, dxc, dyc, C.byref(self.coarse._bc), C.byref(self.coarse._ph),
+                                      alpha, beta, ci0, cj0, ci1, cj1)
+
+    def fine_shape(self, field, ghosted=False):
+        if field == F_BX:
+            return (self.nyp, self.nxp + 1)
+        if field == F_BY:
+            return (self.nyp + 1, self.nxp)
+        return (self.nyp + 2, self.nxp + 2) if ghosted else (self.nyp, self.nxp)
+
+    def fine_set(self, field, arr, ghosted=False):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        assert a.shape == self.fine_shape(field, ghosted), (a.shape, self.fine_shape(field, ghosted))
+        lib().or_amr2_fine_io(self.h, field, _dp(a), int(ghosted), 1)
+
+    def fine_get(self, field, ghosted=False):
+        out = np.zeros(self.fine_shape(field, ghosted))
+        lib().or_amr2_fine_io(self.h, field, _dp(out), int(ghosted), 0)
+        return out
+
+    def set_fine_inputs(self, f):
+        self.fine_set(F_PHI, f["phi"])
+        self.fine_set(F_RHS, f["rhs"])
+        self.fine_set(F_ACOEF, f["aCoef"])
+        for k, fid in (("B", F_B), ("Pi", F_PI), ("zb", F_ZB), ("mask", F_MASK)):
+            self.fine_set(fid, f[k], ghosted=True)
+
+    def cf_interp(self): lib().or_amr2_cf_interp_phi(self.h)
+    def fine_gsrb(self, sweeps): lib().or_amr2_fine_gsrb(self.h, sweeps)
+    def fine_residual(self): lib().or_amr2_fine_residual(self.h)
+    def fine_apply_op(self, homogeneous=False): lib().or_amr2_fine_apply_op(self.h, int(homogeneous))
+    def fine_update_operator(self): lib().or_amr2_fine_update_operator(self.h)
+    def residual(self): return lib().or_amr2_residual(self.h)
+
+    def vcycle(self, sp):
+        s = make_solver_params(sp)
+        lib().or_amr2_vcycle(self.h, C.byref(s))
+
+    def solve(self, sp):
+        s = make_solver_params(sp)
+        hist = np.zeros(s.max_iter + 2)
+        n = lib().or_amr2_solve(self.h, C.byref(s), _dp(hist))
+        return n, hist[: n + 1]
+
+    def close(self):
+        if self.h:
+            lib().or_amr2_destroy(self.h)
+            self.h = None
+            self.coarse.close()

@@ -139,3 +139,41 @@ def shmip_postproc_table(dx, dy, qwx, cd, src, mR, Pw, Pi, mask, rho_w=1000.0):
     mr = np.cumsum(mr[::-1])[::-1]
     x = (np.arange(nx) + 0.5) * dx / 1e3
     return np.stack([x, ylen, -q_tot[:nx], -q_chan[:nx], -q_dist[:nx], ext, mr, avp / np.maximum(cnt, 1.0) / 1e6], axis=1)
+
+
+# ---- two-level AMR inputs: cfg3 of BASELINE.json = exec/0_convergence_channelized/2lev_base/input.hydro
+# (64 m x 16 m, 64 x 16 base cells, y periodic, slope 0.02, IceHeight 500, A = 2.5e-25, one moulin at
+# (16.015625, 8.015625), sigma 1, flux 30) with a FIXED refined box around the moulin (the reference tags on the
+# melt rate, which needs the time loop; AmrHydro.grids_file is the reference's own way to fix the grids)
+CFG3_PHYS = dict(A3_PHYS, A=2.5e-25)
+CFG3_PATCH = (8, 4, 23, 11)          # coarse cells [8..23] x [4..11]: 32 x 16 fine cells around the moulin
+
+
+def amr2_fields(nxc=64, nyc=16, patch=CFG3_PATCH, lx=64.0, ly=16.0, slope=0.02, ice_height=500.0, gap_init=0.01,
+                moulin=(16.015625, 8.015625, 1.0, 30.0), background=1.0e-11, seed=2024, vary_B=True):
+    """(coarse, fine) input dicts.  Every field is the same analytic function sampled at the two resolutions
+    (zb = slope x; H, Pi as SqrtIBC; rhs = background + a Gaussian moulin, value at the cell centre); the head gets
+    an independent random perturbation per level."""
+    def level(nx, ny, i0, j0, nxg, nyg, rng):
+        dx, dy = lx / nxg, ly / nyg
+        i = np.arange(i0 - 1, i0 + nx + 1, dtype=np.float64)
+        j = np.arange(j0 - 1, j0 + ny + 1, dtype=np.float64)
+        X, Y = np.meshgrid((i + 0.5) * dx, (j + 0.5) * dy)
+        zb = slope * X
+        H = np.maximum(6.0 * (np.sqrt(np.maximum(X + ice_height, 0.0)) - np.sqrt(ice_height)) + 1.0, 0.0)
+        Pi = np.maximum(RHO_I * GRAV * H, 0.0)
+        mask = np.where(Pi > 0.0, 1.0, -1.0)
+        B = np.full_like(X, gap_init)
+        if vary_B:
+            B = B * (1.0 + 0.3 * np.sin(2.0 * np.pi * X / (0.5 * lx)) * np.cos(2.0 * np.pi * Y / ly))
+        mx, my, sig, flux = moulin
+        src = background + flux / (2.0 * np.pi * sig * sig) * np.exp(-((X - mx) ** 2 + (Y - my) ** 2) / (2.0 * sig * sig)) * 1.0e-6
+        phi = 101325.0 / (RHO_W * GRAV) + zb + 1.0e-3 * rng.uniform(-1.0, 1.0, size=X.shape)
+        v = (slice(1, -1), slice(1, -1))
+        return dict(nx=nx, ny=ny, dx=dx, dy=dy, phi=np.ascontiguousarray(phi[v]), rhs=np.ascontiguousarray(src[v]),
+                    aCoef=np.zeros((ny, nx)), B=np.ascontiguousarray(B), Pi=np.ascontiguousarray(Pi),
+                    zb=np.ascontiguousarray(zb), mask=np.ascontiguousarray(mask))
+    ci0, cj0, ci1, cj1 = patch
+    coarse = level(nxc, nyc, 0, 0, nxc, nyc, np.random.default_rng([seed, 0]))
+    fine = level(2 * (ci1 - ci0 + 1), 2 * (cj1 - cj0 + 1), 2 * ci0, 2 * cj0, 2 * nxc, 2 * nyc, np.random.default_rng([seed, 1]))
+    return coarse, fine
