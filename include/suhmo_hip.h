@@ -69,6 +69,10 @@ typedef struct suhmo_level_desc {
     suhmo_phys_t phys;
     int device;          /* HIP device ordinal */
     int halo_rows;       /* ghost rows kept on the strip's y sides (>= 1) */
+    int i0, nx_global;   /* AMR patch: first global column held and columns of the whole (refined) domain;
+                            0, 0 = the level spans the domain in x.  A side of the rectangle that is not on the
+                            domain boundary (and not a rank boundary) is a COARSE-FINE side: its ghost cells hold
+                            data (suhmo_amr2_cf_interp) instead of the physical boundary condition */
 } suhmo_level_desc_t;
 
 /* field ids (same numbering as the test oracle) */
@@ -80,6 +84,7 @@ enum {
     /* fields of the caller of the solve (suhmo_level_timestep): melt rate, water pressure, water
      * flux on x / y faces, lagged head, channelisation degree */
     SUHMO_F_MR, SUHMO_F_PW, SUHMO_F_QWX, SUHMO_F_QWY, SUHMO_F_HLAG, SUHMO_F_CD,
+    SUHMO_F_RHS0,        /* AMR: the base level's own rhs while it carries the FAS rhs */
     SUHMO_F_COUNT
 };
 
@@ -225,6 +230,24 @@ int suhmo_level_attach_rccl(suhmo_level_t *L, const void *id128, int rank, int w
                             suhmo_stream_t s);
 int suhmo_level_detach_rccl(suhmo_level_t *L);
 long suhmo_level_rccl_exchanges(const suhmo_level_t *L);
+
+/* ---- two AMR levels: base level `coarse` (spans the domain) + one patch `fine` refined by 2, created with
+ * desc.i0 / nx_global / j0 / ny_global = its place in the refined domain (coarse-aligned), dx = coarse dx / 2.
+ * Method names of the reference in brackets (src/AMRNonLinearPoissonOp.cpp, src/VCAMRNonLinearPoissonOp.cpp).
+ *   suhmo_amr2_cf_interp    fine coarse-fine ghosts of field_f <- QuadCFInterp(coarse field_c)  [m_interpWithCoarser.coarseFineInterp :701,:933]
+ *   suhmo_amr2_average      coarse field_c under the patch <- average of fine field_f           [AMRRestrictS :1027-1069]
+ *   suhmo_amr2_fine_update_operator   bCoef of the fine level from head + coarse head          [UpdateOperator :34-64, WFlx_level :1455-1488]
+ *   suhmo_amr2_residual     RES on both levels (coarse: with reflux, covered cells zeroed), composite max norm
+ *                           [AMRResidual/AMRResidualNF :889-939, reflux :555-652, AMRNorm :1222-1264]
+ *   suhmo_amr2_vcycle / suhmo_amr2_solve   AMR FAS cycle (relaxNF, AMRRestrictS, base-level V-cycle, AMRProlongS_2
+ *                           :1143-1206) and the solveNoInit loop on the composite norm */
+int suhmo_amr2_cf_interp(suhmo_level_t *coarse, suhmo_level_t *fine, int field_f, int field_c, suhmo_stream_t s);
+int suhmo_amr2_average(suhmo_level_t *coarse, suhmo_level_t *fine, int field_f, int field_c, suhmo_stream_t s);
+int suhmo_amr2_fine_update_operator(suhmo_level_t *coarse, suhmo_level_t *fine, suhmo_stream_t s);
+int suhmo_amr2_residual(suhmo_level_t *coarse, suhmo_level_t *fine, double *norm, suhmo_stream_t s);
+int suhmo_amr2_vcycle(suhmo_level_t *coarse, suhmo_level_t *fine, const suhmo_solver_params_t *sp, suhmo_stream_t s);
+int suhmo_amr2_solve(suhmo_level_t *coarse, suhmo_level_t *fine, const suhmo_solver_params_t *sp, int *iters,
+                     double *resid_hist, suhmo_stream_t s);
 
 /* timing helper: average device time (ms) of the GSRB sweep kernel launches since the
  * last reset, measured with HIP events on the launch stream */

@@ -45,7 +45,8 @@ class LevelDesc(C.Structure):
     _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("j0", C.c_int), ("ny_global", C.c_int),
                 ("dx", C.c_double), ("dy", C.c_double), ("nbox", C.c_int), ("boxes", C.POINTER(C.c_int)),
                 ("max_box", C.c_int), ("alpha", C.c_double), ("beta", C.c_double),
-                ("bc", BC), ("phys", Phys), ("device", C.c_int), ("halo_rows", C.c_int)]
+                ("bc", BC), ("phys", Phys), ("device", C.c_int), ("halo_rows", C.c_int),
+                ("i0", C.c_int), ("nx_global", C.c_int)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p)
@@ -66,6 +67,8 @@ SYMBOLS = [
     "suhmo_level_profile_enable", "suhmo_level_profile_read", "suhmo_level_timestep",
     "suhmo_rccl_load", "suhmo_rccl_unique_id", "suhmo_level_attach_rccl", "suhmo_level_detach_rccl",
     "suhmo_level_rccl_exchanges",
+    "suhmo_amr2_cf_interp", "suhmo_amr2_average", "suhmo_amr2_fine_update_operator", "suhmo_amr2_residual",
+    "suhmo_amr2_vcycle", "suhmo_amr2_solve",
 ]
 
 
@@ -123,6 +126,12 @@ def lib():
     L.suhmo_level_detach_rccl.argtypes = [vp]
     L.suhmo_level_rccl_exchanges.argtypes = [vp]
     L.suhmo_level_rccl_exchanges.restype = C.c_long
+    L.suhmo_amr2_cf_interp.argtypes = [vp, vp, ci, ci, vp]
+    L.suhmo_amr2_average.argtypes = [vp, vp, ci, ci, vp]
+    L.suhmo_amr2_fine_update_operator.argtypes = [vp, vp, vp]
+    L.suhmo_amr2_residual.argtypes = [vp, vp, dp, vp]
+    L.suhmo_amr2_vcycle.argtypes = [vp, vp, C.POINTER(SolverParams), vp]
+    L.suhmo_amr2_solve.argtypes = [vp, vp, C.POINTER(SolverParams), C.POINTER(ci), dp, vp]
     L.suhmo_level_profile_reset.argtypes = [vp]
     L.suhmo_level_profile_enable.argtypes = [vp, ci]
     L.suhmo_level_profile_read.argtypes = [vp, vp, dp, C.POINTER(C.c_long), C.POINTER(C.c_long)]

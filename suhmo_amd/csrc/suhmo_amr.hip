@@ -1,0 +1,280 @@
+// suhmo_amr.hip -- two AMR levels: a base level (with its multigrid depths) and ONE rectangular fine patch
+// refined by 2 (cfg3 of BASELINE.json: exec/0_convergence_channelized/2lev_base, fixed refined box).
+//
+// From the reference's own source:
+//   relaxNF / AMRResidualNF / AMROperator / AMRRestrictS / AMRProlongS_2 / AMRNorm
+//                                    src/AMRNonLinearPoissonOp.cpp:690-704, 889-1069, 1143-1264
+//   reflux + getFlux                 src/VCAMRNonLinearPoissonOp.cpp:555-652, 792-841
+//   UpdateOperator / WFlx_level with a coarser level   src/VCAMRNonLinearPoissonOp.cpp:34-64, src/AmrHydro.cpp:1455-1488
+// Restated from upstream Chombo's documented semantics because the fork is not vendored (UNPINNED, SURVEY.md
+// Appendix E): QuadCFInterp, LevelFluxRegister, FORT_AVERAGE, the ghosted coarse copy of AMRProlongS_2 and the AMR
+// FAS cycle order.  The oracle's amr2.c states the same arithmetic; parity is bitwise.
+//
+// The fine level is an ordinary suhmo_level created with desc.i0/nx_global/j0/ny_global: sides of its rectangle
+// inside the domain are coarse-fine sides whose ghost cells are STORED (DV::cfx / DV::ext) and filled here.
+#include "suhmo_common.h"
+
+namespace {
+struct Pair { suhmo_level *C, *F; };
+
+int check_pair(suhmo_level *C, suhmo_level *F)
+{
+    ARG(C && F);
+    const DV &c = C->d[0].v, &f = F->d[0].v;
+    if (c.i0 || c.j0 || c.nx != c.nxg || c.ny != c.nyg) { suhmo_set_error("amr2: the base level must span the domain"); return -1; }
+    if (f.nxg != 2 * c.nxg || f.nyg != 2 * c.nyg || (f.i0 & 1) || (f.j0 & 1) || (f.nx & 1) || (f.ny & 1)) {
+        suhmo_set_error("amr2: the fine level must be a coarse-aligned patch of the domain refined by 2"); return -1; }
+    if (C->device != F->device) { suhmo_set_error("amr2: both levels on one device"); return -1; }
+    return 0;
+}
+
+// coarse value at GLOBAL coarse cell (I, J), periodic wrap
+__device__ __forceinline__ double cval(const DV &vc, const double *__restrict__ c, int I, int J)
+{
+    if (vc.per[0]) { if (I < 0) I += vc.nxg; else if (I >= vc.nxg) I -= vc.nxg; }
+    if (vc.per[1]) { if (J < 0) J += vc.nyg; else if (J >= vc.nyg) J -= vc.nyg; }
+    return c[cidx(vc, I, J)];
+}
+
+// [Chombo] QuadCFInterp::coarseFineInterp, ratio 2 (oracle/amr2.c:cf_interp): tangential quadratic on the coarse
+// level (one-sided next to a non-periodic domain boundary), then a normal quadratic through that value and the two
+// fine cells inside: ghost = 8/15 phistar + 2/3 near - 1/5 far.  One thread per coarse-fine ghost cell.
+__global__ void k_cf_interp(DV vf, double *__restrict__ f, DV vc, const double *__restrict__ c)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int dir, side, tt;
+    if (t < 2 * vf.ny) { dir = 0; side = t / vf.ny; tt = t % vf.ny; if (!vf.cfx[side]) return; }
+    else { t -= 2 * vf.ny; if (t >= 2 * vf.nx) return; dir = 1; side = t / vf.nx; tt = t % vf.nx; if (!vf.ext[side]) return; }
+    const double c_s = 8.0 / 15.0, c_b = 2.0 / 3.0, c_a = -0.2;
+    const int tdir = 1 - dir;
+    int gl = dir == 0 ? (side ? vf.nx : -1) : (side ? vf.ny : -1);            // local normal index of the ghost cell
+    int inward = side ? -1 : 1;
+    int g = gl + (dir == 0 ? vf.i0 : vf.j0), tg = tt + (dir == 0 ? vf.j0 : vf.i0);   // global fine indices
+    int icn = g >> 1, ict = tg >> 1;
+    double xt = (tg & 1) ? 0.25 : -0.25;
+    int per = vc.per[tdir], nct = tdir == 0 ? vc.nxg : vc.nyg;
+    bool have_lo = per || ict - 1 >= 0, have_hi = per || ict + 1 <= nct - 1;
+#define CV(o) (dir == 0 ? cval(vc, c, icn, ict + (o)) : cval(vc, c, ict + (o), icn))
+    double c0 = CV(0), d1 = 0.0, d2 = 0.0;
+    if (have_lo && have_hi) { double cm = CV(-1), cp = CV(1); d1 = 0.5 * (cp - cm); d2 = cp - 2.0 * c0 + cm; }
+    else if (have_hi) { double cp = CV(1), cpp = CV(2); d1 = 0.5 * (-3.0 * c0 + 4.0 * cp - cpp); d2 = c0 - 2.0 * cp + cpp; }
+    else if (have_lo) { double cm = CV(-1), cmm = CV(-2); d1 = 0.5 * (3.0 * c0 - 4.0 * cm + cmm); d2 = c0 - 2.0 * cm + cmm; }
+#undef CV
+    double phistar = c0 + xt * d1 + (0.5 * xt * xt) * d2;
+    int ig = dir == 0 ? gl : tt, jg = dir == 0 ? tt : gl;
+    int idx = cidx(vf, ig, jg), step = dir == 0 ? inward : inward * vf.P;
+    f[idx] = c_s * phistar + c_b * f[idx + step] + c_a * f[idx + 2 * step];
+}
+
+// [Chombo] FORT_AVERAGE: covered coarse cell = (sum of its 4 fine cells, i fastest) * 1/4
+__global__ void k_amr_average(DV vf, const double *__restrict__ f, DV vc, double *__restrict__ c)
+{
+    int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y * blockDim.y + threadIdx.y;
+    if (I >= vf.nx / 2 || J >= vf.ny / 2) return;
+    int b = cidx(vf, 2 * I, 2 * J);
+    double s = 0.0;
+    s = s + f[b]; s = s + f[b + 1]; s = s + f[b + vf.P]; s = s + f[b + vf.P + 1];
+    c[cidx(vc, I + vf.i0 / 2, J + vf.j0 / 2)] = s * 0.25;
+}
+__global__ void k_amr_set_covered(DV vf, DV vc, double *__restrict__ c, double val)
+{
+    int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y * blockDim.y + threadIdx.y;
+    if (I >= vf.nx / 2 || J >= vf.ny / 2) return;
+    c[cidx(vc, I + vf.i0 / 2, J + vf.j0 / 2)] = val;
+}
+
+// [Chombo] LevelFluxRegister (oracle/amr2.c:reflux): on every coarse-fine face the coarse flux is replaced by the
+// average of the two fine fluxes; L(phi) of the coarse cell outside the patch += sign * reg / (dx dy).
+// Fluxes as VCAMRNonLinearPoissonOp::getFlux (:792-841).  One thread per coarse face of the patch boundary.
+__global__ void k_amr_reflux(DV vf, FP ff, DV vc, FP fc, double *__restrict__ lofphi)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ncx = vf.nx / 2, ncy = vf.ny / 2, ci0 = vf.i0 / 2, cj0 = vf.j0 / 2;
+    int dir, side, T;
+    if (t < 2 * ncy) { dir = 0; side = t / ncy; T = cj0 + t % ncy; }
+    else { t -= 2 * ncy; if (t >= 2 * ncx) return; dir = 1; side = t / ncx; T = ci0 + t % ncx; }
+    int F = dir == 0 ? (side == 0 ? ci0 : ci0 + ncx) : (side == 0 ? cj0 : cj0 + ncy);      // coarse face index
+    int outside = side == 0 ? F - 1 : F, ndomc = dir == 0 ? vc.nxg : vc.nyg;
+    if (outside < 0 || outside > ndomc - 1) return;              // patch side on the domain boundary
+    const double rscale = 1.0 / (vc.dx * vc.dy);
+    const double dxd = dir == 0 ? vc.dx : vc.dy, tsize = dir == 0 ? vc.dy : vc.dx;
+    const double cs = vc.beta * 1 / dxd, fs = vc.beta * 2 / dxd;
+    const double sign = side == 0 ? 1.0 : -1.0;
+    const double *__restrict__ phic = fc.f[SUHMO_F_PHI], *__restrict__ phif = ff.f[SUHMO_F_PHI];
+    double phihi, philo, bc_;
+    if (dir == 0) { int idx = cidx(vc, F, T); phihi = phic[idx]; philo = phic[idx - 1]; bc_ = fc.f[SUHMO_F_BX][idx]; }
+    else { int idx = cidx(vc, T, F); phihi = phic[idx]; philo = phic[idx - vc.P]; bc_ = fc.f[SUHMO_F_BY][idx]; }
+    double Fc = -bc_ * ((phihi - philo) * cs);
+    double reg = -(tsize * Fc);
+    for (int k = 0; k < 2; k++) {
+        int fi = (dir == 0 ? 2 * F : 2 * T + k) - vf.i0, fj = (dir == 0 ? 2 * T + k : 2 * F) - vf.j0;   // local fine face
+        int idx = cidx(vf, fi, fj);
+        double ph_hi = phif[idx], ph_lo = dir == 0 ? phif[idx - 1] : phif[idx - vf.P];
+        double bf = dir == 0 ? ff.f[SUHMO_F_BX][idx] : ff.f[SUHMO_F_BY][idx];
+        double Ff = -bf * ((ph_hi - ph_lo) * fs);
+        reg = reg + (tsize * Ff) * 0.5;
+    }
+    int oidx = dir == 0 ? cidx(vc, outside, T) : cidx(vc, T, outside);
+    lofphi[oidx] = lofphi[oidx] + sign * rscale * reg;
+}
+
+// PROLONG_2_NL (src/AMRNonLinearPoissonOpF.ChF:660-705) from the coarse LEVEL's correction canvas (its ghost ring
+// holds the BC values, AMRProlongS_2 :1160-1166)
+__global__ void k_amr_prolong2(DV vf, double *__restrict__ phi, DV vc, const double *__restrict__ c)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= vf.nx || j >= vf.ny) return;
+    const double den = 1.0 / 16.0, fx1 = 3.0 * den, fx2 = 9.0 * den, f0 = 1.0 * den;
+    int gi = i + vf.i0, gj = j + vf.j0;
+    int ic = gi / 2, jc = gj / 2, o1 = 2 * (gi % 2) - 1, o2 = 2 * (gj % 2) - 1;
+    int idx = cidx(vf, i, j), cc = cidx(vc, ic, jc);
+    // the diagonal neighbour: a ghost cell of the coarsened patch box that lies outside the domain is filled by
+    // m_bc only along the box's own extent -- the corner cell beyond it is never written (:1160-1172), value 0
+    double cd = c[cc + o1 + o2 * vc.P];
+    {
+        const int I = ic + o1, J = jc + o2, ci0 = vf.i0 / 2, ci1 = ci0 + vf.nx / 2 - 1, cj0 = vf.j0 / 2, cj1 = cj0 + vf.ny / 2 - 1;
+        const bool xout = !vc.per[0] && (I < 0 || I >= vc.nxg), yout = !vc.per[1] && (J < 0 || J >= vc.nyg);
+        if ((xout && (J < cj0 || J > cj1)) || (yout && (I < ci0 || I > ci1))) cd = 0.0;
+    }
+    double p = phi[idx];
+    p = p + fx2 * c[cc] + f0 * cd;
+    p = p + fx1 * (c[cc + o1] + c[cc + o2 * vc.P]);
+    phi[idx] = p;
+}
+}  // namespace
+
+int suhmo_grad_cc(suhmo_level *L, int depth, hipStream_t st);          // suhmo_level.hip: k_gradcc (+ k_grad_ghosts)
+int suhmo_re_bcoef_unfused(suhmo_level *L, int depth, hipStream_t st);  // suhmo_level.hip: k_grad_ghosts, k_re, k_bcoef_faces
+
+extern "C" int suhmo_amr2_cf_interp(suhmo_level_t *C, suhmo_level_t *F, int field_f, int field_c, suhmo_stream_t s)
+{
+    int rc = check_pair(C, F); if (rc) return rc;
+    ARG(field_f >= 0 && field_f < SUHMO_F_COUNT && field_c >= 0 && field_c < SUHMO_F_COUNT);
+    HIPCHK(hipSetDevice(F->device));
+    const DV &vf = F->d[0].v, &vc = C->d[0].v;
+    double *pf = suhmo_field(F, 0, field_f), *pc = suhmo_field(C, 0, field_c);
+    if (!pf || !pc) { suhmo_set_error("field allocation failed"); return -2; }
+    int n = 2 * vf.ny + 2 * vf.nx;
+    hipLaunchKernelGGL(k_cf_interp, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, vf, pf, vc, pc);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int suhmo_amr2_average(suhmo_level_t *C, suhmo_level_t *F, int field_f, int field_c, suhmo_stream_t s)
+{
+    int rc = check_pair(C, F); if (rc) return rc;
+    ARG(field_f >= 0 && field_f < SUHMO_F_COUNT && field_c >= 0 && field_c < SUHMO_F_COUNT);
+    HIPCHK(hipSetDevice(F->device));
+    const DV &vf = F->d[0].v, &vc = C->d[0].v;
+    double *pf = suhmo_field(F, 0, field_f), *pc = suhmo_field(C, 0, field_c);
+    if (!pf || !pc) { suhmo_set_error("field allocation failed"); return -2; }
+    if (field_c == SUHMO_F_PHI) C->d[0].phi_fresh = 0;
+    hipLaunchKernelGGL(k_amr_average, dim3((vf.nx / 2 + 63) / 64, (vf.ny / 2 + 3) / 4), dim3(64, 4), 0, (hipStream_t)s, vf, pf, vc, pc);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// UpdateOperator of the fine level with a coarser level (src/VCAMRNonLinearPoissonOp.cpp:34-64 ->
+// AmrHydro::WFlx_level :1415-1539): fine cell-centred gradient, coarse gradient + QuadCFInterp of both components
+// into the fine coarse-fine ghosts, ExtrapGhostCells on domain sides, Re on the ghosted box, bCoef on the faces
+extern "C" int suhmo_amr2_fine_update_operator(suhmo_level_t *C, suhmo_level_t *F, suhmo_stream_t s)
+{
+    int rc = check_pair(C, F); if (rc) return rc;
+    HIPCHK(hipSetDevice(F->device));
+    hipStream_t st = (hipStream_t)s;
+    if ((rc = suhmo_grad_cc(F, 0, st))) return rc;
+    if ((rc = suhmo_grad_cc(C, 0, st))) return rc;                 // includes exchange (periodic) + ExtrapGhostCells
+    if ((rc = suhmo_amr2_cf_interp(C, F, SUHMO_F_GRADX, SUHMO_F_GRADX, s))) return rc;
+    if ((rc = suhmo_amr2_cf_interp(C, F, SUHMO_F_GRADY, SUHMO_F_GRADY, s))) return rc;
+    return suhmo_re_bcoef_unfused(F, 0, st);
+}
+
+// composite residual: fine RES = rhs1 - L1(phi1) after coarseFineInterp (AMRResidualNF :922-939); coarse RES =
+// rhs0 - [applyOpI(phi0) + reflux] (AMRResidual :889-903, AMROperator :942-967); covered coarse cells are zeroed
+// and the max norm over both levels is returned (AMRNorm :1222-1264)
+extern "C" int suhmo_amr2_residual(suhmo_level_t *C, suhmo_level_t *F, double *norm, suhmo_stream_t s)
+{
+    int rc = check_pair(C, F); if (rc) return rc;
+    HIPCHK(hipSetDevice(F->device));
+    hipStream_t st = (hipStream_t)s;
+    const DV &vf = F->d[0].v, &vc = C->d[0].v;
+    if ((rc = suhmo_amr2_cf_interp(C, F, SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc;
+    if ((rc = suhmo_level_residual(F, 0, s))) return rc;
+    if ((rc = suhmo_level_apply_op(C, 0, 0, s))) return rc;                       // LPHI = L0(phi0), kept
+    double *res = suhmo_field(C, 0, SUHMO_F_RES), *lphi = suhmo_field(C, 0, SUHMO_F_LPHI);
+    HIPCHK(hipMemcpyAsync(res, lphi, C->d[0].elems * sizeof(double), hipMemcpyDeviceToDevice, st));
+    int n = vf.ny + vf.nx;                                                        // 2 * (ncy + ncx) coarse faces
+    hipLaunchKernelGGL(k_amr_reflux, dim3((n + 255) / 256), dim3(256), 0, st, vf, F->d[0].fp, vc, C->d[0].fp, res);
+    HIPCHK(hipGetLastError());
+    if ((rc = suhmo_level_axby(C, 0, SUHMO_F_RES, SUHMO_F_RES, SUHMO_F_RHS, -1.0, 1.0, s))) return rc;
+    hipLaunchKernelGGL(k_amr_set_covered, dim3((vf.nx / 2 + 63) / 64, (vf.ny / 2 + 3) / 4), dim3(64, 4), 0, st, vf, vc, res, 0.0);
+    HIPCHK(hipGetLastError());
+    if (norm) {
+        double a = 0.0, b = 0.0;
+        if ((rc = suhmo_level_norm(C, 0, SUHMO_F_RES, 0, &a, s))) return rc;
+        if ((rc = suhmo_level_norm(F, 0, SUHMO_F_RES, 0, &b, s))) return rc;
+        *norm = a > b ? a : b;
+    }
+    return 0;
+}
+
+// one AMR FAS V-cycle (VCycleAMR; same order as oracle/amr2.c:or_amr2_vcycle)
+extern "C" int suhmo_amr2_vcycle(suhmo_level_t *C, suhmo_level_t *F, const suhmo_solver_params_t *sp, suhmo_stream_t s)
+{
+    int rc = check_pair(C, F); if (rc) return rc;
+    ARG(sp);
+    HIPCHK(hipSetDevice(F->device));
+    hipStream_t st = (hipStream_t)s;
+    Depth &DC = C->d[0], &DF = F->d[0];
+    const size_t cbytes = DC.elems * sizeof(double);
+    double *rhs0 = suhmo_field(C, 0, SUHMO_F_RHS0), *phiold = suhmo_field(C, 0, SUHMO_F_PHIOLD), *corr = suhmo_field(C, 0, SUHMO_F_CORR);
+    if (!rhs0 || !phiold || !corr) { suhmo_set_error("field allocation failed"); return -2; }
+    // operator of the fine level from the current head
+    if ((rc = suhmo_amr2_cf_interp(C, F, SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc;
+    if (sp->bcoeff_otf && (rc = suhmo_amr2_fine_update_operator(C, F, s))) return rc;
+    // relaxNF(phi1, phi0, rhs1, pre)
+    if ((rc = suhmo_level_gsrb(F, 0, sp->num_smooth, s))) return rc;
+    // AMRRestrictS(skip_res): phi0 under the patch <- average(phi1)
+    if ((rc = suhmo_amr2_average(C, F, SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc;
+    // residuals; covered coarse cells <- average(res1); FAS rhs of the base level = res0' + L0(phi0)
+    if ((rc = suhmo_amr2_residual(C, F, nullptr, s))) return rc;
+    if ((rc = suhmo_amr2_average(C, F, SUHMO_F_RES, SUHMO_F_RES, s))) return rc;
+    HIPCHK(hipMemcpyAsync(rhs0, DC.fp.f[SUHMO_F_RHS], cbytes, hipMemcpyDeviceToDevice, st));
+    if ((rc = suhmo_level_axby(C, 0, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
+    HIPCHK(hipMemcpyAsync(phiold, DC.fp.f[SUHMO_F_PHI], cbytes, hipMemcpyDeviceToDevice, st));
+    if ((rc = suhmo_level_vcycle(C, sp, s))) return rc;                          // MGCycle of the base level
+    HIPCHK(hipMemcpyAsync(DC.fp.f[SUHMO_F_RHS], rhs0, cbytes, hipMemcpyDeviceToDevice, st));
+    // AMRProlongS_2: phi1 += PROLONG_2_NL(phi0 - phi0_old), coarse correction with inhomogeneous-BC ghosts
+    if ((rc = suhmo_level_axby(C, 0, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) return rc;
+    if ((rc = suhmo_level_fill_ghosts(C, 0, SUHMO_F_CORR, 0, s))) return rc;
+    hipLaunchKernelGGL(k_amr_prolong2, dim3((DF.v.nx + 63) / 64, (DF.v.ny + 3) / 4), dim3(64, 4), 0, st, DF.v, DF.fp.f[SUHMO_F_PHI], DC.v, corr);
+    HIPCHK(hipGetLastError());
+    // relaxNF(phi1, phi0, rhs1, post)
+    if ((rc = suhmo_amr2_cf_interp(C, F, SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc;
+    return suhmo_level_gsrb(F, 0, sp->num_smooth, s);
+}
+
+// AMRMultiGrid::solveNoInit stopping rule on the composite residual norm
+extern "C" int suhmo_amr2_solve(suhmo_level_t *C, suhmo_level_t *F, const suhmo_solver_params_t *sp, int *iters, double *hist, suhmo_stream_t s)
+{
+    ARG(sp);
+    int rc;
+    double rnorm = 0.0;
+    if ((rc = suhmo_amr2_residual(C, F, &rnorm, s))) return rc;
+    double initial_rnorm = rnorm, norm_last = 2.0 * initial_rnorm;
+    int iter = 0;
+    if (hist) hist[0] = rnorm;
+    bool goNorm = rnorm > sp->norm_thresh, goRedu = rnorm > sp->eps * initial_rnorm, goIter = iter < sp->max_iter;
+    bool goHang = iter < sp->imin || rnorm < (1.0 - sp->hang) * norm_last, goMin = iter < sp->iter_min;
+    while (goMin || (goIter && goRedu && goHang && goNorm)) {
+        norm_last = rnorm;
+        if ((rc = suhmo_amr2_vcycle(C, F, sp, s))) return rc;
+        if ((rc = suhmo_amr2_residual(C, F, &rnorm, s))) return rc;
+        iter++;
+        if (hist) hist[iter] = rnorm;
+        goNorm = rnorm > sp->norm_thresh; goRedu = rnorm > sp->eps * initial_rnorm; goIter = iter < sp->max_iter;
+        goHang = iter < sp->imin || rnorm < (1.0 - sp->hang) * norm_last; goMin = iter < sp->iter_min;
+    }
+    if (iters) *iters = iter;
+    return 0;
+}

@@ -30,7 +30,9 @@ struct DV {
     double two_v[2][2];// 2.0*value               (DiriBC order 1: 2*value - near)
     double neu[2][2];  // (sign*dx)*value         (NeumBC: near + sign*dx*value)
     int per[2];        // periodic
-    int ext[2];        // y side is a rank boundary: ghost rows hold exchanged data
+    int ext[2];        // y side is a rank boundary or a coarse-fine side: ghost rows hold data
+    int i0, nxg;       // AMR patch: global column of local i = 0, columns of the whole (refined) domain
+    int cfx[2];        // x side is a coarse-fine side: ghost columns hold interpolated data
 };
 
 struct FP { double *f[SUHMO_F_COUNT]; };
@@ -46,14 +48,14 @@ __host__ __device__ __forceinline__ int cidx(const DV &v, int i, int j)
 // it is recomputed from registers instead of being stored between colour passes.
 __device__ __forceinline__ double phiW(const DV &v, const double *__restrict__ p, int idx, int i, double c, bool homog)
 {
-    if (i > 0) return p[idx - 1];
+    if (i > 0 || v.cfx[0]) return p[idx - 1];
     if (v.per[0]) return p[idx + v.nx - 1];
     if (v.bct[0][0] == 0) return (homog ? 0.0 : v.two_v[0][0]) - c;
     return homog ? c : c + v.neu[0][0];
 }
 __device__ __forceinline__ double phiE(const DV &v, const double *__restrict__ p, int idx, int i, double c, bool homog)
 {
-    if (i < v.nx - 1) return p[idx + 1];
+    if (i < v.nx - 1 || v.cfx[1]) return p[idx + 1];
     if (v.per[0]) return p[idx - (v.nx - 1)];
     if (v.bct[0][1] == 0) return (homog ? 0.0 : v.two_v[0][1]) - c;
     return homog ? c : c + v.neu[0][1];

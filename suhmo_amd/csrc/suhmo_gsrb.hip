@@ -231,6 +231,7 @@ static bool fused_ok(const suhmo_level *L, const Depth &D, int K)
 {
     const DV &v = D.v;
     if (v.nx % 2 || v.nx < 64 || v.ny < 4 * K + 4) return false;
+    if (v.cfx[0] || v.cfx[1] || L->desc.nx_global > 0) return false;   // AMR patch: colour-pass kernel (stored coarse-fine ghosts)
     if ((v.ext[0] || v.ext[1]) && (v.gy < 2 * K || v.ny < 2 * K)) return false;   // halo rows must be real data
     if (v.per[1] && !(v.ext[0] || v.ext[1]) && v.ny < 4 * K) return false;
     return true;

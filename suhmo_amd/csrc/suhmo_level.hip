@@ -36,6 +36,7 @@ static void make_dv(DV &v, const suhmo_level_desc_t &d, int depth)
     v.rows = v.ny + 2 * v.gy;
     v.P = ((v.nx + 2 * SUHMO_XOFF + 15) / 16) * 16;
     v.j0 = d.j0 / c; v.nyg = d.ny_global / c;
+    v.i0 = d.i0 / c; v.nxg = (d.nx_global > 0 ? d.nx_global : d.nx) / c;
     v.dx = d.dx * c; v.dy = d.dy * c;
     v.rdx = 1.0 / (v.dx * v.dx); v.rdy = 1.0 / (v.dy * v.dy);
     v.fdx = 1.0 / v.dx; v.fdy = 1.0 / v.dy;
@@ -52,6 +53,8 @@ static void make_dv(DV &v, const suhmo_level_desc_t &d, int depth)
     bool whole = (d.j0 == 0 && d.ny == d.ny_global);
     v.ext[0] = (!whole) && (d.j0 > 0 || d.bc.periodic[1]);
     v.ext[1] = (!whole) && (d.j0 + d.ny < d.ny_global || d.bc.periodic[1]);
+    v.cfx[0] = v.i0 > 0;
+    v.cfx[1] = v.i0 + v.nx < v.nxg;
 }
 
 double *suhmo_field(suhmo_level *L, int depth, int field)
@@ -71,6 +74,8 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     ARG(out && desc);
     ARG(desc->nx >= 2 && desc->ny >= 2 && desc->dx > 0 && desc->dy > 0);
     ARG(desc->ny_global >= desc->ny && desc->j0 >= 0 && desc->j0 + desc->ny <= desc->ny_global);
+    ARG(desc->i0 >= 0 && (desc->nx_global == 0 ? desc->i0 == 0 : desc->i0 + desc->nx <= desc->nx_global));
+    ARG(desc->i0 % 2 == 0);                  // colour parity is taken from the local column
     ARG((long)(desc->nx + 64) * (long)(desc->ny + 2 * (desc->halo_rows < 1 ? 1 : desc->halo_rows)) < (1L << 31));
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
@@ -94,8 +99,8 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
         int mb = desc->max_box > 0 ? desc->max_box : 64;
         for (int bj = 0; bj * mb < desc->ny; bj++)
             for (int bi = 0; bi * mb < desc->nx; bi++) {
-                int lo0 = bi * mb, lo1 = desc->j0 + bj * mb;
-                int hi0 = std::min(lo0 + mb, desc->nx) - 1, hi1 = std::min(lo1 + mb, desc->j0 + desc->ny) - 1;
+                int lo0 = desc->i0 + bi * mb, lo1 = desc->j0 + bj * mb;
+                int hi0 = std::min(lo0 + mb, desc->i0 + desc->nx) - 1, hi1 = std::min(lo1 + mb, desc->j0 + desc->ny) - 1;
                 int b[4] = {lo0, lo1, hi0, hi1};
                 L->boxes.insert(L->boxes.end(), b, b + 4);
             }
@@ -107,7 +112,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
         long cells = 0;
         for (size_t k = 0; k < L->boxes.size(); k += 4) {
             const int *b = &L->boxes[k];
-            if (b[0] < 0 || b[2] >= desc->nx || b[1] < desc->j0 || b[3] >= desc->j0 + desc->ny || b[0] > b[2] || b[1] > b[3]) {
+            if (b[0] < desc->i0 || b[2] >= desc->i0 + desc->nx || b[1] < desc->j0 || b[3] >= desc->j0 + desc->ny || b[0] > b[2] || b[1] > b[3]) {
                 suhmo_set_error("box %zu outside the strip", k / 4); delete L; return -1;
             }
             cells += (long)(b[2] - b[0] + 1) * (b[3] - b[1] + 1);
@@ -119,6 +124,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     for (int dep = 1; dep < SUHMO_MAXDEPTH; dep++) {
         if (!boxes_coarsenable(L->boxes, (1 << dep) * 2)) break;
         if ((desc->j0 % (1 << dep)) || (desc->ny_global % (1 << dep))) break;
+        if ((desc->i0 % (2 << dep)) || (desc->nx_global % (1 << dep))) break;
         L->ndepth = dep + 1;
     }
     static const int eager[] = {SUHMO_F_PHI, SUHMO_F_RHS, SUHMO_F_ACOEF, SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB,
@@ -266,7 +272,8 @@ static void box_region(const suhmo_level *L, int depth, int field, int ibox, int
 {
     const int *b = &L->boxes[4 * (size_t)ibox];
     int c = 1 << depth;
-    r[0] = b[0] / c; r[1] = b[1] / c - L->d[depth].v.j0; r[2] = (b[2] + 1) / c - 1; r[3] = (b[3] + 1) / c - 1 - L->d[depth].v.j0;
+    r[0] = b[0] / c - L->d[depth].v.i0; r[1] = b[1] / c - L->d[depth].v.j0;
+    r[2] = (b[2] + 1) / c - 1 - L->d[depth].v.i0; r[3] = (b[3] + 1) / c - 1 - L->d[depth].v.j0;
     if (field == SUHMO_F_BX || field == SUHMO_F_QWX) r[2] += 1;
     if (field == SUHMO_F_BY || field == SUHMO_F_QWY) r[3] += 1;
 }
@@ -281,6 +288,8 @@ extern "C" int suhmo_level_put_box(suhmo_level_t *L, int depth, int field, int i
     if (field == SUHMO_F_PHI) phi_changed(L, depth);
     int r[4]; box_region(L, depth, field, ibox, r);
     int j0 = v.j0;                         // fab indices are global: local j = global j - j0
+    flo0 -= v.i0; fhi0 -= v.i0;            // ... and local i = global i - i0 (AMR patch)
+    const bool patch = L->desc.nx_global > 0;   // patch sides inside the domain: the fab's ghosts are the coarse-fine data
     long fp = fhi0 - flo0 + 1;
     ARG(flo0 <= r[0] && fhi0 >= r[2] && flo1 - j0 <= r[1] && fhi1 - j0 >= r[3]);
     double *h = (double *)fab;
@@ -295,8 +304,12 @@ extern "C" int suhmo_level_put_box(suhmo_level_t *L, int depth, int field, int i
             rc |= copy2d(L, depth, field, h + (long)(r[1] + j0 - flo1) * fp + (v.nx - flo0), fp, v.nx, r[1], 1, r[3] - r[1] + 1, true, false, st);
         if (r[1] + j0 == 0 && flo1 <= -1)
             rc |= copy2d(L, depth, field, h + (long)(-1 - flo1) * fp + (r[0] - flo0), fp, r[0], -1 - j0, r[2] - r[0] + 1, 1, true, false, st);
+        else if (patch && r[1] == 0 && flo1 <= j0 - 1)
+            rc |= copy2d(L, depth, field, h + (long)(j0 - 1 - flo1) * fp + (r[0] - flo0), fp, r[0], -1, r[2] - r[0] + 1, 1, true, false, st);
         if (r[3] + j0 == v.nyg - 1 && fhi1 >= v.nyg)
             rc |= copy2d(L, depth, field, h + (long)(v.nyg - flo1) * fp + (r[0] - flo0), fp, r[0], v.nyg - j0, r[2] - r[0] + 1, 1, true, false, st);
+        else if (patch && r[3] == v.ny - 1 && fhi1 >= j0 + v.ny)
+            rc |= copy2d(L, depth, field, h + (long)(j0 + v.ny - flo1) * fp + (r[0] - flo0), fp, r[0], v.ny, r[2] - r[0] + 1, 1, true, false, st);
         if (rc) return rc;
     }
     HIPCHK(hipStreamSynchronize(st));
@@ -311,6 +324,7 @@ extern "C" int suhmo_level_get_box(suhmo_level_t *L, int depth, int field, int i
     hipStream_t st = (hipStream_t)s;
     const DV &v = L->d[depth].v;
     int j0 = v.j0;
+    flo0 -= v.i0; fhi0 -= v.i0;
     long fp = fhi0 - flo0 + 1;
     // clip the fab box to the stored canvas region (1 ghost layer in x, gy rows in y)
     int lo0 = std::max(flo0, -1), hi0 = std::min(fhi0, v.nx + (field == SUHMO_F_BX ? 0 : 0));
@@ -333,6 +347,7 @@ __global__ void k_fill_ghosts(DV v, double *__restrict__ p, int homog)
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 2 * v.ny) {                       // x sides
         int side = t / v.ny, j = t % v.ny;
+        if (v.cfx[side]) return;              // coarse-fine side: ghost columns hold interpolated data
         int i = side ? v.nx - 1 : 0;
         int idx = cidx(v, i, j);
         double c = p[idx];
@@ -632,6 +647,7 @@ __global__ void k_grad_ghosts(DV v, double *__restrict__ gx, double *__restrict_
     double *g2[2] = {gx, gy};
     if (t < 2 * v.ny) {
         int side = t / v.ny, j = t % v.ny;
+        if (v.cfx[side]) return;
         for (int c = 0; c < 2; c++) {
             double *g = g2[c];
             if (side == 0) { int idx = cidx(v, 0, j); g[idx - 1] = v.per[0] ? g[idx + v.nx - 1] : 2.0 * g[idx] - g[idx + 1]; }
@@ -684,7 +700,7 @@ __global__ __launch_bounds__(256) void k_bcoef_faces(DV v, FP fp, suhmo_phys_t p
     int idx = cidx(v, i, j);
     const double *__restrict__ Re = fp.f[SUHMO_F_RE], *__restrict__ B = fp.f[SUHMO_F_B], *__restrict__ m = fp.f[SUHMO_F_MASK];
     if (j < v.ny)   // x-face (i,j) between cells (i-1,j) and (i,j)
-        fp.f[SUHMO_F_BX][idx] = bcoef_face(ph, Re[idx], Re[idx - 1], B[idx], B[idx - 1], m[idx], m[idx - 1], i == 0 || i == v.nx);
+        fp.f[SUHMO_F_BX][idx] = bcoef_face(ph, Re[idx], Re[idx - 1], B[idx], B[idx - 1], m[idx], m[idx - 1], i + v.i0 == 0 || i + v.i0 == v.nxg);
     if (i < v.nx) { // y-face (i,j) between cells (i,j-1) and (i,j)
         int jg = j + v.j0;
         fp.f[SUHMO_F_BY][idx] = bcoef_face(ph, Re[idx], Re[idx - v.P], B[idx], B[idx - v.P], m[idx], m[idx - v.P], jg == 0 || jg == v.nyg);
@@ -832,7 +848,8 @@ extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_st
     Depth &D = L->d[depth];
     // fused single-kernel path: needs >= 3 cells per direction (extrapolation sources inside every
     // edge tile) and, on rank boundaries, 2 exchanged phi rows for the halo-row gradient
-    bool fused = L->bcoef_fused && D.v.nx >= 4 && D.v.ny >= 4 && (!(D.v.ext[0] || D.v.ext[1]) || (D.v.gy >= 2 && D.v.ny >= 2));
+    bool fused = L->bcoef_fused && D.v.nx >= 4 && D.v.ny >= 4 && (!(D.v.ext[0] || D.v.ext[1]) || (D.v.gy >= 2 && D.v.ny >= 2))
+                 && L->desc.nx_global == 0;      // AMR patches: un-fused kernels (coarse-fine ghosts are stored data)
     int rc = suhmo_ensure_phi_halo(L, depth, fused ? 2 : 1, st); if (rc) return rc;
     if (fused) {
         dim3 grd((D.v.nx + BT_X - 1) / BT_X, (D.v.ny + BT_Y - 1) / BT_Y);   // the last tile column / row also owns the E / N faces
@@ -849,6 +866,27 @@ extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_st
     HIPCHK(hipGetLastError());
     // strips: the fused relaxation recomputes halo rows, so it needs the coefficients there too
     rc = exchange_fields(L, depth, {SUHMO_F_BX, SUHMO_F_BY}, st); if (rc) return rc;
+    return 0;
+}
+
+// pieces of the un-fused WFlx_level for the AMR fine level (suhmo_amr.hip): cell-centred gradient with its
+// domain-side ghosts; then (after the coarse-fine ghosts were interpolated) Re and bCoef
+int suhmo_grad_cc(suhmo_level *L, int depth, hipStream_t st)
+{
+    Depth &D = L->d[depth];
+    if (!suhmo_field(L, depth, SUHMO_F_GRADX) || !suhmo_field(L, depth, SUHMO_F_GRADY) || !suhmo_field(L, depth, SUHMO_F_RE)) return -2;
+    hipLaunchKernelGGL(k_gradcc, grid2d(D.v.nx, D.v.ny), BLK2D, 0, st, D.v, D.fp, L->ph.use_mask_gradients);
+    int n = 2 * D.v.ny + 2 * D.v.nx;
+    hipLaunchKernelGGL(k_grad_ghosts, dim3((n + 255) / 256), dim3(256), 0, st, D.v, D.fp.f[SUHMO_F_GRADX], D.fp.f[SUHMO_F_GRADY]);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int suhmo_re_bcoef_unfused(suhmo_level *L, int depth, hipStream_t st)
+{
+    Depth &D = L->d[depth];
+    hipLaunchKernelGGL(k_re, grid2d(D.v.nx + 2, D.v.ny + 2), BLK2D, 0, st, D.v, D.fp, L->ph);
+    hipLaunchKernelGGL(k_bcoef_faces, grid2d(D.v.nx + 1, D.v.ny + 1), BLK2D, 0, st, D.v, D.fp, L->ph);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -988,6 +1026,7 @@ __global__ void k_coef_ghosts(DV v, double *__restrict__ p)
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 2 * v.ny) {
         int side = t / v.ny, j = t % v.ny;
+        if (v.cfx[side]) return;
         if (side == 0) { int idx = cidx(v, 0, j); p[idx - 1] = v.per[0] ? p[idx + v.nx - 1] : p[idx]; }
         else { int idx = cidx(v, v.nx - 1, j); p[idx + 1] = v.per[0] ? p[idx - (v.nx - 1)] : p[idx]; }
         return;

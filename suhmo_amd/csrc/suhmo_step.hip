@@ -180,7 +180,7 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
     ARG(L && mp); ARG(dt > 0 && cur_step >= 1);
     if (mp->diffFactor != 0.0) { suhmo_set_error("suhmo.diffFactor != 0: the diffusive term is not built"); return -5; }
     Depth &D = L->d[0];
-    if (D.v.ext[0] || D.v.ext[1]) { suhmo_set_error("timestep on a rank strip is not built yet"); return -5; }
+    if (D.v.ext[0] || D.v.ext[1] || L->desc.nx_global > 0) { suhmo_set_error("timestep on a rank strip / AMR patch is not built yet"); return -5; }
     HIPCHK(hipSetDevice(L->device));
     hipStream_t st = (hipStream_t)s;
     static const int need[] = {SUHMO_F_MR, SUHMO_F_PW, SUHMO_F_QWX, SUHMO_F_QWY, SUHMO_F_HLAG, SUHMO_F_CD,

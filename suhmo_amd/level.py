@@ -12,7 +12,7 @@ from . import capi
 from .capi import check
 
 F_PHI, F_RHS, F_ACOEF, F_B, F_PI, F_ZB, F_MASK, F_BX, F_BY, F_LAMBDA, F_RES, F_LPHI, F_NL, F_DNL, \
-    F_PHIOLD, F_CORR, F_GRADX, F_GRADY, F_RE, F_MR, F_PW, F_QWX, F_QWY, F_HLAG, F_CD = range(25)
+    F_PHIOLD, F_CORR, F_GRADX, F_GRADY, F_RE, F_MR, F_PW, F_QWX, F_QWY, F_HLAG, F_CD, F_RHS0 = range(26)
 
 
 def _phys(p):
@@ -41,7 +41,7 @@ class HipLevel:
     """One AMR level (or this rank's strip of rows of it) resident in HBM."""
 
     def __init__(self, nx, ny, dx, dy, bc, phys, alpha=0.0, beta=-1.0, max_box=64, boxes=None,
-                 j0=0, ny_global=None, device=0, halo_rows=1, stream=None):
+                 j0=0, ny_global=None, device=0, halo_rows=1, stream=None, i0=0, nx_global=0):
         self.nx, self.ny, self.dx, self.dy = nx, ny, dx, dy
         self.j0, self.ny_global = j0, (ny if ny_global is None else ny_global)
         self.stream = C.c_void_p(stream) if stream else C.c_void_p(0)
@@ -55,6 +55,7 @@ class HipLevel:
             d.nbox, d.boxes = 0, None
         d.max_box, d.alpha, d.beta = max_box, alpha, beta
         d.bc, d.phys, d.device, d.halo_rows = _bc(bc), _phys(phys), device, halo_rows
+        d.i0, d.nx_global = i0, nx_global            # AMR patch (see HipAmr2)
         self._desc = d
         h = C.c_void_p()
         check(capi.lib().suhmo_level_create(C.byref(h), C.byref(d)))
@@ -173,3 +174,43 @@ class HipLevel:
         ms, n, c = C.c_double(), C.c_long(), C.c_long()
         check(capi.lib().suhmo_level_profile_read(self.h, self.stream, C.byref(ms), C.byref(n), C.byref(c)))
         return ms.value, n.value, c.value
+
+
+class HipAmr2:
+    """Base level + one fine patch (coarse cells ci0..ci1 x cj0..cj1, refined by 2), both resident in HBM; the
+    mirror of what AMRFASMultiGrid drives through AMRNonLinearPoissonOp::{relaxNF, AMRResidual, AMRRestrictS,
+    AMRProlongS_2, reflux} (src/AMRNonLinearPoissonOp.cpp:690-704, 889-1206)."""
+
+    def __init__(self, nxc, nyc, dxc, dyc, bc, phys, patch, alpha=0.0, beta=-1.0, max_box=64, device=0):
+        ci0, cj0, ci1, cj1 = [int(v) for v in patch]
+        self.coarse = HipLevel(nxc, nyc, dxc, dyc, bc, phys, alpha, beta, max_box, device=device)
+        self.fine = HipLevel(2 * (ci1 - ci0 + 1), 2 * (cj1 - cj0 + 1), dxc / 2.0, dyc / 2.0, bc, phys, alpha, beta, max_box,
+                             j0=2 * cj0, ny_global=2 * nyc, i0=2 * ci0, nx_global=2 * nxc, device=device)
+        self.stream = self.coarse.stream
+
+    def _call(self, name, *args):
+        check(getattr(capi.lib(), "suhmo_amr2_" + name)(self.coarse.h, self.fine.h, *args, self.stream))
+
+    def cf_interp(self, field_f=F_PHI, field_c=F_PHI): self._call("cf_interp", field_f, field_c)
+    def average(self, field_f=F_PHI, field_c=F_PHI): self._call("average", field_f, field_c)
+    def fine_update_operator(self): self._call("fine_update_operator")
+
+    def residual(self):
+        r = C.c_double()
+        self._call("residual", r if False else C.cast(C.pointer(r), C.POINTER(C.c_double)))
+        return r.value
+
+    def vcycle(self, sp):
+        s = solver_params(sp)
+        self._call("vcycle", C.byref(s))
+
+    def solve(self, sp):
+        s = solver_params(sp)
+        hist = np.zeros(s.max_iter + 2)
+        n = C.c_int()
+        self._call("solve", C.byref(s), C.byref(n), hist.ctypes.data_as(C.POINTER(C.c_double)))
+        return n.value, hist[: n.value + 1]
+
+    def close(self):
+        self.fine.close()
+        self.coarse.close()
