@@ -33,7 +33,7 @@ void VCAMRNonLinearPoissonOpHIPFactory::define(const ProblemDomain &a_dom, const
                                                bool a_update_operator, int a_device)
 {
     if (m_level) { suhmo_level_destroy(m_level); m_level = nullptr; m_ops.clear(); m_grids.clear(); }
-    suhmo_level_desc_t d;
+    suhmo_level_desc_t d = {};                 // i0 = nx_global = 0: the level spans the domain in x
     d.nx = a_dom.dom.size(0); d.ny = a_dom.dom.size(1); d.j0 = 0; d.ny_global = d.ny;
     d.dx = a_dx[0]; d.dy = a_dx[1];
     std::vector<int> boxes;
