@@ -85,6 +85,7 @@ enum {
      * flux on x / y faces, lagged head, channelisation degree */
     SUHMO_F_MR, SUHMO_F_PW, SUHMO_F_QWX, SUHMO_F_QWY, SUHMO_F_HLAG, SUHMO_F_CD,
     SUHMO_F_RHS0,        /* AMR: the base level's own rhs while it carries the FAS rhs */
+    SUHMO_F_MSRC,        /* moulin source term, m/s (suhmo_level_moulin_source) */
     SUHMO_F_COUNT
 };
 
@@ -190,11 +191,22 @@ typedef struct suhmo_model_params {
     double distributed_input;          /* suhmo.distributed_input */
     double eps_picard;                 /* solver.eps_PicardIte */
     int basal_friction, use_mask_rhs_b;
+    int use_moulin_source;             /* suhmo.n_moulins > 0: RHS_h += MSRC * ramp + distributed_input (:3060-3066) */
+    double ramp;                       /* suhmo.ramp factor of this step (:2448-2467); 1 when off */
 } suhmo_model_params_t;
 /* cur_step = AmrHydro::m_cur_step after its increment (1 for the first step): selects the solver
  * parameters and the Picard stopping rule.  picard_iters / vcycles: totals of this step. */
 int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t *mp, double dt, int cur_step,
                          int *picard_iters, int *vcycles, suhmo_stream_t s);
+
+/* Moulin source term of one level (Calc_moulin_integral + Calc_moulin_source_term_distributed,
+ * src/AmrHydro.cpp:1866-2066): n Gaussians (positions x0,y0,x1,y1,..., sigma, flux in m3/s; HOST arrays) sampled
+ * with the reference's 3 x 3 Gauss-Legendre rule per cell, each normalised by its integral over the level;
+ * time_factor = max(1 - runoff sin(2 pi (t - t_restart) / 86400), 0).  Result in SUHMO_F_MSRC (m/s);
+ * integrals (m2, n values) are returned when the pointer is not NULL.  exp() is the device library's: results
+ * agree with the CPU restatement to ~1e-14 relative, not bitwise. */
+int suhmo_level_moulin_source(suhmo_level_t *L, int n_moulins, const double *positions, const double *sigma,
+                              const double *flux, double time_factor, double *integrals, suhmo_stream_t s);
 
 /* multi-GPU strips: pack the `rows` owned rows next to side (0 = y-lo, 1 = y-hi) of a
  * field into a contiguous device buffer (rows x (nx+1) doubles) / unpack a neighbour's rows

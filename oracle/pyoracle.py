@@ -32,7 +32,8 @@ class OrModelParams(C.Structure):
                 ("L", C.c_double), ("ct", C.c_double), ("cw", C.c_double), ("ub0", C.c_double), ("ub1", C.c_double),
                 ("br", C.c_double), ("lr", C.c_double), ("diffFactor", C.c_double),
                 ("distributed_input", C.c_double), ("eps_picard", C.c_double),
-                ("basal_friction", C.c_int), ("use_mask_rhs_b", C.c_int)]
+                ("basal_friction", C.c_int), ("use_mask_rhs_b", C.c_int), ("use_moulin_source", C.c_int),
+                ("ramp", C.c_double)]
 
 
 class OrSolverParams(C.Structure):
@@ -94,6 +95,7 @@ def lib():
         L.or_model_field.argtypes = [C.c_void_p, C.c_int]
         L.or_model_timestep.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.or_model_step_index.argtypes = [C.c_void_p]
+        L.or_moulin_source.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, dp, dp, dp, C.c_double, dp, dp]
         L.or_amr2_create.restype = C.c_void_p
         L.or_amr2_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(OrBC), C.POINTER(OrPhys),
                                      C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -255,14 +257,15 @@ def getflux(phi_ghosted, bface, direction, beta, dx_dir, ref=1):
 
 
 # ---- time loop ("next rows"): one AmrHydro::timeStepFAS per call
-OM_H, OM_B, OM_BOLD, OM_PI, OM_ZB, OM_MASK, OM_MR, OM_PW, OM_SRC, OM_RHSH, OM_CD, OM_GRADX, OM_GRADY, OM_RE, OM_HLAG = range(15)
+OM_H, OM_B, OM_BOLD, OM_PI, OM_ZB, OM_MASK, OM_MR, OM_PW, OM_SRC, OM_RHSH, OM_CD, OM_GRADX, OM_GRADY, OM_RE, OM_HLAG, OM_MSRC = range(16)
 OM_QWX, OM_QWY = 100, 101
 
 
 def make_model_params(m):
     return OrModelParams(m["rho_i"], m["rho_w"], m["gravity"], m["G"], m["L"], m["ct"], m["cw"], m["ub"][0], m["ub"][1],
                          m["br"], m["lr"], m["diffFactor"], m["distributed_input"], m["eps_picard"],
-                         int(m["basal_friction"]), int(m.get("use_mask_rhs_b", 0)))
+                         int(m["basal_friction"]), int(m.get("use_mask_rhs_b", 0)), int(m.get("use_moulin_source", 0)),
+                         float(m.get("ramp", 1.0)))
 
 
 class OracleModel:
@@ -361,3 +364,13 @@ class OracleAmr2:
             lib().or_amr2_destroy(self.h)
             self.h = None
             self.coarse.close()
+
+
+def moulin_source(nx, ny, dx, dy, positions, sigma, flux, time_factor=1.0):
+    """(src (ny, nx), integrals (n,)): oracle/time_loop.c:or_moulin_source"""
+    pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1)
+    sg, fl = np.ascontiguousarray(sigma, dtype=np.float64), np.ascontiguousarray(flux, dtype=np.float64)
+    nm = sg.size
+    integ, src = np.zeros(nm), np.zeros((ny, nx))
+    lib().or_moulin_source(nx, ny, dx, dy, nm, _dp(pos), _dp(sg), _dp(fl), float(time_factor), _dp(integ), _dp(src))
+    return src, integ

@@ -30,10 +30,12 @@ typedef struct OrModelParams {
     double eps_picard;                  /* solver.eps_PicardIte */
     int basal_friction;
     int use_mask_rhs_b;
+    int use_moulin_source;              /* suhmo.n_moulins > 0: RHS_h += msrc * ramp + distributed_input (:3060-3066) */
+    double ramp;                        /* suhmo.ramp (:2448-2467), 1 when off */
 } OrModelParams;
 
 enum { OM_H = 0, OM_B, OM_BOLD, OM_PI, OM_ZB, OM_MASK, OM_MR, OM_PW, OM_SRC, OM_RHSH, OM_CD,
-       OM_GRADX, OM_GRADY, OM_RE, OM_HLAG, OM_NCELL, OM_QWX = 100, OM_QWY = 101 };
+       OM_GRADX, OM_GRADY, OM_RE, OM_HLAG, OM_MSRC, OM_NCELL, OM_QWX = 100, OM_QWY = 101 };
 
 typedef struct OrModel {
     OrLevel *L;
@@ -245,8 +247,10 @@ int or_model_timestep(OrModel *M, double dt, int *picard_iters, int *vcycles_tot
         memcpy(hl, h, nc * sizeof(double));
         cell_to_edge(M, B, M->bxf, M->byf);
         grad_re_qw(M);
-        for (int j = -1; j <= ny; j++) for (int i = -1; i <= nx; i++)       /* distributed input :2865-2877 */
-            CC(src, i, j) = (CC(IM, i, j) > 0.0) ? p->distributed_input : 0.0;
+        for (int j = -1; j <= ny; j++) for (int i = -1; i <= nx; i++) {     /* distributed input :2865-2877 */
+            if (p->use_moulin_source) CC(src, i, j) = CC(M->c[OM_MSRC], i, j) * p->ramp + p->distributed_input;   /* :3065 */
+            else CC(src, i, j) = (CC(IM, i, j) > 0.0) ? p->distributed_input : 0.0;
+        }
         melting_rate(M);
         double rho_coef = (1.0 / p->rho_w - 1.0 / p->rho_i);                 /* :3023 */
         {   /* diagnosis knob (tools/run_shmip_a.py --head-melt-coef, DESIGN.md "end-to-end pin"): scales the melt
@@ -312,4 +316,46 @@ int or_model_timestep(OrModel *M, double dt, int *picard_iters, int *vcycles_tot
     if (vcycles_total) *vcycles_total = nv;
     free(tmp);
     return 0;
+}
+
+
+/* Calc_moulin_integral + Calc_moulin_source_term_distributed (src/AmrHydro.cpp:1866-2066), single level:
+ * every moulin is a Gaussian evaluated with a 3 x 3 Gauss-Legendre rule per cell, normalised by its integral over
+ * the level so that it delivers exactly moulin_flux; time_factor = max(1 - runoff sin(2 pi (t - t0)/86400), 0).
+ * src: valid cells ny x nx (m/s); integ: the nm integrals (m2). */
+void or_moulin_source(int nx, int ny, double dx, double dy, int nm, const double *pos, const double *sigma,
+                      const double *flux, double time_factor, double *integ, double *src)
+{
+    const double v[3] = {0.5555555555, 0.8888888888, 0.5555555555};
+    const double l[3] = {-0.77459666924 / 2.0, 0.0, 0.77459666924 / 2.0};
+    double *ms = (double *)malloc(sizeof(double) * (size_t)nx * ny * nm);
+    for (int m = 0; m < nm; m++) integ[m] = 0.0;
+    for (int j = 0; j < ny; j++)
+        for (int i = 0; i < nx; i++) {
+            double xl[3], yl[3];
+            for (int k = 0; k < 3; k++) { xl[k] = (i + 0.5 + l[k]) * dx; yl[k] = (j + 0.5 + l[k]) * dy; }
+            for (int m = 0; m < nm; m++) {
+                double prefac = 1.0 / (sigma[m] * sqrt(2.0 * 3.14));
+                double MS[9];
+                for (int b = 0; b < 3; b++)
+                    for (int a = 0; a < 3; a++) {
+                        double ex = xl[a] - pos[2 * m], ey = yl[b] - pos[2 * m + 1];
+                        double rad = ex * ex + ey * ey;                          /* std::pow(., 2) */
+                        MS[3 * b + a] = prefac * exp(-1.0 / (2.0 * sigma[m] * sigma[m]) * rad);
+                    }
+                double val = v[0] * v[0] * MS[0] + v[1] * v[0] * MS[1] + v[2] * v[0] * MS[2]
+                           + v[0] * v[1] * MS[3] + v[1] * v[1] * MS[4] + v[2] * v[1] * MS[5]
+                           + v[0] * v[2] * MS[6] + v[1] * v[2] * MS[7] + v[2] * v[2] * MS[8];
+                ms[((size_t)j * nx + i) * nm + m] = val;
+            }
+        }
+    for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int m = 0; m < nm; m++)
+        integ[m] += ms[((size_t)j * nx + i) * nm + m] * dx * dy;
+    for (int j = 0; j < ny; j++)
+        for (int i = 0; i < nx; i++) {
+            double sum = 0.0;
+            for (int m = 0; m < nm; m++) sum += ms[((size_t)j * nx + i) * nm + m] * time_factor / integ[m] * flux[m];
+            src[(size_t)j * nx + i] = sum;
+        }
+    free(ms);
 }

@@ -38,7 +38,8 @@ class ModelParams(C.Structure):
                 ("L", C.c_double), ("ct", C.c_double), ("cw", C.c_double), ("ub0", C.c_double), ("ub1", C.c_double),
                 ("br", C.c_double), ("lr", C.c_double), ("diffFactor", C.c_double),
                 ("distributed_input", C.c_double), ("eps_picard", C.c_double),
-                ("basal_friction", C.c_int), ("use_mask_rhs_b", C.c_int)]
+                ("basal_friction", C.c_int), ("use_mask_rhs_b", C.c_int), ("use_moulin_source", C.c_int),
+                ("ramp", C.c_double)]
 
 
 class LevelDesc(C.Structure):
@@ -68,7 +69,7 @@ SYMBOLS = [
     "suhmo_rccl_load", "suhmo_rccl_unique_id", "suhmo_level_attach_rccl", "suhmo_level_detach_rccl",
     "suhmo_level_rccl_exchanges",
     "suhmo_amr2_cf_interp", "suhmo_amr2_average", "suhmo_amr2_fine_update_operator", "suhmo_amr2_residual",
-    "suhmo_amr2_vcycle", "suhmo_amr2_solve",
+    "suhmo_amr2_vcycle", "suhmo_amr2_solve", "suhmo_level_moulin_source",
 ]
 
 
@@ -126,6 +127,7 @@ def lib():
     L.suhmo_level_detach_rccl.argtypes = [vp]
     L.suhmo_level_rccl_exchanges.argtypes = [vp]
     L.suhmo_level_rccl_exchanges.restype = C.c_long
+    L.suhmo_level_moulin_source.argtypes = [vp, ci, dp, dp, dp, C.c_double, dp, vp]
     L.suhmo_amr2_cf_interp.argtypes = [vp, vp, ci, ci, vp]
     L.suhmo_amr2_average.argtypes = [vp, vp, ci, ci, vp]
     L.suhmo_amr2_fine_update_operator.argtypes = [vp, vp, vp]

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void k_melt(DV v, FP fp, suhmo_phys_t ph, suhm
         double rho_coef = (1.0 / mp.rho_w - 1.0 / mp.rho_i);
         double r = m * rho_coef;
         if (b < mp.br) r -= ub_norm * (mp.br - b) / mp.lr;
-        r += (im > 0.0) ? mp.distributed_input : 0.0;          // distributed input where there is ice, :2871-2875
+        if (mp.use_moulin_source) r += fp.f[SUHMO_F_MSRC][idx] * mp.ramp + mp.distributed_input;   // :3060-3066
+        else r += (im > 0.0) ? mp.distributed_input : 0.0;     // distributed input where there is ice, :2871-2875
         if (im < 0.0) r = 0.0;
         fp.f[SUHMO_F_RHS][idx] = r;
     } else {                                                   // CalcRHS_gapHeightFAS :2113-2168 + forward Euler :3406
@@ -183,6 +184,7 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
     if (D.v.ext[0] || D.v.ext[1] || L->desc.nx_global > 0) { suhmo_set_error("timestep on a rank strip / AMR patch is not built yet"); return -5; }
     HIPCHK(hipSetDevice(L->device));
     hipStream_t st = (hipStream_t)s;
+    if (mp->use_moulin_source && !L->d[0].fp.f[SUHMO_F_MSRC]) { suhmo_set_error("use_moulin_source without suhmo_level_moulin_source"); return -1; }
     static const int need[] = {SUHMO_F_MR, SUHMO_F_PW, SUHMO_F_QWX, SUHMO_F_QWY, SUHMO_F_HLAG, SUHMO_F_CD,
                                SUHMO_F_GRADX, SUHMO_F_GRADY, SUHMO_F_RE};
     for (int f : need) if (!suhmo_field(L, 0, f)) { suhmo_set_error("field allocation failed"); return -2; }
@@ -222,5 +224,113 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
     if ((rc = suhmo_copy_ghosts(L, 0, SUHMO_F_B, st))) return rc;  // :3419-3420
     if (picard_iters) *picard_iters = ite_idx;
     if (vcycles) *vcycles = nv;
+    return 0;
+}
+
+
+// ------------------------------------------------------------------ moulin source term
+// Calc_moulin_integral / Calc_moulin_source_term_distributed (src/AmrHydro.cpp:1866-2066).  The n x N array of the
+// reference (one component per moulin) is never stored: pass 1 integrates every Gaussian (per-tile partial sums in a
+// fixed order, then one block per moulin), pass 2 re-evaluates and normalises.  A Gaussian whose argument exceeds
+// 760 underflows to exactly 0 in the reference too, so tiles / cells that far away are skipped without changing a bit.
+namespace {
+constexpr double GL_V[3] = {0.5555555555, 0.8888888888, 0.5555555555};
+__device__ __forceinline__ double moulin_cell(double xc, double yc, double dx, double dy, double mx, double my, double sg, bool &zero)
+{
+    const double l[3] = {-0.77459666924 / 2.0, 0.0, 0.77459666924 / 2.0};
+    const double v[3] = {0.5555555555, 0.8888888888, 0.5555555555};
+    const double k = -1.0 / (2.0 * sg * sg), prefac = 1.0 / (sg * sqrt(2.0 * 3.14));
+    double ex[3], ey[3];
+    for (int q = 0; q < 3; q++) { ex[q] = (xc + l[q]) * dx - mx; ey[q] = (yc + l[q]) * dy - my; }
+    double ax = fmin(fabs(ex[0]), fabs(ex[2])), ay = fmin(fabs(ey[0]), fabs(ey[2]));
+    if (ex[0] * ex[2] < 0.0) ax = 0.0;
+    if (ey[0] * ey[2] < 0.0) ay = 0.0;
+    zero = -k * (ax * ax + ay * ay) > 760.0;
+    if (zero) return 0.0;
+    double MS[9];
+    for (int b = 0; b < 3; b++)
+        for (int a = 0; a < 3; a++) { double rad = ex[a] * ex[a] + ey[b] * ey[b]; MS[3 * b + a] = prefac * exp(k * rad); }
+    return v[0] * v[0] * MS[0] + v[1] * v[0] * MS[1] + v[2] * v[0] * MS[2]
+         + v[0] * v[1] * MS[3] + v[1] * v[1] * MS[4] + v[2] * v[1] * MS[5]
+         + v[0] * v[2] * MS[6] + v[1] * v[2] * MS[7] + v[2] * v[2] * MS[8];
+}
+__global__ __launch_bounds__(256) void k_moulin_partial(DV v, int n, const double *__restrict__ mo, double *__restrict__ partial)
+{
+    __shared__ double sm[256];
+    const int tid = threadIdx.y * 16 + threadIdx.x;
+    const int i = blockIdx.x * 16 + threadIdx.x, j = blockIdx.y * 16 + threadIdx.y;
+    const bool in = i < v.nx && j < v.ny;
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    const double tx0 = (blockIdx.x * 16) * v.dx, tx1 = (blockIdx.x * 16 + 16) * v.dx, ty0 = (blockIdx.y * 16) * v.dy, ty1 = (blockIdx.y * 16 + 16) * v.dy;
+    for (int m = 0; m < n; m++) {
+        const double mx = mo[3 * m], my = mo[3 * m + 1], sg = mo[3 * m + 2];
+        double ddx = mx < tx0 ? tx0 - mx : (mx > tx1 ? mx - tx1 : 0.0), ddy = my < ty0 ? ty0 - my : (my > ty1 ? my - ty1 : 0.0);
+        if ((ddx * ddx + ddy * ddy) / (2.0 * sg * sg) > 760.0) { if (tid == 0) partial[(size_t)blk * n + m] = 0.0; continue; }   // uniform
+        bool z;
+        double val = in ? moulin_cell(i + 0.5 + v.i0, j + 0.5 + v.j0, v.dx, v.dy, mx, my, sg, z) * v.dx * v.dy : 0.0;
+        sm[tid] = val;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = sm[tid] + sm[tid + s]; __syncthreads(); }
+        if (tid == 0) partial[(size_t)blk * n + m] = sm[0];
+        __syncthreads();
+    }
+}
+__global__ void k_moulin_final(const double *__restrict__ partial, int nblk, int n, double *__restrict__ integ)
+{
+    __shared__ double sm[256];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    double acc = 0.0;
+    for (int b = tid; b < nblk; b += 256) acc = acc + partial[(size_t)b * n + m];
+    sm[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = sm[tid] + sm[tid + s]; __syncthreads(); }
+    if (tid == 0) integ[m] = sm[0];
+}
+__global__ __launch_bounds__(256) void k_moulin_src(DV v, int n, const double *__restrict__ mo, const double *__restrict__ flux,
+                                                    const double *__restrict__ integ, double tf, double *__restrict__ out)
+{
+    const int i = blockIdx.x * 16 + threadIdx.x, j = blockIdx.y * 16 + threadIdx.y;
+    if (i >= v.nx || j >= v.ny) return;
+    double sum = 0.0;
+    for (int m = 0; m < n; m++) {
+        bool z;
+        double val = moulin_cell(i + 0.5 + v.i0, j + 0.5 + v.j0, v.dx, v.dy, mo[3 * m], mo[3 * m + 1], mo[3 * m + 2], z);
+        if (!z) sum += val * tf / integ[m] * flux[m];
+    }
+    out[cidx(v, i, j)] = sum;
+}
+}  // namespace
+
+extern "C" int suhmo_level_moulin_source(suhmo_level_t *L, int n, const double *positions, const double *sigma,
+                                         const double *flux, double time_factor, double *integrals, suhmo_stream_t s)
+{
+    ARG(L && n >= 1 && positions && sigma && flux);
+    HIPCHK(hipSetDevice(L->device));
+    hipStream_t st = (hipStream_t)s;
+    Depth &D = L->d[0];
+    if (D.v.ext[0] || D.v.ext[1] || L->desc.nx_global > 0) { suhmo_set_error("moulin source on a rank strip / AMR patch is not built yet (the integral spans all levels)"); return -5; }
+    double *out = suhmo_field(L, 0, SUHMO_F_MSRC);
+    if (!out) { suhmo_set_error("field allocation failed"); return -2; }
+    std::vector<double> h(4 * (size_t)n);
+    for (int m = 0; m < n; m++) {
+        ARG(sigma[m] > 0.0);
+        h[3 * m] = positions[2 * m]; h[3 * m + 1] = positions[2 * m + 1]; h[3 * m + 2] = sigma[m]; h[3 * (size_t)n + m] = flux[m];
+    }
+    dim3 blk(16, 16), grd((D.v.nx + 15) / 16, (D.v.ny + 15) / 16);
+    const size_t nblk = (size_t)grd.x * grd.y;
+    double *dev = nullptr;
+    HIPCHK(hipMalloc(&dev, (5 * (size_t)n + nblk * n) * sizeof(double)));
+    double *mo = dev, *fl = dev + 3 * (size_t)n, *integ = dev + 4 * (size_t)n, *partial = dev + 5 * (size_t)n;
+    hipError_t e = hipMemcpyAsync(dev, h.data(), 4 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_moulin_partial, grd, blk, 0, st, D.v, n, mo, partial);
+        hipLaunchKernelGGL(k_moulin_final, dim3(n), dim3(256), 0, st, partial, (int)nblk, n, integ);
+        hipLaunchKernelGGL(k_moulin_src, grd, blk, 0, st, D.v, n, mo, fl, integ, time_factor, out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && integrals) e = hipMemcpyAsync(integrals, integ, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dev);
+    if (e != hipSuccess) { suhmo_set_error("moulin source: %s", hipGetErrorString(e)); return -2; }
     return 0;
 }

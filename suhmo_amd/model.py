@@ -14,12 +14,13 @@ def model_params(m):
     ub = m.get("ub", (0.0, 0.0))
     return capi.ModelParams(m["rho_i"], m["rho_w"], m["gravity"], m["G"], m["L"], m["ct"], m["cw"], ub[0], ub[1],
                             m["br"], m["lr"], m.get("diffFactor", 0.0), m["distributed_input"], m["eps_picard"],
-                            int(m.get("basal_friction", 1)), int(m.get("use_mask_rhs_b", 0)))
+                            int(m.get("basal_friction", 1)), int(m.get("use_mask_rhs_b", 0)),
+                            int(m.get("use_moulin_source", 0)), float(m.get("ramp", 1.0)))
 
 
 class HipModel:
     FIELDS = dict(head=lv.F_PHI, B=lv.F_B, Pi=lv.F_PI, zb=lv.F_ZB, mask=lv.F_MASK, mR=lv.F_MR, Pw=lv.F_PW,
-                  qwx=lv.F_QWX, qwy=lv.F_QWY, cd=lv.F_CD, rhs_h=lv.F_RHS, Re=lv.F_RE)
+                  qwx=lv.F_QWX, qwy=lv.F_QWY, cd=lv.F_CD, rhs_h=lv.F_RHS, Re=lv.F_RE, msrc=lv.F_MSRC)
 
     def __init__(self, nx, ny, dx, dy, bc, phys, model, max_box=64, device=0):
         self.level = lv.HipLevel(nx, ny, dx, dy, bc, phys, alpha=0.0, beta=-1.0, max_box=max_box, device=device)
@@ -35,6 +36,16 @@ class HipModel:
         L.set(lv.F_ACOEF, np.zeros((self.ny, self.nx)))
         for k, fid in (("B", lv.F_B), ("Pi", lv.F_PI), ("zb", lv.F_ZB), ("mask", lv.F_MASK)):
             L.set(fid, f[k], ghosted=True)
+
+    def moulin_source(self, positions, sigma, flux, time_factor=1.0):
+        """Calc_moulin_integral + Calc_moulin_source_term_distributed (src/AmrHydro.cpp:1866-2066) -> F_MSRC; returns the integrals"""
+        pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1)
+        sg, fl = np.ascontiguousarray(sigma, dtype=np.float64), np.ascontiguousarray(flux, dtype=np.float64)
+        integ = np.zeros(sg.size)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        check(capi.lib().suhmo_level_moulin_source(self.level.h, sg.size, dp(pos), dp(sg), dp(fl), float(time_factor), dp(integ),
+                                                   self.level.stream))
+        return integ
 
     def timestep(self, dt):
         self.cur_step += 1                                         # src/AmrHydro.cpp:2259
