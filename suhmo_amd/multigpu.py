@@ -211,7 +211,21 @@ def attach(level, dist, rank, world, periodic_y=False):
     other backends (gloo in CPU-side tests): torch.distributed P2P.  Returns the exchanger."""
     import torch
     if dist.get_backend() == "nccl" and os.environ.get("SUHMO_TRANSPORT", "rccl") != "torch":
-        return attach_rccl(level, rank, world, periodic_y, dist)
+        # every rank must end up on the same transport: agree that librccl could be loaded everywhere BEFORE the
+        # collective part (id broadcast, ncclCommInitRank) starts
+        ok, err = 1, None
+        try:
+            path = os.environ.get("SUHMO_LIBRCCL")
+            check(capi.lib().suhmo_rccl_load(path.encode() if path else None))
+        except Exception as e:
+            ok, err = 0, e
+        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return attach_rccl(level, rank, world, periodic_y, dist)
+        import sys
+        print("suhmo_amd.multigpu: native RCCL transport unavailable (%s); falling back to torch.distributed P2P"
+              % (err if err is not None else "another rank failed"), file=sys.stderr, flush=True)
     tr = TorchDistTransport(dist, torch.device("cuda", torch.cuda.current_device()))
     ex = StripExchanger(level, tr, rank, world, periodic_y)
     level._exchanger = ex
