@@ -358,7 +358,8 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
             int want = 2 * (sweeps - it - K) + tail;
             int E = ext ? (F - 2 * K < want ? F - 2 * K : want) : 0;
             int rc;
-            if (L->fused_nt == 64) rc = (K == 2) ? launch_fused<2, 64>(L, depth, E, st) : launch_fused<1, 64>(L, depth, E, st);
+            const int nt = L->fused_nt ? L->fused_nt : ((long)D.v.nx * D.v.ny >= 8000000L ? 256 : 64);   // 0 = by size
+            if (nt == 64) rc = (K == 2) ? launch_fused<2, 64>(L, depth, E, st) : launch_fused<1, 64>(L, depth, E, st);
             else rc = (K == 2) ? launch_fused<2, 256>(L, depth, E, st) : launch_fused<1, 256>(L, depth, E, st);
             if (rc) return rc;
             if (ext) { F = E; D.phi_fresh = F; }

@@ -89,7 +89,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     if (const char *e = getenv("SUHMO_FUSED_HC")) L->fused_hc = atoi(e);
     L->bcoef_fused = 1;
     if (const char *e = getenv("SUHMO_BCOEF_FUSED")) L->bcoef_fused = atoi(e);
-    L->fused_nt = 256;
+    L->fused_nt = 64;                        // one wave per workgroup: 316 vs 308 V-cycles/s at 4096^2 (profiles/r01_i_nt_ab.txt)
     if (const char *e = getenv("SUHMO_FUSED_NT")) L->fused_nt = atoi(e);
     L->fused_min_cells = 2000000;
     if (const char *e = getenv("SUHMO_FUSED_MIN_CELLS")) L->fused_min_cells = atol(e);
