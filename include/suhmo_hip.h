@@ -255,6 +255,8 @@ long suhmo_level_rccl_exchanges(const suhmo_level_t *L);
  *                           :1143-1206) and the solveNoInit loop on the composite norm */
 int suhmo_amr2_cf_interp(suhmo_level_t *coarse, suhmo_level_t *fine, int field_f, int field_c, suhmo_stream_t s);
 int suhmo_amr2_average(suhmo_level_t *coarse, suhmo_level_t *fine, int field_f, int field_c, suhmo_stream_t s);
+int suhmo_amr2_prolong2(suhmo_level_t *coarse, suhmo_level_t *fine, int field_c, suhmo_stream_t s);      /* AMRProlongS_2 :1143-1206 */
+int suhmo_amr2_set_covered(suhmo_level_t *coarse, suhmo_level_t *fine, int field_c, double value, suhmo_stream_t s); /* AMRNorm :1241-1258 */
 int suhmo_amr2_fine_update_operator(suhmo_level_t *coarse, suhmo_level_t *fine, suhmo_stream_t s);
 int suhmo_amr2_residual(suhmo_level_t *coarse, suhmo_level_t *fine, double *norm, suhmo_stream_t s);
 int suhmo_amr2_vcycle(suhmo_level_t *coarse, suhmo_level_t *fine, const suhmo_solver_params_t *sp, suhmo_stream_t s);

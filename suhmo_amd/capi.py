@@ -69,7 +69,7 @@ SYMBOLS = [
     "suhmo_rccl_load", "suhmo_rccl_unique_id", "suhmo_level_attach_rccl", "suhmo_level_detach_rccl",
     "suhmo_level_rccl_exchanges",
     "suhmo_amr2_cf_interp", "suhmo_amr2_average", "suhmo_amr2_fine_update_operator", "suhmo_amr2_residual",
-    "suhmo_amr2_vcycle", "suhmo_amr2_solve", "suhmo_level_moulin_source",
+    "suhmo_amr2_vcycle", "suhmo_amr2_solve", "suhmo_level_moulin_source", "suhmo_amr2_prolong2", "suhmo_amr2_set_covered",
 ]
 
 
@@ -128,6 +128,8 @@ def lib():
     L.suhmo_level_rccl_exchanges.argtypes = [vp]
     L.suhmo_level_rccl_exchanges.restype = C.c_long
     L.suhmo_level_moulin_source.argtypes = [vp, ci, dp, dp, dp, C.c_double, dp, vp]
+    L.suhmo_amr2_prolong2.argtypes = [vp, vp, ci, vp]
+    L.suhmo_amr2_set_covered.argtypes = [vp, vp, ci, C.c_double, vp]
     L.suhmo_amr2_cf_interp.argtypes = [vp, vp, ci, ci, vp]
     L.suhmo_amr2_average.argtypes = [vp, vp, ci, ci, vp]
     L.suhmo_amr2_fine_update_operator.argtypes = [vp, vp, vp]

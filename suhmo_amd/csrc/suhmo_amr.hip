@@ -218,6 +218,37 @@ extern "C" int suhmo_amr2_residual(suhmo_level_t *C, suhmo_level_t *F, double *n
     return 0;
 }
 
+// AMRProlongS_2 (:1143-1206): fine PHI += PROLONG_2_NL(coarse field_c), the coarse field first gets its physical-BC
+// ghost ring (inhomogeneous in FAS mode :1163-1165)
+extern "C" int suhmo_amr2_prolong2(suhmo_level_t *C, suhmo_level_t *F, int field_c, suhmo_stream_t s)
+{
+    int rc = check_pair(C, F); if (rc) return rc;
+    ARG(field_c >= 0 && field_c < SUHMO_F_COUNT && field_c != SUHMO_F_BX && field_c != SUHMO_F_BY);
+    HIPCHK(hipSetDevice(F->device));
+    Depth &DC = C->d[0], &DF = F->d[0];
+    double *corr = suhmo_field(C, 0, field_c);
+    if (!corr) { suhmo_set_error("field allocation failed"); return -2; }
+    if ((rc = suhmo_level_fill_ghosts(C, 0, field_c, 0, s))) return rc;
+    DF.phi_fresh = 0;
+    hipLaunchKernelGGL(k_amr_prolong2, dim3((DF.v.nx + 63) / 64, (DF.v.ny + 3) / 4), dim3(64, 4), 0, (hipStream_t)s, DF.v, DF.fp.f[SUHMO_F_PHI], DC.v, corr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// coarse cells under the patch <- value (AMRNorm / zeroCovered :1222-1264)
+extern "C" int suhmo_amr2_set_covered(suhmo_level_t *C, suhmo_level_t *F, int field_c, double value, suhmo_stream_t s)
+{
+    int rc = check_pair(C, F); if (rc) return rc;
+    ARG(field_c >= 0 && field_c < SUHMO_F_COUNT);
+    HIPCHK(hipSetDevice(F->device));
+    const DV &vf = F->d[0].v, &vc = C->d[0].v;
+    double *p = suhmo_field(C, 0, field_c);
+    if (!p) { suhmo_set_error("field allocation failed"); return -2; }
+    if (field_c == SUHMO_F_PHI) C->d[0].phi_fresh = 0;
+    hipLaunchKernelGGL(k_amr_set_covered, dim3((vf.nx / 2 + 63) / 64, (vf.ny / 2 + 3) / 4), dim3(64, 4), 0, (hipStream_t)s, vf, vc, p, value);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // one AMR FAS V-cycle (VCycleAMR; same order as oracle/amr2.c:or_amr2_vcycle)
 extern "C" int suhmo_amr2_vcycle(suhmo_level_t *C, suhmo_level_t *F, const suhmo_solver_params_t *sp, suhmo_stream_t s)
 {
@@ -225,7 +256,7 @@ extern "C" int suhmo_amr2_vcycle(suhmo_level_t *C, suhmo_level_t *F, const suhmo
     ARG(sp);
     HIPCHK(hipSetDevice(F->device));
     hipStream_t st = (hipStream_t)s;
-    Depth &DC = C->d[0], &DF = F->d[0];
+    Depth &DC = C->d[0];
     const size_t cbytes = DC.elems * sizeof(double);
     double *rhs0 = suhmo_field(C, 0, SUHMO_F_RHS0), *phiold = suhmo_field(C, 0, SUHMO_F_PHIOLD), *corr = suhmo_field(C, 0, SUHMO_F_CORR);
     if (!rhs0 || !phiold || !corr) { suhmo_set_error("field allocation failed"); return -2; }
@@ -246,9 +277,7 @@ extern "C" int suhmo_amr2_vcycle(suhmo_level_t *C, suhmo_level_t *F, const suhmo
     HIPCHK(hipMemcpyAsync(DC.fp.f[SUHMO_F_RHS], rhs0, cbytes, hipMemcpyDeviceToDevice, st));
     // AMRProlongS_2: phi1 += PROLONG_2_NL(phi0 - phi0_old), coarse correction with inhomogeneous-BC ghosts
     if ((rc = suhmo_level_axby(C, 0, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) return rc;
-    if ((rc = suhmo_level_fill_ghosts(C, 0, SUHMO_F_CORR, 0, s))) return rc;
-    hipLaunchKernelGGL(k_amr_prolong2, dim3((DF.v.nx + 63) / 64, (DF.v.ny + 3) / 4), dim3(64, 4), 0, st, DF.v, DF.fp.f[SUHMO_F_PHI], DC.v, corr);
-    HIPCHK(hipGetLastError());
+    if ((rc = suhmo_amr2_prolong2(C, F, SUHMO_F_CORR, s))) return rc;
     // relaxNF(phi1, phi0, rhs1, post)
     if ((rc = suhmo_amr2_cf_interp(C, F, SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc;
     return suhmo_level_gsrb(F, 0, sp->num_smooth, s);

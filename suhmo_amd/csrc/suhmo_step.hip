@@ -234,7 +234,6 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
 // fixed order, then one block per moulin), pass 2 re-evaluates and normalises.  A Gaussian whose argument exceeds
 // 760 underflows to exactly 0 in the reference too, so tiles / cells that far away are skipped without changing a bit.
 namespace {
-constexpr double GL_V[3] = {0.5555555555, 0.8888888888, 0.5555555555};
 __device__ __forceinline__ double moulin_cell(double xc, double yc, double dx, double dy, double mx, double my, double sg, bool &zero)
 {
     const double l[3] = {-0.77459666924 / 2.0, 0.0, 0.77459666924 / 2.0};

@@ -1,5 +1,6 @@
 // VCAMRNonLinearPoissonOpHIP.cpp -- see the header.  Plain C++ (g++), links libsuhmo_hip.so.
 #include "VCAMRNonLinearPoissonOpHIP.H"
+#include <algorithm>
 #include <cmath>
 #include <string>
 
@@ -22,7 +23,11 @@ HeadSolverParameters::HeadSolverParameters(int a_cur_step, bool a_bcoeff_otf)
 }
 
 VCAMRNonLinearPoissonOpHIPFactory::VCAMRNonLinearPoissonOpHIPFactory() : m_level(nullptr), m_update_operator(true) {}
-VCAMRNonLinearPoissonOpHIPFactory::~VCAMRNonLinearPoissonOpHIPFactory() { if (m_level) suhmo_level_destroy(m_level); }
+VCAMRNonLinearPoissonOpHIPFactory::~VCAMRNonLinearPoissonOpHIPFactory()
+{
+    if (m_fine) suhmo_level_destroy(m_fine);
+    if (m_level) suhmo_level_destroy(m_level);
+}
 
 void VCAMRNonLinearPoissonOpHIPFactory::define(const ProblemDomain &a_dom, const DisjointBoxLayout &a_grids,
                                                const RealVect &a_dx, const suhmo_bc_t &a_bc, const Real &a_alpha,
@@ -41,6 +46,7 @@ void VCAMRNonLinearPoissonOpHIPFactory::define(const ProblemDomain &a_dom, const
     d.nbox = a_grids.size(); d.boxes = boxes.data(); d.max_box = 0;
     d.alpha = a_alpha; d.beta = a_beta; d.bc = a_bc; d.phys = a_phys; d.device = a_device; d.halo_rows = 1;
     chk(suhmo_level_create(&m_level, &d), "VCAMRNonLinearPoissonOpHIPFactory::define");
+    m_desc = d; m_desc.boxes = nullptr; m_desc.nbox = 0;
     m_update_operator = a_update_operator;
     int nd = suhmo_level_num_depths(m_level);
     for (int dep = 0; dep < nd; dep++) m_grids.push_back(dep == 0 ? a_grids : a_grids.coarsened(1 << dep));
@@ -57,6 +63,51 @@ void VCAMRNonLinearPoissonOpHIPFactory::define(const ProblemDomain &a_dom, const
                                     f.box().hi[0], f.box().hi[1], 0, nullptr), "put bCoef");
         }
     chk(suhmo_level_build_mg_coefficients(m_level, nullptr), "MGnewOp coefficient coarsening");
+}
+
+void VCAMRNonLinearPoissonOpHIPFactory::defineFineLevel(const ProblemDomain &a_fineDomain, const DisjointBoxLayout &a_fineGrids,
+                                                        const LevelData<FArrayBox> &a_aCoef, const LevelData<FluxBox> &a_bCoef,
+                                                        const LevelData<FArrayBox> &a_B, const LevelData<FArrayBox> &a_Pi,
+                                                        const LevelData<FArrayBox> &a_zb, const LevelData<FArrayBox> &a_iceMask)
+{
+    if (!m_level) MayDay::Error("defineFineLevel before define");
+    if (m_fine) { suhmo_level_destroy(m_fine); m_fine = nullptr; }
+    Box bb = a_fineGrids[0];
+    for (int k = 1; k < a_fineGrids.size(); k++)
+        for (int d = 0; d < 2; d++) { bb.lo[d] = std::min(bb.lo[d], a_fineGrids[k].lo[d]); bb.hi[d] = std::max(bb.hi[d], a_fineGrids[k].hi[d]); }
+    suhmo_level_desc_t d = m_desc;
+    d.nx = bb.size(0); d.ny = bb.size(1); d.i0 = bb.lo[0]; d.j0 = bb.lo[1];
+    d.nx_global = a_fineDomain.dom.size(0); d.ny_global = a_fineDomain.dom.size(1);
+    d.dx = m_desc.dx / 2.0; d.dy = m_desc.dy / 2.0;                                  // refRatio 2
+    std::vector<int> boxes;
+    for (int k = 0; k < a_fineGrids.size(); k++) { const Box &b = a_fineGrids[k]; boxes.insert(boxes.end(), {b.lo[0], b.lo[1], b.hi[0], b.hi[1]}); }
+    d.nbox = a_fineGrids.size(); d.boxes = boxes.data(); d.max_box = 0;
+    chk(suhmo_level_create(&m_fine, &d), "VCAMRNonLinearPoissonOpHIPFactory::defineFineLevel");
+    m_fineDomain = a_fineDomain;
+    m_fineOp.reset(new VCAMRNonLinearPoissonOpHIP(this, 0, 1));
+    VCAMRNonLinearPoissonOpHIP &op = *m_fineOp;
+    op.put(SUHMO_F_ACOEF, a_aCoef, 0);
+    op.put(SUHMO_F_B, a_B, 0, true); op.put(SUHMO_F_PI, a_Pi, 0, true); op.put(SUHMO_F_ZB, a_zb, 0, true); op.put(SUHMO_F_MASK, a_iceMask, 0, true);
+    for (int k = 0; k < a_bCoef.size(); k++)
+        for (int dir = 0; dir < 2; dir++) {
+            const FArrayBox &f = a_bCoef[k][dir];
+            chk(suhmo_level_put_box(m_fine, 0, dir == 0 ? SUHMO_F_BX : SUHMO_F_BY, k, f.dataPtr(), f.box().lo[0], f.box().lo[1],
+                                    f.box().hi[0], f.box().hi[1], 0, nullptr), "put fine bCoef");
+        }
+}
+
+int VCAMRNonLinearPoissonOpHIPFactory::solveAMR(std::vector<LevelData<FArrayBox> *> &a_phi, const std::vector<LevelData<FArrayBox> *> &a_rhs,
+                                                const HeadSolverParameters &a_sp, std::vector<Real> *a_hist)
+{
+    if (!m_fine || a_phi.size() != 2 || a_rhs.size() != 2) MayDay::Error("solveAMR: two levels");
+    m_ops[0]->put(SUHMO_F_PHI, *a_phi[0], 0); m_ops[0]->put(SUHMO_F_RHS, *a_rhs[0], 0);
+    m_fineOp->put(SUHMO_F_PHI, *a_phi[1], 0); m_fineOp->put(SUHMO_F_RHS, *a_rhs[1], 0);
+    std::vector<Real> hist(a_sp.max_iter + 2, 0.0);
+    int iters = 0;
+    chk(suhmo_amr2_solve(m_level, m_fine, &a_sp, &iters, hist.data(), nullptr), "AMRFASMultiGrid::solve (2 levels)");
+    m_ops[0]->get(SUHMO_F_PHI, *a_phi[0], 0); m_fineOp->get(SUHMO_F_PHI, *a_phi[1], 0);
+    if (a_hist) a_hist->assign(hist.begin(), hist.begin() + iters + 1);
+    return iters;
 }
 
 int VCAMRNonLinearPoissonOpHIPFactory::numDepths() const { return m_level ? suhmo_level_num_depths(m_level) : 0; }
@@ -82,11 +133,13 @@ int VCAMRNonLinearPoissonOpHIPFactory::solve(LevelData<FArrayBox> &a_phi, const 
 }
 
 // ---------------------------------------------------------------- operator
+suhmo_level_t *VCAMRNonLinearPoissonOpHIP::h() const { return m_amrLevel == 1 ? m_factory->m_fine : m_factory->m_level; }
+
 void VCAMRNonLinearPoissonOpHIP::put(int field, const LevelData<FArrayBox> &ld, int depth, bool domainGhosts)
 {
     for (int k = 0; k < ld.size(); k++) {
         const FArrayBox &f = ld[k];
-        chk(suhmo_level_put_box(m_factory->m_level, depth, field, k, f.dataPtr(), f.box().lo[0], f.box().lo[1],
+        chk(suhmo_level_put_box(h(), depth, field, k, f.dataPtr(), f.box().lo[0], f.box().lo[1],
                                 f.box().hi[0], f.box().hi[1], domainGhosts ? 1 : 0, nullptr), "put_box");
     }
 }
@@ -94,7 +147,7 @@ void VCAMRNonLinearPoissonOpHIP::get(int field, LevelData<FArrayBox> &ld, int de
 {
     for (int k = 0; k < ld.size(); k++) {
         FArrayBox &f = ld[k];
-        chk(suhmo_level_get_box(m_factory->m_level, depth, field, k, f.dataPtr(), f.box().lo[0], f.box().lo[1],
+        chk(suhmo_level_get_box(h(), depth, field, k, f.dataPtr(), f.box().lo[0], f.box().lo[1],
                                 f.box().hi[0], f.box().hi[1], nullptr), "get_box");
     }
 }
@@ -102,22 +155,22 @@ void VCAMRNonLinearPoissonOpHIP::get(int field, LevelData<FArrayBox> &ld, int de
 void VCAMRNonLinearPoissonOpHIP::levelGSRB(LevelData<FArrayBox> &a_phi, const LevelData<FArrayBox> &a_rhs, int, int, int a_depth)
 {
     put(SUHMO_F_PHI, a_phi, a_depth); put(SUHMO_F_RHS, a_rhs, a_depth);
-    chk(suhmo_level_gsrb(m_factory->m_level, a_depth, 1, nullptr), "levelGSRB");
+    chk(suhmo_level_gsrb(h(), a_depth, 1, nullptr), "levelGSRB");
     get(SUHMO_F_PHI, a_phi, a_depth);
 }
 void VCAMRNonLinearPoissonOpHIP::relax(LevelData<FArrayBox> &a_e, const LevelData<FArrayBox> &a_residual, int a_iterations, int, int a_depth)
 {
     put(SUHMO_F_PHI, a_e, a_depth); put(SUHMO_F_RHS, a_residual, a_depth);
-    chk(suhmo_level_gsrb(m_factory->m_level, a_depth, a_iterations, nullptr), "relax");   // s_relaxMode 1 only
+    chk(suhmo_level_gsrb(h(), a_depth, a_iterations, nullptr), "relax");   // s_relaxMode 1 only
     get(SUHMO_F_PHI, a_e, a_depth);
 }
 void VCAMRNonLinearPoissonOpHIP::applyOpI(LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_phi, bool a_homogeneous)
 {
     put(SUHMO_F_PHI, a_phi, m_depth);
-    chk(suhmo_level_apply_op(m_factory->m_level, m_depth, a_homogeneous ? 1 : 0, nullptr), "applyOpI");
+    chk(suhmo_level_apply_op(h(), m_depth, a_homogeneous ? 1 : 0, nullptr), "applyOpI");
     get(SUHMO_F_LPHI, a_lhs, m_depth);
     // the reference leaves phi's ghosts filled (it const-casts a_phi, :278); mirror that
-    chk(suhmo_level_fill_ghosts(m_factory->m_level, m_depth, SUHMO_F_PHI, a_homogeneous ? 1 : 0, nullptr), "BC");
+    chk(suhmo_level_fill_ghosts(h(), m_depth, SUHMO_F_PHI, a_homogeneous ? 1 : 0, nullptr), "BC");
     get(SUHMO_F_PHI, const_cast<LevelData<FArrayBox> &>(a_phi), m_depth);
 }
 void VCAMRNonLinearPoissonOpHIP::applyOpMg(LevelData<FArrayBox> &a_lhs, LevelData<FArrayBox> &a_phi, LevelData<FArrayBox> *a_phiCoarse, bool a_homogeneous)
@@ -130,7 +183,7 @@ void VCAMRNonLinearPoissonOpHIP::residualI(LevelData<FArrayBox> &a_lhs, const Le
 {
     if (a_homogeneous) MayDay::Abort("VCAMRNonLinearPoissonOp::residualI homogeneous");            // :107-109
     put(SUHMO_F_PHI, a_phi, m_depth); put(SUHMO_F_RHS, a_rhs, m_depth);
-    chk(suhmo_level_residual(m_factory->m_level, m_depth, nullptr), "residualI");
+    chk(suhmo_level_residual(h(), m_depth, nullptr), "residualI");
     get(SUHMO_F_RES, a_lhs, m_depth);
 }
 void VCAMRNonLinearPoissonOpHIP::restrictResidual(LevelData<FArrayBox> &a_resCoarse, LevelData<FArrayBox> &a_phiFine,
@@ -139,14 +192,14 @@ void VCAMRNonLinearPoissonOpHIP::restrictResidual(LevelData<FArrayBox> &a_resCoa
     if (homogeneous) MayDay::Abort("VCAMRNonLinearPoissonOp::restrictResidual homogeneous");       // :391-393
     if (a_phiCoarse != nullptr) MayDay::Abort("VCAMRNonLinearPoissonOpHIP::restrictResidual: coarse-fine interpolation not built yet");
     put(SUHMO_F_PHI, a_phiFine, m_depth); put(SUHMO_F_RHS, a_rhsFine, m_depth);
-    chk(suhmo_level_restrict_residual(m_factory->m_level, m_depth, nullptr), "restrictResidual");
+    chk(suhmo_level_restrict_residual(h(), m_depth, nullptr), "restrictResidual");
     get(SUHMO_F_RES, a_resCoarse, m_depth + 1);
 }
 void VCAMRNonLinearPoissonOpHIP::restrictR(LevelData<FArrayBox> &a_phiCoarse, const LevelData<FArrayBox> &a_phiFine)
 {
     put(SUHMO_F_PHI, a_phiFine, m_depth);
     for (int k = 0; k < a_phiCoarse.size(); k++) a_phiCoarse[k].setVal(0.0);                      // :365
-    chk(suhmo_level_restrict_r(m_factory->m_level, m_depth, nullptr), "restrictR");
+    chk(suhmo_level_restrict_r(h(), m_depth, nullptr), "restrictR");
     // valid cells only (the coarse ghosts stay zero as in the reference)
     LevelData<FArrayBox> tmp(a_phiCoarse.disjointBoxLayout(), 1, 0);
     get(SUHMO_F_PHI, tmp, m_depth + 1);
@@ -158,7 +211,7 @@ void VCAMRNonLinearPoissonOpHIP::restrictR(LevelData<FArrayBox> &a_phiCoarse, co
 void VCAMRNonLinearPoissonOpHIP::prolongIncrement(LevelData<FArrayBox> &a_phiThisLevel, const LevelData<FArrayBox> &a_correctCoarse)
 {
     put(SUHMO_F_PHI, a_phiThisLevel, m_depth); put(SUHMO_F_CORR, a_correctCoarse, m_depth + 1);
-    chk(suhmo_level_prolong_increment(m_factory->m_level, m_depth, nullptr), "prolongIncrement");
+    chk(suhmo_level_prolong_increment(h(), m_depth, nullptr), "prolongIncrement");
     LevelData<FArrayBox> tmp(a_phiThisLevel.disjointBoxLayout(), 1, 0);
     get(SUHMO_F_PHI, tmp, m_depth);
     for (int k = 0; k < tmp.size(); k++) {
@@ -169,20 +222,25 @@ void VCAMRNonLinearPoissonOpHIP::prolongIncrement(LevelData<FArrayBox> &a_phiThi
 void VCAMRNonLinearPoissonOpHIP::UpdateOperator(const LevelData<FArrayBox> &a_phi, const LevelData<FArrayBox> *a_phicoarsePtr, int a_depth, int, bool a_homogeneous)
 {
     if (a_homogeneous) MayDay::Abort("VCAMRNonLinearPoissonOp::UpdateOperator homogeneous");       // :42-44
-    if (a_phicoarsePtr != nullptr) MayDay::Abort("VCAMRNonLinearPoissonOpHIP::UpdateOperator: coarser AMR level not built yet");
     put(SUHMO_F_PHI, a_phi, a_depth);
-    chk(suhmo_level_update_operator(m_factory->m_level, a_depth, nullptr), "UpdateOperator");
+    if (a_phicoarsePtr != nullptr) {                                                               // WFlx_level with a coarser level, AmrHydro.cpp:1455-1488
+        if (m_amrLevel != 1) MayDay::Error("UpdateOperator with a coarser level: fine operator only");
+        m_factory->m_ops[0]->put(SUHMO_F_PHI, *a_phicoarsePtr, 0);
+        chk(suhmo_amr2_fine_update_operator(m_factory->m_level, m_factory->m_fine, nullptr), "UpdateOperator (fine)");
+        return;
+    }
+    chk(suhmo_level_update_operator(h(), a_depth, nullptr), "UpdateOperator");
 }
 void VCAMRNonLinearPoissonOpHIP::AverageOperator(const VCAMRNonLinearPoissonOpHIP &, int a_depth)
 {
-    chk(suhmo_level_average_operator(m_factory->m_level, a_depth, nullptr), "AverageOperator");
+    chk(suhmo_level_average_operator(h(), a_depth, nullptr), "AverageOperator");
 }
 void VCAMRNonLinearPoissonOpHIP::getBCoef(LevelData<FluxBox> &a_bCoef)
 {
     for (int k = 0; k < a_bCoef.size(); k++)
         for (int dir = 0; dir < 2; dir++) {
             FArrayBox &f = a_bCoef[k][dir];
-            chk(suhmo_level_get_box(m_factory->m_level, m_depth, dir == 0 ? SUHMO_F_BX : SUHMO_F_BY, k, f.dataPtr(), f.box().lo[0],
+            chk(suhmo_level_get_box(h(), m_depth, dir == 0 ? SUHMO_F_BX : SUHMO_F_BY, k, f.dataPtr(), f.box().lo[0],
                                     f.box().lo[1], f.box().hi[0], f.box().hi[1], nullptr), "get bCoef");
         }
 }
@@ -190,9 +248,78 @@ Real VCAMRNonLinearPoissonOpHIP::norm(const LevelData<FArrayBox> &a_x, int a_ord
 {
     put(SUHMO_F_RES, a_x, m_depth);
     double r = 0.0;
-    chk(suhmo_level_norm(m_factory->m_level, m_depth, SUHMO_F_RES, a_ord, &r, nullptr), "norm");
+    chk(suhmo_level_norm(h(), m_depth, SUHMO_F_RES, a_ord, &r, nullptr), "norm");
     return r;
 }
+// ---- AMR level methods
+void VCAMRNonLinearPoissonOpHIP::relaxNF(LevelData<FArrayBox> &a_e, const LevelData<FArrayBox> *a_eCoarse, const LevelData<FArrayBox> &a_residual,
+                                         int a_iterations, int, int a_depth, bool)
+{
+    put(SUHMO_F_PHI, a_e, a_depth); put(SUHMO_F_RHS, a_residual, a_depth);
+    if (a_eCoarse != nullptr) {                                                                   // m_interpWithCoarser.coarseFineInterp :700-702
+        if (m_amrLevel != 1) MayDay::Error("relaxNF with a coarser level: fine operator only");
+        m_factory->m_ops[0]->put(SUHMO_F_PHI, *a_eCoarse, 0);
+        chk(suhmo_amr2_cf_interp(m_factory->m_level, m_factory->m_fine, SUHMO_F_PHI, SUHMO_F_PHI, nullptr), "coarseFineInterp");
+    }
+    chk(suhmo_level_gsrb(h(), a_depth, a_iterations, nullptr), "relaxNF");
+    get(SUHMO_F_PHI, a_e, a_depth);
+}
+void VCAMRNonLinearPoissonOpHIP::AMRResidualNF(LevelData<FArrayBox> &a_residual, const LevelData<FArrayBox> &a_phi, const LevelData<FArrayBox> &a_phiCoarse,
+                                               const LevelData<FArrayBox> &a_rhs, bool a_homogeneousPhysBC)
+{
+    if (a_homogeneousPhysBC) MayDay::Abort("VCAMRNonLinearPoissonOp::residualI homogeneous");
+    if (m_amrLevel != 1) MayDay::Error("AMRResidualNF: fine operator only");
+    put(SUHMO_F_PHI, a_phi, 0); put(SUHMO_F_RHS, a_rhs, 0);
+    m_factory->m_ops[0]->put(SUHMO_F_PHI, a_phiCoarse, 0);
+    chk(suhmo_amr2_cf_interp(m_factory->m_level, m_factory->m_fine, SUHMO_F_PHI, SUHMO_F_PHI, nullptr), "coarseFineInterp");
+    chk(suhmo_level_residual(h(), 0, nullptr), "AMRResidualNF");
+    get(SUHMO_F_RES, a_residual, 0);
+}
+void VCAMRNonLinearPoissonOpHIP::AMRRestrictS(LevelData<FArrayBox> &a_resCoarse, const LevelData<FArrayBox> &a_residual, const LevelData<FArrayBox> &a_correction,
+                                              const LevelData<FArrayBox> &a_coarseCorrection, LevelData<FArrayBox> &a_scratch, bool a_skip_res)
+{
+    if (m_amrLevel != 1) MayDay::Error("AMRRestrictS: fine operator only");
+    // a_resCoarse lives on the coarse LEVEL here (the reference's coarsened-fine layout + copyTo collapse into one step)
+    m_factory->m_ops[0]->put(SUHMO_F_RES, a_resCoarse, 0);
+    if (!a_skip_res) { AMRResidualNF(a_scratch, a_correction, a_coarseCorrection, a_residual, false); }
+    else { put(SUHMO_F_RES, a_residual, 0); assign(a_scratch, a_residual); }                       // "just copy data (phi in this case)"
+    chk(suhmo_amr2_average(m_factory->m_level, m_factory->m_fine, SUHMO_F_RES, SUHMO_F_RES, nullptr), "FORT_AVERAGE");
+    m_factory->m_ops[0]->get(SUHMO_F_RES, a_resCoarse, 0);
+}
+void VCAMRNonLinearPoissonOpHIP::AMRProlongS_2(LevelData<FArrayBox> &a_correction, const LevelData<FArrayBox> &a_coarseCorrection)
+{
+    if (m_amrLevel != 1) MayDay::Error("AMRProlongS_2: fine operator only");
+    put(SUHMO_F_PHI, a_correction, 0);
+    m_factory->m_ops[0]->put(SUHMO_F_CORR, a_coarseCorrection, 0);
+    chk(suhmo_amr2_prolong2(m_factory->m_level, m_factory->m_fine, SUHMO_F_CORR, nullptr), "AMRProlongS_2");
+    LevelData<FArrayBox> tmp(a_correction.disjointBoxLayout(), 1, 0);
+    get(SUHMO_F_PHI, tmp, 0);
+    for (int k = 0; k < tmp.size(); k++) {
+        const Box &b = tmp[k].box();
+        for (int j = b.lo[1]; j <= b.hi[1]; j++) for (int i = b.lo[0]; i <= b.hi[0]; i++) a_correction[k](i, j) = tmp[k](i, j);
+    }
+}
+void VCAMRNonLinearPoissonOpHIP::AMRResidual(LevelData<FArrayBox> &a_residual, const LevelData<FArrayBox> &a_phiFine, const LevelData<FArrayBox> &a_phi,
+                                             const LevelData<FArrayBox> &a_rhs, bool a_homogeneousPhysBC, VCAMRNonLinearPoissonOpHIP *a_finerOp)
+{
+    if (a_homogeneousPhysBC) MayDay::Abort("VCAMRNonLinearPoissonOp::applyOpI homogeneous AMR");
+    if (m_amrLevel != 0 || a_finerOp == nullptr || a_finerOp->m_amrLevel != 1) MayDay::Error("AMRResidual: base operator with its finer operator");
+    put(SUHMO_F_PHI, a_phi, 0); put(SUHMO_F_RHS, a_rhs, 0);
+    a_finerOp->put(SUHMO_F_PHI, a_phiFine, 0);
+    chk(suhmo_amr2_residual(m_factory->m_level, m_factory->m_fine, nullptr, nullptr), "AMRResidual");   // applyOpI + reflux; covered cells zeroed
+    get(SUHMO_F_RES, a_residual, 0);
+}
+Real VCAMRNonLinearPoissonOpHIP::AMRNorm(const LevelData<FArrayBox> &a_coarResid, const LevelData<FArrayBox> &a_fineResid, const int &a_refRat, const int &a_ord)
+{
+    if (a_refRat != 2) MayDay::Error("AMRNorm: refinement ratio 2");
+    put(SUHMO_F_RES, a_coarResid, 0);
+    if (a_fineResid.size() > 0 && m_factory->m_fine)
+        chk(suhmo_amr2_set_covered(m_factory->m_level, m_factory->m_fine, SUHMO_F_RES, 0.0, nullptr), "AMRNorm: zero under the finer grids");
+    double r = 0.0;
+    chk(suhmo_level_norm(h(), 0, SUHMO_F_RES, a_ord, &r, nullptr), "AMRNorm");
+    return r;
+}
+
 void VCAMRNonLinearPoissonOpHIP::create(LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_rhs)
 { a_lhs.define(a_rhs.disjointBoxLayout(), 1, a_rhs.ghost()); }
 void VCAMRNonLinearPoissonOpHIP::createCoarser(LevelData<FArrayBox> &a_coarse, const LevelData<FArrayBox> &a_fine, bool)

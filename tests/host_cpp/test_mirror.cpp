@@ -12,6 +12,19 @@
 
 using namespace suhmo_host;
 
+// oracle/amr2.c (test infrastructure; no public header)
+extern "C" {
+typedef struct OrAmr2 OrAmr2;
+OrAmr2 *or_amr2_create(OrLevel *coarse, int nxc, int nyc, double dxc, double dyc, const OrBC *bc, const OrPhys *ph,
+                       double alpha, double beta, int ci0, int cj0, int ci1, int cj1);
+void or_amr2_destroy(OrAmr2 *A);
+void or_amr2_fine_io(OrAmr2 *A, int field, double *g, int ghosted, int set);
+int or_amr2_solve(OrAmr2 *A, const OrSolverParams *sp, double *hist);
+void or_amr2_cf_interp_phi(OrAmr2 *A);
+void or_amr2_fine_gsrb(OrAmr2 *A, int sweeps);
+void or_amr2_fine_update_operator(OrAmr2 *A);
+}
+
 static int g_fail = 0;
 #define CHECK(cond, msg) do { if (!(cond)) { printf("FAIL: %s\n", msg); g_fail++; } else printf("ok:   %s\n", msg); } while (0)
 
@@ -138,6 +151,89 @@ int main()
     CHECK(n == on, "solve: same number of V-cycles as the oracle");
     CHECK(same_valid(phi, og, nx), "solve: converged head == oracle (bitwise)");
     printf("V-cycles %d, residual %.3e -> %.3e\n", n, hist.front(), hist.back());
+
+    // ================= two AMR levels: the base level above + a fine patch (coarse cells [32..95] x [16..47])
+    {
+        const int ci0 = 32, cj0 = 16, ci1 = 95, cj1 = 47, fnx = 2 * (ci1 - ci0 + 1), fny = 2 * (cj1 - cj0 + 1), fmb = 32;
+        ProblemDomain fdom; fdom.dom = Box(0, 0, 2 * nx - 1, 2 * ny - 1); fdom.periodic[0] = false; fdom.periodic[1] = false;
+        std::vector<Box> fbx;
+        for (int bj = 0; bj < fny / fmb; bj++) for (int bi = 0; bi < fnx / fmb; bi++)
+            fbx.push_back(Box(2 * ci0 + bi * fmb, 2 * cj0 + bj * fmb, 2 * ci0 + bi * fmb + fmb - 1, 2 * cj0 + bj * fmb + fmb - 1));
+        DisjointBoxLayout fgrids(fbx, fdom);
+        LevelData<FArrayBox> fphi(fgrids, 1, 1), frhs(fgrids, 1, 0), faCoef(fgrids, 1, 0), fB(fgrids, 1, 1), fPi(fgrids, 1, 1), fzb(fgrids, 1, 1), fmask(fgrids, 1, 1);
+        LevelData<FluxBox> fbCoef(fgrids, 1, 0);
+        const double fdx = dxv / 2, fdy = dyv / 2;
+        for (int k = 0; k < fgrids.size(); k++) {
+            const Box g = fgrids[k].grown(1);
+            for (int j = g.lo[1]; j <= g.hi[1]; j++)
+                for (int i = g.lo[0]; i <= g.hi[0]; i++) {
+                    double x = (i + 0.5) * fdx;
+                    double H = 6.0 * (std::sqrt(x + 5000.0) - std::sqrt(5000.0)) + 1.0; if (H < 0) H = 0;
+                    fB[k](i, j) = 0.01 * (1.0 + 0.4 * std::sin(0.185 * i) * std::cos(0.115 * j));
+                    fPi[k](i, j) = 910.0 * 9.8 * H; fzb[k](i, j) = 0.0; fmask[k](i, j) = 1.0;
+                    fphi[k](i, j) = 101325.0 / 9800.0 + 1e-3 * hashv(i * 977 + j, -1.0, 1.0);
+                }
+            const Box &v = fgrids[k];
+            for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++) { frhs[k](i, j) = 5.79e-9; faCoef[k](i, j) = 0.0; }
+        }
+        // patch-sized global arrays for the oracle (offset 2 ci0, 2 cj0)
+        auto patch = [&](const LevelData<FArrayBox> &ld, int g) {
+            std::vector<double> a((size_t)(fnx + 2 * g) * (fny + 2 * g), 0.0);
+            for (int k = 0; k < ld.size(); k++) {
+                Box b = ld.disjointBoxLayout()[k].grown(g);
+                for (int j = b.lo[1]; j <= b.hi[1]; j++) for (int i = b.lo[0]; i <= b.hi[0]; i++) {
+                    int li = i - 2 * ci0 + g, lj = j - 2 * cj0 + g;
+                    if (li >= 0 && li < fnx + 2 * g && lj >= 0 && lj < fny + 2 * g) a[(size_t)lj * (fnx + 2 * g) + li] = ld[k](i, j);
+                }
+            }
+            return a;
+        };
+        OrAmr2 *A = or_amr2_create(O, nx, ny, dxv, dyv, &obc, &oph, 0.0, -1.0, ci0, cj0, ci1, cj1);
+        { auto g = patch(fphi, 0); or_amr2_fine_io(A, OR_F_PHI, g.data(), 0, 1); }
+        { auto g = patch(frhs, 0); or_amr2_fine_io(A, OR_F_RHS, g.data(), 0, 1); }
+        { auto g = patch(faCoef, 0); or_amr2_fine_io(A, OR_F_ACOEF, g.data(), 0, 1); }
+        { auto g = patch(fB, 1); or_amr2_fine_io(A, OR_F_B, g.data(), 1, 1); }
+        { auto g = patch(fPi, 1); or_amr2_fine_io(A, OR_F_PI, g.data(), 1, 1); }
+        { auto g = patch(fzb, 1); or_amr2_fine_io(A, OR_F_ZB, g.data(), 1, 1); }
+        { auto g = patch(fmask, 1); or_amr2_fine_io(A, OR_F_MASK, g.data(), 1, 1); }
+        fac.defineFineLevel(fdom, fgrids, faCoef, fbCoef, fB, fPi, fzb, fmask);
+        VCAMRNonLinearPoissonOpHIP *fop = fac.AMRnewOp(fdom);
+        CHECK(fop != op && fop != nullptr, "AMRnewOp(fine domain) returns the fine-level operator");
+        auto same_patch = [&](const LevelData<FArrayBox> &ld, const std::vector<double> &glob) {
+            for (int k = 0; k < ld.size(); k++) {
+                const Box &v = ld.disjointBoxLayout()[k];
+                for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++) {
+                    double a = ld[k](i, j), b = glob[(size_t)(j - 2 * cj0) * fnx + (i - 2 * ci0)];
+                    if (memcmp(&a, &b, 8) != 0) { printf("   mismatch at (%d,%d): %.17g vs %.17g\n", i, j, a, b); return false; }
+                }
+            }
+            return true;
+        };
+        std::vector<double> fg((size_t)fnx * fny);
+        // coarse-fine ghosts of the head (relaxNF with 0 sweeps), UpdateOperator with the coarser level, then
+        // relaxNF: coarse-fine interpolation from the current base-level head + 2 sweeps
+        fop->relaxNF(fphi, &phi, frhs, 0, 0, 0);
+        or_amr2_cf_interp_phi(A);
+        fop->UpdateOperator(fphi, &phi, 0, 0, false);
+        or_amr2_fine_update_operator(A);
+        fop->relaxNF(fphi, &phi, frhs, 2, 0, 0);
+        or_amr2_cf_interp_phi(A); or_amr2_fine_gsrb(A, 2); or_amr2_fine_io(A, OR_F_PHI, fg.data(), 0, 0);
+        CHECK(same_patch(fphi, fg), "relaxNF (coarseFineInterp + levelGSRB x2 on the patch) == oracle");
+        // the two-level solve
+        HeadSolverParameters sp2(100, true); sp2.max_iter = 5;
+        OrSolverParams osp2; memcpy(&osp2, static_cast<suhmo_solver_params_t *>(&sp2), sizeof(osp2));
+        std::vector<LevelData<FArrayBox> *> vphi = {&phi, &fphi};
+        std::vector<LevelData<FArrayBox> *> vrhs = {&rhs, &frhs};
+        std::vector<double> h2, oh2(sp2.max_iter + 2);
+        int n2 = fac.solveAMR(vphi, vrhs, sp2, &h2);
+        int on2 = or_amr2_solve(A, &osp2, oh2.data());
+        or_level_get(O, 0, OR_F_PHI, og.data(), 0); or_amr2_fine_io(A, OR_F_PHI, fg.data(), 0, 0);
+        CHECK(n2 == on2 && h2.back() == oh2[on2], "solveAMR: V-cycle count and composite residual == oracle");
+        CHECK(same_valid(phi, og, nx), "solveAMR: base-level head == oracle (bitwise)");
+        CHECK(same_patch(fphi, fg), "solveAMR: fine-level head == oracle (bitwise)");
+        printf("AMR V-cycles %d, composite residual %.3e -> %.3e\n", n2, h2.front(), h2.back());
+        or_amr2_destroy(A);
+    }
 
     or_level_destroy(O);
     printf(g_fail ? "RESULT: FAIL (%d)\n" : "RESULT: PASS\n", g_fail);
