@@ -269,8 +269,8 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st)
         int nch = slots_k[K] / g.nstrips;
         if (nch < 1) nch = 1;
         g.Hc = (nrows + nch - 1) / nch;
-        if (L->fused_hc > 0) g.Hc = L->fused_hc;
         if (g.Hc < 16 * K) g.Hc = 16 * K;
+        if (L->fused_hc > 0) g.Hc = L->fused_hc;          // explicit: no lower clamp (tools/sweep_small_hc.sh)
         if (g.Hc > nrows) g.Hc = nrows;
         g.nchunks = (nrows + g.Hc - 1) / g.Hc;
     }
