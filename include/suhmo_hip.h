@@ -263,6 +263,14 @@ int suhmo_amr2_vcycle(suhmo_level_t *coarse, suhmo_level_t *fine, const suhmo_so
 int suhmo_amr2_solve(suhmo_level_t *coarse, suhmo_level_t *fine, const suhmo_solver_params_t *sp, int *iters,
                      double *resid_hist, suhmo_stream_t s);
 
+/* N nested levels: levels[0] = base level, levels[l] = one patch refined by 2 and properly nested (2 cells) in
+ * level l-1 (cfg4 / cfg5 hierarchies); the suhmo_amr2_* calls are the nlev = 2 case.  A coarser level that is itself
+ * a patch gets its own coarse-fine ghosts interpolated before its operator or gradient is evaluated. */
+int suhmo_amr_residual(suhmo_level_t **levels, int nlev, double *norm, suhmo_stream_t s);
+int suhmo_amr_vcycle(suhmo_level_t **levels, int nlev, const suhmo_solver_params_t *sp, suhmo_stream_t s);
+int suhmo_amr_solve(suhmo_level_t **levels, int nlev, const suhmo_solver_params_t *sp, int *iters,
+                    double *resid_hist, suhmo_stream_t s);
+
 /* timing helper: average device time (ms) of the GSRB sweep kernel launches since the
  * last reset, measured with HIP events on the launch stream */
 int suhmo_level_profile_reset(suhmo_level_t *L);

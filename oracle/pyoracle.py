@@ -110,6 +110,16 @@ def lib():
         L.or_amr2_vcycle.argtypes = [C.c_void_p, C.POINTER(OrSolverParams)]
         L.or_amr2_solve.restype = C.c_int
         L.or_amr2_solve.argtypes = [C.c_void_p, C.POINTER(OrSolverParams), dp]
+        L.or_amr_create.restype = C.c_void_p
+        L.or_amr_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(OrBC), C.POINTER(OrPhys),
+                                    C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int)]
+        L.or_amr_destroy.argtypes = [C.c_void_p]
+        L.or_amr_patch_io.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int, C.c_int]
+        L.or_amr_residual.restype = C.c_double
+        L.or_amr_residual.argtypes = [C.c_void_p]
+        L.or_amr_vcycle.argtypes = [C.c_void_p, C.POINTER(OrSolverParams)]
+        L.or_amr_solve.restype = C.c_int
+        L.or_amr_solve.argtypes = [C.c_void_p, C.POINTER(OrSolverParams), dp]
         L.or_prolong2_global.argtypes = [dp, dp, C.c_int, C.c_int]
         L.or_divergence_global.argtypes = [dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double]
         L.or_difterm_global.argtypes = [dp, dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double]
@@ -374,3 +384,57 @@ def moulin_source(nx, ny, dx, dy, positions, sigma, flux, time_factor=1.0):
     integ, src = np.zeros(nm), np.zeros((ny, nx))
     lib().or_moulin_source(nx, ny, dx, dy, nm, _dp(pos), _dp(sg), _dp(fl), float(time_factor), _dp(integ), _dp(src))
     return src, integ
+
+
+class OracleAmr:
+    """Base level + nested patches (patches[k] = box of level k+1 in the index space of level k): oracle/amrn.c"""
+
+    def __init__(self, nx0, ny0, dx0, dy0, bc, phys, patches, alpha=0.0, beta=-1.0, max_box=64, nthreads=1):
+        self.coarse = OracleLevel(nx0, ny0, dx0, dy0, bc, phys, alpha, beta, max_box, nthreads)
+        self.patches = [tuple(int(v) for v in p) for p in patches]
+        self.nlev = 1 + len(self.patches)
+        flat = (C.c_int * (4 * len(self.patches)))(*[v for p in self.patches for v in p])
+        self.h = lib().or_amr_create(self.coarse.h, nx0, ny0, dx0, dy0, C.byref(self.coarse._bc), C.byref(self.coarse._ph),
+                                     alpha, beta, self.nlev, flat)
+
+    def patch_shape(self, l, field, ghosted=False):
+        ci0, cj0, ci1, cj1 = self.patches[l - 1]
+        nxp, nyp = 2 * (ci1 - ci0 + 1), 2 * (cj1 - cj0 + 1)
+        if field == F_BX:
+            return (nyp, nxp + 1)
+        if field == F_BY:
+            return (nyp + 1, nxp)
+        return (nyp + 2, nxp + 2) if ghosted else (nyp, nxp)
+
+    def patch_set(self, l, field, arr, ghosted=False):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        assert a.shape == self.patch_shape(l, field, ghosted), (a.shape, self.patch_shape(l, field, ghosted))
+        lib().or_amr_patch_io(self.h, l, field, _dp(a), int(ghosted), 1)
+
+    def patch_get(self, l, field, ghosted=False):
+        out = np.zeros(self.patch_shape(l, field, ghosted))
+        lib().or_amr_patch_io(self.h, l, field, _dp(out), int(ghosted), 0)
+        return out
+
+    def set_patch_inputs(self, l, f):
+        self.patch_set(l, F_PHI, f["phi"]); self.patch_set(l, F_RHS, f["rhs"]); self.patch_set(l, F_ACOEF, f["aCoef"])
+        for k, fid in (("B", F_B), ("Pi", F_PI), ("zb", F_ZB), ("mask", F_MASK)):
+            self.patch_set(l, fid, f[k], ghosted=True)
+
+    def residual(self): return lib().or_amr_residual(self.h)
+
+    def vcycle(self, sp):
+        s = make_solver_params(sp)
+        lib().or_amr_vcycle(self.h, C.byref(s))
+
+    def solve(self, sp):
+        s = make_solver_params(sp)
+        hist = np.zeros(s.max_iter + 2)
+        n = lib().or_amr_solve(self.h, C.byref(s), _dp(hist))
+        return n, hist[: n + 1]
+
+    def close(self):
+        if self.h:
+            lib().or_amr_destroy(self.h)
+            self.h = None
+            self.coarse.close()

@@ -21,9 +21,19 @@ int check_pair(suhmo_level *C, suhmo_level *F)
 {
     ARG(C && F);
     const DV &c = C->d[0].v, &f = F->d[0].v;
-    if (c.i0 || c.j0 || c.nx != c.nxg || c.ny != c.nyg) { suhmo_set_error("amr2: the base level must span the domain"); return -1; }
     if (f.nxg != 2 * c.nxg || f.nyg != 2 * c.nyg || (f.i0 & 1) || (f.j0 & 1) || (f.nx & 1) || (f.ny & 1)) {
-        suhmo_set_error("amr2: the fine level must be a coarse-aligned patch of the domain refined by 2"); return -1; }
+        suhmo_set_error("amr: the fine level must be a coarse-aligned patch of the domain refined by 2"); return -1; }
+    // proper nesting: 2 coarse cells between the fine patch and the edge of a coarse PATCH (the tangential stencil of
+    // the coarse-fine interpolation and the reflux cell live there); nothing required towards a domain boundary
+    {
+        const int lo[2] = {f.i0 / 2, f.j0 / 2}, hi[2] = {(f.i0 + f.nx) / 2 - 1, (f.j0 + f.ny) / 2 - 1};
+        const int clo[2] = {c.i0, c.j0}, chi[2] = {c.i0 + c.nx - 1, c.j0 + c.ny - 1}, dom[2] = {c.nxg, c.nyg};
+        for (int d = 0; d < 2; d++) {
+            bool ok_lo = (clo[d] == 0) ? lo[d] >= 0 : lo[d] - clo[d] >= 2;      // coarse edge on the domain boundary: no margin needed
+            bool ok_hi = (chi[d] == dom[d] - 1) ? hi[d] <= chi[d] : chi[d] - hi[d] >= 2;
+            if (!ok_lo || !ok_hi) { suhmo_set_error("amr: the fine patch is not properly nested in its coarse level (2 cells)"); return -1; }
+        }
+    }
     if (C->device != F->device) { suhmo_set_error("amr2: both levels on one device"); return -1; }
     return 0;
 }
@@ -33,7 +43,7 @@ __device__ __forceinline__ double cval(const DV &vc, const double *__restrict__ 
 {
     if (vc.per[0]) { if (I < 0) I += vc.nxg; else if (I >= vc.nxg) I -= vc.nxg; }
     if (vc.per[1]) { if (J < 0) J += vc.nyg; else if (J >= vc.nyg) J -= vc.nyg; }
-    return c[cidx(vc, I, J)];
+    return c[cidx(vc, I - vc.i0, J - vc.j0)];
 }
 
 // [Chombo] QuadCFInterp::coarseFineInterp, ratio 2 (oracle/amr2.c:cf_interp): tangential quadratic on the coarse
@@ -74,13 +84,13 @@ __global__ void k_amr_average(DV vf, const double *__restrict__ f, DV vc, double
     int b = cidx(vf, 2 * I, 2 * J);
     double s = 0.0;
     s = s + f[b]; s = s + f[b + 1]; s = s + f[b + vf.P]; s = s + f[b + vf.P + 1];
-    c[cidx(vc, I + vf.i0 / 2, J + vf.j0 / 2)] = s * 0.25;
+    c[cidx(vc, I + vf.i0 / 2 - vc.i0, J + vf.j0 / 2 - vc.j0)] = s * 0.25;
 }
 __global__ void k_amr_set_covered(DV vf, DV vc, double *__restrict__ c, double val)
 {
     int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y * blockDim.y + threadIdx.y;
     if (I >= vf.nx / 2 || J >= vf.ny / 2) return;
-    c[cidx(vc, I + vf.i0 / 2, J + vf.j0 / 2)] = val;
+    c[cidx(vc, I + vf.i0 / 2 - vc.i0, J + vf.j0 / 2 - vc.j0)] = val;
 }
 
 // [Chombo] LevelFluxRegister (oracle/amr2.c:reflux): on every coarse-fine face the coarse flux is replaced by the
@@ -102,8 +112,8 @@ __global__ void k_amr_reflux(DV vf, FP ff, DV vc, FP fc, double *__restrict__ lo
     const double sign = side == 0 ? 1.0 : -1.0;
     const double *__restrict__ phic = fc.f[SUHMO_F_PHI], *__restrict__ phif = ff.f[SUHMO_F_PHI];
     double phihi, philo, bc_;
-    if (dir == 0) { int idx = cidx(vc, F, T); phihi = phic[idx]; philo = phic[idx - 1]; bc_ = fc.f[SUHMO_F_BX][idx]; }
-    else { int idx = cidx(vc, T, F); phihi = phic[idx]; philo = phic[idx - vc.P]; bc_ = fc.f[SUHMO_F_BY][idx]; }
+    if (dir == 0) { int idx = cidx(vc, F - vc.i0, T - vc.j0); phihi = phic[idx]; philo = phic[idx - 1]; bc_ = fc.f[SUHMO_F_BX][idx]; }
+    else { int idx = cidx(vc, T - vc.i0, F - vc.j0); phihi = phic[idx]; philo = phic[idx - vc.P]; bc_ = fc.f[SUHMO_F_BY][idx]; }
     double Fc = -bc_ * ((phihi - philo) * cs);
     double reg = -(tsize * Fc);
     for (int k = 0; k < 2; k++) {
@@ -114,7 +124,7 @@ __global__ void k_amr_reflux(DV vf, FP ff, DV vc, FP fc, double *__restrict__ lo
         double Ff = -bf * ((ph_hi - ph_lo) * fs);
         reg = reg + (tsize * Ff) * 0.5;
     }
-    int oidx = dir == 0 ? cidx(vc, outside, T) : cidx(vc, T, outside);
+    int oidx = dir == 0 ? cidx(vc, outside - vc.i0, T - vc.j0) : cidx(vc, T - vc.i0, outside - vc.j0);
     lofphi[oidx] = lofphi[oidx] + sign * rscale * reg;
 }
 
@@ -127,7 +137,7 @@ __global__ void k_amr_prolong2(DV vf, double *__restrict__ phi, DV vc, const dou
     const double den = 1.0 / 16.0, fx1 = 3.0 * den, fx2 = 9.0 * den, f0 = 1.0 * den;
     int gi = i + vf.i0, gj = j + vf.j0;
     int ic = gi / 2, jc = gj / 2, o1 = 2 * (gi % 2) - 1, o2 = 2 * (gj % 2) - 1;
-    int idx = cidx(vf, i, j), cc = cidx(vc, ic, jc);
+    int idx = cidx(vf, i, j), cc = cidx(vc, ic - vc.i0, jc - vc.j0);
     // the diagonal neighbour: a ghost cell of the coarsened patch box that lies outside the domain is filled by
     // m_bc only along the box's own extent -- the corner cell beyond it is never written (:1160-1172), value 0
     double cd = c[cc + o1 + o2 * vc.P];
@@ -299,6 +309,122 @@ extern "C" int suhmo_amr2_solve(suhmo_level_t *C, suhmo_level_t *F, const suhmo_
         norm_last = rnorm;
         if ((rc = suhmo_amr2_vcycle(C, F, sp, s))) return rc;
         if ((rc = suhmo_amr2_residual(C, F, &rnorm, s))) return rc;
+        iter++;
+        if (hist) hist[iter] = rnorm;
+        goNorm = rnorm > sp->norm_thresh; goRedu = rnorm > sp->eps * initial_rnorm; goIter = iter < sp->max_iter;
+        goHang = iter < sp->imin || rnorm < (1.0 - sp->hang) * norm_last; goMin = iter < sp->iter_min;
+    }
+    if (iters) *iters = iter;
+    return 0;
+}
+
+
+// ================================================================ N nested levels
+// levels[0] = base level, levels[l] = patch of level l (properly nested in level l-1): oracle/amrn.c states the same
+// cycle.  The two-level entry points above are the nlev = 2 case.
+namespace {
+int cf_phi(suhmo_level_t **lv, int l, suhmo_stream_t s)      // head of level l: coarse-fine ghosts from level l-1
+{
+    if (l == 0) return 0;
+    return suhmo_amr2_cf_interp(lv[l - 1], lv[l], SUHMO_F_PHI, SUHMO_F_PHI, s);
+}
+// RES of level l-1 = rhs - [applyOpI(phi) + reflux from level l]; LPHI of level l-1 keeps the plain L(phi)
+int composite_residual(suhmo_level_t **lv, int l, suhmo_stream_t s)
+{
+    suhmo_level *C = lv[l - 1], *F = lv[l];
+    hipStream_t st = (hipStream_t)s;
+    int rc;
+    if ((rc = cf_phi(lv, l - 1, s))) return rc;
+    if ((rc = suhmo_level_apply_op(C, 0, 0, s))) return rc;
+    double *res = suhmo_field(C, 0, SUHMO_F_RES), *lphi = suhmo_field(C, 0, SUHMO_F_LPHI);
+    HIPCHK(hipMemcpyAsync(res, lphi, C->d[0].elems * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if ((rc = cf_phi(lv, l, s))) return rc;
+    const DV &vf = F->d[0].v, &vc = C->d[0].v;
+    int n = vf.ny + vf.nx;
+    hipLaunchKernelGGL(k_amr_reflux, dim3((n + 255) / 256), dim3(256), 0, st, vf, F->d[0].fp, vc, C->d[0].fp, res);
+    HIPCHK(hipGetLastError());
+    return suhmo_level_axby(C, 0, SUHMO_F_RES, SUHMO_F_RES, SUHMO_F_RHS, -1.0, 1.0, s);
+}
+int vcycle_amr(suhmo_level_t **lv, int l, const suhmo_solver_params_t *sp, suhmo_stream_t s)
+{
+    if (l == 0) return suhmo_level_vcycle(lv[0], sp, s);
+    suhmo_level *C = lv[l - 1], *F = lv[l];
+    hipStream_t st = (hipStream_t)s;
+    int rc;
+    Depth &DC = C->d[0];
+    const size_t cbytes = DC.elems * sizeof(double);
+    double *rhs0 = suhmo_field(C, 0, SUHMO_F_RHS0), *phiold = suhmo_field(C, 0, SUHMO_F_PHIOLD), *corr = suhmo_field(C, 0, SUHMO_F_CORR);
+    if (!rhs0 || !phiold || !corr) { suhmo_set_error("field allocation failed"); return -2; }
+    if ((rc = cf_phi(lv, l, s))) return rc;
+    if (sp->bcoeff_otf) {
+        if ((rc = cf_phi(lv, l - 1, s))) return rc;            // the coarser level's own coarse-fine ghosts (its gradient reads them)
+        if ((rc = suhmo_amr2_fine_update_operator(C, F, s))) return rc;
+    }
+    if ((rc = suhmo_level_gsrb(F, 0, sp->num_smooth, s))) return rc;                       // relaxNF
+    if ((rc = suhmo_amr2_average(C, F, SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc;           // AMRRestrictS(skip_res)
+    if ((rc = cf_phi(lv, l, s))) return rc;
+    if ((rc = suhmo_level_residual(F, 0, s))) return rc;                                   // res_l = rhs_l - L_l(phi_l)
+    if ((rc = composite_residual(lv, l, s))) return rc;
+    if ((rc = suhmo_amr2_average(C, F, SUHMO_F_RES, SUHMO_F_RES, s))) return rc;
+    HIPCHK(hipMemcpyAsync(rhs0, DC.fp.f[SUHMO_F_RHS], cbytes, hipMemcpyDeviceToDevice, st));
+    if ((rc = suhmo_level_axby(C, 0, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
+    HIPCHK(hipMemcpyAsync(phiold, DC.fp.f[SUHMO_F_PHI], cbytes, hipMemcpyDeviceToDevice, st));
+    if ((rc = vcycle_amr(lv, l - 1, sp, s))) return rc;
+    HIPCHK(hipMemcpyAsync(DC.fp.f[SUHMO_F_RHS], rhs0, cbytes, hipMemcpyDeviceToDevice, st));
+    if ((rc = suhmo_level_axby(C, 0, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) return rc;
+    if ((rc = suhmo_amr2_prolong2(C, F, SUHMO_F_CORR, s))) return rc;                      // AMRProlongS_2
+    if ((rc = cf_phi(lv, l, s))) return rc;
+    return suhmo_level_gsrb(F, 0, sp->num_smooth, s);
+}
+int check_hierarchy(suhmo_level_t **lv, int nlev)
+{
+    ARG(lv && nlev >= 1 && nlev <= 8);
+    for (int l = 0; l < nlev; l++) ARG(lv[l]);
+    const DV &b = lv[0]->d[0].v;
+    if (b.i0 || b.j0 || b.nx != b.nxg || b.ny != b.nyg) { suhmo_set_error("amr: level 0 must span the domain"); return -1; }
+    for (int l = 1; l < nlev; l++) { int rc = check_pair(lv[l - 1], lv[l]); if (rc) return rc; }
+    return 0;
+}
+}  // namespace
+
+extern "C" int suhmo_amr_residual(suhmo_level_t **lv, int nlev, double *norm, suhmo_stream_t s)
+{
+    int rc = check_hierarchy(lv, nlev); if (rc) return rc;
+    HIPCHK(hipSetDevice(lv[0]->device));
+    const int top = nlev - 1;
+    if ((rc = cf_phi(lv, top, s))) return rc;
+    if ((rc = suhmo_level_residual(lv[top], 0, s))) return rc;                             // AMRResidualNF on the finest level
+    for (int l = top; l >= 1; l--) if ((rc = composite_residual(lv, l, s))) return rc;
+    for (int l = top; l >= 1; l--) if ((rc = suhmo_amr2_set_covered(lv[l - 1], lv[l], SUHMO_F_RES, 0.0, s))) return rc;   // AMRNorm
+    if (norm) {
+        double m = 0.0;
+        for (int l = 0; l <= top; l++) { double a = 0.0; if ((rc = suhmo_level_norm(lv[l], 0, SUHMO_F_RES, 0, &a, s))) return rc; if (a > m) m = a; }
+        *norm = m;
+    }
+    return 0;
+}
+extern "C" int suhmo_amr_vcycle(suhmo_level_t **lv, int nlev, const suhmo_solver_params_t *sp, suhmo_stream_t s)
+{
+    int rc = check_hierarchy(lv, nlev); if (rc) return rc;
+    ARG(sp);
+    HIPCHK(hipSetDevice(lv[0]->device));
+    return vcycle_amr(lv, nlev - 1, sp, s);
+}
+extern "C" int suhmo_amr_solve(suhmo_level_t **lv, int nlev, const suhmo_solver_params_t *sp, int *iters, double *hist, suhmo_stream_t s)
+{
+    ARG(sp);
+    int rc;
+    double rnorm = 0.0;
+    if ((rc = suhmo_amr_residual(lv, nlev, &rnorm, s))) return rc;
+    double initial_rnorm = rnorm, norm_last = 2.0 * initial_rnorm;
+    int iter = 0;
+    if (hist) hist[0] = rnorm;
+    bool goNorm = rnorm > sp->norm_thresh, goRedu = rnorm > sp->eps * initial_rnorm, goIter = iter < sp->max_iter;
+    bool goHang = iter < sp->imin || rnorm < (1.0 - sp->hang) * norm_last, goMin = iter < sp->iter_min;
+    while (goMin || (goIter && goRedu && goHang && goNorm)) {
+        norm_last = rnorm;
+        if ((rc = suhmo_amr_vcycle(lv, nlev, sp, s))) return rc;
+        if ((rc = suhmo_amr_residual(lv, nlev, &rnorm, s))) return rc;
         iter++;
         if (hist) hist[iter] = rnorm;
         goNorm = rnorm > sp->norm_thresh; goRedu = rnorm > sp->eps * initial_rnorm; goIter = iter < sp->max_iter;

@@ -214,3 +214,39 @@ class HipAmr2:
     def close(self):
         self.fine.close()
         self.coarse.close()
+
+
+class HipAmr:
+    """Base level + nested patches (patches[k] = box of level k+1 in the index space of level k), all resident in
+    HBM: suhmo_amr_vcycle / suhmo_amr_solve over the array of level handles."""
+
+    def __init__(self, nx0, ny0, dx0, dy0, bc, phys, patches, alpha=0.0, beta=-1.0, max_box=64, device=0):
+        self.levels = [HipLevel(nx0, ny0, dx0, dy0, bc, phys, alpha, beta, max_box, device=device)]
+        nxg, nyg, dx, dy = nx0, ny0, dx0, dy0
+        for (ci0, cj0, ci1, cj1) in patches:
+            nxg, nyg, dx, dy = 2 * nxg, 2 * nyg, dx / 2.0, dy / 2.0
+            self.levels.append(HipLevel(2 * (ci1 - ci0 + 1), 2 * (cj1 - cj0 + 1), dx, dy, bc, phys, alpha, beta, max_box,
+                                        j0=2 * cj0, ny_global=nyg, i0=2 * ci0, nx_global=nxg, device=device))
+        self.stream = self.levels[0].stream
+        self._arr = (C.c_void_p * len(self.levels))(*[lv.h for lv in self.levels])
+
+    def residual(self):
+        r = C.c_double()
+        check(capi.lib().suhmo_amr_residual(self._arr, len(self.levels), C.cast(C.pointer(r), C.POINTER(C.c_double)), self.stream))
+        return r.value
+
+    def vcycle(self, sp):
+        s = solver_params(sp)
+        check(capi.lib().suhmo_amr_vcycle(self._arr, len(self.levels), C.byref(s), self.stream))
+
+    def solve(self, sp):
+        s = solver_params(sp)
+        hist = np.zeros(s.max_iter + 2)
+        n = C.c_int()
+        check(capi.lib().suhmo_amr_solve(self._arr, len(self.levels), C.byref(s), C.byref(n),
+                                         hist.ctypes.data_as(C.POINTER(C.c_double)), self.stream))
+        return n.value, hist[: n.value + 1]
+
+    def close(self):
+        for lv in reversed(self.levels):
+            lv.close()

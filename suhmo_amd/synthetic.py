@@ -149,11 +149,12 @@ CFG3_PHYS = dict(A3_PHYS, A=2.5e-25)
 CFG3_PATCH = (8, 4, 23, 11)          # coarse cells [8..23] x [4..11]: 32 x 16 fine cells around the moulin
 
 
-def amr2_fields(nxc=64, nyc=16, patch=CFG3_PATCH, lx=64.0, ly=16.0, slope=0.02, ice_height=500.0, gap_init=0.01,
-                moulin=(16.015625, 8.015625, 1.0, 30.0), background=1.0e-11, seed=2024, vary_B=True):
-    """(coarse, fine) input dicts.  Every field is the same analytic function sampled at the two resolutions
-    (zb = slope x; H, Pi as SqrtIBC; rhs = background + a Gaussian moulin, value at the cell centre); the head gets
-    an independent random perturbation per level."""
+def amr_fields(nx0=64, ny0=16, patches=(CFG3_PATCH,), lx=64.0, ly=16.0, slope=0.02, ice_height=500.0, gap_init=0.01,
+               moulin=(16.015625, 8.015625, 1.0, 30.0), background=1.0e-11, seed=2024, vary_B=True):
+    """List of input dicts, one per AMR level (level 0 = base; patches[k] = box of level k+1 in the index space of
+    level k).  Every field is the same analytic function sampled at each resolution (zb = slope x; H, Pi as SqrtIBC;
+    rhs = background + a Gaussian moulin, value at the cell centre); the head gets an independent random
+    perturbation per level."""
     def level(nx, ny, i0, j0, nxg, nyg, rng):
         dx, dy = lx / nxg, ly / nyg
         i = np.arange(i0 - 1, i0 + nx + 1, dtype=np.float64)
@@ -173,7 +174,15 @@ def amr2_fields(nxc=64, nyc=16, patch=CFG3_PATCH, lx=64.0, ly=16.0, slope=0.02, 
         return dict(nx=nx, ny=ny, dx=dx, dy=dy, phi=np.ascontiguousarray(phi[v]), rhs=np.ascontiguousarray(src[v]),
                     aCoef=np.zeros((ny, nx)), B=np.ascontiguousarray(B), Pi=np.ascontiguousarray(Pi),
                     zb=np.ascontiguousarray(zb), mask=np.ascontiguousarray(mask))
-    ci0, cj0, ci1, cj1 = patch
-    coarse = level(nxc, nyc, 0, 0, nxc, nyc, np.random.default_rng([seed, 0]))
-    fine = level(2 * (ci1 - ci0 + 1), 2 * (cj1 - cj0 + 1), 2 * ci0, 2 * cj0, 2 * nxc, 2 * nyc, np.random.default_rng([seed, 1]))
-    return coarse, fine
+    out = [level(nx0, ny0, 0, 0, nx0, ny0, np.random.default_rng([seed, 0]))]
+    nxg, nyg = nx0, ny0
+    for k, (ci0, cj0, ci1, cj1) in enumerate(patches):
+        nxg, nyg = 2 * nxg, 2 * nyg
+        out.append(level(2 * (ci1 - ci0 + 1), 2 * (cj1 - cj0 + 1), 2 * ci0, 2 * cj0, nxg, nyg, np.random.default_rng([seed, k + 1])))
+    return out
+
+
+def amr2_fields(nxc=64, nyc=16, patch=CFG3_PATCH, **kw):
+    """(coarse, fine): the two-level case of amr_fields"""
+    c, f = amr_fields(nxc, nyc, (patch,), **kw)
+    return c, f

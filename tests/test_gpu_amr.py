@@ -87,3 +87,40 @@ def test_amr2_vcycle_and_solve_bitwise(oracle, case):
     eq(O.fine_get(oracle.F_PHI), G.fine.get(F_PHI), "fine head after the solve")
     eq(O.coarse.get(oracle.F_PHI), G.coarse.get(F_PHI), "coarse head after the solve")
     O.close(); G.close()
+
+
+PATCHES3 = (sy.CFG3_PATCH, (22, 11, 37, 20))      # level 2 nested (2+ cells) in level 1 = [16..47] x [8..23]
+NCASES = [
+    ("two-levels", 64, 16, (sy.CFG3_PATCH,), BC, sy.CFG3_PHYS),
+    ("three-levels", 64, 16, PATCHES3, BC, sy.CFG3_PHYS),
+    ("three-levels-nonperiodic-mask", 64, 32, ((0, 8, 23, 23), (4, 20, 35, 43)), BC_NP,
+     dict(sy.CFG3_PHYS, use_mask_gradients=1, cutOffbr=0.008, maxOffbr=0.012, cutOffB=1)),
+]
+
+
+@pytest.mark.parametrize("case", NCASES, ids=[c[0] for c in NCASES])
+def test_amr_n_levels_bitwise(oracle, case):
+    from suhmo_amd import level
+    from suhmo_amd.level import F_PHI
+    _, nx0, ny0, patches, bc, ph = case
+    fs = sy.amr_fields(nx0, ny0, patches)
+    O = oracle.OracleAmr(nx0, ny0, fs[0]["dx"], fs[0]["dy"], bc, ph, patches, max_box=32, nthreads=2)
+    G = level.HipAmr(nx0, ny0, fs[0]["dx"], fs[0]["dy"], bc, ph, patches, max_box=32)
+    O.coarse.set_inputs(fs[0]); O.coarse.build_mg_coefficients()
+    G.levels[0].set_inputs(fs[0]); G.levels[0].build_mg_coefficients()
+    for l in range(1, len(fs)):
+        O.set_patch_inputs(l, fs[l])
+        G.levels[l].set_inputs(fs[l])
+    assert O.residual() == G.residual()
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-9, norm_thresh=1e-14, max_iter=5, imin=30)
+    O.vcycle(sp); G.vcycle(sp)
+    for l in range(1, len(fs)):
+        eq(O.patch_get(l, oracle.F_PHI), G.levels[l].get(F_PHI), "level %d head after one AMR V-cycle" % l)
+    eq(O.coarse.get(oracle.F_PHI), G.levels[0].get(F_PHI), "base head after one AMR V-cycle")
+    no, ho = O.solve(sp)
+    ng, hg = G.solve(sp)
+    assert no == ng and np.array_equal(ho, hg), (ho, hg)
+    for l in range(1, len(fs)):
+        eq(O.patch_get(l, oracle.F_PHI), G.levels[l].get(F_PHI), "level %d head after the solve" % l)
+    eq(O.coarse.get(oracle.F_PHI), G.levels[0].get(F_PHI), "base head after the solve")
+    O.close(); G.close()

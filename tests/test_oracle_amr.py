@@ -64,3 +64,46 @@ def test_two_level_solve_converges_and_beats_the_coarse_solve(oracle):
     avg = 0.25 * (phi_f[0::2, 0::2] + phi_f[0::2, 1::2] + phi_f[1::2, 0::2] + phi_f[1::2, 1::2])
     assert np.max(np.abs(avg - phi_c2[cj0:cj1 + 1, ci0:ci1 + 1])) < 1e-3 * np.max(np.abs(avg))
     A.close(); U.close(); Cc.close()
+
+
+PATCHES3 = (sy.CFG3_PATCH, (22, 11, 37, 20))      # level 2 inside level 1 ([16..47] x [8..23]) with 2+ cells of nesting
+
+
+def make_n(oracle, patches, nx0=64, ny0=16, bc=BC, ph=sy.CFG3_PHYS, **kw):
+    fs = sy.amr_fields(nx0, ny0, patches, **kw)
+    A = oracle.OracleAmr(nx0, ny0, fs[0]["dx"], fs[0]["dy"], bc, ph, patches, max_box=32, nthreads=2)
+    A.coarse.set_inputs(fs[0])
+    A.coarse.build_mg_coefficients()
+    for l in range(1, len(fs)):
+        A.set_patch_inputs(l, fs[l])
+    return A, fs
+
+
+def test_n_level_code_with_two_levels_equals_the_two_level_code(oracle):
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-9, norm_thresh=1e-14, max_iter=4, imin=30)
+    A2, c, f = make(oracle)
+    AN, fs = make_n(oracle, (sy.CFG3_PATCH,))
+    assert A2.residual() == AN.residual()
+    n2, h2 = A2.solve(sp)
+    nn, hn = AN.solve(sp)
+    assert n2 == nn and np.array_equal(h2, hn)
+    assert np.array_equal(A2.fine_get(oracle.F_PHI), AN.patch_get(1, oracle.F_PHI))
+    assert np.array_equal(A2.coarse.get(oracle.F_PHI), AN.coarse.get(oracle.F_PHI))
+    A2.close(); AN.close()
+
+
+def test_three_level_solve_converges(oracle):
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-9, norm_thresh=1e-14, max_iter=30, imin=30)
+    A, fs = make_n(oracle, PATCHES3)
+    r0 = A.residual()
+    n, hist = A.solve(sp)
+    assert hist[-1] < 1e-6 * r0 and hist[-1] < 1e-9 * np.max(hist), hist
+    assert np.all(hist[8:] < 0.6 * hist[7:-1]), hist
+    # every coarser level holds the average of the finer one under the patch (up to the last post-smoothing)
+    p2, p1 = A.patch_get(2, oracle.F_PHI), A.patch_get(1, oracle.F_PHI)
+    avg = 0.25 * (p2[0::2, 0::2] + p2[0::2, 1::2] + p2[1::2, 0::2] + p2[1::2, 1::2])
+    ci0, cj0, ci1, cj1 = PATCHES3[1]
+    o0, o1 = 2 * sy.CFG3_PATCH[0], 2 * sy.CFG3_PATCH[1]
+    win = p1[cj0 - o1:cj1 - o1 + 1, ci0 - o0:ci1 - o0 + 1]
+    assert np.max(np.abs(avg - win)) < 1e-3 * np.max(np.abs(avg))
+    A.close()
