@@ -60,7 +60,7 @@ def main():
     ny_global = n * world
     f = sy.shmip_fields(n, n, j0=rank * n, ny_total=ny_global)
     G = level.HipLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64, j0=rank * n,
-                       ny_global=ny_global, device=local_rank, halo_rows=int(os.environ.get("SUHMO_HALO_ROWS", "16")) if world > 1 else 1)
+                       ny_global=ny_global, device=local_rank, halo_rows=int(os.environ.get("SUHMO_HALO_ROWS", "24")) if world > 1 else 1)
     G.set_inputs(f)
     if world > 1:
         from suhmo_amd import multigpu

@@ -141,7 +141,7 @@ struct suhmo_level {
     suhmo_allreduce_max_fn ar;
     void *user;
     int (*ex_begin)(void *user);                       // optional: open / close a batch of exchanges that
-    int (*ex_end)(void *user, suhmo_stream_t s);        // travel as ONE message group (native transport)
+    int (*ex_end)(void *user, suhmo_level *L, suhmo_stream_t s);   // travel as ONE message group (native transport)
     void *rccl;                 // native transport state (suhmo_rccl.hip), owned by the level
     int prof_on;
     std::vector<ProfEv> prof;

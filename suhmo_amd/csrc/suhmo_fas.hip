@@ -30,26 +30,41 @@ static int relax(suhmo_level *L, int dep, int sweeps, int tail, suhmo_stream_t s
     return 0;
 }
 
+// Strips: halo rows of phi a depth wants valid right after the prolongation (= through its post-smoothing plus what
+// the next reader takes: UpdateOperator of the next cycle reads 2 rows at depth 0, the parent's prolongation reads
+// half of what the parent wants).  Purely an exchange-saving hint: the relax kernels advance that many halo rows
+// redundantly when they have them, and Depth::phi_fresh keeps every stencil honest whatever the halo depth.
+static int rows_after_prolong(int dep, int num_smooth)
+{
+    int tail_post = 2;
+    for (int d = 1; d <= dep; d++) tail_post = (2 * num_smooth + tail_post + 1) / 2;
+    return 2 * num_smooth + tail_post;
+}
+int suhmo_prolong_with_halo(suhmo_level *L, int depth, hipStream_t st);     // suhmo_level.hip
+
 static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, int nd, suhmo_stream_t s)
 {
     int rc;
-    if (dep == nd - 1) return relax(L, dep, sp->num_bottom, 0, s);                // bottom relaxes
+    const int S = sp->num_smooth;
+    const int tail_post = dep == 0 ? 2 : (rows_after_prolong(dep - 1, S) + 1) / 2;
+    if (dep == nd - 1) return relax(L, dep, sp->num_bottom, tail_post, s);        // bottom relaxes
     Depth &C = L->d[dep + 1];
-    if ((rc = relax(L, dep, sp->num_smooth, 1, s))) return rc;                    // pre-smooth (the restriction reads 1 halo row)
+    if ((rc = relax(L, dep, S, rows_after_prolong(dep, S), s))) return rc;        // pre-smooth (the restriction reads 1 halo row,
+                                                                                  //  the prolongation below the rest)
     if ((rc = suhmo_restrict_both(L, dep, (hipStream_t)s))) return rc;            // RES[dep+1] and PHI[dep+1] = R(phi)
-    HIPCHK(hipMemcpyAsync(C.fp.f[SUHMO_F_PHIOLD], C.fp.f[SUHMO_F_PHI], C.elems * sizeof(double),
+    if ((rc = suhmo_ensure_phi_halo(L, dep + 1, suhmo_halo_rows(C.v), (hipStream_t)s))) return rc;   // strips: before the copy, so that
+    HIPCHK(hipMemcpyAsync(C.fp.f[SUHMO_F_PHIOLD], C.fp.f[SUHMO_F_PHI], C.elems * sizeof(double),      // PHIOLD carries the halo rows too
                           hipMemcpyDeviceToDevice, (hipStream_t)s));
     if ((rc = suhmo_level_apply_op(L, dep + 1, 0, s))) return rc;                 // LPHI = L_c(R phi)
     if ((rc = suhmo_level_axby(L, dep + 1, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
     if ((rc = suhmo_level_exchange(L, dep + 1, SUHMO_F_RHS, s))) return rc;   // strips: rhs halo rows for the fused relax
     if ((rc = fas_cycle(L, dep + 1, sp, nd, s))) return rc;
-    if (suhmo_gsrb_can_fuse_prolong(L, dep, sp->num_smooth)) {
+    if (suhmo_gsrb_can_fuse_prolong(L, dep, S)) {
         L->d[dep].prolong_pending = 1;      // phi += P(phi_c - phi_c,old) happens inside the first post-smoothing pass
     } else {
-        if ((rc = suhmo_level_axby(L, dep + 1, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) return rc;
-        if ((rc = suhmo_level_prolong_increment(L, dep, s))) return rc;
+        if ((rc = suhmo_prolong_with_halo(L, dep, (hipStream_t)s))) return rc;    // corr = phi_c - phi_c,old; phi += P(corr), halo rows included
     }
-    return relax(L, dep, sp->num_smooth, dep == 0 ? 2 : 0, s);                    // post-smooth (depth 0: UpdateOperator of the next cycle reads 2)
+    return relax(L, dep, S, tail_post, s);                                        // post-smooth
 }
 
 extern "C" int suhmo_level_vcycle(suhmo_level_t *L, const suhmo_solver_params_t *sp, suhmo_stream_t s)

@@ -311,11 +311,23 @@ static int pick_K(const suhmo_level *L, const Depth &D, int variant, int remaini
     if (variant >= 1 && fused_ok(L, D, 1)) return 1;
     return 0;
 }
+// rank strips: halo rows that are valid on the fine depth AND (halved) on the coarse one stay valid when the
+// correction is added while loading
+static int prolong_halo_rows(const suhmo_level *L, int depth)
+{
+    const Depth &D = L->d[depth], &C = L->d[depth + 1];
+    int R = D.phi_fresh < 2 * C.phi_fresh ? D.phi_fresh : 2 * C.phi_fresh;
+    return R & ~1;
+}
 bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps)
 {
     Depth &D = L->d[depth];
-    if (sweeps < 1 || depth + 1 >= L->ndepth || D.v.ext[0] || D.v.ext[1]) return false;
-    return pick_K(L, D, pick_variant(L, D), sweeps) > 0;
+    if (sweeps < 1 || depth + 1 >= L->ndepth) return false;
+    int K = pick_K(L, D, pick_variant(L, D), sweeps);
+    if (K <= 0) return false;
+    const bool ext = L->ex && (D.v.ext[0] || D.v.ext[1]);
+    if ((D.v.ext[0] || D.v.ext[1]) && !ext) return false;                 // stored ghost rows without a transport (AMR patch)
+    return !ext || prolong_halo_rows(L, depth) >= 2 * K;                  // else: un-fused prolongation, then an exchange
 }
 
 int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream_t st)
@@ -328,6 +340,7 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
     // rows as the work still to come (rest of these sweeps + `tail` rows for the next reader) can use, so
     // one exchange of halo_rows rows feeds up to halo_rows colour passes.
     int F = ext ? D.phi_fresh : 0;
+    if (ext && D.prolong_pending) F = prolong_halo_rows(L, depth);   // the first launch adds the correction while loading
     int it = 0;
     while (it < sweeps) {
         int K = pick_K(L, D, variant, sweeps - it);   // sweeps done by the next launch (0 = simple path, 1 sweep)

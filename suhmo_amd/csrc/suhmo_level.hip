@@ -84,7 +84,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     HIPCHK(hipSetDevice(desc->device));
     suhmo_level *L = new suhmo_level();
     L->desc = *desc; L->ph = desc->phys; L->device = desc->device;
-    L->ex = nullptr; L->ar = nullptr; L->user = nullptr; L->prof_on = 0; L->gsrb_variant = -1; L->fused_hc = 0;
+    L->ex = nullptr; L->ar = nullptr; L->user = nullptr; L->ex_begin = nullptr; L->ex_end = nullptr; L->rccl = nullptr; L->prof_on = 0; L->gsrb_variant = -1; L->fused_hc = 0;
     if (const char *e = getenv("SUHMO_GSRB_VARIANT")) L->gsrb_variant = atoi(e);
     if (const char *e = getenv("SUHMO_FUSED_HC")) L->fused_hc = atoi(e);
     L->bcoef_fused = 1;
@@ -177,7 +177,7 @@ extern "C" int suhmo_level_synchronize(suhmo_level_t *L, suhmo_stream_t s)
 extern "C" int suhmo_level_set_hooks(suhmo_level_t *L, suhmo_exchange_fn ex, suhmo_allreduce_max_fn ar, void *user)
 {
     ARG(L);
-    L->ex = ex; L->ar = ar; L->user = user;
+    L->ex = ex; L->ar = ar; L->user = user; L->ex_begin = nullptr; L->ex_end = nullptr;
     return 0;
 }
 
@@ -588,6 +588,41 @@ extern "C" int suhmo_level_prolong_increment(suhmo_level_t *L, int depth, suhmo_
     phi_changed(L, depth);
     hipLaunchKernelGGL(k_prolong, grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp.f[SUHMO_F_PHI], C.v, C.fp.f[SUHMO_F_CORR]);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// FAS correction of the cycle: CORR_c = 1*phi_c + (-1)*phi_c,old (LevelDataOps::axby), phi += P(CORR_c) (PROLONGNL).
+// On rank strips both kernels also cover the halo rows that are valid on BOTH depths (fine: phi_fresh rows, coarse:
+// phi_fresh rows of phi_c; PHIOLD was copied after the exchange), so the post-smoothing can start without an exchange.
+__global__ void k_axby_rows(DV v, double *__restrict__ dst, const double *__restrict__ x, const double *__restrict__ y, double a, double b, int jlo, int jhi)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = jlo + (int)(blockIdx.y * blockDim.y + threadIdx.y);
+    if (i >= v.nx || j > jhi) return;
+    int idx = cidx(v, i, j);
+    dst[idx] = a * x[idx] + b * y[idx];
+}
+__global__ void k_prolong_rows(DV v, double *__restrict__ phi, DV vc, const double *__restrict__ c, int jlo, int jhi)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = jlo + (int)(blockIdx.y * blockDim.y + threadIdx.y);
+    if (i >= v.nx || j > jhi) return;
+    int idx = cidx(v, i, j);
+    phi[idx] = phi[idx] + c[cidx(vc, i / 2, j >> 1)];          // j >> 1: floor, halo rows have j < 0
+}
+int suhmo_prolong_with_halo(suhmo_level *L, int depth, hipStream_t st)
+{
+    Depth &D = L->d[depth], &C = L->d[depth + 1];
+    const bool ext = L->ex && (D.v.ext[0] || D.v.ext[1]);
+    int R = 0;                                              // fine halo rows that stay valid through the prolongation
+    if (ext) { R = D.phi_fresh < 2 * C.phi_fresh ? D.phi_fresh : 2 * C.phi_fresh; R &= ~1; }
+    const int Rc = R / 2;
+    const int jlo = D.v.ext[0] ? -R : 0, jhi = D.v.ny - 1 + (D.v.ext[1] ? R : 0);
+    const int cjlo = C.v.ext[0] ? -Rc : 0, cjhi = C.v.ny - 1 + (C.v.ext[1] ? Rc : 0);
+    double *corr = suhmo_field(L, depth + 1, SUHMO_F_CORR);
+    if (!corr) return -2;
+    hipLaunchKernelGGL(k_axby_rows, grid2d(C.v.nx, cjhi - cjlo + 1), BLK2D, 0, st, C.v, corr, C.fp.f[SUHMO_F_PHI], C.fp.f[SUHMO_F_PHIOLD], 1.0, -1.0, cjlo, cjhi);
+    hipLaunchKernelGGL(k_prolong_rows, grid2d(D.v.nx, jhi - jlo + 1), BLK2D, 0, st, D.v, D.fp.f[SUHMO_F_PHI], C.v, corr, jlo, jhi);
+    HIPCHK(hipGetLastError());
+    D.phi_fresh = R;
     return 0;
 }
 
@@ -1002,9 +1037,12 @@ int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st)
     dim3 gy((F.v.nx + 63) / 64, (F.v.ny / 2 + 1 + 3) / 4);
     hipLaunchKernelGGL(k_average_faces_y_all, gy, dim3(256), 0, st, F.v, F.fp.f[SUHMO_F_BY], o, nd);
     HIPCHK(hipGetLastError());
+    // strips: the coarse face coefficients of all depths travel as one message group when the transport can batch
+    if (L->ex_begin && L->ex) { int rc = L->ex_begin(L->user); if (rc) return rc; }
     for (int k = 1; k < nd; k++) {
         int rc = exchange_fields(L, k, {SUHMO_F_BX, SUHMO_F_BY}, st); if (rc) return rc;
     }
+    if (L->ex_end && L->ex) { int rc = L->ex_end(L->user, L, (suhmo_stream_t)st); if (rc) return rc; }
     return 0;
 }
 

@@ -11,6 +11,7 @@
 #include "suhmo_common.h"
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <vector>
 
 namespace {
 struct Fns {
@@ -27,6 +28,8 @@ struct Fns {
 } g;
 
 constexpr int MAXF = 8;           // fields per message
+struct PackList { double *p[MAXF]; int pack_lo[MAXF], pack_hi[MAXF], unpack_lo[MAXF], unpack_hi[MAXF]; int n; };
+struct Pending { int depth; PackList pl; size_t cnt; int rows; };
 struct Strip {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, lo = -1, hi = -1;
@@ -34,8 +37,9 @@ struct Strip {
     double *buf[SUHMO_MAXDEPTH][4] = {};   // send lo, send hi, recv lo, recv hi
     double *dscalar = nullptr;
     long exchanges = 0;
+    bool batching = false;        // between ex_begin and ex_end: packs run at once, the transfers of all queued messages
+    std::vector<Pending> queue;   // form ONE ncclGroup (one kernel), the unpacks follow
 };
-struct PackList { double *p[MAXF]; int pack_lo[MAXF], pack_hi[MAXF], unpack_lo[MAXF], unpack_hi[MAXF]; int n; };
 
 #define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { \
     suhmo_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #x, g.GetErrorString ? g.GetErrorString(r_) : "rccl error"); return -7; } } while (0)
@@ -58,6 +62,40 @@ __global__ void k_unpack_multi(DV v, PackList pl, int rows, const double *__rest
     if (i > v.nx || r >= rows || !b) return;
     int j = (side ? pl.unpack_hi[q] : pl.unpack_lo[q]) + r;
     pl.p[q][cidx(v, i, j)] = b[((size_t)q * rows + r) * (v.nx + 1) + i];
+}
+
+// send / receive every queued message in one group, then unpack them
+int flush(Strip *S, suhmo_level_t *L, hipStream_t st)
+{
+    if (S->queue.empty()) return 0;
+    NCCLCHK(g.GroupStart());
+    for (const Pending &q : S->queue) {
+        double **B = S->buf[q.depth];
+        if (S->hi >= 0) NCCLCHK(g.Send(B[1], q.cnt, ncclFloat64, S->hi, S->comm, st));
+        if (S->lo >= 0) NCCLCHK(g.Send(B[0], q.cnt, ncclFloat64, S->lo, S->comm, st));
+    }
+    for (const Pending &q : S->queue) {
+        double **B = S->buf[q.depth];
+        if (S->lo >= 0) NCCLCHK(g.Recv(B[2], q.cnt, ncclFloat64, S->lo, S->comm, st));
+        if (S->hi >= 0) NCCLCHK(g.Recv(B[3], q.cnt, ncclFloat64, S->hi, S->comm, st));
+    }
+    NCCLCHK(g.GroupEnd());
+    for (const Pending &q : S->queue) {
+        const DV &v = L->d[q.depth].v;
+        double **B = S->buf[q.depth];
+        dim3 blk(64, 4), grd((v.nx + 1 + 63) / 64, (q.rows + 3) / 4, 2 * q.pl.n);
+        hipLaunchKernelGGL(k_unpack_multi, grd, blk, 0, st, v, q.pl, q.rows, S->lo >= 0 ? B[2] : nullptr, S->hi >= 0 ? B[3] : nullptr);
+    }
+    HIPCHK(hipGetLastError());
+    S->queue.clear();
+    return 0;
+}
+int begin_hook(void *user) { ((Strip *)user)->batching = true; return 0; }
+int end_hook(void *user, suhmo_level_t *L, suhmo_stream_t s)
+{
+    Strip *S = (Strip *)user;
+    S->batching = false;
+    return flush(S, L, (hipStream_t)s);
 }
 
 int exchange_hook(void *user, suhmo_level_t *L, int depth, const int *fields, int nfields, suhmo_stream_t s)
@@ -87,6 +125,15 @@ int exchange_hook(void *user, suhmo_level_t *L, int depth, const int *fields, in
         hipLaunchKernelGGL(k_pack_multi, grd, blk, 0, st, v, pl, rows, S->lo >= 0 ? B[0] : nullptr, S->hi >= 0 ? B[1] : nullptr);
         HIPCHK(hipGetLastError());
         const size_t cnt = n * pl.n;
+        if (S->batching) {
+            // one message per depth in a batch (the staging buffers are per depth); anything else flushes first
+            bool clash = nfields > MAXF;
+            for (const Pending &q : S->queue) clash = clash || q.depth == depth;
+            if (!clash) { S->queue.push_back(Pending{depth, pl, cnt, rows}); S->exchanges++; continue; }
+            int rc = flush(S, L, st); if (rc) return rc;
+            hipLaunchKernelGGL(k_pack_multi, grd, blk, 0, st, v, pl, rows, S->lo >= 0 ? B[0] : nullptr, S->hi >= 0 ? B[1] : nullptr);   // buffers were reused
+            HIPCHK(hipGetLastError());
+        }
         // order matters when lo == hi (2 ranks, periodic; or a rank that is its own neighbour):
         // to-hi before to-lo, from-lo before from-hi
         NCCLCHK(g.GroupStart());
@@ -170,7 +217,7 @@ extern "C" int suhmo_level_detach_rccl(suhmo_level_t *L)
     for (int d = 0; d < SUHMO_MAXDEPTH; d++) for (int k = 0; k < 4; k++) if (S->buf[d][k]) (void)hipFree(S->buf[d][k]);
     if (S->dscalar) (void)hipFree(S->dscalar);
     if (S->comm && g.CommDestroy) (void)g.CommDestroy(S->comm);
-    if (L->user == S) { L->ex = nullptr; L->ar = nullptr; L->user = nullptr; }
+    if (L->user == S) { L->ex = nullptr; L->ar = nullptr; L->user = nullptr; L->ex_begin = nullptr; L->ex_end = nullptr; }
     delete S;
     L->rccl = nullptr;
     return 0;
@@ -201,7 +248,7 @@ extern "C" int suhmo_level_attach_rccl(suhmo_level_t *L, const void *id128, int 
             if (hipMalloc(&S->buf[d][k], cap) != hipSuccess) { suhmo_set_error("halo buffer allocation failed"); suhmo_level_detach_rccl(L); return -2; }
     }
     if (hipMalloc(&S->dscalar, sizeof(double)) != hipSuccess) { suhmo_level_detach_rccl(L); return -2; }
-    L->ex = exchange_hook; L->ar = allreduce_hook; L->user = S;
+    L->ex = exchange_hook; L->ar = allreduce_hook; L->user = S; L->ex_begin = begin_hook; L->ex_end = end_hook;
     return 0;
 }
 

@@ -24,7 +24,7 @@ def make_pair(nx, ny, f, ph, halo):
     return W, S
 
 
-@pytest.mark.parametrize("nx,ny,variant,halo", [(64, 32, "simple", 4), (2048, 1024, "fused", 4), (128, 64, "simple", 16), (2048, 1024, "fused", 16)])
+@pytest.mark.parametrize("nx,ny,variant,halo", [(64, 32, "simple", 4), (2048, 1024, "fused", 4), (128, 64, "simple", 16), (2048, 1024, "fused", 16), (256, 128, "simple", 24), (2048, 1024, "fused", 24)])
 def test_self_neighbour_vcycle_bitwise(nx, ny, variant, halo, monkeypatch):
     from suhmo_amd import capi
     from suhmo_amd.level import F_PHI, F_RES, F_BX, F_BY

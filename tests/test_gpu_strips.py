@@ -88,7 +88,7 @@ CASES = [
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 @pytest.mark.parametrize("variant", [0, 1, 2])
-@pytest.mark.parametrize("halo", [4, 9, 16])
+@pytest.mark.parametrize("halo", [4, 9, 16, 24])
 def test_strips_gsrb_and_operators(case, variant, halo, monkeypatch):
     from suhmo_amd import level as lv
     monkeypatch.setenv("SUHMO_GSRB_VARIANT", str(variant))
@@ -114,7 +114,7 @@ def test_strips_gsrb_and_operators(case, variant, halo, monkeypatch):
     assert all(p[4] == ref[4] for p in parts)       # MAX all-reduce of the norm
 
 
-@pytest.mark.parametrize("world,halo,fused", [(2, 4, 0), (4, 4, 0), (2, 16, 0), (4, 9, 0), (2, 16, 1), (4, 12, 1)])
+@pytest.mark.parametrize("world,halo,fused", [(2, 4, 0), (4, 4, 0), (2, 16, 0), (4, 9, 0), (2, 16, 1), (4, 12, 1), (2, 24, 0), (2, 24, 1), (4, 24, 1), (2, 1, 0)])
 def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
     from suhmo_amd import level as lv
     if fused:

@@ -21,7 +21,7 @@ n = int(os.environ.get("PROBE_N", "4096"))
 f = wrap_ghosts(sy.shmip_fields(n, n), sy.CONV_BC)
 W = level.HipLevel(n, n, f["dx"], f["dy"], sy.CONV_BC, sy.A3_PHYS, 0.0, -1.0, 64)
 W.set_inputs(f)
-S2 = level.HipLevel(n, n, f["dx"], f["dy"], sy.CONV_BC, sy.A3_PHYS, 0.0, -1.0, 64, j0=0, ny_global=2 * n, halo_rows=int(os.environ.get("SUHMO_HALO_ROWS", "16")))
+S2 = level.HipLevel(n, n, f["dx"], f["dy"], sy.CONV_BC, sy.A3_PHYS, 0.0, -1.0, 64, j0=0, ny_global=2 * n, halo_rows=int(os.environ.get("SUHMO_HALO_ROWS", "24")))
 S2.set_inputs(f)
 multigpu.attach_rccl(S2, 0, 1, periodic_y=True)
 sp = dict(sy.SOLVER_DEFAULT)
