@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--cells", dest="n", type=int, default=4096, help="cells per side of one rank strip")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--sweeps-only", type=int, default=0, help="also time this many bare GSRB sweeps")
+    ap.add_argument("--no-side", action="store_true", help="skip the side figures of the smaller BASELINE configurations")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,6 +133,12 @@ def main():
                               "event_ms_per_sweep": ms / max(nc / cells, 1),
                               "cell_updates_per_s": cells * args.sweeps_only / dt}
 
+    # the other configurations of BASELINE.json that fit this run, as side figures (not `value`): configs[1] =
+    # SHMIP A3 on 1024^2 single-level (cache-resident: 9 arrays x 8 MB, so it is not an HBM-roofline case),
+    # configs[2] = 2-level AMR (64 x 16 base + refined box), and the time step of SHMIP A3 (320 x 64)
+    if world == 1 and not args.no_side:
+        extra["other_configs"] = side_configs(sy, level, sp, args)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(sy, n if n <= 4096 else 4096, sp)
@@ -160,6 +167,59 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def side_configs(sy, level, sp, args):
+    out = {}
+    # configs[1]: SHMIP A3, 1024^2 single level
+    n = 1024
+    f = sy.shmip_fields(n, n)
+    G = level.HipLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64)
+    G.set_inputs(f); G.build_mg_coefficients()
+    for _ in range(3):
+        G.vcycle(sp)
+    G.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        G.vcycle(sp)
+    G.synchronize()
+    dt = (time.perf_counter() - t0) / 20
+    out["shmip_a3_1024x1024_single_level"] = {"vcycles_per_s": 1.0 / dt, "ms_per_vcycle": 1e3 * dt, "mg_depths": G.ndepth}
+    G.close()
+    # configs[2]: exec/0_convergence_channelized 2lev_base, base 64 x 16 + refined box (and the same shape x 16)
+    for tag, nx0, ny0, patch, kw in (("amr2_cfg3_64x16", 64, 16, sy.CFG3_PATCH, {}),
+                                     ("amr2_1024x256_base", 1024, 256, (256, 64, 767, 191), dict(lx=1024.0, ly=256.0))):
+        c, fi = sy.amr2_fields(nx0, ny0, patch, **kw)
+        bc = dict(type=[[0, 0], [1, 0]], value=[[0.0, 0.0], [0.0, 0.0]], periodic=[0, 1])
+        A = level.HipAmr2(nx0, ny0, c["dx"], c["dy"], bc, sy.CFG3_PHYS, patch, max_box=32)
+        A.coarse.set_inputs(c); A.coarse.build_mg_coefficients(); A.fine.set_inputs(fi)
+        for _ in range(2):
+            A.vcycle(sp)
+        A.coarse.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            A.vcycle(sp)
+        A.coarse.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        out[tag] = {"amr_vcycles_per_s": 1.0 / dt, "ms_per_vcycle": 1e3 * dt,
+                    "fine_cells": int(fi["nx"] * fi["ny"]), "base_cells": nx0 * ny0}
+        A.close()
+    # the caller of the solve: SHMIP A3 time steps (320 x 64, dt = 1 h), 200 steps
+    from suhmo_amd import model
+    m = sy.A3_MODEL
+    st = sy.shmip_initial_state(m["nx"], m["ny"], m["lx"], m["ly"])
+    M = model.HipModel(m["nx"], m["ny"], st["dx"], st["dy"], sy.A3_BC, sy.A3_PHYS, m, max_box=64)
+    M.set_state(st)
+    for _ in range(60):
+        M.timestep(m["dt"])
+    t0 = time.perf_counter()
+    nv = 0
+    for _ in range(200):
+        nv += M.timestep(m["dt"])[1]
+    dt = (time.perf_counter() - t0) / 200
+    out["shmip_a3_320x64_timestep"] = {"steps_per_s": 1.0 / dt, "ms_per_step": 1e3 * dt, "vcycles_per_step": nv / 200.0}
+    M.close()
+    return out
 
 
 def host_cores():

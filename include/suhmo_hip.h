@@ -86,6 +86,7 @@ enum {
     SUHMO_F_MR, SUHMO_F_PW, SUHMO_F_QWX, SUHMO_F_QWY, SUHMO_F_HLAG, SUHMO_F_CD,
     SUHMO_F_RHS0,        /* AMR: the base level's own rhs while it carries the FAS rhs */
     SUHMO_F_MSRC,        /* moulin source term, m/s (suhmo_level_moulin_source) */
+    SUHMO_F_DCX, SUHMO_F_DCY, SUHMO_F_DTERM,   /* diffusion coefficient of the gap height on x / y faces, div(D grad b) */
     SUHMO_F_COUNT
 };
 
@@ -187,12 +188,13 @@ typedef struct suhmo_model_params {
     double G, L, ct, cw;               /* suhmo.GeoFlux, LatHeat, ct, cw */
     double ub0, ub1;                   /* suhmo.SlidingVelocity */
     double br, lr;                     /* suhmo.br, suhmo.lr */
-    double diffFactor;                 /* suhmo.diffFactor (must be 0 in this build) */
+    double diffFactor;                 /* suhmo.diffFactor: weight of div(D grad b) in both equations (:3071, :2145) */
     double distributed_input;          /* suhmo.distributed_input */
     double eps_picard;                 /* solver.eps_PicardIte */
     int basal_friction, use_mask_rhs_b;
     int use_moulin_source;             /* suhmo.n_moulins > 0: RHS_h += MSRC * ramp + distributed_input (:3060-3066) */
     double ramp;                       /* suhmo.ramp factor of this step (:2448-2467); 1 when off */
+    int use_impl_diff;                 /* solver.use_ImplDiff: gap height by the implicit VC Helmholtz solve (:593-662) */
 } suhmo_model_params_t;
 /* cur_step = AmrHydro::m_cur_step after its increment (1 for the first step): selects the solver
  * parameters and the Picard stopping rule.  picard_iters / vcycles: totals of this step. */

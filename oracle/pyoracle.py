@@ -33,7 +33,7 @@ class OrModelParams(C.Structure):
                 ("br", C.c_double), ("lr", C.c_double), ("diffFactor", C.c_double),
                 ("distributed_input", C.c_double), ("eps_picard", C.c_double),
                 ("basal_friction", C.c_int), ("use_mask_rhs_b", C.c_int), ("use_moulin_source", C.c_int),
-                ("ramp", C.c_double)]
+                ("ramp", C.c_double), ("use_impl_diff", C.c_int)]
 
 
 class OrSolverParams(C.Structure):
@@ -91,6 +91,7 @@ def lib():
         L.or_model_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(OrBC),
                                       C.POINTER(OrPhys), C.POINTER(OrModelParams)]
         L.or_model_destroy.argtypes = [C.c_void_p]
+        L.or_model_gap_solver_layout.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.or_model_field.restype = dp
         L.or_model_field.argtypes = [C.c_void_p, C.c_int]
         L.or_model_timestep.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -275,7 +276,7 @@ def make_model_params(m):
     return OrModelParams(m["rho_i"], m["rho_w"], m["gravity"], m["G"], m["L"], m["ct"], m["cw"], m["ub"][0], m["ub"][1],
                          m["br"], m["lr"], m["diffFactor"], m["distributed_input"], m["eps_picard"],
                          int(m["basal_friction"]), int(m.get("use_mask_rhs_b", 0)), int(m.get("use_moulin_source", 0)),
-                         float(m.get("ramp", 1.0)))
+                         float(m.get("ramp", 1.0)), int(m.get("use_impl_diff", 0)))
 
 
 class OracleModel:
@@ -287,6 +288,7 @@ class OracleModel:
         self._mp = make_model_params(model)
         self.h = lib().or_model_create(self.level.h, nx, ny, dx, dy, C.byref(self.level._bc), C.byref(self.level._ph),
                                        C.byref(self._mp))
+        lib().or_model_gap_solver_layout(self.h, max_box, nthreads)
 
     def field(self, fid):
         """numpy VIEW of a model array (ghosted cells (ny+2, nx+2); QWX (ny, nx+1); QWY (ny+1, nx))"""

@@ -32,6 +32,7 @@ typedef struct OrModelParams {
     int use_mask_rhs_b;
     int use_moulin_source;              /* suhmo.n_moulins > 0: RHS_h += msrc * ramp + distributed_input (:3060-3066) */
     double ramp;                        /* suhmo.ramp (:2448-2467), 1 when off */
+    int use_impl_diff;                  /* solver.use_ImplDiff: gap height by the implicit VC Helmholtz solve (:593-662, :3376-3455) */
 } OrModelParams;
 
 enum { OM_H = 0, OM_B, OM_BOLD, OM_PI, OM_ZB, OM_MASK, OM_MR, OM_PW, OM_SRC, OM_RHSH, OM_CD,
@@ -49,6 +50,10 @@ typedef struct OrModel {
     double *bxf, *byf, *rxf, *ryf;      /* B_ec, Re_ec */
     double *qx, *qy;                    /* Qw_ec */
     double *t1x, *t1y, *t2x, *t2y;      /* Qw*gradH, Qw*gradZb on faces */
+    double *mrxf, *mryf, *dxf, *dyf;    /* mR_ec, Dcoef (suhmo.diffFactor != 0) */
+    double *dterm;                      /* div(D grad b), valid cells */
+    OrLevel *G;                         /* implicit gap-height operator (alpha = 1, beta = dt * diffFactor, no NL) */
+    double G_dt; int G_max_box, G_nthreads;
     int cur_step;
     double time;
 } OrModel;
@@ -65,9 +70,11 @@ OrModel *or_model_create(OrLevel *L, int nx, int ny, double dx, double dy, const
     M->L = L; M->nx = nx; M->ny = ny; M->dx = dx; M->dy = dy; M->bc = *bc; M->ph = *ph; M->mp = *mp;
     size_t nc = (size_t)(nx + 2) * (ny + 2), nfx = (size_t)(nx + 1) * ny, nfy = (size_t)nx * (ny + 1);
     for (int f = 0; f < OM_NCELL; f++) M->c[f] = (double *)calloc(nc, sizeof(double));
-    double **fxs[] = {&M->gxf, &M->zxf, &M->bxf, &M->rxf, &M->qx, &M->t1x, &M->t2x};
-    double **fys[] = {&M->gyf, &M->zyf, &M->byf, &M->ryf, &M->qy, &M->t1y, &M->t2y};
-    for (int k = 0; k < 7; k++) { *fxs[k] = (double *)calloc(nfx, sizeof(double)); *fys[k] = (double *)calloc(nfy, sizeof(double)); }
+    double **fxs[] = {&M->gxf, &M->zxf, &M->bxf, &M->rxf, &M->qx, &M->t1x, &M->t2x, &M->mrxf, &M->dxf};
+    double **fys[] = {&M->gyf, &M->zyf, &M->byf, &M->ryf, &M->qy, &M->t1y, &M->t2y, &M->mryf, &M->dyf};
+    for (int k = 0; k < 9; k++) { *fxs[k] = (double *)calloc(nfx, sizeof(double)); *fys[k] = (double *)calloc(nfy, sizeof(double)); }
+    M->dterm = (double *)calloc((size_t)nx * ny, sizeof(double));
+    M->G_max_box = 64; M->G_nthreads = 1;
     return M;
 }
 void or_model_destroy(OrModel *M)
@@ -76,6 +83,8 @@ void or_model_destroy(OrModel *M)
     for (int f = 0; f < OM_NCELL; f++) free(M->c[f]);
     free(M->gxf); free(M->gyf); free(M->zxf); free(M->zyf); free(M->bxf); free(M->byf); free(M->rxf); free(M->ryf);
     free(M->qx); free(M->qy); free(M->t1x); free(M->t1y); free(M->t2x); free(M->t2y);
+    free(M->mrxf); free(M->mryf); free(M->dxf); free(M->dyf); free(M->dterm);
+    if (M->G) or_level_destroy(M->G);
     free(M);
 }
 double *or_model_field(OrModel *M, int id)
@@ -85,6 +94,7 @@ double *or_model_field(OrModel *M, int id)
     return (id >= 0 && id < OM_NCELL) ? M->c[id] : NULL;
 }
 int or_model_step_index(const OrModel *M) { return M->cur_step; }
+void or_model_gap_solver_layout(OrModel *M, int max_box, int nthreads) { M->G_max_box = max_box; M->G_nthreads = nthreads; }
 
 /* exchange (periodic wrap) of a ghosted global array */
 static void wrap_ghosts(OrModel *M, double *a)
@@ -160,12 +170,23 @@ static void grad_re_qw(OrModel *M)
 {
     double *h = M->c[OM_H], *B = M->c[OM_B], *gx = M->c[OM_GRADX], *gy = M->c[OM_GRADY], *Re = M->c[OM_RE];
     mac_grad(M, h, M->gxf, M->gyf);
+    /* diagnosis knob (DESIGN.md "end-to-end pin"): the face gradient on Dirichlet domain faces as the reference's
+     * committed tables imply it (zero); 1 = before the cell-centred gradient is formed, 2 = after.  Unset = the source. */
+    const char *zk = getenv("SUHMO_ORACLE_ZERO_DIRICHLET_FACE_GRAD");
+    int zmode = zk ? atoi(zk) : 0;
+#define ZERO_DIRICHLET_FACES() do { \
+        if (!M->bc.periodic[0]) { if (M->bc.type[0][0] == 0) for (int j = 0; j < M->ny; j++) FX(M->gxf, 0, j) = 0.0; \
+                                  if (M->bc.type[0][1] == 0) for (int j = 0; j < M->ny; j++) FX(M->gxf, M->nx, j) = 0.0; } \
+        if (!M->bc.periodic[1]) { if (M->bc.type[1][0] == 0) for (int i = 0; i < M->nx; i++) FY(M->gyf, i, 0) = 0.0; \
+                                  if (M->bc.type[1][1] == 0) for (int i = 0; i < M->nx; i++) FY(M->gyf, i, M->ny) = 0.0; } } while (0)
+    if (zmode == 1) ZERO_DIRICHLET_FACES();
     for (int j = 0; j < M->ny; j++)
         for (int i = 0; i < M->nx; i++) {              /* EdgeToCell */
             CC(gx, i, j) = 0.5 * (FX(M->gxf, i, j) + FX(M->gxf, i + 1, j));
             CC(gy, i, j) = 0.5 * (FY(M->gyf, i, j) + FY(M->gyf, i, j + 1));
         }
     extrap_ghosts(M, gx); extrap_ghosts(M, gy);
+    if (zmode == 2) ZERO_DIRICHLET_FACES();
     for (int j = -1; j <= M->ny; j++)
         for (int i = -1; i <= M->nx; i++) {            /* COMPUTERE on the ghosted box, AmrHydroF.ChF:92-109 */
             double s = sqrt(CC(gx, i, j) * CC(gx, i, j) + CC(gy, i, j) * CC(gy, i, j));
@@ -216,6 +237,73 @@ static void melting_rate(OrModel *M)
         }
 }
 
+/* dCoeff (src/AmrHydro.cpp:1831-1862, COMPUTEDCOEFF src/AmrHydroF.ChF:241-265) from mR_ec and B_ec; the EC ice mask as
+ * setup_iceMask_EC (src/HydroIBC.cpp:139-184); then DiffusiveTerm = COMPUTEDIFTERM2D(b, D) (:2982-2992, ...F.ChF:289-343) */
+static void diffusion_coefficients(OrModel *M)
+{
+    const double *IM = M->c[OM_MASK], *B = M->c[OM_B];
+    double *mR = M->c[OM_MR];
+    int nx = M->nx, ny = M->ny;
+    extrap_ghosts(M, mR);                                   /* levelmR.exchange(); ExtrapGhostCells(levelmR) :2513,:2526 */
+    cell_to_edge(M, mR, M->mrxf, M->mryf);                  /* :2530 */
+    for (int dir = 0; dir < 2; dir++) {
+        int ii = dir == 0, jj = dir == 1, face_hi = dir == 0 ? nx : ny;
+        for (int j = 0; j < ny + jj; j++)
+            for (int i = 0; i < nx + ii; i++) {
+                double m = CC(IM, i, j), mm1 = CC(IM, i - ii, j - jj), mec;
+                if (fabs(m - mm1) < 1e-10) mec = (m > 0.0) ? 1.0 : -1.0; else mec = 0.0;
+                int idx = dir == 0 ? i : j;
+                if (idx == 0 || idx == face_hi) mec = 0.0;
+                double bec = dir == 0 ? FX(M->bxf, i, j) : FY(M->byf, i, j), mrec = dir == 0 ? FX(M->mrxf, i, j) : FY(M->mryf, i, j), d;
+                if (mec < 0.0 && M->ph.cutOffB > 0) d = 0.0; else d = fmax(bec * mrec / M->mp.rho_i, 5.0e-6);
+                if (dir == 0) FX(M->dxf, i, j) = d; else FY(M->dyf, i, j) = d;
+            }
+    }
+    double dxinv0 = 1.0 / (M->dx * M->dx), dxinv1 = 1.0 / (M->dy * M->dy);
+    for (int j = 0; j < ny; j++)
+        for (int i = 0; i < nx; i++)
+            M->dterm[(size_t)j * nx + i] =
+                (FX(M->dxf, i + 1, j) * (CC(B, i + 1, j) - CC(B, i, j)) * dxinv0 - FX(M->dxf, i, j) * (CC(B, i, j) - CC(B, i - 1, j)) * dxinv0
+                 + FY(M->dyf, i, j + 1) * (CC(B, i, j + 1) - CC(B, i, j)) * dxinv1 - FY(M->dyf, i, j) * (CC(B, i, j) - CC(B, i, j - 1)) * dxinv1);
+}
+
+/* SolveForGap_nl (src/AmrHydro.cpp:593-662): (aCoef - dt diffFactor div(D grad)) b = rhs, aCoef = 1, bCoef = D, FixedNeumBCFill
+ * (copy) on the domain sides; AMRMultiGrid V-cycles with 2 + 2 smoothings, 4 at the bottom, eps = normThresh = 1e-7,
+ * hang 1e-6, iterMin 2, imin 10 while step < 50.  [Chombo] VCAMRPoissonOp2 is not in the reference's tree: the operator
+ * here is the linear part of VCAMRNonLinearPoissonOp (alpha a phi - beta div(b grad phi)), the cycle the FAS cycle of
+ * level_shim.c, which for a linear operator converges to the same solution. */
+static void solve_gap_implicit(OrModel *M, double dt, const double *rhs_valid)
+{
+    int nx = M->nx, ny = M->ny;
+    if (!M->G || M->G_dt != dt) {
+        if (M->G) or_level_destroy(M->G);
+        OrBC nb = M->bc;
+        for (int d = 0; d < 2; d++) for (int s = 0; s < 2; s++) { nb.type[d][s] = 1; nb.value[d][s] = 0.0; }
+        OrPhys lp = M->ph; lp.use_NL = 0;
+        M->G = or_level_create(nx, ny, M->dx, M->dy, M->G_max_box, &nb, &lp, 1.0, dt * M->mp.diffFactor, M->G_nthreads);
+        M->G_dt = dt;
+        double *one = (double *)malloc(sizeof(double) * (size_t)nx * ny);
+        for (size_t k = 0; k < (size_t)nx * ny; k++) one[k] = 1.0;
+        or_level_set(M->G, 0, OR_F_ACOEF, one, 0);                               /* aCoeff_GH :1820-1828 */
+        free(one);
+        or_level_set(M->G, 0, OR_F_MASK, M->c[OM_MASK], 1);
+    }
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)nx * ny);
+    for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) tmp[(size_t)j * nx + i] = CC(M->c[OM_B], i, j);
+    or_level_set(M->G, 0, OR_F_PHI, tmp, 0);                                     /* a_gh_curr = b (initial guess) :3382-3385 */
+    or_level_set(M->G, 0, OR_F_RHS, rhs_valid, 0);
+    or_level_set(M->G, 0, OR_F_BX, M->dxf, 0);
+    or_level_set(M->G, 0, OR_F_BY, M->dyf, 0);
+    or_level_build_mg_coefficients(M->G);                                        /* coarse D = average of the fine faces */
+    OrSolverParams sp;
+    sp.num_smooth = 2; sp.num_bottom = 4; sp.max_iter = 100; sp.iter_min = 2; sp.imin = M->cur_step < 50 ? 10 : 5;
+    sp.eps = 1.0e-7; sp.hang = 1.0e-6; sp.norm_thresh = 1.0e-7; sp.bcoeff_otf = 0; sp.max_depth = -1;
+    (void)or_level_solve(M->G, &sp, NULL);
+    or_level_get(M->G, 0, OR_F_PHI, tmp, 0);
+    for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) CC(M->c[OM_B], i, j) = tmp[(size_t)j * nx + i];
+    free(tmp);
+}
+
 static double max_valid(OrModel *M, const double *a)
 {
     double m = -1e300;
@@ -251,6 +339,7 @@ int or_model_timestep(OrModel *M, double dt, int *picard_iters, int *vcycles_tot
             if (p->use_moulin_source) CC(src, i, j) = CC(M->c[OM_MSRC], i, j) * p->ramp + p->distributed_input;   /* :3065 */
             else CC(src, i, j) = (CC(IM, i, j) > 0.0) ? p->distributed_input : 0.0;
         }
+        if (p->diffFactor != 0.0) diffusion_coefficients(M);                  /* lagged mR (before this iteration's melt rate) :2548-2551 */
         melting_rate(M);
         double rho_coef = (1.0 / p->rho_w - 1.0 / p->rho_i);                 /* :3023 */
         {   /* diagnosis knob (tools/run_shmip_a.py --head-melt-coef, DESIGN.md "end-to-end pin"): scales the melt
@@ -264,6 +353,7 @@ int or_model_timestep(OrModel *M, double dt, int *picard_iters, int *vcycles_tot
                 double r = CC(mR, i, j) * rho_coef;
                 if (CC(B, i, j) < p->br) r -= ub_norm * (p->br - CC(B, i, j)) / p->lr;
                 r += CC(src, i, j);
+                if (p->diffFactor != 0.0) r -= p->diffFactor * M->dterm[(size_t)j * nx + i];   /* :3071 */
                 if (CC(IM, i, j) < 0.0) r = 0.0;
                 CC(rhs, i, j) = r;
             }
@@ -294,21 +384,26 @@ int or_model_timestep(OrModel *M, double dt, int *picard_iters, int *vcycles_tot
     melting_rate(M);
     {
         double ub_norm = sqrt(p->ub0 * p->ub0 + p->ub1 * p->ub1);
+        double *rhs_b = p->use_impl_diff ? (double *)malloc(sizeof(double) * (size_t)nx * ny) : NULL;
         for (int j = 0; j < ny; j++)
             for (int i = 0; i < nx; i++) {            /* CalcRHS_gapHeightFAS :2069-2171 */
                 double b = CC(B, i, j);
                 double RHS = CC(mR, i, j) * (1.0 / p->rho_i), RHS_A = RHS, RHS_B = 0.0;
-                if ((CC(IM, i, j) < 0.0) && p->use_mask_rhs_b) { RHS = 0.0; CC(CD, i, j) = 0.0; }
+                if ((CC(IM, i, j) < 0.0) && p->use_mask_rhs_b) { RHS = 0.0; CC(CD, i, j) = 0.0; if (p->use_impl_diff) RHS = b; }
                 else {
                     if (b < p->br) { RHS += ub_norm * (p->br - b) / p->lr; RHS_B = ub_norm * (p->br - b) / p->lr; }
                     double PimPw = CC(Pi, i, j) - CC(Pw, i, j), AbsPimPw = fabs(PimPw);
                     if (M->ph.cutOffbr > b) RHS -= M->ph.A * (AbsPimPw * AbsPimPw) * PimPw * b * (1.0 - (M->ph.cutOffbr - b) / M->ph.cutOffbr);
                     else if (M->ph.maxOffbr < b) RHS -= M->ph.A * (AbsPimPw * AbsPimPw) * PimPw * b * (1.0 - (M->ph.maxOffbr - b) / M->ph.maxOffbr);
                     else RHS -= M->ph.A * (AbsPimPw * AbsPimPw) * PimPw * b;
+                    if (!p->use_impl_diff && p->diffFactor != 0.0) RHS += p->diffFactor * M->dterm[(size_t)j * nx + i];   /* :2145,:2152,:2159 */
                     CC(CD, i, j) = RHS_A / (RHS_A + RHS_B);
+                    if (p->use_impl_diff) RHS = b + dt * RHS;                                                          /* :2165 */
                 }
-                CC(B, i, j) = RHS * dt + CC(Bold, i, j);     /* forward Euler :3406 */
+                if (p->use_impl_diff) rhs_b[(size_t)j * nx + i] = RHS;
+                else CC(B, i, j) = RHS * dt + CC(Bold, i, j);     /* forward Euler :3406 */
             }
+        if (p->use_impl_diff) { solve_gap_implicit(M, dt, rhs_b); free(rhs_b); }                                   /* :3425-3439 */
     }
     copy_ghosts(M, B);                                /* :3419-3420 */
     M->time += dt;

@@ -142,6 +142,7 @@ struct suhmo_level {
     void *user;
     int (*ex_begin)(void *user);                       // optional: open / close a batch of exchanges that
     int (*ex_end)(void *user, suhmo_level *L, suhmo_stream_t s);   // travel as ONE message group (native transport)
+    suhmo_level *gap; double gap_dt;   // implicit gap-height operator of the time step (suhmo_step.hip), owned
     void *rccl;                 // native transport state (suhmo_rccl.hip), owned by the level
     int prof_on;
     std::vector<ProfEv> prof;

@@ -84,7 +84,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     HIPCHK(hipSetDevice(desc->device));
     suhmo_level *L = new suhmo_level();
     L->desc = *desc; L->ph = desc->phys; L->device = desc->device;
-    L->ex = nullptr; L->ar = nullptr; L->user = nullptr; L->ex_begin = nullptr; L->ex_end = nullptr; L->rccl = nullptr; L->prof_on = 0; L->gsrb_variant = -1; L->fused_hc = 0;
+    L->ex = nullptr; L->ar = nullptr; L->user = nullptr; L->ex_begin = nullptr; L->ex_end = nullptr; L->rccl = nullptr; L->gap = nullptr; L->gap_dt = 0.0; L->prof_on = 0; L->gsrb_variant = -1; L->fused_hc = 0;
     if (const char *e = getenv("SUHMO_GSRB_VARIANT")) L->gsrb_variant = atoi(e);
     if (const char *e = getenv("SUHMO_FUSED_HC")) L->fused_hc = atoi(e);
     L->bcoef_fused = 1;
@@ -155,6 +155,7 @@ extern "C" int suhmo_level_destroy(suhmo_level_t *L)
     (void)hipSetDevice(L->device);
     (void)hipDeviceSynchronize();
     if (L->rccl) (void)suhmo_level_detach_rccl(L);
+    if (L->gap) { (void)suhmo_level_destroy(L->gap); L->gap = nullptr; }
     for (int dep = 0; dep < L->ndepth; dep++)
         for (int f = 0; f < SUHMO_F_COUNT; f++)
             if (L->d[dep].fp.f[f]) (void)hipFree(L->d[dep].fp.f[f]);
@@ -207,7 +208,9 @@ extern "C" int suhmo_level_halo_info(const suhmo_level_t *L, int depth, int *hal
 
 // ------------------------------------------------------------------ LevelData traffic
 static inline void phi_changed(suhmo_level *L, int depth) { L->d[depth].phi_fresh = 0; }   // see suhmo_ensure_phi_halo
-static bool is_face(int f) { return f == SUHMO_F_BX || f == SUHMO_F_BY || f == SUHMO_F_QWX || f == SUHMO_F_QWY; }
+static bool is_xface(int f) { return f == SUHMO_F_BX || f == SUHMO_F_QWX || f == SUHMO_F_DCX; }
+static bool is_yface(int f) { return f == SUHMO_F_BY || f == SUHMO_F_QWY || f == SUHMO_F_DCY; }
+static bool is_face(int f) { return is_xface(f) || is_yface(f); }
 #define CHECK_DF(L, depth, field) ARG(L); ARG(depth >= 0 && depth < L->ndepth); ARG(field >= 0 && field < SUHMO_F_COUNT)
 
 extern "C" int suhmo_level_field_view(suhmo_level_t *L, int depth, int field, double **base, long *pitch, long *origin)
@@ -242,8 +245,8 @@ static int field_io(suhmo_level *L, int depth, int field, double *buf, int ghost
 {
     const DV &v = L->d[depth].v;
     int rc;
-    if (field == SUHMO_F_BX || field == SUHMO_F_QWX) rc = copy2d(L, depth, field, buf, v.nx + 1, 0, 0, v.nx + 1, v.ny, set, on_device, st);
-    else if (field == SUHMO_F_BY || field == SUHMO_F_QWY) rc = copy2d(L, depth, field, buf, v.nx, 0, 0, v.nx, v.ny + 1, set, on_device, st);
+    if (is_xface(field)) rc = copy2d(L, depth, field, buf, v.nx + 1, 0, 0, v.nx + 1, v.ny, set, on_device, st);
+    else if (is_yface(field)) rc = copy2d(L, depth, field, buf, v.nx, 0, 0, v.nx, v.ny + 1, set, on_device, st);
     else if (ghosted) rc = copy2d(L, depth, field, buf, v.nx + 2, -1, -1, v.nx + 2, v.ny + 2, set, on_device, st);
     else rc = copy2d(L, depth, field, buf, v.nx, 0, 0, v.nx, v.ny, set, on_device, st);
     if (rc) return rc;
@@ -274,8 +277,8 @@ static void box_region(const suhmo_level *L, int depth, int field, int ibox, int
     int c = 1 << depth;
     r[0] = b[0] / c - L->d[depth].v.i0; r[1] = b[1] / c - L->d[depth].v.j0;
     r[2] = (b[2] + 1) / c - 1 - L->d[depth].v.i0; r[3] = (b[3] + 1) / c - 1 - L->d[depth].v.j0;
-    if (field == SUHMO_F_BX || field == SUHMO_F_QWX) r[2] += 1;
-    if (field == SUHMO_F_BY || field == SUHMO_F_QWY) r[3] += 1;
+    if (is_xface(field)) r[2] += 1;
+    if (is_yface(field)) r[3] += 1;
 }
 
 extern "C" int suhmo_level_put_box(suhmo_level_t *L, int depth, int field, int ibox, const double *fab,

@@ -102,21 +102,25 @@ __global__ __launch_bounds__(256) void k_melt(DV v, FP fp, suhmo_phys_t ph, suhm
         if (b < mp.br) r -= ub_norm * (mp.br - b) / mp.lr;
         if (mp.use_moulin_source) r += fp.f[SUHMO_F_MSRC][idx] * mp.ramp + mp.distributed_input;   // :3060-3066
         else r += (im > 0.0) ? mp.distributed_input : 0.0;     // distributed input where there is ice, :2871-2875
+        if (mp.diffFactor != 0.0) r -= mp.diffFactor * fp.f[SUHMO_F_DTERM][idx];     // :3071
         if (im < 0.0) r = 0.0;
         fp.f[SUHMO_F_RHS][idx] = r;
     } else {                                                   // CalcRHS_gapHeightFAS :2113-2168 + forward Euler :3406
         double RHS = m * (1.0 / mp.rho_i), RHS_A = RHS, RHS_B = 0.0, cd = 0.0;
-        if ((im < 0.0) && mp.use_mask_rhs_b) { RHS = 0.0; }
+        if ((im < 0.0) && mp.use_mask_rhs_b) { RHS = 0.0; if (mp.use_impl_diff) RHS = b; }
         else {
             if (b < mp.br) { RHS += ub_norm * (mp.br - b) / mp.lr; RHS_B = ub_norm * (mp.br - b) / mp.lr; }
             double PimPw = Pi - Pw, AbsPimPw = fabs(PimPw);
             if (ph.cutOffbr > b) RHS -= ph.A * (AbsPimPw * AbsPimPw) * PimPw * b * (1.0 - (ph.cutOffbr - b) / ph.cutOffbr);
             else if (ph.maxOffbr < b) RHS -= ph.A * (AbsPimPw * AbsPimPw) * PimPw * b * (1.0 - (ph.maxOffbr - b) / ph.maxOffbr);
             else RHS -= ph.A * (AbsPimPw * AbsPimPw) * PimPw * b;
+            if (!mp.use_impl_diff && mp.diffFactor != 0.0) RHS += mp.diffFactor * fp.f[SUHMO_F_DTERM][idx];   // :2145,:2152,:2159
             cd = RHS_A / (RHS_A + RHS_B);
+            if (mp.use_impl_diff) RHS = b + dt * RHS;          // :2165
         }
         fp.f[SUHMO_F_CD][idx] = cd;
-        fp.f[SUHMO_F_B][idx] = RHS * dt + b;                   // old b == b: the gap height is untouched during [II]
+        if (mp.use_impl_diff) fp.f[SUHMO_F_RES][idx] = RHS;    // right-hand side of the implicit solve (RES is free here)
+        else fp.f[SUHMO_F_B][idx] = RHS * dt + b;              // old b == b: the gap height is untouched during [II]
     }
 }
 
@@ -175,11 +179,105 @@ static int lagged_chain(suhmo_level *L, hipStream_t st)
     return 0;
 }
 
+// ---- diffusion of the gap height (suhmo.diffFactor != 0)
+// ghosts of the melt rate: exchange + ExtrapGhostCells (:2513,:2526); only the edges are read (CellToEdge)
+__global__ void k_extrap_ghosts(DV v, double *__restrict__ g)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 2 * v.ny) {
+        int side = t / v.ny, j = t % v.ny;
+        if (side == 0) { int idx = cidx(v, 0, j); g[idx - 1] = v.per[0] ? g[idx + v.nx - 1] : 2.0 * g[idx] - g[idx + 1]; }
+        else { int idx = cidx(v, v.nx - 1, j); g[idx + 1] = v.per[0] ? g[idx - (v.nx - 1)] : 2.0 * g[idx] - g[idx - 1]; }
+        return;
+    }
+    t -= 2 * v.ny;
+    if (t < 2 * v.nx) {
+        int side = t / v.nx, i = t % v.nx;
+        if (side == 0) { int idx = cidx(v, i, 0); g[idx - v.P] = v.per[1] ? g[idx + (v.ny - 1) * v.P] : 2.0 * g[idx] - g[idx + v.P]; }
+        else { int idx = cidx(v, i, v.ny - 1); g[idx + v.P] = v.per[1] ? g[idx - (v.ny - 1) * v.P] : 2.0 * g[idx] - g[idx - v.P]; }
+    }
+}
+// dCoeff: CellToEdge(mR), CellToEdge(b), setup_iceMask_EC, COMPUTEDCOEFF (src/AmrHydro.cpp:1831-1862, ...F.ChF:241-265)
+__global__ __launch_bounds__(256) void k_dcoef_faces(DV v, FP fp, suhmo_phys_t ph, double rho_i)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > v.nx || j > v.ny) return;
+    const double *__restrict__ B = fp.f[SUHMO_F_B], *__restrict__ mR = fp.f[SUHMO_F_MR], *__restrict__ mk = fp.f[SUHMO_F_MASK];
+    int idx = cidx(v, i, j);
+    for (int dir = 0; dir < 2; dir++) {
+        if ((dir == 0 && j >= v.ny) || (dir == 1 && i >= v.nx)) continue;
+        int im = dir == 0 ? idx - 1 : idx - v.P;
+        double m = mk[idx], mm1 = mk[im], mec;
+        if (fabs(m - mm1) < 1e-10) mec = (m > 0.0) ? 1.0 : -1.0; else mec = 0.0;
+        int f = dir == 0 ? i : j, fhi = dir == 0 ? v.nx : v.ny;
+        if (f == 0 || f == fhi) mec = 0.0;
+        double bec = 0.5 * (B[idx] + B[im]), mrec = 0.5 * (mR[idx] + mR[im]), d;
+        if (mec < 0.0 && ph.cutOffB > 0) d = 0.0; else d = fmax(bec * mrec / rho_i, 5.0e-6);
+        fp.f[dir == 0 ? SUHMO_F_DCX : SUHMO_F_DCY][idx] = d;
+    }
+}
+// COMPUTEDIFTERM2D (src/AmrHydroF.ChF:289-343) of the gap height with its copied ghosts
+__global__ __launch_bounds__(256) void k_difterm(DV v, FP fp)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || j >= v.ny) return;
+    const double *__restrict__ B = fp.f[SUHMO_F_B], *__restrict__ dx_ = fp.f[SUHMO_F_DCX], *__restrict__ dy_ = fp.f[SUHMO_F_DCY];
+    int idx = cidx(v, i, j);
+    const double dxinv0 = 1.0 / (v.dx * v.dx), dxinv1 = 1.0 / (v.dy * v.dy);
+    fp.f[SUHMO_F_DTERM][idx] =
+        (dx_[idx + 1] * (B[idx + 1] - B[idx]) * dxinv0 - dx_[idx] * (B[idx] - B[idx - 1]) * dxinv0
+         + dy_[idx + v.P] * (B[idx + v.P] - B[idx]) * dxinv1 - dy_[idx] * (B[idx] - B[idx - v.P]) * dxinv1);
+}
+static int diffusion_terms(suhmo_level *L, const suhmo_model_params_t *mp, hipStream_t st)
+{
+    Depth &D = L->d[0];
+    for (int f : {SUHMO_F_DCX, SUHMO_F_DCY, SUHMO_F_DTERM}) if (!suhmo_field(L, 0, f)) { suhmo_set_error("field allocation failed"); return -2; }
+    int n = 2 * D.v.ny + 2 * D.v.nx;
+    hipLaunchKernelGGL(k_extrap_ghosts, dim3((n + 255) / 256), dim3(256), 0, st, D.v, D.fp.f[SUHMO_F_MR]);
+    hipLaunchKernelGGL(k_dcoef_faces, dim3((D.v.nx + 1 + 63) / 64, (D.v.ny + 1 + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, L->ph, mp->rho_i);
+    hipLaunchKernelGGL(k_difterm, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// SolveForGap_nl (src/AmrHydro.cpp:593-662): (1 - dt diffFactor div(D grad)) b = RES on a second level handle with the
+// linear operator (alpha = 1, aCoef = 1, beta = dt diffFactor, bCoef = D, no nonlinear term), FixedNeumBCFill = Neumann 0.
+// [Chombo] VCAMRPoissonOp2 / AMRMultiGrid are not in the reference's tree: the cycle is the FAS cycle of suhmo_fas.hip,
+// which for a linear operator converges to the same solution (oracle/time_loop.c:solve_gap_implicit does the same).
+static int solve_gap_implicit(suhmo_level *L, const suhmo_model_params_t *mp, double dt, int cur_step, hipStream_t st)
+{
+    Depth &D = L->d[0];
+    if (!L->gap || L->gap_dt != dt) {
+        if (L->gap) { suhmo_level_destroy(L->gap); L->gap = nullptr; }
+        suhmo_level_desc_t d = L->desc;
+        d.boxes = L->boxes.data(); d.nbox = (int)(L->boxes.size() / 4);
+        for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) { d.bc.type[a][b] = 1; d.bc.value[a][b] = 0.0; }
+        d.phys.use_NL = 0; d.alpha = 1.0; d.beta = dt * mp->diffFactor;
+        int rc = suhmo_level_create(&L->gap, &d); if (rc) return rc;
+        L->gap_dt = dt;
+        if ((rc = suhmo_level_set_value(L->gap, 0, SUHMO_F_ACOEF, 1.0, (suhmo_stream_t)st))) return rc;       // aCoeff_GH :1820-1828
+    }
+    suhmo_level *G = L->gap;
+    Depth &GD = G->d[0];
+    if (GD.elems != D.elems) { suhmo_set_error("internal: gap level geometry"); return -4; }
+    const size_t bytes = D.elems * sizeof(double);
+    HIPCHK(hipMemcpyAsync(GD.fp.f[SUHMO_F_PHI], D.fp.f[SUHMO_F_B], bytes, hipMemcpyDeviceToDevice, st));      // initial guess = b :3382-3385
+    HIPCHK(hipMemcpyAsync(GD.fp.f[SUHMO_F_RHS], D.fp.f[SUHMO_F_RES], bytes, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(GD.fp.f[SUHMO_F_BX], D.fp.f[SUHMO_F_DCX], bytes, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(GD.fp.f[SUHMO_F_BY], D.fp.f[SUHMO_F_DCY], bytes, hipMemcpyDeviceToDevice, st));
+    int rc = suhmo_level_build_mg_coefficients(G, (suhmo_stream_t)st); if (rc) return rc;    // coarse D = average of the fine faces
+    suhmo_solver_params_t sp;
+    sp.num_smooth = 2; sp.num_bottom = 4; sp.max_iter = 100; sp.iter_min = 2; sp.imin = cur_step < 50 ? 10 : 5;
+    sp.eps = 1.0e-7; sp.hang = 1.0e-6; sp.norm_thresh = 1.0e-7; sp.bcoeff_otf = 0; sp.max_depth = -1;
+    if ((rc = suhmo_level_solve(G, &sp, nullptr, nullptr, (suhmo_stream_t)st))) return rc;
+    HIPCHK(hipMemcpyAsync(D.fp.f[SUHMO_F_B], GD.fp.f[SUHMO_F_PHI], bytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
 extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t *mp, double dt, int cur_step,
                                     int *picard_iters, int *vcycles, suhmo_stream_t s)
 {
     ARG(L && mp); ARG(dt > 0 && cur_step >= 1);
-    if (mp->diffFactor != 0.0) { suhmo_set_error("suhmo.diffFactor != 0: the diffusive term is not built"); return -5; }
+    if (mp->use_impl_diff && mp->diffFactor == 0.0) { suhmo_set_error("use_ImplDiff with diffFactor = 0"); return -1; }
     Depth &D = L->d[0];
     if (D.v.ext[0] || D.v.ext[1] || L->desc.nx_global > 0) { suhmo_set_error("timestep on a rank strip / AMR patch is not built yet"); return -5; }
     HIPCHK(hipSetDevice(L->device));
@@ -203,6 +301,7 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
     while (!converged) {                                           // [II]
         HIPCHK(hipMemcpyAsync(D.fp.f[SUHMO_F_HLAG], D.fp.f[SUHMO_F_PHI], D.elems * sizeof(double), hipMemcpyDeviceToDevice, st));
         if ((rc = lagged_chain(L, st))) return rc;
+        if (mp->diffFactor != 0.0 && (rc = diffusion_terms(L, mp, st))) return rc;   // lagged melt rate :2548-2551, :2982-2992
         hipLaunchKernelGGL(k_melt<0>, grd, blk, 0, st, D.v, D.fp, L->ph, *mp, dt);
         HIPCHK(hipGetLastError());
         int it = 0;
@@ -221,7 +320,8 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
     if ((rc = lagged_chain(L, st))) return rc;
     hipLaunchKernelGGL(k_melt<1>, grd, blk, 0, st, D.v, D.fp, L->ph, *mp, dt);
     HIPCHK(hipGetLastError());
-    if ((rc = suhmo_copy_ghosts(L, 0, SUHMO_F_B, st))) return rc;  // :3419-3420
+    if (mp->use_impl_diff && (rc = solve_gap_implicit(L, mp, dt, cur_step, st))) return rc;   // :3425-3439
+    if ((rc = suhmo_copy_ghosts(L, 0, SUHMO_F_B, st))) return rc;  // :3419-3420 / :3451-3452
     if (picard_iters) *picard_iters = ite_idx;
     if (vcycles) *vcycles = nv;
     return 0;

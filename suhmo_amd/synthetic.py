@@ -101,6 +101,14 @@ def shmip_a_model(case):
     return dict(A3_MODEL, distributed_input=SHMIP_A_INPUT[case])
 
 
+def shmip_b_model(case, inputs):
+    """exec/B_SHMIP/B<k>/input.hydro: suite A physics + moulins (inputs = tests/golden/shmip_B_inputs.json[case]),
+    diffFactor 1 and the implicit gap-height solve"""
+    b = inputs
+    return dict(A3_MODEL, distributed_input=b["distributed_input"], diffFactor=b["diffFactor"], use_impl_diff=1,
+                use_moulin_source=1, ramp=1.0)
+
+
 def shmip_initial_state(nx, ny, lx=1.0e5, ly=2.0e4, ice_height=5000.0, slope=0.0, gap_init=0.01):
     """SqrtIBC::initializeData (src/SqrtIBC.cpp:219-262) evaluated over the ghosted level:
     zb = slope x, H = max(6(sqrt(x+IceHeight)-sqrt(IceHeight))+1, 0), Pi = rho_i g H,

@@ -55,3 +55,28 @@ def test_timestep_with_moulin_source_bitwise(oracle):
             assert np.array_equal(a, b), (k, nm, float(np.max(np.abs(a - b))))
     assert np.all(np.isfinite(G.get("head")))
     O.close(); G.close()
+
+
+@pytest.mark.parametrize("impl", [1, 0])
+def test_timestep_with_diffusion_bitwise(oracle, impl):
+    """suhmo.diffFactor = 1: the diffusive term div(D grad b) in RHS_h and, with solver.use_ImplDiff, the implicit
+    gap-height solve (exec/B_SHMIP/B<k>/input.hydro:31,56) -- head, gap height, D and the term itself bit for bit"""
+    from suhmo_amd import model, level as lv
+    nx, ny = 160, 32
+    m = dict(sy.A3_MODEL, use_moulin_source=1, ramp=1.0, distributed_input=7.93e-11, diffFactor=1.0, use_impl_diff=impl)
+    st = sy.shmip_initial_state(nx, ny)
+    pos, sg, fl = moulins(3, 9)
+    sg = sg * 8.0
+    src, _ = oracle.moulin_source(nx, ny, st["dx"], st["dy"], pos, sg, fl, 1.0)
+    O = oracle.OracleModel(nx, ny, st["dx"], st["dy"], sy.A3_BC, sy.A3_PHYS, m, max_box=32, nthreads=2)
+    G = model.HipModel(nx, ny, st["dx"], st["dy"], sy.A3_BC, sy.A3_PHYS, m, max_box=32)
+    O.set_state(st); G.set_state(st)
+    O.field(oracle.OM_MSRC)[1:-1, 1:-1] = src
+    G.level.set(lv.F_MSRC, src)
+    for k in range(4):
+        assert O.timestep(m["dt"]) == G.timestep(m["dt"]), k
+        for nm, fid in (("head", oracle.OM_H), ("B", oracle.OM_B), ("rhs_h", oracle.OM_RHSH), ("mR", oracle.OM_MR)):
+            a, b = np.array(O.field(fid))[1:-1, 1:-1], G.get(nm)
+            assert np.array_equal(a, b), (k, nm, float(np.max(np.abs(a - b))))
+    assert np.all(np.isfinite(G.get("B"))) and G.get("B").min() > 0.0
+    O.close(); G.close()

@@ -71,11 +71,13 @@ def test_timestep_bitwise(oracle, hipmodel, name, nx, ny, bc, ph, mpo, holes, ns
 def test_timestep_refuses_what_is_not_built(hipmodel):
     from suhmo_amd import capi
     st = sy.shmip_initial_state(32, 16)
-    G = hipmodel.HipModel(32, 16, st["dx"], st["dy"], sy.A3_BC, sy.A3_PHYS, dict(sy.A3_MODEL, diffFactor=1.0))
-    G.set_state(st)
-    with pytest.raises(capi.SuhmoError):
-        G.timestep(3600.0)
-    G.close()
+    for bad in (dict(use_impl_diff=1, diffFactor=0.0),          # implicit diffusion without diffusion
+                dict(use_moulin_source=1)):                     # moulin source that was never computed
+        G = hipmodel.HipModel(32, 16, st["dx"], st["dy"], sy.A3_BC, sy.A3_PHYS, dict(sy.A3_MODEL, **bad))
+        G.set_state(st)
+        with pytest.raises(capi.SuhmoError):
+            G.timestep(3600.0)
+        G.close()
 
 
 @pytest.mark.parametrize("case", ["A1", "A2", "A3", "A4", "A5", "A6"])
@@ -99,6 +101,41 @@ def test_shmip_a_full_run(hipmodel, case):
         tot_p += p
         tot_v += nv
     table = G.postproc_table()
+    G.close()
+    orc = np.loadtxt(os.path.join(GOLD, "shmip_%s_oracle_run_table.dat" % case))
+    run = json.load(open(os.path.join(GOLD, "shmip_%s_oracle_run.json" % case)))
+    assert (tot_p, tot_v) == (run["picard_total"], run["vcycles_total"])
+    scale = np.max(np.abs(orc), axis=0)
+    assert np.all(np.abs(table - orc) <= 1e-9 * scale), np.max(np.abs(table - orc) / scale, axis=0)
+    check_against_reference(table, case, "run")
+
+
+@pytest.mark.parametrize("case", ["B1", "B5"])
+def test_shmip_b_full_run(hipmodel, oracle, case):
+    """exec/B_SHMIP/B<k>: suite A physics + 1 / 100 moulins, diffFactor = 1, implicit gap-height solve; 10000 + 2 steps on
+    the device.  The moulin source array is the oracle's (its exp() differs from the device's in the last bits,
+    tests/test_gpu_moulin.py bounds that), so the run must stay on the oracle's trajectory: same Picard / V-cycle
+    totals, table equal to 1e-9."""
+    import json
+    from suhmo_amd import level as lv
+    from test_oracle_timeloop import check_against_reference
+    binp = json.load(open(os.path.join(GOLD, "shmip_B_inputs.json")))[case]
+    m = sy.shmip_b_model(case, binp)
+    st = sy.shmip_initial_state(m["nx"], m["ny"], m["lx"], m["ly"])
+    src, _ = oracle.moulin_source(m["nx"], m["ny"], st["dx"], st["dy"], np.array(binp["positions"]).reshape(-1, 2),
+                                  binp["sigma"], binp["flux"], 1.0)
+    G = hipmodel.HipModel(m["nx"], m["ny"], st["dx"], st["dy"], sy.A3_BC, sy.A3_PHYS, m, max_box=64)
+    G.set_state(st)
+    G.level.set(lv.F_MSRC, src)
+    tot_p = tot_v = 0
+    for k in range(m["max_step"] + 2):
+        p, nv = G.timestep(m["dt"])
+        tot_p += p
+        tot_v += nv
+    mask = G.get("mask")
+    table = sy.shmip_postproc_table(st["dx"], st["dy"], G.get("qwx"), G.get("cd", ghosted=True),
+                                    np.where(mask > 0.0, src * m["ramp"] + m["distributed_input"], 0.0),
+                                    G.get("mR"), G.get("Pw"), G.get("Pi"), mask, m["rho_w"])
     G.close()
     orc = np.loadtxt(os.path.join(GOLD, "shmip_%s_oracle_run_table.dat" % case))
     run = json.load(open(os.path.join(GOLD, "shmip_%s_oracle_run.json" % case)))

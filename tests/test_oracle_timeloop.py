@@ -27,10 +27,19 @@ PIN_TOL_A6 = {**PIN_TOL, 6: 3e-4, 7: 2e-4}          # A6 (input x 100, fully tur
 ASIS_TOL = {0: 1e-6, 1: 0.0, 2: 8e-3, 5: 1e-5, 6: 1e-3, 7: 1e-3}
 
 
+BCASES = ["B1", "B2", "B3", "B4", "B5"]
+# suite B (moulins, diffFactor = 1, implicit gap-height solve): the reference prints 7 digits
+PIN_TOL_B = {0: 1e-6, 1: 0.0, 2: 1e-6, 5: 1e-6, 6: 5e-5, 7: 5e-5}
+ASIS_TOL_B = {0: 1e-6, 1: 0.0, 2: 3e-3, 5: 1e-6, 6: 2e-3, 7: 2e-3}
+
+
 def check_against_reference(table, case, variant):
     ref = np.loadtxt(os.path.join(GOLD, "shmip_%s_postproc_reference.dat" % case))
     assert table.shape == ref.shape == (320, 8)
-    tol = ASIS_TOL if variant == "run" else (PIN_TOL_A6 if case == "A6" else PIN_TOL)
+    if case.startswith("B"):
+        tol = ASIS_TOL_B if variant == "run" else PIN_TOL_B
+    else:
+        tol = ASIS_TOL if variant == "run" else (PIN_TOL_A6 if case == "A6" else PIN_TOL)
     for c, t in tol.items():
         sel = slice(1, None) if c == 2 else slice(None)     # the reference prints -0 in row 0 of the discharge columns
         sc = np.max(np.abs(ref[sel, c]))
@@ -42,18 +51,19 @@ def check_against_reference(table, case, variant):
         qs = np.max(np.abs(ref[1:, 2]))
         t = 1e-3 if case == "A6" else 1e-5
         for c in (3, 4):
-            assert np.max(np.abs(table[5:, c] - ref[5:, c])) <= t * qs, (case, c)
+            assert np.max(np.abs(table[8:, c] - ref[8:, c])) <= t * qs, (case, c)
 
 
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", CASES + BCASES)
 def test_oracle_pinned_by_reference_results(case):
-    """10002 steps of SHMIP A<k> through the oracle (every kernel of the restatement, the level shim, the FAS
-    reconstruction, the Picard loop, the gap-height update) against the reference's own committed result table"""
+    """10002 steps of SHMIP A<k> / B<k> through the oracle (every kernel of the restatement, the level shim, the FAS
+    reconstruction, the Picard loop, the gap-height update; suite B adds the moulin source term, the diffusive
+    term and the implicit gap-height solve) against the reference's own committed result table"""
     t = np.loadtxt(os.path.join(GOLD, "shmip_%s_oracle_nomelt_table.dat" % case))
     check_against_reference(t, case, "nomelt")
 
 
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", CASES + BCASES)
 def test_source_as_it_is_differs_by_the_melt_share_only(case):
     ref = np.loadtxt(os.path.join(GOLD, "shmip_%s_postproc_reference.dat" % case))
     t = np.loadtxt(os.path.join(GOLD, "shmip_%s_oracle_run_table.dat" % case))

@@ -37,7 +37,12 @@ def main():
         os.environ["SUHMO_ORACLE_HEAD_MELT_COEF"] = coef
     which = sys.argv[1] if len(sys.argv) > 1 else "oracle"
     case = sys.argv[2] if len(sys.argv) > 2 else "A3"
-    m = sy.shmip_a_model(case)
+    binp = None
+    if case.startswith("B"):
+        binp = json.load(open(os.path.join(ROOT, "tests", "golden", "shmip_B_inputs.json")))[case]
+        m = sy.shmip_b_model(case, binp)
+    else:
+        m = sy.shmip_a_model(case)
     nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else m["max_step"] + 2
     out_json = sys.argv[4] if len(sys.argv) > 4 else None
     st = sy.shmip_initial_state(m["nx"], m["ny"], m["lx"], m["ly"])
@@ -47,6 +52,10 @@ def main():
         M = po.OracleModel(m["nx"], m["ny"], st["dx"], st["dy"], sy.A3_BC, sy.A3_PHYS, m, max_box=64,
                            nthreads=min(8, os.cpu_count() or 1))
         M.set_state(st)
+        if binp:
+            src, _ = po.moulin_source(m["nx"], m["ny"], st["dx"], st["dy"], np.array(binp["positions"]).reshape(-1, 2),
+                                      binp["sigma"], binp["flux"], 1.0)
+            M.field(po.OM_MSRC)[1:-1, 1:-1] = src
         tot_p = tot_v = 0
         for k in range(nsteps):
             p, v = M.timestep(m["dt"]); tot_p += p; tot_v += v
