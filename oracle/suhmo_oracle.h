@@ -13,12 +13,12 @@
  * single function below is pinned in isolation ("parity unpinned" at kernel level; only
  * reference-free known-answer tests, tests/test_oracle_kat.py, and a hand-computed fixture).
  * What IS pinned: the whole restatement -- these kernels + level_shim.c (box orchestration,
- * FAS cycle) + time_loop.c (Picard loop, gap-height update) -- run for the 10002 steps of
- * SHMIP A1..A6 reproduces the reference's committed tables exec/A_SHMIP/A<k>/results/postproc.dat
- * (6 digits printed) to print precision (<= 1.6e-5 of each column's scale for A1-A5,
- * <= 1.6e-4 for A6) once the one term the tables were evidently written without (the melt
- * term of RHS_h, src/AmrHydro.cpp:3046) is switched off; see tests/test_oracle_timeloop.py
- * and DESIGN.md section 4.
+ * FAS cycle) + time_loop.c (Picard loop, moulin source, diffusive term, explicit and implicit
+ * gap-height update) -- run for the 10002 steps of SHMIP A1..A6 and B1..B5 reproduces EVERY
+ * column and row of the reference's committed tables exec/{A,B}_SHMIP/<case>/results/postproc.dat
+ * to print precision (6 / 7 digits) under the two settings the tables were evidently written
+ * with: no melt term in RHS_h (src/AmrHydro.cpp:3046) and use_mask_for_gradients = true; see
+ * tests/test_oracle_timeloop.py and DESIGN.md section 4.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
  *

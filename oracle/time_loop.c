@@ -170,23 +170,12 @@ static void grad_re_qw(OrModel *M)
 {
     double *h = M->c[OM_H], *B = M->c[OM_B], *gx = M->c[OM_GRADX], *gy = M->c[OM_GRADY], *Re = M->c[OM_RE];
     mac_grad(M, h, M->gxf, M->gyf);
-    /* diagnosis knob (DESIGN.md "end-to-end pin"): the face gradient on Dirichlet domain faces as the reference's
-     * committed tables imply it (zero); 1 = before the cell-centred gradient is formed, 2 = after.  Unset = the source. */
-    const char *zk = getenv("SUHMO_ORACLE_ZERO_DIRICHLET_FACE_GRAD");
-    int zmode = zk ? atoi(zk) : 0;
-#define ZERO_DIRICHLET_FACES() do { \
-        if (!M->bc.periodic[0]) { if (M->bc.type[0][0] == 0) for (int j = 0; j < M->ny; j++) FX(M->gxf, 0, j) = 0.0; \
-                                  if (M->bc.type[0][1] == 0) for (int j = 0; j < M->ny; j++) FX(M->gxf, M->nx, j) = 0.0; } \
-        if (!M->bc.periodic[1]) { if (M->bc.type[1][0] == 0) for (int i = 0; i < M->nx; i++) FY(M->gyf, i, 0) = 0.0; \
-                                  if (M->bc.type[1][1] == 0) for (int i = 0; i < M->nx; i++) FY(M->gyf, i, M->ny) = 0.0; } } while (0)
-    if (zmode == 1) ZERO_DIRICHLET_FACES();
     for (int j = 0; j < M->ny; j++)
         for (int i = 0; i < M->nx; i++) {              /* EdgeToCell */
             CC(gx, i, j) = 0.5 * (FX(M->gxf, i, j) + FX(M->gxf, i + 1, j));
             CC(gy, i, j) = 0.5 * (FY(M->gyf, i, j) + FY(M->gyf, i, j + 1));
         }
     extrap_ghosts(M, gx); extrap_ghosts(M, gy);
-    if (zmode == 2) ZERO_DIRICHLET_FACES();
     for (int j = -1; j <= M->ny; j++)
         for (int i = -1; i <= M->nx; i++) {            /* COMPUTERE on the ghosted box, AmrHydroF.ChF:92-109 */
             double s = sqrt(CC(gx, i, j) * CC(gx, i, j) + CC(gy, i, j) * CC(gy, i, j));

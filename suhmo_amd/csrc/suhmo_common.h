@@ -125,6 +125,7 @@ struct Depth {
     int phi_fresh;     // strips: halo rows of phi (each rank-boundary side) that hold the neighbour's CURRENT values
 };
 
+struct VGraph { int key[4]; hipGraphExec_t exec; };     // a V-cycle captured for one set of solver parameters (suhmo_fas.hip)
 struct ProfEv { hipEvent_t a, b; long cells; };
 
 struct suhmo_level {
@@ -142,6 +143,8 @@ struct suhmo_level {
     void *user;
     int (*ex_begin)(void *user);                       // optional: open / close a batch of exchanges that
     int (*ex_end)(void *user, suhmo_level *L, suhmo_stream_t s);   // travel as ONE message group (native transport)
+    long graph_max_cells;        // V-cycles of levels up to this size are replayed as HIP graphs (env SUHMO_GRAPH_MAX_CELLS, 0 = off)
+    std::vector<VGraph> vgraphs; int vgraph_seen[4]; hipStream_t gstream;
     suhmo_level *gap; double gap_dt;   // implicit gap-height operator of the time step (suhmo_step.hip), owned
     void *rccl;                 // native transport state (suhmo_rccl.hip), owned by the level
     int prof_on;
@@ -163,5 +166,6 @@ int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st);      // 
 int suhmo_restrict_both(suhmo_level *L, int depth, hipStream_t st);                 // suhmo_level.hip
 bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps);           // suhmo_gsrb.hip
 int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream_t st);   // suhmo_gsrb.hip; tail = halo rows worth keeping valid at exit
+void suhmo_level_drop_graphs(suhmo_level *L);                                     // suhmo_fas.hip
 int suhmo_ensure_phi_halo(suhmo_level *L, int depth, int need, hipStream_t st);      // suhmo_level.hip
 static inline int suhmo_halo_rows(const DV &v) { return v.gy < v.ny ? v.gy : v.ny; }

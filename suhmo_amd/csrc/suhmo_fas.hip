@@ -67,16 +67,81 @@ static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, i
     return relax(L, dep, S, tail_post, s);                                        // post-smooth
 }
 
-extern "C" int suhmo_level_vcycle(suhmo_level_t *L, const suhmo_solver_params_t *sp, suhmo_stream_t s)
+static int vcycle_body(suhmo_level *L, const suhmo_solver_params_t *sp, int nd, suhmo_stream_t s)
 {
-    ARG(L && sp);
-    HIPCHK(hipSetDevice(L->device));
-    int nd = eff_depths(L, sp), rc;
+    int rc;
     if (sp->bcoeff_otf) {
         if ((rc = suhmo_level_update_operator(L, 0, s))) return rc;
         if ((rc = suhmo_average_operator_all(L, nd, (hipStream_t)s))) return rc;   // AverageOperator on every depth > 0
     }
     return fas_cycle(L, 0, sp, nd, s);
+}
+
+// Small levels are launch-bound (a 1024^2 V-cycle is ~170 dependent launches of a few microseconds each): the cycle is a
+// fixed sequence of kernels for given solver parameters, so from its second use it is replayed as a HIP graph.  The first
+// use runs eagerly (lazy allocations, occupancy queries), the second is captured on a private stream -- host-side state the
+// cycle toggles (phi ping-pong pointers, prolong_pending) must come back to where it started, otherwise the graph is
+// dropped.  Not used on rank strips (the exchange hooks are host calls), while profiling, or above SUHMO_GRAPH_MAX_CELLS.
+void suhmo_level_drop_graphs(suhmo_level *L)
+{
+    for (VGraph &g : L->vgraphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    L->vgraphs.clear();
+    if (L->gstream) { (void)hipStreamDestroy(L->gstream); L->gstream = nullptr; }
+}
+static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd, suhmo_stream_t s, bool &done)
+{
+    done = false;
+    const int key[4] = {sp->num_smooth, sp->num_bottom, sp->bcoeff_otf, nd};
+    for (const VGraph &g : L->vgraphs)
+        if (!memcmp(g.key, key, sizeof(key))) {
+            if (!g.exec) return 0;                                       // known not to be capturable
+            HIPCHK(hipGraphLaunch(g.exec, (hipStream_t)s));
+            done = true;
+            return 0;
+        }
+    // first sighting of these parameters: run eagerly now, capture at the next call
+    for (int k = 0; k < 4; k++) if (L->vgraph_seen[k] != key[k]) { memcpy(L->vgraph_seen, key, sizeof(key)); return 0; }
+    if (!L->gstream) HIPCHK(hipStreamCreateWithFlags(&L->gstream, hipStreamNonBlocking));
+    double *phi0[SUHMO_MAXDEPTH], *alt0[SUHMO_MAXDEPTH];
+    for (int d = 0; d < L->ndepth; d++) { phi0[d] = L->d[d].fp.f[SUHMO_F_PHI]; alt0[d] = L->d[d].phi_alt; }
+    VGraph g; memcpy(g.key, key, sizeof(key)); g.exec = nullptr;
+    HIPCHK(hipStreamSynchronize((hipStream_t)s));                        // the private stream starts from a quiescent state
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(L->gstream, hipStreamCaptureModeThreadLocal);
+    int rc = 0;
+    if (e == hipSuccess) {
+        rc = vcycle_body(L, sp, nd, (suhmo_stream_t)L->gstream);
+        e = hipStreamEndCapture(L->gstream, &graph);
+    }
+    bool same = true;
+    for (int d = 0; d < L->ndepth; d++) {
+        same = same && L->d[d].fp.f[SUHMO_F_PHI] == phi0[d] && L->d[d].phi_alt == alt0[d] && !L->d[d].prolong_pending;
+        L->d[d].fp.f[SUHMO_F_PHI] = phi0[d]; L->d[d].phi_alt = alt0[d]; L->d[d].prolong_pending = 0;
+    }
+    if (e == hipSuccess && rc == 0 && same && graph && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) g.exec = nullptr;
+    if (!(e == hipSuccess && rc == 0 && same)) g.exec = nullptr;
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    L->vgraphs.push_back(g);
+    if (!g.exec) return 0;                                               // nothing was executed during capture: run eagerly
+    HIPCHK(hipGraphLaunch(g.exec, (hipStream_t)s));
+    done = true;
+    return 0;
+}
+
+extern "C" int suhmo_level_vcycle(suhmo_level_t *L, const suhmo_solver_params_t *sp, suhmo_stream_t s)
+{
+    ARG(L && sp);
+    HIPCHK(hipSetDevice(L->device));
+    int nd = eff_depths(L, sp);
+    const Depth &D = L->d[0];
+    const bool ext = D.v.ext[0] || D.v.ext[1];
+    if (L->graph_max_cells > 0 && !L->ex && !ext && !L->prof_on && (long)D.v.nx * D.v.ny <= L->graph_max_cells) {
+        bool done = false;
+        int rc = vcycle_graph(L, sp, nd, s, done);
+        if (rc || done) return rc;
+    }
+    return vcycle_body(L, sp, nd, s);
 }
 
 extern "C" int suhmo_level_solve(suhmo_level_t *L, const suhmo_solver_params_t *sp, int *iters, double *hist, suhmo_stream_t s)

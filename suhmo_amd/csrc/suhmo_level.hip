@@ -91,6 +91,8 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     if (const char *e = getenv("SUHMO_BCOEF_FUSED")) L->bcoef_fused = atoi(e);
     L->fused_nt = 64;                        // one wave per workgroup: 316 vs 308 V-cycles/s at 4096^2 (profiles/r01_i_nt_ab.txt)
     if (const char *e = getenv("SUHMO_FUSED_NT")) L->fused_nt = atoi(e);
+    L->graph_max_cells = 1500000; L->gstream = nullptr; memset(L->vgraph_seen, 0, sizeof(L->vgraph_seen));
+    if (const char *e = getenv("SUHMO_GRAPH_MAX_CELLS")) L->graph_max_cells = atol(e);
     L->fused_min_cells = 2000000;
     if (const char *e = getenv("SUHMO_FUSED_MIN_CELLS")) L->fused_min_cells = atol(e);
     if (desc->boxes && desc->nbox > 0) {
@@ -156,6 +158,7 @@ extern "C" int suhmo_level_destroy(suhmo_level_t *L)
     (void)hipDeviceSynchronize();
     if (L->rccl) (void)suhmo_level_detach_rccl(L);
     if (L->gap) { (void)suhmo_level_destroy(L->gap); L->gap = nullptr; }
+    suhmo_level_drop_graphs(L);
     for (int dep = 0; dep < L->ndepth; dep++)
         for (int f = 0; f < SUHMO_F_COUNT; f++)
             if (L->d[dep].fp.f[f]) (void)hipFree(L->d[dep].fp.f[f]);

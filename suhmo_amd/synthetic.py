@@ -194,3 +194,39 @@ def amr2_fields(nxc=64, nyc=16, patch=CFG3_PATCH, **kw):
     """(coarse, fine): the two-level case of amr_fields"""
     c, f = amr_fields(nxc, nyc, (patch,), **kw)
     return c, f
+
+
+# ---- SHMIP suite E: valley glacier (exec/E_SHMIP/E<k>/input.hydro, src/ValleyIBC.cpp:120-330)
+E_GAMMA = dict(E1=0.05, E2=0.0, E3=-0.1, E4=-0.5, E5=-0.7)
+E_PHYS = dict(A3_PHYS, use_mask_gradients=1)            # + cutOffB = 1 for E1, E4, E5 (solver.cut_solve_outside_domain)
+E_CUTOFFB = dict(E1=1, E2=0, E3=0, E4=1, E5=1)
+E_MODEL = dict(A3_MODEL, G=0.05, ct=0.0, diffFactor=1.0, distributed_input=1.158e-6, use_impl_diff=1, use_mask_rhs_b=1,
+               max_step=5000, nx=256, ny=64, lx=6000.0, ly=1500.0)
+
+
+def shmip_e_model(case):
+    return dict(E_MODEL, eps_picard=5.0e-4 if case == "E5" else 1.0e-4)
+
+
+def valley_initial_state(nx, ny, gamma, lx=6000.0, ly=1500.0, gap_init=0.01):
+    """ValleyIBC::initializeData (src/ValleyIBC.cpp:236-330) over the ghosted level: surface
+    100 (x+200)^(1/4) + x/60 - (2e10)^(1/4) + 1, bed f(x) + g(y) h(x), Pi = rho_i g max(surface - bed, 0),
+    head = Pi / (2 rho_w g) + zb, gap = GapInit (1e-16 where Pi < 1e-10); mask: ValleyIBC::setup_iceMask"""
+    dx, dy = lx / nx, ly / ny
+    i = np.arange(-1, nx + 1, dtype=np.float64)
+    j = np.arange(-1, ny + 1, dtype=np.float64)
+    X, Y = np.meshgrid((i + 0.5) * dx, (j + 0.5) * dy - 750.0)
+    surf = 100.0 * np.power(X + 200.0, 0.25) + X / 60.0 - np.power(2.0e10, 0.25) + 1.0
+    gamma_b = 0.05
+    H6 = 100.0 * np.power(6000.0 + 200.0, 0.25) + 6000.0 / 60.0 - np.power(2.0e10, 0.25) + 1.0
+    fx = (H6 - 6000.0 * gamma) * X * X / (6000.0 * 6000.0) + gamma * X
+    fxg = (H6 - 6000.0 * gamma_b) * X * X / (6000.0 * 6000.0) + gamma_b * X
+    gy = 0.5e-6 * np.abs(Y * Y * Y)
+    hx = (-4.5 * X / 6000.0 + 5.0) * (surf - fx) / (surf - fxg + 1.0e-16)
+    zb = fx + gy * hx
+    Pi = RHO_I * GRAV * np.maximum(surf - zb, 0.0)
+    B = np.where(Pi < 1.0e-10, 1.0e-16, gap_init)
+    head = (Pi * 0.5) * (1.0 / (RHO_W * GRAV)) + zb
+    head = np.where(head < 0.0, 0.0, head)                 # ValleyIBC::resetCovered
+    mask = np.where(Pi > 0.0, 1.0, -1.0)
+    return dict(nx=nx, ny=ny, dx=dx, dy=dy, head=head, B=B, Pi=Pi, zb=zb, mask=mask)

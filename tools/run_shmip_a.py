@@ -4,6 +4,7 @@ post-processing steps of input.hydro_pp; the six cases differ in suhmo.distribut
 loop and compares the cross-section table with the reference's committed result
 tests/golden/shmip_A<k>_postproc_reference.dat (a DATA fixture copied from exec/A_SHMIP/A<k>/results/postproc.dat).
 usage: run_shmip_a.py oracle|hip A<k> [nsteps] [out.json] [--head-melt-coef X]
+--mask-gradients 0|1 overrides solver.use_mask_for_gradients of the case.
 --head-melt-coef X (oracle only) scales the melt term of RHS_h (src/AmrHydro.cpp:3046); X = 0 reproduces the
 code state the reference's committed results were evidently produced with ("end-to-end pin").
 The committed tests/golden/shmip_A<k>_oracle_run{.json,_table.dat} were written by
@@ -35,23 +36,38 @@ def main():
         coef = sys.argv[k + 1]
         del sys.argv[k:k + 2]
         os.environ["SUHMO_ORACLE_HEAD_MELT_COEF"] = coef
+    mask_grad = None
+    if "--mask-gradients" in sys.argv:
+        k = sys.argv.index("--mask-gradients")
+        mask_grad = int(sys.argv[k + 1])
+        del sys.argv[k:k + 2]
     which = sys.argv[1] if len(sys.argv) > 1 else "oracle"
     case = sys.argv[2] if len(sys.argv) > 2 else "A3"
     binp = None
     if case.startswith("B"):
         binp = json.load(open(os.path.join(ROOT, "tests", "golden", "shmip_B_inputs.json")))[case]
         m = sy.shmip_b_model(case, binp)
+    elif case.startswith("E"):
+        m = sy.shmip_e_model(case)
     else:
         m = sy.shmip_a_model(case)
     nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else m["max_step"] + 2
     out_json = sys.argv[4] if len(sys.argv) > 4 else None
-    st = sy.shmip_initial_state(m["nx"], m["ny"], m["lx"], m["ly"])
+    phys = sy.A3_PHYS
+    if case.startswith("E"):
+        st = sy.valley_initial_state(m["nx"], m["ny"], sy.E_GAMMA[case], m["lx"], m["ly"])
+        phys = dict(sy.E_PHYS, cutOffB=sy.E_CUTOFFB[case])
+    else:
+        st = sy.shmip_initial_state(m["nx"], m["ny"], m["lx"], m["ly"])
+    if mask_grad is not None:
+        phys = dict(phys, use_mask_gradients=mask_grad)
     t0 = time.time()
     if which == "oracle":
         from oracle import pyoracle as po
-        M = po.OracleModel(m["nx"], m["ny"], st["dx"], st["dy"], sy.A3_BC, sy.A3_PHYS, m, max_box=64,
+        M = po.OracleModel(m["nx"], m["ny"], st["dx"], st["dy"], sy.A3_BC, phys, m, max_box=64,
                            nthreads=min(8, os.cpu_count() or 1))
         M.set_state(st)
+        M.field(po.OM_MR)[:] = m["G"] / m["L"]            # thismeltRate = G / L (SqrtIBC / ValleyIBC::initializeData)
         if binp:
             src, _ = po.moulin_source(m["nx"], m["ny"], st["dx"], st["dy"], np.array(binp["positions"]).reshape(-1, 2),
                                       binp["sigma"], binp["flux"], 1.0)
@@ -79,7 +95,7 @@ def main():
         head, gap = M.get("head"), M.get("B")
     ref = np.loadtxt(os.path.join(ROOT, "tests", "golden", "shmip_%s_postproc_reference.dat" % case))
     cmp_ = compare(table, ref)
-    res = {"which": which, "case": case, "head_melt_coef": coef, "steps": nsteps, "picard_total": tot_p, "vcycles_total": tot_v, "seconds": time.time() - t0,
+    res = {"which": which, "case": case, "head_melt_coef": coef, "mask_gradients": mask_grad, "steps": nsteps, "picard_total": tot_p, "vcycles_total": tot_v, "seconds": time.time() - t0,
            "head_min_max": [float(head.min()), float(head.max())], "gap_min_max": [float(gap.min()), float(gap.max())],
            "vs_reference": cmp_}
     print(json.dumps(res, indent=1))
