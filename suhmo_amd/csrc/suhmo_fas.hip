@@ -22,11 +22,13 @@ static int eff_depths(const suhmo_level *L, const suhmo_solver_params_t *sp)
 
 // relax() of the operator: levelGSRB sweeps, then the homogeneous-BC ghost fill levelGSRB ends with
 // (src/VCAMRNonLinearPoissonOp.cpp:757-759).  `tail`: halo rows (strips) worth keeping valid for the next reader.
-static int relax(suhmo_level *L, int dep, int sweeps, int tail, suhmo_stream_t s)
+// Inside the cycle nothing reads the stored ghost ring (every kernel evaluates the boundary condition from the
+// adjacent interior value), so only the relax that ends the cycle -- whose state the caller can observe -- fills it.
+static int relax(suhmo_level *L, int dep, int sweeps, int tail, suhmo_stream_t s, bool observable = false)
 {
     int rc = suhmo_launch_gsrb(L, dep, sweeps, tail, (hipStream_t)s);
     if (rc) return rc;
-    if (sweeps > 0) return suhmo_level_fill_ghosts(L, dep, SUHMO_F_PHI, 1, s);
+    if (sweeps > 0 && observable) return suhmo_level_fill_ghosts(L, dep, SUHMO_F_PHI, 1, s);
     return 0;
 }
 
@@ -47,7 +49,7 @@ static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, i
     int rc;
     const int S = sp->num_smooth;
     const int tail_post = dep == 0 ? 2 : (rows_after_prolong(dep - 1, S) + 1) / 2;
-    if (dep == nd - 1) return relax(L, dep, sp->num_bottom, tail_post, s);        // bottom relaxes
+    if (dep == nd - 1) return relax(L, dep, sp->num_bottom, tail_post, s, dep == 0);   // bottom relaxes
     Depth &C = L->d[dep + 1];
     if ((rc = relax(L, dep, S, rows_after_prolong(dep, S), s))) return rc;        // pre-smooth (the restriction reads 1 halo row,
                                                                                   //  the prolongation below the rest)
@@ -64,7 +66,7 @@ static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, i
     } else {
         if ((rc = suhmo_prolong_with_halo(L, dep, (hipStream_t)s))) return rc;    // corr = phi_c - phi_c,old; phi += P(corr), halo rows included
     }
-    return relax(L, dep, S, tail_post, s);                                        // post-smooth
+    return relax(L, dep, S, tail_post, s, dep == 0);                              // post-smooth
 }
 
 static int vcycle_body(suhmo_level *L, const suhmo_solver_params_t *sp, int nd, suhmo_stream_t s)
