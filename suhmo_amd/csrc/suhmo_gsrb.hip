@@ -270,6 +270,9 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st)
         if (nch < 1) nch = 1;
         g.Hc = (nrows + nch - 1) / nch;
         if (g.Hc < 16 * K) g.Hc = 16 * K;
+        // cache-resident depths (about 1 M cells) are latency-bound: many short chunks beat few long ones
+        // (profiles/r01_k_sweep_small_hc.log: 1024^2, K = 2: 22.3 us per sweep at 6 rows vs 28.1 for the colour passes)
+        if ((long)v.nx * v.ny < 2000000L) g.Hc = 6;
         if (L->fused_hc > 0) g.Hc = L->fused_hc;          // explicit: no lower clamp (tools/sweep_small_hc.sh)
         if (g.Hc > nrows) g.Hc = nrows;
         g.nchunks = (nrows + g.Hc - 1) / g.Hc;

@@ -93,7 +93,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     if (const char *e = getenv("SUHMO_FUSED_NT")) L->fused_nt = atoi(e);
     L->graph_max_cells = 1500000; L->gstream = nullptr; memset(L->vgraph_seen, 0, sizeof(L->vgraph_seen));
     if (const char *e = getenv("SUHMO_GRAPH_MAX_CELLS")) L->graph_max_cells = atol(e);
-    L->fused_min_cells = 2000000;
+    L->fused_min_cells = 1000000;
     if (const char *e = getenv("SUHMO_FUSED_MIN_CELLS")) L->fused_min_cells = atol(e);
     if (desc->boxes && desc->nbox > 0) {
         L->boxes.assign(desc->boxes, desc->boxes + 4 * (size_t)desc->nbox);
