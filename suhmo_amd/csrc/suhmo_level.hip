@@ -749,16 +749,17 @@ __global__ __launch_bounds__(256) void k_bcoef_faces(DV v, FP fp, suhmo_phys_t p
 }
 
 // ---- fused WFlx_level: one kernel = steps 1-4 above on a tile staged in LDS.
-// A block of 64 x 4 threads owns BT_X x BT_Y = 62 x 30 cells.  phi tile (halo 2, 66 x 34) and
+// A block of 64 x 4 threads owns BT_X x BT_Y = 62 x 14 cells (26 KB of LDS, 6 blocks per CU: 0.26 ms at 4096^2 vs
+// 0.29 ms with 30 rows).  phi tile (halo 2) and
 // the B / mask tiles (halo 1) are loaded up front (one exposure to HBM latency); then
-// cell-centred gradient on the Re range (halo 1 = 64 x 32: one lane per column, 8 rows per
+// cell-centred gradient on the Re range (halo 1: one lane per column, NK rows per
 // thread, in registers) -> ghost gradients by linear extrapolation (periodic images and
 // exchanged halo rows are ordinary cells) -> Re (LDS, aliasing the dead phi tile) -> the
 // tile's W and S faces (+ the domain's E / N faces in the last tile column / row).
 // Every value comes from the same expressions as the four-kernel path (bitwise equal); halo
 // cells are recomputed instead of stored, so HBM sees phi, B, mask once and bx, by once.
 #define BT_X 62
-#define BT_Y 30
+#define BT_Y 14
 __global__ __launch_bounds__(256) void k_bcoef_fused(DV v, FP fp, suhmo_phys_t ph, int hasMask)
 {
     constexpr int PW = BT_X + 4, PH = BT_Y + 4;     // phi tile: cells [i0-2, i0+BT_X+1] x [j0-2, j0+BT_Y+1]
