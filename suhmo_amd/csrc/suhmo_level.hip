@@ -511,25 +511,46 @@ __global__ __launch_bounds__(256) void k_restrict_residual(DV v, FP fp, DV vc, d
     int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y * blockDim.y + threadIdx.y;
     if (I >= vc.nx || J >= vc.ny) return;
     const double *__restrict__ phi = fp.f[SUHMO_F_PHI];
+    // the thread's 2 x 2 fine cells start at an even column: every row is read as 16-byte pairs (canvas column
+    // SUHMO_XOFF + 2I is 16-byte aligned), the W / E neighbours of the pair as single values
+    const int i0 = 2 * I, j0 = 2 * J, base = cidx(v, i0, j0);
+    auto ld2 = [&](const double *__restrict__ p, int idx) { return *reinterpret_cast<const double2 *>(p + idx); };
+    double2 pc[2], pS, pN;
+    pc[0] = ld2(phi, base); pc[1] = ld2(phi, base + v.P);
+    // south of row j0 / north of row j0 + 1 (physical BC evaluated from the adjacent interior value)
+    if (j0 > 0 || v.ext[0]) pS = ld2(phi, base - v.P);
+    else if (v.per[1]) pS = ld2(phi, base + (v.ny - 1) * v.P);
+    else { pS.x = phiS(v, phi, base, j0, pc[0].x, false); pS.y = phiS(v, phi, base + 1, j0, pc[0].y, false); }
+    if (j0 + 1 < v.ny - 1 || v.ext[1]) pN = ld2(phi, base + 2 * v.P);
+    else if (v.per[1]) pN = ld2(phi, base + v.P - (v.ny - 1) * v.P);
+    else { pN.x = phiN(v, phi, base + v.P, j0 + 1, pc[1].x, false); pN.y = phiN(v, phi, base + v.P + 1, j0 + 1, pc[1].y, false); }
     double acc = 0.0, accp = 0.0;      // accp: RESTRICTVCNL of phi (restrictR), same visiting order
 #pragma unroll
-    for (int b = 0; b < 2; b++)
+    for (int b = 0; b < 2; b++) {
+        const int j = j0 + b, idx = base + b * v.P;
+        const double2 cc = pc[b];
+        const double w0 = phiW(v, phi, idx, i0, cc.x, false), e1 = phiE(v, phi, idx + 1, i0 + 1, cc.y, false);
+        const double2 sS = b == 0 ? pS : pc[0], nN = b == 0 ? pc[1] : pN;
+        const double2 bx01 = ld2(fp.f[SUHMO_F_BX], idx); const double bx2 = fp.f[SUHMO_F_BX][idx + 2];
+        const double2 byS = ld2(fp.f[SUHMO_F_BY], idx), byN = ld2(fp.f[SUHMO_F_BY], idx + v.P);
+        const double2 B2 = ld2(fp.f[SUHMO_F_B], idx), Pi2 = ld2(fp.f[SUHMO_F_PI], idx), zb2 = ld2(fp.f[SUHMO_F_ZB], idx), mk2 = ld2(fp.f[SUHMO_F_MASK], idx);
+        const double2 rhs2 = ld2(fp.f[SUHMO_F_RHS], idx);
+        double2 a2 = make_double2(0.0, 0.0);
+        if (HAS_ALPHA) a2 = ld2(fp.f[SUHMO_F_ACOEF], idx);
+        (void)j;
 #pragma unroll
         for (int a = 0; a < 2; a++) {
-            int i = 2 * I + a, j = 2 * J + b;
-            int idx = cidx(v, i, j);
-            double c = phi[idx];
-            double e = phiE(v, phi, idx, i, c, false), w = phiW(v, phi, idx, i, c, false);
-            double n = phiN(v, phi, idx, j, c, false), s = phiS(v, phi, idx, j, c, false);
-            double bxW = fp.f[SUHMO_F_BX][idx], bxE = fp.f[SUHMO_F_BX][idx + 1];
-            double byS = fp.f[SUHMO_F_BY][idx], byN = fp.f[SUHMO_F_BY][idx + v.P];
+            const double c = a ? cc.y : cc.x, w = a ? cc.x : w0, e = a ? e1 : cc.y;
+            const double n = a ? nN.y : nN.x, s_ = a ? sS.y : sS.x;
+            const double bxW = a ? bx01.y : bx01.x, bxE = a ? bx2 : bx01.y;
             double nl, dnl;
-            nl_terms(ph, c, fp.f[SUHMO_F_B][idx], fp.f[SUHMO_F_PI][idx], fp.f[SUHMO_F_ZB][idx], fp.f[SUHMO_F_MASK][idx], nl, dnl);
-            double aterm = HAS_ALPHA ? v.alpha * fp.f[SUHMO_F_ACOEF][idx] : v.alpha;
-            double lofphi = lofphi_cell(v, aterm, c, e, w, n, s, bxE, bxW, byN, byS, nl);
-            acc = acc + (fp.f[SUHMO_F_RHS][idx] - lofphi) / 4.0;
+            nl_terms(ph, c, a ? B2.y : B2.x, a ? Pi2.y : Pi2.x, a ? zb2.y : zb2.x, a ? mk2.y : mk2.x, nl, dnl);
+            double aterm = HAS_ALPHA ? v.alpha * (a ? a2.y : a2.x) : v.alpha;
+            double lofphi = lofphi_cell(v, aterm, c, e, w, n, s_, bxE, bxW, a ? byN.y : byN.x, a ? byS.y : byS.x, nl);
+            acc = acc + ((a ? rhs2.y : rhs2.x) - lofphi) / 4.0;
             accp = accp + c / 4.0;
         }
+    }
     resC[cidx(vc, I, J)] = acc;
     if (phiC) phiC[cidx(vc, I, J)] = accp;
 }
