@@ -31,6 +31,7 @@ def perturbed_state(nx, ny, seed, mask_holes=False, ly=2.0e4):
 
 
 CASES = [
+    ("a3-2048x512-fused-kernels", 2048, 512, sy.A3_BC, sy.A3_PHYS, dict(), False, 1),    # depth 0 on the fused GSRB / bCoef kernels
     ("a3-32x16", 32, 16, sy.A3_BC, sy.A3_PHYS, dict(), False, 3),
     ("a3-128x32-perturbed", 128, 32, sy.A3_BC, sy.A3_PHYS, dict(), False, 3),
     ("yperiodic-mask", 64, 32, sy.CONV_BC, dict(sy.A3_PHYS, use_mask_gradients=1, cutOffbr=0.02, maxOffbr=0.08, cutOffB=1),
@@ -44,8 +45,9 @@ CASES = [
 def test_timestep_bitwise(oracle, hipmodel, name, nx, ny, bc, ph, mpo, holes, nsteps):
     m = dict(sy.A3_MODEL, **mpo)
     st = sy.shmip_initial_state(nx, ny) if name == "a3-32x16" else perturbed_state(nx, ny, 11, holes)
-    O = oracle.OracleModel(nx, ny, st["dx"], st["dy"], bc, ph, m, max_box=16, nthreads=2)
-    G = hipmodel.HipModel(nx, ny, st["dx"], st["dy"], bc, ph, m, max_box=16)
+    mb = 64 if nx >= 1024 else 16
+    O = oracle.OracleModel(nx, ny, st["dx"], st["dy"], bc, ph, m, max_box=mb, nthreads=8 if nx >= 1024 else 2)
+    G = hipmodel.HipModel(nx, ny, st["dx"], st["dy"], bc, ph, m, max_box=mb)
     O.set_state(st)
     G.set_state(st)
     v = lambda a: np.array(a)[1:-1, 1:-1]
