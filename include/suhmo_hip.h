@@ -210,6 +210,15 @@ int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t *mp, doubl
 int suhmo_level_moulin_source(suhmo_level_t *L, int n_moulins, const double *positions, const double *sigma,
                               const double *flux, double time_factor, double *integrals, suhmo_stream_t s);
 
+/* SHMIP cross-section table of the current state (AmrHydro::timeStepFAS post-processing, src/AmrHydro.cpp:3647-4102;
+ * columns of the results/postproc.dat files under exec/A_SHMIP, exec/B_SHMIP, ...): for every cell column i the row
+ *   x [km], ice-covered width, discharge, channelised part, distributed part (through x-face i, weighted with the
+ *   channelisation degree on the face), recharge by the external input and by melt upstream of the column (cumulative
+ *   from the upper end), mean effective pressure [MPa].
+ * table: HOST array nx x 8, row-major.  Uses QWX, CD, MR, PW, PI, MASK (and MSRC with use_moulin_source) as the last
+ * suhmo_level_timestep left them. */
+int suhmo_level_postproc_table(suhmo_level_t *L, const suhmo_model_params_t *mp, double *table, suhmo_stream_t s);
+
 /* multi-GPU strips: pack the `rows` owned rows next to side (0 = y-lo, 1 = y-hi) of a
  * field into a contiguous device buffer (rows x (nx+1) doubles) / unpack a neighbour's rows
  * into the ghost rows of that side.  The transport (RCCL send/recv) belongs to the host. */

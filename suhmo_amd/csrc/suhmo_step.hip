@@ -433,3 +433,57 @@ extern "C" int suhmo_level_moulin_source(suhmo_level_t *L, int n, const double *
     if (e != hipSuccess) { suhmo_set_error("moulin source: %s", hipGetErrorString(e)); return -2; }
     return 0;
 }
+
+
+// ------------------------------------------------------------------ SHMIP cross-section table
+// one thread per cell column, rows summed in ascending j (the order of the reference's BoxIterator per column)
+__global__ void k_postproc_columns(DV v, FP fp, suhmo_model_params_t mp, double *__restrict__ out /* 7 x nx */)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.nx) return;
+    const double *__restrict__ qx = fp.f[SUHMO_F_QWX], *__restrict__ cd = fp.f[SUHMO_F_CD], *__restrict__ mR = fp.f[SUHMO_F_MR];
+    const double *__restrict__ Pw = fp.f[SUHMO_F_PW], *__restrict__ Pi = fp.f[SUHMO_F_PI], *__restrict__ mk = fp.f[SUHMO_F_MASK];
+    const double *__restrict__ ms = mp.use_moulin_source ? fp.f[SUHMO_F_MSRC] : nullptr;
+    double qt = 0.0, qc = 0.0, qd = 0.0, ext = 0.0, mr = 0.0, yl = 0.0, avp = 0.0, cnt = 0.0;
+    for (int j = 0; j < v.ny; j++) {
+        int idx = cidx(v, i, j);
+        double cdec = 0.5 * (cd[idx] + cd[idx - 1]);                     // CellToEdge(chanDegree), :3696-3697
+        double q = qx[idx] * v.dy;
+        qt += q; qc += q * cdec; qd += q * (1.0 - cdec);                 // :3734-3738
+        bool ice = mk[idx] > 0.0;
+        double src = ms ? ms[idx] * mp.ramp + mp.distributed_input : (ice ? mp.distributed_input : 0.0);
+        if (ice) { ext += src * v.dy * v.dx; mr += (mR[idx] / mp.rho_w) * v.dy * v.dx; yl += v.dy; }    // :3766-3775
+        if (ice && Pi[idx] > 0.0) { avp += Pi[idx] - Pw[idx]; cnt += 1.0; }                             // :3778-3783
+    }
+    out[0 * v.nx + i] = yl; out[1 * v.nx + i] = qt; out[2 * v.nx + i] = qc; out[3 * v.nx + i] = qd;
+    out[4 * v.nx + i] = ext; out[5 * v.nx + i] = mr; out[6 * v.nx + i] = avp / fmax(cnt, 1.0) / 1.0e6;
+}
+extern "C" int suhmo_level_postproc_table(suhmo_level_t *L, const suhmo_model_params_t *mp, double *table, suhmo_stream_t s)
+{
+    ARG(L && mp && table);
+    HIPCHK(hipSetDevice(L->device));
+    hipStream_t st = (hipStream_t)s;
+    Depth &D = L->d[0];
+    if (D.v.ext[0] || D.v.ext[1] || L->desc.nx_global > 0) { suhmo_set_error("post-processing table on a rank strip / AMR patch is not built"); return -5; }
+    for (int f : {SUHMO_F_QWX, SUHMO_F_CD, SUHMO_F_MR, SUHMO_F_PW}) if (!D.fp.f[f]) { suhmo_set_error("no time step has run on this level"); return -1; }
+    if (mp->use_moulin_source && !D.fp.f[SUHMO_F_MSRC]) { suhmo_set_error("use_moulin_source without suhmo_level_moulin_source"); return -1; }
+    const int nx = D.v.nx;
+    double *dev = nullptr;
+    HIPCHK(hipMalloc(&dev, 7 * (size_t)nx * sizeof(double)));
+    hipLaunchKernelGGL(k_postproc_columns, dim3((nx + 63) / 64), dim3(64), 0, st, D.v, D.fp, *mp, dev);
+    std::vector<double> h(7 * (size_t)nx);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), dev, h.size() * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dev);
+    if (e != hipSuccess) { suhmo_set_error("postproc table: %s", hipGetErrorString(e)); return -2; }
+    double cext = 0.0, cmr = 0.0;
+    for (int i = nx - 1; i >= 0; i--) {                    // recharge upstream of the column: cumulative from the upper end
+        cext += h[4 * (size_t)nx + i]; cmr += h[5 * (size_t)nx + i];
+        double *row = table + 8 * (size_t)i;
+        row[0] = (i + 0.5) * D.v.dx / 1.0e3; row[1] = h[0 * (size_t)nx + i];
+        row[2] = -h[1 * (size_t)nx + i]; row[3] = -h[2 * (size_t)nx + i]; row[4] = -h[3 * (size_t)nx + i];
+        row[5] = cext; row[6] = cmr; row[7] = h[6 * (size_t)nx + i];
+    }
+    return 0;
+}

@@ -57,8 +57,15 @@ class HipModel:
     def get(self, name, ghosted=False):
         return self.level.get(self.FIELDS[name], ghosted=ghosted)
 
+    def postproc_table_device(self):
+        """SHMIP cross-section table reduced on the device (suhmo_level_postproc_table)"""
+        t = np.zeros((self.nx, 8))
+        check(capi.lib().suhmo_level_postproc_table(self.level.h, C.byref(self._mp), t.ctypes.data_as(C.POINTER(C.c_double)),
+                                                    self.level.stream))
+        return t
+
     def postproc_table(self):
-        """SHMIP cross-section table (src/AmrHydro.cpp:3647-4102) from the device-resident state"""
+        """SHMIP cross-section table (src/AmrHydro.cpp:3647-4102) from the device-resident state, reduced on the host"""
         mask = self.get("mask")
         src = np.where(mask > 0.0, self.model["distributed_input"], 0.0)
         return sy.shmip_postproc_table(self.dx, self.dy, self.get("qwx"), self.get("cd", ghosted=True), src,

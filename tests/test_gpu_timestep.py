@@ -103,6 +103,8 @@ def test_shmip_a_full_run(hipmodel, case):
         tot_p += p
         tot_v += nv
     table = G.postproc_table()
+    tdev = G.postproc_table_device()                      # the same table reduced on the device
+    assert np.all(np.abs(tdev - table) <= 1e-12 * np.max(np.abs(table), axis=0))
     G.close()
     orc = np.loadtxt(os.path.join(GOLD, "shmip_%s_oracle_run_table.dat" % case))
     run = json.load(open(os.path.join(GOLD, "shmip_%s_oracle_run.json" % case)))
