@@ -73,6 +73,9 @@ typedef struct suhmo_level_desc {
                             0, 0 = the level spans the domain in x.  A side of the rectangle that is not on the
                             domain boundary (and not a rank boundary) is a COARSE-FINE side: its ghost cells hold
                             data (suhmo_amr2_cf_interp) instead of the physical boundary condition */
+    int patch_j0, patch_ny; /* AMR patch cut into rank strips: rows of the WHOLE patch (0, 0 = this handle holds all of it);
+                            a y side of the strip that lies inside that range is a rank boundary (exchanged halo rows),
+                            the ends of the range are coarse-fine sides */
 } suhmo_level_desc_t;
 
 /* field ids (same numbering as the test oracle) */

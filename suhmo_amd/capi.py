@@ -47,7 +47,7 @@ class LevelDesc(C.Structure):
                 ("dx", C.c_double), ("dy", C.c_double), ("nbox", C.c_int), ("boxes", C.POINTER(C.c_int)),
                 ("max_box", C.c_int), ("alpha", C.c_double), ("beta", C.c_double),
                 ("bc", BC), ("phys", Phys), ("device", C.c_int), ("halo_rows", C.c_int),
-                ("i0", C.c_int), ("nx_global", C.c_int)]
+                ("i0", C.c_int), ("nx_global", C.c_int), ("patch_j0", C.c_int), ("patch_ny", C.c_int)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p)

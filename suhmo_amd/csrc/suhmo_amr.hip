@@ -31,6 +31,12 @@ int check_pair(suhmo_level *C, suhmo_level *F)
         for (int d = 0; d < 2; d++) {
             bool ok_lo = (clo[d] == 0) ? lo[d] >= 0 : lo[d] - clo[d] >= 2;      // coarse edge on the domain boundary: no margin needed
             bool ok_hi = (chi[d] == dom[d] - 1) ? hi[d] <= chi[d] : chi[d] - hi[d] >= 2;
+            if (d == 1) {
+                // rank strips: a rank boundary of the fine strip coincides with one of the coarse strip (same physical rows);
+                // a coarse-fine end must keep its coarse neighbour row on this rank (the reflux target lives there)
+                if (f.rk[0]) ok_lo = lo[1] == clo[1] && c.rk[0]; else if (c.rk[0]) ok_lo = lo[1] - clo[1] >= 1;
+                if (f.rk[1]) ok_hi = hi[1] == chi[1] && c.rk[1]; else if (c.rk[1]) ok_hi = chi[1] - hi[1] >= 1;
+            }
             if (!ok_lo || !ok_hi) { suhmo_set_error("amr: the fine patch is not properly nested in its coarse level (2 cells)"); return -1; }
         }
     }
@@ -54,7 +60,7 @@ __global__ void k_cf_interp(DV vf, double *__restrict__ f, DV vc, const double *
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     int dir, side, tt;
     if (t < 2 * vf.ny) { dir = 0; side = t / vf.ny; tt = t % vf.ny; if (!vf.cfx[side]) return; }
-    else { t -= 2 * vf.ny; if (t >= 2 * vf.nx) return; dir = 1; side = t / vf.nx; tt = t % vf.nx; if (!vf.ext[side]) return; }
+    else { t -= 2 * vf.ny; if (t >= 2 * vf.nx) return; dir = 1; side = t / vf.nx; tt = t % vf.nx; if (!vf.ext[side] || vf.rk[side]) return; }
     const double c_s = 8.0 / 15.0, c_b = 2.0 / 3.0, c_a = -0.2;
     const int tdir = 1 - dir;
     int gl = dir == 0 ? (side ? vf.nx : -1) : (side ? vf.ny : -1);            // local normal index of the ghost cell
@@ -102,7 +108,7 @@ __global__ void k_amr_reflux(DV vf, FP ff, DV vc, FP fc, double *__restrict__ lo
     const int ncx = vf.nx / 2, ncy = vf.ny / 2, ci0 = vf.i0 / 2, cj0 = vf.j0 / 2;
     int dir, side, T;
     if (t < 2 * ncy) { dir = 0; side = t / ncy; T = cj0 + t % ncy; }
-    else { t -= 2 * ncy; if (t >= 2 * ncx) return; dir = 1; side = t / ncx; T = ci0 + t % ncx; }
+    else { t -= 2 * ncy; if (t >= 2 * ncx) return; dir = 1; side = t / ncx; T = ci0 + t % ncx; if (vf.rk[side]) return; }   // rank boundary: no coarse-fine face
     int F = dir == 0 ? (side == 0 ? ci0 : ci0 + ncx) : (side == 0 ? cj0 : cj0 + ncy);      // coarse face index
     int outside = side == 0 ? F - 1 : F, ndomc = dir == 0 ? vc.nxg : vc.nyg;
     if (outside < 0 || outside > ndomc - 1) return;              // patch side on the domain boundary
@@ -164,6 +170,8 @@ extern "C" int suhmo_amr2_cf_interp(suhmo_level_t *C, suhmo_level_t *F, int fiel
     const DV &vf = F->d[0].v, &vc = C->d[0].v;
     double *pf = suhmo_field(F, 0, field_f), *pc = suhmo_field(C, 0, field_c);
     if (!pf || !pc) { suhmo_set_error("field allocation failed"); return -2; }
+    if (field_c == SUHMO_F_PHI && (rc = suhmo_ensure_phi_halo(C, 0, 1, (hipStream_t)s))) return rc;   // rank strips: the stencil reaches
+                                                                                                    // one coarse halo row
     int n = 2 * vf.ny + 2 * vf.nx;
     hipLaunchKernelGGL(k_cf_interp, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, vf, pf, vc, pc);
     HIPCHK(hipGetLastError());
@@ -238,6 +246,7 @@ extern "C" int suhmo_amr2_prolong2(suhmo_level_t *C, suhmo_level_t *F, int field
     Depth &DC = C->d[0], &DF = F->d[0];
     double *corr = suhmo_field(C, 0, field_c);
     if (!corr) { suhmo_set_error("field allocation failed"); return -2; }
+    if ((rc = suhmo_level_exchange(C, 0, field_c, s))) return rc;         // rank strips: one halo row of the coarse correction
     if ((rc = suhmo_level_fill_ghosts(C, 0, field_c, 0, s))) return rc;
     DF.phi_fresh = 0;
     hipLaunchKernelGGL(k_amr_prolong2, dim3((DF.v.nx + 63) / 64, (DF.v.ny + 3) / 4), dim3(64, 4), 0, (hipStream_t)s, DF.v, DF.fp.f[SUHMO_F_PHI], DC.v, corr);
@@ -322,16 +331,25 @@ extern "C" int suhmo_amr2_solve(suhmo_level_t *C, suhmo_level_t *F, const suhmo_
 // ================================================================ N nested levels
 // levels[0] = base level, levels[l] = patch of level l (properly nested in level l-1): oracle/amrn.c states the same
 // cycle.  The two-level entry points above are the nlev = 2 case.
+// Rank strips: a rank holds of every level the rows of its own physical slab, so levels[l] may be NULL on a rank the
+// patch of level l does not reach.  Such a rank still runs the coarse half of every pair it has a coarse strip of (the
+// FAS right-hand side res' + L(phi) replaces rhs on the WHOLE coarse level) and every base-level collective.
 namespace {
-int cf_phi(suhmo_level_t **lv, int l, suhmo_stream_t s)      // head of level l: coarse-fine ghosts from level l-1
+// head of level l: coarse-fine ghosts from level l-1.  A rank with a strip of level l-1 but none of level l MIRRORS the
+// halo demand the interpolation puts on level l-1, so that every rank of that level's communicator runs the same sequence
+// of exchanges (they are demand-driven by Depth::phi_fresh, which must evolve identically on all of them).
+int cf_phi(suhmo_level_t **lv, int l, suhmo_stream_t s)
 {
     if (l == 0) return 0;
-    return suhmo_amr2_cf_interp(lv[l - 1], lv[l], SUHMO_F_PHI, SUHMO_F_PHI, s);
+    if (lv[l]) return suhmo_amr2_cf_interp(lv[l - 1], lv[l], SUHMO_F_PHI, SUHMO_F_PHI, s);
+    if (lv[l - 1]) return suhmo_ensure_phi_halo(lv[l - 1], 0, 1, (hipStream_t)s);
+    return 0;
 }
 // RES of level l-1 = rhs - [applyOpI(phi) + reflux from level l]; LPHI of level l-1 keeps the plain L(phi)
 int composite_residual(suhmo_level_t **lv, int l, suhmo_stream_t s)
 {
     suhmo_level *C = lv[l - 1], *F = lv[l];
+    if (!C) return 0;
     hipStream_t st = (hipStream_t)s;
     int rc;
     if ((rc = cf_phi(lv, l - 1, s))) return rc;
@@ -339,10 +357,12 @@ int composite_residual(suhmo_level_t **lv, int l, suhmo_stream_t s)
     double *res = suhmo_field(C, 0, SUHMO_F_RES), *lphi = suhmo_field(C, 0, SUHMO_F_LPHI);
     HIPCHK(hipMemcpyAsync(res, lphi, C->d[0].elems * sizeof(double), hipMemcpyDeviceToDevice, st));
     if ((rc = cf_phi(lv, l, s))) return rc;
-    const DV &vf = F->d[0].v, &vc = C->d[0].v;
-    int n = vf.ny + vf.nx;
-    hipLaunchKernelGGL(k_amr_reflux, dim3((n + 255) / 256), dim3(256), 0, st, vf, F->d[0].fp, vc, C->d[0].fp, res);
-    HIPCHK(hipGetLastError());
+    if (F) {
+        const DV &vf = F->d[0].v, &vc = C->d[0].v;
+        int n = vf.ny + vf.nx;
+        hipLaunchKernelGGL(k_amr_reflux, dim3((n + 255) / 256), dim3(256), 0, st, vf, F->d[0].fp, vc, C->d[0].fp, res);
+        HIPCHK(hipGetLastError());
+    }
     return suhmo_level_axby(C, 0, SUHMO_F_RES, SUHMO_F_RES, SUHMO_F_RHS, -1.0, 1.0, s);
 }
 int vcycle_amr(suhmo_level_t **lv, int l, const suhmo_solver_params_t *sp, suhmo_stream_t s)
@@ -351,38 +371,59 @@ int vcycle_amr(suhmo_level_t **lv, int l, const suhmo_solver_params_t *sp, suhmo
     suhmo_level *C = lv[l - 1], *F = lv[l];
     hipStream_t st = (hipStream_t)s;
     int rc;
-    Depth &DC = C->d[0];
-    const size_t cbytes = DC.elems * sizeof(double);
-    double *rhs0 = suhmo_field(C, 0, SUHMO_F_RHS0), *phiold = suhmo_field(C, 0, SUHMO_F_PHIOLD), *corr = suhmo_field(C, 0, SUHMO_F_CORR);
-    if (!rhs0 || !phiold || !corr) { suhmo_set_error("field allocation failed"); return -2; }
     if ((rc = cf_phi(lv, l, s))) return rc;
-    if (sp->bcoeff_otf) {
-        if ((rc = cf_phi(lv, l - 1, s))) return rc;            // the coarser level's own coarse-fine ghosts (its gradient reads them)
-        if ((rc = suhmo_amr2_fine_update_operator(C, F, s))) return rc;
+    if (sp->bcoeff_otf) {                                          // UpdateOperator of level l with its coarser level
+        if ((rc = cf_phi(lv, l - 1, s))) return rc;                // the coarser level's own coarse-fine ghosts (its gradient reads them)
+        if (F && (rc = suhmo_grad_cc(F, 0, st))) return rc;
+        if (C && (rc = suhmo_grad_cc(C, 0, st))) return rc;        // every rank of the coarser level's communicator (gradient halo exchange)
+        if (F) {
+            if ((rc = suhmo_amr2_cf_interp(C, F, SUHMO_F_GRADX, SUHMO_F_GRADX, s))) return rc;
+            if ((rc = suhmo_amr2_cf_interp(C, F, SUHMO_F_GRADY, SUHMO_F_GRADY, s))) return rc;
+            if ((rc = suhmo_re_bcoef_unfused(F, 0, st))) return rc;
+        }
     }
-    if ((rc = suhmo_level_gsrb(F, 0, sp->num_smooth, s))) return rc;                       // relaxNF
-    if ((rc = suhmo_amr2_average(C, F, SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc;           // AMRRestrictS(skip_res)
+    if (F) {
+        if ((rc = suhmo_level_gsrb(F, 0, sp->num_smooth, s))) return rc;                       // relaxNF
+        if ((rc = suhmo_amr2_average(C, F, SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc;           // AMRRestrictS(skip_res)
+    } else if (C) C->d[0].phi_fresh = 0;                                                       // phi of level l-1 changed on the other ranks
     if ((rc = cf_phi(lv, l, s))) return rc;
-    if ((rc = suhmo_level_residual(F, 0, s))) return rc;                                   // res_l = rhs_l - L_l(phi_l)
-    if ((rc = composite_residual(lv, l, s))) return rc;
-    if ((rc = suhmo_amr2_average(C, F, SUHMO_F_RES, SUHMO_F_RES, s))) return rc;
-    HIPCHK(hipMemcpyAsync(rhs0, DC.fp.f[SUHMO_F_RHS], cbytes, hipMemcpyDeviceToDevice, st));
-    if ((rc = suhmo_level_axby(C, 0, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
-    HIPCHK(hipMemcpyAsync(phiold, DC.fp.f[SUHMO_F_PHI], cbytes, hipMemcpyDeviceToDevice, st));
+    if (F && (rc = suhmo_level_residual(F, 0, s))) return rc;                                  // res_l = rhs_l - L_l(phi_l)
+    double *rhs0 = nullptr, *phiold = nullptr;
+    size_t cbytes = 0;
+    if (C) {
+        Depth &DC = C->d[0];
+        cbytes = DC.elems * sizeof(double);
+        rhs0 = suhmo_field(C, 0, SUHMO_F_RHS0); phiold = suhmo_field(C, 0, SUHMO_F_PHIOLD);
+        if (!rhs0 || !phiold || !suhmo_field(C, 0, SUHMO_F_CORR)) { suhmo_set_error("field allocation failed"); return -2; }
+        if ((rc = composite_residual(lv, l, s))) return rc;
+        if (F && (rc = suhmo_amr2_average(C, F, SUHMO_F_RES, SUHMO_F_RES, s))) return rc;
+        HIPCHK(hipMemcpyAsync(rhs0, DC.fp.f[SUHMO_F_RHS], cbytes, hipMemcpyDeviceToDevice, st));
+        if ((rc = suhmo_level_axby(C, 0, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
+        if ((rc = suhmo_level_exchange(C, 0, SUHMO_F_RHS, s))) return rc;                      // rank strips: rhs halo rows
+        HIPCHK(hipMemcpyAsync(phiold, DC.fp.f[SUHMO_F_PHI], cbytes, hipMemcpyDeviceToDevice, st));
+    }
     if ((rc = vcycle_amr(lv, l - 1, sp, s))) return rc;
-    HIPCHK(hipMemcpyAsync(DC.fp.f[SUHMO_F_RHS], rhs0, cbytes, hipMemcpyDeviceToDevice, st));
-    if ((rc = suhmo_level_axby(C, 0, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) return rc;
-    if ((rc = suhmo_amr2_prolong2(C, F, SUHMO_F_CORR, s))) return rc;                      // AMRProlongS_2
+    if (C) {
+        Depth &DC = C->d[0];
+        HIPCHK(hipMemcpyAsync(DC.fp.f[SUHMO_F_RHS], rhs0, cbytes, hipMemcpyDeviceToDevice, st));   // rhs0 was copied with its halo rows
+        if ((rc = suhmo_level_axby(C, 0, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) return rc;
+        if (F) {
+            if ((rc = suhmo_amr2_prolong2(C, F, SUHMO_F_CORR, s))) return rc;                  // AMRProlongS_2
+        } else if ((rc = suhmo_level_exchange(C, 0, SUHMO_F_CORR, s))) return rc;              // the exchange inside prolong2, for the ranks that prolong
+    }
     if ((rc = cf_phi(lv, l, s))) return rc;
-    return suhmo_level_gsrb(F, 0, sp->num_smooth, s);
+    if (F) return suhmo_level_gsrb(F, 0, sp->num_smooth, s);
+    return 0;
 }
 int check_hierarchy(suhmo_level_t **lv, int nlev)
 {
-    ARG(lv && nlev >= 1 && nlev <= 8);
-    for (int l = 0; l < nlev; l++) ARG(lv[l]);
+    ARG(lv && nlev >= 1 && nlev <= 8 && lv[0]);
     const DV &b = lv[0]->d[0].v;
-    if (b.i0 || b.j0 || b.nx != b.nxg || b.ny != b.nyg) { suhmo_set_error("amr: level 0 must span the domain"); return -1; }
-    for (int l = 1; l < nlev; l++) { int rc = check_pair(lv[l - 1], lv[l]); if (rc) return rc; }
+    if (b.i0 || b.nx != b.nxg) { suhmo_set_error("amr: level 0 must span the domain in x"); return -1; }
+    for (int l = 1; l < nlev; l++) {
+        if (lv[l] && !lv[l - 1]) { suhmo_set_error("amr: a rank holding a strip of level %d must hold one of level %d", l, l - 1); return -1; }
+        if (lv[l]) { int rc = check_pair(lv[l - 1], lv[l]); if (rc) return rc; }
+    }
     return 0;
 }
 }  // namespace
@@ -391,14 +432,17 @@ extern "C" int suhmo_amr_residual(suhmo_level_t **lv, int nlev, double *norm, su
 {
     int rc = check_hierarchy(lv, nlev); if (rc) return rc;
     HIPCHK(hipSetDevice(lv[0]->device));
-    const int top = nlev - 1;
+    int top = nlev - 1;
     if ((rc = cf_phi(lv, top, s))) return rc;
-    if ((rc = suhmo_level_residual(lv[top], 0, s))) return rc;                             // AMRResidualNF on the finest level
+    if (lv[top] && (rc = suhmo_level_residual(lv[top], 0, s))) return rc;                  // AMRResidualNF on the finest level
     for (int l = top; l >= 1; l--) if ((rc = composite_residual(lv, l, s))) return rc;
-    for (int l = top; l >= 1; l--) if ((rc = suhmo_amr2_set_covered(lv[l - 1], lv[l], SUHMO_F_RES, 0.0, s))) return rc;   // AMRNorm
+    for (int l = top; l >= 1; l--)
+        if (lv[l] && (rc = suhmo_amr2_set_covered(lv[l - 1], lv[l], SUHMO_F_RES, 0.0, s))) return rc;   // AMRNorm
     if (norm) {
         double m = 0.0;
-        for (int l = 0; l <= top; l++) { double a = 0.0; if ((rc = suhmo_level_norm(lv[l], 0, SUHMO_F_RES, 0, &a, s))) return rc; if (a > m) m = a; }
+        for (int l = 0; l <= top; l++)
+            if (lv[l]) { double a = 0.0; if ((rc = suhmo_level_norm(lv[l], 0, SUHMO_F_RES, 0, &a, s))) return rc; if (a > m) m = a; }
+        if (lv[0]->ar && (rc = lv[0]->ar(lv[0]->user, &m))) return rc;                    // ranks without the finer levels
         *norm = m;
     }
     return 0;

@@ -33,6 +33,7 @@ struct DV {
     int ext[2];        // y side is a rank boundary or a coarse-fine side: ghost rows hold data
     int i0, nxg;       // AMR patch: global column of local i = 0, columns of the whole (refined) domain
     int cfx[2];        // x side is a coarse-fine side: ghost columns hold interpolated data
+    int rk[2];         // y side is a RANK boundary (halo rows exchanged with a neighbour); ext && !rk = coarse-fine side
 };
 
 struct FP { double *f[SUHMO_F_COUNT]; };

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_gsrb_pass_simple(DV v, FP fp, suhmo_phy
 static void launch_simple(suhmo_level *L, int depth, int pass, int ext_rows, hipStream_t st)
 {
     Depth &D = L->d[depth];
-    int jlo = D.v.ext[0] ? -ext_rows : 0, jhi = D.v.ny - 1 + (D.v.ext[1] ? ext_rows : 0);
+    int jlo = D.v.rk[0] ? -ext_rows : 0, jhi = D.v.ny - 1 + (D.v.rk[1] ? ext_rows : 0);
     dim3 blk(64, 4), grd(((D.v.nx + 1) / 2 + 63) / 64, (jhi - jlo + 1 + 3) / 4);
     if (D.v.alpha != 0.0)
         hipLaunchKernelGGL(k_gsrb_pass_simple<true>, grd, blk, 0, st, D.v, D.fp, L->ph, pass, jlo, jhi);
@@ -362,6 +362,8 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
                 }
                 int want = 2 * (sweeps - it) - (pass + 1) + tail;          // halo rows the work after this pass can use
                 int E = ext ? (F - 1 < want ? F - 1 : want) : 0;
+                if (L->desc.nx_global > 0) E = 0;                          // AMR patch strips: the coarse-fine ghost columns of halo
+                                                                           // rows are not exchanged -> no redundant advance
                 launch_simple(L, depth, pass, E, st);
                 if (ext) { F = E; D.phi_fresh = F; }
             }

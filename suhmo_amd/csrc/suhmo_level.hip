@@ -55,6 +55,10 @@ static void make_dv(DV &v, const suhmo_level_desc_t &d, int depth)
     v.ext[1] = (!whole) && (d.j0 + d.ny < d.ny_global || d.bc.periodic[1]);
     v.cfx[0] = v.i0 > 0;
     v.cfx[1] = v.i0 + v.nx < v.nxg;
+    if (d.nx_global > 0) {               // AMR patch: rank boundaries only inside the patch's own row range
+        const int pj0 = d.patch_ny > 0 ? d.patch_j0 : d.j0, pj1 = d.patch_ny > 0 ? d.patch_j0 + d.patch_ny : d.j0 + d.ny;
+        v.rk[0] = d.j0 > pj0; v.rk[1] = d.j0 + d.ny < pj1;
+    } else { v.rk[0] = v.ext[0]; v.rk[1] = v.ext[1]; }
 }
 
 double *suhmo_field(suhmo_level *L, int depth, int field)
@@ -76,6 +80,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     ARG(desc->ny_global >= desc->ny && desc->j0 >= 0 && desc->j0 + desc->ny <= desc->ny_global);
     ARG(desc->i0 >= 0 && (desc->nx_global == 0 ? desc->i0 == 0 : desc->i0 + desc->nx <= desc->nx_global));
     ARG(desc->i0 % 2 == 0);                  // colour parity is taken from the local column
+    ARG(desc->patch_ny == 0 || (desc->nx_global > 0 && desc->patch_j0 <= desc->j0 && desc->j0 + desc->ny <= desc->patch_j0 + desc->patch_ny));
     ARG((long)(desc->nx + 64) * (long)(desc->ny + 2 * (desc->halo_rows < 1 ? 1 : desc->halo_rows)) < (1L << 31));
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
@@ -938,7 +943,9 @@ int suhmo_grad_cc(suhmo_level *L, int depth, hipStream_t st)
 {
     Depth &D = L->d[depth];
     if (!suhmo_field(L, depth, SUHMO_F_GRADX) || !suhmo_field(L, depth, SUHMO_F_GRADY) || !suhmo_field(L, depth, SUHMO_F_RE)) return -2;
+    int rc = suhmo_ensure_phi_halo(L, depth, 1, st); if (rc) return rc;
     hipLaunchKernelGGL(k_gradcc, grid2d(D.v.nx, D.v.ny), BLK2D, 0, st, D.v, D.fp, L->ph.use_mask_gradients);
+    rc = exchange_fields(L, depth, {SUHMO_F_GRADX, SUHMO_F_GRADY}, st); if (rc) return rc;    // lvlgradH.exchange() :1490
     int n = 2 * D.v.ny + 2 * D.v.nx;
     hipLaunchKernelGGL(k_grad_ghosts, dim3((n + 255) / 256), dim3(256), 0, st, D.v, D.fp.f[SUHMO_F_GRADX], D.fp.f[SUHMO_F_GRADY]);
     HIPCHK(hipGetLastError());

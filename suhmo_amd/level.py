@@ -41,7 +41,7 @@ class HipLevel:
     """One AMR level (or this rank's strip of rows of it) resident in HBM."""
 
     def __init__(self, nx, ny, dx, dy, bc, phys, alpha=0.0, beta=-1.0, max_box=64, boxes=None,
-                 j0=0, ny_global=None, device=0, halo_rows=1, stream=None, i0=0, nx_global=0):
+                 j0=0, ny_global=None, device=0, halo_rows=1, stream=None, i0=0, nx_global=0, patch_j0=0, patch_ny=0):
         self.nx, self.ny, self.dx, self.dy = nx, ny, dx, dy
         self.j0, self.ny_global = j0, (ny if ny_global is None else ny_global)
         self.stream = C.c_void_p(stream) if stream else C.c_void_p(0)
@@ -56,6 +56,7 @@ class HipLevel:
         d.max_box, d.alpha, d.beta = max_box, alpha, beta
         d.bc, d.phys, d.device, d.halo_rows = _bc(bc), _phys(phys), device, halo_rows
         d.i0, d.nx_global = i0, nx_global            # AMR patch (see HipAmr2)
+        d.patch_j0, d.patch_ny = patch_j0, patch_ny  # ... cut into rank strips
         self._desc = d
         h = C.c_void_p()
         check(capi.lib().suhmo_level_create(C.byref(h), C.byref(d)))

@@ -25,10 +25,13 @@ from .capi import check
 class StripExchanger:
     """Owns the hook closures for one level (keep a reference alive as long as the level)."""
 
-    def __init__(self, level, transport, rank, world, periodic_y):
+    def __init__(self, level, transport, rank, world, periodic_y, peers=None):
         self.level, self.tr, self.rank, self.world = level, transport, rank, world
         self.lo = rank - 1 if rank > 0 else (world - 1 if periodic_y else None)
         self.hi = rank + 1 if rank < world - 1 else (0 if periodic_y else None)
+        if peers is not None:          # rank / world index a sub-group (AMR patch strips): the transport addresses peers[k]
+            self.lo = peers[self.lo] if self.lo is not None else None
+            self.hi = peers[self.hi] if self.hi is not None else None
         self._bufs = {}
         self._ex = capi.EXCHANGE_FN(self._exchange)
         self._ar = capi.ALLREDUCE_FN(self._allreduce)
@@ -94,9 +97,9 @@ class StripExchanger:
 class TorchDistTransport:
     """torch.distributed point-to-point; buffers are torch tensors on `device`."""
 
-    def __init__(self, dist, device):
+    def __init__(self, dist, device, group=None):
         import torch
-        self.torch, self.dist, self.device = torch, dist, device
+        self.torch, self.dist, self.device, self.group = torch, dist, device, group
         self._ops = {}
 
     def alloc(self, n):
@@ -121,12 +124,17 @@ class TorchDistTransport:
             if tag is not None:
                 self._ops[tag] = ops      # buffers are fixed per (depth, fields): build the op list once
         if ops:
+            host_staged = self.dist.get_backend() != "nccl" and self.device.type == "cuda"   # gloo moves device tensors through the host on its own streams
+            if host_staged:
+                self.torch.cuda.synchronize()
             for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
+            if host_staged:
+                self.torch.cuda.synchronize()
 
     def allreduce_max(self, rank, v):
         t = self.torch.tensor([v], dtype=self.torch.float64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
 
@@ -137,7 +145,7 @@ class ThreadTransport:
 
     def __init__(self, world):
         self.world = world
-        self.barrier = threading.Barrier(world)
+        self.barrier = threading.Barrier(world, timeout=120)      # a rank that skips a collective breaks the barrier instead of hanging
         self.box = {}
         self.vals = [0.0] * world
         self._hip = C.CDLL("libamdhip64.so")
@@ -231,3 +239,35 @@ def attach(level, dist, rank, world, periodic_y=False):
     level._exchanger = ex
     ex.exchange_static()
     return ex
+
+
+def attach_amr(levels, ranges, dist, rank, world):
+    """AMR hierarchy cut into rank strips: levels[l] is this rank's strip of level l (None where the patch does not reach
+    this rank's slab), ranges[l] = ranks that hold a strip of level l (ascending rows, the same list on every rank).
+    Every level gets its own communicator over exactly those ranks (native RCCL on the "nccl" backend, torch.distributed
+    P2P otherwise).  COLLECTIVE over all ranks."""
+    import torch
+    native = dist.get_backend() == "nccl" and os.environ.get("SUHMO_TRANSPORT", "rccl") != "torch"
+    lib = capi.lib()
+    if native:
+        path = os.environ.get("SUHMO_LIBRCCL")
+        check(lib.suhmo_rccl_load(path.encode() if path else None))
+    dev = torch.device("cuda", torch.cuda.current_device())       # halo staging buffers are device memory on every backend
+    keep = []
+    for l, part in enumerate(ranges):
+        group = dist.new_group(part) if not native else None          # collective over the world, also for non-members
+        if native:
+            idbuf = (C.c_char * 128)()
+            if rank == part[0]:
+                check(lib.suhmo_rccl_unique_id(C.cast(idbuf, C.c_void_p)))
+            t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8).to(dev)
+            dist.broadcast(t, part[0])
+            if levels[l] is not None:
+                attach_rccl(levels[l], part.index(rank), len(part), False, dist, unique_id=bytes(t.cpu().tolist()))
+        elif levels[l] is not None:
+            tr = TorchDistTransport(dist, dev, group)
+            ex = StripExchanger(levels[l], tr, part.index(rank), len(part), False, peers=part)
+            ex.exchange_static()
+            levels[l]._exchanger = ex
+            keep.append(ex)
+    return keep

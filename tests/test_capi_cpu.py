@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(capi.Phys) == 7 * 8 + 3 * 4 + 4
     assert ctypes.sizeof(capi.BC) == 16 + 32 + 8
     assert ctypes.sizeof(capi.SolverParams) == 5 * 4 + 4 + 3 * 8 + 2 * 4
-    assert ctypes.sizeof(capi.LevelDesc) == 16 + 16 + 4 + 4 + 8 + 4 + 4 + 16 + 56 + 72 + 4 + 4 + 8
+    assert ctypes.sizeof(capi.LevelDesc) == 16 + 16 + 4 + 4 + 8 + 4 + 4 + 16 + 56 + 72 + 4 + 4 + 8 + 8
 
 
 def test_fails_loudly_without_gpu(lib):
