@@ -185,7 +185,10 @@ int suhmo_level_solve(suhmo_level_t *L, const suhmo_solver_params_t *sp, int *it
  * (src/AmrHydro.cpp:2254-3460) for a single level with distributed water input and the explicit
  * gap-height update: Picard loop { lagged Re / Qw / melt rate -> RHS_h (:2920-3079) ->
  * SolveForHead_nl (:3119) -> convergence test (:3169-3228) } then CalcRHS_gapHeightFAS (:2069-2171)
- * + forward Euler (:3394-3408).  PHI holds the head, B the gap height (both updated in place). */
+ * + forward Euler (:3394-3408).  PHI holds the head, B the gap height (both updated in place).
+ * On a rank strip (desc.j0 / ny_global, hooks attached) every rank calls it with the same arguments: the halo rows of
+ * b, mR, grad h and RHS_h travel through the exchange hook where the reference calls exchange(), the Picard test is
+ * MAX all-reduced, and the result equals the single-process one bit for bit. */
 typedef struct suhmo_model_params {
     double rho_i, rho_w, gravity;      /* suhmo_params.cpp:51-53 */
     double G, L, ct, cw;               /* suhmo.GeoFlux, LatHeat, ct, cw */
@@ -209,7 +212,8 @@ int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t *mp, doubl
  * with the reference's 3 x 3 Gauss-Legendre rule per cell, each normalised by its integral over the level;
  * time_factor = max(1 - runoff sin(2 pi (t - t_restart) / 86400), 0).  Result in SUHMO_F_MSRC (m/s);
  * integrals (m2, n values) are returned when the pointer is not NULL.  exp() is the device library's: results
- * agree with the CPU restatement to ~1e-14 relative, not bitwise. */
+ * agree with the CPU restatement to ~1e-14 relative, not bitwise.  On a rank strip every rank integrates over the
+ * whole level itself (the integrand is analytic), in the single-process order: no communication, same bits. */
 int suhmo_level_moulin_source(suhmo_level_t *L, int n_moulins, const double *positions, const double *sigma,
                               const double *flux, double time_factor, double *integrals, suhmo_stream_t s);
 
@@ -221,6 +225,11 @@ int suhmo_level_moulin_source(suhmo_level_t *L, int n_moulins, const double *pos
  * table: HOST array nx x 8, row-major.  Uses QWX, CD, MR, PW, PI, MASK (and MSRC with use_moulin_source) as the last
  * suhmo_level_timestep left them. */
 int suhmo_level_postproc_table(suhmo_level_t *L, const suhmo_model_params_t *mp, double *table, suhmo_stream_t s);
+/* the same in two steps for a level cut into rank strips: column sums over this strip's rows (HOST array 8 x nx: width,
+ * Q, Q channelised, Q distributed, external recharge, melt recharge, sum and count of Pi - Pw), which the host adds over
+ * the ranks (the reference: MPI_Allreduce, src/AmrHydro.cpp:3818-4013), and the table from the added sums */
+int suhmo_level_postproc_partial(suhmo_level_t *L, const suhmo_model_params_t *mp, double *sums, suhmo_stream_t s);
+int suhmo_postproc_finish(const double *sums, int nx, double dx, double *table);
 
 /* multi-GPU strips: pack the `rows` owned rows next to side (0 = y-lo, 1 = y-hi) of a
  * field into a contiguous device buffer (rows x (nx+1) doubles) / unpack a neighbour's rows

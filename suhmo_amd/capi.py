@@ -70,7 +70,7 @@ SYMBOLS = [
     "suhmo_level_rccl_exchanges",
     "suhmo_amr2_cf_interp", "suhmo_amr2_average", "suhmo_amr2_fine_update_operator", "suhmo_amr2_residual",
     "suhmo_amr2_vcycle", "suhmo_amr2_solve", "suhmo_level_moulin_source", "suhmo_amr2_prolong2", "suhmo_amr2_set_covered",
-    "suhmo_amr_residual", "suhmo_amr_vcycle", "suhmo_amr_solve", "suhmo_level_postproc_table",
+    "suhmo_amr_residual", "suhmo_amr_vcycle", "suhmo_amr_solve", "suhmo_level_postproc_table", "suhmo_level_postproc_partial", "suhmo_postproc_finish",
 ]
 
 
@@ -130,6 +130,8 @@ def lib():
     L.suhmo_level_rccl_exchanges.restype = C.c_long
     L.suhmo_level_moulin_source.argtypes = [vp, ci, dp, dp, dp, C.c_double, dp, vp]
     L.suhmo_level_postproc_table.argtypes = [vp, C.POINTER(ModelParams), dp, vp]
+    L.suhmo_level_postproc_partial.argtypes = [vp, C.POINTER(ModelParams), dp, vp]
+    L.suhmo_postproc_finish.argtypes = [dp, C.c_int, C.c_double, dp]
     L.suhmo_amr_residual.argtypes = [C.POINTER(vp), ci, dp, vp]
     L.suhmo_amr_vcycle.argtypes = [C.POINTER(vp), ci, C.POINTER(SolverParams), vp]
     L.suhmo_amr_solve.argtypes = [C.POINTER(vp), ci, C.POINTER(SolverParams), C.POINTER(ci), dp, vp]

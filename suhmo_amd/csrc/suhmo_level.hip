@@ -419,6 +419,15 @@ static int exchange_fields(suhmo_level *L, int depth, std::initializer_list<int>
     if (!rc) for (int f : fields) if (f == SUHMO_F_PHI) L->d[depth].phi_fresh = suhmo_halo_rows(v);
     return rc;
 }
+int suhmo_exchange_list(suhmo_level *L, int depth, const int *fields, int n, hipStream_t st)    // for suhmo_step.hip
+{
+    const DV &v = L->d[depth].v;
+    if (!(L->ex && (v.ext[0] || v.ext[1]))) return 0;
+    for (int k = 0; k < n; k++) if (!suhmo_field(L, depth, fields[k])) return -2;
+    int rc = L->ex(L->user, L, depth, fields, n, (suhmo_stream_t)st);
+    if (!rc) for (int k = 0; k < n; k++) if (fields[k] == SUHMO_F_PHI) L->d[depth].phi_fresh = suhmo_halo_rows(v);
+    return rc;
+}
 // strips: make sure `need` halo rows of phi hold the neighbours' current values.  Every kernel that
 // changes phi lowers Depth::phi_fresh (a colour pass that also advances the halo rows redundantly loses
 // one row, a K-sweep fused launch 2K), so an exchange happens only when the stencil about to run would
@@ -965,10 +974,7 @@ int suhmo_re_bcoef_unfused(suhmo_level *L, int depth, hipStream_t st)
 int suhmo_grad_re(suhmo_level *L, int depth, hipStream_t st)
 {
     Depth &D = L->d[depth];
-    if (!suhmo_field(L, depth, SUHMO_F_GRADX) || !suhmo_field(L, depth, SUHMO_F_GRADY) || !suhmo_field(L, depth, SUHMO_F_RE)) return -2;
-    hipLaunchKernelGGL(k_gradcc, grid2d(D.v.nx, D.v.ny), BLK2D, 0, st, D.v, D.fp, L->ph.use_mask_gradients);
-    int n = 2 * D.v.ny + 2 * D.v.nx;
-    hipLaunchKernelGGL(k_grad_ghosts, dim3((n + 255) / 256), dim3(256), 0, st, D.v, D.fp.f[SUHMO_F_GRADX], D.fp.f[SUHMO_F_GRADY]);
+    int rc = suhmo_grad_cc(L, depth, st); if (rc) return rc;       // rank strips: phi halo row + exchange of the gradient
     hipLaunchKernelGGL(k_re, grid2d(D.v.nx + 2, D.v.ny + 2), BLK2D, 0, st, D.v, D.fp, L->ph);
     HIPCHK(hipGetLastError());
     return 0;

@@ -9,7 +9,10 @@
 //   [III] the same chain with the new head, CalcRHS_gapHeightFAS (:2069-2171), forward Euler (:3406)
 // Head = PHI, gap height = B: both stay in HBM across Picard iterations and timesteps; per step
 // the host sees two scalars per Picard iteration (max head, max relative change).
-// The diffusive term (suhmo.diffFactor, COMPUTEDIFTERM2D) is not built: diffFactor must be 0.
+// On a rank strip (suhmo_level_desc.j0 / ny_global) the same step runs on every rank: wherever the reference exchanges
+// a field (b, mR, grad h, RHS halos for the redundant halo-row relaxation) the strip's exchange hook is called, the
+// Picard test is MAX all-reduced; the moulin integrals are evaluated redundantly over the whole domain (analytic
+// integrand, no data), so the result does not depend on the partition bit for bit.
 #include "suhmo_common.h"
 #include <cmath>
 
@@ -162,8 +165,10 @@ static int reduce_max(suhmo_level *L, const double *h, const double *hl, double 
     HIPCHK(hipMemcpyAsync(L->hscratch, L->scratch, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     *out = L->hscratch[0];
+    if (L->ar && (D.v.ext[0] || D.v.ext[1])) { int rc = L->ar(L->user, out); if (rc) return rc; }   // computeMax / norm over all ranks
     return 0;
 }
+static int exchange1(suhmo_level *L, int f, hipStream_t st) { return suhmo_exchange_list(L, 0, &f, 1, st); }
 
 // grad h (cell centred, ghosted) and Re on the ghosted level: reuses the WFlx_level kernels of
 // suhmo_level.hip (identical arithmetic: NEWMACGRAD + EdgeToCell + ExtrapGhostCells + COMPUTERE)
@@ -193,6 +198,7 @@ __global__ void k_extrap_ghosts(DV v, double *__restrict__ g)
     t -= 2 * v.ny;
     if (t < 2 * v.nx) {
         int side = t / v.nx, i = t % v.nx;
+        if (v.ext[side]) return;                             // rank boundary: exchanged
         if (side == 0) { int idx = cidx(v, i, 0); g[idx - v.P] = v.per[1] ? g[idx + (v.ny - 1) * v.P] : 2.0 * g[idx] - g[idx + v.P]; }
         else { int idx = cidx(v, i, v.ny - 1); g[idx + v.P] = v.per[1] ? g[idx - (v.ny - 1) * v.P] : 2.0 * g[idx] - g[idx - v.P]; }
     }
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256) void k_dcoef_faces(DV v, FP fp, suhmo_phys_t p
         int im = dir == 0 ? idx - 1 : idx - v.P;
         double m = mk[idx], mm1 = mk[im], mec;
         if (fabs(m - mm1) < 1e-10) mec = (m > 0.0) ? 1.0 : -1.0; else mec = 0.0;
-        int f = dir == 0 ? i : j, fhi = dir == 0 ? v.nx : v.ny;
+        int f = dir == 0 ? i : j + v.j0, fhi = dir == 0 ? v.nx : v.nyg;   // domain faces (global row on a rank strip)
         if (f == 0 || f == fhi) mec = 0.0;
         double bec = 0.5 * (B[idx] + B[im]), mrec = 0.5 * (mR[idx] + mR[im]), d;
         if (mec < 0.0 && ph.cutOffB > 0) d = 0.0; else d = fmax(bec * mrec / rho_i, 5.0e-6);
@@ -233,6 +239,7 @@ static int diffusion_terms(suhmo_level *L, const suhmo_model_params_t *mp, hipSt
     Depth &D = L->d[0];
     for (int f : {SUHMO_F_DCX, SUHMO_F_DCY, SUHMO_F_DTERM}) if (!suhmo_field(L, 0, f)) { suhmo_set_error("field allocation failed"); return -2; }
     int n = 2 * D.v.ny + 2 * D.v.nx;
+    int rc = exchange1(L, SUHMO_F_MR, st); if (rc) return rc;          // levelmR.exchange() :2513
     hipLaunchKernelGGL(k_extrap_ghosts, dim3((n + 255) / 256), dim3(256), 0, st, D.v, D.fp.f[SUHMO_F_MR]);
     hipLaunchKernelGGL(k_dcoef_faces, dim3((D.v.nx + 1 + 63) / 64, (D.v.ny + 1 + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, L->ph, mp->rho_i);
     hipLaunchKernelGGL(k_difterm, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp);
@@ -257,6 +264,7 @@ static int solve_gap_implicit(suhmo_level *L, const suhmo_model_params_t *mp, do
         if ((rc = suhmo_level_set_value(L->gap, 0, SUHMO_F_ACOEF, 1.0, (suhmo_stream_t)st))) return rc;       // aCoeff_GH :1820-1828
     }
     suhmo_level *G = L->gap;
+    G->ex = L->ex; G->ar = L->ar; G->user = L->user; G->ex_begin = L->ex_begin; G->ex_end = L->ex_end;       // same strip, same neighbours
     Depth &GD = G->d[0];
     if (GD.elems != D.elems) { suhmo_set_error("internal: gap level geometry"); return -4; }
     const size_t bytes = D.elems * sizeof(double);
@@ -264,7 +272,10 @@ static int solve_gap_implicit(suhmo_level *L, const suhmo_model_params_t *mp, do
     HIPCHK(hipMemcpyAsync(GD.fp.f[SUHMO_F_RHS], D.fp.f[SUHMO_F_RES], bytes, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(GD.fp.f[SUHMO_F_BX], D.fp.f[SUHMO_F_DCX], bytes, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(GD.fp.f[SUHMO_F_BY], D.fp.f[SUHMO_F_DCY], bytes, hipMemcpyDeviceToDevice, st));
-    int rc = suhmo_level_build_mg_coefficients(G, (suhmo_stream_t)st); if (rc) return rc;    // coarse D = average of the fine faces
+    GD.phi_fresh = 0;
+    static const int halo_fields[] = {SUHMO_F_RHS, SUHMO_F_ACOEF, SUHMO_F_BX, SUHMO_F_BY};
+    int rc = suhmo_exchange_list(G, 0, halo_fields, 4, st); if (rc) return rc;
+    rc = suhmo_level_build_mg_coefficients(G, (suhmo_stream_t)st); if (rc) return rc;    // coarse D = average of the fine faces
     suhmo_solver_params_t sp;
     sp.num_smooth = 2; sp.num_bottom = 4; sp.max_iter = 100; sp.iter_min = 2; sp.imin = cur_step < 50 ? 10 : 5;
     sp.eps = 1.0e-7; sp.hang = 1.0e-6; sp.norm_thresh = 1.0e-7; sp.bcoeff_otf = 0; sp.max_depth = -1;
@@ -279,7 +290,8 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
     ARG(L && mp); ARG(dt > 0 && cur_step >= 1);
     if (mp->use_impl_diff && mp->diffFactor == 0.0) { suhmo_set_error("use_ImplDiff with diffFactor = 0"); return -1; }
     Depth &D = L->d[0];
-    if (D.v.ext[0] || D.v.ext[1] || L->desc.nx_global > 0) { suhmo_set_error("timestep on a rank strip / AMR patch is not built yet"); return -5; }
+    if (L->desc.nx_global > 0 || (D.v.ext[0] && !D.v.rk[0]) || (D.v.ext[1] && !D.v.rk[1])) { suhmo_set_error("timestep on an AMR patch is not built yet"); return -5; }
+    if ((D.v.ext[0] || D.v.ext[1]) && !(L->ex && L->ar)) { suhmo_set_error("timestep on a rank strip needs the exchange hooks (suhmo_level_attach_rccl / suhmo_level_set_hooks)"); return -1; }
     HIPCHK(hipSetDevice(L->device));
     hipStream_t st = (hipStream_t)s;
     if (mp->use_moulin_source && !L->d[0].fp.f[SUHMO_F_MSRC]) { suhmo_set_error("use_moulin_source without suhmo_level_moulin_source"); return -1; }
@@ -289,6 +301,7 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
     int rc;
     // [I] ghosts of b (exchange + CopyGhostCells, :2385,:2429); ghosts of h are evaluated on the fly
     if ((rc = suhmo_copy_ghosts(L, 0, SUHMO_F_B, st))) return rc;
+    if ((rc = exchange1(L, SUHMO_F_B, st))) return rc;
     // MGnewOp coarsening of B (+ static Pi, zb, mask, aCoef): once per step, b does not change in [II]
     if ((rc = suhmo_level_build_mg_coefficients(L, s))) return rc;
     suhmo_solver_params_t sp;                                      // SolveForHead_nl, :737-762
@@ -304,6 +317,7 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
         if (mp->diffFactor != 0.0 && (rc = diffusion_terms(L, mp, st))) return rc;   // lagged melt rate :2548-2551, :2982-2992
         hipLaunchKernelGGL(k_melt<0>, grd, blk, 0, st, D.v, D.fp, L->ph, *mp, dt);
         HIPCHK(hipGetLastError());
+        if ((rc = exchange1(L, SUHMO_F_RHS, st))) return rc;        // rank strips relax their halo rows redundantly
         int it = 0;
         if ((rc = suhmo_level_solve(L, &sp, &it, nullptr, s))) return rc;
         nv += it;
@@ -322,6 +336,7 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
     HIPCHK(hipGetLastError());
     if (mp->use_impl_diff && (rc = solve_gap_implicit(L, mp, dt, cur_step, st))) return rc;   // :3425-3439
     if ((rc = suhmo_copy_ghosts(L, 0, SUHMO_F_B, st))) return rc;  // :3419-3420 / :3451-3452
+    if ((rc = exchange1(L, SUHMO_F_B, st))) return rc;
     if (picard_iters) *picard_iters = ite_idx;
     if (vcycles) *vcycles = nv;
     return 0;
@@ -407,7 +422,7 @@ extern "C" int suhmo_level_moulin_source(suhmo_level_t *L, int n, const double *
     HIPCHK(hipSetDevice(L->device));
     hipStream_t st = (hipStream_t)s;
     Depth &D = L->d[0];
-    if (D.v.ext[0] || D.v.ext[1] || L->desc.nx_global > 0) { suhmo_set_error("moulin source on a rank strip / AMR patch is not built yet (the integral spans all levels)"); return -5; }
+    if (L->desc.nx_global > 0) { suhmo_set_error("moulin source on an AMR patch is not built yet (the integral spans all levels)"); return -5; }
     double *out = suhmo_field(L, 0, SUHMO_F_MSRC);
     if (!out) { suhmo_set_error("field allocation failed"); return -2; }
     std::vector<double> h(4 * (size_t)n);
@@ -415,14 +430,17 @@ extern "C" int suhmo_level_moulin_source(suhmo_level_t *L, int n, const double *
         ARG(sigma[m] > 0.0);
         h[3 * m] = positions[2 * m]; h[3 * m + 1] = positions[2 * m + 1]; h[3 * m + 2] = sigma[m]; h[3 * (size_t)n + m] = flux[m];
     }
-    dim3 blk(16, 16), grd((D.v.nx + 15) / 16, (D.v.ny + 15) / 16);
-    const size_t nblk = (size_t)grd.x * grd.y;
+    // rank strip: the integrals run over the whole level on every rank (geometry only), in the single-level order
+    DV vg = D.v;
+    vg.ny = D.v.nyg; vg.j0 = 0;
+    dim3 blk(16, 16), grd((D.v.nx + 15) / 16, (D.v.ny + 15) / 16), grdg((vg.nx + 15) / 16, (vg.ny + 15) / 16);
+    const size_t nblk = (size_t)grdg.x * grdg.y;
     double *dev = nullptr;
     HIPCHK(hipMalloc(&dev, (5 * (size_t)n + nblk * n) * sizeof(double)));
     double *mo = dev, *fl = dev + 3 * (size_t)n, *integ = dev + 4 * (size_t)n, *partial = dev + 5 * (size_t)n;
     hipError_t e = hipMemcpyAsync(dev, h.data(), 4 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_moulin_partial, grd, blk, 0, st, D.v, n, mo, partial);
+        hipLaunchKernelGGL(k_moulin_partial, grdg, blk, 0, st, vg, n, mo, partial);
         hipLaunchKernelGGL(k_moulin_final, dim3(n), dim3(256), 0, st, partial, (int)nblk, n, integ);
         hipLaunchKernelGGL(k_moulin_src, grd, blk, 0, st, D.v, n, mo, fl, integ, time_factor, out);
         e = hipGetLastError();
@@ -437,7 +455,7 @@ extern "C" int suhmo_level_moulin_source(suhmo_level_t *L, int n, const double *
 
 // ------------------------------------------------------------------ SHMIP cross-section table
 // one thread per cell column, rows summed in ascending j (the order of the reference's BoxIterator per column)
-__global__ void k_postproc_columns(DV v, FP fp, suhmo_model_params_t mp, double *__restrict__ out /* 7 x nx */)
+__global__ void k_postproc_columns(DV v, FP fp, suhmo_model_params_t mp, double *__restrict__ out /* 8 x nx */)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.nx) return;
@@ -456,34 +474,51 @@ __global__ void k_postproc_columns(DV v, FP fp, suhmo_model_params_t mp, double 
         if (ice && Pi[idx] > 0.0) { avp += Pi[idx] - Pw[idx]; cnt += 1.0; }                             // :3778-3783
     }
     out[0 * v.nx + i] = yl; out[1 * v.nx + i] = qt; out[2 * v.nx + i] = qc; out[3 * v.nx + i] = qd;
-    out[4 * v.nx + i] = ext; out[5 * v.nx + i] = mr; out[6 * v.nx + i] = avp / fmax(cnt, 1.0) / 1.0e6;
+    out[4 * v.nx + i] = ext; out[5 * v.nx + i] = mr; out[6 * v.nx + i] = avp; out[7 * v.nx + i] = cnt;
 }
-extern "C" int suhmo_level_postproc_table(suhmo_level_t *L, const suhmo_model_params_t *mp, double *table, suhmo_stream_t s)
+// column sums over the rows of this level / strip: 8 x nx = width, Q, Q channelised, Q distributed, external recharge,
+// melt recharge, sum of (Pi - Pw), count of its terms
+extern "C" int suhmo_level_postproc_partial(suhmo_level_t *L, const suhmo_model_params_t *mp, double *sums, suhmo_stream_t s)
 {
-    ARG(L && mp && table);
+    ARG(L && mp && sums);
     HIPCHK(hipSetDevice(L->device));
     hipStream_t st = (hipStream_t)s;
     Depth &D = L->d[0];
-    if (D.v.ext[0] || D.v.ext[1] || L->desc.nx_global > 0) { suhmo_set_error("post-processing table on a rank strip / AMR patch is not built"); return -5; }
+    if (L->desc.nx_global > 0) { suhmo_set_error("post-processing table on an AMR patch is not built"); return -5; }
     for (int f : {SUHMO_F_QWX, SUHMO_F_CD, SUHMO_F_MR, SUHMO_F_PW}) if (!D.fp.f[f]) { suhmo_set_error("no time step has run on this level"); return -1; }
     if (mp->use_moulin_source && !D.fp.f[SUHMO_F_MSRC]) { suhmo_set_error("use_moulin_source without suhmo_level_moulin_source"); return -1; }
     const int nx = D.v.nx;
     double *dev = nullptr;
-    HIPCHK(hipMalloc(&dev, 7 * (size_t)nx * sizeof(double)));
+    HIPCHK(hipMalloc(&dev, 8 * (size_t)nx * sizeof(double)));
     hipLaunchKernelGGL(k_postproc_columns, dim3((nx + 63) / 64), dim3(64), 0, st, D.v, D.fp, *mp, dev);
-    std::vector<double> h(7 * (size_t)nx);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), dev, h.size() * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(sums, dev, 8 * (size_t)nx * sizeof(double), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(dev);
     if (e != hipSuccess) { suhmo_set_error("postproc table: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+// the table from column sums (of the whole level: on rank strips the host adds the strips' sums first)
+extern "C" int suhmo_postproc_finish(const double *sums, int nx, double dx, double *table)
+{
+    ARG(sums && table && nx > 0);
+    const double *h = sums;
     double cext = 0.0, cmr = 0.0;
     for (int i = nx - 1; i >= 0; i--) {                    // recharge upstream of the column: cumulative from the upper end
         cext += h[4 * (size_t)nx + i]; cmr += h[5 * (size_t)nx + i];
         double *row = table + 8 * (size_t)i;
-        row[0] = (i + 0.5) * D.v.dx / 1.0e3; row[1] = h[0 * (size_t)nx + i];
+        row[0] = (i + 0.5) * dx / 1.0e3; row[1] = h[0 * (size_t)nx + i];
         row[2] = -h[1 * (size_t)nx + i]; row[3] = -h[2 * (size_t)nx + i]; row[4] = -h[3 * (size_t)nx + i];
-        row[5] = cext; row[6] = cmr; row[7] = h[6 * (size_t)nx + i];
+        row[5] = cext; row[6] = cmr; row[7] = h[6 * (size_t)nx + i] / fmax(h[7 * (size_t)nx + i], 1.0) / 1.0e6;
     }
     return 0;
+}
+extern "C" int suhmo_level_postproc_table(suhmo_level_t *L, const suhmo_model_params_t *mp, double *table, suhmo_stream_t s)
+{
+    ARG(L && mp && table);
+    Depth &D = L->d[0];
+    if (D.v.ext[0] || D.v.ext[1]) { suhmo_set_error("rank strip: add the strips' suhmo_level_postproc_partial sums, then suhmo_postproc_finish"); return -5; }
+    std::vector<double> h(8 * (size_t)D.v.nx);
+    int rc = suhmo_level_postproc_partial(L, mp, h.data(), s); if (rc) return rc;
+    return suhmo_postproc_finish(h.data(), D.v.nx, D.v.dx, table);
 }

@@ -22,8 +22,11 @@ class HipModel:
     FIELDS = dict(head=lv.F_PHI, B=lv.F_B, Pi=lv.F_PI, zb=lv.F_ZB, mask=lv.F_MASK, mR=lv.F_MR, Pw=lv.F_PW,
                   qwx=lv.F_QWX, qwy=lv.F_QWY, cd=lv.F_CD, rhs_h=lv.F_RHS, Re=lv.F_RE, msrc=lv.F_MSRC)
 
-    def __init__(self, nx, ny, dx, dy, bc, phys, model, max_box=64, device=0):
-        self.level = lv.HipLevel(nx, ny, dx, dy, bc, phys, alpha=0.0, beta=-1.0, max_box=max_box, device=device)
+    def __init__(self, nx, ny, dx, dy, bc, phys, model, max_box=64, device=0, j0=0, ny_global=None, halo_rows=1):
+        """j0 / ny_global: this process holds rows j0 .. j0 + ny - 1 of a level of ny_global rows (one strip per GPU;
+        couple the strips with suhmo_amd.multigpu.attach(model.level, ...) before the first step)"""
+        self.level = lv.HipLevel(nx, ny, dx, dy, bc, phys, alpha=0.0, beta=-1.0, max_box=max_box, device=device,
+                                 j0=j0, ny_global=ny_global, halo_rows=halo_rows)
         self.nx, self.ny, self.dx, self.dy = nx, ny, dx, dy
         self.model = dict(model)
         self._mp = model_params(model)
@@ -62,6 +65,19 @@ class HipModel:
         t = np.zeros((self.nx, 8))
         check(capi.lib().suhmo_level_postproc_table(self.level.h, C.byref(self._mp), t.ctypes.data_as(C.POINTER(C.c_double)),
                                                     self.level.stream))
+        return t
+
+    def postproc_partial(self):
+        """column sums over this strip's rows (8 x nx); add them over the ranks, then postproc_finish"""
+        t = np.zeros((8, self.nx))
+        check(capi.lib().suhmo_level_postproc_partial(self.level.h, C.byref(self._mp), t.ctypes.data_as(C.POINTER(C.c_double)),
+                                                      self.level.stream))
+        return t
+
+    def postproc_finish(self, sums):
+        t, a = np.zeros((self.nx, 8)), np.ascontiguousarray(sums, dtype=np.float64)
+        check(capi.lib().suhmo_postproc_finish(a.ctypes.data_as(C.POINTER(C.c_double)), self.nx, self.dx,
+                                               t.ctypes.data_as(C.POINTER(C.c_double))))
         return t
 
     def postproc_table(self):

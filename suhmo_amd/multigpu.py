@@ -53,7 +53,8 @@ class StripExchanger:
             if key not in self._bufs:
                 self._bufs[key] = [self.tr.alloc(n * nfields) for _ in range(4)]   # send lo/hi, recv lo/hi
             slo, shi, rlo, rhi = self._bufs[key]
-            lib, h, st = capi.lib(), self.level.h, C.c_void_p(stream)
+            # L: the handle whose rows travel (the level itself, or its implicit gap-height solver: same strip, same hooks)
+            lib, h, st = capi.lib(), (C.c_void_p(L) if L else self.level.h), C.c_void_p(stream)
             for q, f in enumerate(fields):
                 off = q * n * 8
                 if self.lo is not None:

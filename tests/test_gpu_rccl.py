@@ -50,3 +50,36 @@ def test_self_neighbour_vcycle_bitwise(nx, ny, variant, halo, monkeypatch):
     assert np.array_equal(W.get(F_PHI), S.get(F_PHI))
     W.close()
     S.close()
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_self_neighbour_timestep_bitwise(impl):
+    """suhmo_level_timestep on a strip coupled through the native RCCL hooks (its own periodic neighbour): gap-height,
+    melt-rate, gradient and RHS halos, the MAX all-reduced Picard test and -- impl = 1 -- the implicit gap-height solver
+    sharing the strip's communicator; must equal the whole periodic level bit for bit."""
+    from suhmo_amd import model, multigpu
+    from test_gpu_timestep import perturbed_state
+    from test_gpu_timestep_strips import wrap, NAMES
+    from test_gpu_moulin import moulins
+    nx, ny, bc = 128, 64, sy.CONV_BC
+    m = dict(sy.A3_MODEL, diffFactor=1.0, use_impl_diff=impl, use_moulin_source=1, distributed_input=7.93e-11)
+    st = wrap(perturbed_state(nx, ny, 23), bc)
+    pos, sg, fl = moulins(5, 9)
+    W = model.HipModel(nx, ny, st["dx"], st["dy"], bc, sy.A3_PHYS, m, max_box=16)
+    S = model.HipModel(nx, ny, st["dx"], st["dy"], bc, sy.A3_PHYS, m, max_box=16, j0=0, ny_global=2 * ny, halo_rows=4)
+    for G in (W, S):
+        G.set_state(st)
+    multigpu.attach_rccl(S.level, 0, 1, periodic_y=True)
+    # the strip believes the level has 2 ny rows, so its own moulin integrals would differ: it gets W's source term
+    W.moulin_source(pos, sg, fl, 1.0)
+    from suhmo_amd import level as lv
+    S.level.set(lv.F_MSRC, W.get("msrc"))
+    for k in range(2):
+        assert W.timestep(m["dt"]) == S.timestep(m["dt"])
+        for nm in NAMES:
+            a, b = W.get(nm), S.get(nm)
+            if nm == "qwy":
+                a, b = a[:-1], b[:-1]
+            assert np.array_equal(a, b, equal_nan=True), (k, nm)
+    W.close()
+    S.close()
