@@ -231,6 +231,11 @@ int suhmo_level_postproc_table(suhmo_level_t *L, const suhmo_model_params_t *mp,
 int suhmo_level_postproc_partial(suhmo_level_t *L, const suhmo_model_params_t *mp, double *sums, suhmo_stream_t s);
 int suhmo_postproc_finish(const double *sums, int nx, double dx, double *table);
 
+/* setAlphaAndBeta (src/VCAMRNonLinearPoissonOp.cpp:462-469) and setBC (src/AMRNonLinearPoissonOp.cpp:1275-1278) of the
+ * operator, for every multigrid depth of the level; setBC keeps the periodicity the level was created with */
+int suhmo_level_set_alpha_beta(suhmo_level_t *L, double alpha, double beta);
+int suhmo_level_set_bc(suhmo_level_t *L, const suhmo_bc_t *bc);
+
 /* multi-GPU strips: pack the `rows` owned rows next to side (0 = y-lo, 1 = y-hi) of a
  * field into a contiguous device buffer (rows x (nx+1) doubles) / unpack a neighbour's rows
  * into the ghost rows of that side.  The transport (RCCL send/recv) belongs to the host. */
@@ -281,6 +286,15 @@ int suhmo_amr2_average(suhmo_level_t *coarse, suhmo_level_t *fine, int field_f, 
 int suhmo_amr2_prolong2(suhmo_level_t *coarse, suhmo_level_t *fine, int field_c, suhmo_stream_t s);      /* AMRProlongS_2 :1143-1206 */
 int suhmo_amr2_set_covered(suhmo_level_t *coarse, suhmo_level_t *fine, int field_c, double value, suhmo_stream_t s); /* AMRNorm :1241-1258 */
 int suhmo_amr2_fine_update_operator(suhmo_level_t *coarse, suhmo_level_t *fine, suhmo_stream_t s);
+/* pieces of the AMRLevelOp interface the FAS cycle of the fork does not use itself:
+ *   suhmo_amr2_reflux       coarse field_c (holding L(phi) of the coarse level) += flux mismatch on the coarse-fine faces,
+ *                           after coarseFineInterp of the fine head               [reflux, src/VCAMRNonLinearPoissonOp.cpp:555-652]
+ *   suhmo_amr2_prolong_pc   fine PHI += coarse field_c, piecewise constant         [AMRProlong / AMRProlongS :1073-1140]
+ *   suhmo_amr2_finer_operator_changed   coarse aCoef, B, Pi, zb, iceMask, bCoef under the patch <- averages of the fine
+ *                           level's                                                [finerOperatorChanged :1356-1439] */
+int suhmo_amr2_reflux(suhmo_level_t *coarse, suhmo_level_t *fine, int field_c, suhmo_stream_t s);
+int suhmo_amr2_prolong_pc(suhmo_level_t *coarse, suhmo_level_t *fine, int field_c, suhmo_stream_t s);
+int suhmo_amr2_finer_operator_changed(suhmo_level_t *coarse, suhmo_level_t *fine, suhmo_stream_t s);
 int suhmo_amr2_residual(suhmo_level_t *coarse, suhmo_level_t *fine, double *norm, suhmo_stream_t s);
 int suhmo_amr2_vcycle(suhmo_level_t *coarse, suhmo_level_t *fine, const suhmo_solver_params_t *sp, suhmo_stream_t s);
 int suhmo_amr2_solve(suhmo_level_t *coarse, suhmo_level_t *fine, const suhmo_solver_params_t *sp, int *iters,

@@ -408,6 +408,9 @@ double or_amr2_residual(OrAmr2 *A)
     return nrm;
 }
 
+/* base-level part of the last composite residual (nxc x nyc, row-major; covered cells hold rhs - L too) */
+const double *or_amr2_coarse_residual(const OrAmr2 *A) { return A->resc; }
+
 /* one AMR FAS V-cycle (VCycleAMR; reconstruction) */
 void or_amr2_vcycle(OrAmr2 *A, const OrSolverParams *sp)
 {

@@ -71,6 +71,7 @@ SYMBOLS = [
     "suhmo_amr2_cf_interp", "suhmo_amr2_average", "suhmo_amr2_fine_update_operator", "suhmo_amr2_residual",
     "suhmo_amr2_vcycle", "suhmo_amr2_solve", "suhmo_level_moulin_source", "suhmo_amr2_prolong2", "suhmo_amr2_set_covered",
     "suhmo_amr_residual", "suhmo_amr_vcycle", "suhmo_amr_solve", "suhmo_level_postproc_table", "suhmo_level_postproc_partial", "suhmo_postproc_finish",
+    "suhmo_level_set_alpha_beta", "suhmo_level_set_bc", "suhmo_amr2_reflux", "suhmo_amr2_prolong_pc", "suhmo_amr2_finer_operator_changed",
 ]
 
 
@@ -132,6 +133,11 @@ def lib():
     L.suhmo_level_postproc_table.argtypes = [vp, C.POINTER(ModelParams), dp, vp]
     L.suhmo_level_postproc_partial.argtypes = [vp, C.POINTER(ModelParams), dp, vp]
     L.suhmo_postproc_finish.argtypes = [dp, C.c_int, C.c_double, dp]
+    L.suhmo_level_set_alpha_beta.argtypes = [vp, C.c_double, C.c_double]
+    L.suhmo_level_set_bc.argtypes = [vp, C.POINTER(BC)]
+    L.suhmo_amr2_reflux.argtypes = [vp, vp, C.c_int, vp]
+    L.suhmo_amr2_prolong_pc.argtypes = [vp, vp, C.c_int, vp]
+    L.suhmo_amr2_finer_operator_changed.argtypes = [vp, vp, vp]
     L.suhmo_amr_residual.argtypes = [C.POINTER(vp), ci, dp, vp]
     L.suhmo_amr_vcycle.argtypes = [C.POINTER(vp), ci, C.POINTER(SolverParams), vp]
     L.suhmo_amr_solve.argtypes = [C.POINTER(vp), ci, C.POINTER(SolverParams), C.POINTER(ci), dp, vp]

@@ -157,6 +157,26 @@ __global__ void k_amr_prolong2(DV vf, double *__restrict__ phi, DV vc, const dou
     p = p + fx1 * (c[cc + o1] + c[cc + o2 * vc.P]);
     phi[idx] = p;
 }
+// PROLONGNL with the AMR refinement ratio (AMRProlong / AMRProlongS, src/AMRNonLinearPoissonOp.cpp:1073-1140)
+__global__ void k_amr_prolong_pc(DV vf, double *__restrict__ phi, DV vc, const double *__restrict__ c)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= vf.nx || j >= vf.ny) return;
+    int idx = cidx(vf, i, j);
+    phi[idx] = phi[idx] + c[cidx(vc, (i + vf.i0) / 2 - vc.i0, (j + vf.j0) / 2 - vc.j0)];
+}
+// [Chombo] CoarseAverageFace with the AMR ratio: coarse face under the patch = (sum of its 2 fine faces) / 2
+// (VCAMRNonLinearPoissonOp::finerOperatorChanged :1356-1439; same summation as AverageOperator's k_average_faces)
+__global__ void k_amr_average_faces(DV vf, const double *__restrict__ bxf, const double *__restrict__ byf, DV vc,
+                                    double *__restrict__ bxc, double *__restrict__ byc)
+{
+    int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y * blockDim.y + threadIdx.y;
+    const int ncx = vf.nx / 2, ncy = vf.ny / 2;
+    if (I > ncx || J > ncy) return;
+    const int co = cidx(vc, I + vf.i0 / 2 - vc.i0, J + vf.j0 / 2 - vc.j0), fo = cidx(vf, 2 * I, 2 * J);
+    if (J < ncy) { double sm = 0.0; sm = sm + bxf[fo]; sm = sm + bxf[fo + vf.P]; bxc[co] = sm / 2.0; }
+    if (I < ncx) { double sm = 0.0; sm = sm + byf[fo]; sm = sm + byf[fo + 1]; byc[co] = sm / 2.0; }
+}
 }  // namespace
 
 int suhmo_grad_cc(suhmo_level *L, int depth, hipStream_t st);          // suhmo_level.hip: k_gradcc (+ k_grad_ghosts)
@@ -233,6 +253,52 @@ extern "C" int suhmo_amr2_residual(suhmo_level_t *C, suhmo_level_t *F, double *n
         if ((rc = suhmo_level_norm(F, 0, SUHMO_F_RES, 0, &b, s))) return rc;
         *norm = a > b ? a : b;
     }
+    return 0;
+}
+
+// reflux (src/VCAMRNonLinearPoissonOp.cpp:555-652): coarse field_c (= L(phi) of the coarse level, e.g. LPHI after
+// applyOpI) += the flux mismatch on the coarse-fine faces; the fine coarse-fine ghosts are interpolated first (:602)
+extern "C" int suhmo_amr2_reflux(suhmo_level_t *C, suhmo_level_t *F, int field_c, suhmo_stream_t s)
+{
+    int rc = check_pair(C, F); if (rc) return rc;
+    ARG(field_c >= 0 && field_c < SUHMO_F_COUNT && field_c != SUHMO_F_PHI && field_c != SUHMO_F_BX && field_c != SUHMO_F_BY);
+    HIPCHK(hipSetDevice(F->device));
+    const DV &vf = F->d[0].v, &vc = C->d[0].v;
+    double *p = suhmo_field(C, 0, field_c);
+    if (!p) { suhmo_set_error("field allocation failed"); return -2; }
+    if ((rc = suhmo_amr2_cf_interp(C, F, SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc;
+    int n = vf.ny + vf.nx;
+    hipLaunchKernelGGL(k_amr_reflux, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, vf, F->d[0].fp, vc, C->d[0].fp, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// AMRProlong / AMRProlongS (:1073-1140): fine PHI += coarse field_c, piecewise constant
+extern "C" int suhmo_amr2_prolong_pc(suhmo_level_t *C, suhmo_level_t *F, int field_c, suhmo_stream_t s)
+{
+    int rc = check_pair(C, F); if (rc) return rc;
+    ARG(field_c >= 0 && field_c < SUHMO_F_COUNT && field_c != SUHMO_F_BX && field_c != SUHMO_F_BY);
+    HIPCHK(hipSetDevice(F->device));
+    Depth &DC = C->d[0], &DF = F->d[0];
+    double *corr = suhmo_field(C, 0, field_c);
+    if (!corr) { suhmo_set_error("field allocation failed"); return -2; }
+    DF.phi_fresh = 0;
+    hipLaunchKernelGGL(k_amr_prolong_pc, dim3((DF.v.nx + 63) / 64, (DF.v.ny + 3) / 4), dim3(64, 4), 0, (hipStream_t)s, DF.v, DF.fp.f[SUHMO_F_PHI], DC.v, corr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// finerOperatorChanged with the AMR ratio (:1356-1439): the coarse level's aCoef, B, Pi, zb, iceMask and bCoef under the
+// patch <- averages of the fine level's
+extern "C" int suhmo_amr2_finer_operator_changed(suhmo_level_t *C, suhmo_level_t *F, suhmo_stream_t s)
+{
+    int rc = check_pair(C, F); if (rc) return rc;
+    HIPCHK(hipSetDevice(F->device));
+    for (int f : {SUHMO_F_ACOEF, SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB, SUHMO_F_MASK})
+        if ((rc = suhmo_amr2_average(C, F, f, f, s))) return rc;
+    const DV &vf = F->d[0].v, &vc = C->d[0].v;
+    hipLaunchKernelGGL(k_amr_average_faces, dim3((vf.nx / 2 + 1 + 63) / 64, (vf.ny / 2 + 1 + 3) / 4), dim3(64, 4), 0, (hipStream_t)s, vf,
+                       F->d[0].fp.f[SUHMO_F_BX], F->d[0].fp.f[SUHMO_F_BY], vc, C->d[0].fp.f[SUHMO_F_BX], C->d[0].fp.f[SUHMO_F_BY]);
+    HIPCHK(hipGetLastError());
+    suhmo_level_drop_graphs(C);
     return 0;
 }
 

@@ -176,6 +176,31 @@ extern "C" int suhmo_level_destroy(suhmo_level_t *L)
     return 0;
 }
 
+// setAlphaAndBeta / setBC of the operator (src/VCAMRNonLinearPoissonOp.cpp:462-469, src/AMRNonLinearPoissonOp.cpp:1275-1278):
+// every multigrid depth of the level takes the new values (the reference keeps them per operator object; its factory
+// hands the same alpha, beta, BCHolder to all of them)
+static int remake_views(suhmo_level *L)
+{
+    for (int dep = 0; dep < L->ndepth; dep++) make_dv(L->d[dep].v, L->desc, dep);
+    suhmo_level_drop_graphs(L);                      // captured launches carry the old view by value
+    return 0;
+}
+extern "C" int suhmo_level_set_alpha_beta(suhmo_level_t *L, double alpha, double beta)
+{
+    ARG(L);
+    L->desc.alpha = alpha; L->desc.beta = beta;
+    return remake_views(L);
+}
+extern "C" int suhmo_level_set_bc(suhmo_level_t *L, const suhmo_bc_t *bc)
+{
+    ARG(L && bc);
+    for (int d = 0; d < 2; d++)
+        if ((bc->periodic[d] != 0) != (L->desc.bc.periodic[d] != 0)) { suhmo_set_error("setBC cannot change the periodicity of the domain"); return -1; }
+    for (int d = 0; d < 2; d++) for (int s = 0; s < 2; s++) ARG(bc->type[d][s] == 0 || bc->type[d][s] == 1);
+    L->desc.bc = *bc;
+    return remake_views(L);
+}
+
 extern "C" int suhmo_level_num_depths(const suhmo_level_t *L) { return L ? L->ndepth : -1; }
 extern "C" int suhmo_level_synchronize(suhmo_level_t *L, suhmo_stream_t s)
 {

@@ -110,6 +110,14 @@ int VCAMRNonLinearPoissonOpHIPFactory::solveAMR(std::vector<LevelData<FArrayBox>
     return iters;
 }
 
+int VCAMRNonLinearPoissonOpHIPFactory::refToFiner(const ProblemDomain &a_domain) const
+{
+    if (m_level && a_domain.dom.size(0) == m_desc.nx && a_domain.dom.size(1) == m_desc.ny_global) return m_fine ? 2 : 1;   // m_refRatios[0]
+    if (m_fine && a_domain.dom.size(0) == m_fineDomain.dom.size(0) && a_domain.dom.size(1) == m_fineDomain.dom.size(1)) return 1;   // finest level
+    MayDay::Abort("Domain not found in AMR hierarchy");
+    return -1;
+}
+
 int VCAMRNonLinearPoissonOpHIPFactory::numDepths() const { return m_level ? suhmo_level_num_depths(m_level) : 0; }
 
 VCAMRNonLinearPoissonOpHIP *VCAMRNonLinearPoissonOpHIPFactory::MGnewOp(const ProblemDomain &, int a_depth, bool)
@@ -318,6 +326,202 @@ Real VCAMRNonLinearPoissonOpHIP::AMRNorm(const LevelData<FArrayBox> &a_coarResid
     double r = 0.0;
     chk(suhmo_level_norm(h(), 0, SUHMO_F_RES, a_ord, &r, nullptr), "AMRNorm");
     return r;
+}
+
+// ---- the rest of the MGLevelOp / AMRLevelOp interface
+void VCAMRNonLinearPoissonOpHIP::residual(LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_phi, const LevelData<FArrayBox> &a_rhs, bool)
+{ residualI(a_lhs, a_phi, a_rhs, false); }                                                         // m_use_FAS: always the inhomogeneous form
+void VCAMRNonLinearPoissonOpHIP::residualNF(LevelData<FArrayBox> &a_lhs, LevelData<FArrayBox> &a_phi, const LevelData<FArrayBox> *a_phiCoarse,
+                                            const LevelData<FArrayBox> &a_rhs, bool a_homogeneous)
+{
+    if (a_phiCoarse != nullptr) AMRResidualNF(a_lhs, a_phi, *a_phiCoarse, a_rhs, a_homogeneous);
+    else residualI(a_lhs, a_phi, a_rhs, a_homogeneous);
+}
+void VCAMRNonLinearPoissonOpHIP::preCond(LevelData<FArrayBox> &a_phi, const LevelData<FArrayBox> &a_rhs)
+{
+    chk(suhmo_level_compute_lambda(h(), m_depth, nullptr), "resetLambda");
+    LevelData<FArrayBox> lam(a_rhs.disjointBoxLayout(), 1, 0);
+    get(SUHMO_F_LAMBDA, lam, m_depth);
+    for (int k = 0; k < a_phi.size(); k++) {                                                       // a_phi = a_rhs / lambda on the rhs box
+        const Box &b = a_rhs[k].box();
+        for (int j = b.lo[1]; j <= b.hi[1]; j++) for (int i = b.lo[0]; i <= b.hi[0]; i++) a_phi[k](i, j) = a_rhs[k](i, j) / lam[k](i, j);
+    }
+    relax(a_phi, a_rhs, 2, 0, m_depth);
+}
+void VCAMRNonLinearPoissonOpHIP::preCond(LevelData<FArrayBox> &a_phi, const LevelData<FArrayBox> &, const LevelData<FArrayBox> &a_rhs)
+{ relax(a_phi, a_rhs, 2, 0, m_depth); }
+void VCAMRNonLinearPoissonOpHIP::applyOp(LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_phi, bool)
+{ applyOpI(a_lhs, a_phi, false); }
+void VCAMRNonLinearPoissonOpHIP::applyOpNoBoundary(LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_phi)
+{
+    // the reference evaluates the stencil on a_phi's ghost cells as they are; it only ever calls this right after the BC
+    // fill of applyOpI (:273-289).  The device evaluates the physical BC on the fly, so for that calling sequence the
+    // result is the same; ghost values a caller invented are not honoured.
+    put(SUHMO_F_PHI, a_phi, m_depth);
+    chk(suhmo_level_apply_op(h(), m_depth, 0, nullptr), "applyOpNoBoundary");
+    get(SUHMO_F_LPHI, a_lhs, m_depth);
+}
+void VCAMRNonLinearPoissonOpHIP::setAlphaAndBeta(const Real &a_alpha, const Real &a_beta)
+{
+    chk(suhmo_level_set_alpha_beta(h(), a_alpha, a_beta), "setAlphaAndBeta");
+    if (m_amrLevel == 0) { m_factory->m_desc.alpha = a_alpha; m_factory->m_desc.beta = a_beta; }
+}
+void VCAMRNonLinearPoissonOpHIP::setBC(const suhmo_bc_t &a_bc) { chk(suhmo_level_set_bc(h(), &a_bc), "setBC"); }
+void VCAMRNonLinearPoissonOpHIP::getFlux(FArrayBox &a_flux, const FArrayBox &a_data, const FluxBox &a_bCoef, const Box &a_facebox,
+                                         int a_dir, int a_ref) const
+{
+    const suhmo_level_desc_t &d = m_factory->m_desc;
+    const Real dxd = (a_dir == 0 ? d.dx : d.dy) * (1 << m_depth) / (m_amrLevel == 1 ? 2.0 : 1.0);
+    const Real scale = d.beta * a_ref / dxd;                                                       // m_beta * a_ref / m_dx_vect[a_dir]
+    a_flux.define(a_facebox, 1);
+    const FArrayBox &b = a_bCoef[a_dir];
+    for (int j = a_facebox.lo[1]; j <= a_facebox.hi[1]; j++)
+        for (int i = a_facebox.lo[0]; i <= a_facebox.hi[0]; i++) {
+            Real phihi = a_data(i, j), philo = a_dir == 0 ? a_data(i - 1, j) : a_data(i, j - 1);
+            Real gradphi = (phihi - philo) * scale;
+            a_flux(i, j) = -b(i, j) * gradphi;
+        }
+}
+void VCAMRNonLinearPoissonOpHIP::finerOperatorChanged(const VCAMRNonLinearPoissonOpHIP &a_operator, int a_coarseningFactor)
+{
+    if (a_coarseningFactor == 1) return;                                                           // only the exchanges remain (:1431-1438)
+    if (a_operator.m_amrLevel == m_amrLevel)                                                       // next finer multigrid depth of the same level
+        chk(suhmo_level_build_mg_coefficients(h(), nullptr), "finerOperatorChanged (multigrid depths)");
+    else {
+        if (!(m_amrLevel == 0 && a_operator.m_amrLevel == 1 && a_coarseningFactor == 2)) MayDay::Error("finerOperatorChanged: base operator <- fine operator, ratio 2");
+        chk(suhmo_amr2_finer_operator_changed(m_factory->m_level, m_factory->m_fine, nullptr), "finerOperatorChanged (AMR levels)");
+    }
+}
+void VCAMRNonLinearPoissonOpHIP::AMROperatorNF(LevelData<FArrayBox> &a_LofPhi, const LevelData<FArrayBox> &a_phi, const LevelData<FArrayBox> &a_phiCoarse,
+                                               bool a_homogeneousPhysBC)
+{
+    if (a_homogeneousPhysBC) MayDay::Abort("VCAMRNonLinearPoissonOp::applyOpI homogeneous AMR");
+    if (m_amrLevel != 1) MayDay::Error("AMROperatorNF: fine operator only");
+    put(SUHMO_F_PHI, a_phi, 0);
+    m_factory->m_ops[0]->put(SUHMO_F_PHI, a_phiCoarse, 0);
+    chk(suhmo_amr2_cf_interp(m_factory->m_level, m_factory->m_fine, SUHMO_F_PHI, SUHMO_F_PHI, nullptr), "coarseFineInterp");
+    chk(suhmo_level_apply_op(h(), 0, 0, nullptr), "AMROperatorNF");
+    get(SUHMO_F_LPHI, a_LofPhi, 0);
+}
+void VCAMRNonLinearPoissonOpHIP::AMROperatorNC(LevelData<FArrayBox> &a_LofPhi, const LevelData<FArrayBox> &a_phiFine, const LevelData<FArrayBox> &a_phi,
+                                               bool a_homogeneousPhysBC, VCAMRNonLinearPoissonOpHIP *a_finerOp)
+{
+    if (a_homogeneousPhysBC) MayDay::Abort("VCAMRNonLinearPoissonOp::applyOpI homogeneous AMR");
+    if (m_amrLevel != 0) MayDay::Error("AMROperatorNC: base operator");
+    put(SUHMO_F_PHI, a_phi, 0);
+    chk(suhmo_level_apply_op(h(), 0, 0, nullptr), "AMROperatorNC: applyOpI");
+    if (a_phiFine.size() > 0) {                                                                    // a_phiFine.isDefined()
+        if (a_finerOp == nullptr || a_finerOp->m_amrLevel != 1) MayDay::Error("AMROperatorNC: finer operator");
+        a_finerOp->put(SUHMO_F_PHI, a_phiFine, 0);
+        chk(suhmo_amr2_reflux(m_factory->m_level, m_factory->m_fine, SUHMO_F_LPHI, nullptr), "reflux");
+    }
+    get(SUHMO_F_LPHI, a_LofPhi, 0);
+}
+void VCAMRNonLinearPoissonOpHIP::AMROperator(LevelData<FArrayBox> &a_LofPhi, const LevelData<FArrayBox> &a_phiFine, const LevelData<FArrayBox> &a_phi,
+                                             const LevelData<FArrayBox> &a_phiCoarse, bool a_homogeneousPhysBC, VCAMRNonLinearPoissonOpHIP *a_finerOp)
+{
+    if (a_phiCoarse.size() == 0) { AMROperatorNC(a_LofPhi, a_phiFine, a_phi, a_homogeneousPhysBC, a_finerOp); return; }
+    if (a_phiFine.size() == 0) { AMROperatorNF(a_LofPhi, a_phi, a_phiCoarse, a_homogeneousPhysBC); return; }
+    MayDay::Error("AMROperator on a middle level: the two-level mirror has none (suhmo_amr_* of the C-ABI handle N levels)");
+}
+void VCAMRNonLinearPoissonOpHIP::reflux(const LevelData<FArrayBox> &a_phiFine, const LevelData<FArrayBox> &a_phi, LevelData<FArrayBox> &a_residual,
+                                        VCAMRNonLinearPoissonOpHIP *a_finerOp)
+{
+    if (m_amrLevel != 0 || a_finerOp == nullptr || a_finerOp->m_amrLevel != 1) MayDay::Error("reflux: base operator with its finer operator");
+    put(SUHMO_F_PHI, a_phi, 0); put(SUHMO_F_LPHI, a_residual, 0);
+    a_finerOp->put(SUHMO_F_PHI, a_phiFine, 0);
+    chk(suhmo_amr2_reflux(m_factory->m_level, m_factory->m_fine, SUHMO_F_LPHI, nullptr), "reflux");
+    get(SUHMO_F_LPHI, a_residual, 0);
+}
+void VCAMRNonLinearPoissonOpHIP::AMRRestrict(LevelData<FArrayBox> &a_resCoarse, const LevelData<FArrayBox> &a_residual, const LevelData<FArrayBox> &a_correction,
+                                             const LevelData<FArrayBox> &a_coarseCorrection, bool a_skip_res)
+{
+    LevelData<FArrayBox> r;
+    create(r, a_residual);
+    AMRRestrictS(a_resCoarse, a_residual, a_correction, a_coarseCorrection, r, a_skip_res);
+}
+void VCAMRNonLinearPoissonOpHIP::AMRProlong(LevelData<FArrayBox> &a_correction, const LevelData<FArrayBox> &a_coarseCorrection)
+{
+    if (m_amrLevel != 1) MayDay::Error("AMRProlong: fine operator only");
+    put(SUHMO_F_PHI, a_correction, 0);
+    m_factory->m_ops[0]->put(SUHMO_F_CORR, a_coarseCorrection, 0);
+    chk(suhmo_amr2_prolong_pc(m_factory->m_level, m_factory->m_fine, SUHMO_F_CORR, nullptr), "AMRProlong");
+    LevelData<FArrayBox> tmp(a_correction.disjointBoxLayout(), 1, 0);
+    get(SUHMO_F_PHI, tmp, 0);
+    for (int k = 0; k < tmp.size(); k++) {
+        const Box &b = tmp[k].box();
+        for (int j = b.lo[1]; j <= b.hi[1]; j++) for (int i = b.lo[0]; i <= b.hi[0]; i++) a_correction[k](i, j) = tmp[k](i, j);
+    }
+}
+void VCAMRNonLinearPoissonOpHIP::AMRProlongS(LevelData<FArrayBox> &a_correction, const LevelData<FArrayBox> &a_coarseCorrection,
+                                             LevelData<FArrayBox> &, const Copier &)
+{ AMRProlong(a_correction, a_coarseCorrection); }                                                  // temp / copier: the device reads the coarse level directly
+void VCAMRNonLinearPoissonOpHIP::AMRUpdateResidual(LevelData<FArrayBox> &a_residual, const LevelData<FArrayBox> &a_correction,
+                                                   const LevelData<FArrayBox> &a_coarseCorrection)
+{ AMRResidualNF(a_residual, a_correction, a_coarseCorrection, a_residual, false); }
+
+void VCAMRNonLinearPoissonOpHIP::createCoarsened(LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_rhs, const int &a_refRat)
+{
+    if (!a_rhs.disjointBoxLayout().coarsenable(a_refRat)) MayDay::Error("createCoarsened: layout not coarsenable");
+    a_lhs.define(a_rhs.disjointBoxLayout().coarsened(a_refRat), 1, a_rhs.ghost());
+}
+void VCAMRNonLinearPoissonOpHIP::assignLocal(LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_rhs)
+{
+    for (int k = 0; k < a_lhs.size(); k++) {
+        const Box &b = a_lhs[k].box(), &r = a_rhs[k].box();
+        for (int j = std::max(b.lo[1], r.lo[1]); j <= std::min(b.hi[1], r.hi[1]); j++)
+            for (int i = std::max(b.lo[0], r.lo[0]); i <= std::min(b.hi[0], r.hi[0]); i++) a_lhs[k](i, j) = a_rhs[k](i, j);
+    }
+}
+void VCAMRNonLinearPoissonOpHIP::buildCopier(Copier &a_copier, const LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_rhs)
+{ a_copier.define(a_rhs.disjointBoxLayout(), a_lhs.disjointBoxLayout()); }
+template <class F> static void for_overlaps(const DisjointBoxLayout &src, const DisjointBoxLayout &dst, F f)
+{
+    for (int kd = 0; kd < dst.size(); kd++)
+        for (int ks = 0; ks < src.size(); ks++) {
+            const Box &a = dst[kd], &b = src[ks];
+            Box o(std::max(a.lo[0], b.lo[0]), std::max(a.lo[1], b.lo[1]), std::min(a.hi[0], b.hi[0]), std::min(a.hi[1], b.hi[1]));
+            if (o.size(0) > 0 && o.size(1) > 0) f(kd, ks, o);
+        }
+}
+void VCAMRNonLinearPoissonOpHIP::assignCopier(LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_rhs, const Copier &a_copier)
+{
+    for_overlaps(a_copier.src(), a_copier.dst(), [&](int kd, int ks, const Box &o) {
+        for (int j = o.lo[1]; j <= o.hi[1]; j++) for (int i = o.lo[0]; i <= o.hi[0]; i++) a_lhs[kd](i, j) = a_rhs[ks](i, j); });
+}
+void VCAMRNonLinearPoissonOpHIP::zeroCovered(LevelData<FArrayBox> &a_lhs, LevelData<FArrayBox> &, const Copier &a_copier)
+{
+    for_overlaps(a_copier.src(), a_copier.dst(), [&](int kd, int, const Box &o) {
+        for (int j = o.lo[1]; j <= o.hi[1]; j++) for (int i = o.lo[0]; i <= o.hi[0]; i++) a_lhs[kd](i, j) = 0.0; });
+}
+Real VCAMRNonLinearPoissonOpHIP::dotProduct(const LevelData<FArrayBox> &a_1, const LevelData<FArrayBox> &a_2)
+{
+    Real sum = 0.0;                                                                                // box by box, Fortran order inside a box
+    for (int k = 0; k < a_1.size(); k++) {
+        const Box &v = a_1.disjointBoxLayout()[k];
+        Real s = 0.0;
+        for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++) s += a_1[k](i, j) * a_2[k](i, j);
+        sum += s;
+    }
+    return sum;
+}
+void VCAMRNonLinearPoissonOpHIP::mDotProduct(const LevelData<FArrayBox> &a_1, const int a_sz, const LevelData<FArrayBox> a_2[], Real a_mdots[])
+{ for (int q = 0; q < a_sz; q++) a_mdots[q] = dotProduct(a_1, a_2[q]); }
+void VCAMRNonLinearPoissonOpHIP::scale(LevelData<FArrayBox> &a_lhs, const Real &a_scale)
+{
+    for (int k = 0; k < a_lhs.size(); k++) {
+        const Box &b = a_lhs[k].box();
+        for (int j = b.lo[1]; j <= b.hi[1]; j++) for (int i = b.lo[0]; i <= b.hi[0]; i++) a_lhs[k](i, j) *= a_scale;
+    }
+}
+Real VCAMRNonLinearPoissonOpHIP::localMaxNorm(const LevelData<FArrayBox> &a_x)
+{
+    Real m = 0.0;
+    for (int k = 0; k < a_x.size(); k++) {
+        const Box &v = a_x.disjointBoxLayout()[k];
+        for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++) m = std::max(m, std::fabs(a_x[k](i, j)));
+    }
+    return m;
 }
 
 void VCAMRNonLinearPoissonOpHIP::create(LevelData<FArrayBox> &a_lhs, const LevelData<FArrayBox> &a_rhs)

@@ -3,6 +3,7 @@
 // applyOpMg, prolongIncrement, UpdateOperator, AverageOperator, norm, solve) on box-decomposed
 // LevelData, and checks every result BITWISE against the CPU oracle (test infrastructure).
 // Built and run by tests/test_gpu_host_mirror.py on the GPU box.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -23,6 +24,9 @@ int or_amr2_solve(OrAmr2 *A, const OrSolverParams *sp, double *hist);
 void or_amr2_cf_interp_phi(OrAmr2 *A);
 void or_amr2_fine_gsrb(OrAmr2 *A, int sweeps);
 void or_amr2_fine_update_operator(OrAmr2 *A);
+void or_amr2_fine_apply_op(OrAmr2 *A, int homogeneous);
+double or_amr2_residual(OrAmr2 *A);
+const double *or_amr2_coarse_residual(const OrAmr2 *A);
 }
 
 static int g_fail = 0;
@@ -152,6 +156,94 @@ int main()
     CHECK(same_valid(phi, og, nx), "solve: converged head == oracle (bitwise)");
     printf("V-cycles %d, residual %.3e -> %.3e\n", n, hist.front(), hist.back());
 
+    // ================= the rest of the MGLevelOp interface on the base level (a second oracle level carries the
+    // changed alpha / beta / boundary values)
+    {
+        LevelData<FArrayBox> L1(grids, 1, 0), L2(grids, 1, 0), r1(grids, 1, 0), r2(grids, 1, 0);
+        op->UpdateOperator(phi, nullptr, 0, 0, false);
+        { auto g = to_global(phi, nx, ny, 0); or_level_set(O, 0, OR_F_PHI, g.data(), 0); }
+        or_level_update_operator(O, 0);
+        op->applyOp(L1, phi, false);
+        or_level_apply_op(O, 0, 0); or_level_get(O, 0, OR_F_LPHI, og.data(), 0);
+        CHECK(same_valid(L1, og, nx), "applyOp == oracle applyOpI");
+        op->applyOpNoBoundary(L2, phi);
+        CHECK(same_valid(L2, og, nx), "applyOpNoBoundary (after the BC fill) == oracle");
+        op->residual(r1, phi, rhs, false); op->residualNF(r2, phi, nullptr, rhs, false);
+        or_level_residual(O, 0); or_level_get(O, 0, OR_F_RES, og.data(), 0);
+        CHECK(same_valid(r1, og, nx) && same_valid(r2, og, nx), "residual / residualNF(no coarser level) == oracle residualI");
+        // getFlux on one box: phi's ghost cells were filled by applyOp (as the reference's const-cast does)
+        LevelData<FluxBox> cb(grids, 1, 0);
+        op->getBCoef(cb);
+        std::vector<double> fl((size_t)(nx + 1) * ny);
+        suhmo_level_get_flux(fac.handle(), 0, 0, 1, fl.data(), nullptr);
+        FArrayBox flux;
+        const Box fbx0 = grids[0].surroundingNodes(0);
+        op->getFlux(flux, phi[0], cb[0], fbx0, 0, 1);
+        bool okfl = true;
+        for (int j = fbx0.lo[1]; j <= fbx0.hi[1]; j++) for (int i = fbx0.lo[0]; i <= fbx0.hi[0]; i++) { double a = flux(i, j), b = fl[(size_t)j * (nx + 1) + i]; if (memcmp(&a, &b, 8)) okfl = false; }
+        CHECK(okfl, "getFlux(box 0, dir 0) == the level-wide device flux (bitwise)");
+        // preCond: correction = residual / lambda, then two sweeps
+        LevelData<FArrayBox> corr(grids, 1, 1);
+        op->preCond(corr, r1);
+        or_level_reset_lambda(O, 0);
+        std::vector<double> lam((size_t)nx * ny), p0((size_t)nx * ny), rg = to_global(r1, nx, ny, 0);
+        or_level_get(O, 0, OR_F_LAMBDA, lam.data(), 0);
+        for (size_t q = 0; q < p0.size(); q++) p0[q] = rg[q] / lam[q];
+        or_level_set(O, 0, OR_F_PHI, p0.data(), 0); or_level_set(O, 0, OR_F_RHS, rg.data(), 0);
+        or_level_gsrb(O, 0, 2); or_level_get(O, 0, OR_F_PHI, og.data(), 0);
+        CHECK(same_valid(corr, og, nx), "preCond == rhs / lambda + relax(2) of the oracle");
+        // setAlphaAndBeta + setBC against an oracle level created with those values
+        suhmo_bc_t bc2 = bc; bc2.value[0][0] = 3.0; bc2.type[1][1] = 0; bc2.value[1][1] = 11.0;
+        OrBC obc2; memcpy(&obc2, &bc2, sizeof(obc2));
+        OrLevel *O2 = or_level_create(nx, ny, dxv, dyv, mb, &obc2, &oph, 0.0, -2.0, 2);
+        { auto g = to_global(phi, nx, ny, 0); or_level_set(O2, 0, OR_F_PHI, g.data(), 0); }
+        { auto g = to_global(rhs, nx, ny, 0); or_level_set(O2, 0, OR_F_RHS, g.data(), 0); }
+        { auto g = to_global(aCoef, nx, ny, 0); or_level_set(O2, 0, OR_F_ACOEF, g.data(), 0); }
+        { auto g = to_global(B, nx, ny, 1); or_level_set(O2, 0, OR_F_B, g.data(), 1); }
+        { auto g = to_global(Pi, nx, ny, 1); or_level_set(O2, 0, OR_F_PI, g.data(), 1); }
+        { auto g = to_global(zb, nx, ny, 1); or_level_set(O2, 0, OR_F_ZB, g.data(), 1); }
+        { auto g = to_global(mask, nx, ny, 1); or_level_set(O2, 0, OR_F_MASK, g.data(), 1); }
+        op->setAlphaAndBeta(0.0, -2.0); op->setBC(bc2);
+        op->UpdateOperator(phi, nullptr, 0, 0, false); or_level_update_operator(O2, 0);
+        op->applyOp(L1, phi, false);
+        or_level_apply_op(O2, 0, 0); or_level_get(O2, 0, OR_F_LPHI, og.data(), 0);
+        CHECK(same_valid(L1, og, nx), "setAlphaAndBeta(0, -2) + setBC(new values, Dirichlet on y-hi): applyOp == oracle level created that way");
+        op->relax(phi, rhs, 2, 0, 0);
+        or_level_gsrb(O2, 0, 2); or_level_get(O2, 0, OR_F_PHI, og.data(), 0);
+        CHECK(same_valid(phi, og, nx), "... and relax(2) too");
+        op->setAlphaAndBeta(0.0, -1.0); op->setBC(bc);
+        or_level_destroy(O2);
+        // LevelDataOps on the host containers
+        LevelData<FArrayBox> a1, a2, cz;
+        op->create(a1, phi); op->assignLocal(a1, phi); op->create(a2, phi); op->assign(a2, phi);
+        Real dp = op->dotProduct(a1, a2), manual = 0.0;
+        for (int k = 0; k < grids.size(); k++) { const Box &v = grids[k]; Real sb = 0.0; for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++) sb += phi[k](i, j) * phi[k](i, j); manual += sb; }
+        LevelData<FArrayBox> two[2]; op->create(two[0], phi); op->assign(two[0], phi); op->create(two[1], phi); op->assign(two[1], phi); op->scale(two[1], 2.0);
+        Real md[2]; op->mDotProduct(a1, 2, two, md);
+        CHECK(dp == manual && md[0] == dp && md[1] == 2.0 * dp, "dotProduct / mDotProduct / scale");
+        CHECK(op->localMaxNorm(a1) == op->norm(a1, 0), "localMaxNorm == norm(x, 0) on one rank");
+        op->createCoarsened(cz, phi, 2);
+        CHECK(cz.size() == grids.size() && cz[0].box().size(0) == mb / 2 + 2, "createCoarsened: coarsened layout, same ghosts");
+        Copier cp; LevelData<FArrayBox> part(DisjointBoxLayout(std::vector<Box>{Box(8, 8, 39, 23)}, dom), 1, 0);
+        part[0].setVal(7.0);
+        op->buildCopier(cp, a1, part); op->assignCopier(a1, part, cp);
+        bool okcp = a1[0](8, 8) == 7.0 && a1[1](39, 23) == 7.0 && a1[0](7, 8) == phi[0](7, 8);
+        op->zeroCovered(a2, part, cp);
+        okcp = okcp && a2[0](8, 8) == 0.0 && a2[1](39, 23) == 0.0 && a2[0](7, 8) == phi[0](7, 8) && a2[1](40, 23) == phi[1](40, 23);
+        CHECK(okcp, "buildCopier / assignCopier / zeroCovered on overlapping layouts");
+        op->setTime(3600.0); op->diagonalScale(a1, true); op->divideByIdentityCoef(a1);
+        // the oracle level continues from the same state as the mirror
+        { auto g = to_global(phi, nx, ny, 0); or_level_set(O, 0, OR_F_PHI, g.data(), 0); }
+        { auto g = to_global(rhs, nx, ny, 0); or_level_set(O, 0, OR_F_RHS, g.data(), 0); }
+        op->UpdateOperator(phi, nullptr, 0, 0, false); or_level_update_operator(O, 0);     // bCoef of the restored BC, both sides
+        HeadSolverParameters sp1(100, true); sp1.max_iter = 2;
+        OrSolverParams osp1; memcpy(&osp1, static_cast<suhmo_solver_params_t *>(&sp1), sizeof(osp1));
+        std::vector<double> oh1(sp1.max_iter + 2);
+        int n1 = fac.solve(phi, rhs, sp1, nullptr), on1 = or_level_solve(O, &osp1, oh1.data());
+        or_level_get(O, 0, OR_F_PHI, og.data(), 0);
+        CHECK(n1 == on1 && same_valid(phi, og, nx), "after the setAlphaAndBeta / setBC round trip: two V-cycles == oracle (bitwise)");
+    }
+
     // ================= two AMR levels: the base level above + a fine patch (coarse cells [32..95] x [16..47])
     {
         const int ci0 = 32, cj0 = 16, ci1 = 95, cj1 = 47, fnx = 2 * (ci1 - ci0 + 1), fny = 2 * (cj1 - cj0 + 1), fmb = 32;
@@ -232,8 +324,98 @@ int main()
         CHECK(same_valid(phi, og, nx), "solveAMR: base-level head == oracle (bitwise)");
         CHECK(same_patch(fphi, fg), "solveAMR: fine-level head == oracle (bitwise)");
         printf("AMR V-cycles %d, composite residual %.3e -> %.3e\n", n2, h2.front(), h2.back());
+
+        // ---- the remaining AMRLevelOp methods on the two levels
+        {
+            LevelData<FArrayBox> fL(fgrids, 1, 0), cL(grids, 1, 0), cR(grids, 1, 0);
+            // AMROperatorNF: coarseFineInterp + applyOpI on the patch
+            fop->AMROperatorNF(fL, fphi, phi, false);
+            or_amr2_cf_interp_phi(A); or_amr2_fine_apply_op(A, 0); or_amr2_fine_io(A, OR_F_LPHI, fg.data(), 0, 0);
+            CHECK(same_patch(fL, fg), "AMROperatorNF == oracle (coarseFineInterp + applyOpI on the patch)");
+            // AMROperatorNC = applyOpI + reflux; rhs - that == the oracle's composite residual outside the patch
+            op->AMROperatorNC(cL, fphi, phi, false, fop);
+            op->AMRResidualNC(cR, fphi, phi, rhs, false, fop);
+            or_amr2_residual(A); memcpy(og.data(), or_amr2_coarse_residual(A), sizeof(double) * (size_t)nx * ny);
+            bool okc = true, okr = true, changed = false;
+            LevelData<FArrayBox> cPlain(grids, 1, 0);
+            op->applyOp(cPlain, phi, false);
+            for (int k = 0; k < grids.size(); k++) {
+                const Box &v = grids[k];
+                for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++) {
+                    bool covered = i >= ci0 && i <= ci1 && j >= cj0 && j <= cj1;
+                    double mine = -1.0 * cL[k](i, j) + 1.0 * rhs[k](i, j), ref = og[(size_t)j * nx + i];
+                    if (!covered && memcmp(&mine, &ref, 8) != 0) okc = false;
+                    double r2 = cR[k](i, j);
+                    if (!covered && memcmp(&r2, &ref, 8) != 0) okr = false;
+                    if (cL[k](i, j) != cPlain[k](i, j)) changed = true;
+                }
+            }
+            CHECK(okc, "AMROperatorNC (applyOpI + reflux): rhs - L == oracle composite residual outside the patch");
+            CHECK(okr, "AMRResidualNC == oracle composite residual outside the patch");
+            CHECK(changed, "reflux changes L(phi) next to the patch");
+            // reflux() on a caller-provided L(phi)
+            LevelData<FArrayBox> cL2(grids, 1, 0);
+            op->assign(cL2, cPlain);
+            op->reflux(fphi, phi, cL2, fop);
+            bool okf = true;
+            for (int k = 0; k < grids.size(); k++) {
+                const Box &v = grids[k];
+                for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++) { double a = cL2[k](i, j), b = cL[k](i, j); if (memcmp(&a, &b, 8)) okf = false; }
+            }
+            CHECK(okf, "applyOp + reflux == AMROperatorNC");
+            // AMRProlong: piecewise-constant interpolation of a coarse correction
+            LevelData<FArrayBox> fcorr(fgrids, 1, 1), ccorr(grids, 1, 1);
+            for (int k = 0; k < grids.size(); k++) { const Box &v = grids[k]; for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++) ccorr[k](i, j) = hashv(i * 31 + j, -1.0, 1.0); }
+            for (int k = 0; k < fgrids.size(); k++) { const Box &v = fgrids[k]; for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++) fcorr[k](i, j) = hashv(i * 17 + j, 0.0, 1.0); }
+            LevelData<FArrayBox> fcorr0(fgrids, 1, 1); fop->assign(fcorr0, fcorr);
+            fop->AMRProlong(fcorr, ccorr);
+            bool okp = true;
+            for (int k = 0; k < fgrids.size(); k++) {
+                const Box &v = fgrids[k];
+                for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++) {
+                    int I = i / 2, J = j / 2, kc = (J / mb) * (nx / mb) + I / mb;
+                    double e = fcorr0[k](i, j) + ccorr[kc](I, J), a = fcorr[k](i, j);
+                    if (memcmp(&a, &e, 8)) okp = false;
+                }
+            }
+            CHECK(okp, "AMRProlong == PROLONGNL with ratio 2 (piecewise constant)");
+            // AMRUpdateResidual: residual <- residual - L(correction) through AMRResidualNF
+            LevelData<FArrayBox> fr1(fgrids, 1, 0), fr2(fgrids, 1, 0);
+            fop->assign(fr1, frhs); fop->AMRUpdateResidual(fr1, fphi, phi);
+            fop->AMRResidualNF(fr2, fphi, phi, frhs, false);
+            bool oku = true;
+            for (int k = 0; k < fgrids.size(); k++) { const Box &v = fgrids[k]; for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++) { double a = fr1[k](i, j), b = fr2[k](i, j); if (memcmp(&a, &b, 8)) oku = false; } }
+            CHECK(oku, "AMRUpdateResidual == AMRResidualNF with the residual as right-hand side");
+            // AMRRestrict (allocates its own scratch) == AMRRestrictS
+            LevelData<FArrayBox> rc1(grids, 1, 0), rc2(grids, 1, 0), scr;
+            fop->create(scr, frhs);
+            fop->AMRRestrict(rc1, frhs, fphi, phi, false);
+            fop->AMRRestrictS(rc2, frhs, fphi, phi, scr, false);
+            bool oka = true;
+            for (int k = 0; k < grids.size(); k++) { const Box &v = grids[k]; for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++) { double a = rc1[k](i, j), b = rc2[k](i, j); if (memcmp(&a, &b, 8)) oka = false; } }
+            CHECK(oka, "AMRRestrict == AMRRestrictS");
+            // finerOperatorChanged across the AMR levels: coarse B and bCoef under the patch = averages of the fine ones
+            LevelData<FluxBox> fb(fgrids, 1, 0), cb(grids, 1, 0);
+            fop->getBCoef(fb);
+            op->finerOperatorChanged(*fop, 2);
+            op->getBCoef(cb);
+            bool okb = true;
+            for (int k = 0; k < grids.size(); k++) {
+                const Box &v = grids[k];
+                for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0] + 1; i++) {
+                    if (!(i >= ci0 && i <= ci1 + 1 && j >= cj0 && j <= cj1)) continue;
+                    int fi = 2 * i, fj = 2 * j, bi = std::min((fi - 2 * ci0) / fmb, fnx / fmb - 1), kf = ((fj - 2 * cj0) / fmb) * (fnx / fmb) + bi;
+                    double sm = 0.0; sm = sm + fb[kf][0](fi, fj); sm = sm + fb[kf][0](fi, fj + 1);
+                    double e = sm / 2.0, a = cb[k][0](i, j);
+                    if (memcmp(&a, &e, 8)) okb = false;
+                }
+            }
+            CHECK(okb, "finerOperatorChanged(fine operator, 2): coarse x-face bCoef under the patch = mean of the two fine faces");
+            CHECK(fac.refToFiner(dom) == 2 && fac.refToFiner(fdom) == 1 && fop->refToCoarser() == 2, "refToFiner / refToCoarser");
+        }
         or_amr2_destroy(A);
     }
+
 
     or_level_destroy(O);
     printf(g_fail ? "RESULT: FAIL (%d)\n" : "RESULT: PASS\n", g_fail);
