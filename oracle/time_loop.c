@@ -20,43 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-typedef struct OrModelParams {
-    double rho_i, rho_w, gravity;       /* suhmo_params.cpp:51-53 */
-    double G, L, ct, cw;                /* GeoFlux, LatHeat, ct, cw */
-    double ub0, ub1;                    /* SlidingVelocity */
-    double br, lr;                      /* bump height / spacing */
-    double diffFactor;
-    double distributed_input;
-    double eps_picard;                  /* solver.eps_PicardIte */
-    int basal_friction;
-    int use_mask_rhs_b;
-    int use_moulin_source;              /* suhmo.n_moulins > 0: RHS_h += msrc * ramp + distributed_input (:3060-3066) */
-    double ramp;                        /* suhmo.ramp (:2448-2467), 1 when off */
-    int use_impl_diff;                  /* solver.use_ImplDiff: gap height by the implicit VC Helmholtz solve (:593-662, :3376-3455) */
-} OrModelParams;
-
-enum { OM_H = 0, OM_B, OM_BOLD, OM_PI, OM_ZB, OM_MASK, OM_MR, OM_PW, OM_SRC, OM_RHSH, OM_CD,
-       OM_GRADX, OM_GRADY, OM_RE, OM_HLAG, OM_MSRC, OM_NCELL, OM_QWX = 100, OM_QWY = 101 };
-
-typedef struct OrModel {
-    OrLevel *L;
-    int nx, ny;
-    double dx, dy;
-    OrBC bc;
-    OrPhys ph;
-    OrModelParams mp;
-    double *c[OM_NCELL];                /* ghosted cell arrays */
-    double *gxf, *gyf, *zxf, *zyf;      /* face gradients of h and zb */
-    double *bxf, *byf, *rxf, *ryf;      /* B_ec, Re_ec */
-    double *qx, *qy;                    /* Qw_ec */
-    double *t1x, *t1y, *t2x, *t2y;      /* Qw*gradH, Qw*gradZb on faces */
-    double *mrxf, *mryf, *dxf, *dyf;    /* mR_ec, Dcoef (suhmo.diffFactor != 0) */
-    double *dterm;                      /* div(D grad b), valid cells */
-    OrLevel *G;                         /* implicit gap-height operator (alpha = 1, beta = dt * diffFactor, no NL) */
-    double G_dt; int G_max_box, G_nthreads;
-    int cur_step;
-    double time;
-} OrModel;
+#include "time_loop.h"
 
 #define NXG (M->nx + 2)
 #define CC(a, i, j) (a)[(size_t)((j) + 1) * NXG + ((i) + 1)]
@@ -75,6 +39,7 @@ OrModel *or_model_create(OrLevel *L, int nx, int ny, double dx, double dy, const
     for (int k = 0; k < 9; k++) { *fxs[k] = (double *)calloc(nfx, sizeof(double)); *fys[k] = (double *)calloc(nfy, sizeof(double)); }
     M->dterm = (double *)calloc((size_t)nx * ny, sizeof(double));
     M->G_max_box = 64; M->G_nthreads = 1;
+    M->nxg = nx; M->nyg = ny;                               /* the level spans its domain */
     return M;
 }
 void or_model_destroy(OrModel *M)
@@ -96,9 +61,16 @@ double *or_model_field(OrModel *M, int id)
 int or_model_step_index(const OrModel *M) { return M->cur_step; }
 void or_model_gap_solver_layout(OrModel *M, int max_box, int nthreads) { M->G_max_box = max_box; M->G_nthreads = nthreads; }
 
-/* exchange (periodic wrap) of a ghosted global array */
+void or_model_set_patch(OrModel *M, int i0, int j0, int nxg, int nyg)
+{
+    M->i0 = i0; M->j0 = j0; M->nxg = nxg; M->nyg = nyg;
+    M->cf[0][0] = i0 > 0; M->cf[0][1] = i0 + M->nx < nxg; M->cf[1][0] = j0 > 0; M->cf[1][1] = j0 + M->ny < nyg;
+}
+#define DOMSIDE(dir, side) (!M->cf[dir][side])             /* this side of the level is a side of the domain */
+/* exchange (periodic wrap) of a ghosted global array; a patch never wraps */
 static void wrap_ghosts(OrModel *M, double *a)
 {
+    if (M->cf[0][0] || M->cf[0][1] || M->cf[1][0] || M->cf[1][1]) return;
     if (M->bc.periodic[0]) for (int j = 0; j < M->ny; j++) { CC(a, -1, j) = CC(a, M->nx - 1, j); CC(a, M->nx, j) = CC(a, 0, j); }
     if (M->bc.periodic[1]) for (int i = 0; i < M->nx; i++) { CC(a, i, -1) = CC(a, i, M->ny - 1); CC(a, i, M->ny) = CC(a, i, 0); }
 }
@@ -110,6 +82,7 @@ static void head_ghosts(OrModel *M, double *h)
         if (M->bc.periodic[dir]) continue;
         int n = dir == 0 ? M->ny : M->nx;
         for (int side = 0; side < 2; side++) {
+            if (!DOMSIDE(dir, side)) continue;
             double isign = side == 0 ? -1.0 : 1.0, value = M->bc.value[dir][side];
             for (int t = 0; t < n; t++) {
                 int ig, jg, in, jn;
@@ -126,18 +99,27 @@ static void head_ghosts(OrModel *M, double *h)
 static void copy_ghosts(OrModel *M, double *a)
 {
     wrap_ghosts(M, a);
-    if (!M->bc.periodic[0]) for (int j = -1; j <= M->ny; j++) { CC(a, -1, j) = CC(a, 0, j); CC(a, M->nx, j) = CC(a, M->nx - 1, j); }
-    if (!M->bc.periodic[1]) for (int i = -1; i <= M->nx; i++) { CC(a, i, -1) = CC(a, i, 0); CC(a, i, M->ny) = CC(a, i, M->ny - 1); }
+    if (!M->bc.periodic[0]) for (int j = -1; j <= M->ny; j++) {
+        if (DOMSIDE(0, 0)) CC(a, -1, j) = CC(a, 0, j);
+        if (DOMSIDE(0, 1)) CC(a, M->nx, j) = CC(a, M->nx - 1, j); }
+    if (!M->bc.periodic[1]) for (int i = -1; i <= M->nx; i++) {
+        if (DOMSIDE(1, 0)) CC(a, i, -1) = CC(a, i, 0);
+        if (DOMSIDE(1, 1)) CC(a, i, M->ny) = CC(a, i, M->ny - 1); }
 }
 /* exchange + ExtrapGhostCells (:94-180): ghost = 2*near - far */
 static void extrap_ghosts(OrModel *M, double *a)
 {
     wrap_ghosts(M, a);
     if (!M->bc.periodic[0]) for (int j = -1; j <= M->ny; j++) {
-        CC(a, -1, j) = 2.0 * CC(a, 0, j) - CC(a, 1, j); CC(a, M->nx, j) = 2.0 * CC(a, M->nx - 1, j) - CC(a, M->nx - 2, j); }
+        if (DOMSIDE(0, 0)) CC(a, -1, j) = 2.0 * CC(a, 0, j) - CC(a, 1, j);
+        if (DOMSIDE(0, 1)) CC(a, M->nx, j) = 2.0 * CC(a, M->nx - 1, j) - CC(a, M->nx - 2, j); }
     if (!M->bc.periodic[1]) for (int i = -1; i <= M->nx; i++) {
-        CC(a, i, -1) = 2.0 * CC(a, i, 0) - CC(a, i, 1); CC(a, i, M->ny) = 2.0 * CC(a, i, M->ny - 1) - CC(a, i, M->ny - 2); }
+        if (DOMSIDE(1, 0)) CC(a, i, -1) = 2.0 * CC(a, i, 0) - CC(a, i, 1);
+        if (DOMSIDE(1, 1)) CC(a, i, M->ny) = 2.0 * CC(a, i, M->ny - 1) - CC(a, i, M->ny - 2); }
 }
+void or_model_head_ghosts(OrModel *M, double *h) { head_ghosts(M, h); }
+void or_model_copy_ghosts(OrModel *M, double *a) { copy_ghosts(M, a); }
+void or_model_extrap_ghosts(OrModel *M, double *a) { extrap_ghosts(M, a); }
 
 /* Gradient::compGradientMAC, normal branch of NEWMACGRAD (util/GradientF.ChF:57-70) */
 static void mac_grad(OrModel *M, const double *phi, double *gx, double *gy)
@@ -166,9 +148,9 @@ static void cell_to_edge(OrModel *M, const double *c, double *fx, double *fy)
 }
 
 /* compute_grad_head (:1610-1674) / evaluate_Re_quadratic (:1711-1778) / evaluate_Qw_ec (:1677-1709) */
-static void grad_re_qw(OrModel *M)
+void or_model_grad(OrModel *M)
 {
-    double *h = M->c[OM_H], *B = M->c[OM_B], *gx = M->c[OM_GRADX], *gy = M->c[OM_GRADY], *Re = M->c[OM_RE];
+    double *h = M->c[OM_H], *gx = M->c[OM_GRADX], *gy = M->c[OM_GRADY];
     mac_grad(M, h, M->gxf, M->gyf);
     for (int j = 0; j < M->ny; j++)
         for (int i = 0; i < M->nx; i++) {              /* EdgeToCell */
@@ -176,6 +158,10 @@ static void grad_re_qw(OrModel *M)
             CC(gy, i, j) = 0.5 * (FY(M->gyf, i, j) + FY(M->gyf, i, j + 1));
         }
     extrap_ghosts(M, gx); extrap_ghosts(M, gy);
+}
+void or_model_re(OrModel *M)
+{
+    double *B = M->c[OM_B], *gx = M->c[OM_GRADX], *gy = M->c[OM_GRADY], *Re = M->c[OM_RE];
     for (int j = -1; j <= M->ny; j++)
         for (int i = -1; i <= M->nx; i++) {            /* COMPUTERE on the ghosted box, AmrHydroF.ChF:92-109 */
             double s = sqrt(CC(gx, i, j) * CC(gx, i, j) + CC(gy, i, j) * CC(gy, i, j));
@@ -183,7 +169,10 @@ static void grad_re_qw(OrModel *M)
             double discr = 1.0 + 4.0 * M->ph.omega * (b * b * b * M->ph.grav * s) / (12.0 * M->ph.nu * M->ph.nu);
             CC(Re, i, j) = (-1.0 + sqrt(discr)) / (2.0 * M->ph.omega);
         }
-    cell_to_edge(M, Re, M->rxf, M->ryf);
+}
+void or_model_qw(OrModel *M)
+{
+    cell_to_edge(M, M->c[OM_RE], M->rxf, M->ryf);
     /* COMPUTEQW, AmrHydroF.ChF:137-150 */
     for (int j = 0; j < M->ny; j++) for (int i = 0; i <= M->nx; i++) {
         double b = FX(M->bxf, i, j);
@@ -198,6 +187,8 @@ static void grad_re_qw(OrModel *M)
         FY(M->qy, i, j) = num_q / denom_q;
     }
 }
+
+static void grad_re_qw(OrModel *M) { or_model_grad(M); or_model_re(M); or_model_qw(M); }
 
 /* COMPUTESCAPROD + EdgeToCell + Calc_meltingRate (:2954-2979, :2174-2252) on valid cells */
 static void melting_rate(OrModel *M)
@@ -236,13 +227,13 @@ static void diffusion_coefficients(OrModel *M)
     extrap_ghosts(M, mR);                                   /* levelmR.exchange(); ExtrapGhostCells(levelmR) :2513,:2526 */
     cell_to_edge(M, mR, M->mrxf, M->mryf);                  /* :2530 */
     for (int dir = 0; dir < 2; dir++) {
-        int ii = dir == 0, jj = dir == 1, face_hi = dir == 0 ? nx : ny;
+        int ii = dir == 0, jj = dir == 1;
         for (int j = 0; j < ny + jj; j++)
             for (int i = 0; i < nx + ii; i++) {
                 double m = CC(IM, i, j), mm1 = CC(IM, i - ii, j - jj), mec;
                 if (fabs(m - mm1) < 1e-10) mec = (m > 0.0) ? 1.0 : -1.0; else mec = 0.0;
-                int idx = dir == 0 ? i : j;
-                if (idx == 0 || idx == face_hi) mec = 0.0;
+                int idx = dir == 0 ? i + M->i0 : j + M->j0;      /* faces of the DOMAIN boundary */
+                if (idx == 0 || idx == (dir == 0 ? M->nxg : M->nyg)) mec = 0.0;
                 double bec = dir == 0 ? FX(M->bxf, i, j) : FY(M->byf, i, j), mrec = dir == 0 ? FX(M->mrxf, i, j) : FY(M->mryf, i, j), d;
                 if (mec < 0.0 && M->ph.cutOffB > 0) d = 0.0; else d = fmax(bec * mrec / M->mp.rho_i, 5.0e-6);
                 if (dir == 0) FX(M->dxf, i, j) = d; else FY(M->dyf, i, j) = d;
@@ -300,52 +291,108 @@ static double max_valid(OrModel *M, const double *a)
     return m;
 }
 
-/* one timestep; returns 0, or -1 if the Picard loop exceeds 100 iterations (:3190-3195) */
-int or_model_timestep(OrModel *M, double dt, int *picard_iters, int *vcycles_total)
+/* ---- phases of one step; or_model_timestep strings them together for one level, amr_step.c for a hierarchy ---- */
+void or_model_begin_step(OrModel *M)                                         /* [I] :2360-2445 */
+{
+    size_t nc = (size_t)(M->nx + 2) * (M->ny + 2);
+    M->cur_step += 1;                                                        /* :2259 */
+    head_ghosts(M, M->c[OM_H]); copy_ghosts(M, M->c[OM_B]);
+    memcpy(M->c[OM_BOLD], M->c[OM_B], nc * sizeof(double));
+    mac_grad(M, M->c[OM_ZB], M->zxf, M->zyf);                                /* compute_grad_zb_ec :1577-1608 (zb is static) */
+}
+void or_model_solver_params(const OrModel *M, OrSolverParams *sp)            /* SolveForHead_nl :737-762 */
+{
+    sp->num_smooth = 4; sp->num_bottom = 16; sp->max_iter = 100; sp->iter_min = 2; sp->imin = 5;
+    sp->eps = 1.0e-7; sp->hang = 0.01; sp->norm_thresh = 1.0e-7; sp->bcoeff_otf = 1; sp->max_depth = -1;
+    if (M->cur_step < 50) { sp->num_bottom = 10; sp->eps = 1.0e-10; sp->hang = 0.0001; sp->imin = 20; }
+}
+void or_model_begin_iteration(OrModel *M)                                    /* :2482-2532 */
+{
+    size_t nc = (size_t)(M->nx + 2) * (M->ny + 2);
+    head_ghosts(M, M->c[OM_H]); copy_ghosts(M, M->c[OM_B]);
+    memcpy(M->c[OM_HLAG], M->c[OM_H], nc * sizeof(double));
+    cell_to_edge(M, M->c[OM_B], M->bxf, M->byf);
+}
+void or_model_rhs_h(OrModel *M)                                              /* :2797-3078 */
 {
     const OrModelParams *p = &M->mp;
     int nx = M->nx, ny = M->ny;
-    double *h = M->c[OM_H], *B = M->c[OM_B], *Bold = M->c[OM_BOLD], *IM = M->c[OM_MASK], *src = M->c[OM_SRC];
-    double *rhs = M->c[OM_RHSH], *mR = M->c[OM_MR], *hl = M->c[OM_HLAG], *Pi = M->c[OM_PI], *Pw = M->c[OM_PW], *CD = M->c[OM_CD];
-    size_t nc = (size_t)(nx + 2) * (ny + 2);
+    double *B = M->c[OM_B], *IM = M->c[OM_MASK], *src = M->c[OM_SRC], *rhs = M->c[OM_RHSH], *mR = M->c[OM_MR];
+    for (int j = -1; j <= ny; j++) for (int i = -1; i <= nx; i++) {         /* distributed input :2865-2877 */
+        if (p->use_moulin_source) CC(src, i, j) = CC(M->c[OM_MSRC], i, j) * p->ramp + p->distributed_input;   /* :3065 */
+        else CC(src, i, j) = (CC(IM, i, j) > 0.0) ? p->distributed_input : 0.0;
+    }
+    if (p->diffFactor != 0.0) diffusion_coefficients(M);                      /* lagged mR (before this iteration's melt rate) :2548-2551 */
+    melting_rate(M);
+    double rho_coef = (1.0 / p->rho_w - 1.0 / p->rho_i);                     /* :3023 */
+    {   /* diagnosis knob (tools/run_shmip_a.py --head-melt-coef, DESIGN.md "end-to-end pin"): scales the melt
+         * term of RHS_h; unset = the reference's source as it is */
+        const char *e = getenv("SUHMO_ORACLE_HEAD_MELT_COEF");
+        if (e) rho_coef *= atof(e);
+    }
+    double ub_norm = sqrt(p->ub0 * p->ub0 + p->ub1 * p->ub1);                /* magVel, SqrtIBC.cpp:280-281 */
+    for (int j = 0; j < ny; j++)
+        for (int i = 0; i < nx; i++) {                                       /* :3044-3077 */
+            double r = CC(mR, i, j) * rho_coef;
+            if (CC(B, i, j) < p->br) r -= ub_norm * (p->br - CC(B, i, j)) / p->lr;
+            r += CC(src, i, j);
+            if (p->diffFactor != 0.0) r -= p->diffFactor * M->dterm[(size_t)j * nx + i];   /* :3071 */
+            if (CC(IM, i, j) < 0.0) r = 0.0;
+            CC(rhs, i, j) = r;
+        }
+}
+int or_model_picard_converged(const OrModel *M, double res, int cur_picard)  /* :3196-3228 */
+{
+    if (M->cur_step < 2) return res < 0.05 && cur_picard > 2;
+    if (M->cur_step < 50) return res < 0.05;
+    return res < M->mp.eps_picard;
+}
+/* [III] after the chain was re-evaluated with the new head: melt rate, CalcRHS_gapHeightFAS :2069-2171, forward Euler
+ * :3406 or the implicit solve :3425-3439, ghosts of b on the domain sides :3419-3420 */
+void or_model_gap_update(OrModel *M, double dt)
+{
+    const OrModelParams *p = &M->mp;
+    int nx = M->nx, ny = M->ny;
+    double *B = M->c[OM_B], *Bold = M->c[OM_BOLD], *IM = M->c[OM_MASK], *mR = M->c[OM_MR], *Pi = M->c[OM_PI], *Pw = M->c[OM_PW], *CD = M->c[OM_CD];
+    melting_rate(M);
+    double ub_norm = sqrt(p->ub0 * p->ub0 + p->ub1 * p->ub1);
+    double *rhs_b = p->use_impl_diff ? (double *)malloc(sizeof(double) * (size_t)nx * ny) : NULL;
+    for (int j = 0; j < ny; j++)
+        for (int i = 0; i < nx; i++) {
+            double b = CC(B, i, j);
+            double RHS = CC(mR, i, j) * (1.0 / p->rho_i), RHS_A = RHS, RHS_B = 0.0;
+            if ((CC(IM, i, j) < 0.0) && p->use_mask_rhs_b) { RHS = 0.0; CC(CD, i, j) = 0.0; if (p->use_impl_diff) RHS = b; }
+            else {
+                if (b < p->br) { RHS += ub_norm * (p->br - b) / p->lr; RHS_B = ub_norm * (p->br - b) / p->lr; }
+                double PimPw = CC(Pi, i, j) - CC(Pw, i, j), AbsPimPw = fabs(PimPw);
+                if (M->ph.cutOffbr > b) RHS -= M->ph.A * (AbsPimPw * AbsPimPw) * PimPw * b * (1.0 - (M->ph.cutOffbr - b) / M->ph.cutOffbr);
+                else if (M->ph.maxOffbr < b) RHS -= M->ph.A * (AbsPimPw * AbsPimPw) * PimPw * b * (1.0 - (M->ph.maxOffbr - b) / M->ph.maxOffbr);
+                else RHS -= M->ph.A * (AbsPimPw * AbsPimPw) * PimPw * b;
+                if (!p->use_impl_diff && p->diffFactor != 0.0) RHS += p->diffFactor * M->dterm[(size_t)j * nx + i];   /* :2145,:2152,:2159 */
+                CC(CD, i, j) = RHS_A / (RHS_A + RHS_B);
+                if (p->use_impl_diff) RHS = b + dt * RHS;                                                          /* :2165 */
+            }
+            if (p->use_impl_diff) rhs_b[(size_t)j * nx + i] = RHS;
+            else CC(B, i, j) = RHS * dt + CC(Bold, i, j);     /* forward Euler :3406 */
+        }
+    if (p->use_impl_diff) { solve_gap_implicit(M, dt, rhs_b); free(rhs_b); }                                   /* :3425-3439 */
+    copy_ghosts(M, B);
+}
+
+/* one timestep; returns 0, or -1 if the Picard loop exceeds 100 iterations (:3190-3195) */
+int or_model_timestep(OrModel *M, double dt, int *picard_iters, int *vcycles_total)
+{
+    int nx = M->nx, ny = M->ny;
+    double *h = M->c[OM_H], *B = M->c[OM_B], *rhs = M->c[OM_RHSH], *hl = M->c[OM_HLAG];
     double *tmp = (double *)malloc(sizeof(double) * (size_t)nx * ny);
-    M->cur_step += 1;                                                        /* :2259 */
-    /* [I] :2360-2445 */
-    head_ghosts(M, h); copy_ghosts(M, B);
-    memcpy(Bold, B, nc * sizeof(double));
-    mac_grad(M, M->c[OM_ZB], M->zxf, M->zyf);                                /* compute_grad_zb_ec :1577-1608 (zb is static) */
-    OrSolverParams sp;                                                       /* SolveForHead_nl :737-762 */
-    sp.num_smooth = 4; sp.num_bottom = 16; sp.max_iter = 100; sp.iter_min = 2; sp.imin = 5;
-    sp.eps = 1.0e-7; sp.hang = 0.01; sp.norm_thresh = 1.0e-7; sp.bcoeff_otf = 1; sp.max_depth = -1;
-    if (M->cur_step < 50) { sp.num_bottom = 10; sp.eps = 1.0e-10; sp.hang = 0.0001; sp.imin = 20; }
+    or_model_begin_step(M);
+    OrSolverParams sp;
+    or_model_solver_params(M, &sp);
     int converged = 0, ite_idx = 0, cur_picard = 0, nv = 0;
     while (!converged) {                                                     /* [II] :2477 */
-        head_ghosts(M, h); copy_ghosts(M, B);
-        memcpy(hl, h, nc * sizeof(double));
-        cell_to_edge(M, B, M->bxf, M->byf);
+        or_model_begin_iteration(M);
         grad_re_qw(M);
-        for (int j = -1; j <= ny; j++) for (int i = -1; i <= nx; i++) {     /* distributed input :2865-2877 */
-            if (p->use_moulin_source) CC(src, i, j) = CC(M->c[OM_MSRC], i, j) * p->ramp + p->distributed_input;   /* :3065 */
-            else CC(src, i, j) = (CC(IM, i, j) > 0.0) ? p->distributed_input : 0.0;
-        }
-        if (p->diffFactor != 0.0) diffusion_coefficients(M);                  /* lagged mR (before this iteration's melt rate) :2548-2551 */
-        melting_rate(M);
-        double rho_coef = (1.0 / p->rho_w - 1.0 / p->rho_i);                 /* :3023 */
-        {   /* diagnosis knob (tools/run_shmip_a.py --head-melt-coef, DESIGN.md "end-to-end pin"): scales the melt
-             * term of RHS_h; unset = the reference's source as it is */
-            const char *e = getenv("SUHMO_ORACLE_HEAD_MELT_COEF");
-            if (e) rho_coef *= atof(e);
-        }
-        double ub_norm = sqrt(p->ub0 * p->ub0 + p->ub1 * p->ub1);            /* magVel, SqrtIBC.cpp:280-281 */
-        for (int j = 0; j < ny; j++)
-            for (int i = 0; i < nx; i++) {                                   /* :3044-3077 */
-                double r = CC(mR, i, j) * rho_coef;
-                if (CC(B, i, j) < p->br) r -= ub_norm * (p->br - CC(B, i, j)) / p->lr;
-                r += CC(src, i, j);
-                if (p->diffFactor != 0.0) r -= p->diffFactor * M->dterm[(size_t)j * nx + i];   /* :3071 */
-                if (CC(IM, i, j) < 0.0) r = 0.0;
-                CC(rhs, i, j) = r;
-            }
+        or_model_rhs_h(M);
         /* SolveForHead_nl: fields into the operator (factory define), solve */
         for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) tmp[(size_t)j * nx + i] = CC(h, i, j);
         or_level_set(M->L, 0, OR_F_PHI, tmp, 0);
@@ -363,38 +410,12 @@ int or_model_timestep(OrModel *M, double dt, int *picard_iters, int *vcycles_tot
             if (d > res) res = d;
         }
         if (ite_idx > 100) { free(tmp); return -1; }
-        if (M->cur_step < 2) { if (res < 0.05 && cur_picard > 2) converged = 1; }
-        else if (M->cur_step < 50) { if (res < 0.05) converged = 1; }
-        else { if (res < p->eps_picard) converged = 1; }
+        converged = or_model_picard_converged(M, res, cur_picard);
         ite_idx++; cur_picard++;
     }
     /* [III] :3238-3421 */
     grad_re_qw(M);                                    /* evaluate_Re_quadratic(lev, true) + evaluate_Qw_ec with the lagged B_ec */
-    melting_rate(M);
-    {
-        double ub_norm = sqrt(p->ub0 * p->ub0 + p->ub1 * p->ub1);
-        double *rhs_b = p->use_impl_diff ? (double *)malloc(sizeof(double) * (size_t)nx * ny) : NULL;
-        for (int j = 0; j < ny; j++)
-            for (int i = 0; i < nx; i++) {            /* CalcRHS_gapHeightFAS :2069-2171 */
-                double b = CC(B, i, j);
-                double RHS = CC(mR, i, j) * (1.0 / p->rho_i), RHS_A = RHS, RHS_B = 0.0;
-                if ((CC(IM, i, j) < 0.0) && p->use_mask_rhs_b) { RHS = 0.0; CC(CD, i, j) = 0.0; if (p->use_impl_diff) RHS = b; }
-                else {
-                    if (b < p->br) { RHS += ub_norm * (p->br - b) / p->lr; RHS_B = ub_norm * (p->br - b) / p->lr; }
-                    double PimPw = CC(Pi, i, j) - CC(Pw, i, j), AbsPimPw = fabs(PimPw);
-                    if (M->ph.cutOffbr > b) RHS -= M->ph.A * (AbsPimPw * AbsPimPw) * PimPw * b * (1.0 - (M->ph.cutOffbr - b) / M->ph.cutOffbr);
-                    else if (M->ph.maxOffbr < b) RHS -= M->ph.A * (AbsPimPw * AbsPimPw) * PimPw * b * (1.0 - (M->ph.maxOffbr - b) / M->ph.maxOffbr);
-                    else RHS -= M->ph.A * (AbsPimPw * AbsPimPw) * PimPw * b;
-                    if (!p->use_impl_diff && p->diffFactor != 0.0) RHS += p->diffFactor * M->dterm[(size_t)j * nx + i];   /* :2145,:2152,:2159 */
-                    CC(CD, i, j) = RHS_A / (RHS_A + RHS_B);
-                    if (p->use_impl_diff) RHS = b + dt * RHS;                                                          /* :2165 */
-                }
-                if (p->use_impl_diff) rhs_b[(size_t)j * nx + i] = RHS;
-                else CC(B, i, j) = RHS * dt + CC(Bold, i, j);     /* forward Euler :3406 */
-            }
-        if (p->use_impl_diff) { solve_gap_implicit(M, dt, rhs_b); free(rhs_b); }                                   /* :3425-3439 */
-    }
-    copy_ghosts(M, B);                                /* :3419-3420 */
+    or_model_gap_update(M, dt);
     M->time += dt;
     if (picard_iters) *picard_iters = ite_idx;
     if (vcycles_total) *vcycles_total = nv;
