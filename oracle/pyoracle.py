@@ -96,6 +96,14 @@ def lib():
         L.or_model_field.argtypes = [C.c_void_p, C.c_int]
         L.or_model_timestep.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.or_model_step_index.argtypes = [C.c_void_p]
+        L.or_amr_model_create.restype = C.c_void_p
+        L.or_amr_model_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(OrBC), C.POINTER(OrPhys),
+                                          C.POINTER(OrModelParams), C.c_int, C.POINTER(C.c_int)]
+        L.or_amr_model_destroy.argtypes = [C.c_void_p]
+        L.or_amr_model_field.restype = dp
+        L.or_amr_model_field.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.or_amr_model_timestep.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.or_amr_model_moulin_source.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, C.c_double, dp]
         L.or_moulin_source.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, dp, dp, dp, C.c_double, dp, dp]
         L.or_amr2_create.restype = C.c_void_p
         L.or_amr2_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(OrBC), C.POINTER(OrPhys),
@@ -315,6 +323,52 @@ class OracleModel:
     def close(self):
         if self.h:
             lib().or_model_destroy(self.h)
+            self.h = None
+            self.level.close()
+
+
+class OracleAmrModel:
+    """Hydrology time loop on a hierarchy (base level + nested patches, patches[k] = box of level k+1 in level-k cells):
+    oracle/amr_step.c"""
+
+    def __init__(self, nx0, ny0, dx0, dy0, bc, phys, model, patches, max_box=64, nthreads=1):
+        self.level = OracleLevel(nx0, ny0, dx0, dy0, bc, phys, 0.0, -1.0, max_box, nthreads)
+        self.patches = [tuple(int(v) for v in p) for p in patches]
+        self.nlev = 1 + len(self.patches)
+        self.dims = [(nx0, ny0)] + [(2 * (p[2] - p[0] + 1), 2 * (p[3] - p[1] + 1)) for p in self.patches]
+        self._mp = make_model_params(model)
+        flat = (C.c_int * max(4 * len(self.patches), 1))(*[v for p in self.patches for v in p])
+        self.h = lib().or_amr_model_create(self.level.h, nx0, ny0, dx0, dy0, C.byref(self.level._bc), C.byref(self.level._ph),
+                                           C.byref(self._mp), self.nlev, flat)
+        self.level.set(F_ACOEF, np.zeros((ny0, nx0)))
+
+    def field(self, l, fid):
+        nx, ny = self.dims[l]
+        p = lib().or_amr_model_field(self.h, l, fid)
+        shape = {OM_QWX: (ny, nx + 1), OM_QWY: (ny + 1, nx)}.get(fid, (ny + 2, nx + 2))
+        return np.ctypeslib.as_array(p, shape=shape)
+
+    def set_state(self, l, f):
+        for k, fid in (("head", OM_H), ("B", OM_B), ("Pi", OM_PI), ("zb", OM_ZB), ("mask", OM_MASK)):
+            self.field(l, fid)[:] = f[k]
+
+    def moulin_source(self, positions, sigma, flux, time_factor=1.0):
+        pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1)
+        sg, fl = np.ascontiguousarray(sigma, dtype=np.float64), np.ascontiguousarray(flux, dtype=np.float64)
+        integ = np.zeros(sg.size)
+        lib().or_amr_model_moulin_source(self.h, sg.size, _dp(pos), _dp(sg), _dp(fl), float(time_factor), _dp(integ))
+        return integ
+
+    def timestep(self, dt):
+        pi, nv = C.c_int(), C.c_int()
+        rc = lib().or_amr_model_timestep(self.h, dt, C.byref(pi), C.byref(nv))
+        if rc:
+            raise RuntimeError("AMR time step failed (rc %d)" % rc)
+        return pi.value, nv.value
+
+    def close(self):
+        if self.h:
+            lib().or_amr_model_destroy(self.h)
             self.h = None
             self.level.close()
 

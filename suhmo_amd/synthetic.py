@@ -126,6 +126,31 @@ def shmip_initial_state(nx, ny, lx=1.0e5, ly=2.0e4, ice_height=5000.0, slope=0.0
     return dict(nx=nx, ny=ny, dx=dx, dy=dy, head=head, B=B, Pi=Pi, zb=zb, mask=mask)
 
 
+def shmip_amr_states(nx0, ny0, patches, lx=1.0e5, ly=2.0e4, ice_height=5000.0, slope=0.0, gap_init=0.01, rough=0.0):
+    """SqrtIBC state (shmip_initial_state) sampled on every level of a hierarchy: level 0 = nx0 x ny0 over the domain,
+    patches[k] = box (ci0, cj0, ci1, cj1) of level k+1 in the cells of level k.  rough > 0 modulates gap height, head and bed
+    with smooth analytic functions of (x, y), the same on every level (tests)."""
+    def level(nx, ny, i0, j0, nxg, nyg):
+        dx, dy = lx / nxg, ly / nyg
+        i = np.arange(i0 - 1, i0 + nx + 1, dtype=np.float64)
+        j = np.arange(j0 - 1, j0 + ny + 1, dtype=np.float64)
+        X, Y = np.meshgrid((i + 0.5) * dx, (j + 0.5) * dy)
+        zb = slope * X + rough * 2.0 * np.sin(2.0 * np.pi * X / (0.37 * lx)) * np.cos(2.0 * np.pi * Y / (0.61 * ly))
+        H = np.maximum(6.0 * (np.sqrt(np.maximum(X + ice_height, 0.0)) - np.sqrt(ice_height)) + 1.0, 0.0)
+        Pi = np.maximum(RHO_I * GRAV * H, 0.0)
+        B = np.where(Pi < 2.0, 1.0e-16, gap_init) * (1.0 + rough * 4.0 * (1.0 + np.sin(2.0 * np.pi * X / (0.23 * lx)) * np.sin(2.0 * np.pi * Y / (0.41 * ly))))
+        head = 101325.0 * (1.0 / (RHO_W * GRAV)) + zb + rough * 20.0 * (1.0 + np.cos(2.0 * np.pi * X / (0.53 * lx)) * np.sin(2.0 * np.pi * Y / (0.77 * ly)))
+        mask = np.where(Pi > 0.0, 1.0, -1.0)
+        return dict(nx=nx, ny=ny, dx=dx, dy=dy, i0=i0, j0=j0, nxg=nxg, nyg=nyg, head=np.ascontiguousarray(head), B=np.ascontiguousarray(B),
+                    Pi=np.ascontiguousarray(Pi), zb=np.ascontiguousarray(zb), mask=np.ascontiguousarray(mask))
+    out = [level(nx0, ny0, 0, 0, nx0, ny0)]
+    nxg, nyg = nx0, ny0
+    for ci0, cj0, ci1, cj1 in patches:
+        nxg, nyg = 2 * nxg, 2 * nyg
+        out.append(level(2 * (ci1 - ci0 + 1), 2 * (cj1 - cj0 + 1), 2 * ci0, 2 * cj0, nxg, nyg))
+    return out
+
+
 def shmip_postproc_table(dx, dy, qwx, cd, src, mR, Pw, Pi, mask, rho_w=1000.0):
     """The SHMIP cross-section table of AmrHydro::timeStepFAS (src/AmrHydro.cpp:3647-4102), columns of
     exec/*_SHMIP/*/results/postproc.dat: x[km], Ylength, discharge, dischargeEFF, dischargeINEFF,
