@@ -291,7 +291,10 @@ int suhmo_amr2_fine_update_operator(suhmo_level_t *coarse, suhmo_level_t *fine, 
  *                           after coarseFineInterp of the fine head               [reflux, src/VCAMRNonLinearPoissonOp.cpp:555-652]
  *   suhmo_amr2_prolong_pc   fine PHI += coarse field_c, piecewise constant         [AMRProlong / AMRProlongS :1073-1140]
  *   suhmo_amr2_finer_operator_changed   coarse aCoef, B, Pi, zb, iceMask, bCoef under the patch <- averages of the fine
- *                           level's                                                [finerOperatorChanged :1356-1439] */
+ *                           level's                                                [finerOperatorChanged :1356-1439]
+ *   suhmo_amr2_pwl_fill     fine ghost ring of field_f <- PiecewiseLinearFillPatch(coarse field_c): limited linear
+ *                           interpolation, the time loop's coarse-fine ghosts of b, mR, Re [src/AmrHydro.cpp:2373-2380, 2499-2507, 2711-2719] */
+int suhmo_amr2_pwl_fill(suhmo_level_t *coarse, suhmo_level_t *fine, int field_f, int field_c, suhmo_stream_t s);
 int suhmo_amr2_reflux(suhmo_level_t *coarse, suhmo_level_t *fine, int field_c, suhmo_stream_t s);
 int suhmo_amr2_prolong_pc(suhmo_level_t *coarse, suhmo_level_t *fine, int field_c, suhmo_stream_t s);
 int suhmo_amr2_finer_operator_changed(suhmo_level_t *coarse, suhmo_level_t *fine, suhmo_stream_t s);
@@ -307,6 +310,12 @@ int suhmo_amr_residual(suhmo_level_t **levels, int nlev, double *norm, suhmo_str
 int suhmo_amr_vcycle(suhmo_level_t **levels, int nlev, const suhmo_solver_params_t *sp, suhmo_stream_t s);
 int suhmo_amr_solve(suhmo_level_t **levels, int nlev, const suhmo_solver_params_t *sp, int *iters,
                     double *resid_hist, suhmo_stream_t s);
+/* suhmo_level_timestep on the hierarchy (AmrHydro::timeStepFAS with m_finest_level > 0): per level the same phases,
+ * PiecewiseLinearFillPatch of the coarse-fine ghosts of b, mR, Re, QuadCFInterp of h and of its cell-centred gradient,
+ * SolveForHead_nl over all levels, CoarseAverage of h (:3138-3141), Picard test over the cells no finer level covers.
+ * Explicit gap-height update (rc -5 with use_impl_diff).  PHI / B of every level updated in place. */
+int suhmo_amr_timestep(suhmo_level_t **levels, int nlev, const suhmo_model_params_t *mp, double dt, int cur_step,
+                       int *picard_iters, int *vcycles, suhmo_stream_t s);
 
 /* timing helper: average device time (ms) of the GSRB sweep kernel launches since the
  * last reset, measured with HIP events on the launch stream */

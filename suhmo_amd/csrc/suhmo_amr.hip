@@ -157,6 +157,46 @@ __global__ void k_amr_prolong2(DV vf, double *__restrict__ phi, DV vc, const dou
     p = p + fx1 * (c[cc + o1] + c[cc + o2 * vc.P]);
     phi[idx] = p;
 }
+// [Chombo] PiecewiseLinearFillPatch, ratio 2, one ghost layer incl. corners (oracle/amr_step.c:or_pwl_fill): coarse value
+// + limited slopes (central, one-sided next to the domain boundary, FORT_INTERPLIMIT over the 3 x 3 neighbourhood) times
+// the offset of the fine cell centre (+-1/4).  One thread per ghost cell of the ring; cells outside the domain stay.
+__global__ void k_pwl_fill(DV vf, double *__restrict__ f, DV vc, const double *__restrict__ c)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int i, j;
+    if (t < 2 * (vf.nx + 2)) { j = t < vf.nx + 2 ? -1 : vf.ny; i = t % (vf.nx + 2) - 1; }
+    else { t -= 2 * (vf.nx + 2); if (t >= 2 * vf.ny) return; i = t < vf.ny ? -1 : vf.nx; j = t % vf.ny; }
+    const int gi = i + vf.i0, gj = j + vf.j0;
+    if (gi < 0 || gi >= vf.nxg || gj < 0 || gj >= vf.nyg) return;
+    if ((j < 0 && vf.rk[0]) || (j >= vf.ny && vf.rk[1])) return;         // rank boundary: exchanged, not interpolated
+    const int I = gi >> 1, J = gj >> 1, cc = cidx(vc, I - vc.i0, J - vc.j0);
+    const double c0 = c[cc];
+    double s0, s1;
+    if (I - 1 >= 0 && I + 1 <= vc.nxg - 1) s0 = 0.5 * (c[cc + 1] - c[cc - 1]);
+    else if (I - 1 < 0) s0 = c[cc + 1] - c0;
+    else s0 = c0 - c[cc - 1];
+    if (J - 1 >= 0 && J + 1 <= vc.nyg - 1) s1 = 0.5 * (c[cc + vc.P] - c[cc - vc.P]);
+    else if (J - 1 < 0) s1 = c[cc + vc.P] - c0;
+    else s1 = c0 - c[cc - vc.P];
+    double smax = c0, smin = c0;
+    for (int jj = -1; jj <= 1; jj++)
+        for (int ii = -1; ii <= 1; ii++) {
+            int In = I + ii, Jn = J + jj;
+            if (In < 0 || In > vc.nxg - 1 || Jn < 0 || Jn > vc.nyg - 1) continue;
+            double v = c[cc + ii + jj * vc.P];
+            smax = fmax(smax, v); smin = fmin(smin, v);
+        }
+    const double deltasum = 0.5 * (fabs(s0) + fabs(s1));
+    if (deltasum > 0.0) {
+        double etamax = (smax - c0) / deltasum, etamin = (c0 - smin) / deltasum;
+        double eta = fmax(fmin(fmin(etamin, etamax), 1.0), 0.0);
+        s0 = eta * s0; s1 = eta * s1;
+    }
+    double v = c0;
+    v = v + s0 * ((gi & 1) ? 0.25 : -0.25);
+    v = v + s1 * ((gj & 1) ? 0.25 : -0.25);
+    f[cidx(vf, i, j)] = v;
+}
 // PROLONGNL with the AMR refinement ratio (AMRProlong / AMRProlongS, src/AMRNonLinearPoissonOp.cpp:1073-1140)
 __global__ void k_amr_prolong_pc(DV vf, double *__restrict__ phi, DV vc, const double *__restrict__ c)
 {
@@ -269,6 +309,24 @@ extern "C" int suhmo_amr2_reflux(suhmo_level_t *C, suhmo_level_t *F, int field_c
     if ((rc = suhmo_amr2_cf_interp(C, F, SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc;
     int n = vf.ny + vf.nx;
     hipLaunchKernelGGL(k_amr_reflux, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, vf, F->d[0].fp, vc, C->d[0].fp, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// PiecewiseLinearFillPatch::fillInterp of one field (the time loop's coarse-fine ghosts of b, mR, Re: src/AmrHydro.cpp:2373-2380,
+// 2499-2507, 2711-2719): fine ghost ring of field_f <- coarse field_c
+extern "C" int suhmo_amr2_pwl_fill(suhmo_level_t *C, suhmo_level_t *F, int field_f, int field_c, suhmo_stream_t s)
+{
+    int rc = check_pair(C, F); if (rc) return rc;
+    ARG(field_f >= 0 && field_f < SUHMO_F_COUNT && field_c >= 0 && field_c < SUHMO_F_COUNT);
+    ARG(field_f != SUHMO_F_BX && field_f != SUHMO_F_BY && field_f != SUHMO_F_QWX && field_f != SUHMO_F_QWY && field_f != SUHMO_F_DCX && field_f != SUHMO_F_DCY);
+    HIPCHK(hipSetDevice(F->device));
+    const DV &vf = F->d[0].v, &vc = C->d[0].v;
+    if (vc.rk[0] || vc.rk[1] || vf.rk[0] || vf.rk[1]) { suhmo_set_error("PiecewiseLinearFillPatch on rank strips is not built"); return -5; }
+    double *pf = suhmo_field(F, 0, field_f), *pc = suhmo_field(C, 0, field_c);
+    if (!pf || !pc) { suhmo_set_error("field allocation failed"); return -2; }
+    if (field_f == SUHMO_F_PHI) F->d[0].phi_fresh = 0;
+    int n = 2 * (vf.nx + 2) + 2 * vf.ny;
+    hipLaunchKernelGGL(k_pwl_fill, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, vf, pf, vc, pc);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -493,6 +551,7 @@ int check_hierarchy(suhmo_level_t **lv, int nlev)
     return 0;
 }
 }  // namespace
+int suhmo_amr_check_hierarchy(suhmo_level_t **lv, int nlev) { return check_hierarchy(lv, nlev); }   // for suhmo_step.hip
 
 extern "C" int suhmo_amr_residual(suhmo_level_t **lv, int nlev, double *norm, suhmo_stream_t s)
 {

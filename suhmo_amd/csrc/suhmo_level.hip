@@ -994,6 +994,13 @@ int suhmo_re_bcoef_unfused(suhmo_level *L, int depth, hipStream_t st)
     return 0;
 }
 
+int suhmo_re_cells(suhmo_level *L, int depth, hipStream_t st)      // COMPUTERE on the ghosted box (time step on a hierarchy)
+{
+    Depth &D = L->d[depth];
+    hipLaunchKernelGGL(k_re, grid2d(D.v.nx + 2, D.v.ny + 2), BLK2D, 0, st, D.v, D.fp, L->ph);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 // grad h (cell centred, extrapolated ghosts) and Re on the ghosted level, for the time step
 // (suhmo_step.hip): the un-fused steps 1-3 above
 int suhmo_grad_re(suhmo_level *L, int depth, hipStream_t st)

@@ -128,14 +128,16 @@ __global__ __launch_bounds__(256) void k_melt(DV v, FP fp, suhmo_phys_t ph, suhm
 }
 
 // max over valid cells (signed) and max |(a - b) / s|: Picard convergence test, :3169-3185
+struct Excl { int i0, j0, i1, j1; };       // local cells [i0, i1) x [j0, j1) do not count (covered by a finer level)
 __global__ __launch_bounds__(256) void k_picard_partial(DV v, const double *__restrict__ h, const double *__restrict__ hl,
-                                                        double scale, int mode, double *__restrict__ partial)
+                                                        double scale, int mode, double *__restrict__ partial, Excl ex)
 {
     __shared__ double sm[256];
     int tid = threadIdx.y * blockDim.x + threadIdx.x;
     double acc = mode == 0 ? -1.0e300 : 0.0;
     for (int j = blockIdx.y * blockDim.y + threadIdx.y; j < v.ny; j += gridDim.y * blockDim.y)
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.nx; i += gridDim.x * blockDim.x) {
+            if (i >= ex.i0 && i < ex.i1 && j >= ex.j0 && j < ex.j1) continue;
             int idx = cidx(v, i, j);
             double val = mode == 0 ? h[idx] : fabs((hl[idx] - h[idx]) / scale);
             acc = fmax(acc, val);
@@ -156,11 +158,12 @@ __global__ void k_max_final(const double *__restrict__ partial, int n, double *_
     for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = fmax(sm[tid], sm[tid + s]); __syncthreads(); }
     if (tid == 0) out[0] = sm[0];
 }
-static int reduce_max(suhmo_level *L, const double *h, const double *hl, double scale, int mode, double *out, hipStream_t st)
+static int reduce_max(suhmo_level *L, const double *h, const double *hl, double scale, int mode, double *out, hipStream_t st,
+                      Excl ex = Excl{0, 0, 0, 0})
 {
     Depth &D = L->d[0];
     dim3 grd(std::min((D.v.nx + 63) / 64, 32), std::min((D.v.ny + 3) / 4, 128));
-    hipLaunchKernelGGL(k_picard_partial, grd, dim3(64, 4), 0, st, D.v, h, hl, scale, mode, L->scratch + 1);
+    hipLaunchKernelGGL(k_picard_partial, grd, dim3(64, 4), 0, st, D.v, h, hl, scale, mode, L->scratch + 1, ex);
     hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, st, L->scratch + 1, (int)(grd.x * grd.y), L->scratch);
     HIPCHK(hipMemcpyAsync(L->hscratch, L->scratch, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -173,6 +176,8 @@ static int exchange1(suhmo_level *L, int f, hipStream_t st) { return suhmo_excha
 // grad h (cell centred, ghosted) and Re on the ghosted level: reuses the WFlx_level kernels of
 // suhmo_level.hip (identical arithmetic: NEWMACGRAD + EdgeToCell + ExtrapGhostCells + COMPUTERE)
 int suhmo_grad_re(suhmo_level *L, int depth, hipStream_t st);      // suhmo_level.hip
+int suhmo_grad_cc(suhmo_level *L, int depth, hipStream_t st);
+int suhmo_re_cells(suhmo_level *L, int depth, hipStream_t st);
 int suhmo_copy_ghosts(suhmo_level *L, int depth, int field, hipStream_t st);
 
 static int lagged_chain(suhmo_level *L, hipStream_t st)
@@ -191,6 +196,7 @@ __global__ void k_extrap_ghosts(DV v, double *__restrict__ g)
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 2 * v.ny) {
         int side = t / v.ny, j = t % v.ny;
+        if (v.cfx[side]) return;                             // coarse-fine side: interpolated
         if (side == 0) { int idx = cidx(v, 0, j); g[idx - 1] = v.per[0] ? g[idx + v.nx - 1] : 2.0 * g[idx] - g[idx + 1]; }
         else { int idx = cidx(v, v.nx - 1, j); g[idx + 1] = v.per[0] ? g[idx - (v.nx - 1)] : 2.0 * g[idx] - g[idx - 1]; }
         return;
@@ -198,7 +204,7 @@ __global__ void k_extrap_ghosts(DV v, double *__restrict__ g)
     t -= 2 * v.ny;
     if (t < 2 * v.nx) {
         int side = t / v.nx, i = t % v.nx;
-        if (v.ext[side]) return;                             // rank boundary: exchanged
+        if (v.ext[side]) return;                             // rank boundary: exchanged; coarse-fine side: interpolated
         if (side == 0) { int idx = cidx(v, i, 0); g[idx - v.P] = v.per[1] ? g[idx + (v.ny - 1) * v.P] : 2.0 * g[idx] - g[idx + v.P]; }
         else { int idx = cidx(v, i, v.ny - 1); g[idx + v.P] = v.per[1] ? g[idx - (v.ny - 1) * v.P] : 2.0 * g[idx] - g[idx - v.P]; }
     }
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(256) void k_dcoef_faces(DV v, FP fp, suhmo_phys_t p
         int im = dir == 0 ? idx - 1 : idx - v.P;
         double m = mk[idx], mm1 = mk[im], mec;
         if (fabs(m - mm1) < 1e-10) mec = (m > 0.0) ? 1.0 : -1.0; else mec = 0.0;
-        int f = dir == 0 ? i : j + v.j0, fhi = dir == 0 ? v.nx : v.nyg;   // domain faces (global row on a rank strip)
+        int f = dir == 0 ? i + v.i0 : j + v.j0, fhi = dir == 0 ? v.nxg : v.nyg;   // domain faces (global index on a strip / patch)
         if (f == 0 || f == fhi) mec = 0.0;
         double bec = 0.5 * (B[idx] + B[im]), mrec = 0.5 * (mR[idx] + mR[im]), d;
         if (mec < 0.0 && ph.cutOffB > 0) d = 0.0; else d = fmax(bec * mrec / rho_i, 5.0e-6);
@@ -337,6 +343,120 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
     if (mp->use_impl_diff && (rc = solve_gap_implicit(L, mp, dt, cur_step, st))) return rc;   // :3425-3439
     if ((rc = suhmo_copy_ghosts(L, 0, SUHMO_F_B, st))) return rc;  // :3419-3420 / :3451-3452
     if ((rc = exchange1(L, SUHMO_F_B, st))) return rc;
+    if (picard_iters) *picard_iters = ite_idx;
+    if (vcycles) *vcycles = nv;
+    return 0;
+}
+
+
+// ------------------------------------------------------------------ the time step on an AMR hierarchy
+// oracle/amr_step.c: every level runs the phases above on its own rectangle; in between PiecewiseLinearFillPatch of the
+// coarse-fine ghosts of b, mR, Re (:2373-2380, :2499-2507, :2711-2719), QuadCFInterp of h (inside compGradientMAC) and of
+// the cell-centred gradient (:1650-1656), SolveForHead_nl over all levels, CoarseAverage of h (:3138-3141) and the
+// Picard test over the cells no finer level covers (:3169-3185).  Explicit gap-height update only.
+static int amr_chain(suhmo_level_t **lv, int l, hipStream_t st)
+{
+    suhmo_level *L = lv[l], *C = l > 0 ? lv[l - 1] : nullptr;
+    suhmo_stream_t s = (suhmo_stream_t)st;
+    Depth &D = L->d[0];
+    int rc;
+    if (C && (rc = suhmo_amr2_cf_interp(C, L, SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc;
+    if ((rc = suhmo_grad_cc(L, 0, st))) return rc;
+    if (C) {
+        if ((rc = suhmo_amr2_cf_interp(C, L, SUHMO_F_GRADX, SUHMO_F_GRADX, s))) return rc;
+        if ((rc = suhmo_amr2_cf_interp(C, L, SUHMO_F_GRADY, SUHMO_F_GRADY, s))) return rc;
+    }
+    if ((rc = suhmo_re_cells(L, 0, st))) return rc;
+    if (C && (rc = suhmo_amr2_pwl_fill(C, L, SUHMO_F_RE, SUHMO_F_RE, s))) return rc;
+    hipLaunchKernelGGL(k_qw_faces, dim3((D.v.nx + 1 + 63) / 64, (D.v.ny + 1 + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, L->ph);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static Excl covered_by(suhmo_level_t **lv, int nlev, int l)
+{
+    if (l >= nlev - 1) return Excl{0, 0, 0, 0};
+    const DV &vf = lv[l + 1]->d[0].v, &v = lv[l]->d[0].v;
+    return Excl{vf.i0 / 2 - v.i0, vf.j0 / 2 - v.j0, (vf.i0 + vf.nx) / 2 - v.i0, (vf.j0 + vf.ny) / 2 - v.j0};
+}
+int suhmo_amr_check_hierarchy(suhmo_level_t **lv, int nlev);      // suhmo_amr.hip
+
+extern "C" int suhmo_amr_timestep(suhmo_level_t **lv, int nlev, const suhmo_model_params_t *mp, double dt, int cur_step,
+                                  int *picard_iters, int *vcycles, suhmo_stream_t s)
+{
+    ARG(lv && mp && nlev >= 1 && nlev <= 8); ARG(dt > 0 && cur_step >= 1);
+    for (int l = 0; l < nlev; l++) ARG(lv[l]);
+    if (mp->use_impl_diff) { suhmo_set_error("implicit gap-height update on an AMR hierarchy is not built"); return -5; }
+    int rc = suhmo_amr_check_hierarchy(lv, nlev); if (rc) return rc;
+    for (int l = 0; l < nlev; l++) {
+        const DV &v = lv[l]->d[0].v;
+        if (v.rk[0] || v.rk[1] || (l == 0 && (v.ext[0] || v.ext[1]))) { suhmo_set_error("time step on an AMR hierarchy cut into rank strips is not built"); return -5; }
+        if (mp->use_moulin_source && !lv[l]->d[0].fp.f[SUHMO_F_MSRC]) { suhmo_set_error("use_moulin_source without suhmo_amr_moulin_source"); return -1; }
+    }
+    HIPCHK(hipSetDevice(lv[0]->device));
+    hipStream_t st = (hipStream_t)s;
+    static const int need[] = {SUHMO_F_MR, SUHMO_F_PW, SUHMO_F_QWX, SUHMO_F_QWY, SUHMO_F_HLAG, SUHMO_F_CD, SUHMO_F_GRADX, SUHMO_F_GRADY, SUHMO_F_RE};
+    for (int l = 0; l < nlev; l++) for (int f : need) if (!suhmo_field(lv[l], 0, f)) { suhmo_set_error("field allocation failed"); return -2; }
+    // [I]
+    for (int l = 0; l < nlev; l++) {
+        if (l > 0 && (rc = suhmo_amr2_pwl_fill(lv[l - 1], lv[l], SUHMO_F_B, SUHMO_F_B, s))) return rc;
+        if ((rc = suhmo_copy_ghosts(lv[l], 0, SUHMO_F_B, st))) return rc;
+    }
+    if ((rc = suhmo_level_build_mg_coefficients(lv[0], s))) return rc;
+    suhmo_solver_params_t sp;
+    sp.num_smooth = 4; sp.num_bottom = 16; sp.max_iter = 100; sp.iter_min = 2; sp.imin = 5;
+    sp.eps = 1.0e-7; sp.hang = 0.01; sp.norm_thresh = 1.0e-7; sp.bcoeff_otf = 1; sp.max_depth = -1;
+    if (cur_step < 50) { sp.num_bottom = 10; sp.eps = 1.0e-10; sp.hang = 0.0001; sp.imin = 20; }
+    bool converged = false;
+    int ite_idx = 0, cur_picard = 0, nv = 0;
+    while (!converged) {
+        for (int l = 0; l < nlev; l++) {
+            Depth &D = lv[l]->d[0];
+            if (l > 0) {
+                if ((rc = suhmo_amr2_pwl_fill(lv[l - 1], lv[l], SUHMO_F_B, SUHMO_F_B, s))) return rc;
+                if ((rc = suhmo_amr2_pwl_fill(lv[l - 1], lv[l], SUHMO_F_MR, SUHMO_F_MR, s))) return rc;
+            }
+            if ((rc = suhmo_copy_ghosts(lv[l], 0, SUHMO_F_B, st))) return rc;
+            HIPCHK(hipMemcpyAsync(D.fp.f[SUHMO_F_HLAG], D.fp.f[SUHMO_F_PHI], D.elems * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+        for (int l = 0; l < nlev; l++) if ((rc = amr_chain(lv, l, st))) return rc;
+        for (int l = 0; l < nlev; l++) {
+            Depth &D = lv[l]->d[0];
+            if (mp->diffFactor != 0.0 && (rc = diffusion_terms(lv[l], mp, st))) return rc;
+            hipLaunchKernelGGL(k_melt<0>, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, lv[l]->ph, *mp, dt);
+            HIPCHK(hipGetLastError());
+        }
+        int it = 0;
+        if (nlev == 1) rc = suhmo_level_solve(lv[0], &sp, &it, nullptr, s);
+        else rc = suhmo_amr_solve(lv, nlev, &sp, &it, nullptr, s);
+        if (rc) return rc;
+        nv += it;
+        for (int l = nlev - 1; l > 0; l--) if ((rc = suhmo_amr2_average(lv[l - 1], lv[l], SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc;
+        double maxHead = -1.0e300, res = 0.0;
+        for (int l = 0; l < nlev; l++) {
+            double m = 0.0;
+            if ((rc = reduce_max(lv[l], lv[l]->d[0].fp.f[SUHMO_F_PHI], nullptr, 1.0, 0, &m, st, covered_by(lv, nlev, l)))) return rc;
+            maxHead = std::max(maxHead, m);
+        }
+        for (int l = 0; l < nlev; l++) {
+            double r = 0.0;
+            if ((rc = reduce_max(lv[l], lv[l]->d[0].fp.f[SUHMO_F_PHI], lv[l]->d[0].fp.f[SUHMO_F_HLAG], maxHead, 1, &r, st, covered_by(lv, nlev, l)))) return rc;
+            res = std::max(res, r);
+        }
+        if (ite_idx > 100) { suhmo_set_error("does not converge (Picard iterations > 100)"); return -6; }
+        if (cur_step < 2) { if (res < 0.05 && cur_picard > 2) converged = true; }
+        else if (cur_step < 50) { if (res < 0.05) converged = true; }
+        else { if (res < mp->eps_picard) converged = true; }
+        ite_idx++; cur_picard++;
+    }
+    // [III] level by level: the coarse gap height is already updated when the fine ghost cells are filled
+    for (int l = 0; l < nlev; l++) {
+        Depth &D = lv[l]->d[0];
+        if ((rc = amr_chain(lv, l, st))) return rc;
+        hipLaunchKernelGGL(k_melt<1>, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, lv[l]->ph, *mp, dt);
+        HIPCHK(hipGetLastError());
+        if (l > 0 && (rc = suhmo_amr2_pwl_fill(lv[l - 1], lv[l], SUHMO_F_B, SUHMO_F_B, s))) return rc;
+        if ((rc = suhmo_copy_ghosts(lv[l], 0, SUHMO_F_B, st))) return rc;
+    }
     if (picard_iters) *picard_iters = ite_idx;
     if (vcycles) *vcycles = nv;
     return 0;

@@ -89,3 +89,38 @@ class HipModel:
 
     def close(self):
         self.level.close()
+
+
+class HipAmrModel:
+    """The time loop on a hierarchy (base level + nested patches, patches[k] = box of level k+1 in the cells of level k):
+    suhmo_amr_timestep over the array of level handles; head and gap height of every level stay in HBM."""
+
+    FIELDS = HipModel.FIELDS
+
+    def __init__(self, nx0, ny0, dx0, dy0, bc, phys, model, patches, max_box=64, device=0):
+        self.amr = lv.HipAmr(nx0, ny0, dx0, dy0, bc, phys, patches, alpha=0.0, beta=-1.0, max_box=max_box, device=device)
+        self.levels = self.amr.levels
+        self.model = dict(model)
+        self._mp = model_params(model)
+        self.cur_step = 0
+
+    def set_state(self, l, f):
+        """f: dict with ghosted arrays head, B, Pi, zb, mask of level l (coarse-fine ghost cells: anything, they are interpolated)"""
+        L = self.levels[l]
+        L.set(lv.F_PHI, f["head"][1:-1, 1:-1])
+        L.set(lv.F_ACOEF, np.zeros((L.ny, L.nx)))
+        for k, fid in (("B", lv.F_B), ("Pi", lv.F_PI), ("zb", lv.F_ZB), ("mask", lv.F_MASK)):
+            L.set(fid, f[k], ghosted=True)
+
+    def timestep(self, dt):
+        self.cur_step += 1
+        pi, nv = C.c_int(), C.c_int()
+        check(capi.lib().suhmo_amr_timestep(self.amr._arr, len(self.levels), C.byref(self._mp), float(dt), self.cur_step,
+                                            C.byref(pi), C.byref(nv), self.amr.stream))
+        return pi.value, nv.value
+
+    def get(self, l, name, ghosted=False):
+        return self.levels[l].get(self.FIELDS[name], ghosted=ghosted)
+
+    def close(self):
+        self.amr.close()

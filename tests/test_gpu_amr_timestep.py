@@ -1,0 +1,73 @@
+"""The time step on an AMR hierarchy (suhmo_amr_timestep: per-level phases + PiecewiseLinearFillPatch / QuadCFInterp
+ghosts, AMR solve, average down, Picard test over the uncovered cells) against oracle/amr_step.c on the same inputs:
+BITWISE on every level over several steps; a one-level hierarchy equals suhmo_level_timestep."""
+import numpy as np
+import pytest
+
+from suhmo_amd import synthetic as sy
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("2-levels", 64, 32, ((16, 8, 47, 23),), dict(), 3),
+    ("3-levels", 64, 32, ((16, 8, 47, 23), (40, 22, 79, 41)), dict(), 3),
+    ("2-levels-patch-on-the-boundary", 64, 32, ((0, 0, 31, 15),), dict(), 2),
+    ("2-levels-diffusion", 64, 32, ((16, 8, 47, 23),), dict(diffFactor=1.0), 2),
+]
+
+
+@pytest.mark.parametrize("name,nx0,ny0,patches,mpo,nsteps", CASES, ids=[c[0] for c in CASES])
+def test_amr_timestep_bitwise(oracle, name, nx0, ny0, patches, mpo, nsteps):
+    from suhmo_amd import model
+    m = dict(sy.A3_MODEL, **mpo)
+    sts = sy.shmip_amr_states(nx0, ny0, patches, rough=0.5)
+    O = oracle.OracleAmrModel(nx0, ny0, sts[0]["dx"], sts[0]["dy"], sy.A3_BC, sy.A3_PHYS, m, patches, max_box=16, nthreads=2)
+    G = model.HipAmrModel(nx0, ny0, sts[0]["dx"], sts[0]["dy"], sy.A3_BC, sy.A3_PHYS, m, patches, max_box=16)
+    for l, st in enumerate(sts):
+        O.set_state(l, st)
+        G.set_state(l, st)
+    v = lambda a: np.array(a)[1:-1, 1:-1]
+    for k in range(nsteps):
+        co, cg = O.timestep(m["dt"]), G.timestep(m["dt"])
+        assert co == cg, (k, co, cg)
+        for l in range(len(sts)):
+            for nm, fid in (("head", oracle.OM_H), ("B", oracle.OM_B), ("mR", oracle.OM_MR), ("Pw", oracle.OM_PW), ("rhs_h", oracle.OM_RHSH),
+                            ("Re", oracle.OM_RE)):
+                a, b = v(O.field(l, fid)), G.get(l, nm)
+                assert np.array_equal(a, b, equal_nan=True), (name, k, l, nm, float(np.nanmax(np.abs(a - b))))
+            for nm, fid in (("qwx", oracle.OM_QWX), ("qwy", oracle.OM_QWY)):
+                a, b = np.array(O.field(l, fid)), G.get(l, nm)
+                assert np.array_equal(a, b, equal_nan=True), (name, k, l, nm, float(np.nanmax(np.abs(a - b))))
+            # ghost cells of the gap height after the step: PiecewiseLinearFillPatch on coarse-fine sides, copies on domain sides
+            a, b = np.array(O.field(l, oracle.OM_B)), G.get(l, "B", ghosted=True)
+            assert np.array_equal(a[1:-1, :], b[1:-1, :]) and np.array_equal(a[:, 1:-1], b[:, 1:-1]), (name, k, l, "B ghosts")
+    O.close()
+    G.close()
+
+
+def test_one_level_hierarchy_equals_the_level_timestep():
+    from suhmo_amd import model
+    nx, ny, m = 64, 32, dict(sy.A3_MODEL)
+    st = sy.shmip_amr_states(nx, ny, (), rough=0.5)[0]
+    A = model.HipAmrModel(nx, ny, st["dx"], st["dy"], sy.A3_BC, sy.A3_PHYS, m, (), max_box=16)
+    S = model.HipModel(nx, ny, st["dx"], st["dy"], sy.A3_BC, sy.A3_PHYS, m, max_box=16)
+    A.set_state(0, st)
+    S.set_state(st)
+    for k in range(3):
+        assert A.timestep(m["dt"]) == S.timestep(m["dt"])
+        for nm in ("head", "B", "mR", "qwx", "qwy"):
+            assert np.array_equal(A.get(0, nm), S.get(nm)), (k, nm)
+    A.close()
+    S.close()
+
+
+def test_amr_timestep_refuses_what_is_not_built():
+    from suhmo_amd import capi, model
+    sts = sy.shmip_amr_states(64, 32, ((16, 8, 47, 23),))
+    G = model.HipAmrModel(64, 32, sts[0]["dx"], sts[0]["dy"], sy.A3_BC, sy.A3_PHYS, dict(sy.A3_MODEL, diffFactor=1.0, use_impl_diff=1),
+                          ((16, 8, 47, 23),), max_box=16)
+    for l, st in enumerate(sts):
+        G.set_state(l, st)
+    with pytest.raises(capi.SuhmoError):
+        G.timestep(3600.0)
+    G.close()
