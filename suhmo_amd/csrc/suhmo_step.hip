@@ -488,12 +488,12 @@ __device__ __forceinline__ double moulin_cell(double xc, double yc, double dx, d
          + v[0] * v[1] * MS[3] + v[1] * v[1] * MS[4] + v[2] * v[1] * MS[5]
          + v[0] * v[2] * MS[6] + v[1] * v[2] * MS[7] + v[2] * v[2] * MS[8];
 }
-__global__ __launch_bounds__(256) void k_moulin_partial(DV v, int n, const double *__restrict__ mo, double *__restrict__ partial)
+__global__ __launch_bounds__(256) void k_moulin_partial(DV v, int n, const double *__restrict__ mo, double *__restrict__ partial, Excl ex)
 {
     __shared__ double sm[256];
     const int tid = threadIdx.y * 16 + threadIdx.x;
     const int i = blockIdx.x * 16 + threadIdx.x, j = blockIdx.y * 16 + threadIdx.y;
-    const bool in = i < v.nx && j < v.ny;
+    const bool in = i < v.nx && j < v.ny && !(i >= ex.i0 && i < ex.i1 && j >= ex.j0 && j < ex.j1);   // covered by a finer level: 0
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
     const double tx0 = (blockIdx.x * 16) * v.dx, tx1 = (blockIdx.x * 16 + 16) * v.dx, ty0 = (blockIdx.y * 16) * v.dy, ty1 = (blockIdx.y * 16 + 16) * v.dy;
     for (int m = 0; m < n; m++) {
@@ -521,10 +521,11 @@ __global__ void k_moulin_final(const double *__restrict__ partial, int nblk, int
     if (tid == 0) integ[m] = sm[0];
 }
 __global__ __launch_bounds__(256) void k_moulin_src(DV v, int n, const double *__restrict__ mo, const double *__restrict__ flux,
-                                                    const double *__restrict__ integ, double tf, double *__restrict__ out)
+                                                    const double *__restrict__ integ, double tf, double *__restrict__ out, Excl ex)
 {
     const int i = blockIdx.x * 16 + threadIdx.x, j = blockIdx.y * 16 + threadIdx.y;
     if (i >= v.nx || j >= v.ny) return;
+    if (i >= ex.i0 && i < ex.i1 && j >= ex.j0 && j < ex.j1) { out[cidx(v, i, j)] = 0.0; return; }   // filled by the average of the finer level
     double sum = 0.0;
     for (int m = 0; m < n; m++) {
         bool z;
@@ -560,15 +561,67 @@ extern "C" int suhmo_level_moulin_source(suhmo_level_t *L, int n, const double *
     double *mo = dev, *fl = dev + 3 * (size_t)n, *integ = dev + 4 * (size_t)n, *partial = dev + 5 * (size_t)n;
     hipError_t e = hipMemcpyAsync(dev, h.data(), 4 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_moulin_partial, grdg, blk, 0, st, vg, n, mo, partial);
+        hipLaunchKernelGGL(k_moulin_partial, grdg, blk, 0, st, vg, n, mo, partial, Excl{0, 0, 0, 0});
         hipLaunchKernelGGL(k_moulin_final, dim3(n), dim3(256), 0, st, partial, (int)nblk, n, integ);
-        hipLaunchKernelGGL(k_moulin_src, grd, blk, 0, st, D.v, n, mo, fl, integ, time_factor, out);
+        hipLaunchKernelGGL(k_moulin_src, grd, blk, 0, st, D.v, n, mo, fl, integ, time_factor, out, Excl{0, 0, 0, 0});
         e = hipGetLastError();
     }
     if (e == hipSuccess && integrals) e = hipMemcpyAsync(integrals, integ, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(dev);
     if (e != hipSuccess) { suhmo_set_error("moulin source: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+// Calc_moulin_integral + Calc_moulin_source_term_distributed on the hierarchy (:1866-2066, :2797-2837): every level samples
+// the Gaussians at its own resolution, cells under a finer level do not count in the integrals (finest level first, :1891)
+// and receive the average of the finer level's source term afterwards (CoarseAverage :2819-2826).
+extern "C" int suhmo_amr_moulin_source(suhmo_level_t **lv, int nlev, int n, const double *positions, const double *sigma,
+                                       const double *flux, double time_factor, double *integrals, suhmo_stream_t s)
+{
+    ARG(lv && nlev >= 1 && nlev <= 8 && n >= 1 && positions && sigma && flux);
+    int rc = suhmo_amr_check_hierarchy(lv, nlev); if (rc) return rc;
+    for (int l = 0; l < nlev; l++) {
+        ARG(lv[l]);
+        const DV &v = lv[l]->d[0].v;
+        if (v.rk[0] || v.rk[1] || (l == 0 && (v.ext[0] || v.ext[1]))) { suhmo_set_error("moulin source on an AMR hierarchy cut into rank strips is not built"); return -5; }
+        if (!suhmo_field(lv[l], 0, SUHMO_F_MSRC)) { suhmo_set_error("field allocation failed"); return -2; }
+    }
+    HIPCHK(hipSetDevice(lv[0]->device));
+    hipStream_t st = (hipStream_t)s;
+    std::vector<double> h(4 * (size_t)n), total((size_t)n, 0.0), part((size_t)n);
+    for (int m = 0; m < n; m++) {
+        ARG(sigma[m] > 0.0);
+        h[3 * m] = positions[2 * m]; h[3 * m + 1] = positions[2 * m + 1]; h[3 * m + 2] = sigma[m]; h[3 * (size_t)n + m] = flux[m];
+    }
+    size_t maxblk = 0;
+    for (int l = 0; l < nlev; l++) { const DV &v = lv[l]->d[0].v; maxblk = std::max(maxblk, (size_t)((v.nx + 15) / 16) * ((v.ny + 15) / 16)); }
+    double *dev = nullptr;
+    HIPCHK(hipMalloc(&dev, (5 * (size_t)n + maxblk * n) * sizeof(double)));
+    double *mo = dev, *fl = dev + 3 * (size_t)n, *integ = dev + 4 * (size_t)n, *partial = dev + 5 * (size_t)n;
+    hipError_t e = hipMemcpyAsync(dev, h.data(), 4 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
+    for (int l = nlev - 1; l >= 0 && e == hipSuccess; l--) {
+        const DV &v = lv[l]->d[0].v;
+        dim3 blk(16, 16), grd((v.nx + 15) / 16, (v.ny + 15) / 16);
+        hipLaunchKernelGGL(k_moulin_partial, grd, blk, 0, st, v, n, mo, partial, covered_by(lv, nlev, l));
+        hipLaunchKernelGGL(k_moulin_final, dim3(n), dim3(256), 0, st, partial, (int)(grd.x * grd.y), n, integ);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(part.data(), integ, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        for (int m = 0; m < n; m++) total[m] += part[m];
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(integ, total.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
+    for (int l = 0; l < nlev && e == hipSuccess; l++) {
+        const DV &v = lv[l]->d[0].v;
+        dim3 blk(16, 16), grd((v.nx + 15) / 16, (v.ny + 15) / 16);
+        hipLaunchKernelGGL(k_moulin_src, grd, blk, 0, st, v, n, mo, fl, integ, time_factor, lv[l]->d[0].fp.f[SUHMO_F_MSRC], covered_by(lv, nlev, l));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dev);
+    if (e != hipSuccess) { suhmo_set_error("moulin source: %s", hipGetErrorString(e)); return -2; }
+    for (int l = nlev - 1; l > 0; l--) if ((rc = suhmo_amr2_average(lv[l - 1], lv[l], SUHMO_F_MSRC, SUHMO_F_MSRC, s))) return rc;
+    if (integrals) for (int m = 0; m < n; m++) integrals[m] = total[m];
     return 0;
 }
 

@@ -119,6 +119,16 @@ class HipAmrModel:
                                             C.byref(pi), C.byref(nv), self.amr.stream))
         return pi.value, nv.value
 
+    def moulin_source(self, positions, sigma, flux, time_factor=1.0):
+        """Calc_moulin_integral over the hierarchy + the source term of every level (suhmo_amr_moulin_source)"""
+        pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1)
+        sg, fl = np.ascontiguousarray(sigma, dtype=np.float64), np.ascontiguousarray(flux, dtype=np.float64)
+        integ = np.zeros(sg.size)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        check(capi.lib().suhmo_amr_moulin_source(self.amr._arr, len(self.levels), sg.size, dp(pos), dp(sg), dp(fl), float(time_factor),
+                                                 dp(integ), self.amr.stream))
+        return integ
+
     def get(self, l, name, ghosted=False):
         return self.levels[l].get(self.FIELDS[name], ghosted=ghosted)
 

@@ -45,6 +45,45 @@ def test_amr_timestep_bitwise(oracle, name, nx0, ny0, patches, mpo, nsteps):
     G.close()
 
 
+def test_amr_moulin_source_and_timestep(oracle):
+    """moulins on the hierarchy: integrals over the uncovered cells of all levels, source term per level, covered cells =
+    average of the finer level (1e-13: two exp libraries); the time step then consumes the oracle's source term bit for bit"""
+    from suhmo_amd import model, level as lv
+    from test_gpu_moulin import moulins
+    nx0, ny0, patches = 64, 32, ((16, 8, 47, 23), (40, 22, 79, 41))
+    m = dict(sy.A3_MODEL, use_moulin_source=1, distributed_input=7.93e-11)
+    sts = sy.shmip_amr_states(nx0, ny0, patches, rough=0.5)
+    pos, sg, fl = moulins(6, 3)
+    pos[0] = (52000.0, 10500.0)                       # one moulin inside the finest patch
+    sg = np.full(6, 1500.0)
+    O = oracle.OracleAmrModel(nx0, ny0, sts[0]["dx"], sts[0]["dy"], sy.A3_BC, sy.A3_PHYS, m, patches, max_box=16, nthreads=2)
+    G = model.HipAmrModel(nx0, ny0, sts[0]["dx"], sts[0]["dy"], sy.A3_BC, sy.A3_PHYS, m, patches, max_box=16)
+    for l, st in enumerate(sts):
+        O.set_state(l, st)
+        G.set_state(l, st)
+    io, ig = O.moulin_source(pos, sg, fl, 0.8), G.moulin_source(pos, sg, fl, 0.8)
+    assert np.max(np.abs(io - ig)) <= 1e-13 * np.max(io)
+    tot = 0.0
+    for l in range(3):
+        a, b = np.array(O.field(l, oracle.OM_MSRC))[1:-1, 1:-1], G.get(l, "msrc")
+        assert np.max(np.abs(a - b)) <= 1e-13 * np.max(a), l
+        # flux delivered by the uncovered cells of this level
+        cov = np.zeros_like(b, dtype=bool)
+        if l < 2:
+            ci0, cj0, ci1, cj1 = patches[l]
+            cov[cj0 - sts[l]["j0"]:cj1 + 1 - sts[l]["j0"], ci0 - sts[l]["i0"]:ci1 + 1 - sts[l]["i0"]] = True
+        tot += b[~cov].sum() * sts[l]["dx"] * sts[l]["dy"]
+        G.levels[l].set(lv.F_MSRC, a)                 # continue from identical source terms
+    assert abs(tot - 0.8 * fl.sum()) < 1e-11 * fl.sum()   # every moulin delivers its flux over the composite grid
+    for k in range(2):
+        assert O.timestep(m["dt"]) == G.timestep(m["dt"])
+        for l in range(3):
+            for nm, fid in (("head", oracle.OM_H), ("B", oracle.OM_B), ("rhs_h", oracle.OM_RHSH)):
+                assert np.array_equal(np.array(O.field(l, fid))[1:-1, 1:-1], G.get(l, nm)), (k, l, nm)
+    O.close()
+    G.close()
+
+
 def test_one_level_hierarchy_equals_the_level_timestep():
     from suhmo_amd import model
     nx, ny, m = 64, 32, dict(sy.A3_MODEL)
