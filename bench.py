@@ -219,6 +219,30 @@ def side_configs(sy, level, sp, args):
     dt = (time.perf_counter() - t0) / 200
     out["shmip_a3_320x64_timestep"] = {"steps_per_s": 1.0 / dt, "ms_per_step": 1e3 * dt, "vcycles_per_step": nv / 200.0}
     M.close()
+    # cfg5 shape: transient head + gap height on a 3-level hierarchy with moulins (base 1024 x 256 over 100 km x 20 km,
+    # two nested patches refined by 2 each), 20 steps after 10
+    nx0, ny0, patches = 1024, 256, ((256, 64, 767, 191), (768, 192, 1279, 319))
+    ma = dict(sy.A3_MODEL, use_moulin_source=1, distributed_input=7.93e-11)
+    sts = sy.shmip_amr_states(nx0, ny0, patches)
+    A = model.HipAmrModel(nx0, ny0, sts[0]["dx"], sts[0]["dy"], sy.A3_BC, sy.A3_PHYS, ma, patches, max_box=64)
+    for l, st_ in enumerate(sts):
+        A.set_state(l, st_)
+    import numpy as np
+    rng = np.random.default_rng(7)
+    pos = np.stack([rng.uniform(3.0e4, 7.0e4, 63), rng.uniform(6.0e3, 1.4e4, 63)], axis=1)      # 63 moulins as exec/AMR_multiMoulins
+    A.moulin_source(pos, np.full(63, 200.0), np.full(63, 90.0 / 63), 1.0)
+    for _ in range(10):
+        A.timestep(ma["dt"])
+    A.levels[0].synchronize()
+    t0 = time.perf_counter()
+    nv = 0
+    for _ in range(20):
+        nv += A.timestep(ma["dt"])[1]
+    A.levels[0].synchronize()
+    dt = (time.perf_counter() - t0) / 20
+    out["amr3_timestep_1024x256_base_63_moulins"] = {"steps_per_s": 1.0 / dt, "ms_per_step": 1e3 * dt, "amr_vcycles_per_step": nv / 20.0,
+                                                     "cells_per_level": [int(st_["nx"] * st_["ny"]) for st_ in sts]}
+    A.close()
     return out
 
 

@@ -63,6 +63,7 @@ void or_amr_model_destroy(OrAmrModel *S)
     or_amr_destroy(S->A);
     free(S);
 }
+OrModel *or_amr_model_level(OrAmrModel *S, int l) { return S->M[l]; }
 double *or_amr_model_field(OrAmrModel *S, int l, int id) { return or_model_field(S->M[l], id); }
 void or_amr_model_dims(OrAmrModel *S, int l, int *nx, int *ny, int *i0, int *j0)
 { *nx = S->M[l]->nx; *ny = S->M[l]->ny; *i0 = S->M[l]->i0; *j0 = S->M[l]->j0; }

@@ -100,6 +100,10 @@ def lib():
         L.or_amr_model_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(OrBC), C.POINTER(OrPhys),
                                           C.POINTER(OrModelParams), C.c_int, C.POINTER(C.c_int)]
         L.or_amr_model_destroy.argtypes = [C.c_void_p]
+        L.or_amr_model_level.restype = C.c_void_p
+        L.or_amr_model_level.argtypes = [C.c_void_p, C.c_int]
+        L.or_pwl_fill.argtypes = [C.c_void_p, C.c_void_p, dp, dp]
+        L.or_quadcf_fill.argtypes = [C.c_void_p, C.c_void_p, dp, dp]
         L.or_amr_model_field.restype = dp
         L.or_amr_model_field.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.or_amr_model_timestep.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -351,6 +355,12 @@ class OracleAmrModel:
     def set_state(self, l, f):
         for k, fid in (("head", OM_H), ("B", OM_B), ("Pi", OM_PI), ("zb", OM_ZB), ("mask", OM_MASK)):
             self.field(l, fid)[:] = f[k]
+
+    def fill_ghosts(self, l, fid, kind="pwl"):
+        """coarse-fine ghost cells of field fid of level l from level l-1: PiecewiseLinearFillPatch or QuadCFInterp"""
+        f = lib().or_pwl_fill if kind == "pwl" else lib().or_quadcf_fill
+        f(lib().or_amr_model_level(self.h, l), lib().or_amr_model_level(self.h, l - 1), lib().or_amr_model_field(self.h, l, fid),
+          lib().or_amr_model_field(self.h, l - 1, fid))
 
     def moulin_source(self, positions, sigma, flux, time_factor=1.0):
         pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1)
