@@ -313,7 +313,8 @@ int suhmo_amr_solve(suhmo_level_t **levels, int nlev, const suhmo_solver_params_
 /* suhmo_level_timestep on the hierarchy (AmrHydro::timeStepFAS with m_finest_level > 0): per level the same phases,
  * PiecewiseLinearFillPatch of the coarse-fine ghosts of b, mR, Re, QuadCFInterp of h and of its cell-centred gradient,
  * SolveForHead_nl over all levels, CoarseAverage of h (:3138-3141), Picard test over the cells no finer level covers.
- * Explicit gap-height update (rc -5 with use_impl_diff).  PHI / B of every level updated in place. */
+ * Gap height: forward Euler level by level, or (use_impl_diff) SolveForGap_nl over the hierarchy.  PHI / B of every level
+ * updated in place. */
 int suhmo_amr_timestep(suhmo_level_t **levels, int nlev, const suhmo_model_params_t *mp, double dt, int cur_step,
                        int *picard_iters, int *vcycles, suhmo_stream_t s);
 /* suhmo_level_moulin_source on the hierarchy (Calc_moulin_integral over all levels, src/AmrHydro.cpp:1866-2019: cells under

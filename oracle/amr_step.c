@@ -9,7 +9,8 @@
  *   QuadCFInterp of h inside Gradient::compGradientMAC and of the cell-centred gradient (:1650-1656)
  *   SolveForHead_nl over all levels (AMRFASMultiGrid, oracle/amrn.c), CoarseAverage of h (:3138-3141)
  *   computeMax over the cells not covered by a finer level (:3169, :3185)
- * explicit gap-height update (the implicit one is single-level here).  [Chombo] PiecewiseLinearFillPatch is restated
+ * explicit gap-height update or the implicit one (SolveForGap_nl over the hierarchy, with the stand-in operator and cycle of
+ * time_loop.c:solve_gap_implicit).  [Chombo] PiecewiseLinearFillPatch is restated
  * from upstream Chombo 3.2's documented algorithm (fillConstantInterp + computeMultiDimSlopes: central differences,
  * one-sided next to the domain boundary, FORT_INTERPLIMIT's multi-dimensional limiter over the 3 x 3 neighbourhood +
  * FORT_INTERPLINEAR) -- the fork is not vendored: UNPINNED, like the rest of the Chombo-side AMR pieces.
@@ -34,6 +35,12 @@ typedef struct OrAmrModel {
     OrAmr *A;
     OrModel *M[AMAXLEV];
     int cur_step;
+    /* implicit gap-height solve on the hierarchy (SolveForGap_nl :593-662): a second set of levels with alpha = 1,
+     * beta = dt diffFactor, bCoef = D, no nonlinear term, Neumann-0 sides (as time_loop.c:solve_gap_implicit) */
+    OrLevel *Gbase; OrAmr *GA; double G_dt;
+    int nx0, ny0, max_box, nthreads, patches[4 * AMAXLEV];
+    double dx0, dy0;
+    OrBC bc; OrPhys ph;
 } OrAmrModel;
 
 #define G(M, a, i, j) (a)[(size_t)((j) + 1) * ((M)->nx + 2) + ((i) + 1)]      /* ghosted array of a level, LOCAL indices */
@@ -43,6 +50,8 @@ OrAmrModel *or_amr_model_create(OrLevel *base, int nx0, int ny0, double dx0, dou
 {
     OrAmrModel *S = (OrAmrModel *)calloc(1, sizeof(OrAmrModel));
     S->nlev = nlev; S->base = base;
+    S->nx0 = nx0; S->ny0 = ny0; S->dx0 = dx0; S->dy0 = dy0; S->bc = *bc; S->ph = *ph; S->max_box = 64; S->nthreads = 1;
+    for (int k = 0; k < 4 * (nlev - 1); k++) S->patches[k] = patches[k];
     S->A = or_amr_create(base, nx0, ny0, dx0, dy0, bc, ph, 0.0, -1.0, nlev, patches);
     S->M[0] = or_model_create(base, nx0, ny0, dx0, dy0, bc, ph, mp);
     int nxg = nx0, nyg = ny0;                              /* domain size at the level being built */
@@ -61,9 +70,12 @@ void or_amr_model_destroy(OrAmrModel *S)
     if (!S) return;
     for (int l = 0; l < S->nlev; l++) or_model_destroy(S->M[l]);
     or_amr_destroy(S->A);
+    if (S->GA) or_amr_destroy(S->GA);
+    if (S->Gbase) or_level_destroy(S->Gbase);
     free(S);
 }
 OrModel *or_amr_model_level(OrAmrModel *S, int l) { return S->M[l]; }
+void or_amr_model_gap_solver_layout(OrAmrModel *S, int max_box, int nthreads) { S->max_box = max_box; S->nthreads = nthreads; }
 double *or_amr_model_field(OrAmrModel *S, int l, int id) { return or_model_field(S->M[l], id); }
 void or_amr_model_dims(OrAmrModel *S, int l, int *nx, int *ny, int *i0, int *j0)
 { *nx = S->M[l]->nx; *ny = S->M[l]->ny; *i0 = S->M[l]->i0; *j0 = S->M[l]->j0; }
@@ -218,7 +230,7 @@ void or_amr_model_moulin_source(OrAmrModel *S, int nm, const double *pos, const 
 int or_amr_model_timestep(OrAmrModel *S, double dt, int *picard_iters, int *vcycles_total)
 {
     const int n = S->nlev;
-    if (S->M[0]->mp.use_impl_diff) return -2;
+    const int impl = S->M[0]->mp.use_impl_diff;
     double *tmp[AMAXLEV];
     for (int l = 0; l < n; l++) tmp[l] = (double *)malloc(sizeof(double) * (size_t)S->M[l]->nx * S->M[l]->ny);
     for (int l = 0; l < n; l++) {                                     /* static fields of the solver's levels (factory define) */
@@ -285,12 +297,58 @@ int or_amr_model_timestep(OrAmrModel *S, double dt, int *picard_iters, int *vcyc
         ite_idx++; cur_picard++;
     }
     /* [III] level by level: the coarse gap height is already updated when the fine ghosts are filled (:3252-3421) */
+    double *rhs_b[AMAXLEV] = {0};
     for (int l = 0; l < n; l++) {
         OrModel *M = S->M[l];
         chain(S, l);
-        or_model_gap_update(M, dt);
-        if (l > 0) { or_pwl_fill(M, S->M[l - 1], M->c[OM_B], S->M[l - 1]->c[OM_B]); or_model_copy_ghosts(M, M->c[OM_B]); }
+        if (impl) { rhs_b[l] = (double *)malloc(sizeof(double) * (size_t)M->nx * M->ny); or_model_gap_rhs(M, dt, rhs_b[l]); }
+        else {
+            or_model_gap_update(M, dt);
+            if (l > 0) { or_pwl_fill(M, S->M[l - 1], M->c[OM_B], S->M[l - 1]->c[OM_B]); or_model_copy_ghosts(M, M->c[OM_B]); }
+        }
         M->time += dt;
+    }
+    if (impl) {                                                       /* SolveForGap_nl over the hierarchy :3425-3455 */
+        const OrModelParams *p = &S->M[0]->mp;
+        if (!S->GA || S->G_dt != dt) {
+            if (S->GA) { or_amr_destroy(S->GA); or_level_destroy(S->Gbase); }
+            OrBC nb = S->bc;
+            for (int d = 0; d < 2; d++) for (int sd = 0; sd < 2; sd++) { nb.type[d][sd] = 1; nb.value[d][sd] = 0.0; }
+            OrPhys lp = S->ph; lp.use_NL = 0;
+            S->Gbase = or_level_create(S->nx0, S->ny0, S->dx0, S->dy0, S->max_box, &nb, &lp, 1.0, dt * p->diffFactor, S->nthreads);
+            S->GA = or_amr_create(S->Gbase, S->nx0, S->ny0, S->dx0, S->dy0, &nb, &lp, 1.0, dt * p->diffFactor, n, S->patches);
+            S->G_dt = dt;
+            for (int l = 0; l < n; l++) {                             /* aCoeff_GH = 1 :1820-1828 */
+                OrModel *M = S->M[l];
+                for (size_t k = 0; k < (size_t)M->nx * M->ny; k++) tmp[l][k] = 1.0;
+                if (l == 0) { or_level_set(S->Gbase, 0, OR_F_ACOEF, tmp[l], 0); or_level_set(S->Gbase, 0, OR_F_MASK, M->c[OM_MASK], 1); }
+                else { or_amr_patch_io(S->GA, l, OR_F_ACOEF, tmp[l], 0, 1); or_amr_patch_io(S->GA, l, OR_F_MASK, M->c[OM_MASK], 1, 1); }
+            }
+        }
+        for (int l = 0; l < n; l++) {
+            OrModel *M = S->M[l];
+            for (int j = 0; j < M->ny; j++) for (int i = 0; i < M->nx; i++) tmp[l][(size_t)j * M->nx + i] = G(M, M->c[OM_B], i, j);
+            if (l == 0) {
+                or_level_set(S->Gbase, 0, OR_F_PHI, tmp[l], 0); or_level_set(S->Gbase, 0, OR_F_RHS, rhs_b[l], 0);
+                or_level_set(S->Gbase, 0, OR_F_BX, or_model_dcoef(M, 0), 0); or_level_set(S->Gbase, 0, OR_F_BY, or_model_dcoef(M, 1), 0);
+                or_level_build_mg_coefficients(S->Gbase);
+            } else {
+                or_amr_patch_io(S->GA, l, OR_F_PHI, tmp[l], 0, 1); or_amr_patch_io(S->GA, l, OR_F_RHS, rhs_b[l], 0, 1);
+                or_amr_patch_io(S->GA, l, OR_F_BX, (double *)or_model_dcoef(M, 0), 0, 1); or_amr_patch_io(S->GA, l, OR_F_BY, (double *)or_model_dcoef(M, 1), 0, 1);
+            }
+        }
+        OrSolverParams spg;
+        spg.num_smooth = 2; spg.num_bottom = 4; spg.max_iter = 100; spg.iter_min = 2; spg.imin = S->M[0]->cur_step < 50 ? 10 : 5;
+        spg.eps = 1.0e-7; spg.hang = 1.0e-6; spg.norm_thresh = 1.0e-7; spg.bcoeff_otf = 0; spg.max_depth = -1;
+        (void)or_amr_solve(S->GA, &spg, NULL);
+        for (int l = 0; l < n; l++) {
+            OrModel *M = S->M[l];
+            if (l == 0) or_level_get(S->Gbase, 0, OR_F_PHI, tmp[l], 0); else or_amr_patch_io(S->GA, l, OR_F_PHI, tmp[l], 0, 0);
+            for (int j = 0; j < M->ny; j++) for (int i = 0; i < M->nx; i++) G(M, M->c[OM_B], i, j) = tmp[l][(size_t)j * M->nx + i];
+            if (l > 0) or_pwl_fill(M, S->M[l - 1], M->c[OM_B], S->M[l - 1]->c[OM_B]);
+            or_model_copy_ghosts(M, M->c[OM_B]);
+            free(rhs_b[l]);
+        }
     }
     for (int l = 0; l < n; l++) free(tmp[l]);
     if (picard_iters) *picard_iters = ite_idx;

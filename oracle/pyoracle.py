@@ -100,6 +100,7 @@ def lib():
         L.or_amr_model_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(OrBC), C.POINTER(OrPhys),
                                           C.POINTER(OrModelParams), C.c_int, C.POINTER(C.c_int)]
         L.or_amr_model_destroy.argtypes = [C.c_void_p]
+        L.or_amr_model_gap_solver_layout.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.or_amr_model_level.restype = C.c_void_p
         L.or_amr_model_level.argtypes = [C.c_void_p, C.c_int]
         L.or_pwl_fill.argtypes = [C.c_void_p, C.c_void_p, dp, dp]
@@ -345,6 +346,7 @@ class OracleAmrModel:
         self.h = lib().or_amr_model_create(self.level.h, nx0, ny0, dx0, dy0, C.byref(self.level._bc), C.byref(self.level._ph),
                                            C.byref(self._mp), self.nlev, flat)
         self.level.set(F_ACOEF, np.zeros((ny0, nx0)))
+        lib().or_amr_model_gap_solver_layout(self.h, max_box, nthreads)
 
     def field(self, l, fid):
         nx, ny = self.dims[l]

@@ -347,16 +347,16 @@ int or_model_picard_converged(const OrModel *M, double res, int cur_picard)  /* 
     if (M->cur_step < 50) return res < 0.05;
     return res < M->mp.eps_picard;
 }
-/* [III] after the chain was re-evaluated with the new head: melt rate, CalcRHS_gapHeightFAS :2069-2171, forward Euler
- * :3406 or the implicit solve :3425-3439, ghosts of b on the domain sides :3419-3420 */
-void or_model_gap_update(OrModel *M, double dt)
+/* [III] after the chain was re-evaluated with the new head: melt rate, CalcRHS_gapHeightFAS :2069-2171 and -- explicit
+ * update -- forward Euler :3406.  With use_impl_diff the gap height stays and rhs_b (valid cells, nx * ny) receives the
+ * right-hand side b + dt RHS of the implicit solve. */
+void or_model_gap_rhs(OrModel *M, double dt, double *rhs_b)
 {
     const OrModelParams *p = &M->mp;
     int nx = M->nx, ny = M->ny;
     double *B = M->c[OM_B], *Bold = M->c[OM_BOLD], *IM = M->c[OM_MASK], *mR = M->c[OM_MR], *Pi = M->c[OM_PI], *Pw = M->c[OM_PW], *CD = M->c[OM_CD];
     melting_rate(M);
     double ub_norm = sqrt(p->ub0 * p->ub0 + p->ub1 * p->ub1);
-    double *rhs_b = p->use_impl_diff ? (double *)malloc(sizeof(double) * (size_t)nx * ny) : NULL;
     for (int j = 0; j < ny; j++)
         for (int i = 0; i < nx; i++) {
             double b = CC(B, i, j);
@@ -375,9 +375,16 @@ void or_model_gap_update(OrModel *M, double dt)
             if (p->use_impl_diff) rhs_b[(size_t)j * nx + i] = RHS;
             else CC(B, i, j) = RHS * dt + CC(Bold, i, j);     /* forward Euler :3406 */
         }
-    if (p->use_impl_diff) { solve_gap_implicit(M, dt, rhs_b); free(rhs_b); }                                   /* :3425-3439 */
-    copy_ghosts(M, B);
 }
+/* ... + the implicit solve of one level :3425-3439, ghosts of b on the domain sides :3419-3420 */
+void or_model_gap_update(OrModel *M, double dt)
+{
+    double *rhs_b = M->mp.use_impl_diff ? (double *)malloc(sizeof(double) * (size_t)M->nx * M->ny) : NULL;
+    or_model_gap_rhs(M, dt, rhs_b);
+    if (M->mp.use_impl_diff) { solve_gap_implicit(M, dt, rhs_b); free(rhs_b); }
+    copy_ghosts(M, M->c[OM_B]);
+}
+const double *or_model_dcoef(const OrModel *M, int dir) { return dir == 0 ? M->dxf : M->dyf; }
 
 /* one timestep; returns 0, or -1 if the Picard loop exceeds 100 iterations (:3190-3195) */
 int or_model_timestep(OrModel *M, double dt, int *picard_iters, int *vcycles_total)

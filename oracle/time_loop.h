@@ -64,5 +64,7 @@ void or_model_qw(OrModel *M);                           /* Re_ec, COMPUTEQW */
 void or_model_rhs_h(OrModel *M);                        /* source, lagged diffusion, melt rate, RHS_h */
 void or_model_solver_params(const OrModel *M, OrSolverParams *sp);
 int or_model_picard_converged(const OrModel *M, double res, int cur_picard);
+void or_model_gap_rhs(OrModel *M, double dt, double *rhs_b);   /* melt rate, CalcRHS_gapHeightFAS; explicit: forward Euler, implicit: rhs_b */
+const double *or_model_dcoef(const OrModel *M, int dir);        /* D on the faces (lagged, from the last or_model_rhs_h) */
 void or_model_gap_update(OrModel *M, double dt);        /* melt rate, CalcRHS_gapHeightFAS, forward Euler / implicit solve, ghosts */
 #endif

@@ -256,7 +256,8 @@ static int diffusion_terms(suhmo_level *L, const suhmo_model_params_t *mp, hipSt
 // linear operator (alpha = 1, aCoef = 1, beta = dt diffFactor, bCoef = D, no nonlinear term), FixedNeumBCFill = Neumann 0.
 // [Chombo] VCAMRPoissonOp2 / AMRMultiGrid are not in the reference's tree: the cycle is the FAS cycle of suhmo_fas.hip,
 // which for a linear operator converges to the same solution (oracle/time_loop.c:solve_gap_implicit does the same).
-static int solve_gap_implicit(suhmo_level *L, const suhmo_model_params_t *mp, double dt, int cur_step, hipStream_t st)
+// the second handle of a level (created on first use / when dt changes) loaded with this step's data
+static int gap_level_prepare(suhmo_level *L, const suhmo_model_params_t *mp, double dt, hipStream_t st)
 {
     Depth &D = L->d[0];
     if (!L->gap || L->gap_dt != dt) {
@@ -280,13 +281,22 @@ static int solve_gap_implicit(suhmo_level *L, const suhmo_model_params_t *mp, do
     HIPCHK(hipMemcpyAsync(GD.fp.f[SUHMO_F_BY], D.fp.f[SUHMO_F_DCY], bytes, hipMemcpyDeviceToDevice, st));
     GD.phi_fresh = 0;
     static const int halo_fields[] = {SUHMO_F_RHS, SUHMO_F_ACOEF, SUHMO_F_BX, SUHMO_F_BY};
-    int rc = suhmo_exchange_list(G, 0, halo_fields, 4, st); if (rc) return rc;
-    rc = suhmo_level_build_mg_coefficients(G, (suhmo_stream_t)st); if (rc) return rc;    // coarse D = average of the fine faces
-    suhmo_solver_params_t sp;
+    return suhmo_exchange_list(G, 0, halo_fields, 4, st);
+}
+static void gap_solver_params(suhmo_solver_params_t &sp, int cur_step)
+{
     sp.num_smooth = 2; sp.num_bottom = 4; sp.max_iter = 100; sp.iter_min = 2; sp.imin = cur_step < 50 ? 10 : 5;
     sp.eps = 1.0e-7; sp.hang = 1.0e-6; sp.norm_thresh = 1.0e-7; sp.bcoeff_otf = 0; sp.max_depth = -1;
+}
+static int solve_gap_implicit(suhmo_level *L, const suhmo_model_params_t *mp, double dt, int cur_step, hipStream_t st)
+{
+    int rc = gap_level_prepare(L, mp, dt, st); if (rc) return rc;
+    suhmo_level *G = L->gap;
+    rc = suhmo_level_build_mg_coefficients(G, (suhmo_stream_t)st); if (rc) return rc;    // coarse D = average of the fine faces
+    suhmo_solver_params_t sp;
+    gap_solver_params(sp, cur_step);
     if ((rc = suhmo_level_solve(G, &sp, nullptr, nullptr, (suhmo_stream_t)st))) return rc;
-    HIPCHK(hipMemcpyAsync(D.fp.f[SUHMO_F_B], GD.fp.f[SUHMO_F_PHI], bytes, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(L->d[0].fp.f[SUHMO_F_B], G->d[0].fp.f[SUHMO_F_PHI], L->d[0].elems * sizeof(double), hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -353,7 +363,8 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
 // oracle/amr_step.c: every level runs the phases above on its own rectangle; in between PiecewiseLinearFillPatch of the
 // coarse-fine ghosts of b, mR, Re (:2373-2380, :2499-2507, :2711-2719), QuadCFInterp of h (inside compGradientMAC) and of
 // the cell-centred gradient (:1650-1656), SolveForHead_nl over all levels, CoarseAverage of h (:3138-3141) and the
-// Picard test over the cells no finer level covers (:3169-3185).  Explicit gap-height update only.
+// Picard test over the cells no finer level covers (:3169-3185); the gap height by forward Euler level by level, or by
+// SolveForGap_nl over a second hierarchy of handles (alpha = 1, beta = dt diffFactor, bCoef = D, as solve_gap_implicit).
 static int amr_chain(suhmo_level_t **lv, int l, hipStream_t st)
 {
     suhmo_level *L = lv[l], *C = l > 0 ? lv[l - 1] : nullptr;
@@ -385,7 +396,7 @@ extern "C" int suhmo_amr_timestep(suhmo_level_t **lv, int nlev, const suhmo_mode
 {
     ARG(lv && mp && nlev >= 1 && nlev <= 8); ARG(dt > 0 && cur_step >= 1);
     for (int l = 0; l < nlev; l++) ARG(lv[l]);
-    if (mp->use_impl_diff) { suhmo_set_error("implicit gap-height update on an AMR hierarchy is not built"); return -5; }
+    if (mp->use_impl_diff && mp->diffFactor == 0.0) { suhmo_set_error("use_ImplDiff with diffFactor = 0"); return -1; }
     int rc = suhmo_amr_check_hierarchy(lv, nlev); if (rc) return rc;
     for (int l = 0; l < nlev; l++) {
         const DV &v = lv[l]->d[0].v;
@@ -454,8 +465,25 @@ extern "C" int suhmo_amr_timestep(suhmo_level_t **lv, int nlev, const suhmo_mode
         if ((rc = amr_chain(lv, l, st))) return rc;
         hipLaunchKernelGGL(k_melt<1>, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, lv[l]->ph, *mp, dt);
         HIPCHK(hipGetLastError());
+        if (mp->use_impl_diff) continue;                               // b stays, RES = b + dt RHS
         if (l > 0 && (rc = suhmo_amr2_pwl_fill(lv[l - 1], lv[l], SUHMO_F_B, SUHMO_F_B, s))) return rc;
         if ((rc = suhmo_copy_ghosts(lv[l], 0, SUHMO_F_B, st))) return rc;
+    }
+    if (mp->use_impl_diff) {                                           // SolveForGap_nl over the hierarchy :3425-3455
+        suhmo_level_t *gaps[8];
+        for (int l = 0; l < nlev; l++) { if ((rc = gap_level_prepare(lv[l], mp, dt, st))) return rc; gaps[l] = lv[l]->gap; }
+        if ((rc = suhmo_level_build_mg_coefficients(gaps[0], s))) return rc;
+        suhmo_solver_params_t spg;
+        gap_solver_params(spg, cur_step);
+        if (nlev == 1) rc = suhmo_level_solve(gaps[0], &spg, nullptr, nullptr, s);
+        else rc = suhmo_amr_solve(gaps, nlev, &spg, nullptr, nullptr, s);
+        if (rc) return rc;
+        for (int l = 0; l < nlev; l++) {
+            Depth &D = lv[l]->d[0];
+            HIPCHK(hipMemcpyAsync(D.fp.f[SUHMO_F_B], gaps[l]->d[0].fp.f[SUHMO_F_PHI], D.elems * sizeof(double), hipMemcpyDeviceToDevice, st));
+            if (l > 0 && (rc = suhmo_amr2_pwl_fill(lv[l - 1], lv[l], SUHMO_F_B, SUHMO_F_B, s))) return rc;
+            if ((rc = suhmo_copy_ghosts(lv[l], 0, SUHMO_F_B, st))) return rc;
+        }
     }
     if (picard_iters) *picard_iters = ite_idx;
     if (vcycles) *vcycles = nv;

@@ -13,6 +13,8 @@ CASES = [
     ("3-levels", 64, 32, ((16, 8, 47, 23), (40, 22, 79, 41)), dict(), 3),
     ("2-levels-patch-on-the-boundary", 64, 32, ((0, 0, 31, 15),), dict(), 2),
     ("2-levels-diffusion", 64, 32, ((16, 8, 47, 23),), dict(diffFactor=1.0), 2),
+    ("2-levels-implicit-gap", 64, 32, ((16, 8, 47, 23),), dict(diffFactor=1.0, use_impl_diff=1), 3),
+    ("3-levels-implicit-gap", 64, 32, ((16, 8, 47, 23), (40, 22, 79, 41)), dict(diffFactor=1.0, use_impl_diff=1), 2),
 ]
 
 
@@ -103,7 +105,7 @@ def test_one_level_hierarchy_equals_the_level_timestep():
 def test_amr_timestep_refuses_what_is_not_built():
     from suhmo_amd import capi, model
     sts = sy.shmip_amr_states(64, 32, ((16, 8, 47, 23),))
-    G = model.HipAmrModel(64, 32, sts[0]["dx"], sts[0]["dy"], sy.A3_BC, sy.A3_PHYS, dict(sy.A3_MODEL, diffFactor=1.0, use_impl_diff=1),
+    G = model.HipAmrModel(64, 32, sts[0]["dx"], sts[0]["dy"], sy.A3_BC, sy.A3_PHYS, dict(sy.A3_MODEL, diffFactor=0.0, use_impl_diff=1),
                           ((16, 8, 47, 23),), max_box=16)
     for l, st in enumerate(sts):
         G.set_state(l, st)
