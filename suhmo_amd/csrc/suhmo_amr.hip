@@ -321,7 +321,7 @@ extern "C" int suhmo_amr2_pwl_fill(suhmo_level_t *C, suhmo_level_t *F, int field
     ARG(field_f != SUHMO_F_BX && field_f != SUHMO_F_BY && field_f != SUHMO_F_QWX && field_f != SUHMO_F_QWY && field_f != SUHMO_F_DCX && field_f != SUHMO_F_DCY);
     HIPCHK(hipSetDevice(F->device));
     const DV &vf = F->d[0].v, &vc = C->d[0].v;
-    if (vc.rk[0] || vc.rk[1] || vf.rk[0] || vf.rk[1]) { suhmo_set_error("PiecewiseLinearFillPatch on rank strips is not built"); return -5; }
+    // rank strips: the 3 x 3 coarse neighbourhood reaches one halo row of the coarse strip (the caller exchanged field_c)
     double *pf = suhmo_field(F, 0, field_f), *pc = suhmo_field(C, 0, field_c);
     if (!pf || !pc) { suhmo_set_error("field allocation failed"); return -2; }
     if (field_f == SUHMO_F_PHI) F->d[0].phi_fresh = 0;

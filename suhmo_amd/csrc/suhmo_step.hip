@@ -159,7 +159,7 @@ __global__ void k_max_final(const double *__restrict__ partial, int n, double *_
     if (tid == 0) out[0] = sm[0];
 }
 static int reduce_max(suhmo_level *L, const double *h, const double *hl, double scale, int mode, double *out, hipStream_t st,
-                      Excl ex = Excl{0, 0, 0, 0})
+                      Excl ex = Excl{0, 0, 0, 0}, bool local_only = false)
 {
     Depth &D = L->d[0];
     dim3 grd(std::min((D.v.nx + 63) / 64, 32), std::min((D.v.ny + 3) / 4, 128));
@@ -168,7 +168,7 @@ static int reduce_max(suhmo_level *L, const double *h, const double *hl, double 
     HIPCHK(hipMemcpyAsync(L->hscratch, L->scratch, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     *out = L->hscratch[0];
-    if (L->ar && (D.v.ext[0] || D.v.ext[1])) { int rc = L->ar(L->user, out); if (rc) return rc; }   // computeMax / norm over all ranks
+    if (!local_only && L->ar && (D.v.ext[0] || D.v.ext[1])) { int rc = L->ar(L->user, out); if (rc) return rc; }   // computeMax / norm over all ranks
     return 0;
 }
 static int exchange1(suhmo_level *L, int f, hipStream_t st) { return suhmo_exchange_list(L, 0, &f, 1, st); }
@@ -365,12 +365,16 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
 // the cell-centred gradient (:1650-1656), SolveForHead_nl over all levels, CoarseAverage of h (:3138-3141) and the
 // Picard test over the cells no finer level covers (:3169-3185); the gap height by forward Euler level by level, or by
 // SolveForGap_nl over a second hierarchy of handles (alpha = 1, beta = dt diffFactor, bCoef = D, as solve_gap_implicit).
+// Rank strips: a rank holds of every level the rows of its own slab (lv[l] = NULL where the patch does not reach it);
+// it still mirrors, on level l-1, the halo demand level l puts there, so that all ranks of a level's communicator issue
+// the same sequence of exchanges (as the AMR cycle does, suhmo_amr.hip).
 static int amr_chain(suhmo_level_t **lv, int l, hipStream_t st)
 {
     suhmo_level *L = lv[l], *C = l > 0 ? lv[l - 1] : nullptr;
     suhmo_stream_t s = (suhmo_stream_t)st;
-    Depth &D = L->d[0];
     int rc;
+    if (!L) return C ? suhmo_ensure_phi_halo(C, 0, 1, st) : 0;
+    Depth &D = L->d[0];
     if (C && (rc = suhmo_amr2_cf_interp(C, L, SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc;
     if ((rc = suhmo_grad_cc(L, 0, st))) return rc;
     if (C) {
@@ -385,33 +389,44 @@ static int amr_chain(suhmo_level_t **lv, int l, hipStream_t st)
 }
 static Excl covered_by(suhmo_level_t **lv, int nlev, int l)
 {
-    if (l >= nlev - 1) return Excl{0, 0, 0, 0};
+    if (l >= nlev - 1 || !lv[l + 1]) return Excl{0, 0, 0, 0};
     const DV &vf = lv[l + 1]->d[0].v, &v = lv[l]->d[0].v;
     return Excl{vf.i0 / 2 - v.i0, vf.j0 / 2 - v.j0, (vf.i0 + vf.nx) / 2 - v.i0, (vf.j0 + vf.ny) / 2 - v.j0};
+}
+// ghosts of b of every level: PiecewiseLinearFillPatch on coarse-fine sides (from the coarser level's current b, whose halo
+// rows were exchanged just before), copies on domain sides, halo rows on rank boundaries
+static int amr_gap_ghosts(suhmo_level_t **lv, int nlev, int l, hipStream_t st)
+{
+    int rc;
+    if (!lv[l]) return 0;
+    if (l > 0 && (rc = suhmo_amr2_pwl_fill(lv[l - 1], lv[l], SUHMO_F_B, SUHMO_F_B, (suhmo_stream_t)st))) return rc;
+    if ((rc = suhmo_copy_ghosts(lv[l], 0, SUHMO_F_B, st))) return rc;
+    return exchange1(lv[l], SUHMO_F_B, st);
 }
 int suhmo_amr_check_hierarchy(suhmo_level_t **lv, int nlev);      // suhmo_amr.hip
 
 extern "C" int suhmo_amr_timestep(suhmo_level_t **lv, int nlev, const suhmo_model_params_t *mp, double dt, int cur_step,
                                   int *picard_iters, int *vcycles, suhmo_stream_t s)
 {
-    ARG(lv && mp && nlev >= 1 && nlev <= 8); ARG(dt > 0 && cur_step >= 1);
-    for (int l = 0; l < nlev; l++) ARG(lv[l]);
+    ARG(lv && mp && nlev >= 1 && nlev <= 8 && lv[0]); ARG(dt > 0 && cur_step >= 1);
     if (mp->use_impl_diff && mp->diffFactor == 0.0) { suhmo_set_error("use_ImplDiff with diffFactor = 0"); return -1; }
     int rc = suhmo_amr_check_hierarchy(lv, nlev); if (rc) return rc;
+    bool strips = false;
     for (int l = 0; l < nlev; l++) {
+        if (!lv[l]) { strips = true; continue; }
         const DV &v = lv[l]->d[0].v;
-        if (v.rk[0] || v.rk[1] || (l == 0 && (v.ext[0] || v.ext[1]))) { suhmo_set_error("time step on an AMR hierarchy cut into rank strips is not built"); return -5; }
-        if (mp->use_moulin_source && !lv[l]->d[0].fp.f[SUHMO_F_MSRC]) { suhmo_set_error("use_moulin_source without suhmo_amr_moulin_source"); return -1; }
+        if (v.rk[0] || v.rk[1]) {
+            strips = true;
+            if (!(lv[l]->ex && lv[l]->ar)) { suhmo_set_error("time step on rank strips needs the exchange hooks on every level"); return -1; }
+        }
+        if (mp->use_moulin_source && !lv[l]->d[0].fp.f[SUHMO_F_MSRC]) { suhmo_set_error("use_moulin_source without a moulin source term (SUHMO_F_MSRC)"); return -1; }
     }
     HIPCHK(hipSetDevice(lv[0]->device));
     hipStream_t st = (hipStream_t)s;
     static const int need[] = {SUHMO_F_MR, SUHMO_F_PW, SUHMO_F_QWX, SUHMO_F_QWY, SUHMO_F_HLAG, SUHMO_F_CD, SUHMO_F_GRADX, SUHMO_F_GRADY, SUHMO_F_RE};
-    for (int l = 0; l < nlev; l++) for (int f : need) if (!suhmo_field(lv[l], 0, f)) { suhmo_set_error("field allocation failed"); return -2; }
+    for (int l = 0; l < nlev; l++) if (lv[l]) for (int f : need) if (!suhmo_field(lv[l], 0, f)) { suhmo_set_error("field allocation failed"); return -2; }
     // [I]
-    for (int l = 0; l < nlev; l++) {
-        if (l > 0 && (rc = suhmo_amr2_pwl_fill(lv[l - 1], lv[l], SUHMO_F_B, SUHMO_F_B, s))) return rc;
-        if ((rc = suhmo_copy_ghosts(lv[l], 0, SUHMO_F_B, st))) return rc;
-    }
+    for (int l = 0; l < nlev; l++) if ((rc = amr_gap_ghosts(lv, nlev, l, st))) return rc;
     if ((rc = suhmo_level_build_mg_coefficients(lv[0], s))) return rc;
     suhmo_solver_params_t sp;
     sp.num_smooth = 4; sp.num_bottom = 16; sp.max_iter = 100; sp.iter_min = 2; sp.imin = 5;
@@ -421,38 +436,46 @@ extern "C" int suhmo_amr_timestep(suhmo_level_t **lv, int nlev, const suhmo_mode
     int ite_idx = 0, cur_picard = 0, nv = 0;
     while (!converged) {
         for (int l = 0; l < nlev; l++) {
+            if (!lv[l]) continue;
             Depth &D = lv[l]->d[0];
-            if (l > 0) {
-                if ((rc = suhmo_amr2_pwl_fill(lv[l - 1], lv[l], SUHMO_F_B, SUHMO_F_B, s))) return rc;
-                if ((rc = suhmo_amr2_pwl_fill(lv[l - 1], lv[l], SUHMO_F_MR, SUHMO_F_MR, s))) return rc;
-            }
-            if ((rc = suhmo_copy_ghosts(lv[l], 0, SUHMO_F_B, st))) return rc;
+            if ((rc = exchange1(lv[l], SUHMO_F_MR, st))) return rc;                    // levelmR.exchange() :2513 (and the stencil of the fill below)
+            if (l > 0 && (rc = suhmo_amr2_pwl_fill(lv[l - 1], lv[l], SUHMO_F_MR, SUHMO_F_MR, s))) return rc;
+            if ((rc = amr_gap_ghosts(lv, nlev, l, st))) return rc;
             HIPCHK(hipMemcpyAsync(D.fp.f[SUHMO_F_HLAG], D.fp.f[SUHMO_F_PHI], D.elems * sizeof(double), hipMemcpyDeviceToDevice, st));
         }
         for (int l = 0; l < nlev; l++) if ((rc = amr_chain(lv, l, st))) return rc;
         for (int l = 0; l < nlev; l++) {
+            if (!lv[l]) continue;
             Depth &D = lv[l]->d[0];
             if (mp->diffFactor != 0.0 && (rc = diffusion_terms(lv[l], mp, st))) return rc;
             hipLaunchKernelGGL(k_melt<0>, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, lv[l]->ph, *mp, dt);
             HIPCHK(hipGetLastError());
+            if ((rc = exchange1(lv[l], SUHMO_F_RHS, st))) return rc;                   // halo rows relaxed redundantly
         }
         int it = 0;
         if (nlev == 1) rc = suhmo_level_solve(lv[0], &sp, &it, nullptr, s);
         else rc = suhmo_amr_solve(lv, nlev, &sp, &it, nullptr, s);
         if (rc) return rc;
         nv += it;
-        for (int l = nlev - 1; l > 0; l--) if ((rc = suhmo_amr2_average(lv[l - 1], lv[l], SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc;
+        for (int l = nlev - 1; l > 0; l--) {                                            // CoarseAverage :3138-3141
+            if (lv[l]) { if ((rc = suhmo_amr2_average(lv[l - 1], lv[l], SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc; }
+            else if (lv[l - 1]) lv[l - 1]->d[0].phi_fresh = 0;                          // changed on the ranks that hold level l
+        }
         double maxHead = -1.0e300, res = 0.0;
         for (int l = 0; l < nlev; l++) {
+            if (!lv[l]) continue;
             double m = 0.0;
-            if ((rc = reduce_max(lv[l], lv[l]->d[0].fp.f[SUHMO_F_PHI], nullptr, 1.0, 0, &m, st, covered_by(lv, nlev, l)))) return rc;
+            if ((rc = reduce_max(lv[l], lv[l]->d[0].fp.f[SUHMO_F_PHI], nullptr, 1.0, 0, &m, st, covered_by(lv, nlev, l), true))) return rc;
             maxHead = std::max(maxHead, m);
         }
+        if (strips && (rc = lv[0]->ar(lv[0]->user, &maxHead))) return rc;              // computeMax over all ranks (level 0 reaches every rank)
         for (int l = 0; l < nlev; l++) {
+            if (!lv[l]) continue;
             double r = 0.0;
-            if ((rc = reduce_max(lv[l], lv[l]->d[0].fp.f[SUHMO_F_PHI], lv[l]->d[0].fp.f[SUHMO_F_HLAG], maxHead, 1, &r, st, covered_by(lv, nlev, l)))) return rc;
+            if ((rc = reduce_max(lv[l], lv[l]->d[0].fp.f[SUHMO_F_PHI], lv[l]->d[0].fp.f[SUHMO_F_HLAG], maxHead, 1, &r, st, covered_by(lv, nlev, l), true))) return rc;
             res = std::max(res, r);
         }
+        if (strips && (rc = lv[0]->ar(lv[0]->user, &res))) return rc;
         if (ite_idx > 100) { suhmo_set_error("does not converge (Picard iterations > 100)"); return -6; }
         if (cur_step < 2) { if (res < 0.05 && cur_picard > 2) converged = true; }
         else if (cur_step < 50) { if (res < 0.05) converged = true; }
@@ -461,17 +484,22 @@ extern "C" int suhmo_amr_timestep(suhmo_level_t **lv, int nlev, const suhmo_mode
     }
     // [III] level by level: the coarse gap height is already updated when the fine ghost cells are filled
     for (int l = 0; l < nlev; l++) {
-        Depth &D = lv[l]->d[0];
         if ((rc = amr_chain(lv, l, st))) return rc;
+        if (!lv[l]) continue;
+        Depth &D = lv[l]->d[0];
         hipLaunchKernelGGL(k_melt<1>, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, lv[l]->ph, *mp, dt);
         HIPCHK(hipGetLastError());
         if (mp->use_impl_diff) continue;                               // b stays, RES = b + dt RHS
-        if (l > 0 && (rc = suhmo_amr2_pwl_fill(lv[l - 1], lv[l], SUHMO_F_B, SUHMO_F_B, s))) return rc;
-        if ((rc = suhmo_copy_ghosts(lv[l], 0, SUHMO_F_B, st))) return rc;
+        if ((rc = amr_gap_ghosts(lv, nlev, l, st))) return rc;
     }
     if (mp->use_impl_diff) {                                           // SolveForGap_nl over the hierarchy :3425-3455
         suhmo_level_t *gaps[8];
-        for (int l = 0; l < nlev; l++) { if ((rc = gap_level_prepare(lv[l], mp, dt, st))) return rc; gaps[l] = lv[l]->gap; }
+        for (int l = 0; l < nlev; l++) {
+            gaps[l] = nullptr;
+            if (!lv[l]) continue;
+            if ((rc = gap_level_prepare(lv[l], mp, dt, st))) return rc;
+            gaps[l] = lv[l]->gap;
+        }
         if ((rc = suhmo_level_build_mg_coefficients(gaps[0], s))) return rc;
         suhmo_solver_params_t spg;
         gap_solver_params(spg, cur_step);
@@ -479,17 +507,16 @@ extern "C" int suhmo_amr_timestep(suhmo_level_t **lv, int nlev, const suhmo_mode
         else rc = suhmo_amr_solve(gaps, nlev, &spg, nullptr, nullptr, s);
         if (rc) return rc;
         for (int l = 0; l < nlev; l++) {
+            if (!lv[l]) continue;
             Depth &D = lv[l]->d[0];
             HIPCHK(hipMemcpyAsync(D.fp.f[SUHMO_F_B], gaps[l]->d[0].fp.f[SUHMO_F_PHI], D.elems * sizeof(double), hipMemcpyDeviceToDevice, st));
-            if (l > 0 && (rc = suhmo_amr2_pwl_fill(lv[l - 1], lv[l], SUHMO_F_B, SUHMO_F_B, s))) return rc;
-            if ((rc = suhmo_copy_ghosts(lv[l], 0, SUHMO_F_B, st))) return rc;
+            if ((rc = amr_gap_ghosts(lv, nlev, l, st))) return rc;
         }
     }
     if (picard_iters) *picard_iters = ite_idx;
     if (vcycles) *vcycles = nv;
     return 0;
 }
-
 
 // ------------------------------------------------------------------ moulin source term
 // Calc_moulin_integral / Calc_moulin_source_term_distributed (src/AmrHydro.cpp:1866-2066).  The n x N array of the
