@@ -318,9 +318,12 @@ int suhmo_amr_solve(suhmo_level_t **levels, int nlev, const suhmo_solver_params_
 int suhmo_amr_timestep(suhmo_level_t **levels, int nlev, const suhmo_model_params_t *mp, double dt, int cur_step,
                        int *picard_iters, int *vcycles, suhmo_stream_t s);
 /* suhmo_level_moulin_source on the hierarchy (Calc_moulin_integral over all levels, src/AmrHydro.cpp:1866-2019: cells under
- * a finer level do not count; :2819-2826: they get the average of the finer level's source term).  MSRC of every level. */
-int suhmo_amr_moulin_source(suhmo_level_t **levels, int nlev, int n_moulins, const double *positions, const double *sigma,
-                            const double *flux, double time_factor, double *integrals, suhmo_stream_t s);
+ * a finer level do not count; :2819-2826: they get the average of the finer level's source term).  MSRC of every level
+ * this process holds.  patch_boxes: 4 (nlev - 1) ints, box (lo0, lo1, hi0, hi1) of level l+1 in the cells of level l;
+ * NULL = take the geometry from the handles (every level whole on this process).  On rank strips every rank integrates
+ * all levels itself from patch_boxes: no communication, the single-process bits. */
+int suhmo_amr_moulin_source(suhmo_level_t **levels, int nlev, const int *patch_boxes, int n_moulins, const double *positions,
+                            const double *sigma, const double *flux, double time_factor, double *integrals, suhmo_stream_t s);
 
 /* timing helper: average device time (ms) of the GSRB sweep kernel launches since the
  * last reset, measured with HIP events on the launch stream */

@@ -137,7 +137,7 @@ def lib():
     L.suhmo_level_set_bc.argtypes = [vp, C.POINTER(BC)]
     L.suhmo_amr2_reflux.argtypes = [vp, vp, C.c_int, vp]
     L.suhmo_amr2_pwl_fill.argtypes = [vp, vp, C.c_int, C.c_int, vp]
-    L.suhmo_amr_moulin_source.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, dp, dp, C.c_double, dp, vp]
+    L.suhmo_amr_moulin_source.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int), C.c_int, dp, dp, dp, C.c_double, dp, vp]
     L.suhmo_amr_timestep.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(ModelParams), C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]
     L.suhmo_amr2_prolong_pc.argtypes = [vp, vp, C.c_int, vp]
     L.suhmo_amr2_finer_operator_changed.argtypes = [vp, vp, vp]

@@ -631,17 +631,33 @@ extern "C" int suhmo_level_moulin_source(suhmo_level_t *L, int n, const double *
 // Calc_moulin_integral + Calc_moulin_source_term_distributed on the hierarchy (:1866-2066, :2797-2837): every level samples
 // the Gaussians at its own resolution, cells under a finer level do not count in the integrals (finest level first, :1891)
 // and receive the average of the finer level's source term afterwards (CoarseAverage :2819-2826).
-extern "C" int suhmo_amr_moulin_source(suhmo_level_t **lv, int nlev, int n, const double *positions, const double *sigma,
-                                       const double *flux, double time_factor, double *integrals, suhmo_stream_t s)
+extern "C" int suhmo_amr_moulin_source(suhmo_level_t **lv, int nlev, const int *patch_boxes, int n, const double *positions,
+                                       const double *sigma, const double *flux, double time_factor, double *integrals, suhmo_stream_t s)
 {
-    ARG(lv && nlev >= 1 && nlev <= 8 && n >= 1 && positions && sigma && flux);
+    ARG(lv && nlev >= 1 && nlev <= 8 && lv[0] && n >= 1 && positions && sigma && flux);
     int rc = suhmo_amr_check_hierarchy(lv, nlev); if (rc) return rc;
-    for (int l = 0; l < nlev; l++) {
-        ARG(lv[l]);
-        const DV &v = lv[l]->d[0].v;
-        if (v.rk[0] || v.rk[1] || (l == 0 && (v.ext[0] || v.ext[1]))) { suhmo_set_error("moulin source on an AMR hierarchy cut into rank strips is not built"); return -5; }
-        if (!suhmo_field(lv[l], 0, SUHMO_F_MSRC)) { suhmo_set_error("field allocation failed"); return -2; }
+    // geometry of every level's WHOLE rectangle: from the boxes (rank strips: a rank may hold a part of a level or none of
+    // it, and integrates all of them itself -- analytic integrand, single-process order, no communication) or the handles
+    struct Geo { int nx, ny, i0, j0; double dx, dy; } geo[8];
+    const DV &b = lv[0]->d[0].v;
+    geo[0] = Geo{b.nx, b.nyg, 0, 0, b.dx, b.dy};
+    for (int l = 1; l < nlev; l++) {
+        if (patch_boxes) {
+            const int *q = patch_boxes + 4 * (l - 1);
+            ARG(q[2] >= q[0] && q[3] >= q[1]);
+            geo[l] = Geo{2 * (q[2] - q[0] + 1), 2 * (q[3] - q[1] + 1), 2 * q[0], 2 * q[1], geo[l - 1].dx / 2.0, geo[l - 1].dy / 2.0};
+            if (lv[l]) { const DV &v = lv[l]->d[0].v; if (v.nx != geo[l].nx || v.i0 != geo[l].i0 || v.j0 < geo[l].j0 || v.j0 + v.ny > geo[l].j0 + geo[l].ny) { suhmo_set_error("moulin source: level %d does not match patch_boxes", l); return -1; } }
+        } else {
+            if (!lv[l] || lv[l]->d[0].v.rk[0] || lv[l]->d[0].v.rk[1]) { suhmo_set_error("moulin source on rank strips needs patch_boxes"); return -1; }
+            const DV &v = lv[l]->d[0].v;
+            geo[l] = Geo{v.nx, v.ny, v.i0, v.j0, v.dx, v.dy};
+        }
     }
+    auto excl_of = [&](int l, int i0, int j0) {                       // the box of level l+1 in cells of level l, relative to (i0, j0)
+        if (l >= nlev - 1) return Excl{0, 0, 0, 0};
+        return Excl{geo[l + 1].i0 / 2 - i0, geo[l + 1].j0 / 2 - j0, (geo[l + 1].i0 + geo[l + 1].nx) / 2 - i0, (geo[l + 1].j0 + geo[l + 1].ny) / 2 - j0};
+    };
+    for (int l = 0; l < nlev; l++) if (lv[l] && !suhmo_field(lv[l], 0, SUHMO_F_MSRC)) { suhmo_set_error("field allocation failed"); return -2; }
     HIPCHK(hipSetDevice(lv[0]->device));
     hipStream_t st = (hipStream_t)s;
     std::vector<double> h(4 * (size_t)n), total((size_t)n, 0.0), part((size_t)n);
@@ -650,15 +666,16 @@ extern "C" int suhmo_amr_moulin_source(suhmo_level_t **lv, int nlev, int n, cons
         h[3 * m] = positions[2 * m]; h[3 * m + 1] = positions[2 * m + 1]; h[3 * m + 2] = sigma[m]; h[3 * (size_t)n + m] = flux[m];
     }
     size_t maxblk = 0;
-    for (int l = 0; l < nlev; l++) { const DV &v = lv[l]->d[0].v; maxblk = std::max(maxblk, (size_t)((v.nx + 15) / 16) * ((v.ny + 15) / 16)); }
+    for (int l = 0; l < nlev; l++) maxblk = std::max(maxblk, (size_t)((geo[l].nx + 15) / 16) * ((geo[l].ny + 15) / 16));
     double *dev = nullptr;
     HIPCHK(hipMalloc(&dev, (5 * (size_t)n + maxblk * n) * sizeof(double)));
     double *mo = dev, *fl = dev + 3 * (size_t)n, *integ = dev + 4 * (size_t)n, *partial = dev + 5 * (size_t)n;
     hipError_t e = hipMemcpyAsync(dev, h.data(), 4 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
-    for (int l = nlev - 1; l >= 0 && e == hipSuccess; l--) {
-        const DV &v = lv[l]->d[0].v;
-        dim3 blk(16, 16), grd((v.nx + 15) / 16, (v.ny + 15) / 16);
-        hipLaunchKernelGGL(k_moulin_partial, grd, blk, 0, st, v, n, mo, partial, covered_by(lv, nlev, l));
+    for (int l = nlev - 1; l >= 0 && e == hipSuccess; l--) {          // finest first (:1891)
+        DV vg = b;                                                     // only the geometry below is read by the kernel
+        vg.nx = geo[l].nx; vg.ny = geo[l].ny; vg.i0 = geo[l].i0; vg.j0 = geo[l].j0; vg.dx = geo[l].dx; vg.dy = geo[l].dy;
+        dim3 blk(16, 16), grd((vg.nx + 15) / 16, (vg.ny + 15) / 16);
+        hipLaunchKernelGGL(k_moulin_partial, grd, blk, 0, st, vg, n, mo, partial, excl_of(l, vg.i0, vg.j0));
         hipLaunchKernelGGL(k_moulin_final, dim3(n), dim3(256), 0, st, partial, (int)(grd.x * grd.y), n, integ);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(part.data(), integ, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
@@ -667,15 +684,16 @@ extern "C" int suhmo_amr_moulin_source(suhmo_level_t **lv, int nlev, int n, cons
     }
     if (e == hipSuccess) e = hipMemcpyAsync(integ, total.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
     for (int l = 0; l < nlev && e == hipSuccess; l++) {
+        if (!lv[l]) continue;
         const DV &v = lv[l]->d[0].v;
         dim3 blk(16, 16), grd((v.nx + 15) / 16, (v.ny + 15) / 16);
-        hipLaunchKernelGGL(k_moulin_src, grd, blk, 0, st, v, n, mo, fl, integ, time_factor, lv[l]->d[0].fp.f[SUHMO_F_MSRC], covered_by(lv, nlev, l));
+        hipLaunchKernelGGL(k_moulin_src, grd, blk, 0, st, v, n, mo, fl, integ, time_factor, lv[l]->d[0].fp.f[SUHMO_F_MSRC], excl_of(l, v.i0, v.j0));
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(dev);
     if (e != hipSuccess) { suhmo_set_error("moulin source: %s", hipGetErrorString(e)); return -2; }
-    for (int l = nlev - 1; l > 0; l--) if ((rc = suhmo_amr2_average(lv[l - 1], lv[l], SUHMO_F_MSRC, SUHMO_F_MSRC, s))) return rc;
+    for (int l = nlev - 1; l > 0; l--) if (lv[l] && (rc = suhmo_amr2_average(lv[l - 1], lv[l], SUHMO_F_MSRC, SUHMO_F_MSRC, s))) return rc;
     if (integrals) for (int m = 0; m < n; m++) integrals[m] = total[m];
     return 0;
 }

@@ -125,7 +125,7 @@ class HipAmrModel:
         sg, fl = np.ascontiguousarray(sigma, dtype=np.float64), np.ascontiguousarray(flux, dtype=np.float64)
         integ = np.zeros(sg.size)
         dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
-        check(capi.lib().suhmo_amr_moulin_source(self.amr._arr, len(self.levels), sg.size, dp(pos), dp(sg), dp(fl), float(time_factor),
+        check(capi.lib().suhmo_amr_moulin_source(self.amr._arr, len(self.levels), None, sg.size, dp(pos), dp(sg), dp(fl), float(time_factor),
                                                  dp(integ), self.amr.stream))
         return integ
 

@@ -20,7 +20,7 @@ def strip_state(st, r0, ny):
     return {k: (v[r0:r0 + ny + 2] if isinstance(v, np.ndarray) else v) for k, v in st.items()}
 
 
-def run_strips(world, nx0, ny0, patches, sts, m, nsteps, msrc=None):
+def run_strips(world, nx0, ny0, patches, sts, m, nsteps, mou=None):
     from suhmo_amd import capi, level as lv, model, multigpu
     nlev = 1 + len(patches)
     n0 = ny0 // world
@@ -57,13 +57,18 @@ def run_strips(world, nx0, ny0, patches, sts, m, nsteps, msrc=None):
                 G.set(lv.F_ACOEF, np.zeros((ny, G.nx)))
                 for k, fid in (("B", lv.F_B), ("Pi", lv.F_PI), ("zb", lv.F_ZB), ("mask", lv.F_MASK)):
                     G.set(fid, f[k], ghosted=True)
-                if msrc is not None:
-                    G.set(lv.F_MSRC, msrc[l][j0 - rng[l][0]:j0 - rng[l][0] + ny])
                 ex = multigpu.StripExchanger(G, trs[l], part[l].index(rank), len(part[l]), False)
                 ex.exchange_static()
                 keep.append(ex)
                 levels.append(G)
             arr = (C.c_void_p * nlev)(*[(g.h if g else None) for g in levels])
+            integ = None
+            if mou is not None:          # every rank integrates the whole hierarchy itself from the patch boxes
+                pos, sg, fl = [np.ascontiguousarray(a, dtype=np.float64) for a in mou]
+                integ = np.zeros(sg.size)
+                boxes = (C.c_int * (4 * len(patches)))(*[v for p in patches for v in p])
+                dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+                capi.check(capi.lib().suhmo_amr_moulin_source(arr, nlev, boxes, sg.size, dp(pos.reshape(-1)), dp(sg), dp(fl), 1.0, dp(integ), None))
             counts = []
             for k in range(nsteps):
                 pi, nv = C.c_int(), C.c_int()
@@ -73,7 +78,7 @@ def run_strips(world, nx0, ny0, patches, sts, m, nsteps, msrc=None):
             for g in levels:
                 if g:
                     g.synchronize()
-            out[rank] = (counts, res)
+            out[rank] = (counts, res, integ, [(g.get(lv.F_MSRC) if (g and mou is not None) else None) for g in levels])
             for g in reversed(levels):
                 if g:
                     g.close()
@@ -109,18 +114,25 @@ def test_amr_timestep_on_strips_bitwise(case):
     A = model.HipAmrModel(nx0, ny0, sts[0]["dx"], sts[0]["dy"], sy.A3_BC, sy.A3_PHYS, m, patches, max_box=MB)
     for l, st in enumerate(sts):
         A.set_state(l, st)
-    msrc = None
+    mou = msrc = iref = None
     if m.get("use_moulin_source"):
         from test_gpu_moulin import moulins
         pos, sg, fl = moulins(5, 3)
-        A.moulin_source(pos, np.full(5, 1500.0), fl, 1.0)
-        msrc = [A.get(l, "msrc") for l in range(len(sts))]       # the strips get the hierarchy's source term
+        mou = (pos, np.full(5, 1500.0), fl)
+        iref = A.moulin_source(*mou, 1.0)
+        msrc = [A.get(l, "msrc") for l in range(len(sts))]
     ref_counts = [A.timestep(m["dt"]) for _ in range(nsteps)]
     ref = [{nm: A.get(l, nm) for nm in NAMES} for l in range(len(sts))]
     A.close()
-    out, own = run_strips(world, nx0, ny0, patches, sts, m, nsteps, msrc)
+    out, own = run_strips(world, nx0, ny0, patches, sts, m, nsteps, mou)
     for r in range(world):
         assert out[r][0] == ref_counts, (r, out[r][0], ref_counts)
+        if mou is not None:
+            assert np.array_equal(out[r][2], iref)                 # integrals: the single-process bits on every rank
+    if mou is not None:
+        for l in range(len(sts)):
+            got = np.vstack([out[r][3][l] for r in range(world) if own[r][l]])
+            assert np.array_equal(got, msrc[l]), (name, l, "msrc")
     for l in range(len(sts)):
         for nm in NAMES:
             got = np.vstack([out[r][1][l][nm] for r in range(world) if own[r][l]])
