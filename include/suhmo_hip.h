@@ -90,6 +90,7 @@ enum {
     SUHMO_F_RHS0,        /* AMR: the base level's own rhs while it carries the FAS rhs */
     SUHMO_F_MSRC,        /* moulin source term, m/s (suhmo_level_moulin_source) */
     SUHMO_F_DCX, SUHMO_F_DCY, SUHMO_F_DTERM,   /* diffusion coefficient of the gap height on x / y faces, div(D grad b) */
+    SUHMO_F_ZS,          /* ice surface height (m_iceheight), input of suhmo_level_time_varying_recharge */
     SUHMO_F_COUNT
 };
 
@@ -216,6 +217,12 @@ int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t *mp, doubl
  * whole level itself (the integrand is analytic), in the single-process order: no communication, same bits. */
 int suhmo_level_moulin_source(suhmo_level_t *L, int n_moulins, const double *positions, const double *sigma,
                               const double *flux, double time_factor, double *integrals, suhmo_stream_t s);
+
+/* Time-varying distributed recharge (suhmo.time_varying_input, suites D / F of SHMIP; COMPUTE_TIMEVARYINGRECHARGE,
+ * src/AmrHydroF.ChF:346-373, caller src/AmrHydro.cpp:2849-2861): MSRC = max(ddf (T_K + zs dT/dz), 0) + background with
+ * ddf = 0.01/86400, dT/dz = -0.0075, zs = SUHMO_F_ZS, T_K = -16 cos(2 pi (t - t_restart)/year) - 5 + deltaT computed by the
+ * caller.  Use with model.use_moulin_source = 1, ramp = 1, distributed_input = 0 (RHS_h takes MSRC as its source term). */
+int suhmo_level_time_varying_recharge(suhmo_level_t *L, double T_K, double background_input, suhmo_stream_t s);
 
 /* SHMIP cross-section table of the current state (AmrHydro::timeStepFAS post-processing, src/AmrHydro.cpp:3647-4102;
  * columns of the results/postproc.dat files under exec/A_SHMIP, exec/B_SHMIP, ...): for every cell column i the row

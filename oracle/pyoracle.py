@@ -96,6 +96,7 @@ def lib():
         L.or_model_field.argtypes = [C.c_void_p, C.c_int]
         L.or_model_timestep.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.or_model_step_index.argtypes = [C.c_void_p]
+        L.or_time_varying_recharge.argtypes = [C.c_int, dp, C.c_double, C.c_double, dp]
         L.or_amr_model_create.restype = C.c_void_p
         L.or_amr_model_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(OrBC), C.POINTER(OrPhys),
                                           C.POINTER(OrModelParams), C.c_int, C.POINTER(C.c_int)]
@@ -330,6 +331,14 @@ class OracleModel:
             lib().or_model_destroy(self.h)
             self.h = None
             self.level.close()
+
+
+def time_varying_recharge(zs, T_K, background):
+    """oracle/time_loop.c:or_time_varying_recharge on an array of ice surface heights"""
+    a = np.ascontiguousarray(zs, dtype=np.float64)
+    out = np.zeros_like(a)
+    lib().or_time_varying_recharge(a.size, _dp(a.reshape(-1)), float(T_K), float(background), _dp(out.reshape(-1)))
+    return out
 
 
 class OracleAmrModel:

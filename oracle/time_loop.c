@@ -431,6 +431,13 @@ int or_model_timestep(OrModel *M, double dt, int *picard_iters, int *vcycles_tot
 }
 
 
+/* COMPUTE_TIMEVARYINGRECHARGE (src/AmrHydroF.ChF:346-373) over n cells */
+void or_time_varying_recharge(int n, const double *zs, double TK, double background, double *recharge)
+{
+    const double ddf = 0.01 / 86400., dT_dZ = -0.0075;
+    for (int k = 0; k < n; k++) recharge[k] = fmax(ddf * (TK + zs[k] * dT_dZ), 0.0) + background;
+}
+
 /* Calc_moulin_integral + Calc_moulin_source_term_distributed (src/AmrHydro.cpp:1866-2066), single level:
  * every moulin is a Gaussian evaluated with a 3 x 3 Gauss-Legendre rule per cell, normalised by its integral over
  * the level so that it delivers exactly moulin_flux; time_factor = max(1 - runoff sin(2 pi (t - t0)/86400), 0).

@@ -71,7 +71,7 @@ SYMBOLS = [
     "suhmo_amr2_cf_interp", "suhmo_amr2_average", "suhmo_amr2_fine_update_operator", "suhmo_amr2_residual",
     "suhmo_amr2_vcycle", "suhmo_amr2_solve", "suhmo_level_moulin_source", "suhmo_amr2_prolong2", "suhmo_amr2_set_covered",
     "suhmo_amr_residual", "suhmo_amr_vcycle", "suhmo_amr_solve", "suhmo_level_postproc_table", "suhmo_level_postproc_partial", "suhmo_postproc_finish",
-    "suhmo_level_set_alpha_beta", "suhmo_level_set_bc", "suhmo_amr2_reflux", "suhmo_amr2_pwl_fill", "suhmo_amr_timestep", "suhmo_amr_moulin_source", "suhmo_amr2_prolong_pc", "suhmo_amr2_finer_operator_changed",
+    "suhmo_level_set_alpha_beta", "suhmo_level_set_bc", "suhmo_amr2_reflux", "suhmo_amr2_pwl_fill", "suhmo_amr_timestep", "suhmo_level_time_varying_recharge", "suhmo_amr_moulin_source", "suhmo_amr2_prolong_pc", "suhmo_amr2_finer_operator_changed",
 ]
 
 
@@ -137,6 +137,7 @@ def lib():
     L.suhmo_level_set_bc.argtypes = [vp, C.POINTER(BC)]
     L.suhmo_amr2_reflux.argtypes = [vp, vp, C.c_int, vp]
     L.suhmo_amr2_pwl_fill.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    L.suhmo_level_time_varying_recharge.argtypes = [vp, C.c_double, C.c_double, vp]
     L.suhmo_amr_moulin_source.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int), C.c_int, dp, dp, dp, C.c_double, dp, vp]
     L.suhmo_amr_timestep.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(ModelParams), C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]
     L.suhmo_amr2_prolong_pc.argtypes = [vp, vp, C.c_int, vp]

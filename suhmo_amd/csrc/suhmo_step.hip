@@ -699,6 +699,28 @@ extern "C" int suhmo_amr_moulin_source(suhmo_level_t **lv, int nlev, const int *
 }
 
 
+// COMPUTE_TIMEVARYINGRECHARGE (src/AmrHydroF.ChF:346-373) on the ghosted box of the source term
+__global__ void k_time_varying_recharge(DV v, const double *__restrict__ zs, double *__restrict__ out, double TK, double background)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x - 1, j = blockIdx.y * blockDim.y + threadIdx.y - 1;
+    if (i > v.nx || j > v.ny) return;
+    const double ddf = 0.01 / 86400., dT_dZ = -0.0075;
+    int idx = cidx(v, i, j);
+    out[idx] = fmax(ddf * (TK + zs[idx] * dT_dZ), 0.0) + background;
+}
+extern "C" int suhmo_level_time_varying_recharge(suhmo_level_t *L, double T_K, double background_input, suhmo_stream_t s)
+{
+    ARG(L);
+    HIPCHK(hipSetDevice(L->device));
+    Depth &D = L->d[0];
+    if (!D.fp.f[SUHMO_F_ZS]) { suhmo_set_error("time-varying recharge: load the ice surface height (SUHMO_F_ZS) first"); return -1; }
+    double *out = suhmo_field(L, 0, SUHMO_F_MSRC);
+    if (!out) { suhmo_set_error("field allocation failed"); return -2; }
+    hipLaunchKernelGGL(k_time_varying_recharge, dim3((D.v.nx + 2 + 63) / 64, (D.v.ny + 2 + 3) / 4), dim3(64, 4), 0, (hipStream_t)s, D.v, D.fp.f[SUHMO_F_ZS], out, T_K, background_input);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ SHMIP cross-section table
 // one thread per cell column, rows summed in ascending j (the order of the reference's BoxIterator per column)
 __global__ void k_postproc_columns(DV v, FP fp, suhmo_model_params_t mp, double *__restrict__ out /* 8 x nx */)

@@ -50,6 +50,11 @@ class HipModel:
                                                    self.level.stream))
         return integ
 
+    def time_varying_recharge(self, zs, T_K, background):
+        """suhmo.time_varying_input (src/AmrHydro.cpp:2849-2861): F_MSRC from the ghosted ice surface height zs"""
+        self.level.set(lv.F_ZS, zs, ghosted=True)
+        check(capi.lib().suhmo_level_time_varying_recharge(self.level.h, float(T_K), float(background), self.level.stream))
+
     def timestep(self, dt):
         self.cur_step += 1                                         # src/AmrHydro.cpp:2259
         pi, nv = C.c_int(), C.c_int()

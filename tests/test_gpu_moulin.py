@@ -80,3 +80,30 @@ def test_timestep_with_diffusion_bitwise(oracle, impl):
             assert np.array_equal(a, b), (k, nm, float(np.max(np.abs(a - b))))
     assert np.all(np.isfinite(G.get("B"))) and G.get("B").min() > 0.0
     O.close(); G.close()
+
+
+def test_time_varying_recharge_and_timestep_bitwise(oracle):
+    """suhmo.time_varying_input (suites D / F): the recharge field COMPUTE_TIMEVARYINGRECHARGE builds from the ice surface
+    height, bitwise, and a time step consuming it as its source term"""
+    from suhmo_amd import model
+    nx, ny = 96, 32
+    st = sy.shmip_initial_state(nx, ny)
+    X = (np.arange(-1, nx + 1) + 0.5)[None, :] * st["dx"] + np.zeros((ny + 2, 1))
+    zs = 6.0 * (np.sqrt(X + 5000.0) - np.sqrt(5000.0)) + 1.0 + st["zb"]           # surface of the sqrt ice sheet, 0 .. 1500 m
+    m = dict(sy.A3_MODEL, use_moulin_source=1, ramp=1.0, distributed_input=0.0)
+    O = oracle.OracleModel(nx, ny, st["dx"], st["dy"], sy.A3_BC, sy.A3_PHYS, m, max_box=16, nthreads=2)
+    G = model.HipModel(nx, ny, st["dx"], st["dy"], sy.A3_BC, sy.A3_PHYS, m, max_box=16)
+    O.set_state(st)
+    G.set_state(st)
+    for k, day in enumerate((200.0, 230.0)):                                        # summer: the lower part of the sheet melts
+        T_K = -16.0 * np.cos(2.0 * np.pi * day / 365.0) - 5.0
+        ro = oracle.time_varying_recharge(zs, T_K, 7.93e-11)
+        G.time_varying_recharge(zs, T_K, 7.93e-11)
+        rg = G.level.get(model.lv.F_MSRC, ghosted=True)
+        assert np.array_equal(ro, rg) and ro.max() > 10.0 * 7.93e-11 and ro.min() == 7.93e-11
+        O.field(oracle.OM_MSRC)[:] = ro
+        assert O.timestep(m["dt"]) == G.timestep(m["dt"])
+        for nm, fid in (("head", oracle.OM_H), ("B", oracle.OM_B), ("rhs_h", oracle.OM_RHSH)):
+            assert np.array_equal(np.array(O.field(fid))[1:-1, 1:-1], G.get(nm)), (k, nm)
+    O.close()
+    G.close()
