@@ -82,6 +82,19 @@ void nullbc_(SUHMO_CHF_FRA(phi), SUHMO_CHF_BOX(bcbox), SUHMO_CHF_INT(dir), SUHMO
 /* util/DivergenceF.ChF:23-27; prototype util/DivergenceF_F.H:17-27 */
 void divergence_(SUHMO_CHF_CONST_FRA(uEdge), SUHMO_CHF_FRA(div), SUHMO_CHF_BOX(gridInt), SUHMO_CHF_CONST_REAL(dx),
                  SUHMO_CHF_INT(idir));
+/* ---- the caller of the solve (AmrHydro::timeStepFAS): src/AmrHydroF.ChF
+ * COMPUTEQW :113-150 (call site src/AmrHydro.cpp:1697-1705), COMPUTESCAPROD :162-186 (:2962-2967), COMPUTEDCOEFF :241-265
+ * (:1851-1858), COMPUTEDIFTERM2D :289-343 (:2986-2991), COMPUTE_TIMEVARYINGRECHARGE :346-373 (:2853-2857) */
+void computeqw_(SUHMO_CHF_CONST_FRA(aB), SUHMO_CHF_CONST_FRA(aRe), SUHMO_CHF_CONST_FRA(agradH), SUHMO_CHF_BOX(region),
+                SUHMO_CHF_FRA(Qw), SUHMO_CHF_CONST_REAL(omegaparam), SUHMO_CHF_CONST_REAL(nuparam));
+void computescaprod_(SUHMO_CHF_CONST_FRA(vara), SUHMO_CHF_CONST_FRA(var1b), SUHMO_CHF_CONST_FRA(var2b), SUHMO_CHF_BOX(region),
+                     SUHMO_CHF_FRA(prod1), SUHMO_CHF_FRA(prod2));
+void computedcoeff_(SUHMO_CHF_BOX(region), SUHMO_CHF_FRA(Dcoeff), SUHMO_CHF_CONST_REALVECT(dx), SUHMO_CHF_CONST_REAL(rho),
+                    SUHMO_CHF_FRA(MRec), SUHMO_CHF_FRA(Bec), SUHMO_CHF_FRA(IMec), SUHMO_CHF_INT(cutOffB));
+void computedifterm2d_(SUHMO_CHF_FRA(phi), SUHMO_CHF_BOX(region), SUHMO_CHF_CONST_REALVECT(dx), SUHMO_CHF_FRA(Dterm),
+                       SUHMO_CHF_CONST_FRA(Dcoef0), SUHMO_CHF_CONST_FRA(Dcoef1));
+void compute_timevaryingrecharge_(SUHMO_CHF_CONST_FRA(aZs), SUHMO_CHF_BOX(region), SUHMO_CHF_FRA(Recharge),
+                                  SUHMO_CHF_CONST_REAL(TK), SUHMO_CHF_CONST_REAL(BackgroundInput));
 /* the Fortran kernels call MAYDAYERROR() on a component mismatch (...OpF.ChF:87-106); the
  * replacement calls this hook (default: message + abort) */
 void suhmo_chf_set_error_handler(void (*handler)(const char *msg));

@@ -278,6 +278,43 @@ void or_computedifterm2d(const OrFab *phi, OrBox region, const double dx[2], OrF
         }
 }
 
+/* src/AmrHydroF.ChF:113-150 */
+void or_computeqw(const OrFab *aB, const OrFab *aRe, const OrFab *agradH, OrBox region, OrFab *Qw, double omega, double nu)
+{
+    for (int j = region.lo1; j <= region.hi1; j++)
+        for (int i = region.lo0; i <= region.hi0; i++) {
+            double num_q = -(AT(aB, i, j, 0) * AT(aB, i, j, 0) * AT(aB, i, j, 0) * 9.8 * AT(agradH, i, j, 0));
+            double denom_q = 12.0 * nu * (1.0 + omega * AT(aRe, i, j, 0));
+            AT(Qw, i, j, 0) = num_q / denom_q;
+        }
+}
+/* src/AmrHydroF.ChF:162-186 */
+void or_computescaprod(const OrFab *vara, const OrFab *var1b, const OrFab *var2b, OrBox region, OrFab *prod1, OrFab *prod2)
+{
+    for (int j = region.lo1; j <= region.hi1; j++)
+        for (int i = region.lo0; i <= region.hi0; i++) {
+            AT(prod1, i, j, 0) = AT(vara, i, j, 0) * AT(var1b, i, j, 0);
+            AT(prod2, i, j, 0) = AT(vara, i, j, 0) * AT(var2b, i, j, 0);
+        }
+}
+/* src/AmrHydroF.ChF:241-265 */
+void or_computedcoeff(OrBox region, OrFab *Dcoeff, double rho, const OrFab *MRec, const OrFab *Bec, const OrFab *IMec, int cutOffB)
+{
+    for (int j = region.lo1; j <= region.hi1; j++)
+        for (int i = region.lo0; i <= region.hi0; i++) {
+            if (AT(IMec, i, j, 0) < 0.0 && cutOffB > 0) AT(Dcoeff, i, j, 0) = 0.0;
+            else AT(Dcoeff, i, j, 0) = fmax(AT(Bec, i, j, 0) * AT(MRec, i, j, 0) / rho, 5.0e-6);
+        }
+}
+/* src/AmrHydroF.ChF:346-373 */
+void or_compute_timevaryingrecharge(const OrFab *aZs, OrBox region, OrFab *Recharge, double TK, double BackgroundInput)
+{
+    const double ddf = 0.01 / 86400., dT_dZ = -0.0075;
+    for (int j = region.lo1; j <= region.hi1; j++)
+        for (int i = region.lo0; i <= region.hi0; i++)
+            AT(Recharge, i, j, 0) = fmax(ddf * (TK + AT(aZs, i, j, 0) * dT_dZ), 0.0) + BackgroundInput;
+}
+
 /* util/GradientF.ChF:55-70 (normal derivative; CHF_FRA1 = single component) */
 void or_newmacgrad(OrFab *edgeGrad, const OrFab *mask, const OrFab *phi, OrBox edgeGrid,
                    const double dx[2], int dir, int hasMask)

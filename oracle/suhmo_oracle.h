@@ -114,6 +114,10 @@ void or_computebcoeff(const OrFab *aB, const OrFab *aRe, OrBox region, OrFab *Bc
 void or_computedifterm2d(const OrFab *phi, OrBox region, const double dx[2], OrFab *Dterm,
                          const OrFab *Dcoef0, const OrFab *Dcoef1);
 /* util/GradientF.ChF:30-85, normal branch 57-70 (dir == edgeDir) */
+void or_computeqw(const OrFab *aB, const OrFab *aRe, const OrFab *agradH, OrBox region, OrFab *Qw, double omega, double nu);
+void or_computescaprod(const OrFab *vara, const OrFab *var1b, const OrFab *var2b, OrBox region, OrFab *prod1, OrFab *prod2);
+void or_computedcoeff(OrBox region, OrFab *Dcoeff, double rho, const OrFab *MRec, const OrFab *Bec, const OrFab *IMec, int cutOffB);
+void or_compute_timevaryingrecharge(const OrFab *aZs, OrBox region, OrFab *Recharge, double TK, double BackgroundInput);
 void or_newmacgrad(OrFab *edgeGrad, const OrFab *mask, const OrFab *phi, OrBox edgeGrid,
                    const double dx[2], int dir, int hasMask);
 /* util/ExtrapBCF.ChF:7-31 / 39-61 / 69-93 */

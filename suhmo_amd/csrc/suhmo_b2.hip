@@ -212,6 +212,38 @@ __global__ void kb_div(DF u, DF div, BX r, double one_on_dx, int idir)
 }
 
 bool ncomp_ok(int a, int b) { if (a != b) { g_handler("ncomp mismatch"); return false; } return true; }
+__global__ void kb_qw(DF aB, DF aRe, DF g, BX r, DF Qw, double omega, double nu)
+{
+    CELL(r);
+    double b = A(aB, i, j);
+    double num_q = -(b * b * b * 9.8 * A(g, i, j));
+    double denom_q = 12.0 * nu * (1.0 + omega * A(aRe, i, j));
+    A(Qw, i, j) = num_q / denom_q;
+}
+__global__ void kb_scaprod(DF a, DF b1, DF b2, BX r, DF p1, DF p2)
+{
+    CELL(r);
+    A(p1, i, j) = A(a, i, j) * A(b1, i, j);
+    A(p2, i, j) = A(a, i, j) * A(b2, i, j);
+}
+__global__ void kb_dcoeff(BX r, DF D, double rho, DF mr, DF b, DF im, int cutOffB)
+{
+    CELL(r);
+    if (A(im, i, j) < 0.0 && cutOffB > 0) A(D, i, j) = 0.0;
+    else A(D, i, j) = fmax(A(b, i, j) * A(mr, i, j) / rho, 5.0e-6);
+}
+__global__ void kb_difterm(DF phi, BX r, double dxinv0, double dxinv1, DF Dt, DF d0, DF d1)
+{
+    CELL(r);
+    A(Dt, i, j) = (A(d0, i + 1, j) * (A(phi, i + 1, j) - A(phi, i, j)) * dxinv0 - A(d0, i, j) * (A(phi, i, j) - A(phi, i - 1, j)) * dxinv0
+                   + A(d1, i, j + 1) * (A(phi, i, j + 1) - A(phi, i, j)) * dxinv1 - A(d1, i, j) * (A(phi, i, j) - A(phi, i, j - 1)) * dxinv1);
+}
+__global__ void kb_tvrecharge(DF zs, BX r, DF out, double TK, double bg)
+{
+    CELL(r);
+    const double ddf = 0.01 / 86400., dT_dZ = -0.0075;
+    A(out, i, j) = fmax(ddf * (TK + A(zs, i, j) * dT_dZ), 0.0) + bg;
+}
 } // namespace
 
 extern "C" {
@@ -339,6 +371,52 @@ void computenonlinearterms_(SUHMO_CHF_CONST_FRA(phi), SUHMO_CHF_CONST_FRA(aB), S
     BX r = HBOX(region);
     hipLaunchKernelGGL(kb_nl, grid(r), BLK, 0, 0, d[0], d[1], d[2], d[3], d[4], r, d[5], d[6], *Aparam, *brparam, *brparamMax);
     unstage(d[5], nlfunc); unstage(d[6], dnlfunc);
+}
+void computeqw_(SUHMO_CHF_CONST_FRA(aB), SUHMO_CHF_CONST_FRA(aRe), SUHMO_CHF_CONST_FRA(agradH), SUHMO_CHF_BOX(region),
+                SUHMO_CHF_FRA(Qw), SUHMO_CHF_CONST_REAL(omegaparam), SUHMO_CHF_CONST_REAL(nuparam))
+{
+    DF d[4];
+    if (!stage({HFAB(aB), HFAB(aRe), HFAB(agradH), HFAB(Qw)}, d)) return;
+    BX r = HBOX(region);
+    hipLaunchKernelGGL(kb_qw, grid(r), BLK, 0, 0, d[0], d[1], d[2], r, d[3], *omegaparam, *nuparam);
+    unstage(d[3], Qw);
+}
+void computescaprod_(SUHMO_CHF_CONST_FRA(vara), SUHMO_CHF_CONST_FRA(var1b), SUHMO_CHF_CONST_FRA(var2b), SUHMO_CHF_BOX(region),
+                     SUHMO_CHF_FRA(prod1), SUHMO_CHF_FRA(prod2))
+{
+    DF d[5];
+    if (!stage({HFAB(vara), HFAB(var1b), HFAB(var2b), HFAB(prod1), HFAB(prod2)}, d)) return;
+    BX r = HBOX(region);
+    hipLaunchKernelGGL(kb_scaprod, grid(r), BLK, 0, 0, d[0], d[1], d[2], r, d[3], d[4]);
+    unstage(d[3], prod1); unstage(d[4], prod2);
+}
+void computedcoeff_(SUHMO_CHF_BOX(region), SUHMO_CHF_FRA(Dcoeff), SUHMO_CHF_CONST_REALVECT(dx), SUHMO_CHF_CONST_REAL(rho),
+                    SUHMO_CHF_FRA(MRec), SUHMO_CHF_FRA(Bec), SUHMO_CHF_FRA(IMec), SUHMO_CHF_INT(cutOffB))
+{
+    (void)dx;
+    DF d[4];
+    if (!stage({HFAB(Dcoeff), HFAB(MRec), HFAB(Bec), HFAB(IMec)}, d)) return;
+    BX r = HBOX(region);
+    hipLaunchKernelGGL(kb_dcoeff, grid(r), BLK, 0, 0, r, d[0], *rho, d[1], d[2], d[3], *cutOffB);
+    unstage(d[0], Dcoeff);
+}
+void computedifterm2d_(SUHMO_CHF_FRA(phi), SUHMO_CHF_BOX(region), SUHMO_CHF_CONST_REALVECT(dx), SUHMO_CHF_FRA(Dterm),
+                       SUHMO_CHF_CONST_FRA(Dcoef0), SUHMO_CHF_CONST_FRA(Dcoef1))
+{
+    DF d[4];
+    if (!stage({HFAB(phi), HFAB(Dterm), HFAB(Dcoef0), HFAB(Dcoef1)}, d)) return;
+    BX r = HBOX(region);
+    hipLaunchKernelGGL(kb_difterm, grid(r), BLK, 0, 0, d[0], r, 1.0 / (dx[0] * dx[0]), 1.0 / (dx[1] * dx[1]), d[1], d[2], d[3]);
+    unstage(d[1], Dterm);
+}
+void compute_timevaryingrecharge_(SUHMO_CHF_CONST_FRA(aZs), SUHMO_CHF_BOX(region), SUHMO_CHF_FRA(Recharge),
+                                  SUHMO_CHF_CONST_REAL(TK), SUHMO_CHF_CONST_REAL(BackgroundInput))
+{
+    DF d[2];
+    if (!stage({HFAB(aZs), HFAB(Recharge)}, d)) return;
+    BX r = HBOX(region);
+    hipLaunchKernelGGL(kb_tvrecharge, grid(r), BLK, 0, 0, d[0], r, d[1], *TK, *BackgroundInput);
+    unstage(d[1], Recharge);
 }
 void computere_(SUHMO_CHF_CONST_FRA(aB), SUHMO_CHF_CONST_FRA(agradH), SUHMO_CHF_BOX(region), SUHMO_CHF_FRA(Re),
                 SUHMO_CHF_CONST_REAL(omegaparam), SUHMO_CHF_CONST_REAL(nuparam))

@@ -134,6 +134,39 @@ int main()
         divergence_(F(b1), F(v1), BOXP(reg), &dx[1], &i1); or_divergence(&ob1, &ov2, reg, dx[1], 1);
         cmp("divergence_", v1, v2);
     }
+    {   // the time-step kernels (src/AmrHydroF.ChF) on the x-faces of the box
+        OrBox fb{reg.lo0, reg.lo1, reg.hi0 + 1, reg.hi1};
+        Fab Bec(fb.lo0, fb.lo1, fb.hi0, fb.hi1, 1, 1e-4, 0.2), Rec(fb.lo0, fb.lo1, fb.hi0, fb.hi1, 1, 0.0, 4000.0), gH(fb.lo0, fb.lo1, fb.hi0, fb.hi1, 1, -0.05, 0.05);
+        Fab gZ(fb.lo0, fb.lo1, fb.hi0, fb.hi1, 1, -0.02, 0.02), MRec(fb.lo0, fb.lo1, fb.hi0, fb.hi1, 1, 0.0, 1e-6), IMec(fb.lo0, fb.lo1, fb.hi0, fb.hi1, 1, -1.0, 1.0);
+        double omega = 1e-3, nu = 1.787e-6, rho = 910.0;
+        Fab q1(fb.lo0, fb.lo1, fb.hi0, fb.hi1, 1, 0, 0), q2 = q1;
+        OrFab oB = Bec.o(), oR = Rec.o(), oG = gH.o(), oZ = gZ.o(), oM = MRec.o(), oI = IMec.o(), oq2 = q2.o();
+        computeqw_(F(Bec), F(Rec), F(gH), BOXP(fb), F(q1), &omega, &nu);
+        or_computeqw(&oB, &oR, &oG, fb, &oq2, omega, nu);
+        cmp("computeqw_", q1, q2);
+        Fab p1(fb.lo0, fb.lo1, fb.hi0, fb.hi1, 1, 0, 0), p2 = p1, r1 = p1, r2 = p1; OrFab op2 = p2.o(), or2 = r2.o();
+        computescaprod_(F(q1), F(gH), F(gZ), BOXP(fb), F(p1), F(r1));
+        or_computescaprod(&oq2, &oG, &oZ, fb, &op2, &or2);
+        cmp("computescaprod_ (Qw grad h)", p1, p2); cmp("computescaprod_ (Qw grad zb)", r1, r2);
+        for (int cut = 0; cut < 2; cut++) {
+            Fab d1(fb.lo0, fb.lo1, fb.hi0, fb.hi1, 1, 0, 0), d2 = d1; OrFab od2 = d2.o(); int c = cut;
+            computedcoeff_(BOXP(fb), F(d1), dx, &rho, F(MRec), F(Bec), F(IMec), &c);
+            or_computedcoeff(fb, &od2, rho, &oM, &oB, &oI, cut);
+            cmp(cut ? "computedcoeff_ (cutOffB)" : "computedcoeff_", d1, d2);
+        }
+        OrBox fby{reg.lo0, reg.lo1, reg.hi0, reg.hi1 + 1};
+        Fab D0(fb.lo0, fb.lo1, fb.hi0, fb.hi1, 1, 5e-6, 1e-3), D1(fby.lo0, fby.lo1, fby.hi0, fby.hi1, 1, 5e-6, 1e-3);
+        Fab t1(reg.lo0, reg.lo1, reg.hi0, reg.hi1, 1, 0, 0), t2 = t1; OrFab ot2 = t2.o(), oD0 = D0.o(), oD1 = D1.o(), oph = phi.o();
+        computedifterm2d_(F(phi), BOXP(reg), dx, F(t1), F(D0), F(D1));
+        or_computedifterm2d(&oph, reg, dx, &ot2, &oD0, &oD1);
+        cmp("computedifterm2d_", t1, t2);
+        Fab zs(reg.lo0 - 1, reg.lo1 - 1, reg.hi0 + 1, reg.hi1 + 1, 1, 0.0, 2000.0), w1(reg.lo0 - 1, reg.lo1 - 1, reg.hi0 + 1, reg.hi1 + 1, 1, 0, 0), w2 = w1;
+        OrBox gb{reg.lo0 - 1, reg.lo1 - 1, reg.hi0 + 1, reg.hi1 + 1}; OrFab ozs = zs.o(), ow2 = w2.o();
+        double TK = 9.5, bg = 7.93e-11;
+        compute_timevaryingrecharge_(F(zs), BOXP(gb), F(w1), &TK, &bg);
+        or_compute_timevaryingrecharge(&ozs, gb, &ow2, TK, bg);
+        cmp("compute_timevaryingrecharge_", w1, w2);
+    }
     printf(g_fail ? "RESULT: FAIL (%d)\n" : "RESULT: PASS\n", g_fail);
     return g_fail ? 1 : 0;
 }
