@@ -92,6 +92,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     gsrb_ms, gsrb_launches, gsrb_cells = G.profile_read()
+    rst_ms, rst_launches, rst_cells = G.profile_read(restricting=True)
     G.profile(False)
 
     sweeps_depth0 = 2 * sp["num_smooth"]
@@ -120,6 +121,13 @@ def main():
     alg_bytes_launch = BYTES_PER_CELL_SWEEP * cells * sweeps_timed / max(gsrb_launches, 1)
 
     extra = {}
+    if rst_launches:
+        # the launch that ends the pre-smoothing also restricts: 2 sweeps (144 B/cell) + RESTRICTRESVCNL2D/RESTRICTVCNL (76 B/cell)
+        rl = rst_ms / rst_launches
+        rbytes = (BYTES_PER_CELL_SWEEP * rst_cells / rst_launches) + 76.0 * cells
+        extra["gsrb_plus_restrict_launch"] = {"kernel": "k_gsrb_fused<2, false, 64, true> (2 sweeps + restriction in one pass)", "avg_launch_ms": rl,
+                                              "launches_timed": rst_launches, "algorithmic_bytes_per_launch": rbytes,
+                                              "achieved_GBs": rbytes / (rl * 1e-3) / 1e9, "frac_of_peak": rbytes / (rl * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if args.sweeps_only:
         sync()
         G.profile(True)

@@ -332,12 +332,15 @@ int suhmo_amr_timestep(suhmo_level_t **levels, int nlev, const suhmo_model_param
 int suhmo_amr_moulin_source(suhmo_level_t **levels, int nlev, const int *patch_boxes, int n_moulins, const double *positions,
                             const double *sigma, const double *flux, double time_factor, double *integrals, suhmo_stream_t s);
 
-/* timing helper: average device time (ms) of the GSRB sweep kernel launches since the
- * last reset, measured with HIP events on the launch stream */
+/* timing helper: average device time (ms) of the depth-0 GSRB sweep kernel launches since the last reset, measured with
+ * HIP events on the launch stream.  suhmo_level_profile_read: the plain K-sweep launches (k_gsrb_fused<K, ., ., false>);
+ * suhmo_level_profile_read_restricting: the launches that end a pre-smoothing and also restrict (k_gsrb_fused<K, ., ., true>:
+ * K sweeps + RESTRICTRESVCNL2D + RESTRICTVCNL in one pass) */
 int suhmo_level_profile_reset(suhmo_level_t *L);
 int suhmo_level_profile_enable(suhmo_level_t *L, int on);
 int suhmo_level_profile_read(suhmo_level_t *L, suhmo_stream_t s, double *gsrb_ms_total,
                              long *gsrb_launches, long *gsrb_cells);
+int suhmo_level_profile_read_restricting(suhmo_level_t *L, suhmo_stream_t s, double *ms_total, long *launches, long *cells);
 
 #ifdef __cplusplus
 }

@@ -65,7 +65,7 @@ SYMBOLS = [
     "suhmo_level_divergence", "suhmo_level_get_flux", "suhmo_level_norm", "suhmo_level_axby",
     "suhmo_level_set_value", "suhmo_level_vcycle", "suhmo_level_solve", "suhmo_level_pack_rows",
     "suhmo_level_unpack_rows", "suhmo_level_set_hooks", "suhmo_level_exchange", "suhmo_level_halo_info", "suhmo_level_profile_reset",
-    "suhmo_level_profile_enable", "suhmo_level_profile_read", "suhmo_level_timestep",
+    "suhmo_level_profile_enable", "suhmo_level_profile_read", "suhmo_level_profile_read_restricting", "suhmo_level_timestep",
     "suhmo_rccl_load", "suhmo_rccl_unique_id", "suhmo_level_attach_rccl", "suhmo_level_detach_rccl",
     "suhmo_level_rccl_exchanges",
     "suhmo_amr2_cf_interp", "suhmo_amr2_average", "suhmo_amr2_fine_update_operator", "suhmo_amr2_residual",
@@ -156,6 +156,7 @@ def lib():
     L.suhmo_level_profile_reset.argtypes = [vp]
     L.suhmo_level_profile_enable.argtypes = [vp, ci]
     L.suhmo_level_profile_read.argtypes = [vp, vp, dp, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    L.suhmo_level_profile_read_restricting.argtypes = [vp, vp, dp, C.POINTER(C.c_long), C.POINTER(C.c_long)]
     _LIB = L
     return L
 

@@ -127,7 +127,7 @@ struct Depth {
 };
 
 struct VGraph { int key[4]; hipGraphExec_t exec; };     // a V-cycle captured for one set of solver parameters (suhmo_fas.hip)
-struct ProfEv { hipEvent_t a, b; long cells; };
+struct ProfEv { hipEvent_t a, b; long cells; int restricts; };   // restricts: the launch also did the restriction (RST)
 
 struct suhmo_level {
     int ndepth;
@@ -154,6 +154,7 @@ struct suhmo_level {
     long fused_min_cells;       // auto mode: use the fused kernel from this many cells (env SUHMO_FUSED_MIN_CELLS)
     int bcoef_fused;            // single-kernel WFlx_level (env SUHMO_BCOEF_FUSED, default 1)
     int fused_nt;               // threads per workgroup of the fused kernel: 256 or 64 (env SUHMO_FUSED_NT)
+    int fused_restrict;         // the last pre-smoothing launch also restricts (env SUHMO_FUSED_RESTRICT, default 1)
     int fused_hc;               // rows per chunk of the fused kernel (0 = auto); env SUHMO_FUSED_HC
 };
 
@@ -166,7 +167,8 @@ double *suhmo_field(suhmo_level *L, int depth, int field);   // lazily allocates
 int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st);      // suhmo_level.hip
 int suhmo_restrict_both(suhmo_level *L, int depth, hipStream_t st);                 // suhmo_level.hip
 bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps);           // suhmo_gsrb.hip
-int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream_t st);   // suhmo_gsrb.hip; tail = halo rows worth keeping valid at exit
+int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream_t st, int *restricted = nullptr);   // suhmo_gsrb.hip; tail = halo
+                                                    // rows worth keeping valid at exit; restricted: see there
 void suhmo_level_drop_graphs(suhmo_level *L);                                     // suhmo_fas.hip
 int suhmo_ensure_phi_halo(suhmo_level *L, int depth, int need, hipStream_t st);      // suhmo_level.hip
 int suhmo_exchange_list(suhmo_level *L, int depth, const int *fields, int n, hipStream_t st);   // LevelData::exchange across rank boundaries

@@ -24,9 +24,9 @@ static int eff_depths(const suhmo_level *L, const suhmo_solver_params_t *sp)
 // (src/VCAMRNonLinearPoissonOp.cpp:757-759).  `tail`: halo rows (strips) worth keeping valid for the next reader.
 // Inside the cycle nothing reads the stored ghost ring (every kernel evaluates the boundary condition from the
 // adjacent interior value), so only the relax that ends the cycle -- whose state the caller can observe -- fills it.
-static int relax(suhmo_level *L, int dep, int sweeps, int tail, suhmo_stream_t s, bool observable = false)
+static int relax(suhmo_level *L, int dep, int sweeps, int tail, suhmo_stream_t s, bool observable = false, int *restricted = nullptr)
 {
-    int rc = suhmo_launch_gsrb(L, dep, sweeps, tail, (hipStream_t)s);
+    int rc = suhmo_launch_gsrb(L, dep, sweeps, tail, (hipStream_t)s, restricted);
     if (rc) return rc;
     if (sweeps > 0 && observable) return suhmo_level_fill_ghosts(L, dep, SUHMO_F_PHI, 1, s);
     return 0;
@@ -51,9 +51,11 @@ static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, i
     const int tail_post = dep == 0 ? 2 : (rows_after_prolong(dep - 1, S) + 1) / 2;
     if (dep == nd - 1) return relax(L, dep, sp->num_bottom, tail_post, s, dep == 0);   // bottom relaxes
     Depth &C = L->d[dep + 1];
-    if ((rc = relax(L, dep, S, rows_after_prolong(dep, S), s))) return rc;        // pre-smooth (the restriction reads 1 halo row,
-                                                                                  //  the prolongation below the rest)
-    if ((rc = suhmo_restrict_both(L, dep, (hipStream_t)s))) return rc;            // RES[dep+1] and PHI[dep+1] = R(phi)
+    int restricted = 0;
+    if ((rc = relax(L, dep, S, rows_after_prolong(dep, S), s, false, &restricted))) return rc;   // pre-smooth (the restriction reads 1 halo
+                                                                                  //  row, the prolongation below the rest)
+    if (!restricted && (rc = suhmo_restrict_both(L, dep, (hipStream_t)s))) return rc;   // RES[dep+1] and PHI[dep+1] = R(phi); the fused
+                                                                                  //  relaxation may have written them already
     if ((rc = suhmo_ensure_phi_halo(L, dep + 1, suhmo_halo_rows(C.v), (hipStream_t)s))) return rc;   // strips: before the copy, so that
     HIPCHK(hipMemcpyAsync(C.fp.f[SUHMO_F_PHIOLD], C.fp.f[SUHMO_F_PHI], C.elems * sizeof(double),      // PHIOLD carries the halo rows too
                           hipMemcpyDeviceToDevice, (hipStream_t)s));

@@ -74,6 +74,8 @@ struct FusedGeom {
     // FAS prolongIncrement fused into the load of phi (PROLONGNL, AMRNonLinearPoissonOpF.ChF:619-627):
     // phi(i,j) += phi_c(i/2,j/2) - phi_c_old(i/2,j/2)
     const double *pc, *pco; int Pc, gyc;
+    // RST: restrictResidual + restrictR fused into the launch that finishes the pre-smoothing: coarse RES / PHI canvases
+    double *rres, *rphi; int rP, rgy;
 };
 
 struct RowCoef {          // per-thread coefficients of its column pair in one row
@@ -90,11 +92,17 @@ __device__ __forceinline__ void copy_coef(RowCoef &d, const RowCoef &s)
     d.bx0 = s.bx0; d.bx1 = s.bx1; d.bx2 = s.bx2;
 }
 
-template <int K, bool HAS_ALPHA, int NT>
+// RST = true: the launch also restricts.  Once row j-1, j, j+1 are final (all 2K half-sweeps), the residual rhs - L(phi) of
+// row j is evaluated from the ring with the same expressions as k_restrict_residual and accumulated, in the reference's
+// visiting order, into the coarse cell of the thread's column pair (RESTRICTRESVCNL2D + RESTRICTVCNL, VCAMR...OpF.ChF:480-561,
+// 419-449): the separate pass over phi and the 8 coefficient arrays (75 B/cell) disappears.  Costs: one more ring row, one
+// more coefficient row, one more final row above and below the chunk and two more halo columns per side.
+template <int K, bool HAS_ALPHA, int NT, bool RST = false>
 __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__restrict__ pin,
                                                    double *__restrict__ pout, suhmo_phys_t ph, FusedGeom g)
 {
-    constexpr int LW = 2 * NT, R = 2 * K + 3;
+    constexpr int LW = 2 * NT, R = 2 * K + 3 + (RST ? 1 : 0);
+    constexpr int HX = 2 * K + (RST ? 2 : 0), EY = RST ? 1 : 0;
     __shared__ double lds[R * LW];
 
     // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs; give every XCD a
@@ -106,8 +114,8 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
     const int t = threadIdx.x;
     const int c0 = strip * g.W;
     const int xl = 2 * t;                      // position of the pair's first cell in an LDS row
-    const int i0 = c0 - 2 * K + xl;            // its global column (even)
-    const bool in_row = xl < g.W + 4 * K;
+    const int i0 = c0 - HX + xl;               // its global column (even)
+    const bool in_row = xl < g.W + 2 * HX;
     int im = i0;
     if (v.per[0]) { if (im < 0) im += v.nx; else if (im >= v.nx) im -= v.nx; }
     const bool cval = in_row && im >= 0 && im < v.nx;                 // pair lies in the domain
@@ -116,8 +124,8 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
 
     const int jA = g.jbeg + chunk * g.Hc;
     const int jB = (jA + g.Hc < g.jend) ? jA + g.Hc : g.jend;
-    const int jmin = (jA - 2 * K > g.ylo) ? jA - 2 * K : g.ylo;
-    const int jmax = (jB - 1 + 2 * K < g.yhi) ? jB - 1 + 2 * K : g.yhi;
+    const int jmin = (jA - EY - 2 * K > g.ylo) ? jA - EY - 2 * K : g.ylo;
+    const int jmax = (jB - 1 + EY + 2 * K < g.yhi) ? jB - 1 + EY + 2 * K : g.yhi;
 
     const double *__restrict__ f_rhs = fp.f[SUHMO_F_RHS], *__restrict__ f_B = fp.f[SUHMO_F_B];
     const double *__restrict__ f_Pi = fp.f[SUHMO_F_PI], *__restrict__ f_zb = fp.f[SUHMO_F_ZB];
@@ -129,14 +137,15 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
 
     // coefficient ring as NAMED variables (an indexed array ends up in scratch memory):
     // cf0 = row r (being prefetched), cfM = row r-M
-    RowCoef cf0, cf1, cf2, cf3, cf4;
+    RowCoef cf0, cf1, cf2, cf3, cf4, cf5;
+    double racc = 0.0, raccp = 0.0;        // RST: the coarse cell's sums after its first fine row
     // physical-BC sides this tile can touch (uniform): skip the per-lane boundary tests elsewhere
-    const bool xbc = !v.per[0] && (c0 - 2 * K <= 0 || c0 + g.W + 2 * K >= v.nx);
+    const bool xbc = !v.per[0] && (c0 - HX <= 0 || c0 + g.W + HX >= v.nx);
     const bool ybc = !v.per[1] && (jmin <= 0 || jmax >= v.ny - 1);
     double2 pnext = make_double2(0.0, 0.0);
 
     int sr = 0;                            // LDS ring slot of row r
-    for (int r = jmin - 1; r <= jB - 1 + 2 * K; r++) {
+    for (int r = jmin - 1; r <= jB - 1 + 2 * K + EY; r++) {
         // ---- 1. prefetch: phi of row r+1, coefficients of row r (both first used in step r+1)
         bool lphi = cval && (r + 1 >= jmin) && (r + 1 <= jmax);
         if (lphi) {
@@ -209,6 +218,41 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
             advance(4, cf4);
         }
 
+        // ---- 2b. RST: rows r-2K-2 .. r-2K are final: residual of row r-2K-1, restricted
+        if constexpr (RST) {
+            const int jr = r - 2 * K - 1;
+            if (own && jr >= jA && jr < jB) {
+                const RowCoef &q = (K >= 2) ? cf5 : cf3;
+                const int s0 = (sr - (2 * K + 1) + 2 * R) % R, sN = (s0 + 1) % R, sS = (s0 + R - 1) % R;
+                const double *row = lds + s0 * LW;
+                double acc = (jr & 1) ? racc : 0.0, accp = (jr & 1) ? raccp : 0.0;
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    const int x = xl + a, i = im + a;
+                    double c = row[x], w = row[x - 1], e = row[x + 1];       // own pairs never sit on the edge of the LDS row (HX >= 2)
+                    double n = lds[sN * LW + x], s = lds[sS * LW + x];
+                    if (xbc) {
+                        if (i == 0) w = (v.bct[0][0] == 0) ? v.two_v[0][0] - c : c + v.neu[0][0];
+                        if (i == v.nx - 1) e = (v.bct[0][1] == 0) ? v.two_v[0][1] - c : c + v.neu[0][1];
+                    }
+                    if (ybc) {
+                        if (jr == 0 && !v.ext[0]) s = (v.bct[1][0] == 0) ? v.two_v[1][0] - c : c + v.neu[1][0];
+                        if (jr == v.ny - 1 && !v.ext[1]) n = (v.bct[1][1] == 0) ? v.two_v[1][1] - c : c + v.neu[1][1];
+                    }
+                    double nl, dnl;
+                    nl_terms(ph, c, q.B[a], q.Pi[a], q.zb[a], q.mask[a], nl, dnl);
+                    const double bxW = a ? q.bx1 : q.bx0, bxE = a ? q.bx2 : q.bx1;
+                    double aterm = HAS_ALPHA ? v.alpha * q.a[a] : v.alpha;
+                    double lofphi = lofphi_cell(v, aterm, c, e, w, n, s, bxE, bxW, q.byN[a], q.byS[a], nl);
+                    acc = acc + (q.rhs[a] - lofphi) / 4.0;
+                    accp = accp + c / 4.0;
+                }
+                if (jr & 1) {
+                    const int ic = ((jr >> 1) + g.rgy) * g.rP + SUHMO_XOFF + (i0 >> 1);
+                    g.rres[ic] = acc; g.rphi[ic] = accp;
+                } else { racc = acc; raccp = accp; }
+            }
+        }
         // ---- 3. row r-2K has all 2K half-sweeps: stream it out (own pair, written by this thread)
         {
             const int jo = r - 2 * K;
@@ -221,7 +265,9 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
         // ---- 4. row r+1 enters the ring (its slot held row r-2K-2: no longer read), rotate
         sr = (sr + 1) % R;
         if (in_row) { lds[sr * LW + xl] = pnext.x; lds[sr * LW + xl + 1] = pnext.y; }
+        if constexpr (RST && K >= 2) copy_coef<HAS_ALPHA>(cf5, cf4);
         if constexpr (K >= 2) { copy_coef<HAS_ALPHA>(cf4, cf3); copy_coef<HAS_ALPHA>(cf3, cf2); }
+        else if constexpr (RST) copy_coef<HAS_ALPHA>(cf3, cf2);
         copy_coef<HAS_ALPHA>(cf2, cf1);
         copy_coef<HAS_ALPHA>(cf1, cf0);
     }
@@ -237,7 +283,7 @@ static bool fused_ok(const suhmo_level *L, const Depth &D, int K)
     return true;
 }
 
-template <int K, int NT>
+template <int K, int NT, bool RST = false>
 static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st)
 {
     Depth &D = L->d[depth];
@@ -247,7 +293,8 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st)
         HIPCHK(hipMemsetAsync(D.phi_alt, 0, D.elems * sizeof(double), st));
     }
     FusedGeom g;
-    const int maxW = 2 * NT - 4 * K;
+    constexpr int HX = 2 * K + (RST ? 2 : 0), EY = RST ? 1 : 0;
+    const int maxW = 2 * NT - 2 * HX;
     g.nstrips = (v.nx + maxW - 1) / maxW;
     g.W = 2 * ((v.nx + 2 * g.nstrips - 1) / (2 * g.nstrips));
     g.nstrips = (v.nx + g.W - 1) / g.W;
@@ -255,12 +302,12 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st)
     // a partial second round costs a full one), but never shorter than 16K rows so that the
     // 4K-row pipeline fill stays small; measured on MI355X: profiles/r01_b_hc_sweep.log
     {
-        static int slots_k[3] = {0, 0, 0};     // per (K, NT) instantiation
+        static int slots_k[3] = {0, 0, 0};     // per (K, NT, RST) instantiation
         if (!slots_k[K]) {
             int nb = 0, ncu = 0, dev = 0;
             HIPCHK(hipGetDevice(&dev));
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gsrb_fused<K, false, NT>, NT, 0));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_gsrb_fused<K, false, NT, RST>), NT, 0));
             slots_k[K] = (nb > 0 ? nb : 1) * (ncu > 0 ? ncu : 256);
         }
         g.jbeg = v.ext[0] ? -ext_rows : 0;
@@ -274,14 +321,15 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st)
         // (profiles/r01_k_sweep_small_hc.log: 1024^2, K = 2: 22.3 us per sweep at 6 rows vs 28.1 for the colour passes)
         if ((long)v.nx * v.ny < 2000000L) g.Hc = 6;
         if (L->fused_hc > 0) g.Hc = L->fused_hc;          // explicit: no lower clamp (tools/sweep_small_hc.sh)
+        if (RST) g.Hc += g.Hc & 1;                        // a coarse cell's two fine rows stay in one chunk
         if (g.Hc > nrows) g.Hc = nrows;
         g.nchunks = (nrows + g.Hc - 1) / g.Hc;
     }
     g.ntiles = g.nstrips * g.nchunks;
     bool selfper = v.per[1] && !(v.ext[0] || v.ext[1]);
     g.wrap_y = selfper;
-    g.ylo = v.ext[0] ? g.jbeg - 2 * K : (selfper ? -2 * K : 0);
-    g.yhi = v.ext[1] ? g.jend - 1 + 2 * K : (selfper ? v.ny - 1 + 2 * K : v.ny - 1);
+    g.ylo = v.ext[0] ? g.jbeg - 2 * K : (selfper ? -2 * K - EY : 0);
+    g.yhi = v.ext[1] ? g.jend - 1 + 2 * K : (selfper ? v.ny - 1 + 2 * K + EY : v.ny - 1);
     const double *pin = D.fp.f[SUHMO_F_PHI];
     g.pc = g.pco = nullptr; g.Pc = g.gyc = 0;
     if (D.prolong_pending) {
@@ -289,10 +337,16 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st)
         g.pc = C.fp.f[SUHMO_F_PHI]; g.pco = C.fp.f[SUHMO_F_PHIOLD]; g.Pc = C.v.P; g.gyc = C.v.gy;
         D.prolong_pending = 0;
     }
+    g.rres = g.rphi = nullptr; g.rP = g.rgy = 0;
+    if (RST) {
+        Depth &C = L->d[depth + 1];
+        g.rres = C.fp.f[SUHMO_F_RES]; g.rphi = C.fp.f[SUHMO_F_PHI]; g.rP = C.v.P; g.rgy = C.v.gy;
+        C.phi_fresh = 0;
+    }
     if (v.alpha != 0.0)
-        hipLaunchKernelGGL((k_gsrb_fused<K, true, NT>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+        hipLaunchKernelGGL((k_gsrb_fused<K, true, NT, false>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
     else
-        hipLaunchKernelGGL((k_gsrb_fused<K, false, NT>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+        hipLaunchKernelGGL((k_gsrb_fused<K, false, NT, RST>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
     std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
     return 0;
 }
@@ -333,11 +387,16 @@ bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps)
     return !ext || prolong_halo_rows(L, depth) >= 2 * K;                  // else: un-fused prolongation, then an exchange
 }
 
-int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream_t st)
+// restricted != NULL: the caller restricts right after these sweeps (pre-smoothing of the FAS cycle); *restricted = 1 if
+// the last launch did it (coarse RES and PHI written), 0 if the caller still has to
+int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream_t st, int *restricted)
 {
     Depth &D = L->d[depth];
     int variant = pick_variant(L, D);
     const bool ext = L->ex && (D.v.ext[0] || D.v.ext[1]);
+    if (restricted) *restricted = 0;
+    const bool may_restrict = restricted && L->fused_restrict && depth + 1 < L->ndepth && !(D.v.ext[0] || D.v.ext[1]) && !(D.v.ny & 1)
+                              && D.v.alpha == 0.0;          // with aCoef the extra coefficient row no longer fits 2 waves per SIMD
     // Strips: F = halo rows of phi that hold current neighbour values (Depth::phi_fresh).  A colour pass
     // needs 1, a K-sweep launch 2K; each launch also advances, redundantly, as many of the remaining halo
     // rows as the work still to come (rest of these sweeps + `tail` rows for the next reader) can use, so
@@ -377,7 +436,8 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
             int E = ext ? (F - 2 * K < want ? F - 2 * K : want) : 0;
             int rc;
             const int nt = L->fused_nt ? L->fused_nt : ((long)D.v.nx * D.v.ny >= 8000000L ? 256 : 64);   // 0 = by size
-            if (nt == 64) rc = (K == 2) ? launch_fused<2, 64>(L, depth, E, st) : launch_fused<1, 64>(L, depth, E, st);
+            if (may_restrict && nt == 64 && K == 2 && it + K == sweeps) { rc = launch_fused<2, 64, true>(L, depth, E, st); *restricted = 1; }
+            else if (nt == 64) rc = (K == 2) ? launch_fused<2, 64>(L, depth, E, st) : launch_fused<1, 64>(L, depth, E, st);
             else rc = (K == 2) ? launch_fused<2, 256>(L, depth, E, st) : launch_fused<1, 256>(L, depth, E, st);
             if (rc) return rc;
             if (ext) { F = E; D.phi_fresh = F; }
@@ -386,6 +446,7 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
         if (prof) {
             HIPCHK(hipEventRecord(pe.b, st));
             pe.cells = (long)D.v.nx * D.v.ny * done;
+            pe.restricts = (restricted && *restricted && it + done == sweeps) ? 1 : 0;
             L->prof.push_back(pe);
         }
         it += done;

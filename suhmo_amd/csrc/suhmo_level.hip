@@ -96,6 +96,8 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     if (const char *e = getenv("SUHMO_BCOEF_FUSED")) L->bcoef_fused = atoi(e);
     L->fused_nt = 64;                        // one wave per workgroup: 316 vs 308 V-cycles/s at 4096^2 (profiles/r01_i_nt_ab.txt)
     if (const char *e = getenv("SUHMO_FUSED_NT")) L->fused_nt = atoi(e);
+    L->fused_restrict = 1;
+    if (const char *e = getenv("SUHMO_FUSED_RESTRICT")) L->fused_restrict = atoi(e);
     L->graph_max_cells = 1500000; L->gstream = nullptr; memset(L->vgraph_seen, 0, sizeof(L->vgraph_seen));
     if (const char *e = getenv("SUHMO_GRAPH_MAX_CELLS")) L->graph_max_cells = atol(e);
     L->fused_min_cells = 1000000;
@@ -1378,12 +1380,18 @@ extern "C" int suhmo_level_profile_reset(suhmo_level_t *L)
     L->prof.clear();
     return 0;
 }
+static int profile_read_kind(suhmo_level_t *L, suhmo_stream_t s, int kind, double *ms_total, long *launches, long *cells);
 extern "C" int suhmo_level_profile_read(suhmo_level_t *L, suhmo_stream_t s, double *ms_total, long *launches, long *cells)
+{ return profile_read_kind(L, s, 0, ms_total, launches, cells); }
+extern "C" int suhmo_level_profile_read_restricting(suhmo_level_t *L, suhmo_stream_t s, double *ms_total, long *launches, long *cells)
+{ return profile_read_kind(L, s, 1, ms_total, launches, cells); }
+static int profile_read_kind(suhmo_level_t *L, suhmo_stream_t s, int kind, double *ms_total, long *launches, long *cells)
 {
     ARG(L);
     HIPCHK(hipStreamSynchronize((hipStream_t)s));
     double tot = 0.0; long n = 0, c = 0;
     for (auto &pe : L->prof) {
+        if (pe.restricts != kind) continue;
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, pe.a, pe.b));
         tot += ms; n++; c += pe.cells;

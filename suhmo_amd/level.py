@@ -171,9 +171,11 @@ class HipLevel:
         check(capi.lib().suhmo_level_profile_reset(self.h))
         check(capi.lib().suhmo_level_profile_enable(self.h, int(on)))
 
-    def profile_read(self):
+    def profile_read(self, restricting=False):
+        """(ms, launches, cell-sweeps) of the plain depth-0 GSRB launches, or of those that also restrict"""
         ms, n, c = C.c_double(), C.c_long(), C.c_long()
-        check(capi.lib().suhmo_level_profile_read(self.h, self.stream, C.byref(ms), C.byref(n), C.byref(c)))
+        f = capi.lib().suhmo_level_profile_read_restricting if restricting else capi.lib().suhmo_level_profile_read
+        check(f(self.h, self.stream, C.byref(ms), C.byref(n), C.byref(c)))
         return ms.value, n.value, c.value
 
 

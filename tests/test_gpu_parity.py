@@ -212,6 +212,42 @@ def test_vcycle_and_solve(oracle, hip, case):
     assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI))      # converged head: bitwise
 
 
+FUSED_VCYCLE_CASES = [
+    ("wide-3strips", lambda: sy.random_fields(1100, 48, seed=21), sy.RANDOM_BC, dict(sy.RANDOM_PHYS), 0.0, -1.0, 16),
+    ("allperiodic", lambda: sy.random_fields(128, 96, seed=22),
+     dict(type=[[0, 0], [0, 0]], value=[[0, 0], [0, 0]], periodic=[1, 1]), sy.RANDOM_PHYS, 0.0, -1.0, 32),
+    ("yperiodic-tall", lambda: sy.random_fields(64, 200, seed=23), sy.CONV_BC, sy.RANDOM_PHYS, 0.0, -1.0, 8),
+    ("shmip-512", lambda: sy.shmip_fields(512, 256), sy.A3_BC, sy.A3_PHYS, 0.0, -1.0, 64),
+    ("mixedbc-helmholtz", lambda: sy.random_fields(256, 64, seed=24), sy.RANDOM_BC, sy.RANDOM_PHYS, 0.6, -1.0, 16),   # alpha != 0: no fused restriction
+]
+
+
+@pytest.mark.parametrize("case", FUSED_VCYCLE_CASES, ids=[c[0] for c in FUSED_VCYCLE_CASES])
+@pytest.mark.parametrize("fused_restrict", [1, 0])
+@pytest.mark.parametrize("hc", [0, 6, 10])
+def test_vcycle_on_fused_kernels(oracle, hip, case, fused_restrict, hc, monkeypatch):
+    """every depth on the streaming kernel (SUHMO_FUSED_MIN_CELLS = 1), with the restriction fused into the launch that
+    ends the pre-smoothing and with the separate restriction kernel: both bitwise equal to the oracle's V-cycle; chunk
+    heights 6 / 10 / automatic move the coarse cells' row pairs relative to the chunk boundaries"""
+    monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "1")
+    monkeypatch.setenv("SUHMO_FUSED_RESTRICT", str(fused_restrict))
+    monkeypatch.setenv("SUHMO_FUSED_HC", str(hc))
+    _, mk, bc, ph, alpha, beta, mb = case
+    f = mk()
+    f.pop("bx", None); f.pop("by", None)
+    O, G = pair(oracle, hip, f, bc, ph, alpha, beta, mb)
+    O.build_mg_coefficients(); G.build_mg_coefficients()
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-10, norm_thresh=1e-13, max_iter=3, imin=6)
+    for k in range(2):
+        O.vcycle(sp); G.vcycle(sp)
+        assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI)), (k, float(np.max(np.abs(G.get(hip.F_PHI) - O.get(oracle.F_PHI)))))
+    for d in range(1, G.ndepth):
+        assert np.array_equal(G.get(hip.F_RES, depth=d), O.get(oracle.F_RES, depth=d)), ("coarse residual", d)
+    no, ho = O.solve(sp)
+    ng, hg = G.solve(sp)
+    assert ng == no and np.array_equal(hg, ho)
+
+
 def test_full_size_properties(hip):
     """BASELINE size (4096^2): size-independent properties instead of the (slow) oracle:
     GSRB fixed point, residual == rhs - applyOp, restriction of a constant, idempotent
