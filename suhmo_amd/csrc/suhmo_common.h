@@ -171,5 +171,6 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
                                                     // rows worth keeping valid at exit; restricted: see there
 void suhmo_level_drop_graphs(suhmo_level *L);                                     // suhmo_fas.hip
 int suhmo_ensure_phi_halo(suhmo_level *L, int depth, int need, hipStream_t st);      // suhmo_level.hip
+int suhmo_fas_coarse_rhs(suhmo_level *L, int depth, hipStream_t st);                // suhmo_level.hip
 int suhmo_exchange_list(suhmo_level *L, int depth, const int *fields, int n, hipStream_t st);   // LevelData::exchange across rank boundaries
 static inline int suhmo_halo_rows(const DV &v) { return v.gy < v.ny ? v.gy : v.ny; }

@@ -12,6 +12,7 @@
 // Single AMR level in this round; all work stays on `st`, the only host round trip is the
 // 8-byte residual norm per V-cycle in the solve loop.
 #include "suhmo_common.h"
+#include <cstdlib>
 
 static int eff_depths(const suhmo_level *L, const suhmo_solver_params_t *sp)
 {
@@ -56,11 +57,16 @@ static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, i
                                                                                   //  row, the prolongation below the rest)
     if (!restricted && (rc = suhmo_restrict_both(L, dep, (hipStream_t)s))) return rc;   // RES[dep+1] and PHI[dep+1] = R(phi); the fused
                                                                                   //  relaxation may have written them already
-    if ((rc = suhmo_ensure_phi_halo(L, dep + 1, suhmo_halo_rows(C.v), (hipStream_t)s))) return rc;   // strips: before the copy, so that
-    HIPCHK(hipMemcpyAsync(C.fp.f[SUHMO_F_PHIOLD], C.fp.f[SUHMO_F_PHI], C.elems * sizeof(double),      // PHIOLD carries the halo rows too
-                          hipMemcpyDeviceToDevice, (hipStream_t)s));
-    if ((rc = suhmo_level_apply_op(L, dep + 1, 0, s))) return rc;                 // LPHI = L_c(R phi)
-    if ((rc = suhmo_level_axby(L, dep + 1, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
+    static const bool one_pass_rhs = !(getenv("SUHMO_FAS_RHS_FUSED") && atoi(getenv("SUHMO_FAS_RHS_FUSED")) == 0);
+    if (one_pass_rhs && !(C.v.ext[0] || C.v.ext[1])) {
+        if ((rc = suhmo_fas_coarse_rhs(L, dep + 1, (hipStream_t)s))) return rc;   // PHIOLD = R phi, rhs_c = res_c + L_c(R phi): one pass
+    } else {
+        if ((rc = suhmo_ensure_phi_halo(L, dep + 1, suhmo_halo_rows(C.v), (hipStream_t)s))) return rc;   // strips: before the copy, so that
+        HIPCHK(hipMemcpyAsync(C.fp.f[SUHMO_F_PHIOLD], C.fp.f[SUHMO_F_PHI], C.elems * sizeof(double),      // PHIOLD carries the halo rows too
+                              hipMemcpyDeviceToDevice, (hipStream_t)s));
+        if ((rc = suhmo_level_apply_op(L, dep + 1, 0, s))) return rc;             // LPHI = L_c(R phi)
+        if ((rc = suhmo_level_axby(L, dep + 1, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
+    }
     if ((rc = suhmo_level_exchange(L, dep + 1, SUHMO_F_RHS, s))) return rc;   // strips: rhs halo rows for the fused relax
     if ((rc = fas_cycle(L, dep + 1, sp, nd, s))) return rc;
     if (suhmo_gsrb_can_fuse_prolong(L, dep, S)) {

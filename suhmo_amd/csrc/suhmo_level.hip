@@ -415,7 +415,8 @@ extern "C" int suhmo_level_fill_ghosts(suhmo_level_t *L, int depth, int field, i
     return 0;
 }
 
-// VCNLCOMPUTEOP2D / VCNLCOMPUTERES2D with BC, NL fused.  MODE 0: LPHI = L(phi); 1: RES = rhs - L(phi)
+// VCNLCOMPUTEOP2D / VCNLCOMPUTERES2D with BC, NL fused.  MODE 0: LPHI = L(phi); 1: RES = rhs - L(phi);
+// 2: the FAS right-hand side of a coarse depth in one pass: LPHI = L(phi), RHS = axby(RES, LPHI, 1, 1), PHIOLD = phi
 template <bool HAS_ALPHA, int MODE>
 __global__ __launch_bounds__(256) void k_apply(DV v, FP fp, suhmo_phys_t ph, int homog)
 {
@@ -434,7 +435,12 @@ __global__ __launch_bounds__(256) void k_apply(DV v, FP fp, suhmo_phys_t ph, int
     double aterm = HAS_ALPHA ? v.alpha * fp.f[SUHMO_F_ACOEF][idx] : v.alpha;
     double lofphi = lofphi_cell(v, aterm, c, e, w, n, s, bxE, bxW, byN, byS, nl);
     if (MODE == 0) fp.f[SUHMO_F_LPHI][idx] = lofphi;
-    else fp.f[SUHMO_F_RES][idx] = fp.f[SUHMO_F_RHS][idx] - lofphi;
+    else if (MODE == 1) fp.f[SUHMO_F_RES][idx] = fp.f[SUHMO_F_RHS][idx] - lofphi;
+    else {
+        fp.f[SUHMO_F_LPHI][idx] = lofphi;
+        fp.f[SUHMO_F_RHS][idx] = 1.0 * fp.f[SUHMO_F_RES][idx] + 1.0 * lofphi;
+        fp.f[SUHMO_F_PHIOLD][idx] = c;
+    }
 }
 
 static int exchange_fields(suhmo_level *L, int depth, std::initializer_list<int> fields, hipStream_t st)
@@ -476,6 +482,18 @@ extern "C" int suhmo_level_apply_op(suhmo_level_t *L, int depth, int homogeneous
     int rc = suhmo_ensure_phi_halo(L, depth, 1, (hipStream_t)s); if (rc) return rc;
     if (D.v.alpha != 0.0) hipLaunchKernelGGL((k_apply<true, 0>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, L->ph, homogeneous);
     else hipLaunchKernelGGL((k_apply<false, 0>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, L->ph, homogeneous);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// FAS cycle, coarse depth after the restriction (whole level on this process): rhs_c = res_c + L_c(R phi) and the copy of
+// R phi the prolongation subtracts, one pass instead of applyOp + axby + a device copy
+int suhmo_fas_coarse_rhs(suhmo_level *L, int depth, hipStream_t st)
+{
+    Depth &D = L->d[depth];
+    if (!suhmo_field(L, depth, SUHMO_F_LPHI) || !suhmo_field(L, depth, SUHMO_F_PHIOLD)) return -2;
+    if (D.v.alpha != 0.0) hipLaunchKernelGGL((k_apply<true, 2>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, st, D.v, D.fp, L->ph, 0);
+    else hipLaunchKernelGGL((k_apply<false, 2>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, st, D.v, D.fp, L->ph, 0);
     HIPCHK(hipGetLastError());
     return 0;
 }
