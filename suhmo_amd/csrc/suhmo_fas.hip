@@ -58,12 +58,12 @@ static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, i
     if (!restricted && (rc = suhmo_restrict_both(L, dep, (hipStream_t)s))) return rc;   // RES[dep+1] and PHI[dep+1] = R(phi); the fused
                                                                                   //  relaxation may have written them already
     static const bool one_pass_rhs = !(getenv("SUHMO_FAS_RHS_FUSED") && atoi(getenv("SUHMO_FAS_RHS_FUSED")) == 0);
-    if (one_pass_rhs && !(C.v.ext[0] || C.v.ext[1])) {
+    if ((rc = suhmo_ensure_phi_halo(L, dep + 1, suhmo_halo_rows(C.v), (hipStream_t)s))) return rc;   // strips: before PHIOLD is taken, so that
+                                                                                                      // it carries the halo rows too
+    if (one_pass_rhs && (L->desc.nx_global == 0)) {
         if ((rc = suhmo_fas_coarse_rhs(L, dep + 1, (hipStream_t)s))) return rc;   // PHIOLD = R phi, rhs_c = res_c + L_c(R phi): one pass
     } else {
-        if ((rc = suhmo_ensure_phi_halo(L, dep + 1, suhmo_halo_rows(C.v), (hipStream_t)s))) return rc;   // strips: before the copy, so that
-        HIPCHK(hipMemcpyAsync(C.fp.f[SUHMO_F_PHIOLD], C.fp.f[SUHMO_F_PHI], C.elems * sizeof(double),      // PHIOLD carries the halo rows too
-                              hipMemcpyDeviceToDevice, (hipStream_t)s));
+        HIPCHK(hipMemcpyAsync(C.fp.f[SUHMO_F_PHIOLD], C.fp.f[SUHMO_F_PHI], C.elems * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)s));
         if ((rc = suhmo_level_apply_op(L, dep + 1, 0, s))) return rc;             // LPHI = L_c(R phi)
         if ((rc = suhmo_level_axby(L, dep + 1, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
     }

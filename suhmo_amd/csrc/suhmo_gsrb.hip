@@ -221,7 +221,7 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
         // ---- 2b. RST: rows r-2K-2 .. r-2K are final: residual of row r-2K-1, restricted
         if constexpr (RST) {
             const int jr = r - 2 * K - 1;
-            if (own && jr >= jA && jr < jB) {
+            if (own && jr >= jA && jr < jB && jr >= 0 && jr < v.ny) {    // (rank strips: halo rows are advanced, not restricted)
                 const RowCoef &q = (K >= 2) ? cf5 : cf3;
                 const int s0 = (sr - (2 * K + 1) + 2 * R) % R, sN = (s0 + 1) % R, sS = (s0 + R - 1) % R;
                 const double *row = lds + s0 * LW;
@@ -328,8 +328,8 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st)
     g.ntiles = g.nstrips * g.nchunks;
     bool selfper = v.per[1] && !(v.ext[0] || v.ext[1]);
     g.wrap_y = selfper;
-    g.ylo = v.ext[0] ? g.jbeg - 2 * K : (selfper ? -2 * K - EY : 0);
-    g.yhi = v.ext[1] ? g.jend - 1 + 2 * K : (selfper ? v.ny - 1 + 2 * K + EY : v.ny - 1);
+    g.ylo = v.ext[0] ? g.jbeg - 2 * K - EY : (selfper ? -2 * K - EY : 0);
+    g.yhi = v.ext[1] ? g.jend - 1 + 2 * K + EY : (selfper ? v.ny - 1 + 2 * K + EY : v.ny - 1);
     const double *pin = D.fp.f[SUHMO_F_PHI];
     g.pc = g.pco = nullptr; g.Pc = g.gyc = 0;
     if (D.prolong_pending) {
@@ -395,7 +395,10 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
     int variant = pick_variant(L, D);
     const bool ext = L->ex && (D.v.ext[0] || D.v.ext[1]);
     if (restricted) *restricted = 0;
-    const bool may_restrict = restricted && L->fused_restrict && depth + 1 < L->ndepth && !(D.v.ext[0] || D.v.ext[1]) && !(D.v.ny & 1)
+    // rank strips: the rows next to the strip's ends come from the halo (one more valid row than the sweeps need, an even
+    // number of redundantly advanced rows so that a coarse cell's two fine rows share a chunk); not on AMR patches
+    const bool may_restrict = restricted && L->fused_restrict && depth + 1 < L->ndepth && !(D.v.ny & 1) && !(D.v.j0 & 1)
+                              && (!(D.v.ext[0] || D.v.ext[1]) || (ext && L->desc.nx_global == 0 && D.v.gy >= 5))
                               && D.v.alpha == 0.0;          // with aCoef the extra coefficient row no longer fits 2 waves per SIMD
     // Strips: F = halo rows of phi that hold current neighbour values (Depth::phi_fresh).  A colour pass
     // needs 1, a K-sweep launch 2K; each launch also advances, redundantly, as many of the remaining halo
@@ -436,7 +439,16 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
             int E = ext ? (F - 2 * K < want ? F - 2 * K : want) : 0;
             int rc;
             const int nt = L->fused_nt ? L->fused_nt : ((long)D.v.nx * D.v.ny >= 8000000L ? 256 : 64);   // 0 = by size
-            if (may_restrict && nt == 64 && K == 2 && it + K == sweeps) { rc = launch_fused<2, 64, true>(L, depth, E, st); *restricted = 1; }
+            bool rst = may_restrict && nt == 64 && K == 2 && it + K == sweeps;
+            if (rst && ext) {
+                if (F < 2 * K + 1) {                                       // one exchange instead of the restriction's own
+                    int rc2 = suhmo_ensure_phi_halo(L, depth, 2 * K + 1, st); if (rc2) return rc2;
+                    F = D.phi_fresh;
+                }
+                if (F < 2 * K + 1) rst = false;
+                else { E = F - 2 * K - 1 < want ? F - 2 * K - 1 : want; E &= ~1; }
+            }
+            if (rst) { rc = launch_fused<2, 64, true>(L, depth, E, st); *restricted = 1; }
             else if (nt == 64) rc = (K == 2) ? launch_fused<2, 64>(L, depth, E, st) : launch_fused<1, 64>(L, depth, E, st);
             else rc = (K == 2) ? launch_fused<2, 256>(L, depth, E, st) : launch_fused<1, 256>(L, depth, E, st);
             if (rc) return rc;
