@@ -1,8 +1,8 @@
 /*
  * time_loop.c -- TEST INFRASTRUCTURE ONLY ("next rows" of SURVEY.md 8f: the caller of the
  * head solve).  CPU restatement of one AmrHydro::timeStepFAS (src/AmrHydro.cpp:2254-3460) for a
- * single AMR level without moulins (n_moulins < 0: distributed input) and with the explicit
- * gap-height update (solver.use_ImplDiff = false):
+ * single AMR level (a hierarchy: amr_step.c strings the phases below together per level): distributed or moulin input,
+ * with or without the diffusive term, explicit or implicit gap-height update:
  *   [I]   ghosts of h and b, copy into old                         :2360-2445
  *   [II]  Picard loop: lagged quantities -> RHS_h -> SolveForHead_nl -> convergence test
  *                                                                   :2477-3235
@@ -13,7 +13,8 @@
  * decomposition does not change a bit; the head solve goes through the level shim
  * (or_level_solve), i.e. the un-fused box-by-box path.
  * Diffusive term (suhmo.diffFactor): the reference multiplies COMPUTEDIFTERM2D by DiffFactor
- * (:3071, :2145); with DiffFactor = 0 (SHMIP A) it contributes +-0 and is skipped here.
+ * (:3071, :2145); with DiffFactor = 0 (SHMIP A) it contributes +-0 and is skipped.
+ * Pinned end to end by the reference's committed SHMIP A1-A6 / B1-B5 tables (tests/test_oracle_timeloop.py).
  */
 #include "level_shim.h"
 #include <math.h>

@@ -1,6 +1,7 @@
 // suhmo_step.hip -- the caller of the head solve, device resident: one AmrHydro::timeStepFAS
-// (src/AmrHydro.cpp:2254-3460) for a single level, distributed water input (n_moulins < 0),
-// explicit gap-height update (solver.use_ImplDiff = false).  "Next rows" of SURVEY.md 8(f).
+// (src/AmrHydro.cpp:2254-3460) on one level (suhmo_level_timestep) or on an AMR hierarchy (suhmo_amr_timestep), each whole
+// or cut into rank strips: distributed, time-varying or moulin water input, with or without the diffusive term
+// (suhmo.diffFactor), explicit or implicit (solver.use_ImplDiff) gap-height update.  "Next rows" of SURVEY.md 8(f).
 //
 //   [II]  Picard loop (:2477-3235): ghosts of h and b -> grad h (compute_grad_head :1610-1674) ->
 //         Re (evaluate_Re_quadratic :1711-1778) -> Qw on faces (evaluate_Qw_ec :1677-1709, COMPUTEQW)
