@@ -1069,8 +1069,7 @@ __global__ __launch_bounds__(256) void k_average_faces_x_all(DV vf, const double
     if (i > vf.nx || jb * R >= vf.ny) return;
     double sum[SUHMO_MAXDEPTH];
     const int base = cidx(vf, i, jb * R);
-    for (int k = 0; k < R; k++) {
-        double f = bxf[base + k * vf.P];
+    auto take = [&](int k, double f) {
 #pragma unroll
         for (int d = 1; d < SUHMO_MAXDEPTH; d++) {
             if (d >= nd) break;
@@ -1080,6 +1079,17 @@ __global__ __launch_bounds__(256) void k_average_faces_x_all(DV vf, const double
             if ((k & (r - 1)) == r - 1)
                 o.bx[d][((jb * R + k) / r + o.gy[d]) * o.P[d] + SUHMO_XOFF + i / r] = sum[d] / (double)r;
         }
+    };
+    if (R >= 8) {
+        for (int k0 = 0; k0 < R; k0 += 8) {              // 8 independent loads in flight, then the (sequential) sums
+            double f8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) f8[u] = bxf[base + (k0 + u) * vf.P];
+#pragma unroll
+            for (int u = 0; u < 8; u++) take(k0 + u, f8[u]);
+        }
+    } else {
+        for (int k = 0; k < R; k++) take(k, bxf[base + k * vf.P]);
     }
 }
 // y-faces: one wave walks 64 consecutive columns of one even fine row; lane l = column
