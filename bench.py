@@ -154,13 +154,17 @@ def main():
     if rank == 0:
         out = {
             "metric": "multigrid V-cycles/s (FAS head solve) + GSRB cell-updates/s; achieved HBM GB/s vs peak",
-            "value": vps * 1.0, "unit": "V-cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # whole-job aggregate: a unit is one V-cycle over one GPU's batch of n x n cells; a step runs one on every GPU
+            # (weak scaling: the level is world x as large), so value = world x steps / time
+            "value": vps * world, "unit": "V-cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "SHMIP-A head solve, %dx%d cells per GPU, single AMR level, 64x64 boxes, "
                                    "%d MG depths, 4+4 GSRB sweeps per depth, %d bottom (BASELINE north_star: 4096^2 single-level)"
                                    % (n, n, ndepth, sp["num_bottom"]),
-                       "global_cells": [n, ny_global], "partition": "row strips, 1 per GPU" if world > 1 else "none"},
+                       "global_cells": [n, ny_global], "partition": "row strips, 1 per GPU" if world > 1 else "none",
+                       "unit_of_value": "V-cycles over %dx%d cells (one per GPU per step; the level of %dx%d cells completes %.4g V-cycles/s)"
+                                        % (n, n, n, ny_global, vps)},
             "gsrb_cell_updates_per_s": updates_per_vcycle * vps * world,
             "gsrb_depth0_cell_updates_per_s_kernel": cells / (sweep_ms * 1e-3) * world if gsrb_launches else None,
             "roofline": {"bound": "hbm", "kernel": "GSRB sweep (red+black) at depth 0", "achieved": achieved,
