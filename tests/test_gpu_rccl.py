@@ -53,10 +53,12 @@ def test_self_neighbour_vcycle_bitwise(nx, ny, variant, halo, monkeypatch):
 
 
 @pytest.mark.parametrize("impl", [0, 1])
-def test_self_neighbour_timestep_bitwise(impl):
+@pytest.mark.parametrize("direct", [0, 1])
+def test_self_neighbour_timestep_bitwise(impl, direct, monkeypatch):
     """suhmo_level_timestep on a strip coupled through the native RCCL hooks (its own periodic neighbour): gap-height,
     melt-rate, gradient and RHS halos, the MAX all-reduced Picard test and -- impl = 1 -- the implicit gap-height solver
     sharing the strip's communicator; must equal the whole periodic level bit for bit."""
+    monkeypatch.setenv("SUHMO_RCCL_DIRECT", str(direct))      # 1: halo rows sent from / received into the canvas itself
     from suhmo_amd import model, multigpu
     from test_gpu_timestep import perturbed_state
     from test_gpu_timestep_strips import wrap, NAMES
