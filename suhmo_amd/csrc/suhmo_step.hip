@@ -647,7 +647,9 @@ extern "C" int suhmo_amr_moulin_source(suhmo_level_t **lv, int nlev, const int *
             const int *q = patch_boxes + 4 * (l - 1);
             ARG(q[2] >= q[0] && q[3] >= q[1]);
             geo[l] = Geo{2 * (q[2] - q[0] + 1), 2 * (q[3] - q[1] + 1), 2 * q[0], 2 * q[1], geo[l - 1].dx / 2.0, geo[l - 1].dy / 2.0};
-            if (lv[l]) { const DV &v = lv[l]->d[0].v; if (v.nx != geo[l].nx || v.i0 != geo[l].i0 || v.j0 < geo[l].j0 || v.j0 + v.ny > geo[l].j0 + geo[l].ny) { suhmo_set_error("moulin source: level %d does not match patch_boxes", l); return -1; } }
+            if (lv[l]) { const DV &v = lv[l]->d[0].v; const bool part = v.rk[0] || v.rk[1];            // a rank strip holds some of the rows, a whole patch all of them
+                if (v.nx != geo[l].nx || v.i0 != geo[l].i0 || v.j0 < geo[l].j0 || v.j0 + v.ny > geo[l].j0 + geo[l].ny
+                    || (!part && (v.j0 != geo[l].j0 || v.ny != geo[l].ny))) { suhmo_set_error("moulin source: level %d does not match patch_boxes", l); return -1; } }
         } else {
             if (!lv[l] || lv[l]->d[0].v.rk[0] || lv[l]->d[0].v.rk[1]) { suhmo_set_error("moulin source on rank strips needs patch_boxes"); return -1; }
             const DV &v = lv[l]->d[0].v;

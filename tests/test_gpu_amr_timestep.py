@@ -112,3 +112,31 @@ def test_amr_timestep_refuses_what_is_not_built():
     with pytest.raises(capi.SuhmoError):
         G.timestep(3600.0)
     G.close()
+
+
+def test_error_paths_of_the_new_entry_points():
+    """refusals carry a message instead of wrong numbers: moulin boxes that do not match the handles, strips without boxes,
+    a boundary-condition change that would alter the periodicity, the time-varying recharge without a surface field"""
+    import ctypes as C
+    from suhmo_amd import capi, model, level as lv
+    patches = ((16, 8, 47, 23),)
+    sts = sy.shmip_amr_states(64, 32, patches)
+    G = model.HipAmrModel(64, 32, sts[0]["dx"], sts[0]["dy"], sy.A3_BC, sy.A3_PHYS, dict(sy.A3_MODEL), patches, max_box=16)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    pos, sg, fl, integ = np.array([3.0e4, 1.0e4]), np.array([500.0]), np.array([10.0]), np.zeros(1)
+    bad = (C.c_int * 4)(16, 8, 47, 25)                        # not the box the fine handle was created with
+    rc = capi.lib().suhmo_amr_moulin_source(G.amr._arr, 2, bad, 1, dp(pos), dp(sg), dp(fl), 1.0, dp(integ), None)
+    assert rc == -1 and b"patch_boxes" in capi.lib().suhmo_last_error()
+    good = (C.c_int * 4)(*patches[0])
+    assert capi.lib().suhmo_amr_moulin_source(G.amr._arr, 2, good, 1, dp(pos), dp(sg), dp(fl), 1.0, dp(integ), None) == 0
+    i2 = G.moulin_source(pos.reshape(1, 2), sg, fl, 1.0)      # geometry from the handles: the same integral
+    assert integ[0] == i2[0] > 0.0
+    bc = lv._bc(dict(type=[[0, 0], [1, 1]], value=[[0.0, 0.0], [0.0, 0.0]], periodic=[0, 1]))
+    assert capi.lib().suhmo_level_set_bc(G.levels[0].h, C.byref(bc)) == -1 and b"periodicity" in capi.lib().suhmo_last_error()
+    assert capi.lib().suhmo_level_time_varying_recharge(G.levels[0].h, 3.0, 1e-10, None) == -1
+    # a hierarchy whose patch is not properly nested is refused by the time step
+    G2 = model.HipAmrModel(64, 32, sts[0]["dx"], sts[0]["dy"], sy.A3_BC, sy.A3_PHYS, dict(sy.A3_MODEL), ((16, 8, 47, 23), (33, 17, 92, 45)), max_box=16)
+    with pytest.raises(capi.SuhmoError):
+        G2.timestep(3600.0)
+    G.close()
+    G2.close()
