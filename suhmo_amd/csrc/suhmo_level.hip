@@ -842,12 +842,14 @@ __global__ __launch_bounds__(256) void k_bcoef_faces(DV v, FP fp, suhmo_phys_t p
 // cells are recomputed instead of stored, so HBM sees phi, B, mask once and bx, by once.
 #define BT_X 62
 #define BT_Y 14
-__global__ __launch_bounds__(256) void k_bcoef_fused(DV v, FP fp, suhmo_phys_t ph, int hasMask)
+// INTERIOR: the tile and its two-cell halo lie inside the level -- no boundary condition, no wrap, no missing cell: the
+// same expressions without the case distinctions (most tiles; uniform per workgroup)
+template <bool INTERIOR>
+__device__ __forceinline__ void bcoef_tile(const DV &v, const FP &fp, const suhmo_phys_t &ph, int hasMask, double *sphi, double *sB, double *sM)
 {
     constexpr int PW = BT_X + 4, PH = BT_Y + 4;     // phi tile: cells [i0-2, i0+BT_X+1] x [j0-2, j0+BT_Y+1]
     constexpr int RW = BT_X + 2, RH = BT_Y + 2;     // Re tile:  cells [i0-1, i0+BT_X]   x [j0-1, j0+BT_Y]
     constexpr int NK = RH / 4;
-    __shared__ double sphi[PW * PH], sB[RW * RH], sM[RW * RH];
     double *sre = sphi;                              // phi is dead once the gradients exist
     const int i0 = blockIdx.x * BT_X, j0 = blockIdx.y * BT_Y;
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -855,10 +857,10 @@ __global__ __launch_bounds__(256) void k_bcoef_fused(DV v, FP fp, suhmo_phys_t p
     double *__restrict__ bxo = fp.f[SUHMO_F_BX], *__restrict__ byo = fp.f[SUHMO_F_BY];
     const bool halo_lo = v.ext[0], halo_hi = v.ext[1], selfper_y = v.per[1] && !halo_lo && !halo_hi;
     // a cell "exists" (has its own phi) inside the domain, as a periodic image, or in an exchanged halo row
-    auto xin = [&](int i) { return (i >= 0 && i < v.nx) || v.per[0]; };
-    auto yin = [&](int j) { return (j >= 0 && j < v.ny) || selfper_y || (j < 0 && halo_lo && j >= -v.gy) || (j >= v.ny && halo_hi && j < v.ny + v.gy); };
-    auto wrapx = [&](int i) { return v.per[0] ? (i < 0 ? i + v.nx : (i >= v.nx ? i - v.nx : i)) : i; };
-    auto wrapy = [&](int j) { return selfper_y ? (j < 0 ? j + v.ny : (j >= v.ny ? j - v.ny : j)) : j; };
+    auto xin = [&](int i) { return INTERIOR || (i >= 0 && i < v.nx) || v.per[0]; };
+    auto yin = [&](int j) { return INTERIOR || (j >= 0 && j < v.ny) || selfper_y || (j < 0 && halo_lo && j >= -v.gy) || (j >= v.ny && halo_hi && j < v.ny + v.gy); };
+    auto wrapx = [&](int i) { return (!INTERIOR && v.per[0]) ? (i < 0 ? i + v.nx : (i >= v.nx ? i - v.nx : i)) : i; };
+    auto wrapy = [&](int j) { return (!INTERIOR && selfper_y) ? (j < 0 ? j + v.ny : (j >= v.ny ? j - v.ny : j)) : j; };
 
     // ---- phi tile.  Cells that do not exist get the physical-BC ghost of their interior
     // neighbour (only the first ghost layer is used: face gradient of the boundary cell).
@@ -890,7 +892,7 @@ __global__ __launch_bounds__(256) void k_bcoef_fused(DV v, FP fp, suhmo_phys_t p
 #pragma unroll
     for (int k = 0; k < NK; k++) {
         const int lj = ty + 4 * k, j = j0 - 1 + lj;
-        hasB[k] = i >= -1 && i <= v.nx && j >= -v.gy && j <= v.ny + v.gy - 1 && !((i < 0 || i >= v.nx) && (j < 0 || j >= v.ny));
+        hasB[k] = INTERIOR || (i >= -1 && i <= v.nx && j >= -v.gy && j <= v.ny + v.gy - 1 && !((i < 0 || i >= v.nx) && (j < 0 || j >= v.ny)));
         double b = 0.0, m = 0.0;
         if (hasB[k]) { int idx = cidx(v, i, j); b = Bf[idx]; m = mk[idx]; }
         Br[k] = b;
@@ -949,19 +951,27 @@ __global__ __launch_bounds__(256) void k_bcoef_fused(DV v, FP fp, suhmo_phys_t p
     __syncthreads();
     // ---- faces (k_bcoef_faces): lane tx >= 1 owns cell column i (its W and S faces); the last tile
     // column / row also owns the domain's E / N faces
-    const int nxt = (i0 + BT_X >= v.nx) ? v.nx - i0 + 1 : BT_X, nyt = (j0 + BT_Y >= v.ny) ? v.ny - j0 + 1 : BT_Y;
+    const int nxt = (!INTERIOR && i0 + BT_X >= v.nx) ? v.nx - i0 + 1 : BT_X, nyt = (!INTERIOR && j0 + BT_Y >= v.ny) ? v.ny - j0 + 1 : BT_Y;
     const int fx = tx - 1;                           // face column index inside the tile
     if (fx >= 0 && fx < nxt) {
         for (int fy = ty; fy < nyt; fy += 4) {
             const int j = j0 + fy, idx = cidx(v, i, j), r = (fy + 1) * RW + tx;
-            if (j < v.ny)
-                bxo[idx] = bcoef_face(ph, sre[r], sre[r - 1], sB[r], sB[r - 1], sM[r], sM[r - 1], i == 0 || i == v.nx);
-            if (i < v.nx) {
+            if (INTERIOR || j < v.ny)
+                bxo[idx] = bcoef_face(ph, sre[r], sre[r - 1], sB[r], sB[r - 1], sM[r], sM[r - 1], !INTERIOR && (i == 0 || i == v.nx));
+            if (INTERIOR || i < v.nx) {
                 int jg = j + v.j0;
-                byo[idx] = bcoef_face(ph, sre[r], sre[r - RW], sB[r], sB[r - RW], sM[r], sM[r - RW], jg == 0 || jg == v.nyg);
+                byo[idx] = bcoef_face(ph, sre[r], sre[r - RW], sB[r], sB[r - RW], sM[r], sM[r - RW], !INTERIOR && (jg == 0 || jg == v.nyg));
             }
         }
     }
+}
+__global__ __launch_bounds__(256) void k_bcoef_fused(DV v, FP fp, suhmo_phys_t ph, int hasMask)
+{
+    __shared__ double sphi[(BT_X + 4) * (BT_Y + 4)], sB[(BT_X + 2) * (BT_Y + 2)], sM[(BT_X + 2) * (BT_Y + 2)];
+    const int i0 = blockIdx.x * BT_X, j0 = blockIdx.y * BT_Y;
+    const bool interior = i0 - 2 >= 0 && i0 + BT_X + 1 <= v.nx - 1 && j0 - 2 >= 0 && j0 + BT_Y + 1 <= v.ny - 1;
+    if (interior) bcoef_tile<true>(v, fp, ph, hasMask, sphi, sB, sM);
+    else bcoef_tile<false>(v, fp, ph, hasMask, sphi, sB, sM);
 }
 
 extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_stream_t s)
