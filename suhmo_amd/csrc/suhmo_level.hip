@@ -1102,24 +1102,36 @@ __global__ __launch_bounds__(256) void k_average_faces_x_all(DV vf, const double
         for (int k = 0; k < R; k++) take(k, bxf[base + k * vf.P]);
     }
 }
-// y-faces: one wave walks 64 consecutive columns of one even fine row; lane l = column
+// y-faces: one wave walks 64 consecutive columns of YR even fine rows (their loads in flight together); lane l = column
+#define AVG_YR 8
 __global__ __launch_bounds__(256) void k_average_faces_y_all(DV vf, const double *__restrict__ byf, AvgOut o, int nd)
 {
     const int lane = threadIdx.x & 63;
-    int i = blockIdx.x * 64 + lane;
-    int j = 2 * (blockIdx.y * (blockDim.x / 64) + (threadIdx.x >> 6));
-    if (j > vf.ny) return;                                // whole wave leaves together
-    double f = (i < vf.nx) ? byf[cidx(vf, i, j)] : 0.0;
-    double run = 0.0 + f;                                 // depth-0 "sum" of a single face
-    for (int d = 1; d < nd; d++) {
-        const int r = 1 << d;
-        if ((j & (r - 1)) != 0) break;                    // row not on depth d's face grid
-        // sequential continuation: (((run + f[l + r/2]) + f[l + r/2 + 1]) + ... + f[l + r - 1])
-        double acc = run;
-        for (int k = r / 2; k < r; k++) acc = acc + __shfl(f, (lane + k) & 63);
-        run = acc;                                        // valid on lanes with (lane % r) == 0
-        if ((lane & (r - 1)) == 0 && i < vf.nx)
-            o.by[d][(j / r + o.gy[d]) * o.P[d] + SUHMO_XOFF + i / r] = run / (double)r;
+    const int i = blockIdx.x * 64 + lane;
+    const int jb = 2 * AVG_YR * (blockIdx.y * (blockDim.x / 64) + (threadIdx.x >> 6));
+    if (jb > vf.ny) return;                               // whole wave leaves together
+    double fr[AVG_YR];
+#pragma unroll
+    for (int q = 0; q < AVG_YR; q++) {
+        const int j = jb + 2 * q;
+        fr[q] = (i < vf.nx && j <= vf.ny) ? byf[cidx(vf, i, j)] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < AVG_YR; q++) {
+        const int j = jb + 2 * q;
+        if (j > vf.ny) break;                             // uniform
+        const double f = fr[q];
+        double run = 0.0 + f;                             // depth-0 "sum" of a single face
+        for (int d = 1; d < nd; d++) {
+            const int r = 1 << d;
+            if ((j & (r - 1)) != 0) break;                // row not on depth d's face grid
+            // sequential continuation: (((run + f[l + r/2]) + f[l + r/2 + 1]) + ... + f[l + r - 1])
+            double acc = run;
+            for (int k = r / 2; k < r; k++) acc = acc + __shfl(f, (lane + k) & 63);
+            run = acc;                                    // valid on lanes with (lane % r) == 0
+            if ((lane & (r - 1)) == 0 && i < vf.nx)
+                o.by[d][(j / r + o.gy[d]) * o.P[d] + SUHMO_XOFF + i / r] = run / (double)r;
+        }
     }
 }
 
@@ -1149,7 +1161,7 @@ int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st)
     const int R = 1 << (nd - 1);
     dim3 gx((F.v.nx / 2 + 1 + 63) / 64, (F.v.ny / R + 3) / 4);
     hipLaunchKernelGGL(k_average_faces_x_all, gx, dim3(64, 4), 0, st, F.v, F.fp.f[SUHMO_F_BX], o, nd);
-    dim3 gy((F.v.nx + 63) / 64, (F.v.ny / 2 + 1 + 3) / 4);
+    dim3 gy((F.v.nx + 63) / 64, ((F.v.ny / 2 + 1 + AVG_YR - 1) / AVG_YR + 3) / 4);
     hipLaunchKernelGGL(k_average_faces_y_all, gy, dim3(256), 0, st, F.v, F.fp.f[SUHMO_F_BY], o, nd);
     HIPCHK(hipGetLastError());
     // strips: the coarse face coefficients of all depths travel as one message group when the transport can batch
