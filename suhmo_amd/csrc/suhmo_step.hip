@@ -469,14 +469,14 @@ extern "C" int suhmo_amr_timestep(suhmo_level_t **lv, int nlev, const suhmo_mode
             if ((rc = reduce_max(lv[l], lv[l]->d[0].fp.f[SUHMO_F_PHI], nullptr, 1.0, 0, &m, st, covered_by(lv, nlev, l), true))) return rc;
             maxHead = std::max(maxHead, m);
         }
-        if (strips && (rc = lv[0]->ar(lv[0]->user, &maxHead))) return rc;              // computeMax over all ranks (level 0 reaches every rank)
+        if (strips && lv[0]->ar && (rc = lv[0]->ar(lv[0]->user, &maxHead))) return rc; // computeMax over all ranks (level 0 reaches every rank)
         for (int l = 0; l < nlev; l++) {
             if (!lv[l]) continue;
             double r = 0.0;
             if ((rc = reduce_max(lv[l], lv[l]->d[0].fp.f[SUHMO_F_PHI], lv[l]->d[0].fp.f[SUHMO_F_HLAG], maxHead, 1, &r, st, covered_by(lv, nlev, l), true))) return rc;
             res = std::max(res, r);
         }
-        if (strips && (rc = lv[0]->ar(lv[0]->user, &res))) return rc;
+        if (strips && lv[0]->ar && (rc = lv[0]->ar(lv[0]->user, &res))) return rc;
         if (ite_idx > 100) { suhmo_set_error("does not converge (Picard iterations > 100)"); return -6; }
         if (cur_step < 2) { if (res < 0.05 && cur_picard > 2) converged = true; }
         else if (cur_step < 50) { if (res < 0.05) converged = true; }
