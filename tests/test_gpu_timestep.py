@@ -147,3 +147,20 @@ def test_shmip_b_full_run(hipmodel, oracle, case):
     scale = np.max(np.abs(orc), axis=0)
     assert np.all(np.abs(table - orc) <= 1e-9 * scale), np.max(np.abs(table - orc) / scale, axis=0)
     check_against_reference(table, case, "run")
+
+
+def test_convergence_distributed_reference_table(hipmodel):
+    """exec/1_convergence_distributed: five runs of 5000 steps (64 x 16 ... 1024 x 256, y-periodic sqrt ice sheet, diffusion and
+    implicit gap-height solve, dt = 2 h) and the L2 self-convergence errors of head, gap height, water pressure and Reynolds
+    number between successive resolutions -- the table the reference commits (CONV_ANA/results/convergence_data.dat, copied as
+    a data fixture).  The device path reproduces all 16 numbers to the 5 digits they are printed with, with the source and the
+    inputs as they are: a direct pin of the HIP path against the reference's own output."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "tools"))
+    import convergence_distributed as cd
+    ref = {int(r[0]): r[1:] for r in np.loadtxt(os.path.join(GOLD, "convergence_distributed_reference.dat"))}
+    got = cd.table("hip", 5000, 1024)
+    assert sorted(got) == sorted(ref) == [64, 128, 256, 512]
+    for nx in ref:
+        for k, (a, b) in enumerate(zip(got[nx], ref[nx])):
+            assert abs(a - b) <= 6e-5 * abs(b), (nx, ("head", "gapHeight", "Pw", "Re")[k], a, b)      # 5 significant digits

@@ -94,3 +94,18 @@ def test_mass_balance_of_the_committed_run(case):
     """steady state of SHMIP A: discharge through a cross-section = recharge upstream of it"""
     orc = np.loadtxt(os.path.join(GOLD, "shmip_%s_oracle_run_table.dat" % case))
     assert np.max(np.abs(orc[:, 2] - (orc[:, 5] + orc[:, 6]))) < 1e-3 * orc[0, 2]
+
+
+def test_oracle_reproduces_the_distributed_convergence_table():
+    """the first row of exec/1_convergence_distributed/CONV_ANA/results/convergence_data.dat (runs at 64 x 16 and 128 x 32, 5000
+    steps each) through the oracle's time loop, source and inputs as they are: 5 digits.  (`tools/convergence_distributed.py
+    oracle 5000 256` gives the second row too, in 2 minutes; all four rows, up to 1024 x 256, are checked on the device path in
+    tests/test_gpu_timestep.py.)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "tools"))
+    import convergence_distributed as cd
+    ref = {int(r[0]): r[1:] for r in np.loadtxt(os.path.join(GOLD, "convergence_distributed_reference.dat"))}
+    got = cd.table("oracle", 5000, 128)
+    for nx in (64,):
+        for a, b in zip(got[nx], ref[nx]):
+            assert abs(a - b) <= 6e-5 * abs(b), (nx, a, b)
