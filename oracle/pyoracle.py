@@ -96,6 +96,7 @@ def lib():
         L.or_model_field.argtypes = [C.c_void_p, C.c_int]
         L.or_model_timestep.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.or_model_step_index.argtypes = [C.c_void_p]
+        L.or_model_set_ramp.argtypes = [C.c_void_p, C.c_double]
         L.or_time_varying_recharge.argtypes = [C.c_int, dp, C.c_double, C.c_double, dp]
         L.or_amr_model_create.restype = C.c_void_p
         L.or_amr_model_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(OrBC), C.POINTER(OrPhys),

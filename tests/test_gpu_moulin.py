@@ -107,3 +107,19 @@ def test_time_varying_recharge_and_timestep_bitwise(oracle):
             assert np.array_equal(np.array(O.field(fid))[1:-1, 1:-1], G.get(nm)), (k, nm)
     O.close()
     G.close()
+
+
+def test_moulin_source_pinned_by_the_channelized_convergence_table():
+    """the RHS_moulin column of exec/0_convergence_channelized/CONV_ANA/results/convergence_data_singleLevel.dat through the
+    device kernels: six rows, 5 digits (see tests/test_oracle_timeloop.py for what the column is)"""
+    import os, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "..", "tools"))
+    import convergence_channelized as cc
+    ref = {int(float(r[0])): r[5] for r in np.loadtxt(os.path.join(here, "golden", "convergence_channelized_singleLevel_reference.dat"))}
+    got = cc.moulin_table("hip", 7)
+    for nx in ref:
+        # the last two rows are differences at the 1e-10 / 1e-12 level of a term of order 5: there the device exp (1e-14
+        # relative to the CPU library's) shows in the fourth / second digit; the oracle matches all six rows to five
+        tol = 6e-5 if nx <= 256 else (1e-3 if nx == 512 else 5e-2)
+        assert abs(got[nx] - ref[nx]) <= tol * ref[nx], (nx, got[nx], ref[nx])

@@ -109,3 +109,18 @@ def test_oracle_reproduces_the_distributed_convergence_table():
     for nx in (64,):
         for a, b in zip(got[nx], ref[nx]):
             assert abs(a - b) <= 6e-5 * abs(b), (nx, a, b)
+
+
+def test_oracle_moulin_source_pinned_by_the_channelized_convergence_table():
+    """exec/0_convergence_channelized/CONV_ANA/results/convergence_data_singleLevel.dat, column RHS_moulin: L2 differences of the
+    moulin source term (one moulin of 30 m3/s, sigma 1 m, on 64 m x 16 m) between 32 x 8 ... 2048 x 512 -- all six rows to the 5
+    digits the reference prints.  (The other columns of that table come from runs whose head is converged only to the Picard
+    tolerance and do not reproduce: gap height within 1 %, head within a factor 2.5; tools/convergence_channelized.py.)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "tools"))
+    import convergence_channelized as cc
+    ref = {int(float(r[0])): r[5] for r in np.loadtxt(os.path.join(GOLD, "convergence_channelized_singleLevel_reference.dat"))}
+    got = cc.moulin_table("oracle", 7)
+    assert sorted(got) == sorted(ref)
+    for nx in ref:
+        assert abs(got[nx] - ref[nx]) <= 6e-5 * ref[nx], (nx, got[nx], ref[nx])
