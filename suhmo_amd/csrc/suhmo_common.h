@@ -156,6 +156,9 @@ struct suhmo_level {
     int fused_nt;               // threads per workgroup of the fused kernel: 256 or 64 (env SUHMO_FUSED_NT)
     int fused_restrict;         // the last pre-smoothing launch also restricts (env SUHMO_FUSED_RESTRICT, default 1)
     int fused_hc;               // rows per chunk of the fused kernel (0 = auto); env SUHMO_FUSED_HC
+    long tile_max_cells;        // auto mode: levels below this many cells relax on the tile kernel (env SUHMO_TILE_MAX_CELLS)
+    int gsrb_tile, tile_t, tile_s;      // cache-resident depths: S sweeps per launch on LDS tiles (env SUHMO_GSRB_TILE, default 1); tile edge 16 / 32
+                                // (env SUHMO_TILE_T, 0 = by size)
 };
 
 void suhmo_set_error(const char *fmt, ...);

@@ -351,6 +351,235 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st)
     return 0;
 }
 
+// ---- variant 3: S sweeps of a T x T tile in LDS (cache-resident depths) ----
+// Depths of up to about a million cells are latency-bound: a colour pass is one launch of ~5 us whatever its size (the
+// dependent launch, the first touch of data the previous kernel wrote on another XCD), so a smoothing of 4 sweeps costs 8 of
+// them.  Here a workgroup loads its tile plus a halo of 2S cells into LDS, keeps the coefficients of its cells in registers
+// and runs all 2S colour passes between barriers; pass p is valid one cell further in from the halo's edge than pass p-1
+// (sides that are physical boundaries do not shrink: the boundary condition is evaluated on the fly there), so after 2S
+// passes exactly the tile is current.  Every update is the expression of k_gsrb_pass_simple on the same operands: the result
+// is bitwise the same, the halo work is redundant.  Output goes to the second phi canvas (neighbour tiles read the old one).
+struct TileGeom {
+    int ntx, nty;
+    const double *pc, *pco; int Pc, gyc;     // prolongIncrement fused into the load (as in FusedGeom)
+    double *rres, *rphi; int rP, rgy;        // RST: coarse RES / PHI canvases
+};
+struct PairCoef { double rhs0, rhs1, B0, B1, Pi0, Pi1, zb0, zb1, mk0, mk1, a0, a1, byS0, byS1, byN0, byN1, bx0, bx1, bx2; };
+
+// RST = true: the launch also restricts (as k_gsrb_fused<.., RST>): one more ring of final values around the tile (two columns,
+// pairs stay aligned), the residual quarters of the tile's cells go through LDS and one thread per coarse cell adds the four in
+// the reference's visiting order (RESTRICTRESVCNL2D + RESTRICTVCNL).  The 32-wide tile is 28 rows high then: the same number
+// of column pairs per thread, hence the same registers, as without the restriction.
+template <int T, bool RST> struct TileShape { static constexpr int TX = T, TY = (RST && T == 32) ? 28 : T; };
+
+template <int S, int T, bool HAS_ALPHA, bool RST = false>
+__global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__restrict__ pin, double *__restrict__ pout,
+                                                   suhmo_phys_t ph, TileGeom g)
+{
+    constexpr int TX = TileShape<T, RST>::TX, TY = TileShape<T, RST>::TY;
+    constexpr int HX = 2 * S + (RST ? 2 : 0), HY = 2 * S + (RST ? 1 : 0);
+    constexpr int LX = TX + 2 * HX, LY = TY + 2 * HY, NP = LX / 2, NPAIR = NP * LY, NK = (NPAIR + 255) / 256;
+    __shared__ double lds[LY * LX];
+    __shared__ double lq[RST ? TY * TX : 1];                  // RST: (rhs - L(phi)) / 4 of the tile's cells
+    const int tx = blockIdx.x % g.ntx, ty = blockIdx.x / g.ntx;
+    const int gx0 = tx * TX - HX, gy0 = ty * TY - HY;         // domain cell of LDS cell (0, 0)
+    const int t = threadIdx.x;
+    // sides of the LDS region that reach a physical boundary: nothing beyond them feeds the tile
+    const bool openW = !v.per[0] && gx0 <= 0, openE = !v.per[0] && gx0 + LX - 1 >= v.nx - 1;
+    const bool openS = !v.per[1] && gy0 <= 0, openN = !v.per[1] && gy0 + LY - 1 >= v.ny - 1;
+    auto wrap = [](int i, int n) { i %= n; return i < 0 ? i + n : i; };
+    auto ld2 = [&](const double *__restrict__ p, int idx) { return *reinterpret_cast<const double2 *>(p + idx); };
+
+    // coefficients of the thread's pairs as NAMED variables (an array ends up in scratch memory)
+    PairCoef cf0, cf1, cf2, cf3, cf4;
+    bool lv0, lv1, lv2, lv3, lv4;                             // the pair lies in the domain (or is a periodic image of one that does)
+    static_assert(NK <= 5 && TX * TY / 4 <= 256, "tile too large for 256 threads");
+#define TILE_EACH(F) { F(0, cf0, lv0); if constexpr (NK > 1) F(1, cf1, lv1); if constexpr (NK > 2) F(2, cf2, lv2); \
+                       if constexpr (NK > 3) F(3, cf3, lv3); if constexpr (NK > 4) F(4, cf4, lv4); }
+    auto load = [&](const int k, PairCoef &c, bool &live) {
+        const int q = t + 256 * k;
+        live = false;
+        if (q < NPAIR) {
+            const int ly = q / NP, lx = 2 * (q % NP);
+            int i = gx0 + lx, j = gy0 + ly;
+            const bool exi = v.per[0] || (i >= 0 && i < v.nx), exj = v.per[1] || (j >= 0 && j < v.ny);
+            double2 p2 = make_double2(0.0, 0.0);
+            if (exi && exj) {
+                live = true;
+                if (v.per[0]) i = wrap(i, v.nx);
+                if (v.per[1]) j = wrap(j, v.ny);
+                const int idx = cidx(v, i, j);
+                p2 = ld2(pin, idx);
+                if (g.pc) {
+                    const int ic = ((j >> 1) + g.gyc) * g.Pc + SUHMO_XOFF + (i >> 1);
+                    const double corr = 1.0 * g.pc[ic] + (-1.0) * g.pco[ic];      // axby(1, -1), then PROLONGNL
+                    p2.x = p2.x + corr; p2.y = p2.y + corr;
+                }
+                double2 d;
+                d = ld2(fp.f[SUHMO_F_RHS], idx); c.rhs0 = d.x; c.rhs1 = d.y;
+                d = ld2(fp.f[SUHMO_F_B], idx); c.B0 = d.x; c.B1 = d.y;
+                d = ld2(fp.f[SUHMO_F_PI], idx); c.Pi0 = d.x; c.Pi1 = d.y;
+                d = ld2(fp.f[SUHMO_F_ZB], idx); c.zb0 = d.x; c.zb1 = d.y;
+                d = ld2(fp.f[SUHMO_F_MASK], idx); c.mk0 = d.x; c.mk1 = d.y;
+                if (HAS_ALPHA) { d = ld2(fp.f[SUHMO_F_ACOEF], idx); c.a0 = d.x; c.a1 = d.y; }
+                d = ld2(fp.f[SUHMO_F_BY], idx); c.byS0 = d.x; c.byS1 = d.y;
+                d = ld2(fp.f[SUHMO_F_BY], idx + v.P); c.byN0 = d.x; c.byN1 = d.y;
+                d = ld2(fp.f[SUHMO_F_BX], idx); c.bx0 = d.x; c.bx1 = d.y; c.bx2 = fp.f[SUHMO_F_BX][idx + 2];
+            }
+            lds[ly * LX + lx] = p2.x; lds[ly * LX + lx + 1] = p2.y;
+        }
+    };
+    TILE_EACH(load);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int p = 0; p < 2 * S; p++) {
+        const int xlo = openW ? 0 : p + 1, xhi = openE ? LX - 1 : LX - 2 - p;
+        const int ylo = openS ? 0 : p + 1, yhi = openN ? LY - 1 : LY - 2 - p;
+        auto relax = [&](const int k, const PairCoef &q_, const bool live) {
+            const int q = t + 256 * k;
+            if (q < NPAIR && live) {
+                const int ly = q / NP, lx = 2 * (q % NP);
+                const int j = gy0 + ly;
+                const int a = (j + v.j0 + p) & 1;             // which cell of the pair has this pass's colour
+                const int x = lx + a, i = gx0 + x;
+                if (x >= xlo && x <= xhi && ly >= ylo && ly <= yhi) {
+                    const double *row = lds + ly * LX;
+                    double c = row[x];
+                    double w = row[x > 0 ? x - 1 : 0], e = row[x < LX - 1 ? x + 1 : LX - 1];
+                    double s = lds[(ly > 0 ? ly - 1 : 0) * LX + x], n = lds[(ly < LY - 1 ? ly + 1 : LY - 1) * LX + x];
+                    if (!v.per[0]) {                          // mixBCValues on the fly
+                        if (i == 0) w = (v.bct[0][0] == 0) ? v.two_v[0][0] - c : c + v.neu[0][0];
+                        if (i == v.nx - 1) e = (v.bct[0][1] == 0) ? v.two_v[0][1] - c : c + v.neu[0][1];
+                    }
+                    if (!v.per[1]) {
+                        if (j == 0) s = (v.bct[1][0] == 0) ? v.two_v[1][0] - c : c + v.neu[1][0];
+                        if (j == v.ny - 1) n = (v.bct[1][1] == 0) ? v.two_v[1][1] - c : c + v.neu[1][1];
+                    }
+                    double nl, dnl;
+                    nl_terms(ph, c, a ? q_.B1 : q_.B0, a ? q_.Pi1 : q_.Pi0, a ? q_.zb1 : q_.zb0, a ? q_.mk1 : q_.mk0, nl, dnl);
+                    const double bxW = a ? q_.bx1 : q_.bx0, bxE = a ? q_.bx2 : q_.bx1;
+                    const double byN = a ? q_.byN1 : q_.byN0, byS = a ? q_.byS1 : q_.byS0;
+                    double aterm = HAS_ALPHA ? v.alpha * (a ? q_.a1 : q_.a0) : v.alpha;
+                    double lofphi = lofphi_cell(v, aterm, c, e, w, n, s, bxE, bxW, byN, byS, nl);
+                    double lam = lambda_cell(v, aterm, bxE, bxW, byN, byS);
+                    double denom = 1.0e-16 + lam + dnl;
+                    lds[ly * LX + x] = c + ((a ? q_.rhs1 : q_.rhs0) - lofphi) / denom;
+                }
+            }
+        };
+        TILE_EACH(relax);
+        __syncthreads();
+    }
+
+    auto store = [&](const int k, const PairCoef &q_, const bool) {
+        const int q = t + 256 * k;
+        if (q < NPAIR) {
+            const int ly = q / NP, lx = 2 * (q % NP);
+            const int i = gx0 + lx, j = gy0 + ly;
+            if (lx >= HX && lx < HX + TX && ly >= HY && ly < HY + TY && i < v.nx && j < v.ny) {
+                *reinterpret_cast<double2 *>(pout + cidx(v, i, j)) = make_double2(lds[ly * LX + lx], lds[ly * LX + lx + 1]);
+                if constexpr (RST) {
+                    const double *row = lds + ly * LX;
+#pragma unroll
+                    for (int a = 0; a < 2; a++) {
+                        const int x = lx + a, ii = i + a;
+                        double c = row[x], w = row[x - 1], e = row[x + 1];          // the tile never touches the edge of the LDS region
+                        double s_ = lds[(ly - 1) * LX + x], n = lds[(ly + 1) * LX + x];
+                        if (!v.per[0]) {
+                            if (ii == 0) w = (v.bct[0][0] == 0) ? v.two_v[0][0] - c : c + v.neu[0][0];
+                            if (ii == v.nx - 1) e = (v.bct[0][1] == 0) ? v.two_v[0][1] - c : c + v.neu[0][1];
+                        }
+                        if (!v.per[1]) {
+                            if (j == 0) s_ = (v.bct[1][0] == 0) ? v.two_v[1][0] - c : c + v.neu[1][0];
+                            if (j == v.ny - 1) n = (v.bct[1][1] == 0) ? v.two_v[1][1] - c : c + v.neu[1][1];
+                        }
+                        double nl, dnl;
+                        nl_terms(ph, c, a ? q_.B1 : q_.B0, a ? q_.Pi1 : q_.Pi0, a ? q_.zb1 : q_.zb0, a ? q_.mk1 : q_.mk0, nl, dnl);
+                        const double bxW = a ? q_.bx1 : q_.bx0, bxE = a ? q_.bx2 : q_.bx1;
+                        double aterm = HAS_ALPHA ? v.alpha * (a ? q_.a1 : q_.a0) : v.alpha;
+                        double lofphi = lofphi_cell(v, aterm, c, e, w, n, s_, bxE, bxW, a ? q_.byN1 : q_.byN0, a ? q_.byS1 : q_.byS0, nl);
+                        lq[(ly - HY) * TX + (lx - HX) + a] = ((a ? q_.rhs1 : q_.rhs0) - lofphi) / 4.0;
+                    }
+                }
+            }
+        }
+    };
+    TILE_EACH(store);
+#undef TILE_EACH
+    if constexpr (RST) {
+        __syncthreads();
+        if (t < TX * TY / 4) {
+            const int cx = t % (TX / 2), cy = t / (TX / 2);
+            const int i = tx * TX + 2 * cx, j = ty * TY + 2 * cy;
+            if (i < v.nx && j < v.ny) {
+                const double *q0 = lq + (2 * cy) * TX + 2 * cx, *p0 = lds + (HY + 2 * cy) * LX + HX + 2 * cx;
+                double acc = 0.0, accp = 0.0;
+                acc = acc + q0[0]; accp = accp + p0[0] / 4.0;
+                acc = acc + q0[1]; accp = accp + p0[1] / 4.0;
+                acc = acc + q0[TX]; accp = accp + p0[LX] / 4.0;
+                acc = acc + q0[TX + 1]; accp = accp + p0[LX + 1] / 4.0;
+                const int ic = ((j >> 1) + g.rgy) * g.rP + SUHMO_XOFF + (i >> 1);
+                g.rres[ic] = acc; g.rphi[ic] = accp;
+            }
+        }
+    }
+}
+
+static bool tile_ok(const suhmo_level *L, const Depth &D)
+{
+    const DV &v = D.v;
+    if (!L->gsrb_tile || (v.nx & 1)) return false;
+    if (v.cfx[0] || v.cfx[1] || v.ext[0] || v.ext[1] || L->desc.nx_global > 0) return false;   // stored ghosts / halo rows: colour passes
+    if (v.per[1] && (v.ny & 1)) return false;                 // colour of a periodic image = colour of the cell
+    return true;
+}
+
+template <int S, int T, bool RST = false>
+static int launch_tile(suhmo_level *L, int depth, hipStream_t st)
+{
+    Depth &D = L->d[depth];
+    const DV &v = D.v;
+    if (!D.phi_alt) {
+        HIPCHK(hipMalloc(&D.phi_alt, D.elems * sizeof(double)));
+        HIPCHK(hipMemsetAsync(D.phi_alt, 0, D.elems * sizeof(double), st));
+    }
+    TileGeom g;
+    constexpr int TX = TileShape<T, RST>::TX, TY = TileShape<T, RST>::TY;
+    g.ntx = (v.nx + TX - 1) / TX; g.nty = (v.ny + TY - 1) / TY;
+    g.pc = g.pco = nullptr; g.Pc = g.gyc = 0;
+    g.rres = g.rphi = nullptr; g.rP = g.rgy = 0;
+    if (RST) {
+        Depth &C = L->d[depth + 1];
+        g.rres = C.fp.f[SUHMO_F_RES]; g.rphi = C.fp.f[SUHMO_F_PHI]; g.rP = C.v.P; g.rgy = C.v.gy;
+        C.phi_fresh = 0;
+    }
+    if (D.prolong_pending) {
+        Depth &C = L->d[depth + 1];
+        g.pc = C.fp.f[SUHMO_F_PHI]; g.pco = C.fp.f[SUHMO_F_PHIOLD]; g.Pc = C.v.P; g.gyc = C.v.gy;
+        D.prolong_pending = 0;
+    }
+    const double *pin = D.fp.f[SUHMO_F_PHI];
+    if (v.alpha != 0.0)
+        hipLaunchKernelGGL((k_gsrb_tile<S, T, true, RST>), dim3(g.ntx * g.nty), dim3(256), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+    else
+        hipLaunchKernelGGL((k_gsrb_tile<S, T, false, RST>), dim3(g.ntx * g.nty), dim3(256), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+    std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
+    return 0;
+}
+static int launch_tile_any(suhmo_level *L, int depth, int S, bool rst, hipStream_t st)
+{
+    const DV &v = L->d[depth].v;
+    int T = L->tile_t;
+    if (!T) T = ((long)v.nx * v.ny >= 200000L) ? 32 : 16;     // enough workgroups for the chip on the smaller depths
+    if (rst) {
+        if (T == 32) return S == 4 ? launch_tile<4, 32, true>(L, depth, st) : S == 2 ? launch_tile<2, 32, true>(L, depth, st) : launch_tile<1, 32, true>(L, depth, st);
+        return S == 4 ? launch_tile<4, 16, true>(L, depth, st) : S == 2 ? launch_tile<2, 16, true>(L, depth, st) : launch_tile<1, 16, true>(L, depth, st);
+    }
+    if (T == 32) return S == 4 ? launch_tile<4, 32>(L, depth, st) : S == 2 ? launch_tile<2, 32>(L, depth, st) : launch_tile<1, 32>(L, depth, st);
+    return S == 4 ? launch_tile<4, 16>(L, depth, st) : S == 2 ? launch_tile<2, 16>(L, depth, st) : launch_tile<1, 16>(L, depth, st);
+}
+
 static int pick_variant(const suhmo_level *L, const Depth &D)
 {
     int variant = L->gsrb_variant;       // -1 auto, 0 simple, 1 fused K=1, 2 fused K=2
@@ -358,7 +587,11 @@ static int pick_variant(const suhmo_level *L, const Depth &D)
         // the streaming kernel pays ~(Hc + 4K) serial row steps per workgroup: below ~2M cells
         // (cache-resident depths) two plain colour-pass launches are faster
         // (profiles/r01_c_vcycle_trace.txt)
-        variant = ((long)D.v.nx * D.v.ny >= (long)L->fused_min_cells) ? 2 : 0;
+        const long cells = (long)D.v.nx * D.v.ny;
+        variant = (cells >= (long)L->fused_min_cells) ? 2 : 0;
+        // whole levels of up to a few million cells: 4 sweeps per launch on LDS tiles beat 2 per streaming pass
+        // (profiles/r01_s_tile_vs_streaming.txt: 2048^2 47.5 vs 56.8 us per sweep, 4096^2 175 vs 146)
+        if (tile_ok(L, D) && cells < L->tile_max_cells) variant = 0;
     }
     return variant;
 }
@@ -381,7 +614,7 @@ bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps)
     Depth &D = L->d[depth];
     if (sweeps < 1 || depth + 1 >= L->ndepth) return false;
     int K = pick_K(L, D, pick_variant(L, D), sweeps);
-    if (K <= 0) return false;
+    if (K <= 0) return tile_ok(L, D);
     const bool ext = L->ex && (D.v.ext[0] || D.v.ext[1]);
     if ((D.v.ext[0] || D.v.ext[1]) && !ext) return false;                 // stored ghost rows without a transport (AMR patch)
     return !ext || prolong_halo_rows(L, depth) >= 2 * K;                  // else: un-fused prolongation, then an exchange
@@ -409,14 +642,19 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
     int it = 0;
     while (it < sweeps) {
         int K = pick_K(L, D, variant, sweeps - it);   // sweeps done by the next launch (0 = simple path, 1 sweep)
-        if (K == 0 && D.prolong_pending) { suhmo_set_error("internal: prolong_pending without a fused relax"); return -4; }
+        const int TS = (K == 0 && tile_ok(L, D)) ? (sweeps - it >= 4 && L->tile_s >= 4 ? 4 : sweeps - it >= 2 && L->tile_s >= 2 ? 2 : 1) : 0;   // sweeps of a tile launch
+        if (K == 0 && !TS && D.prolong_pending) { suhmo_set_error("internal: prolong_pending without a fused relax"); return -4; }
         ProfEv pe{};
         bool prof = L->prof_on && depth == 0;
         if (prof) {
             HIPCHK(hipEventCreate(&pe.a)); HIPCHK(hipEventCreate(&pe.b));
             HIPCHK(hipEventRecord(pe.a, st));
         }
-        if (K == 0) {
+        if (TS) {
+            const bool rst = restricted && L->fused_restrict && depth + 1 < L->ndepth && !(D.v.ny & 1) && it + TS == sweeps;
+            int rc = launch_tile_any(L, depth, TS, rst, st); if (rc) return rc;
+            if (rst) *restricted = 1;
+        } else if (K == 0) {
             for (int pass = 0; pass < 2; pass++) {
                 if (ext && F < 1) {
                     int rc = suhmo_ensure_phi_halo(L, depth, 1, st); if (rc) return rc;
@@ -454,7 +692,7 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
             if (rc) return rc;
             if (ext) { F = E; D.phi_fresh = F; }
         }
-        int done = K == 0 ? 1 : K;
+        int done = TS ? TS : K == 0 ? 1 : K;
         if (prof) {
             HIPCHK(hipEventRecord(pe.b, st));
             pe.cells = (long)D.v.nx * D.v.ny * done;

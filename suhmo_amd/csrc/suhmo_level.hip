@@ -97,6 +97,12 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     L->fused_nt = 64;                        // one wave per workgroup: 316 vs 308 V-cycles/s at 4096^2 (profiles/r01_i_nt_ab.txt)
     if (const char *e = getenv("SUHMO_FUSED_NT")) L->fused_nt = atoi(e);
     L->fused_restrict = 1;
+    L->gsrb_tile = 1; L->tile_t = 0; L->tile_s = 4;
+    L->tile_max_cells = 8000000;
+    if (const char *e = getenv("SUHMO_TILE_MAX_CELLS")) L->tile_max_cells = atol(e);
+    if (const char *e = getenv("SUHMO_TILE_S")) L->tile_s = atoi(e);        // most sweeps per tile launch (4, 2, 1)
+    if (const char *e = getenv("SUHMO_GSRB_TILE")) L->gsrb_tile = atoi(e);
+    if (const char *e = getenv("SUHMO_TILE_T")) { L->tile_t = atoi(e); if (L->tile_t != 16 && L->tile_t != 32) L->tile_t = 0; }
     if (const char *e = getenv("SUHMO_FUSED_RESTRICT")) L->fused_restrict = atoi(e);
     L->graph_max_cells = 1500000; L->gstream = nullptr; memset(L->vgraph_seen, 0, sizeof(L->vgraph_seen));
     if (const char *e = getenv("SUHMO_GRAPH_MAX_CELLS")) L->graph_max_cells = atol(e);

@@ -101,6 +101,7 @@ def test_gsrb_fused_variants(oracle, hip, case, variant, hc, sweeps, monkeypatch
     """every relaxation kernel variant (two-pass, fused red+black, two sweeps fused; several
     chunk heights = many workgroup seams) gives the oracle's phi bit for bit"""
     monkeypatch.setenv("SUHMO_GSRB_VARIANT", str(variant))
+    monkeypatch.setenv("SUHMO_GSRB_TILE", "0")
     monkeypatch.setenv("SUHMO_FUSED_HC", str(hc))
     f, O, G = prep(oracle, hip, case)
     O.gsrb(sweeps); G.gsrb(sweeps)
@@ -230,6 +231,7 @@ def test_vcycle_on_fused_kernels(oracle, hip, case, fused_restrict, hc, monkeypa
     ends the pre-smoothing and with the separate restriction kernel: both bitwise equal to the oracle's V-cycle; chunk
     heights 6 / 10 / automatic move the coarse cells' row pairs relative to the chunk boundaries"""
     monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "1")
+    monkeypatch.setenv("SUHMO_GSRB_TILE", "0")
     monkeypatch.setenv("SUHMO_FUSED_RESTRICT", str(fused_restrict))
     monkeypatch.setenv("SUHMO_FUSED_HC", str(hc))
     _, mk, bc, ph, alpha, beta, mb = case
@@ -246,6 +248,63 @@ def test_vcycle_on_fused_kernels(oracle, hip, case, fused_restrict, hc, monkeypa
     no, ho = O.solve(sp)
     ng, hg = G.solve(sp)
     assert ng == no and np.array_equal(hg, ho)
+
+
+TILE_CASES = CASES + FUSED_VCYCLE_CASES[1:] + [
+    ("tiny-mixedbc", lambda: sy.random_fields(8, 6, seed=31), sy.RANDOM_BC, sy.RANDOM_PHYS, 0.0, -1.0, 8),
+    ("odd-rows-70x51", lambda: sy.random_fields(70, 51, seed=32), sy.RANDOM_BC, sy.RANDOM_PHYS, 0.0, -1.0, 64),
+    ("allperiodic-smaller-than-halo", lambda: sy.random_fields(12, 10, seed=33),
+     dict(type=[[0, 0], [0, 0]], value=[[0, 0], [0, 0]], periodic=[1, 1]), sy.RANDOM_PHYS, 0.3, -1.0, 4),
+    ("yperiodic-33-tiles", lambda: sy.random_fields(66, 36, seed=34), sy.CONV_BC, sy.RANDOM_PHYS, 0.0, -1.0, 64),
+]
+
+
+@pytest.mark.parametrize("case", TILE_CASES, ids=[c[0] for c in TILE_CASES])
+@pytest.mark.parametrize("tile_t", [16, 32])
+def test_gsrb_tile_kernel(oracle, hip, case, tile_t, monkeypatch):
+    """cache-resident depths: S = 4 / 2 / 1 sweeps per launch on LDS tiles with a 2S halo (k_gsrb_tile), tile edge 16 and
+    32: bitwise the colour passes, for every sweep count's decomposition, domains that are not a multiple of the tile,
+    odd row counts, periodic domains smaller than tile + halo (the halo then holds several images of a cell)"""
+    monkeypatch.setenv("SUHMO_GSRB_TILE", "1")
+    monkeypatch.setenv("SUHMO_TILE_T", str(tile_t))
+    monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "100000000")
+    for sweeps in (1, 2, 3, 4, 7):
+        f, O, G = prep(oracle, hip, case)
+        O.gsrb(sweeps); G.gsrb(sweeps)
+        assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI)), sweeps
+        go, gg = O.get(oracle.F_PHI, ghosted=True), G.get(hip.F_PHI, ghosted=True)
+        if not case[2]["periodic"][0]:
+            assert np.array_equal(gg[1:-1, 0], go[1:-1, 0]) and np.array_equal(gg[1:-1, -1], go[1:-1, -1])
+        if not case[2]["periodic"][1]:
+            assert np.array_equal(gg[0, 1:-1], go[0, 1:-1]) and np.array_equal(gg[-1, 1:-1], go[-1, 1:-1])
+
+
+@pytest.mark.parametrize("case", FUSED_VCYCLE_CASES + SOLVE_CASES, ids=[c[0] for c in FUSED_VCYCLE_CASES + SOLVE_CASES])
+@pytest.mark.parametrize("tile,fused_restrict,tile_t", [(1, 1, 0), (1, 1, 32), (1, 1, 16), (1, 0, 0), (0, 1, 0)],
+                         ids=["tile+restrict", "tile32+restrict", "tile16+restrict", "tile", "colour-passes"])
+def test_vcycle_on_tile_kernels(oracle, hip, case, tile, fused_restrict, tile_t, monkeypatch):
+    """V-cycles and a solve with every depth on the tile kernel (prolongation fused into its load, restriction into the
+    launch that ends the pre-smoothing or as a separate kernel) and with the tile kernel off (colour passes): all bitwise
+    the oracle's"""
+    monkeypatch.setenv("SUHMO_GSRB_TILE", str(tile))
+    monkeypatch.setenv("SUHMO_FUSED_RESTRICT", str(fused_restrict))
+    monkeypatch.setenv("SUHMO_TILE_T", str(tile_t))
+    monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "100000000")
+    _, mk, bc, ph, alpha, beta, mb = case
+    f = mk()
+    f.pop("bx", None); f.pop("by", None)
+    O, G = pair(oracle, hip, f, bc, ph, alpha, beta, mb)
+    O.build_mg_coefficients(); G.build_mg_coefficients()
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-10, norm_thresh=1e-13, max_iter=3, imin=6)
+    for k in range(3):                                                   # the third cycle is the replayed HIP graph
+        O.vcycle(sp); G.vcycle(sp)
+        assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI)), (k, float(np.max(np.abs(G.get(hip.F_PHI) - O.get(oracle.F_PHI)))))
+    for d in range(1, G.ndepth):
+        assert np.array_equal(G.get(hip.F_RES, depth=d), O.get(oracle.F_RES, depth=d)), ("coarse residual", d)
+    no, ho = O.solve(sp)
+    ng, hg = G.solve(sp)
+    assert ng == no and np.array_equal(hg, ho)
+    assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI))
 
 
 def test_full_size_properties(hip):
