@@ -384,9 +384,12 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
     const int tx = blockIdx.x % g.ntx, ty = blockIdx.x / g.ntx;
     const int gx0 = tx * TX - HX, gy0 = ty * TY - HY;         // domain cell of LDS cell (0, 0)
     const int t = threadIdx.x;
+    // a coarse-fine side takes precedence over the domain's periodicity (the patch does not wrap onto itself)
+    const bool perx = v.per[0] && !v.cfx[0] && !v.cfx[1], pery = v.per[1] && !v.ext[0] && !v.ext[1];
     // sides of the LDS region that reach a physical boundary: nothing beyond them feeds the tile
-    const bool openW = !v.per[0] && gx0 <= 0, openE = !v.per[0] && gx0 + LX - 1 >= v.nx - 1;
-    const bool openS = !v.per[1] && gy0 <= 0, openN = !v.per[1] && gy0 + LY - 1 >= v.ny - 1;
+    // (a coarse-fine side of an AMR patch: once the stored ghost column / row is in the region)
+    const bool openW = !perx && gx0 <= (v.cfx[0] ? -1 : 0), openE = !perx && gx0 + LX - 1 >= v.nx - 1 + (v.cfx[1] ? 1 : 0);
+    const bool openS = !pery && gy0 <= (v.ext[0] ? -1 : 0), openN = !pery && gy0 + LY - 1 >= v.ny - 1 + (v.ext[1] ? 1 : 0);
     auto wrap = [](int i, int n) { i %= n; return i < 0 ? i + n : i; };
     auto ld2 = [&](const double *__restrict__ p, int idx) { return *reinterpret_cast<const double2 *>(p + idx); };
 
@@ -402,14 +405,20 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
         if (q < NPAIR) {
             const int ly = q / NP, lx = 2 * (q % NP);
             int i = gx0 + lx, j = gy0 + ly;
-            const bool exi = v.per[0] || (i >= 0 && i < v.nx), exj = v.per[1] || (j >= 0 && j < v.ny);
+            const bool inx = perx || (i >= 0 && i < v.nx), iny = pery || (j >= 0 && j < v.ny);
+            // AMR patch: the ghost column / row beyond a coarse-fine side holds interpolated data: loaded, never advanced
+            const bool exi = inx || (i == -2 && v.cfx[0]) || (i == v.nx && v.cfx[1]);
+            const bool exj = iny || (j == -1 && v.ext[0]) || (j == v.ny && v.ext[1]);
             double2 p2 = make_double2(0.0, 0.0);
             if (exi && exj) {
-                live = true;
-                if (v.per[0]) i = wrap(i, v.nx);
-                if (v.per[1]) j = wrap(j, v.ny);
+                live = inx && iny;
+                if (perx) i = wrap(i, v.nx);
+                if (pery) j = wrap(j, v.ny);
                 const int idx = cidx(v, i, j);
                 p2 = ld2(pin, idx);
+            }
+            if (live) {
+                const int idx = cidx(v, i, j);
                 if (g.pc) {
                     const int ic = ((j >> 1) + g.gyc) * g.Pc + SUHMO_XOFF + (i >> 1);
                     const double corr = 1.0 * g.pc[ic] + (-1.0) * g.pco[ic];      // axby(1, -1), then PROLONGNL
@@ -448,13 +457,13 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
                     double c = row[x];
                     double w = row[x > 0 ? x - 1 : 0], e = row[x < LX - 1 ? x + 1 : LX - 1];
                     double s = lds[(ly > 0 ? ly - 1 : 0) * LX + x], n = lds[(ly < LY - 1 ? ly + 1 : LY - 1) * LX + x];
-                    if (!v.per[0]) {                          // mixBCValues on the fly
-                        if (i == 0) w = (v.bct[0][0] == 0) ? v.two_v[0][0] - c : c + v.neu[0][0];
-                        if (i == v.nx - 1) e = (v.bct[0][1] == 0) ? v.two_v[0][1] - c : c + v.neu[0][1];
+                    if (!perx) {                          // mixBCValues on the fly
+                        if (i == 0 && !v.cfx[0]) w = (v.bct[0][0] == 0) ? v.two_v[0][0] - c : c + v.neu[0][0];
+                        if (i == v.nx - 1 && !v.cfx[1]) e = (v.bct[0][1] == 0) ? v.two_v[0][1] - c : c + v.neu[0][1];
                     }
-                    if (!v.per[1]) {
-                        if (j == 0) s = (v.bct[1][0] == 0) ? v.two_v[1][0] - c : c + v.neu[1][0];
-                        if (j == v.ny - 1) n = (v.bct[1][1] == 0) ? v.two_v[1][1] - c : c + v.neu[1][1];
+                    if (!pery) {
+                        if (j == 0 && !v.ext[0]) s = (v.bct[1][0] == 0) ? v.two_v[1][0] - c : c + v.neu[1][0];
+                        if (j == v.ny - 1 && !v.ext[1]) n = (v.bct[1][1] == 0) ? v.two_v[1][1] - c : c + v.neu[1][1];
                     }
                     double nl, dnl;
                     nl_terms(ph, c, a ? q_.B1 : q_.B0, a ? q_.Pi1 : q_.Pi0, a ? q_.zb1 : q_.zb0, a ? q_.mk1 : q_.mk0, nl, dnl);
@@ -472,13 +481,23 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
         __syncthreads();
     }
 
+    const int oi1 = (tx * TX + TX < v.nx) ? tx * TX + TX : v.nx, oj1 = (ty * TY + TY < v.ny) ? ty * TY + TY : v.ny;
+    const int wi0 = tx * TX - ((tx == 0 && v.cfx[0]) ? 1 : 0), wi1 = oi1 + ((oi1 == v.nx && v.cfx[1]) ? 1 : 0);
+    const int wj0 = ty * TY - ((ty == 0 && v.ext[0]) ? 1 : 0), wj1 = oj1 + ((oj1 == v.ny && v.ext[1]) ? 1 : 0);
     auto store = [&](const int k, const PairCoef &q_, const bool) {
         const int q = t + 256 * k;
         if (q < NPAIR) {
             const int ly = q / NP, lx = 2 * (q % NP);
             const int i = gx0 + lx, j = gy0 + ly;
+            // cells this tile writes: its own and, next to a coarse-fine side, the stored ghosts (the other canvas has to
+            // carry them too)
+            if (j >= wj0 && j < wj1) {
+                const bool m0 = i >= wi0 && i < wi1, m1 = i + 1 >= wi0 && i + 1 < wi1;
+                if (m0 && m1) *reinterpret_cast<double2 *>(pout + cidx(v, i, j)) = make_double2(lds[ly * LX + lx], lds[ly * LX + lx + 1]);
+                else if (m0) pout[cidx(v, i, j)] = lds[ly * LX + lx];
+                else if (m1) pout[cidx(v, i + 1, j)] = lds[ly * LX + lx + 1];
+            }
             if (lx >= HX && lx < HX + TX && ly >= HY && ly < HY + TY && i < v.nx && j < v.ny) {
-                *reinterpret_cast<double2 *>(pout + cidx(v, i, j)) = make_double2(lds[ly * LX + lx], lds[ly * LX + lx + 1]);
                 if constexpr (RST) {
                     const double *row = lds + ly * LX;
 #pragma unroll
@@ -486,13 +505,13 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
                         const int x = lx + a, ii = i + a;
                         double c = row[x], w = row[x - 1], e = row[x + 1];          // the tile never touches the edge of the LDS region
                         double s_ = lds[(ly - 1) * LX + x], n = lds[(ly + 1) * LX + x];
-                        if (!v.per[0]) {
-                            if (ii == 0) w = (v.bct[0][0] == 0) ? v.two_v[0][0] - c : c + v.neu[0][0];
-                            if (ii == v.nx - 1) e = (v.bct[0][1] == 0) ? v.two_v[0][1] - c : c + v.neu[0][1];
+                        if (!perx) {
+                            if (ii == 0 && !v.cfx[0]) w = (v.bct[0][0] == 0) ? v.two_v[0][0] - c : c + v.neu[0][0];
+                            if (ii == v.nx - 1 && !v.cfx[1]) e = (v.bct[0][1] == 0) ? v.two_v[0][1] - c : c + v.neu[0][1];
                         }
-                        if (!v.per[1]) {
-                            if (j == 0) s_ = (v.bct[1][0] == 0) ? v.two_v[1][0] - c : c + v.neu[1][0];
-                            if (j == v.ny - 1) n = (v.bct[1][1] == 0) ? v.two_v[1][1] - c : c + v.neu[1][1];
+                        if (!pery) {
+                            if (j == 0 && !v.ext[0]) s_ = (v.bct[1][0] == 0) ? v.two_v[1][0] - c : c + v.neu[1][0];
+                            if (j == v.ny - 1 && !v.ext[1]) n = (v.bct[1][1] == 0) ? v.two_v[1][1] - c : c + v.neu[1][1];
                         }
                         double nl, dnl;
                         nl_terms(ph, c, a ? q_.B1 : q_.B0, a ? q_.Pi1 : q_.Pi0, a ? q_.zb1 : q_.zb0, a ? q_.mk1 : q_.mk0, nl, dnl);
@@ -530,8 +549,9 @@ static bool tile_ok(const suhmo_level *L, const Depth &D)
 {
     const DV &v = D.v;
     if (!L->gsrb_tile || (v.nx & 1)) return false;
-    if (v.cfx[0] || v.cfx[1] || v.ext[0] || v.ext[1] || L->desc.nx_global > 0) return false;   // stored ghosts / halo rows: colour passes
+    if (v.rk[0] || v.rk[1]) return false;                     // rank strips (halo rows advanced redundantly): colour passes / streaming kernel
     if (v.per[1] && (v.ny & 1)) return false;                 // colour of a periodic image = colour of the cell
+    if ((v.per[0] && v.cfx[0] != v.cfx[1]) || (v.per[1] && v.ext[0] != v.ext[1])) return false;   // patch on one side of a periodic domain
     return true;
 }
 

@@ -1181,19 +1181,55 @@ int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st)
 
 // MGnewOp coefficient coarsening: CoarseAverage (arithmetic) of aCoef, B, Pi, zb, iceMask from
 // depth 0 with ratio r: sequential sum (ii fastest) * 1/r^2 (src/VCAMRNonLinearPoissonOp.cpp:1116-1138)
-__global__ void k_average_cells(DV vf, const double *__restrict__ f, DV vc, double *__restrict__ c, int r)
+// The five coefficient fields of one depth in one launch (blockIdx.z = field).  The sum of a coarse cell is one
+// sequential chain of r*r additions whatever the kernel does, so at the deep depths (few coarse cells, r = 16, 32) the time is
+// the chain plus the latency of its loads: a row of the block is fetched as r/2 independent 16-byte loads, then added in order.
+struct AvgFields { const double *f[5]; double *c[5]; };
+template <int R>
+__global__ __launch_bounds__(256) void k_average_cells_all(DV vf, DV vc, AvgFields a, int r_)
 {
-    int ic = blockIdx.x * blockDim.x + threadIdx.x, jc = blockIdx.y * blockDim.y + threadIdx.y;
+    const int ic = blockIdx.x * blockDim.x + threadIdx.x, jc = blockIdx.y * blockDim.y + threadIdx.y, q = blockIdx.z;
     if (ic >= vc.nx || jc >= vc.ny) return;
+    const double *__restrict__ f = a.f[q];
+    const int r = R ? R : r_;
+    const int base = cidx(vf, ic * r, jc * r);
     double sm = 0.0;
-    int base = cidx(vf, ic * r, jc * r);
-    for (int jj = 0; jj < r; jj++)
-        for (int ii = 0; ii < r; ii++) sm = sm + f[base + jj * vf.P + ii];
-    c[cidx(vc, ic, jc)] = sm * (1.0 / (double)(r * r));
+    if constexpr (R >= 2) {
+        for (int jj = 0; jj < R; jj++) {
+            double2 row[R / 2];
+#pragma unroll
+            for (int k = 0; k < R / 2; k++) row[k] = *reinterpret_cast<const double2 *>(f + base + jj * vf.P + 2 * k);   // ic * r is even
+#pragma unroll
+            for (int k = 0; k < R / 2; k++) { sm = sm + row[k].x; sm = sm + row[k].y; }
+        }
+    } else {
+        for (int jj = 0; jj < r; jj++)
+            for (int ii = 0; ii < r; ii++) sm = sm + f[base + jj * vf.P + ii];
+    }
+    a.c[q][cidx(vc, ic, jc)] = sm * (1.0 / (double)(r * r));
 }
 // ghosts of coarse B / Pi / zb / mask: periodic wrap or Neumann copy (NeumBCForB :1309-1341)
 __global__ void k_coef_ghosts(DV v, double *__restrict__ p)
 {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 2 * v.ny) {
+        int side = t / v.ny, j = t % v.ny;
+        if (v.cfx[side]) return;
+        if (side == 0) { int idx = cidx(v, 0, j); p[idx - 1] = v.per[0] ? p[idx + v.nx - 1] : p[idx]; }
+        else { int idx = cidx(v, v.nx - 1, j); p[idx + 1] = v.per[0] ? p[idx - (v.nx - 1)] : p[idx]; }
+        return;
+    }
+    t -= 2 * v.ny;
+    if (t < 2 * v.nx) {
+        int side = t / v.nx, i = t % v.nx;
+        if (v.ext[side]) return;
+        if (side == 0) { int idx = cidx(v, i, 0); p[idx - v.P] = v.per[1] ? p[idx + (v.ny - 1) * v.P] : p[idx]; }
+        else { int idx = cidx(v, i, v.ny - 1); p[idx + v.P] = v.per[1] ? p[idx - (v.ny - 1) * v.P] : p[idx]; }
+    }
+}
+__global__ void k_coef_ghosts_all(DV v, AvgFields a)        // fields 1..4 of AvgFields (B, Pi, zb, mask) in one launch
+{
+    double *__restrict__ p = a.c[1 + blockIdx.y];
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 2 * v.ny) {
         int side = t / v.ny, j = t % v.ny;
@@ -1230,12 +1266,21 @@ extern "C" int suhmo_level_build_mg_coefficients(suhmo_level_t *L, suhmo_stream_
     Depth &F = L->d[0];
     for (int dep = 1; dep < L->ndepth; dep++) {
         Depth &C = L->d[dep];
-        for (int q = 0; q < 5; q++) {
-            hipLaunchKernelGGL(k_average_cells, grid2d(C.v.nx, C.v.ny), BLK2D, 0, st, F.v, F.fp.f[fields[q]], C.v, C.fp.f[fields[q]], 1 << dep);
-            if (q > 0) {
-                int n = 2 * C.v.ny + 2 * C.v.nx;
-                hipLaunchKernelGGL(k_coef_ghosts, dim3((n + 255) / 256), dim3(256), 0, st, C.v, C.fp.f[fields[q]]);
-            }
+        AvgFields a;
+        for (int q = 0; q < 5; q++) { a.f[q] = F.fp.f[fields[q]]; a.c[q] = C.fp.f[fields[q]]; }
+        const int r = 1 << dep;
+        const dim3 blk(64, 4), grd((C.v.nx + 63) / 64, (C.v.ny + 3) / 4, 5);
+        switch (r) {
+        case 2: hipLaunchKernelGGL(k_average_cells_all<2>, grd, blk, 0, st, F.v, C.v, a, r); break;
+        case 4: hipLaunchKernelGGL(k_average_cells_all<4>, grd, blk, 0, st, F.v, C.v, a, r); break;
+        case 8: hipLaunchKernelGGL(k_average_cells_all<8>, grd, blk, 0, st, F.v, C.v, a, r); break;
+        case 16: hipLaunchKernelGGL(k_average_cells_all<16>, grd, blk, 0, st, F.v, C.v, a, r); break;
+        case 32: hipLaunchKernelGGL(k_average_cells_all<32>, grd, blk, 0, st, F.v, C.v, a, r); break;
+        default: hipLaunchKernelGGL(k_average_cells_all<0>, grd, blk, 0, st, F.v, C.v, a, r); break;
+        }
+        {
+            const int n = 2 * C.v.ny + 2 * C.v.nx;
+            hipLaunchKernelGGL(k_coef_ghosts_all, dim3((n + 255) / 256, 4), dim3(256), 0, st, C.v, a);
         }
         int rc = suhmo_level_average_operator(L, dep, s);
         if (rc) return rc;
