@@ -122,6 +122,7 @@ struct Depth {
     size_t elems;      // doubles per canvas
     int nbox;
     int prolong_pending; // the next fused relax adds P(phi_c - phi_c,old) while loading phi (FAS prolongIncrement)
+    int rhs_pending;     // the next tile relax forms the FAS right-hand side rhs = res + L(phi) while loading (and PHIOLD, LPHI)
     double *phi_alt;   // second phi canvas: the fused GSRB kernel writes out of place (ping-pong)
     int phi_fresh;     // strips: halo rows of phi (each rank-boundary side) that hold the neighbour's CURRENT values
 };
@@ -156,6 +157,7 @@ struct suhmo_level {
     int fused_nt;               // threads per workgroup of the fused kernel: 256 or 64 (env SUHMO_FUSED_NT)
     int fused_restrict;         // the last pre-smoothing launch also restricts (env SUHMO_FUSED_RESTRICT, default 1)
     int fused_hc;               // rows per chunk of the fused kernel (0 = auto); env SUHMO_FUSED_HC
+    int fas_rhs_in_relax;       // coarse FAS right-hand side formed by the first tile relax of the depth (env SUHMO_FAS_RHS_IN_RELAX, default 1)
     long tile_max_cells;        // auto mode: levels below this many cells relax on the tile kernel (env SUHMO_TILE_MAX_CELLS)
     int gsrb_tile, tile_t, tile_s;      // cache-resident depths: S sweeps per launch on LDS tiles (env SUHMO_GSRB_TILE, default 1); tile edge 16 / 32
                                 // (env SUHMO_TILE_T, 0 = by size)
@@ -170,6 +172,7 @@ double *suhmo_field(suhmo_level *L, int depth, int field);   // lazily allocates
 int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st);      // suhmo_level.hip
 int suhmo_restrict_both(suhmo_level *L, int depth, hipStream_t st);                 // suhmo_level.hip
 bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps);           // suhmo_gsrb.hip
+bool suhmo_gsrb_can_fuse_rhs(suhmo_level *L, int depth, int sweeps);               // suhmo_gsrb.hip
 int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream_t st, int *restricted = nullptr);   // suhmo_gsrb.hip; tail = halo
                                                     // rows worth keeping valid at exit; restricted: see there
 void suhmo_level_drop_graphs(suhmo_level *L);                                     // suhmo_fas.hip

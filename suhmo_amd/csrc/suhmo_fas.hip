@@ -61,7 +61,9 @@ static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, i
     if ((rc = suhmo_ensure_phi_halo(L, dep + 1, suhmo_halo_rows(C.v), (hipStream_t)s))) return rc;   // strips: before PHIOLD is taken, so that
                                                                                                       // it carries the halo rows too
     if (one_pass_rhs && (L->desc.nx_global == 0)) {
-        if ((rc = suhmo_fas_coarse_rhs(L, dep + 1, (hipStream_t)s))) return rc;   // PHIOLD = R phi, rhs_c = res_c + L_c(R phi): one pass
+        const int next_sweeps = (dep + 1 == nd - 1) ? sp->num_bottom : S;
+        if (suhmo_gsrb_can_fuse_rhs(L, dep + 1, next_sweeps)) C.rhs_pending = 1;   // ... inside the first relaxation of the depth
+        else if ((rc = suhmo_fas_coarse_rhs(L, dep + 1, (hipStream_t)s))) return rc;   // PHIOLD = R phi, rhs_c = res_c + L_c(R phi): one pass
     } else {
         HIPCHK(hipMemcpyAsync(C.fp.f[SUHMO_F_PHIOLD], C.fp.f[SUHMO_F_PHI], C.elems * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)s));
         if ((rc = suhmo_level_apply_op(L, dep + 1, 0, s))) return rc;             // LPHI = L_c(R phi)
@@ -125,8 +127,8 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
     }
     bool same = true;
     for (int d = 0; d < L->ndepth; d++) {
-        same = same && L->d[d].fp.f[SUHMO_F_PHI] == phi0[d] && L->d[d].phi_alt == alt0[d] && !L->d[d].prolong_pending;
-        L->d[d].fp.f[SUHMO_F_PHI] = phi0[d]; L->d[d].phi_alt = alt0[d]; L->d[d].prolong_pending = 0;
+        same = same && L->d[d].fp.f[SUHMO_F_PHI] == phi0[d] && L->d[d].phi_alt == alt0[d] && !L->d[d].prolong_pending && !L->d[d].rhs_pending;
+        L->d[d].fp.f[SUHMO_F_PHI] = phi0[d]; L->d[d].phi_alt = alt0[d]; L->d[d].prolong_pending = 0; L->d[d].rhs_pending = 0;
     }
     if (e == hipSuccess && rc == 0 && same && graph && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) g.exec = nullptr;
     if (!(e == hipSuccess && rc == 0 && same)) g.exec = nullptr;

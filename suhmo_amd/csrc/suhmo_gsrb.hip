@@ -363,6 +363,7 @@ struct TileGeom {
     int ntx, nty;
     const double *pc, *pco; int Pc, gyc;     // prolongIncrement fused into the load (as in FusedGeom)
     double *rres, *rphi; int rP, rgy;        // RST: coarse RES / PHI canvases
+    int frhs;                                // first relaxation of a coarse FAS depth: rhs = res + L(phi) is formed here
 };
 struct PairCoef { double rhs0, rhs1, B0, B1, Pi0, Pi1, zb0, zb1, mk0, mk1, a0, a1, byS0, byS1, byN0, byN1, bx0, bx1, bx2; };
 
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
                     p2.x = p2.x + corr; p2.y = p2.y + corr;
                 }
                 double2 d;
-                d = ld2(fp.f[SUHMO_F_RHS], idx); c.rhs0 = d.x; c.rhs1 = d.y;
+                d = ld2(g.frhs ? fp.f[SUHMO_F_RES] : fp.f[SUHMO_F_RHS], idx); c.rhs0 = d.x; c.rhs1 = d.y;
                 d = ld2(fp.f[SUHMO_F_B], idx); c.B0 = d.x; c.B1 = d.y;
                 d = ld2(fp.f[SUHMO_F_PI], idx); c.Pi0 = d.x; c.Pi1 = d.y;
                 d = ld2(fp.f[SUHMO_F_ZB], idx); c.zb0 = d.x; c.zb1 = d.y;
@@ -440,6 +441,57 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
     };
     TILE_EACH(load);
     __syncthreads();
+
+    // The FAS right-hand side of a coarse depth, rhs = res + L(R phi) (applyOpMg + axby of the cycle, k_apply<., 2>), formed
+    // from the restricted phi just loaded, for every cell the passes will advance; the tile's own cells also store it, L(phi)
+    // and the copy of R phi the prolongation subtracts later.
+    if (g.frhs) {
+        const int ylo = openS ? 0 : 1, yhi = openN ? LY - 1 : LY - 2;
+        auto mkrhs = [&](const int k, PairCoef &q_, const bool live) {
+            const int q = t + 256 * k;
+            if (q < NPAIR && live) {
+                const int ly = q / NP, lx = 2 * (q % NP);
+                const int i = gx0 + lx, j = gy0 + ly;
+                if (ly >= ylo && ly <= yhi) {
+                    const double *row = lds + ly * LX;
+                    double lo[2], cc[2];
+#pragma unroll
+                    for (int a = 0; a < 2; a++) {
+                        const int x = lx + a, ii = i + a;
+                        double c = row[x];
+                        double w = row[x > 0 ? x - 1 : 0], e = row[x < LX - 1 ? x + 1 : LX - 1];
+                        double s_ = lds[(ly > 0 ? ly - 1 : 0) * LX + x], n = lds[(ly < LY - 1 ? ly + 1 : LY - 1) * LX + x];
+                        if (!perx) {
+                            if (ii == 0 && !v.cfx[0]) w = (v.bct[0][0] == 0) ? v.two_v[0][0] - c : c + v.neu[0][0];
+                            if (ii == v.nx - 1 && !v.cfx[1]) e = (v.bct[0][1] == 0) ? v.two_v[0][1] - c : c + v.neu[0][1];
+                        }
+                        if (!pery) {
+                            if (j == 0 && !v.ext[0]) s_ = (v.bct[1][0] == 0) ? v.two_v[1][0] - c : c + v.neu[1][0];
+                            if (j == v.ny - 1 && !v.ext[1]) n = (v.bct[1][1] == 0) ? v.two_v[1][1] - c : c + v.neu[1][1];
+                        }
+                        double nl, dnl;
+                        nl_terms(ph, c, a ? q_.B1 : q_.B0, a ? q_.Pi1 : q_.Pi0, a ? q_.zb1 : q_.zb0, a ? q_.mk1 : q_.mk0, nl, dnl);
+                        const double bxW = a ? q_.bx1 : q_.bx0, bxE = a ? q_.bx2 : q_.bx1;
+                        double aterm = HAS_ALPHA ? v.alpha * (a ? q_.a1 : q_.a0) : v.alpha;
+                        lo[a] = lofphi_cell(v, aterm, c, e, w, n, s_, bxE, bxW, a ? q_.byN1 : q_.byN0, a ? q_.byS1 : q_.byS0, nl);
+                        cc[a] = c;
+                    }
+                    // (a cell on the region's edge, which no pass advances, gets a value nobody reads)
+                    q_.rhs0 = 1.0 * q_.rhs0 + 1.0 * lo[0]; q_.rhs1 = 1.0 * q_.rhs1 + 1.0 * lo[1];
+                    if (lx >= HX && lx < HX + TX && ly >= HY && ly < HY + TY && i < v.nx && j < v.ny) {
+                        const int idx = cidx(v, i, j);
+                        *reinterpret_cast<double2 *>(fp.f[SUHMO_F_LPHI] + idx) = make_double2(lo[0], lo[1]);
+                        *reinterpret_cast<double2 *>(fp.f[SUHMO_F_RHS] + idx) = make_double2(q_.rhs0, q_.rhs1);
+                        *reinterpret_cast<double2 *>(fp.f[SUHMO_F_PHIOLD] + idx) = make_double2(cc[0], cc[1]);
+                    }
+                }
+            }
+        };
+        TILE_EACH(mkrhs);
+        // (the passes below only write phi in LDS, which mkrhs only read: but a pass may overwrite a cell a slower wave still has
+        // to read for its L(phi))
+        __syncthreads();
+    }
 
 #pragma unroll 1
     for (int p = 0; p < 2 * S; p++) {
@@ -579,6 +631,11 @@ static int launch_tile(suhmo_level *L, int depth, hipStream_t st)
         g.pc = C.fp.f[SUHMO_F_PHI]; g.pco = C.fp.f[SUHMO_F_PHIOLD]; g.Pc = C.v.P; g.gyc = C.v.gy;
         D.prolong_pending = 0;
     }
+    g.frhs = 0;
+    if (D.rhs_pending) {
+        if (!suhmo_field(L, depth, SUHMO_F_LPHI) || !suhmo_field(L, depth, SUHMO_F_PHIOLD)) return -2;
+        g.frhs = 1; D.rhs_pending = 0;
+    }
     const double *pin = D.fp.f[SUHMO_F_PHI];
     if (v.alpha != 0.0)
         hipLaunchKernelGGL((k_gsrb_tile<S, T, true, RST>), dim3(g.ntx * g.nty), dim3(256), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
@@ -628,6 +685,13 @@ static int prolong_halo_rows(const suhmo_level *L, int depth)
     const Depth &D = L->d[depth], &C = L->d[depth + 1];
     int R = D.phi_fresh < 2 * C.phi_fresh ? D.phi_fresh : 2 * C.phi_fresh;
     return R & ~1;
+}
+// the first relaxation of a coarse FAS depth can form its right-hand side itself (tile kernel only)
+bool suhmo_gsrb_can_fuse_rhs(suhmo_level *L, int depth, int sweeps)
+{
+    Depth &D = L->d[depth];
+    if (sweeps < 1 || !L->fas_rhs_in_relax) return false;
+    return pick_K(L, D, pick_variant(L, D), sweeps) <= 0 && tile_ok(L, D);
 }
 bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps)
 {

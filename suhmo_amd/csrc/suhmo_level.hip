@@ -99,6 +99,8 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     L->fused_restrict = 1;
     L->gsrb_tile = 1; L->tile_t = 0; L->tile_s = 4;
     L->tile_max_cells = 8000000;
+    L->fas_rhs_in_relax = 1;
+    if (const char *e = getenv("SUHMO_FAS_RHS_IN_RELAX")) L->fas_rhs_in_relax = atoi(e);
     if (const char *e = getenv("SUHMO_TILE_MAX_CELLS")) L->tile_max_cells = atol(e);
     if (const char *e = getenv("SUHMO_TILE_S")) L->tile_s = atoi(e);        // most sweeps per tile launch (4, 2, 1)
     if (const char *e = getenv("SUHMO_GSRB_TILE")) L->gsrb_tile = atoi(e);
@@ -150,7 +152,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
         D.elems = (size_t)D.v.P * (size_t)(D.v.rows + 1);
         D.nbox = L->desc.nbox;
         memset(&D.fp, 0, sizeof(D.fp));
-        D.phi_alt = nullptr; D.prolong_pending = 0; D.phi_fresh = 0;
+        D.phi_alt = nullptr; D.prolong_pending = 0; D.rhs_pending = 0; D.phi_fresh = 0;
         for (int f : eager) {
             if (dep == 0 && f == SUHMO_F_LPHI) continue;       // lazily (only tests / AMR use it at depth 0)
             if (!suhmo_field(L, dep, f)) { suhmo_set_error("hipMalloc failed (depth %d field %d)", dep, f); delete L; return -2; }

@@ -280,15 +280,16 @@ def test_gsrb_tile_kernel(oracle, hip, case, tile_t, monkeypatch):
 
 
 @pytest.mark.parametrize("case", FUSED_VCYCLE_CASES + SOLVE_CASES, ids=[c[0] for c in FUSED_VCYCLE_CASES + SOLVE_CASES])
-@pytest.mark.parametrize("tile,fused_restrict,tile_t", [(1, 1, 0), (1, 1, 32), (1, 1, 16), (1, 0, 0), (0, 1, 0)],
-                         ids=["tile+restrict", "tile32+restrict", "tile16+restrict", "tile", "colour-passes"])
-def test_vcycle_on_tile_kernels(oracle, hip, case, tile, fused_restrict, tile_t, monkeypatch):
+@pytest.mark.parametrize("tile,fused_restrict,tile_t,rhs_in_relax", [(1, 1, 0, 1), (1, 1, 32, 1), (1, 1, 16, 1), (1, 0, 0, 1), (1, 1, 0, 0), (0, 1, 0, 1)],
+                         ids=["tile+restrict+rhs", "tile32+restrict+rhs", "tile16+restrict+rhs", "tile+rhs", "tile+restrict", "colour-passes"])
+def test_vcycle_on_tile_kernels(oracle, hip, case, tile, fused_restrict, tile_t, rhs_in_relax, monkeypatch):
     """V-cycles and a solve with every depth on the tile kernel (prolongation fused into its load, restriction into the
-    launch that ends the pre-smoothing or as a separate kernel) and with the tile kernel off (colour passes): all bitwise
-    the oracle's"""
+    launch that ends the pre-smoothing or as a separate kernel, the FAS right-hand side of a coarse depth formed by its first
+    relaxation or by its own kernel) and with the tile kernel off (colour passes): all bitwise the oracle's"""
     monkeypatch.setenv("SUHMO_GSRB_TILE", str(tile))
     monkeypatch.setenv("SUHMO_FUSED_RESTRICT", str(fused_restrict))
     monkeypatch.setenv("SUHMO_TILE_T", str(tile_t))
+    monkeypatch.setenv("SUHMO_FAS_RHS_IN_RELAX", str(rhs_in_relax))
     monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "100000000")
     _, mk, bc, ph, alpha, beta, mb = case
     f = mk()
@@ -301,6 +302,8 @@ def test_vcycle_on_tile_kernels(oracle, hip, case, tile, fused_restrict, tile_t,
         assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI)), (k, float(np.max(np.abs(G.get(hip.F_PHI) - O.get(oracle.F_PHI)))))
     for d in range(1, G.ndepth):
         assert np.array_equal(G.get(hip.F_RES, depth=d), O.get(oracle.F_RES, depth=d)), ("coarse residual", d)
+        assert np.array_equal(G.get(hip.F_RHS, depth=d), O.get(oracle.F_RHS, depth=d)), ("coarse right-hand side", d)
+        assert np.array_equal(G.get(hip.F_PHI, depth=d), O.get(oracle.F_PHI, depth=d)), ("coarse phi", d)
     no, ho = O.solve(sp)
     ng, hg = G.solve(sp)
     assert ng == no and np.array_equal(hg, ho)
