@@ -178,5 +178,6 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
 void suhmo_level_drop_graphs(suhmo_level *L);                                     // suhmo_fas.hip
 int suhmo_ensure_phi_halo(suhmo_level *L, int depth, int need, hipStream_t st);      // suhmo_level.hip
 int suhmo_fas_coarse_rhs(suhmo_level *L, int depth, hipStream_t st);                // suhmo_level.hip
+int suhmo_build_mg_coefficients(suhmo_level *L, bool with_faces, hipStream_t st);   // suhmo_level.hip
 int suhmo_exchange_list(suhmo_level *L, int depth, const int *fields, int n, hipStream_t st);   // LevelData::exchange across rank boundaries
 static inline int suhmo_halo_rows(const DV &v) { return v.gy < v.ny ? v.gy : v.ny; }

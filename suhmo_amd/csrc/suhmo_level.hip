@@ -1183,32 +1183,49 @@ int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st)
 
 // MGnewOp coefficient coarsening: CoarseAverage (arithmetic) of aCoef, B, Pi, zb, iceMask from
 // depth 0 with ratio r: sequential sum (ii fastest) * 1/r^2 (src/VCAMRNonLinearPoissonOp.cpp:1116-1138)
-// The five coefficient fields of one depth in one launch (blockIdx.z = field).  The sum of a coarse cell is one
-// sequential chain of r*r additions whatever the kernel does, so at the deep depths (few coarse cells, r = 16, 32) the time is
-// the chain plus the latency of its loads: a row of the block is fetched as r/2 independent 16-byte loads, then added in order.
-struct AvgFields { const double *f[5]; double *c[5]; };
+// The five coefficient fields of every coarse depth in ONE launch (blockIdx.z = (depth - 1) * 5 + field): each depth averages
+// depth 0 directly, so they are independent.  The sum of a coarse cell is one sequential chain of r*r additions whatever the
+// kernel does, so at the deep depths (few coarse cells, r = 16, 32) the time is the chain plus the latency of its loads: a row
+// of the block is fetched as r/2 independent 16-byte loads, then added in order.
+struct AvgDepth { int nx, ny, P, gy; double *c[5]; };
+struct AvgAll { const double *f[5]; AvgDepth d[SUHMO_MAXDEPTH - 1]; };
 template <int R>
-__global__ __launch_bounds__(256) void k_average_cells_all(DV vf, DV vc, AvgFields a, int r_)
+__device__ __forceinline__ double average_block(const double *__restrict__ f, int base, int P, int r_)
 {
-    const int ic = blockIdx.x * blockDim.x + threadIdx.x, jc = blockIdx.y * blockDim.y + threadIdx.y, q = blockIdx.z;
-    if (ic >= vc.nx || jc >= vc.ny) return;
-    const double *__restrict__ f = a.f[q];
     const int r = R ? R : r_;
-    const int base = cidx(vf, ic * r, jc * r);
     double sm = 0.0;
     if constexpr (R >= 2) {
         for (int jj = 0; jj < R; jj++) {
             double2 row[R / 2];
 #pragma unroll
-            for (int k = 0; k < R / 2; k++) row[k] = *reinterpret_cast<const double2 *>(f + base + jj * vf.P + 2 * k);   // ic * r is even
+            for (int k = 0; k < R / 2; k++) row[k] = *reinterpret_cast<const double2 *>(f + base + jj * P + 2 * k);   // ic * r is even
 #pragma unroll
             for (int k = 0; k < R / 2; k++) { sm = sm + row[k].x; sm = sm + row[k].y; }
         }
     } else {
         for (int jj = 0; jj < r; jj++)
-            for (int ii = 0; ii < r; ii++) sm = sm + f[base + jj * vf.P + ii];
+            for (int ii = 0; ii < r; ii++) sm = sm + f[base + jj * P + ii];
     }
-    a.c[q][cidx(vc, ic, jc)] = sm * (1.0 / (double)(r * r));
+    return sm * (1.0 / (double)(r * r));
+}
+__global__ __launch_bounds__(256) void k_average_cells_all(DV vf, AvgAll a)
+{
+    const int ic = blockIdx.x * blockDim.x + threadIdx.x, jc = blockIdx.y * blockDim.y + threadIdx.y;
+    const int dep = blockIdx.z / 5 + 1, q = blockIdx.z % 5;
+    const AvgDepth &C = a.d[dep - 1];
+    if (ic >= C.nx || jc >= C.ny) return;
+    const double *__restrict__ f = a.f[q];
+    const int r = 1 << dep, base = cidx(vf, ic * r, jc * r);
+    double m;
+    switch (r) {
+    case 2: m = average_block<2>(f, base, vf.P, r); break;
+    case 4: m = average_block<4>(f, base, vf.P, r); break;
+    case 8: m = average_block<8>(f, base, vf.P, r); break;
+    case 16: m = average_block<16>(f, base, vf.P, r); break;
+    case 32: m = average_block<32>(f, base, vf.P, r); break;
+    default: m = average_block<0>(f, base, vf.P, r); break;
+    }
+    C.c[q][(jc + C.gy) * C.P + SUHMO_XOFF + ic] = m;
 }
 // ghosts of coarse B / Pi / zb / mask: periodic wrap or Neumann copy (NeumBCForB :1309-1341)
 __global__ void k_coef_ghosts(DV v, double *__restrict__ p)
@@ -1229,23 +1246,25 @@ __global__ void k_coef_ghosts(DV v, double *__restrict__ p)
         else { int idx = cidx(v, i, v.ny - 1); p[idx + v.P] = v.per[1] ? p[idx - (v.ny - 1) * v.P] : p[idx]; }
     }
 }
-__global__ void k_coef_ghosts_all(DV v, AvgFields a)        // fields 1..4 of AvgFields (B, Pi, zb, mask) in one launch
+__global__ void k_coef_ghosts_all(DV v0, AvgAll a)        // B, Pi, zb, mask of every coarse depth (blockIdx.y = (depth - 1) * 4 + field - 1)
 {
-    double *__restrict__ p = a.c[1 + blockIdx.y];
+    const AvgDepth &C = a.d[blockIdx.y / 4];
+    double *__restrict__ p = C.c[1 + blockIdx.y % 4];
+    const int nx = C.nx, ny = C.ny, P = C.P;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < 2 * v.ny) {
-        int side = t / v.ny, j = t % v.ny;
-        if (v.cfx[side]) return;
-        if (side == 0) { int idx = cidx(v, 0, j); p[idx - 1] = v.per[0] ? p[idx + v.nx - 1] : p[idx]; }
-        else { int idx = cidx(v, v.nx - 1, j); p[idx + 1] = v.per[0] ? p[idx - (v.nx - 1)] : p[idx]; }
+    if (t < 2 * ny) {
+        int side = t / ny, j = t % ny;
+        if (v0.cfx[side]) return;
+        if (side == 0) { int idx = (j + C.gy) * P + SUHMO_XOFF; p[idx - 1] = v0.per[0] ? p[idx + nx - 1] : p[idx]; }
+        else { int idx = (j + C.gy) * P + SUHMO_XOFF + nx - 1; p[idx + 1] = v0.per[0] ? p[idx - (nx - 1)] : p[idx]; }
         return;
     }
-    t -= 2 * v.ny;
-    if (t < 2 * v.nx) {
-        int side = t / v.nx, i = t % v.nx;
-        if (v.ext[side]) return;
-        if (side == 0) { int idx = cidx(v, i, 0); p[idx - v.P] = v.per[1] ? p[idx + (v.ny - 1) * v.P] : p[idx]; }
-        else { int idx = cidx(v, i, v.ny - 1); p[idx + v.P] = v.per[1] ? p[idx - (v.ny - 1) * v.P] : p[idx]; }
+    t -= 2 * ny;
+    if (t < 2 * nx) {
+        int side = t / nx, i = t % nx;
+        if (v0.ext[side]) return;
+        if (side == 0) { int idx = C.gy * P + SUHMO_XOFF + i; p[idx - P] = v0.per[1] ? p[idx + (ny - 1) * P] : p[idx]; }
+        else { int idx = (ny - 1 + C.gy) * P + SUHMO_XOFF + i; p[idx + P] = v0.per[1] ? p[idx - (ny - 1) * P] : p[idx]; }
     }
 }
 // exchange + CopyGhostCells of a cell field (util/ExtrapGhostCells.cpp:182-269)
@@ -1259,37 +1278,39 @@ int suhmo_copy_ghosts(suhmo_level *L, int depth, int field, hipStream_t st)
     HIPCHK(hipGetLastError());
     return 0;
 }
+// with_faces = false: the caller's cycle re-averages bCoef itself (bcoeff_otf: UpdateOperator + AverageOperator every V-cycle)
+int suhmo_build_mg_coefficients(suhmo_level *L, bool with_faces, hipStream_t st)
+{
+    static const int fields[5] = {SUHMO_F_ACOEF, SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB, SUHMO_F_MASK};
+    Depth &F = L->d[0];
+    const int nd = L->ndepth;
+    if (nd > 1) {
+        AvgAll a;
+        for (int q = 0; q < 5; q++) a.f[q] = F.fp.f[fields[q]];
+        for (int dep = 1; dep < nd; dep++) {
+            const Depth &C = L->d[dep];
+            AvgDepth &o = a.d[dep - 1];
+            o.nx = C.v.nx; o.ny = C.v.ny; o.P = C.v.P; o.gy = C.v.gy;
+            for (int q = 0; q < 5; q++) o.c[q] = C.fp.f[fields[q]];
+        }
+        const Depth &C1 = L->d[1];                       // the largest coarse depth sizes the grid, the others leave early
+        hipLaunchKernelGGL(k_average_cells_all, dim3((C1.v.nx + 63) / 64, (C1.v.ny + 3) / 4, 5 * (nd - 1)), dim3(64, 4), 0, st, F.v, a);
+        const int n = 2 * C1.v.ny + 2 * C1.v.nx;
+        hipLaunchKernelGGL(k_coef_ghosts_all, dim3((n + 255) / 256, 4 * (nd - 1)), dim3(256), 0, st, F.v, a);
+        HIPCHK(hipGetLastError());
+    }
+    for (int dep = 1; dep < nd; dep++) {
+        int rc;
+        if (with_faces && (rc = suhmo_level_average_operator(L, dep, (suhmo_stream_t)st))) return rc;
+        rc = exchange_fields(L, dep, {SUHMO_F_ACOEF, SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB, SUHMO_F_MASK}, st); if (rc) return rc;
+    }
+    return 0;
+}
 extern "C" int suhmo_level_build_mg_coefficients(suhmo_level_t *L, suhmo_stream_t s)
 {
     ARG(L);
     HIPCHK(hipSetDevice(L->device));
-    hipStream_t st = (hipStream_t)s;
-    static const int fields[5] = {SUHMO_F_ACOEF, SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB, SUHMO_F_MASK};
-    Depth &F = L->d[0];
-    for (int dep = 1; dep < L->ndepth; dep++) {
-        Depth &C = L->d[dep];
-        AvgFields a;
-        for (int q = 0; q < 5; q++) { a.f[q] = F.fp.f[fields[q]]; a.c[q] = C.fp.f[fields[q]]; }
-        const int r = 1 << dep;
-        const dim3 blk(64, 4), grd((C.v.nx + 63) / 64, (C.v.ny + 3) / 4, 5);
-        switch (r) {
-        case 2: hipLaunchKernelGGL(k_average_cells_all<2>, grd, blk, 0, st, F.v, C.v, a, r); break;
-        case 4: hipLaunchKernelGGL(k_average_cells_all<4>, grd, blk, 0, st, F.v, C.v, a, r); break;
-        case 8: hipLaunchKernelGGL(k_average_cells_all<8>, grd, blk, 0, st, F.v, C.v, a, r); break;
-        case 16: hipLaunchKernelGGL(k_average_cells_all<16>, grd, blk, 0, st, F.v, C.v, a, r); break;
-        case 32: hipLaunchKernelGGL(k_average_cells_all<32>, grd, blk, 0, st, F.v, C.v, a, r); break;
-        default: hipLaunchKernelGGL(k_average_cells_all<0>, grd, blk, 0, st, F.v, C.v, a, r); break;
-        }
-        {
-            const int n = 2 * C.v.ny + 2 * C.v.nx;
-            hipLaunchKernelGGL(k_coef_ghosts_all, dim3((n + 255) / 256, 4), dim3(256), 0, st, C.v, a);
-        }
-        int rc = suhmo_level_average_operator(L, dep, s);
-        if (rc) return rc;
-        rc = exchange_fields(L, dep, {SUHMO_F_ACOEF, SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB, SUHMO_F_MASK}, st); if (rc) return rc;
-    }
-    HIPCHK(hipGetLastError());
-    return 0;
+    return suhmo_build_mg_coefficients(L, true, (hipStream_t)s);
 }
 
 // ------------------------------------------------------------------ small operators

@@ -320,7 +320,7 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
     if ((rc = suhmo_copy_ghosts(L, 0, SUHMO_F_B, st))) return rc;
     if ((rc = exchange1(L, SUHMO_F_B, st))) return rc;
     // MGnewOp coarsening of B (+ static Pi, zb, mask, aCoef): once per step, b does not change in [II]
-    if ((rc = suhmo_level_build_mg_coefficients(L, s))) return rc;
+    if ((rc = suhmo_build_mg_coefficients(L, false, (hipStream_t)s))) return rc;    // bCoef: re-averaged by every V-cycle (bcoeff_otf)
     suhmo_solver_params_t sp;                                      // SolveForHead_nl, :737-762
     sp.num_smooth = 4; sp.num_bottom = 16; sp.max_iter = 100; sp.iter_min = 2; sp.imin = 5;
     sp.eps = 1.0e-7; sp.hang = 0.01; sp.norm_thresh = 1.0e-7; sp.bcoeff_otf = 1; sp.max_depth = -1;
@@ -428,7 +428,7 @@ extern "C" int suhmo_amr_timestep(suhmo_level_t **lv, int nlev, const suhmo_mode
     for (int l = 0; l < nlev; l++) if (lv[l]) for (int f : need) if (!suhmo_field(lv[l], 0, f)) { suhmo_set_error("field allocation failed"); return -2; }
     // [I]
     for (int l = 0; l < nlev; l++) if ((rc = amr_gap_ghosts(lv, nlev, l, st))) return rc;
-    if ((rc = suhmo_level_build_mg_coefficients(lv[0], s))) return rc;
+    if ((rc = suhmo_build_mg_coefficients(lv[0], false, (hipStream_t)s))) return rc;    // bCoef: re-averaged by every V-cycle (bcoeff_otf)
     suhmo_solver_params_t sp;
     sp.num_smooth = 4; sp.num_bottom = 16; sp.max_iter = 100; sp.iter_min = 2; sp.imin = 5;
     sp.eps = 1.0e-7; sp.hang = 0.01; sp.norm_thresh = 1.0e-7; sp.bcoeff_otf = 1; sp.max_depth = -1;
