@@ -139,6 +139,9 @@ struct suhmo_level {
     int device;
     double *scratch;            // reduction scratch (device)
     double *hscratch;           // pinned host scratch
+    double *hscratch_dev;       // its device address: the last kernel of a reduction writes the result and a sequence number there
+    unsigned long long hseq;    // and the host polls for the number instead of synchronising the stream (env SUHMO_POLL_READBACK, default 1)
+    int poll_readback;
     size_t scratch_elems;
     suhmo_exchange_fn ex;
     suhmo_allreduce_max_fn ar;
@@ -178,6 +181,16 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
 void suhmo_level_drop_graphs(suhmo_level *L);                                     // suhmo_fas.hip
 int suhmo_ensure_phi_halo(suhmo_level *L, int depth, int need, hipStream_t st);      // suhmo_level.hip
 int suhmo_fas_coarse_rhs(suhmo_level *L, int depth, hipStream_t st);                // suhmo_level.hip
+// Result of a reduction whose last kernel was launched with suhmo_host_slot(L): 8 bytes back on the host.
+struct HostSlot { double *val; unsigned long long *flag; unsigned long long seq; };
+HostSlot suhmo_host_slot(suhmo_level *L);                                           // suhmo_level.hip; call right before the launch
+int suhmo_readback(suhmo_level *L, hipStream_t st, double *out);                    // after the launch
+__device__ __forceinline__ void suhmo_publish(const HostSlot &h, double v)
+{
+    if (!h.val) return;
+    h.val[0] = v;
+    __hip_atomic_store(h.flag, h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 int suhmo_build_mg_coefficients(suhmo_level *L, bool with_faces, hipStream_t st);   // suhmo_level.hip
 int suhmo_exchange_list(suhmo_level *L, int depth, const int *fields, int n, hipStream_t st);   // LevelData::exchange across rank boundaries
 static inline int suhmo_halo_rows(const DV &v) { return v.gy < v.ny ? v.gy : v.ny; }

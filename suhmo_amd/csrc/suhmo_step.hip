@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_picard_partial(DV v, const double *__re
     for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = fmax(sm[tid], sm[tid + s]); __syncthreads(); }
     if (tid == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = sm[0];
 }
-__global__ void k_max_final(const double *__restrict__ partial, int n, double *__restrict__ out)
+__global__ void k_max_final(const double *__restrict__ partial, int n, double *__restrict__ out, HostSlot hs)
 {
     __shared__ double sm[256];
     int tid = threadIdx.x;
@@ -157,7 +157,7 @@ __global__ void k_max_final(const double *__restrict__ partial, int n, double *_
     sm[tid] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = fmax(sm[tid], sm[tid + s]); __syncthreads(); }
-    if (tid == 0) out[0] = sm[0];
+    if (tid == 0) { out[0] = sm[0]; suhmo_publish(hs, sm[0]); }
 }
 static int reduce_max(suhmo_level *L, const double *h, const double *hl, double scale, int mode, double *out, hipStream_t st,
                       Excl ex = Excl{0, 0, 0, 0}, bool local_only = false)
@@ -165,10 +165,8 @@ static int reduce_max(suhmo_level *L, const double *h, const double *hl, double 
     Depth &D = L->d[0];
     dim3 grd(std::min((D.v.nx + 63) / 64, 32), std::min((D.v.ny + 3) / 4, 128));
     hipLaunchKernelGGL(k_picard_partial, grd, dim3(64, 4), 0, st, D.v, h, hl, scale, mode, L->scratch + 1, ex);
-    hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, st, L->scratch + 1, (int)(grd.x * grd.y), L->scratch);
-    HIPCHK(hipMemcpyAsync(L->hscratch, L->scratch, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    *out = L->hscratch[0];
+    hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, st, L->scratch + 1, (int)(grd.x * grd.y), L->scratch, suhmo_host_slot(L));
+    { int rc = suhmo_readback(L, st, out); if (rc) return rc; }
     if (!local_only && L->ar && (D.v.ext[0] || D.v.ext[1])) { int rc = L->ar(L->user, out); if (rc) return rc; }   // computeMax / norm over all ranks
     return 0;
 }
