@@ -184,7 +184,7 @@ int suhmo_fas_coarse_rhs(suhmo_level *L, int depth, hipStream_t st);            
 // Result of a reduction whose last kernel was launched with suhmo_host_slot(L): 8 bytes back on the host.
 struct HostSlot { double *val; unsigned long long *flag; unsigned long long seq; };
 HostSlot suhmo_host_slot(suhmo_level *L);                                           // suhmo_level.hip; call right before the launch
-int suhmo_readback(suhmo_level *L, hipStream_t st, double *out);                    // after the launch
+int suhmo_readback(suhmo_level *L, hipStream_t st, double *out, double *out2 = nullptr);   // after the launch; out2: a second value (scratch[1] / val[1])
 __device__ __forceinline__ void suhmo_publish(const HostSlot &h, double v)
 {
     if (!h.val) return;

@@ -159,7 +159,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
         }
         if (dep > 0) { suhmo_field(L, dep, SUHMO_F_PHIOLD); suhmo_field(L, dep, SUHMO_F_CORR); }
     }
-    L->scratch_elems = 8192;
+    L->scratch_elems = 16384;
     HIPCHK(hipMalloc(&L->scratch, L->scratch_elems * sizeof(double)));
     HIPCHK(hipHostMalloc(&L->hscratch, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     memset(L->hscratch, 0, 64 * sizeof(double));
@@ -1452,23 +1452,24 @@ HostSlot suhmo_host_slot(suhmo_level *L)
     if (L->poll_readback) { h.val = L->hscratch_dev; h.flag = (unsigned long long *)(L->hscratch_dev + 8); h.seq = ++L->hseq; }
     return h;
 }
-int suhmo_readback(suhmo_level *L, hipStream_t st, double *out)
+int suhmo_readback(suhmo_level *L, hipStream_t st, double *out, double *out2)
 {
     if (L->poll_readback) {
         HIPCHK(hipGetLastError());
         volatile unsigned long long *flag = (volatile unsigned long long *)(L->hscratch + 8);
         for (long spin = 0; spin < 400000000L; spin++) {
-            if (__atomic_load_n((unsigned long long *)flag, __ATOMIC_ACQUIRE) == L->hseq) { *out = L->hscratch[0]; return 0; }
+            if (__atomic_load_n((unsigned long long *)flag, __ATOMIC_ACQUIRE) == L->hseq) { *out = L->hscratch[0]; if (out2) *out2 = L->hscratch[1]; return 0; }
             if ((spin & 0xffff) == 0xffff && hipStreamQuery(st) == hipSuccess) break;     // finished without us seeing the store: read below
         }
         HIPCHK(hipStreamSynchronize(st));
-        if (__atomic_load_n((unsigned long long *)flag, __ATOMIC_ACQUIRE) == L->hseq) { *out = L->hscratch[0]; return 0; }
+        if (__atomic_load_n((unsigned long long *)flag, __ATOMIC_ACQUIRE) == L->hseq) { *out = L->hscratch[0]; if (out2) *out2 = L->hscratch[1]; return 0; }
         // not published (mapping not coherent on this system): fall back for good
         L->poll_readback = 0;
     }
-    HIPCHK(hipMemcpyAsync(L->hscratch, L->scratch, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(L->hscratch, L->scratch, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     *out = L->hscratch[0];
+    if (out2) *out2 = L->hscratch[1];
     return 0;
 }
 extern "C" int suhmo_level_norm(suhmo_level_t *L, int depth, int field, int ord, double *out, suhmo_stream_t s)

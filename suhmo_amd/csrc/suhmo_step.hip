@@ -171,6 +171,56 @@ static int reduce_max(suhmo_level *L, const double *h, const double *hl, double 
     return 0;
 }
 static int exchange1(suhmo_level *L, int f, hipStream_t st) { return suhmo_exchange_list(L, 0, &f, 1, st); }
+// Both numbers of the Picard test in one pass and one read-back: max h and max |h_lagged - h|.  The reference's
+// max |(h_lagged - h) / maxHead| is the second divided by |maxHead| afterwards: a correctly rounded division by a fixed
+// divisor is monotone and sign-symmetric, so the maximum of the quotients is the quotient of the maximum, bit for bit.
+__global__ __launch_bounds__(256) void k_picard2_partial(DV v, const double *__restrict__ h, const double *__restrict__ hl,
+                                                         double *__restrict__ partial, Excl ex)
+{
+    __shared__ double sm0[256], sm1[256];
+    int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    double a0 = -1.0e300, a1 = 0.0;
+    for (int j = blockIdx.y * blockDim.y + threadIdx.y; j < v.ny; j += gridDim.y * blockDim.y)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.nx; i += gridDim.x * blockDim.x) {
+            if (i >= ex.i0 && i < ex.i1 && j >= ex.j0 && j < ex.j1) continue;
+            int idx = cidx(v, i, j);
+            a0 = fmax(a0, h[idx]);
+            a1 = fmax(a1, fabs(hl[idx] - h[idx]));
+        }
+    sm0[tid] = a0; sm1[tid] = a1;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { sm0[tid] = fmax(sm0[tid], sm0[tid + s]); sm1[tid] = fmax(sm1[tid], sm1[tid + s]); }
+        __syncthreads();
+    }
+    if (tid == 0) { int b = blockIdx.y * gridDim.x + blockIdx.x; partial[2 * b] = sm0[0]; partial[2 * b + 1] = sm1[0]; }
+}
+__global__ void k_max2_final(const double *__restrict__ partial, int n, double *__restrict__ out, HostSlot hs)
+{
+    __shared__ double sm0[256], sm1[256];
+    int tid = threadIdx.x;
+    double a0 = -1.0e300, a1 = 0.0;
+    for (int k = tid; k < n; k += 256) { a0 = fmax(a0, partial[2 * k]); a1 = fmax(a1, partial[2 * k + 1]); }
+    sm0[tid] = a0; sm1[tid] = a1;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { sm0[tid] = fmax(sm0[tid], sm0[tid + s]); sm1[tid] = fmax(sm1[tid], sm1[tid + s]); }
+        __syncthreads();
+    }
+    if (tid == 0) { out[0] = sm0[0]; out[1] = sm1[0]; if (hs.val) hs.val[1] = sm1[0]; suhmo_publish(hs, sm0[0]); }
+}
+// max h and max |hl - h| over the level's cells (local to the rank)
+static int picard_maxima(suhmo_level *L, const double *h, const double *hl, double *maxh, double *maxd, hipStream_t st,
+                         Excl ex = Excl{0, 0, 0, 0})
+{
+    Depth &D = L->d[0];
+    dim3 grd(std::min((D.v.nx + 63) / 64, 32), std::min((D.v.ny + 3) / 4, 128));
+    hipLaunchKernelGGL(k_picard2_partial, grd, dim3(64, 4), 0, st, D.v, h, hl, L->scratch + 2, ex);
+    hipLaunchKernelGGL(k_max2_final, dim3(1), dim3(256), 0, st, L->scratch + 2, (int)(grd.x * grd.y), L->scratch, suhmo_host_slot(L));
+    int rc = suhmo_readback(L, st, maxh, maxd); if (rc) return rc;
+    return 0;
+}
+static inline double picard_quotient(double maxd, double maxHead) { return maxd == 0.0 ? 0.0 : maxd / fabs(maxHead); }
 
 // grad h (cell centred, ghosted) and Re on the ghosted level: reuses the WFlx_level kernels of
 // suhmo_level.hip (identical arithmetic: NEWMACGRAD + EdgeToCell + ExtrapGhostCells + COMPUTERE)
@@ -336,9 +386,13 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
         int it = 0;
         if ((rc = suhmo_level_solve(L, &sp, &it, nullptr, s))) return rc;
         nv += it;
-        double maxHead = 0.0, res = 0.0;
-        if ((rc = reduce_max(L, D.fp.f[SUHMO_F_PHI], nullptr, 1.0, 0, &maxHead, st))) return rc;
-        if ((rc = reduce_max(L, D.fp.f[SUHMO_F_PHI], D.fp.f[SUHMO_F_HLAG], maxHead, 1, &res, st))) return rc;
+        double maxHead = 0.0, maxd = 0.0, res = 0.0;
+        if ((rc = picard_maxima(L, D.fp.f[SUHMO_F_PHI], D.fp.f[SUHMO_F_HLAG], &maxHead, &maxd, st))) return rc;
+        if (L->ar && (D.v.ext[0] || D.v.ext[1])) {                // computeMax / norm over all ranks
+            if ((rc = L->ar(L->user, &maxHead))) return rc;
+            if ((rc = L->ar(L->user, &maxd))) return rc;
+        }
+        res = picard_quotient(maxd, maxHead);
         if (ite_idx > 100) { suhmo_set_error("does not converge (Picard iterations > 100)"); return -6; }   // :3190-3195
         if (cur_step < 2) { if (res < 0.05 && cur_picard > 2) converged = true; }
         else if (cur_step < 50) { if (res < 0.05) converged = true; }
@@ -460,21 +514,18 @@ extern "C" int suhmo_amr_timestep(suhmo_level_t **lv, int nlev, const suhmo_mode
             if (lv[l]) { if ((rc = suhmo_amr2_average(lv[l - 1], lv[l], SUHMO_F_PHI, SUHMO_F_PHI, s))) return rc; }
             else if (lv[l - 1]) lv[l - 1]->d[0].phi_fresh = 0;                          // changed on the ranks that hold level l
         }
-        double maxHead = -1.0e300, res = 0.0;
+        double maxHead = -1.0e300, maxd = 0.0, res = 0.0;
         for (int l = 0; l < nlev; l++) {
             if (!lv[l]) continue;
-            double m = 0.0;
-            if ((rc = reduce_max(lv[l], lv[l]->d[0].fp.f[SUHMO_F_PHI], nullptr, 1.0, 0, &m, st, covered_by(lv, nlev, l), true))) return rc;
-            maxHead = std::max(maxHead, m);
+            double m = 0.0, d = 0.0;
+            if ((rc = picard_maxima(lv[l], lv[l]->d[0].fp.f[SUHMO_F_PHI], lv[l]->d[0].fp.f[SUHMO_F_HLAG], &m, &d, st, covered_by(lv, nlev, l)))) return rc;
+            maxHead = std::max(maxHead, m); maxd = std::max(maxd, d);
         }
-        if (strips && lv[0]->ar && (rc = lv[0]->ar(lv[0]->user, &maxHead))) return rc; // computeMax over all ranks (level 0 reaches every rank)
-        for (int l = 0; l < nlev; l++) {
-            if (!lv[l]) continue;
-            double r = 0.0;
-            if ((rc = reduce_max(lv[l], lv[l]->d[0].fp.f[SUHMO_F_PHI], lv[l]->d[0].fp.f[SUHMO_F_HLAG], maxHead, 1, &r, st, covered_by(lv, nlev, l), true))) return rc;
-            res = std::max(res, r);
+        if (strips && lv[0]->ar) {                                  // computeMax over all ranks (level 0 reaches every rank)
+            if ((rc = lv[0]->ar(lv[0]->user, &maxHead))) return rc;
+            if ((rc = lv[0]->ar(lv[0]->user, &maxd))) return rc;
         }
-        if (strips && lv[0]->ar && (rc = lv[0]->ar(lv[0]->user, &res))) return rc;
+        res = picard_quotient(maxd, maxHead);
         if (ite_idx > 100) { suhmo_set_error("does not converge (Picard iterations > 100)"); return -6; }
         if (cur_step < 2) { if (res < 0.05 && cur_picard > 2) converged = true; }
         else if (cur_step < 50) { if (res < 0.05) converged = true; }
