@@ -1191,7 +1191,7 @@ int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st)
 // depth 0 directly, so they are independent.  The sum of a coarse cell is one sequential chain of r*r additions whatever the
 // kernel does, so at the deep depths (few coarse cells, r = 16, 32) the time is the chain plus the latency of its loads: a row
 // of the block is fetched as r/2 independent 16-byte loads, then added in order.
-struct AvgDepth { int nx, ny, P, gy; double *c[5]; };
+struct AvgDepth { int nx, ny, P, gy; int boff, nbx; double *c[5]; };   // boff: first workgroup of the depth, nbx: its workgroups per row of tiles
 struct AvgAll { const double *f[5]; AvgDepth d[SUHMO_MAXDEPTH - 1]; };
 template <int R>
 __device__ __forceinline__ double average_block(const double *__restrict__ f, int base, int P, int r_)
@@ -1212,11 +1212,14 @@ __device__ __forceinline__ double average_block(const double *__restrict__ f, in
     }
     return sm * (1.0 / (double)(r * r));
 }
-__global__ __launch_bounds__(256) void k_average_cells_all(DV vf, AvgAll a)
+__global__ __launch_bounds__(256) void k_average_cells_all(DV vf, AvgAll a, int nd)
 {
-    const int ic = blockIdx.x * blockDim.x + threadIdx.x, jc = blockIdx.y * blockDim.y + threadIdx.y;
-    const int dep = blockIdx.z / 5 + 1, q = blockIdx.z % 5;
+    // workgroups are numbered depth by depth (a grid sized for the largest depth would dispatch mostly empty ones)
+    int dep = 1;
+    while (dep + 1 < nd && (int)blockIdx.x >= a.d[dep].boff) dep++;
     const AvgDepth &C = a.d[dep - 1];
+    const int local = blockIdx.x - C.boff, q = local % 5, tile = local / 5;
+    const int ic = (tile % C.nbx) * blockDim.x + threadIdx.x, jc = (tile / C.nbx) * blockDim.y + threadIdx.y;
     if (ic >= C.nx || jc >= C.ny) return;
     const double *__restrict__ f = a.f[q];
     const int r = 1 << dep, base = cidx(vf, ic * r, jc * r);
@@ -1290,15 +1293,18 @@ int suhmo_build_mg_coefficients(suhmo_level *L, bool with_faces, hipStream_t st)
     const int nd = L->ndepth;
     if (nd > 1) {
         AvgAll a;
+        int nblocks = 0;
         for (int q = 0; q < 5; q++) a.f[q] = F.fp.f[fields[q]];
         for (int dep = 1; dep < nd; dep++) {
             const Depth &C = L->d[dep];
             AvgDepth &o = a.d[dep - 1];
             o.nx = C.v.nx; o.ny = C.v.ny; o.P = C.v.P; o.gy = C.v.gy;
             for (int q = 0; q < 5; q++) o.c[q] = C.fp.f[fields[q]];
+            o.boff = nblocks; o.nbx = (C.v.nx + 63) / 64;
+            nblocks += 5 * o.nbx * ((C.v.ny + 3) / 4);
         }
-        const Depth &C1 = L->d[1];                       // the largest coarse depth sizes the grid, the others leave early
-        hipLaunchKernelGGL(k_average_cells_all, dim3((C1.v.nx + 63) / 64, (C1.v.ny + 3) / 4, 5 * (nd - 1)), dim3(64, 4), 0, st, F.v, a);
+        const Depth &C1 = L->d[1];
+        hipLaunchKernelGGL(k_average_cells_all, dim3(nblocks), dim3(64, 4), 0, st, F.v, a, nd);
         const int n = 2 * C1.v.ny + 2 * C1.v.nx;
         hipLaunchKernelGGL(k_coef_ghosts_all, dim3((n + 255) / 256, 4 * (nd - 1)), dim3(256), 0, st, F.v, a);
         HIPCHK(hipGetLastError());
