@@ -188,7 +188,7 @@ def side_configs(sy, level, sp, args):
     f = sy.shmip_fields(n, n)
     G = level.HipLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64)
     G.set_inputs(f); G.build_mg_coefficients()
-    for _ in range(3):
+    for _ in range(4):
         G.vcycle(sp)
     G.synchronize()
     t0 = time.perf_counter()
@@ -205,7 +205,7 @@ def side_configs(sy, level, sp, args):
         bc = dict(type=[[0, 0], [1, 0]], value=[[0.0, 0.0], [0.0, 0.0]], periodic=[0, 1])
         A = level.HipAmr2(nx0, ny0, c["dx"], c["dy"], bc, sy.CFG3_PHYS, patch, max_box=32)
         A.coarse.set_inputs(c); A.coarse.build_mg_coefficients(); A.fine.set_inputs(fi)
-        for _ in range(2):
+        for _ in range(4):                       # eager, then one captured graph per ping-pong state, then replays
             A.vcycle(sp)
         A.coarse.synchronize()
         t0 = time.perf_counter()

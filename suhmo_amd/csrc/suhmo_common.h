@@ -127,7 +127,11 @@ struct Depth {
     int phi_fresh;     // strips: halo rows of phi (each rank-boundary side) that hold the neighbour's CURRENT values
 };
 
-struct VGraph { int key[4]; hipGraphExec_t exec; };     // a V-cycle captured for one set of solver parameters (suhmo_fas.hip)
+struct VGraph {                 // a V-cycle captured for one set of solver parameters and one state of the phi ping-pong (suhmo_fas.hip)
+    int key[4]; hipGraphExec_t exec;
+    double *p0[SUHMO_MAXDEPTH], *a0[SUHMO_MAXDEPTH];     // PHI / second canvas of every depth when the cycle starts ...
+    double *p1[SUHMO_MAXDEPTH], *a1[SUHMO_MAXDEPTH];     // ... and when it ends (an odd number of out-of-place launches on a depth swaps them)
+};
 struct ProfEv { hipEvent_t a, b; long cells; int restricts; };   // restricts: the launch also did the restriction (RST)
 
 struct suhmo_level {
@@ -160,6 +164,7 @@ struct suhmo_level {
     int fused_nt;               // threads per workgroup of the fused kernel: 256 or 64 (env SUHMO_FUSED_NT)
     int fused_restrict;         // the last pre-smoothing launch also restricts (env SUHMO_FUSED_RESTRICT, default 1)
     int fused_hc;               // rows per chunk of the fused kernel (0 = auto); env SUHMO_FUSED_HC
+    int tile_chunks;            // a level that is one tile relaxes all its sweeps in one launch (env SUHMO_TILE_CHUNKS, default 1)
     int fas_rhs_in_relax;       // coarse FAS right-hand side formed by the first tile relax of the depth (env SUHMO_FAS_RHS_IN_RELAX, default 1)
     long tile_max_cells;        // auto mode: levels below this many cells relax on the tile kernel (env SUHMO_TILE_MAX_CELLS)
     int gsrb_tile, tile_t, tile_s;      // cache-resident depths: S sweeps per launch on LDS tiles (env SUHMO_GSRB_TILE, default 1); tile edge 16 / 32

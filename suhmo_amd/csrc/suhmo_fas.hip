@@ -91,11 +91,13 @@ static int vcycle_body(suhmo_level *L, const suhmo_solver_params_t *sp, int nd, 
 
 // Small levels are launch-bound (a 1024^2 V-cycle is ~170 dependent launches of a few microseconds each): the cycle is a
 // fixed sequence of kernels for given solver parameters, so from its second use it is replayed as a HIP graph.  The first
-// use runs eagerly (lazy allocations, occupancy queries), the second is captured on a private stream -- host-side state the
-// cycle toggles (phi ping-pong pointers, prolong_pending) must come back to where it started, otherwise the graph is
-// dropped.  Not used on rank strips (the exchange hooks are host calls), while profiling, or above SUHMO_GRAPH_MAX_CELLS.
+// use runs eagerly (lazy allocations, occupancy queries), later ones are captured on a private stream, one graph per state of
+// the phi ping-pong pointers the cycle starts from (a depth with an odd number of out-of-place relaxation launches ends
+// with its two canvases swapped: the next cycle is a different graph); the pointers the capture ended with are re-applied
+// after every replay.  Not used on rank strips (the exchange hooks are host calls), while profiling, or above SUHMO_GRAPH_MAX_CELLS.
 void suhmo_level_drop_graphs(suhmo_level *L)
 {
+    if (getenv("SUHMO_GRAPH_DEBUG")) { int ok = 0; for (VGraph &g : L->vgraphs) ok += g.exec != nullptr; fprintf(stderr, "[suhmo] level %dx%d: %zu V-cycle graphs, %d executable\n", L->d[0].v.nx, L->d[0].v.ny, L->vgraphs.size(), ok); }
     for (VGraph &g : L->vgraphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     L->vgraphs.clear();
     if (L->gstream) { (void)hipStreamDestroy(L->gstream); L->gstream = nullptr; }
@@ -104,19 +106,26 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
 {
     done = false;
     const int key[4] = {sp->num_smooth, sp->num_bottom, sp->bcoeff_otf, nd};
+    auto at_start = [&](const VGraph &g) {
+        if (memcmp(g.key, key, sizeof(key))) return false;
+        for (int d = 0; d < L->ndepth; d++) if (L->d[d].fp.f[SUHMO_F_PHI] != g.p0[d] || L->d[d].phi_alt != g.a0[d]) return false;
+        return true;
+    };
     for (const VGraph &g : L->vgraphs)
-        if (!memcmp(g.key, key, sizeof(key))) {
+        if (at_start(g)) {
             if (!g.exec) return 0;                                       // known not to be capturable
             HIPCHK(hipGraphLaunch(g.exec, (hipStream_t)s));
+            for (int d = 0; d < L->ndepth; d++) { L->d[d].fp.f[SUHMO_F_PHI] = g.p1[d]; L->d[d].phi_alt = g.a1[d]; }
             done = true;
             return 0;
         }
-    // first sighting of these parameters: run eagerly now, capture at the next call
+    // first sighting of these parameters: run eagerly now (lazy allocations, occupancy queries), capture from the next call on
     for (int k = 0; k < 4; k++) if (L->vgraph_seen[k] != key[k]) { memcpy(L->vgraph_seen, key, sizeof(key)); return 0; }
+    if (L->vgraphs.size() >= 16) return 0;                               // (pointer states keep changing: give up capturing)
     if (!L->gstream) HIPCHK(hipStreamCreateWithFlags(&L->gstream, hipStreamNonBlocking));
-    double *phi0[SUHMO_MAXDEPTH], *alt0[SUHMO_MAXDEPTH];
-    for (int d = 0; d < L->ndepth; d++) { phi0[d] = L->d[d].fp.f[SUHMO_F_PHI]; alt0[d] = L->d[d].phi_alt; }
     VGraph g; memcpy(g.key, key, sizeof(key)); g.exec = nullptr;
+    for (int d = 0; d < SUHMO_MAXDEPTH; d++) { g.p0[d] = g.a0[d] = g.p1[d] = g.a1[d] = nullptr; }
+    for (int d = 0; d < L->ndepth; d++) { g.p0[d] = L->d[d].fp.f[SUHMO_F_PHI]; g.a0[d] = L->d[d].phi_alt; }
     HIPCHK(hipStreamSynchronize((hipStream_t)s));                        // the private stream starts from a quiescent state
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamBeginCapture(L->gstream, hipStreamCaptureModeThreadLocal);
@@ -125,18 +134,21 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
         rc = vcycle_body(L, sp, nd, (suhmo_stream_t)L->gstream);
         e = hipStreamEndCapture(L->gstream, &graph);
     }
-    bool same = true;
+    bool clean = true;                                                   // host-side state the cycle must leave behind: none pending
     for (int d = 0; d < L->ndepth; d++) {
-        same = same && L->d[d].fp.f[SUHMO_F_PHI] == phi0[d] && L->d[d].phi_alt == alt0[d] && !L->d[d].prolong_pending && !L->d[d].rhs_pending;
-        L->d[d].fp.f[SUHMO_F_PHI] = phi0[d]; L->d[d].phi_alt = alt0[d]; L->d[d].prolong_pending = 0; L->d[d].rhs_pending = 0;
+        clean = clean && !L->d[d].prolong_pending && !L->d[d].rhs_pending;
+        g.p1[d] = L->d[d].fp.f[SUHMO_F_PHI]; g.a1[d] = L->d[d].phi_alt;
+        L->d[d].prolong_pending = 0; L->d[d].rhs_pending = 0;
+        L->d[d].fp.f[SUHMO_F_PHI] = g.p0[d]; L->d[d].phi_alt = g.a0[d];  // nothing was executed during capture
     }
-    if (e == hipSuccess && rc == 0 && same && graph && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) g.exec = nullptr;
-    if (!(e == hipSuccess && rc == 0 && same)) g.exec = nullptr;
+    if (e == hipSuccess && rc == 0 && clean && graph && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) g.exec = nullptr;
+    if (!(e == hipSuccess && rc == 0 && clean)) g.exec = nullptr;
     if (graph) (void)hipGraphDestroy(graph);
     (void)hipGetLastError();
     L->vgraphs.push_back(g);
-    if (!g.exec) return 0;                                               // nothing was executed during capture: run eagerly
+    if (!g.exec) return 0;                                               // run eagerly
     HIPCHK(hipGraphLaunch(g.exec, (hipStream_t)s));
+    for (int d = 0; d < L->ndepth; d++) { L->d[d].fp.f[SUHMO_F_PHI] = g.p1[d]; L->d[d].phi_alt = g.a1[d]; }
     done = true;
     return 0;
 }

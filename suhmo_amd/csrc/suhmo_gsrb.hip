@@ -364,6 +364,7 @@ struct TileGeom {
     const double *pc, *pco; int Pc, gyc;     // prolongIncrement fused into the load (as in FusedGeom)
     double *rres, *rphi; int rP, rgy;        // RST: coarse RES / PHI canvases
     int frhs;                                // first relaxation of a coarse FAS depth: rhs = res + L(phi) is formed here
+    int chunks;                              // level = one tile: this many times S sweeps in the launch (halo images refreshed in LDS)
 };
 struct PairCoef { double rhs0, rhs1, B0, B1, Pi0, Pi1, zb0, zb1, mk0, mk1, a0, a1, byS0, byS1, byN0, byN1, bx0, bx1, bx2; };
 
@@ -373,7 +374,7 @@ struct PairCoef { double rhs0, rhs1, B0, B1, Pi0, Pi1, zb0, zb1, mk0, mk1, a0, a
 // of column pairs per thread, hence the same registers, as without the restriction.
 template <int T, bool RST> struct TileShape { static constexpr int TX = T, TY = (RST && T == 32) ? 28 : T; };
 
-template <int S, int T, bool HAS_ALPHA, bool RST = false>
+template <int S, int T, bool HAS_ALPHA, bool RST = false, bool CHUNKED = false>
 __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__restrict__ pin, double *__restrict__ pout,
                                                    suhmo_phys_t ph, TileGeom g)
 {
@@ -493,6 +494,26 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
         __syncthreads();
     }
 
+    // CHUNKED (its own instantiation: the outer loop costs the large tiles their second workgroup per CU): a level that is one
+    // tile can go on after 2S passes, what the halo lacks then are only the periodic images of its own cells
+#pragma unroll 1
+    for (int chunk = 0; chunk < (CHUNKED ? g.chunks : 1); chunk++) {
+    if (CHUNKED && chunk > 0 && (perx || pery)) {
+        auto refresh = [&](const int k, const PairCoef &, const bool live) {
+            const int q = t + 256 * k;
+            if (q < NPAIR && live) {
+                const int ly = q / NP, lx = 2 * (q % NP);
+                const int i = gx0 + lx, j = gy0 + ly;
+                if (i < 0 || i >= v.nx || j < 0 || j >= v.ny) {
+                    const int src = ((pery ? wrap(j, v.ny) : j) - gy0) * LX + ((perx ? wrap(i, v.nx) : i) - gx0);
+                    const double a0 = lds[src], a1 = lds[src + 1];      // cells of the domain: nobody writes them here
+                    lds[ly * LX + lx] = a0; lds[ly * LX + lx + 1] = a1;
+                }
+            }
+        };
+        TILE_EACH(refresh);
+        __syncthreads();
+    }
 #pragma unroll 1
     for (int p = 0; p < 2 * S; p++) {
         const int xlo = openW ? 0 : p + 1, xhi = openE ? LX - 1 : LX - 2 - p;
@@ -531,6 +552,7 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
         };
         TILE_EACH(relax);
         __syncthreads();
+    }
     }
 
     const int oi1 = (tx * TX + TX < v.nx) ? tx * TX + TX : v.nx, oj1 = (ty * TY + TY < v.ny) ? ty * TY + TY : v.ny;
@@ -608,7 +630,7 @@ static bool tile_ok(const suhmo_level *L, const Depth &D)
 }
 
 template <int S, int T, bool RST = false>
-static int launch_tile(suhmo_level *L, int depth, hipStream_t st)
+static int launch_tile(suhmo_level *L, int depth, int chunks, hipStream_t st)
 {
     Depth &D = L->d[depth];
     const DV &v = D.v;
@@ -631,12 +653,24 @@ static int launch_tile(suhmo_level *L, int depth, hipStream_t st)
         g.pc = C.fp.f[SUHMO_F_PHI]; g.pco = C.fp.f[SUHMO_F_PHIOLD]; g.Pc = C.v.P; g.gyc = C.v.gy;
         D.prolong_pending = 0;
     }
+    g.chunks = chunks;
     g.frhs = 0;
     if (D.rhs_pending) {
         if (!suhmo_field(L, depth, SUHMO_F_LPHI) || !suhmo_field(L, depth, SUHMO_F_PHIOLD)) return -2;
         g.frhs = 1; D.rhs_pending = 0;
     }
     const double *pin = D.fp.f[SUHMO_F_PHI];
+    if constexpr (S == 4) {
+        if (chunks > 1) {
+            if (v.alpha != 0.0)
+                hipLaunchKernelGGL((k_gsrb_tile<S, T, true, RST, true>), dim3(g.ntx * g.nty), dim3(256), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+            else
+                hipLaunchKernelGGL((k_gsrb_tile<S, T, false, RST, true>), dim3(g.ntx * g.nty), dim3(256), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+            std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
+            return 0;
+        }
+    }
+    if (chunks > 1) { suhmo_set_error("internal: chunked tile launch with S != 4"); return -4; }
     if (v.alpha != 0.0)
         hipLaunchKernelGGL((k_gsrb_tile<S, T, true, RST>), dim3(g.ntx * g.nty), dim3(256), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
     else
@@ -644,17 +678,29 @@ static int launch_tile(suhmo_level *L, int depth, hipStream_t st)
     std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
     return 0;
 }
-static int launch_tile_any(suhmo_level *L, int depth, int S, bool rst, hipStream_t st)
+// tile edge: 16 below 200 k cells (enough workgroups for the chip; also the shorter launch on tiny levels), 32 above
+static int tile_edge(const suhmo_level *L, const DV &v)
 {
-    const DV &v = L->d[depth].v;
-    int T = L->tile_t;
-    if (!T) T = ((long)v.nx * v.ny >= 200000L) ? 32 : 16;     // enough workgroups for the chip on the smaller depths
+    if (L->tile_t) return L->tile_t;
+    return ((long)v.nx * v.ny >= 200000L) ? 32 : 16;
+}
+// a level that is ONE tile (16-wide, or 32-wide when there are sweeps enough to pay for the larger region) can take all its
+// sweeps in one launch; returns the tile edge to use or 0
+static int single_tile(const suhmo_level *L, const DV &v)
+{
+    if (L->tile_t != 32 && v.nx <= 16 && v.ny <= 16) return 16;
+    if (L->tile_t != 16 && v.nx <= 32 && v.ny <= 28) return 32;   // (the restricting variant of the 32-wide tile is 28 rows high)
+    return 0;
+}
+static int launch_tile_any(suhmo_level *L, int depth, int S, int chunks, bool rst, hipStream_t st)
+{
+    const int T = chunks > 1 ? single_tile(L, L->d[depth].v) : tile_edge(L, L->d[depth].v);
     if (rst) {
-        if (T == 32) return S == 4 ? launch_tile<4, 32, true>(L, depth, st) : S == 2 ? launch_tile<2, 32, true>(L, depth, st) : launch_tile<1, 32, true>(L, depth, st);
-        return S == 4 ? launch_tile<4, 16, true>(L, depth, st) : S == 2 ? launch_tile<2, 16, true>(L, depth, st) : launch_tile<1, 16, true>(L, depth, st);
+        if (T == 32) return S == 4 ? launch_tile<4, 32, true>(L, depth, chunks, st) : S == 2 ? launch_tile<2, 32, true>(L, depth, chunks, st) : launch_tile<1, 32, true>(L, depth, chunks, st);
+        return S == 4 ? launch_tile<4, 16, true>(L, depth, chunks, st) : S == 2 ? launch_tile<2, 16, true>(L, depth, chunks, st) : launch_tile<1, 16, true>(L, depth, chunks, st);
     }
-    if (T == 32) return S == 4 ? launch_tile<4, 32>(L, depth, st) : S == 2 ? launch_tile<2, 32>(L, depth, st) : launch_tile<1, 32>(L, depth, st);
-    return S == 4 ? launch_tile<4, 16>(L, depth, st) : S == 2 ? launch_tile<2, 16>(L, depth, st) : launch_tile<1, 16>(L, depth, st);
+    if (T == 32) return S == 4 ? launch_tile<4, 32>(L, depth, chunks, st) : S == 2 ? launch_tile<2, 32>(L, depth, chunks, st) : launch_tile<1, 32>(L, depth, chunks, st);
+    return S == 4 ? launch_tile<4, 16>(L, depth, chunks, st) : S == 2 ? launch_tile<2, 16>(L, depth, chunks, st) : launch_tile<1, 16>(L, depth, chunks, st);
 }
 
 static int pick_variant(const suhmo_level *L, const Depth &D)
@@ -734,9 +780,11 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
             HIPCHK(hipEventCreate(&pe.a)); HIPCHK(hipEventCreate(&pe.b));
             HIPCHK(hipEventRecord(pe.a, st));
         }
+        int tchunks = 1;
         if (TS) {
-            const bool rst = restricted && L->fused_restrict && depth + 1 < L->ndepth && !(D.v.ny & 1) && it + TS == sweeps;
-            int rc = launch_tile_any(L, depth, TS, rst, st); if (rc) return rc;
+            if (L->tile_chunks && TS == 4 && single_tile(L, D.v)) tchunks = (sweeps - it) / TS;       // e.g. the 16 bottom sweeps in one launch (1: as before)
+            const bool rst = restricted && L->fused_restrict && depth + 1 < L->ndepth && !(D.v.ny & 1) && it + TS * tchunks == sweeps;
+            int rc = launch_tile_any(L, depth, TS, tchunks, rst, st); if (rc) return rc;
             if (rst) *restricted = 1;
         } else if (K == 0) {
             for (int pass = 0; pass < 2; pass++) {
@@ -776,7 +824,7 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
             if (rc) return rc;
             if (ext) { F = E; D.phi_fresh = F; }
         }
-        int done = TS ? TS : K == 0 ? 1 : K;
+        int done = TS ? TS * tchunks : K == 0 ? 1 : K;
         if (prof) {
             HIPCHK(hipEventRecord(pe.b, st));
             pe.cells = (long)D.v.nx * D.v.ny * done;

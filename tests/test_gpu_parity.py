@@ -268,7 +268,7 @@ def test_gsrb_tile_kernel(oracle, hip, case, tile_t, monkeypatch):
     monkeypatch.setenv("SUHMO_GSRB_TILE", "1")
     monkeypatch.setenv("SUHMO_TILE_T", str(tile_t))
     monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "100000000")
-    for sweeps in (1, 2, 3, 4, 7):
+    for sweeps in (1, 2, 3, 4, 7, 9, 16):           # 9, 16: a level that is one tile does them in one launch (2 / 4 chunks of 4)
         f, O, G = prep(oracle, hip, case)
         O.gsrb(sweeps); G.gsrb(sweeps)
         assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI)), sweeps
@@ -297,7 +297,7 @@ def test_vcycle_on_tile_kernels(oracle, hip, case, tile, fused_restrict, tile_t,
     O, G = pair(oracle, hip, f, bc, ph, alpha, beta, mb)
     O.build_mg_coefficients(); G.build_mg_coefficients()
     sp = dict(sy.SOLVER_DEFAULT, eps=1e-10, norm_thresh=1e-13, max_iter=3, imin=6)
-    for k in range(3):                                                   # the third cycle is the replayed HIP graph
+    for k in range(5):                                                   # from the second on: captured / replayed HIP graphs (two ping-pong states)
         O.vcycle(sp); G.vcycle(sp)
         assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI)), (k, float(np.max(np.abs(G.get(hip.F_PHI) - O.get(oracle.F_PHI)))))
     for d in range(1, G.ndepth):
