@@ -164,6 +164,7 @@ struct suhmo_level {
     int fused_nt;               // threads per workgroup of the fused kernel: 256 or 64 (env SUHMO_FUSED_NT)
     int fused_restrict;         // the last pre-smoothing launch also restricts (env SUHMO_FUSED_RESTRICT, default 1)
     int fused_hc;               // rows per chunk of the fused kernel (0 = auto); env SUHMO_FUSED_HC
+    int tile_strips;            // tile kernel on rank strips (env SUHMO_TILE_STRIPS, default 1)
     int tile_chunks;            // a level that is one tile relaxes all its sweeps in one launch (env SUHMO_TILE_CHUNKS, default 1)
     int fas_rhs_in_relax;       // coarse FAS right-hand side formed by the first tile relax of the depth (env SUHMO_FAS_RHS_IN_RELAX, default 1)
     long tile_max_cells;        // auto mode: levels below this many cells relax on the tile kernel (env SUHMO_TILE_MAX_CELLS)

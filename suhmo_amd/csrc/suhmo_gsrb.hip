@@ -364,6 +364,7 @@ struct TileGeom {
     const double *pc, *pco; int Pc, gyc;     // prolongIncrement fused into the load (as in FusedGeom)
     double *rres, *rphi; int rP, rgy;        // RST: coarse RES / PHI canvases
     int frhs;                                // first relaxation of a coarse FAS depth: rhs = res + L(phi) is formed here
+    int jbeg, jend;                          // rows written: the level's, plus on a rank strip the halo rows that stay current for the next launch
     int chunks;                              // level = one tile: this many times S sweeps in the launch (halo images refreshed in LDS)
 };
 struct PairCoef { double rhs0, rhs1, B0, B1, Pi0, Pi1, zb0, zb1, mk0, mk1, a0, a1, byS0, byS1, byN0, byN1, bx0, bx1, bx2; };
@@ -384,14 +385,15 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
     __shared__ double lds[LY * LX];
     __shared__ double lq[RST ? TY * TX : 1];                  // RST: (rhs - L(phi)) / 4 of the tile's cells
     const int tx = blockIdx.x % g.ntx, ty = blockIdx.x / g.ntx;
-    const int gx0 = tx * TX - HX, gy0 = ty * TY - HY;         // domain cell of LDS cell (0, 0)
+    const int tj0 = g.jbeg + ty * TY;                         // first row the tile writes
+    const int gx0 = tx * TX - HX, gy0 = tj0 - HY;             // domain cell of LDS cell (0, 0)
     const int t = threadIdx.x;
     // a coarse-fine side takes precedence over the domain's periodicity (the patch does not wrap onto itself)
     const bool perx = v.per[0] && !v.cfx[0] && !v.cfx[1], pery = v.per[1] && !v.ext[0] && !v.ext[1];
     // sides of the LDS region that reach a physical boundary: nothing beyond them feeds the tile
     // (a coarse-fine side of an AMR patch: once the stored ghost column / row is in the region)
     const bool openW = !perx && gx0 <= (v.cfx[0] ? -1 : 0), openE = !perx && gx0 + LX - 1 >= v.nx - 1 + (v.cfx[1] ? 1 : 0);
-    const bool openS = !pery && gy0 <= (v.ext[0] ? -1 : 0), openN = !pery && gy0 + LY - 1 >= v.ny - 1 + (v.ext[1] ? 1 : 0);
+    const bool openS = !pery && !v.rk[0] && gy0 <= (v.ext[0] ? -1 : 0), openN = !pery && !v.rk[1] && gy0 + LY - 1 >= v.ny - 1 + (v.ext[1] ? 1 : 0);
     auto wrap = [](int i, int n) { i %= n; return i < 0 ? i + n : i; };
     auto ld2 = [&](const double *__restrict__ p, int idx) { return *reinterpret_cast<const double2 *>(p + idx); };
 
@@ -407,10 +409,12 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
         if (q < NPAIR) {
             const int ly = q / NP, lx = 2 * (q % NP);
             int i = gx0 + lx, j = gy0 + ly;
-            const bool inx = perx || (i >= 0 && i < v.nx), iny = pery || (j >= 0 && j < v.ny);
+            // (rank boundary of a strip: the rows beyond are the neighbour's cells, held in the canvas' halo rows with their
+            //  coefficients; they are advanced redundantly like periodic images, without the wrap)
+            const bool inx = perx || (i >= 0 && i < v.nx), iny = pery || (j >= 0 && j < v.ny) || (j < 0 && v.rk[0] && j >= g.jbeg - HY) || (j >= v.ny && v.rk[1] && j < g.jend + HY);   // (only the halo rows the written rows depend on: the canvas ends at gy)
             // AMR patch: the ghost column / row beyond a coarse-fine side holds interpolated data: loaded, never advanced
             const bool exi = inx || (i == -2 && v.cfx[0]) || (i == v.nx && v.cfx[1]);
-            const bool exj = iny || (j == -1 && v.ext[0]) || (j == v.ny && v.ext[1]);
+            const bool exj = iny || (j == -1 && v.ext[0] && !v.rk[0]) || (j == v.ny && v.ext[1] && !v.rk[1]);
             double2 p2 = make_double2(0.0, 0.0);
             if (exi && exj) {
                 live = inx && iny;
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
                     }
                     // (a cell on the region's edge, which no pass advances, gets a value nobody reads)
                     q_.rhs0 = 1.0 * q_.rhs0 + 1.0 * lo[0]; q_.rhs1 = 1.0 * q_.rhs1 + 1.0 * lo[1];
-                    if (lx >= HX && lx < HX + TX && ly >= HY && ly < HY + TY && i < v.nx && j < v.ny) {
+                    if (lx >= HX && lx < HX + TX && ly >= HY && ly < HY + TY && i < v.nx && j < g.jend) {
                         const int idx = cidx(v, i, j);
                         *reinterpret_cast<double2 *>(fp.f[SUHMO_F_LPHI] + idx) = make_double2(lo[0], lo[1]);
                         *reinterpret_cast<double2 *>(fp.f[SUHMO_F_RHS] + idx) = make_double2(q_.rhs0, q_.rhs1);
@@ -555,9 +559,9 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
     }
     }
 
-    const int oi1 = (tx * TX + TX < v.nx) ? tx * TX + TX : v.nx, oj1 = (ty * TY + TY < v.ny) ? ty * TY + TY : v.ny;
+    const int oi1 = (tx * TX + TX < v.nx) ? tx * TX + TX : v.nx, oj1 = (tj0 + TY < g.jend) ? tj0 + TY : g.jend;
     const int wi0 = tx * TX - ((tx == 0 && v.cfx[0]) ? 1 : 0), wi1 = oi1 + ((oi1 == v.nx && v.cfx[1]) ? 1 : 0);
-    const int wj0 = ty * TY - ((ty == 0 && v.ext[0]) ? 1 : 0), wj1 = oj1 + ((oj1 == v.ny && v.ext[1]) ? 1 : 0);
+    const int wj0 = tj0 - ((ty == 0 && v.ext[0] && !v.rk[0]) ? 1 : 0), wj1 = oj1 + ((oj1 == v.ny && v.ext[1] && !v.rk[1]) ? 1 : 0);
     auto store = [&](const int k, const PairCoef &q_, const bool) {
         const int q = t + 256 * k;
         if (q < NPAIR) {
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
                 else if (m0) pout[cidx(v, i, j)] = lds[ly * LX + lx];
                 else if (m1) pout[cidx(v, i + 1, j)] = lds[ly * LX + lx + 1];
             }
-            if (lx >= HX && lx < HX + TX && ly >= HY && ly < HY + TY && i < v.nx && j < v.ny) {
+            if (lx >= HX && lx < HX + TX && ly >= HY && ly < HY + TY && i < v.nx && j >= 0 && j < v.ny) {   // (halo rows: advanced, not restricted)
                 if constexpr (RST) {
                     const double *row = lds + ly * LX;
 #pragma unroll
@@ -604,8 +608,8 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
         __syncthreads();
         if (t < TX * TY / 4) {
             const int cx = t % (TX / 2), cy = t / (TX / 2);
-            const int i = tx * TX + 2 * cx, j = ty * TY + 2 * cy;
-            if (i < v.nx && j < v.ny) {
+            const int i = tx * TX + 2 * cx, j = tj0 + 2 * cy;
+            if (i < v.nx && j >= 0 && j < v.ny) {
                 const double *q0 = lq + (2 * cy) * TX + 2 * cx, *p0 = lds + (HY + 2 * cy) * LX + HX + 2 * cx;
                 double acc = 0.0, accp = 0.0;
                 acc = acc + q0[0]; accp = accp + p0[0] / 4.0;
@@ -623,14 +627,15 @@ static bool tile_ok(const suhmo_level *L, const Depth &D)
 {
     const DV &v = D.v;
     if (!L->gsrb_tile || (v.nx & 1)) return false;
-    if (v.rk[0] || v.rk[1]) return false;                     // rank strips (halo rows advanced redundantly): colour passes / streaming kernel
+    if ((v.rk[0] || v.rk[1]) && (!L->ex || !L->tile_strips || L->desc.nx_global > 0 || v.gy < 10 || v.ny < 10)) return false;   // rank strips: 2S + 1
+                                                              // valid halo rows per launch (AMR patch strips: colour passes)
     if (v.per[1] && (v.ny & 1)) return false;                 // colour of a periodic image = colour of the cell
     if ((v.per[0] && v.cfx[0] != v.cfx[1]) || (v.per[1] && v.ext[0] != v.ext[1])) return false;   // patch on one side of a periodic domain
     return true;
 }
 
 template <int S, int T, bool RST = false>
-static int launch_tile(suhmo_level *L, int depth, int chunks, hipStream_t st)
+static int launch_tile(suhmo_level *L, int depth, int chunks, int ext_rows, hipStream_t st)
 {
     Depth &D = L->d[depth];
     const DV &v = D.v;
@@ -640,7 +645,8 @@ static int launch_tile(suhmo_level *L, int depth, int chunks, hipStream_t st)
     }
     TileGeom g;
     constexpr int TX = TileShape<T, RST>::TX, TY = TileShape<T, RST>::TY;
-    g.ntx = (v.nx + TX - 1) / TX; g.nty = (v.ny + TY - 1) / TY;
+    g.jbeg = v.rk[0] ? -ext_rows : 0; g.jend = v.ny + (v.rk[1] ? ext_rows : 0);
+    g.ntx = (v.nx + TX - 1) / TX; g.nty = (g.jend - g.jbeg + TY - 1) / TY;
     g.pc = g.pco = nullptr; g.Pc = g.gyc = 0;
     g.rres = g.rphi = nullptr; g.rP = g.rgy = 0;
     if (RST) {
@@ -692,15 +698,15 @@ static int single_tile(const suhmo_level *L, const DV &v)
     if (L->tile_t != 16 && v.nx <= 32 && v.ny <= 28) return 32;   // (the restricting variant of the 32-wide tile is 28 rows high)
     return 0;
 }
-static int launch_tile_any(suhmo_level *L, int depth, int S, int chunks, bool rst, hipStream_t st)
+static int launch_tile_any(suhmo_level *L, int depth, int S, int chunks, bool rst, int ext_rows, hipStream_t st)
 {
     const int T = chunks > 1 ? single_tile(L, L->d[depth].v) : tile_edge(L, L->d[depth].v);
     if (rst) {
-        if (T == 32) return S == 4 ? launch_tile<4, 32, true>(L, depth, chunks, st) : S == 2 ? launch_tile<2, 32, true>(L, depth, chunks, st) : launch_tile<1, 32, true>(L, depth, chunks, st);
-        return S == 4 ? launch_tile<4, 16, true>(L, depth, chunks, st) : S == 2 ? launch_tile<2, 16, true>(L, depth, chunks, st) : launch_tile<1, 16, true>(L, depth, chunks, st);
+        if (T == 32) return S == 4 ? launch_tile<4, 32, true>(L, depth, chunks, ext_rows, st) : S == 2 ? launch_tile<2, 32, true>(L, depth, chunks, ext_rows, st) : launch_tile<1, 32, true>(L, depth, chunks, ext_rows, st);
+        return S == 4 ? launch_tile<4, 16, true>(L, depth, chunks, ext_rows, st) : S == 2 ? launch_tile<2, 16, true>(L, depth, chunks, ext_rows, st) : launch_tile<1, 16, true>(L, depth, chunks, ext_rows, st);
     }
-    if (T == 32) return S == 4 ? launch_tile<4, 32>(L, depth, chunks, st) : S == 2 ? launch_tile<2, 32>(L, depth, chunks, st) : launch_tile<1, 32>(L, depth, chunks, st);
-    return S == 4 ? launch_tile<4, 16>(L, depth, chunks, st) : S == 2 ? launch_tile<2, 16>(L, depth, chunks, st) : launch_tile<1, 16>(L, depth, chunks, st);
+    if (T == 32) return S == 4 ? launch_tile<4, 32>(L, depth, chunks, ext_rows, st) : S == 2 ? launch_tile<2, 32>(L, depth, chunks, ext_rows, st) : launch_tile<1, 32>(L, depth, chunks, ext_rows, st);
+    return S == 4 ? launch_tile<4, 16>(L, depth, chunks, ext_rows, st) : S == 2 ? launch_tile<2, 16>(L, depth, chunks, ext_rows, st) : launch_tile<1, 16>(L, depth, chunks, ext_rows, st);
 }
 
 static int pick_variant(const suhmo_level *L, const Depth &D)
@@ -737,6 +743,7 @@ bool suhmo_gsrb_can_fuse_rhs(suhmo_level *L, int depth, int sweeps)
 {
     Depth &D = L->d[depth];
     if (sweeps < 1 || !L->fas_rhs_in_relax) return false;
+    if (D.v.rk[0] || D.v.rk[1]) return false;                 // rank strips: k_apply<., 2> also copies the halo rows of R phi
     return pick_K(L, D, pick_variant(L, D), sweeps) <= 0 && tile_ok(L, D);
 }
 bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps)
@@ -744,7 +751,12 @@ bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps)
     Depth &D = L->d[depth];
     if (sweeps < 1 || depth + 1 >= L->ndepth) return false;
     int K = pick_K(L, D, pick_variant(L, D), sweeps);
-    if (K <= 0) return tile_ok(L, D);
+    if (K <= 0) {
+        if (!tile_ok(L, D)) return false;
+        if (!(D.v.rk[0] || D.v.rk[1])) return true;
+        const int TS = sweeps >= 4 && L->tile_s >= 4 ? 4 : sweeps >= 2 && L->tile_s >= 2 ? 2 : 1;
+        return prolong_halo_rows(L, depth) >= 2 * TS;        // else: un-fused prolongation, then an exchange
+    }
     const bool ext = L->ex && (D.v.ext[0] || D.v.ext[1]);
     if ((D.v.ext[0] || D.v.ext[1]) && !ext) return false;                 // stored ghost rows without a transport (AMR patch)
     return !ext || prolong_halo_rows(L, depth) >= 2 * K;                  // else: un-fused prolongation, then an exchange
@@ -772,7 +784,29 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
     int it = 0;
     while (it < sweeps) {
         int K = pick_K(L, D, variant, sweeps - it);   // sweeps done by the next launch (0 = simple path, 1 sweep)
-        const int TS = (K == 0 && tile_ok(L, D)) ? (sweeps - it >= 4 && L->tile_s >= 4 ? 4 : sweeps - it >= 2 && L->tile_s >= 2 ? 2 : 1) : 0;   // sweeps of a tile launch
+        int TS = (K == 0 && tile_ok(L, D)) ? (sweeps - it >= 4 && L->tile_s >= 4 ? 4 : sweeps - it >= 2 && L->tile_s >= 2 ? 2 : 1) : 0;   // sweeps of a tile launch
+        int tE = 0;                                            // rank strip: halo rows the tile launch advances redundantly
+        bool trst = TS && restricted && L->fused_restrict && depth + 1 < L->ndepth && !(D.v.ny & 1) && !(D.v.j0 & 1);
+        if (TS && ext) {
+            // rank strip: the tile's halo rows beyond the strip are the neighbour's cells: 2S of them must be current (one more
+            // when the launch also restricts); they are advanced redundantly and stale afterwards
+            trst = trst && it + TS == sweeps;
+            const int need = 2 * TS + (trst ? 1 : 0);
+            if (F < need && !D.prolong_pending) {
+                int rc = suhmo_ensure_phi_halo(L, depth, need, st); if (rc) return rc;
+                F = D.phi_fresh;
+            }
+            if (F < need) {
+                if (D.prolong_pending) { suhmo_set_error("internal: fused prolongation with a shallow halo"); return -4; }
+                TS = 0;                                        // halo shallower than the tile needs: colour passes
+            } else {
+                // as many more halo rows as the work still to come can use are advanced too (one exchange feeds several launches)
+                const int want = 2 * (sweeps - it - TS) + tail;
+                tE = F - need < want ? F - need : want;
+                if (tE > D.v.gy - need - 1) tE = D.v.gy - need - 1;
+                tE = tE < 0 ? 0 : tE & ~1;
+            }
+        }
         if (K == 0 && !TS && D.prolong_pending) { suhmo_set_error("internal: prolong_pending without a fused relax"); return -4; }
         ProfEv pe{};
         bool prof = L->prof_on && depth == 0;
@@ -782,10 +816,11 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
         }
         int tchunks = 1;
         if (TS) {
-            if (L->tile_chunks && TS == 4 && single_tile(L, D.v)) tchunks = (sweeps - it) / TS;       // e.g. the 16 bottom sweeps in one launch (1: as before)
-            const bool rst = restricted && L->fused_restrict && depth + 1 < L->ndepth && !(D.v.ny & 1) && it + TS * tchunks == sweeps;
-            int rc = launch_tile_any(L, depth, TS, tchunks, rst, st); if (rc) return rc;
+            if (L->tile_chunks && !ext && TS == 4 && single_tile(L, D.v)) tchunks = (sweeps - it) / TS;       // e.g. the 16 bottom sweeps in one launch (1: as before)
+            const bool rst = trst && it + TS * tchunks == sweeps;
+            int rc = launch_tile_any(L, depth, TS, tchunks, rst, tE, st); if (rc) return rc;
             if (rst) *restricted = 1;
+            if (ext) { F = tE; D.phi_fresh = tE; }
         } else if (K == 0) {
             for (int pass = 0; pass < 2; pass++) {
                 if (ext && F < 1) {

@@ -101,6 +101,8 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     L->tile_max_cells = 8000000;
     L->fas_rhs_in_relax = 1;
     L->tile_chunks = 1;
+    L->tile_strips = 1;
+    if (const char *e = getenv("SUHMO_TILE_STRIPS")) L->tile_strips = atoi(e);
     if (const char *e = getenv("SUHMO_TILE_CHUNKS")) L->tile_chunks = atoi(e);
     if (const char *e = getenv("SUHMO_FAS_RHS_IN_RELAX")) L->fas_rhs_in_relax = atoi(e);
     if (const char *e = getenv("SUHMO_TILE_MAX_CELLS")) L->tile_max_cells = atol(e);
