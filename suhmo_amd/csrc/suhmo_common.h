@@ -164,6 +164,8 @@ struct suhmo_level {
     int fused_nt;               // threads per workgroup of the fused kernel: 256 or 64 (env SUHMO_FUSED_NT)
     int fused_restrict;         // the last pre-smoothing launch also restricts (env SUHMO_FUSED_RESTRICT, default 1)
     int fused_hc;               // rows per chunk of the fused kernel (0 = auto); env SUHMO_FUSED_HC
+    int strips_rhs_local;       // rank strips: R phi and RES travel together, the coarse right-hand side of the halo rows is computed locally
+                                // (env SUHMO_STRIPS_RHS_LOCAL, default 1)
     int tile_strips;            // tile kernel on rank strips (env SUHMO_TILE_STRIPS, default 1)
     int tile_chunks;            // a level that is one tile relaxes all its sweeps in one launch (env SUHMO_TILE_CHUNKS, default 1)
     int fas_rhs_in_relax;       // coarse FAS right-hand side formed by the first tile relax of the depth (env SUHMO_FAS_RHS_IN_RELAX, default 1)
@@ -186,7 +188,7 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
                                                     // rows worth keeping valid at exit; restricted: see there
 void suhmo_level_drop_graphs(suhmo_level *L);                                     // suhmo_fas.hip
 int suhmo_ensure_phi_halo(suhmo_level *L, int depth, int need, hipStream_t st);      // suhmo_level.hip
-int suhmo_fas_coarse_rhs(suhmo_level *L, int depth, hipStream_t st);                // suhmo_level.hip
+int suhmo_fas_coarse_rhs(suhmo_level *L, int depth, hipStream_t st, int hcomp = 0);  // suhmo_level.hip; hcomp: halo rows that get rhs computed too
 // Result of a reduction whose last kernel was launched with suhmo_host_slot(L): 8 bytes back on the host.
 struct HostSlot { double *val; unsigned long long *flag; unsigned long long seq; };
 HostSlot suhmo_host_slot(suhmo_level *L);                                           // suhmo_level.hip; call right before the launch

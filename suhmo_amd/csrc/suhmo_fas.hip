@@ -58,18 +58,26 @@ static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, i
     if (!restricted && (rc = suhmo_restrict_both(L, dep, (hipStream_t)s))) return rc;   // RES[dep+1] and PHI[dep+1] = R(phi); the fused
                                                                                   //  relaxation may have written them already
     static const bool one_pass_rhs = !(getenv("SUHMO_FAS_RHS_FUSED") && atoi(getenv("SUHMO_FAS_RHS_FUSED")) == 0);
-    if ((rc = suhmo_ensure_phi_halo(L, dep + 1, suhmo_halo_rows(C.v), (hipStream_t)s))) return rc;   // strips: before PHIOLD is taken, so that
-                                                                                                      // it carries the halo rows too
+    // rank strips: R phi and RES travel in one message group and the right-hand side of the halo rows is computed here from them,
+    // bit for bit what the neighbour computes for its own rows: the exchange of RHS disappears
+    const bool rhs_local = L->ex && (C.v.rk[0] || C.v.rk[1]) && one_pass_rhs && L->desc.nx_global == 0 && L->strips_rhs_local
+                           && suhmo_halo_rows(C.v) >= 2;
+    if (rhs_local) {
+        static const int both[2] = {SUHMO_F_PHI, SUHMO_F_RES};
+        if ((rc = suhmo_exchange_list(L, dep + 1, both, 2, (hipStream_t)s))) return rc;
+    } else if ((rc = suhmo_ensure_phi_halo(L, dep + 1, suhmo_halo_rows(C.v), (hipStream_t)s))) return rc;   // strips: before PHIOLD is taken, so
+                                                                                                             // that it carries the halo rows too
     if (one_pass_rhs && (L->desc.nx_global == 0)) {
         const int next_sweeps = (dep + 1 == nd - 1) ? sp->num_bottom : S;
         if (suhmo_gsrb_can_fuse_rhs(L, dep + 1, next_sweeps)) C.rhs_pending = 1;   // ... inside the first relaxation of the depth
-        else if ((rc = suhmo_fas_coarse_rhs(L, dep + 1, (hipStream_t)s))) return rc;   // PHIOLD = R phi, rhs_c = res_c + L_c(R phi): one pass
+        else if ((rc = suhmo_fas_coarse_rhs(L, dep + 1, (hipStream_t)s, rhs_local ? suhmo_halo_rows(C.v) - 1 : 0))) return rc;   // PHIOLD = R phi,
+                                                                                   // rhs_c = res_c + L_c(R phi): one pass
     } else {
         HIPCHK(hipMemcpyAsync(C.fp.f[SUHMO_F_PHIOLD], C.fp.f[SUHMO_F_PHI], C.elems * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)s));
         if ((rc = suhmo_level_apply_op(L, dep + 1, 0, s))) return rc;             // LPHI = L_c(R phi)
         if ((rc = suhmo_level_axby(L, dep + 1, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
     }
-    if ((rc = suhmo_level_exchange(L, dep + 1, SUHMO_F_RHS, s))) return rc;   // strips: rhs halo rows for the fused relax
+    if (!rhs_local && (rc = suhmo_level_exchange(L, dep + 1, SUHMO_F_RHS, s))) return rc;   // strips: rhs halo rows for the fused relax
     if ((rc = fas_cycle(L, dep + 1, sp, nd, s))) return rc;
     if (suhmo_gsrb_can_fuse_prolong(L, dep, S)) {
         L->d[dep].prolong_pending = 1;      // phi += P(phi_c - phi_c,old) happens inside the first post-smoothing pass

@@ -102,6 +102,8 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     L->fas_rhs_in_relax = 1;
     L->tile_chunks = 1;
     L->tile_strips = 1;
+    L->strips_rhs_local = 1;
+    if (const char *e = getenv("SUHMO_STRIPS_RHS_LOCAL")) L->strips_rhs_local = atoi(e);
     if (const char *e = getenv("SUHMO_TILE_STRIPS")) L->tile_strips = atoi(e);
     if (const char *e = getenv("SUHMO_TILE_CHUNKS")) L->tile_chunks = atoi(e);
     if (const char *e = getenv("SUHMO_FAS_RHS_IN_RELAX")) L->fas_rhs_in_relax = atoi(e);
@@ -434,14 +436,19 @@ extern "C" int suhmo_level_fill_ghosts(suhmo_level_t *L, int depth, int field, i
 // VCNLCOMPUTEOP2D / VCNLCOMPUTERES2D with BC, NL fused.  MODE 0: LPHI = L(phi); 1: RES = rhs - L(phi);
 // 2: the FAS right-hand side of a coarse depth in one pass: LPHI = L(phi), RHS = axby(RES, LPHI, 1, 1), PHIOLD = phi
 template <bool HAS_ALPHA, int MODE>
-__global__ __launch_bounds__(256) void k_apply(DV v, FP fp, suhmo_phys_t ph, int homog, int halo = 0)
+__global__ __launch_bounds__(256) void k_apply(DV v, FP fp, suhmo_phys_t ph, int homog, int halo = 0, int hcomp = 0)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - halo;     // MODE 2 on a rank strip: the halo rows only copy phi
     if (i >= v.nx || j >= v.ny + halo) return;
     const double *__restrict__ phi = fp.f[SUHMO_F_PHI];
     int idx = cidx(v, i, j);
-    if (MODE == 2 && (j < 0 || j >= v.ny)) { fp.f[SUHMO_F_PHIOLD][idx] = phi[idx]; return; }
+    if (MODE == 2 && (j < 0 || j >= v.ny)) {
+        // rank strip: the first hcomp halo rows beyond a rank boundary get the neighbour's right-hand side computed here (its phi
+        // and RES were exchanged together), which saves the exchange of RHS; the rows further out only copy phi
+        const bool comp = (j < 0 && v.rk[0] && j >= -hcomp) || (j >= v.ny && v.rk[1] && j < v.ny + hcomp);
+        if (!comp) { fp.f[SUHMO_F_PHIOLD][idx] = phi[idx]; return; }
+    }
     double c = phi[idx];
     double e = phiE(v, phi, idx, i, c, homog), w = phiW(v, phi, idx, i, c, homog);
     double n = phiN(v, phi, idx, j, c, homog), s = phiS(v, phi, idx, j, c, homog);
@@ -505,13 +512,13 @@ extern "C" int suhmo_level_apply_op(suhmo_level_t *L, int depth, int homogeneous
 
 // FAS cycle, coarse depth after the restriction: rhs_c = res_c + L_c(R phi) and the copy of R phi the prolongation
 // subtracts (on a rank strip with its exchanged halo rows), one pass instead of applyOp + axby + a device copy
-int suhmo_fas_coarse_rhs(suhmo_level *L, int depth, hipStream_t st)
+int suhmo_fas_coarse_rhs(suhmo_level *L, int depth, hipStream_t st, int hcomp)
 {
     Depth &D = L->d[depth];
     if (!suhmo_field(L, depth, SUHMO_F_LPHI) || !suhmo_field(L, depth, SUHMO_F_PHIOLD)) return -2;
     const int halo = (D.v.ext[0] || D.v.ext[1]) ? D.v.gy : 0;
-    if (D.v.alpha != 0.0) hipLaunchKernelGGL((k_apply<true, 2>), grid2d(D.v.nx, D.v.ny + 2 * halo), BLK2D, 0, st, D.v, D.fp, L->ph, 0, halo);
-    else hipLaunchKernelGGL((k_apply<false, 2>), grid2d(D.v.nx, D.v.ny + 2 * halo), BLK2D, 0, st, D.v, D.fp, L->ph, 0, halo);
+    if (D.v.alpha != 0.0) hipLaunchKernelGGL((k_apply<true, 2>), grid2d(D.v.nx, D.v.ny + 2 * halo), BLK2D, 0, st, D.v, D.fp, L->ph, 0, halo, hcomp);
+    else hipLaunchKernelGGL((k_apply<false, 2>), grid2d(D.v.nx, D.v.ny + 2 * halo), BLK2D, 0, st, D.v, D.fp, L->ph, 0, halo, hcomp);
     HIPCHK(hipGetLastError());
     return 0;
 }
