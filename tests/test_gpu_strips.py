@@ -114,11 +114,22 @@ def test_strips_gsrb_and_operators(case, variant, halo, monkeypatch):
     assert all(p[4] == ref[4] for p in parts)       # MAX all-reduce of the norm
 
 
-@pytest.mark.parametrize("world,halo,fused", [(2, 4, 0), (4, 4, 0), (2, 16, 0), (4, 9, 0), (2, 16, 1), (4, 12, 1), (2, 24, 0), (2, 24, 1), (4, 24, 1), (2, 1, 0)])
+@pytest.mark.parametrize("world,halo,fused", [(2, 4, 0), (4, 4, 0), (2, 16, 0), (4, 9, 0), (2, 16, 1), (4, 12, 1), (2, 24, 0), (2, 24, 1), (4, 24, 1), (2, 1, 0),
+                                              (2, 24, "no-tile"), (4, 12, "no-tile"), (2, 24, "rhs-exchanged"), (2, 24, "copy-readback")])
 def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
+    """strips of 2 / 4 ranks against the oracle's whole level, bitwise.  Halo >= 10 rows: the tile kernel relaxes the strips
+    (halo rows advanced redundantly), R phi + RES travel together and the halo rows' right-hand side is computed locally; the
+    named variants keep the paths they replace covered (colour passes, exchanged RHS, copy + synchronise read-back)"""
     from suhmo_amd import level as lv
-    if fused:
+    if fused == 1:
         monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "4000")     # fused K=2 launches down to 64 x 64 strips
+        monkeypatch.setenv("SUHMO_GSRB_TILE", "0")
+    elif fused == "no-tile":
+        monkeypatch.setenv("SUHMO_TILE_STRIPS", "0")
+    elif fused == "rhs-exchanged":
+        monkeypatch.setenv("SUHMO_STRIPS_RHS_LOCAL", "0")
+    elif fused == "copy-readback":
+        monkeypatch.setenv("SUHMO_POLL_READBACK", "0")
     f = sy.shmip_fields(256, 256)
     bc, ph = sy.A3_BC, sy.A3_PHYS
     sp = dict(sy.SOLVER_DEFAULT, eps=1e-10, norm_thresh=1e-13, max_iter=4, imin=4)
