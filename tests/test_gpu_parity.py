@@ -310,6 +310,40 @@ def test_vcycle_on_tile_kernels(oracle, hip, case, tile, fused_restrict, tile_t,
     assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI))
 
 
+def _random_tile_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    nx = 2 * int(rng.integers(1, 60))
+    per = [int(rng.integers(0, 2)), int(rng.integers(0, 2))]
+    ny = int(rng.integers(1, 90))
+    if per[1]:
+        ny += ny & 1                                         # periodic y: even number of rows (the colour of an image)
+    bc = dict(type=[[int(rng.integers(0, 2)), int(rng.integers(0, 2))], [int(rng.integers(0, 2)), int(rng.integers(0, 2))]],
+              value=[[float(rng.uniform(-5, 5)), float(rng.uniform(-0.05, 0.05))], [float(rng.uniform(-0.05, 0.05)), float(rng.uniform(-5, 5))]],
+              periodic=per)
+    alpha = float(rng.choice([0.0, 0.0, 0.37]))
+    return nx, ny, bc, alpha, int(rng.integers(1, 12)), int(rng.choice([0, 16, 32]))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_tile_kernel_random_shapes(hip, seed, monkeypatch):
+    """tile kernel against the colour passes (both on the device) on random level shapes (2..118 x 1..90, narrower and lower
+    than a tile, ragged last tiles), boundary types / values, periodicity, alpha and sweep counts: bitwise, ghosts included"""
+    nx, ny, bc, alpha, sweeps, tile_t = _random_tile_case(seed)
+    f = sy.random_fields(nx, ny, seed=2000 + seed)
+    out = []
+    for tile in (0, 1):
+        monkeypatch.setenv("SUHMO_GSRB_TILE", str(tile))
+        monkeypatch.setenv("SUHMO_TILE_T", str(tile_t))
+        monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "100000000")
+        G = hip.HipLevel(nx, ny, f["dx"], f["dy"], bc, sy.RANDOM_PHYS, alpha, -1.0, 64)
+        G.set_inputs(f)
+        G.gsrb(sweeps)
+        out.append(G.get(hip.F_PHI, ghosted=True))
+        G.close()
+    assert np.array_equal(out[0][1:-1, 1:-1], out[1][1:-1, 1:-1]), (nx, ny, bc, alpha, sweeps, tile_t)
+    assert np.array_equal(out[0][1:-1, :], out[1][1:-1, :]) and np.array_equal(out[0][:, 1:-1], out[1][:, 1:-1])
+
+
 def test_full_size_properties(hip):
     """BASELINE size (4096^2): size-independent properties instead of the (slow) oracle:
     GSRB fixed point, residual == rhs - applyOp, restriction of a constant, idempotent
