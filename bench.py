@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_PER_CELL_SWEEP = 72.0    # phi r+w, rhs, bx, by, B, Pi, zb, mask
+LX = 1.0e5                     # width of the synthetic domain in metres (SHMIP-A: 100 km)
 
 
 def main():
@@ -59,7 +60,10 @@ def main():
     assert capi.lib().suhmo_device_count() > 0, "no GPU visible: the product path has no CPU fallback"
 
     ny_global = n * world
-    f = sy.shmip_fields(n, n, j0=rank * n, ny_total=ny_global)
+    # square cells (100 km across n columns, as many metres per row): on them the cycle being timed is a contractive solver
+    # (SHMIP-A's own 20 km width over n rows would make the cells 5 : 1, where point relaxation stalls: same arithmetic per
+    # cycle, but not a solve anybody would run)
+    f = sy.shmip_fields(n, n, ly=LX * ny_global / n, j0=rank * n, ny_total=ny_global)
     G = level.HipLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64, j0=rank * n,
                        ny_global=ny_global, device=local_rank, halo_rows=int(os.environ.get("SUHMO_HALO_ROWS", "24")) if world > 1 else 1)
     G.set_inputs(f)
@@ -76,6 +80,7 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    G.residual(); res_before = G.norm(level.F_RES, 0)     # max norm over all ranks (outside the timed region)
     for _ in range(args.warmup):
         G.vcycle(sp)
     sync()
@@ -91,6 +96,7 @@ def main():
         t = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    G.residual(); res_after = G.norm(level.F_RES, 0)
     gsrb_ms, gsrb_launches, gsrb_cells = G.profile_read()
     rst_ms, rst_launches, rst_cells = G.profile_read(restricting=True)
     G.profile(False)
@@ -159,12 +165,13 @@ def main():
             "value": vps * world, "unit": "V-cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "SHMIP-A head solve, %dx%d cells per GPU, single AMR level, 64x64 boxes, "
+            "config": {"workload": "SHMIP-A head solve, %dx%d cells per GPU (square cells of %.1f m), single AMR level, 64x64 boxes, "
                                    "%d MG depths, 4+4 GSRB sweeps per depth, %d bottom (BASELINE north_star: 4096^2 single-level)"
-                                   % (n, n, ndepth, sp["num_bottom"]),
+                                   % (n, n, LX / n, ndepth, sp["num_bottom"]),
                        "global_cells": [n, ny_global], "partition": "row strips, 1 per GPU" if world > 1 else "none",
                        "unit_of_value": "V-cycles over %dx%d cells (one per GPU per step; the level of %dx%d cells completes %.4g V-cycles/s)"
                                         % (n, n, n, ny_global, vps)},
+            "residual_max_norm": {"before_warmup": res_before, "after_timed_cycles": res_after, "cycles": args.warmup + args.steps},
             "gsrb_cell_updates_per_s": updates_per_vcycle * vps * world,
             "gsrb_depth0_cell_updates_per_s_kernel": cells / (sweep_ms * 1e-3) * world if gsrb_launches else None,
             "roofline": {"bound": "hbm", "kernel": "GSRB sweep (red+black) at depth 0", "achieved": achieved,
@@ -185,7 +192,7 @@ def side_configs(sy, level, sp, args):
     out = {}
     # configs[1]: SHMIP A3, 1024^2 single level
     n = 1024
-    f = sy.shmip_fields(n, n)
+    f = sy.shmip_fields(n, n, ly=LX)
     G = level.HipLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64)
     G.set_inputs(f); G.build_mg_coefficients()
     for _ in range(4):
@@ -282,7 +289,7 @@ def cpu_baseline(sy, n, sp):
     boxes, OpenMP over boxes), same workload, bounded sample: 1 warm-up + 2 timed V-cycles."""
     from oracle import pyoracle as po
     cores = host_cores()
-    f = sy.shmip_fields(n, n)
+    f = sy.shmip_fields(n, n, ly=LX)
     O = po.OracleLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64, nthreads=cores)
     O.set_inputs(f)
     O.build_mg_coefficients()
