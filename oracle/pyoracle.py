@@ -136,6 +136,23 @@ def lib():
         L.or_amr_vcycle.argtypes = [C.c_void_p, C.POINTER(OrSolverParams)]
         L.or_amr_solve.restype = C.c_int
         L.or_amr_solve.argtypes = [C.c_void_p, C.POINTER(OrSolverParams), dp]
+        ip = C.POINTER(C.c_int)
+        L.or_amrm_create.restype = C.c_void_p
+        L.or_amrm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(OrBC), C.POINTER(OrPhys),
+                                     C.c_double, C.c_double, C.c_int, ip, ip]
+        L.or_amrm_destroy.argtypes = [C.c_void_p]
+        L.or_amrm_box_io.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dp, C.c_int, C.c_int]
+        L.or_amrm_residual.restype = C.c_double
+        L.or_amrm_residual.argtypes = [C.c_void_p]
+        L.or_amrm_vcycle.argtypes = [C.c_void_p, C.POINTER(OrSolverParams)]
+        L.or_amrm_solve.restype = C.c_int
+        L.or_amrm_solve.argtypes = [C.c_void_p, C.POINTER(OrSolverParams), dp]
+        L.or_amrm_cf_interp_phi.argtypes = [C.c_void_p, C.c_int]
+        L.or_amrm_exchange.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.or_amrm_gsrb.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.or_amrm_level_residual.argtypes = [C.c_void_p, C.c_int]
+        L.or_amrm_update_operator.argtypes = [C.c_void_p, C.c_int]
+        L.or_amrm_average_down.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.or_prolong2_global.argtypes = [dp, dp, C.c_int, C.c_int]
         L.or_divergence_global.argtypes = [dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double]
         L.or_difterm_global.argtypes = [dp, dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double]
@@ -514,5 +531,87 @@ class OracleAmr:
     def close(self):
         if self.h:
             lib().or_amr_destroy(self.h)
+            self.h = None
+            self.coarse.close()
+
+
+class OracleAmrM:
+    """Base level + levels that are unions of boxes (boxes[l-1] = list of (lo0, lo1, hi0, hi1) in the index space of level l):
+    oracle/amrm.c"""
+
+    def __init__(self, nx0, ny0, dx0, dy0, bc, phys, boxes, alpha=0.0, beta=-1.0, max_box=64, nthreads=1):
+        self.coarse = OracleLevel(nx0, ny0, dx0, dy0, bc, phys, alpha, beta, max_box, nthreads)
+        self.boxes = [[tuple(int(v) for v in b) for b in bl] for bl in boxes]
+        self.nlev = 1 + len(self.boxes)
+        nbox = (C.c_int * self.nlev)(0, *[len(bl) for bl in self.boxes])
+        flat = [v for bl in self.boxes for b in bl for v in b]
+        arr = (C.c_int * max(len(flat), 1))(*flat)
+        self.h = lib().or_amrm_create(self.coarse.h, nx0, ny0, dx0, dy0, C.byref(self.coarse._bc), C.byref(self.coarse._ph),
+                                      alpha, beta, self.nlev, nbox, arr)
+        if not self.h:
+            self.coarse.close()
+            raise ValueError("boxes misaligned, overlapping or not properly nested")
+
+    def box_shape(self, l, k, field, ghosted=False):
+        lo0, lo1, hi0, hi1 = self.boxes[l - 1][k]
+        nxp, nyp = hi0 - lo0 + 1, hi1 - lo1 + 1
+        if field == F_BX:
+            return (nyp, nxp + 1)
+        if field == F_BY:
+            return (nyp + 1, nxp)
+        return (nyp + 2, nxp + 2) if ghosted else (nyp, nxp)
+
+    def box_set(self, l, k, field, arr, ghosted=False):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        assert a.shape == self.box_shape(l, k, field, ghosted), (a.shape, self.box_shape(l, k, field, ghosted))
+        lib().or_amrm_box_io(self.h, l, k, field, _dp(a), int(ghosted), 1)
+
+    def box_get(self, l, k, field, ghosted=False):
+        out = np.zeros(self.box_shape(l, k, field, ghosted))
+        lib().or_amrm_box_io(self.h, l, k, field, _dp(out), int(ghosted), 0)
+        return out
+
+    def set_box_inputs(self, l, k, f):
+        self.box_set(l, k, F_PHI, f["phi"]); self.box_set(l, k, F_RHS, f["rhs"]); self.box_set(l, k, F_ACOEF, f["aCoef"])
+        for key, fid in (("B", F_B), ("Pi", F_PI), ("zb", F_ZB), ("mask", F_MASK)):
+            self.box_set(l, k, fid, f[key], ghosted=True)
+
+    def set_inputs(self, fs):
+        """fs as suhmo_amd.synthetic.amrm_fields returns it"""
+        self.coarse.set_inputs(fs[0])
+        self.coarse.build_mg_coefficients()
+        for l in range(1, self.nlev):
+            for k, f in enumerate(fs[l]):
+                self.set_box_inputs(l, k, f)
+
+    def level_array(self, l, field):
+        """valid cells of level l >= 1 over its whole domain (NaN where the level has no box)"""
+        nx, ny = self.coarse.nx << l, self.coarse.ny << l
+        out = np.full((ny, nx), np.nan)
+        for k, (lo0, lo1, hi0, hi1) in enumerate(self.boxes[l - 1]):
+            out[lo1:hi1 + 1, lo0:hi0 + 1] = self.box_get(l, k, field)
+        return out
+
+    def residual(self): return lib().or_amrm_residual(self.h)
+    def cf_interp_phi(self, l): lib().or_amrm_cf_interp_phi(self.h, l)
+    def exchange(self, l, field, corners=False): lib().or_amrm_exchange(self.h, l, field, int(corners))
+    def gsrb(self, l, sweeps): lib().or_amrm_gsrb(self.h, l, sweeps)
+    def level_residual(self, l): lib().or_amrm_level_residual(self.h, l)
+    def update_operator(self, l): lib().or_amrm_update_operator(self.h, l)
+    def average_down(self, l, field): lib().or_amrm_average_down(self.h, l, field)
+
+    def vcycle(self, sp):
+        s = make_solver_params(sp)
+        lib().or_amrm_vcycle(self.h, C.byref(s))
+
+    def solve(self, sp):
+        s = make_solver_params(sp)
+        hist = np.zeros(s.max_iter + 2)
+        n = lib().or_amrm_solve(self.h, C.byref(s), _dp(hist))
+        return n, hist[: n + 1]
+
+    def close(self):
+        if self.h:
+            lib().or_amrm_destroy(self.h)
             self.h = None
             self.coarse.close()

@@ -215,6 +215,45 @@ def amr_fields(nx0=64, ny0=16, patches=(CFG3_PATCH,), lx=64.0, ly=16.0, slope=0.
     return out
 
 
+def amrm_fields(nx0=64, ny0=16, boxes=(), lx=64.0, ly=16.0, slope=0.02, ice_height=500.0, gap_init=0.01,
+                moulin=(16.015625, 8.015625, 1.0, 30.0), background=1.0e-11, seed=2024, vary_B=True):
+    """Inputs of a hierarchy whose levels >= 1 are unions of boxes: boxes[l-1] = list of (lo0, lo1, hi0, hi1) in the index
+    space of level l.  Returns [level0 dict, [box dicts of level 1], ...].  The analytic functions of amr_fields; the head
+    perturbation is drawn once per level over the level's whole domain, so that the same level cut into different boxes
+    gets the same data (ghost cells of a box = the neighbour's valid cells or the function's own values)."""
+    def whole(nxg, nyg, rng):
+        dx, dy = lx / nxg, ly / nyg
+        i = np.arange(-1, nxg + 1, dtype=np.float64)
+        j = np.arange(-1, nyg + 1, dtype=np.float64)
+        X, Y = np.meshgrid((i + 0.5) * dx, (j + 0.5) * dy)
+        zb = slope * X
+        H = np.maximum(6.0 * (np.sqrt(np.maximum(X + ice_height, 0.0)) - np.sqrt(ice_height)) + 1.0, 0.0)
+        Pi = np.maximum(RHO_I * GRAV * H, 0.0)
+        mask = np.where(Pi > 0.0, 1.0, -1.0)
+        B = np.full_like(X, gap_init)
+        if vary_B:
+            B = B * (1.0 + 0.3 * np.sin(2.0 * np.pi * X / (0.5 * lx)) * np.cos(2.0 * np.pi * Y / ly))
+        mx, my, sig, flux = moulin
+        src = background + flux / (2.0 * np.pi * sig * sig) * np.exp(-((X - mx) ** 2 + (Y - my) ** 2) / (2.0 * sig * sig)) * 1.0e-6
+        phi = 101325.0 / (RHO_W * GRAV) + zb + 1.0e-3 * rng.uniform(-1.0, 1.0, size=X.shape)
+        return dict(dx=dx, dy=dy, phi=phi, rhs=src, B=B, Pi=Pi, zb=zb, mask=mask)
+
+    def cut(w, lo0, lo1, hi0, hi1):
+        nx, ny = hi0 - lo0 + 1, hi1 - lo1 + 1
+        g = (slice(lo1, hi1 + 3), slice(lo0, hi0 + 3))          # ghosted window (the arrays start at index -1)
+        v = (slice(lo1 + 1, hi1 + 2), slice(lo0 + 1, hi0 + 2))
+        return dict(nx=nx, ny=ny, dx=w["dx"], dy=w["dy"], box=(lo0, lo1, hi0, hi1), phi=np.ascontiguousarray(w["phi"][v]),
+                    rhs=np.ascontiguousarray(w["rhs"][v]), aCoef=np.zeros((ny, nx)), B=np.ascontiguousarray(w["B"][g]),
+                    Pi=np.ascontiguousarray(w["Pi"][g]), zb=np.ascontiguousarray(w["zb"][g]), mask=np.ascontiguousarray(w["mask"][g]))
+    out = [cut(whole(nx0, ny0, np.random.default_rng([seed, 0])), 0, 0, nx0 - 1, ny0 - 1)]
+    nxg, nyg = nx0, ny0
+    for l, bl in enumerate(boxes):
+        nxg, nyg = 2 * nxg, 2 * nyg
+        w = whole(nxg, nyg, np.random.default_rng([seed, l + 1]))
+        out.append([cut(w, *b) for b in bl])
+    return out
+
+
 def amr2_fields(nxc=64, nyc=16, patch=CFG3_PATCH, **kw):
     """(coarse, fine): the two-level case of amr_fields"""
     c, f = amr_fields(nxc, nyc, (patch,), **kw)
