@@ -332,6 +332,34 @@ int suhmo_amr_timestep(suhmo_level_t **levels, int nlev, const suhmo_model_param
 int suhmo_amr_moulin_source(suhmo_level_t **levels, int nlev, const int *patch_boxes, int n_moulins, const double *positions,
                             const double *sigma, const double *flux, double time_factor, double *integrals, suhmo_stream_t s);
 
+/* ---- hierarchies whose levels are UNIONS OF BOXES, as the reference grids them (BRMeshRefine: several abutting and
+ * disjoint boxes per level, src/AmrHydro.cpp:4176-4604; exec/AMR_multiMoulins/run_C_3lev/input.hydro:37,64-83).
+ * Level 0 = the domain (desc `base`, one level handle with its multigrid depths); level l >= 1 = nbox[l] disjoint,
+ * coarse-aligned boxes (lo0, lo1, hi0, hi1 in the index space of level l, one after the other in `boxes`, level 1
+ * first; nbox[0] is ignored) refined by 2, whose union is properly nested in level l-1: coarsen(box) grown by 2 cells lies
+ * in the union of level l-1 or outside the domain.  Every box is a level handle of its own (suhmo_hier_box: load and read
+ * its fields with suhmo_level_set_field / get_field, ghosted = with the box's own ghost ring) keeping ITS OWN ghost cells,
+ * as a Chombo box does; ghost cells are fine-fine (another box of the level holds the cell: suhmo_hier_exchange =
+ * Copier::exchange, src/VCAMRNonLinearPoissonOp.cpp:912-913), coarse-fine (suhmo_hier_cf_interp = QuadCFInterp with the
+ * tangential stencil restricted to coarse cells the level does not cover, suhmo_hier_pwl_fill = PiecewiseLinearFillPatch)
+ * or domain ghosts (physical BC).  The cycle is suhmo_amr_vcycle's; with one box per level the
+ * results equal suhmo_amr_*'s bit for bit.  Single process (no rank strips yet). */
+typedef struct suhmo_hier suhmo_hier_t;
+int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *base, int nlev, const int *nbox, const int *boxes);
+int suhmo_hier_destroy(suhmo_hier_t *H);
+int suhmo_hier_num_levels(const suhmo_hier_t *H);
+int suhmo_hier_num_boxes(const suhmo_hier_t *H, int level);
+suhmo_level_t *suhmo_hier_box(suhmo_hier_t *H, int level, int box);   /* level 0, box 0 = the base level */
+int suhmo_hier_exchange(suhmo_hier_t *H, int level, int field, int corners, suhmo_stream_t s);
+int suhmo_hier_cf_interp(suhmo_hier_t *H, int level, int field_f, int field_c, suhmo_stream_t s);   /* from level - 1 */
+int suhmo_hier_pwl_fill(suhmo_hier_t *H, int level, int field_f, int field_c, suhmo_stream_t s);
+int suhmo_hier_average(suhmo_hier_t *H, int level, int field_f, int field_c, suhmo_stream_t s);     /* into level - 1 [AMRRestrictS :1027-1069] */
+int suhmo_hier_gsrb(suhmo_hier_t *H, int level, int sweeps, suhmo_stream_t s);                      /* relax of one level */
+int suhmo_hier_update_operator(suhmo_hier_t *H, int level, suhmo_stream_t s);
+int suhmo_hier_residual(suhmo_hier_t *H, double *norm, suhmo_stream_t s);
+int suhmo_hier_vcycle(suhmo_hier_t *H, const suhmo_solver_params_t *sp, suhmo_stream_t s);
+int suhmo_hier_solve(suhmo_hier_t *H, const suhmo_solver_params_t *sp, int *iters, double *resid_hist, suhmo_stream_t s);
+
 /* timing helper: average device time (ms) of the depth-0 GSRB sweep kernel launches since the last reset, measured with
  * HIP events on the launch stream.  suhmo_level_profile_read: the plain K-sweep launches (k_gsrb_fused<K, ., ., false>);
  * suhmo_level_profile_read_restricting: the launches that end a pre-smoothing and also restrict (k_gsrb_fused<K, ., ., true>:

@@ -72,6 +72,9 @@ SYMBOLS = [
     "suhmo_amr2_vcycle", "suhmo_amr2_solve", "suhmo_level_moulin_source", "suhmo_amr2_prolong2", "suhmo_amr2_set_covered",
     "suhmo_amr_residual", "suhmo_amr_vcycle", "suhmo_amr_solve", "suhmo_level_postproc_table", "suhmo_level_postproc_partial", "suhmo_postproc_finish",
     "suhmo_level_set_alpha_beta", "suhmo_level_set_bc", "suhmo_amr2_reflux", "suhmo_amr2_pwl_fill", "suhmo_amr_timestep", "suhmo_level_time_varying_recharge", "suhmo_amr_moulin_source", "suhmo_amr2_prolong_pc", "suhmo_amr2_finer_operator_changed",
+    "suhmo_hier_create", "suhmo_hier_destroy", "suhmo_hier_num_levels", "suhmo_hier_num_boxes", "suhmo_hier_box", "suhmo_hier_exchange",
+    "suhmo_hier_cf_interp", "suhmo_hier_pwl_fill", "suhmo_hier_average", "suhmo_hier_gsrb", "suhmo_hier_update_operator",
+    "suhmo_hier_residual", "suhmo_hier_vcycle", "suhmo_hier_solve",
 ]
 
 
@@ -153,6 +156,22 @@ def lib():
     L.suhmo_amr2_residual.argtypes = [vp, vp, dp, vp]
     L.suhmo_amr2_vcycle.argtypes = [vp, vp, C.POINTER(SolverParams), vp]
     L.suhmo_amr2_solve.argtypes = [vp, vp, C.POINTER(SolverParams), C.POINTER(ci), dp, vp]
+    ip = C.POINTER(ci)
+    L.suhmo_hier_create.argtypes = [C.POINTER(vp), C.POINTER(LevelDesc), ci, ip, ip]
+    L.suhmo_hier_destroy.argtypes = [vp]
+    L.suhmo_hier_num_levels.argtypes = [vp]
+    L.suhmo_hier_num_boxes.argtypes = [vp, ci]
+    L.suhmo_hier_box.argtypes = [vp, ci, ci]
+    L.suhmo_hier_box.restype = vp
+    L.suhmo_hier_exchange.argtypes = [vp, ci, ci, ci, vp]
+    L.suhmo_hier_cf_interp.argtypes = [vp, ci, ci, ci, vp]
+    L.suhmo_hier_pwl_fill.argtypes = [vp, ci, ci, ci, vp]
+    L.suhmo_hier_average.argtypes = [vp, ci, ci, ci, vp]
+    L.suhmo_hier_gsrb.argtypes = [vp, ci, ci, vp]
+    L.suhmo_hier_update_operator.argtypes = [vp, ci, vp]
+    L.suhmo_hier_residual.argtypes = [vp, dp, vp]
+    L.suhmo_hier_vcycle.argtypes = [vp, C.POINTER(SolverParams), vp]
+    L.suhmo_hier_solve.argtypes = [vp, C.POINTER(SolverParams), ip, dp, vp]
     L.suhmo_level_profile_reset.argtypes = [vp]
     L.suhmo_level_profile_enable.argtypes = [vp, ci]
     L.suhmo_level_profile_read.argtypes = [vp, vp, dp, C.POINTER(C.c_long), C.POINTER(C.c_long)]

@@ -62,6 +62,16 @@ static void launch_simple(suhmo_level *L, int depth, int pass, int ext_rows, hip
         hipLaunchKernelGGL(k_gsrb_pass_simple<false>, grd, blk, 0, st, D.v, D.fp, L->ph, pass, jlo, jhi);
 }
 
+// one colour pass of one box of a multi-box AMR level (suhmo_hier.hip): in place, the ghost ring holds exchanged /
+// interpolated data
+int suhmo_gsrb_colour_pass(suhmo_level *L, int depth, int pass, hipStream_t st)
+{
+    launch_simple(L, depth, pass, 0, st);
+    HIPCHK(hipGetLastError());
+    L->d[depth].phi_fresh = 0;
+    return 0;
+}
+
 // ---- variant 1: K sweeps fused, streaming over rows ----
 struct FusedGeom {
     int W;        // owned columns per strip (even)

@@ -1,0 +1,934 @@
+// suhmo_hier.hip -- AMR hierarchies whose levels are UNIONS OF BOXES, the way the reference grids them
+// (BRMeshRefine with fill_ratio < 1 and block_factor 2: several abutting and disjoint boxes per level,
+// src/AmrHydro.cpp:4176-4604, exec/AMR_multiMoulins/run_C_3lev/input.hydro:37,64-83).
+//
+// Level 0 is one level handle (the domain, with its multigrid depths: every fast kernel of suhmo_gsrb.hip runs there).
+// A level l >= 1 is a list of rectangles, each an ordinary level handle created as a patch of the refined domain
+// (desc.i0 / nx_global / j0 / ny_global): a rectangle keeps its own ghost ring in its canvas, exactly as a Chombo box
+// keeps its own ghost cells -- at a re-entrant corner of the union the same index is the x-ghost of one box and the
+// y-ghost of another, with different interpolated values.  What ties the rectangles together is compiled ONCE, when
+// the hierarchy is created, into index plans that live in HBM; every inter-box / inter-level step is then one kernel
+// launch over a plan, whatever the number of boxes:
+//   ff      ghost cell <- the cell of the box of the same level that holds it (Copier::exchange,
+//           src/VCAMRNonLinearPoissonOp.cpp:912-913; sides, and corners for the fields exchanged with the default copier)
+//   cf      coarse-fine ghost cell <- QuadCFInterp from level l-1, the tangential stencil chosen on the host from the
+//           coverage of the coarse cells ([Chombo] QuadCFStencil; oracle/amrm.c:cf_interp states the same rule)
+//   pwl     ghost cell (corners included) <- PiecewiseLinearFillPatch from level l-1
+//   avg     rectangles (fine box x coarse box) for FORT_AVERAGE / zeroing covered cells
+//   win     per fine box the coarse correction over coarsen(box) grown by one cell, gathered from the boxes of level
+//           l-1 (the copyTo of AMRProlongS_2, src/AMRNonLinearPoissonOp.cpp:1156), then PROLONG_2_NL
+//   reflux  per coarse cell next to coarse-fine faces: its faces in the order (fine box, direction, side)
+// Field pointers of levels >= 1 are held in a device table per level (the boxes relax with in-place colour passes, so
+// the pointers never move); the base level's pointers travel as a kernel argument (its phi canvases ping-pong).
+//
+// Cycle = suhmo_amr.hip's, arithmetic = oracle/amrm.c, bit for bit.  [Chombo] pieces are
+// restated from upstream Chombo 3.2 (fork not vendored): unpinned against the reference.
+#include "suhmo_common.h"
+#include <algorithm>
+#include <map>
+
+int suhmo_grad_cc(suhmo_level *L, int depth, hipStream_t st);          // suhmo_level.hip
+int suhmo_re_bcoef_unfused(suhmo_level *L, int depth, hipStream_t st);
+int suhmo_re_cells(suhmo_level *L, int depth, hipStream_t st);
+int suhmo_copy_ghosts(suhmo_level *L, int depth, int field, hipStream_t st);
+int suhmo_gsrb_colour_pass(suhmo_level *L, int depth, int pass, hipStream_t st);   // suhmo_gsrb.hip
+
+namespace {
+struct Ref { int b, off; };                          // cell of a level: box index, canvas offset
+struct CopyEnt { Ref d, s; };
+struct CfEnt { Ref f; int step; int kind; int xsign; Ref c[3]; };
+// kind: 0 centred (c = cm, c0, cp)   1 forward 2nd order (c0, cp, cpp)   2 forward 1st order (c0, cp)
+//       3 backward 2nd order (c0, cm, cmm)   4 backward 1st order (c0, cm)   5 no tangential derivative (c0)
+struct PwlEnt { Ref f; Ref c[9]; int par; int sx, sy; };   // c[4] = the coarse cell; b = -1: outside the domain; par: bit0 gi&1, bit1 gj&1
+                                                           // sx, sy: slope stencil 0 central, 1 one-sided hi (no lo neighbour), 2 one-sided lo
+struct RectEnt { int fb, cb, foff, coff, w, h; };          // average: w x h coarse cells
+struct WinEnt { int cb, coff, woff, w, h; };               // window gather: w x h coarse cells into the window buffer
+struct Face { int dir, side; int fb, foff; Ref hi, lo, bq; };
+struct Target { Ref t; int first, count; };
+struct Win { int i0, j0, nx, ny; size_t base; };           // coarse window of a fine box: origin (level l-1 indices), size, offset in the level's buffer
+
+template <class T> struct DevVec {
+    T *d = nullptr; size_t n = 0;
+    int upload(const std::vector<T> &h)
+    {
+        n = h.size();
+        if (!n) return 0;
+        if (hipMalloc(&d, n * sizeof(T)) != hipSuccess) return -2;
+        if (hipMemcpy(d, h.data(), n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return -2;
+        return 0;
+    }
+    void release() { if (d) (void)hipFree(d); d = nullptr; n = 0; }
+};
+
+// spatial index of a level's boxes (bucket grid), for the point and rectangle queries of the plan builder
+struct BoxIndex {
+    int nxd = 0, nyd = 0, bs = 32, nbx = 0, nby = 0;
+    std::vector<int> start, items;
+    const std::vector<int> *b4 = nullptr;
+    void build(const std::vector<int> &boxes, int nx, int ny)
+    {
+        b4 = &boxes; nxd = nx; nyd = ny; nbx = (nx + bs - 1) / bs; nby = (ny + bs - 1) / bs;
+        std::vector<int> cnt((size_t)nbx * nby + 1, 0);
+        const int nb = (int)boxes.size() / 4;
+        for (int pass = 0; pass < 2; pass++) {
+            for (int k = 0; k < nb; k++) {
+                const int *b = &boxes[4 * k];
+                for (int by = b[1] / bs; by <= b[3] / bs; by++)
+                    for (int bx = b[0] / bs; bx <= b[2] / bs; bx++) {
+                        size_t q = (size_t)by * nbx + bx;
+                        if (pass == 0) cnt[q + 1]++; else items[start[q] + cnt[q]++] = k;
+                    }
+            }
+            if (pass == 0) {
+                start.assign(cnt.size(), 0);
+                for (size_t q = 1; q < cnt.size(); q++) start[q] = start[q - 1] + cnt[q];
+                items.resize(start.back());
+                std::fill(cnt.begin(), cnt.end(), 0);
+            }
+        }
+    }
+    int find(int i, int j) const            // box holding cell (i,j) (inside the domain), -1 = none
+    {
+        size_t q = (size_t)(j / bs) * nbx + i / bs;
+        for (int p = start[q]; p < start[q + 1]; p++) {
+            const int *b = &(*b4)[4 * items[p]];
+            if (i >= b[0] && i <= b[2] && j >= b[1] && j <= b[3]) return items[p];
+        }
+        return -1;
+    }
+};
+
+struct HLev {
+    int l = 0, nxd = 0, nyd = 0;
+    std::vector<suhmo_level *> box;
+    std::vector<int> b4;
+    BoxIndex index;
+    // plans (device)
+    DevVec<CopyEnt> ff_side, ff_corner;
+    DevVec<CfEnt> cf;
+    DevVec<PwlEnt> pwl;
+    DevVec<RectEnt> avg; int avg_w = 0, avg_h = 0;
+    DevVec<WinEnt> wing; int wing_w = 0, wing_h = 0;
+    DevVec<Target> targets; DevVec<Face> faces;
+    std::vector<Win> win; double *winbuf = nullptr; size_t winelems = 0; Win *d_win = nullptr; int *d_wing_box = nullptr;
+    // field pointer / view tables of the boxes
+    std::vector<FP> h_fp; FP *d_fp = nullptr; DV *d_dv = nullptr;
+};
+}  // namespace
+
+struct suhmo_hier {
+    int nlev = 0, device = 0;
+    HLev lev[8];
+    suhmo_bc_t bc;
+    suhmo_hier *gap = nullptr; double gap_dt = 0.0;        // implicit gap-height operator of the time step, owned
+};
+
+namespace {
+inline bool wrap_cell(const suhmo_hier *H, const HLev &V, int &i, int &j)
+{
+    if (H->bc.periodic[0]) { if (i < 0) i += V.nxd; else if (i >= V.nxd) i -= V.nxd; }
+    if (H->bc.periodic[1]) { if (j < 0) j += V.nyd; else if (j >= V.nyd) j -= V.nyd; }
+    return i >= 0 && i < V.nxd && j >= 0 && j < V.nyd;
+}
+inline int owner_of(const suhmo_hier *H, const HLev &V, int i, int j)
+{
+    if (!wrap_cell(H, V, i, j)) return -1;
+    if (V.l == 0) return 0;
+    return V.index.find(i, j);
+}
+// canvas reference of the cell (i,j) (level indices, wrapped into the domain) in the box that holds it; b = -1 if none
+inline Ref cell_ref(const suhmo_hier *H, const HLev &V, int i, int j)
+{
+    Ref r{-1, 0};
+    if (!wrap_cell(H, V, i, j)) return r;
+    int o = V.l == 0 ? 0 : V.index.find(i, j);
+    if (o < 0) return r;
+    const DV &v = V.box[o]->d[0].v;
+    r.b = o; r.off = cidx(v, i - v.i0, j - v.j0);
+    return r;
+}
+inline Ref local_ref(const HLev &V, int k, int il, int jl) { return Ref{k, cidx(V.box[k]->d[0].v, il, jl)}; }
+
+// ------------------------------------------------------------------ kernels over the plans
+__device__ __forceinline__ double *fptr(const FP *tab, const FP &base, int use_base, int b, int field)
+{
+    return use_base ? base.f[field] : tab[b].f[field];
+}
+__global__ void k_ff(const CopyEnt *__restrict__ e, int n, const FP *__restrict__ tab, int f0, int f1)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    CopyEnt c = e[t];
+    tab[c.d.b].f[f0][c.d.off] = tab[c.s.b].f[f0][c.s.off];
+    if (f1 >= 0) tab[c.d.b].f[f1][c.d.off] = tab[c.s.b].f[f1][c.s.off];
+}
+// [Chombo] QuadCFInterp (oracle/amrm.c:cf_interp)
+__global__ void k_cf(const CfEnt *__restrict__ e, int n, const FP *__restrict__ ftab, int ff, const FP *__restrict__ ctab, FP cbase,
+                     int use_base, int fc)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    CfEnt q = e[t];
+    const double c_s = 8.0 / 15.0, c_b = 2.0 / 3.0, c_a = -0.2;
+    const double xt = q.xsign ? 0.25 : -0.25;
+#define CVAL(m) fptr(ctab, cbase, use_base, q.c[m].b, fc)[q.c[m].off]
+    double c0, d1 = 0.0, d2 = 0.0;
+    if (q.kind == 0) { double cm = CVAL(0), cp = CVAL(2); c0 = CVAL(1); d1 = 0.5 * (cp - cm); d2 = cp - 2.0 * c0 + cm; }
+    else if (q.kind == 1) { c0 = CVAL(0); double cp = CVAL(1), cpp = CVAL(2); d1 = 0.5 * (-3.0 * c0 + 4.0 * cp - cpp); d2 = c0 - 2.0 * cp + cpp; }
+    else if (q.kind == 2) { c0 = CVAL(0); double cp = CVAL(1); d1 = cp - c0; }
+    else if (q.kind == 3) { c0 = CVAL(0); double cm = CVAL(1), cmm = CVAL(2); d1 = 0.5 * (3.0 * c0 - 4.0 * cm + cmm); d2 = c0 - 2.0 * cm + cmm; }
+    else if (q.kind == 4) { c0 = CVAL(0); double cm = CVAL(1); d1 = c0 - cm; }
+    else c0 = CVAL(0);
+#undef CVAL
+    double phistar = c0 + xt * d1 + (0.5 * xt * xt) * d2;
+    double *f = ftab[q.f.b].f[ff];
+    f[q.f.off] = c_s * phistar + c_b * f[q.f.off + q.step] + c_a * f[q.f.off + 2 * q.step];
+}
+// [Chombo] PiecewiseLinearFillPatch (oracle/amr_step.c:or_pwl_fill)
+__global__ void k_pwl(const PwlEnt *__restrict__ e, int n, const FP *__restrict__ ftab, int ff, const FP *__restrict__ ctab, FP cbase,
+                      int use_base, int fc)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    PwlEnt q = e[t];
+#define CVAL(m) fptr(ctab, cbase, use_base, q.c[m].b, fc)[q.c[m].off]
+    const double c0 = CVAL(4);
+    double s0, s1;
+    if (q.sx == 0) s0 = 0.5 * (CVAL(5) - CVAL(3)); else if (q.sx == 1) s0 = CVAL(5) - c0; else s0 = c0 - CVAL(3);
+    if (q.sy == 0) s1 = 0.5 * (CVAL(7) - CVAL(1)); else if (q.sy == 1) s1 = CVAL(7) - c0; else s1 = c0 - CVAL(1);
+    double smax = c0, smin = c0;
+    for (int m = 0; m < 9; m++) {
+        if (q.c[m].b < 0) continue;
+        double v = CVAL(m);
+        smax = fmax(smax, v); smin = fmin(smin, v);
+    }
+#undef CVAL
+    const double deltasum = 0.5 * (fabs(s0) + fabs(s1));
+    if (deltasum > 0.0) {
+        double etamax = (smax - c0) / deltasum, etamin = (c0 - smin) / deltasum;
+        double eta = fmax(fmin(fmin(etamin, etamax), 1.0), 0.0);
+        s0 = eta * s0; s1 = eta * s1;
+    }
+    double v = c0;
+    v = v + s0 * ((q.par & 1) ? 0.25 : -0.25);
+    v = v + s1 * ((q.par & 2) ? 0.25 : -0.25);
+    ftab[q.f.b].f[ff][q.f.off] = v;
+}
+// [Chombo] FORT_AVERAGE (mode 0) / covered cells <- val (mode 1)
+__global__ void k_avg(const RectEnt *__restrict__ e, const FP *__restrict__ ftab, const DV *__restrict__ fdv, int ff,
+                      const FP *__restrict__ ctab, const DV *__restrict__ cdv, FP cbase, DV cbdv, int use_base, int fc, int mode, double val)
+{
+    RectEnt q = e[blockIdx.z];
+    int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y * blockDim.y + threadIdx.y;
+    if (I >= q.w || J >= q.h) return;
+    const int Pc = use_base ? cbdv.P : cdv[q.cb].P;
+    double *c = fptr(ctab, cbase, use_base, q.cb, fc);
+    if (mode == 1) { c[q.coff + J * Pc + I] = val; return; }
+    const int Pf = fdv[q.fb].P;
+    const double *f = ftab[q.fb].f[ff];
+    int b = q.foff + 2 * J * Pf + 2 * I;
+    double s = 0.0;
+    s = s + f[b]; s = s + f[b + 1]; s = s + f[b + Pf]; s = s + f[b + Pf + 1];
+    c[q.coff + J * Pc + I] = s * 0.25;
+}
+__global__ void k_win_gather(const WinEnt *__restrict__ e, double *__restrict__ wbuf, const FP *__restrict__ ctab, const DV *__restrict__ cdv,
+                             FP cbase, DV cbdv, int use_base, int fc, const Win *__restrict__ wins, const int *__restrict__ went_box)
+{
+    WinEnt q = e[blockIdx.z];
+    int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y * blockDim.y + threadIdx.y;
+    if (I >= q.w || J >= q.h) return;
+    const int Pc = use_base ? cbdv.P : cdv[q.cb].P;
+    const double *c = fptr(ctab, cbase, use_base, q.cb, fc);
+    const Win w = wins[went_box[blockIdx.z]];
+    wbuf[w.base + q.woff + (size_t)J * w.nx + I] = c[q.coff + J * Pc + I];
+}
+// physical BC of the coarse level on the window of every fine box (m_bc on a_temp, AMRProlongS_2 :1160-1166), along the
+// coarsened box's own extent only: the corner cells beyond it are never written (value 0)
+__global__ void k_win_bc(const Win *__restrict__ wins, int nwin, double *__restrict__ wbuf, DV cv /* a view of level l-1: BC data, domain size */)
+{
+    int k = blockIdx.y;
+    if (k >= nwin) return;
+    const Win w = wins[k];
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int inx = w.nx - 2, iny = w.ny - 2;             // the coarsened box itself
+    double *p = wbuf + w.base;
+    int dir, side, tt;
+    if (t < 2 * iny) { dir = 0; side = t / iny; tt = t % iny; }
+    else { t -= 2 * iny; if (t >= 2 * inx) return; dir = 1; side = t / inx; tt = t % inx; }
+    if (cv.per[dir]) return;
+    const int ndom = dir == 0 ? cv.nxg : cv.nyg;
+    const int g = dir == 0 ? (side ? w.i0 + w.nx - 1 : w.i0) : (side ? w.j0 + w.ny - 1 : w.j0);   // global index of the ghost layer
+    if (g >= 0 && g <= ndom - 1) return;
+    const int il = dir == 0 ? (side ? w.nx - 1 : 0) : tt + 1, jl = dir == 0 ? tt + 1 : (side ? w.ny - 1 : 0);
+    const int in_ = dir == 0 ? (side ? w.nx - 2 : 1) : il, jn_ = dir == 0 ? jl : (side ? w.ny - 2 : 1);
+    const double nearv = p[(size_t)jn_ * w.nx + in_];
+    double gv;
+    if (cv.bct[dir][side] == 0) gv = cv.two_v[dir][side] - nearv; else gv = nearv + cv.neu[dir][side];
+    p[(size_t)jl * w.nx + il] = gv;
+}
+// PROLONG_2_NL (src/AMRNonLinearPoissonOpF.ChF:660-705) of every box of a level from its window
+__global__ void k_prolong2_win(const Win *__restrict__ wins, const double *__restrict__ wbuf, const FP *__restrict__ ftab, const DV *__restrict__ fdv)
+{
+    const int k = blockIdx.z;
+    const DV v = fdv[k];
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || j >= v.ny) return;
+    const Win w = wins[k];
+    const double *c = wbuf + w.base;
+    const double den = 1.0 / 16.0, fx1 = 3.0 * den, fx2 = 9.0 * den, f0 = 1.0 * den;
+    int gi = i + v.i0, gj = j + v.j0;
+    int ic = gi / 2, jc = gj / 2, o1 = 2 * (gi % 2) - 1, o2 = 2 * (gj % 2) - 1;
+    int cc = (jc - w.j0) * w.nx + (ic - w.i0);
+    double *phi = ftab[k].f[SUHMO_F_PHI];
+    int idx = cidx(v, i, j);
+    double p = phi[idx];
+    p = p + fx2 * c[cc] + f0 * c[cc + o1 + o2 * w.nx];
+    p = p + fx1 * (c[cc + o1] + c[cc + o2 * w.nx]);
+    phi[idx] = p;
+}
+// [Chombo] LevelFluxRegister (oracle/amrm.c:reflux): one thread per coarse cell next to coarse-fine faces
+__global__ void k_reflux(const Target *__restrict__ tg, int n, const Face *__restrict__ faces, const FP *__restrict__ ftab, const DV *__restrict__ fdv,
+                         const FP *__restrict__ ctab, FP cbase, int use_base, int field_c, double dxc, double dyc, double beta)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Target T = tg[t];
+    double *lof = fptr(ctab, cbase, use_base, T.t.b, field_c);
+    const double rscale = 1.0 / (dxc * dyc);
+    double acc = lof[T.t.off];
+    for (int m = 0; m < T.count; m++) {
+        Face f = faces[T.first + m];
+        const double dxd = f.dir == 0 ? dxc : dyc, tsize = f.dir == 0 ? dyc : dxc;
+        const double cs = beta * 1 / dxd, fs = beta * 2 / dxd;
+        const double sign = f.side == 0 ? 1.0 : -1.0;
+        double phihi = fptr(ctab, cbase, use_base, f.hi.b, SUHMO_F_PHI)[f.hi.off], philo = fptr(ctab, cbase, use_base, f.lo.b, SUHMO_F_PHI)[f.lo.off];
+        double bc_ = fptr(ctab, cbase, use_base, f.bq.b, f.dir == 0 ? SUHMO_F_BX : SUHMO_F_BY)[f.bq.off];
+        double Fc = -bc_ * ((phihi - philo) * cs);
+        double reg = -(tsize * Fc);
+        const double *phif = ftab[f.fb].f[SUHMO_F_PHI], *bf = ftab[f.fb].f[f.dir == 0 ? SUHMO_F_BX : SUHMO_F_BY];
+        const int Pf = fdv[f.fb].P;
+        for (int k = 0; k < 2; k++) {
+            int idx = f.foff + (f.dir == 0 ? k * Pf : k);
+            double ph_hi = phif[idx], ph_lo = f.dir == 0 ? phif[idx - 1] : phif[idx - Pf];
+            double Ff = -bf[idx] * ((ph_hi - ph_lo) * fs);
+            reg = reg + (tsize * Ff) * 0.5;
+        }
+        acc = acc + sign * rscale * reg;
+    }
+    lof[T.t.off] = acc;
+}
+
+// ------------------------------------------------------------------ plan building (host)
+int build_plans(suhmo_hier *H, int l)
+{
+    HLev &F = H->lev[l], &C = H->lev[l - 1];
+    const int nb = (int)F.box.size();
+    std::vector<CopyEnt> ffs, ffc;
+    std::vector<CfEnt> cf;
+    std::vector<PwlEnt> pwl;
+    std::vector<RectEnt> avg;
+    std::vector<WinEnt> wing; std::vector<int> wing_box;
+    F.win.resize(nb);
+    size_t wtot = 0;
+    auto good_cell = [&](int I, int J) -> bool {          // coarse cell (I,J) of level l-1 good for tangential stencils?
+        if (!wrap_cell(H, C, I, J)) return false;
+        return F.index.find(2 * I, 2 * J) < 0;
+    };
+    for (int k = 0; k < nb; k++) {
+        const int *b = &F.b4[4 * k];
+        const DV &v = F.box[k]->d[0].v;
+        // ---- ghost ring: fine-fine copies, coarse-fine interpolation entries, linear fill entries
+        for (int j = b[1] - 1; j <= b[3] + 1; j++)
+            for (int i = b[0] - 1; i <= b[2] + 1; i++) {
+                const bool gx = i < b[0] || i > b[2], gy = j < b[1] || j > b[3];
+                if (!gx && !gy) continue;
+                int iw = i, jw = j;
+                if (!wrap_cell(H, F, iw, jw)) continue;                       // domain ghost
+                const Ref me = local_ref(F, k, i - b[0], j - b[1]);
+                const int o = F.index.find(iw, jw);
+                if (o >= 0) {
+                    const DV &vo = F.box[o]->d[0].v;
+                    CopyEnt e{me, Ref{o, cidx(vo, iw - vo.i0, jw - vo.j0)}};
+                    (gx && gy ? ffc : ffs).push_back(e);
+                    continue;
+                }
+                // coarse-fine cell
+                {
+                    PwlEnt p;
+                    p.f = me; p.par = (iw & 1) | ((jw & 1) << 1);
+                    const int I = iw >> 1, J = jw >> 1;
+                    for (int jj = -1; jj <= 1; jj++)
+                        for (int ii = -1; ii <= 1; ii++) {
+                            int In = I + ii, Jn = J + jj;
+                            Ref r{-1, 0};
+                            if (In >= 0 && In <= C.nxd - 1 && Jn >= 0 && Jn <= C.nyd - 1) {     // as or_pwl_fill: no periodic images
+                                r = cell_ref(H, C, In, Jn);
+                                if (r.b < 0) { suhmo_set_error("hier: level %d is not properly nested in level %d (linear fill stencil)", l, l - 1); return -1; }
+                            }
+                            p.c[(jj + 1) * 3 + (ii + 1)] = r;
+                        }
+                    p.sx = (I - 1 >= 0 && I + 1 <= C.nxd - 1) ? 0 : (I - 1 < 0 ? 1 : 2);
+                    p.sy = (J - 1 >= 0 && J + 1 <= C.nyd - 1) ? 0 : (J - 1 < 0 ? 1 : 2);
+                    pwl.push_back(p);
+                }
+                if (gx && gy) continue;                                       // QuadCFInterp: sides only
+                const int dir = gx ? 0 : 1, side = gx ? (i < b[0] ? 0 : 1) : (j < b[1] ? 0 : 1);
+                const int g = dir == 0 ? i : j, t = dir == 0 ? j : i;
+                CfEnt e;
+                e.f = me; e.step = (side == 0 ? 1 : -1) * (dir == 0 ? 1 : v.P);
+                e.xsign = t & 1;
+                const int icn = g >> 1, ict = t >> 1;
+                auto good = [&](int o_) { return dir == 0 ? good_cell(icn, ict + o_) : good_cell(ict + o_, icn); };
+                auto cref = [&](int o_) { return dir == 0 ? cell_ref(H, C, icn, ict + o_) : cell_ref(H, C, ict + o_, icn); };
+                const bool lo = good(-1), hi = good(1);
+                int need[3] = {0, 0, 0}, nneed = 1;
+                if (lo && hi) { e.kind = 0; need[0] = -1; need[1] = 0; need[2] = 1; nneed = 3; }
+                else if (hi) { if (good(2)) { e.kind = 1; need[1] = 1; need[2] = 2; nneed = 3; } else { e.kind = 2; need[1] = 1; nneed = 2; } }
+                else if (lo) { if (good(-2)) { e.kind = 3; need[1] = -1; need[2] = -2; nneed = 3; } else { e.kind = 4; need[1] = -1; nneed = 2; } }
+                else e.kind = 5;
+                for (int m = 0; m < 3; m++) {
+                    e.c[m] = m < nneed ? cref(need[m]) : Ref{0, 0};
+                    if (m < nneed && e.c[m].b < 0) { suhmo_set_error("hier: level %d is not properly nested in level %d (coarse-fine stencil)", l, l - 1); return -1; }
+                }
+                cf.push_back(e);
+            }
+        // ---- average / covered rectangles: coarsen(box) split over the boxes of level l-1
+        const int ci0 = b[0] / 2, cj0 = b[1] / 2, ci1 = b[2] / 2, cj1 = b[3] / 2;
+        auto split = [&](int I0, int J0, int I1, int J1, auto &&emit) -> int {     // region inside the domain
+            if (C.l == 0) { emit(0, I0, J0, I1, J1); return 0; }
+            long cells = 0;
+            for (int by = J0 / C.index.bs; by <= J1 / C.index.bs; by++)
+                for (int bx = I0 / C.index.bs; bx <= I1 / C.index.bs; bx++) {
+                    size_t q = (size_t)by * C.index.nbx + bx;
+                    for (int p = C.index.start[q]; p < C.index.start[q + 1]; p++) {
+                        const int o = C.index.items[p];
+                        const int *cb = &C.b4[4 * o];
+                        // each box once: only from the bucket that holds the corner of the intersection
+                        int a0 = std::max(I0, cb[0]), a1 = std::min(I1, cb[2]), c0 = std::max(J0, cb[1]), c1 = std::min(J1, cb[3]);
+                        if (a0 > a1 || c0 > c1) continue;
+                        if (a0 / C.index.bs != bx || c0 / C.index.bs != by) continue;
+                        emit(o, a0, c0, a1, c1);
+                        cells += (long)(a1 - a0 + 1) * (c1 - c0 + 1);
+                    }
+                }
+            if (cells != (long)(I1 - I0 + 1) * (J1 - J0 + 1)) { suhmo_set_error("hier: level %d is not nested in level %d", l, l - 1); return -1; }
+            return 0;
+        };
+        int rc = split(ci0, cj0, ci1, cj1, [&](int o, int a0, int c0, int a1, int c1) {
+            const DV &vc = C.box[o]->d[0].v;
+            avg.push_back(RectEnt{k, o, cidx(v, 2 * a0 - b[0], 2 * c0 - b[1]), cidx(vc, a0 - vc.i0, c0 - vc.j0), a1 - a0 + 1, c1 - c0 + 1});
+        });
+        if (rc) return rc;
+        // ---- window: coarsen(box) grown by one cell, gathered from level l-1 (periodic images included)
+        Win &w = F.win[k];
+        w.i0 = ci0 - 1; w.j0 = cj0 - 1; w.nx = ci1 - ci0 + 3; w.ny = cj1 - cj0 + 3; w.base = wtot;
+        wtot += (size_t)w.nx * w.ny;
+        for (int sy = -1; sy <= 1; sy++)
+            for (int sx = -1; sx <= 1; sx++) {
+                if ((sx && !H->bc.periodic[0]) || (sy && !H->bc.periodic[1])) continue;
+                // window cells [w.i0 .. ] that are images (shifted by sx nxd, sy nyd) of domain cells
+                int I0 = std::max(w.i0, sx * C.nxd), I1 = std::min(w.i0 + w.nx - 1, sx * C.nxd + C.nxd - 1);
+                int J0 = std::max(w.j0, sy * C.nyd), J1 = std::min(w.j0 + w.ny - 1, sy * C.nyd + C.nyd - 1);
+                if (I0 > I1 || J0 > J1) continue;
+                rc = split(I0 - sx * C.nxd, J0 - sy * C.nyd, I1 - sx * C.nxd, J1 - sy * C.nyd, [&](int o, int a0, int c0, int a1, int c1) {
+                    const DV &vc = C.box[o]->d[0].v;
+                    wing.push_back(WinEnt{o, cidx(vc, a0 - vc.i0, c0 - vc.j0), (c0 + sy * C.nyd - w.j0) * w.nx + (a0 + sx * C.nxd - w.i0), a1 - a0 + 1, c1 - c0 + 1});
+                    wing_box.push_back(k);
+                });
+                if (rc) return rc;
+            }
+    }
+    // ---- reflux: faces grouped by the coarse cell they feed, in the order (fine box, direction, side)
+    std::map<std::pair<int, int>, std::vector<Face>> by_target;
+    std::vector<std::pair<int, int>> order;
+    for (int k = 0; k < nb; k++) {
+        const int *b = &F.b4[4 * k];
+        const DV &v = F.box[k]->d[0].v;
+        const int ci0 = b[0] / 2, cj0 = b[1] / 2, ci1 = b[2] / 2, cj1 = b[3] / 2;
+        for (int dir = 0; dir < 2; dir++) {
+            const int ndomc = dir == 0 ? C.nxd : C.nyd;
+            for (int side = 0; side < 2; side++) {
+                const int Fc = dir == 0 ? (side == 0 ? ci0 : ci1 + 1) : (side == 0 ? cj0 : cj1 + 1);
+                const int outside = side == 0 ? Fc - 1 : Fc;
+                if ((outside < 0 || outside > ndomc - 1) && !H->bc.periodic[dir]) continue;
+                const int tlo = dir == 0 ? cj0 : ci0, thi = dir == 0 ? cj1 : ci1;
+                for (int T = tlo; T <= thi; T++) {
+                    const int oi = dir == 0 ? outside : T, oj = dir == 0 ? T : outside;
+                    if (owner_of(H, F, 2 * oi, 2 * oj) >= 0) continue;                 // fine-fine side
+                    Face f;
+                    f.dir = dir; f.side = side; f.fb = k;
+                    f.foff = dir == 0 ? cidx(v, 2 * Fc - b[0], 2 * T - b[1]) : cidx(v, 2 * T - b[0], 2 * Fc - b[1]);
+                    f.hi = dir == 0 ? cell_ref(H, C, Fc, T) : cell_ref(H, C, T, Fc);
+                    f.lo = dir == 0 ? cell_ref(H, C, Fc - 1, T) : cell_ref(H, C, T, Fc - 1);
+                    if (f.hi.b < 0 || f.lo.b < 0) { suhmo_set_error("hier: level %d is not properly nested in level %d (reflux)", l, l - 1); return -1; }
+                    f.bq = f.hi;                                                       // the face is the low face of its high-side cell
+                    Ref t = side == 0 ? f.lo : f.hi;
+                    auto key = std::make_pair(t.b, t.off);
+                    if (!by_target.count(key)) order.push_back(key);
+                    by_target[key].push_back(f);
+                }
+            }
+        }
+    }
+    std::vector<Target> targets; std::vector<Face> faces;
+    for (auto &key : order) {
+        auto &fv = by_target[key];
+        targets.push_back(Target{Ref{key.first, key.second}, (int)faces.size(), (int)fv.size()});
+        faces.insert(faces.end(), fv.begin(), fv.end());
+    }
+    int rc = 0;
+    rc |= F.ff_side.upload(ffs); rc |= F.ff_corner.upload(ffc); rc |= F.cf.upload(cf); rc |= F.pwl.upload(pwl);
+    rc |= F.avg.upload(avg); rc |= F.wing.upload(wing); rc |= F.targets.upload(targets); rc |= F.faces.upload(faces);
+    if (rc) { suhmo_set_error("hier: plan upload failed"); return -2; }
+    F.avg_w = F.avg_h = F.wing_w = F.wing_h = 0;
+    for (auto &e : avg) { F.avg_w = std::max(F.avg_w, e.w); F.avg_h = std::max(F.avg_h, e.h); }
+    for (auto &e : wing) { F.wing_w = std::max(F.wing_w, e.w); F.wing_h = std::max(F.wing_h, e.h); }
+    F.winelems = wtot;
+    if (hipMalloc(&F.winbuf, std::max<size_t>(1, wtot) * sizeof(double)) != hipSuccess) { suhmo_set_error("hier: window allocation failed"); return -2; }
+    (void)hipMemset(F.winbuf, 0, std::max<size_t>(1, wtot) * sizeof(double));
+    if (hipMalloc(&F.d_win, std::max<size_t>(1, F.win.size()) * sizeof(Win)) != hipSuccess) return -2;
+    if (hipMalloc(&F.d_wing_box, std::max<size_t>(1, wing_box.size()) * sizeof(int)) != hipSuccess) return -2;
+    if (hipMemcpy(F.d_win, F.win.data(), F.win.size() * sizeof(Win), hipMemcpyHostToDevice) != hipSuccess) return -2;
+    if (!wing_box.empty() && hipMemcpy(F.d_wing_box, wing_box.data(), wing_box.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -2;
+    return 0;
+}
+}  // namespace
+
+// ------------------------------------------------------------------ tables, launches of the plans
+namespace {
+#define HST(s) ((hipStream_t)(s))
+inline suhmo_level *base_of(suhmo_hier *H) { return H->lev[0].box[0]; }
+inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+// device table of the boxes' field pointers (levels >= 1).  The boxes relax in place, so a pointer changes only when a
+// field is allocated for the first time: then the table is uploaded again (rare; synchronous).
+int refresh_tables(suhmo_hier *H, int l, hipStream_t st)
+{
+    HLev &V = H->lev[l];
+    if (l == 0) return 0;
+    const size_t nb = V.box.size();
+    bool dirty = V.d_fp == nullptr;
+    if (V.h_fp.size() != nb) { V.h_fp.assign(nb, FP{}); dirty = true; }
+    for (size_t k = 0; k < nb; k++)
+        if (memcmp(&V.h_fp[k], &V.box[k]->d[0].fp, sizeof(FP))) { V.h_fp[k] = V.box[k]->d[0].fp; dirty = true; }
+    if (!dirty) return 0;
+    HIPCHK(hipStreamSynchronize(st));
+    if (!V.d_fp) HIPCHK(hipMalloc(&V.d_fp, nb * sizeof(FP)));
+    HIPCHK(hipMemcpy(V.d_fp, V.h_fp.data(), nb * sizeof(FP), hipMemcpyHostToDevice));
+    if (!V.d_dv) {
+        std::vector<DV> dv(nb);
+        for (size_t k = 0; k < nb; k++) dv[k] = V.box[k]->d[0].v;
+        HIPCHK(hipMalloc(&V.d_dv, nb * sizeof(DV)));
+        HIPCHK(hipMemcpy(V.d_dv, dv.data(), nb * sizeof(DV), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+int ensure_field(suhmo_hier *H, int l, int field)
+{
+    for (suhmo_level *L : H->lev[l].box) if (!suhmo_field(L, 0, field)) { suhmo_set_error("field allocation failed"); return -2; }
+    return 0;
+}
+// coarse-side arguments of a kernel that reads / writes level l-1
+struct CoarseArgs { const FP *tab; const DV *dv; FP base; DV bdv; int use_base; };
+int coarse_args(suhmo_hier *H, int lc, hipStream_t st, CoarseArgs &a)
+{
+    memset(&a, 0, sizeof(a));
+    if (lc == 0) { a.base = base_of(H)->d[0].fp; a.bdv = base_of(H)->d[0].v; a.use_base = 1; return 0; }
+    int rc = refresh_tables(H, lc, st); if (rc) return rc;
+    a.tab = H->lev[lc].d_fp; a.dv = H->lev[lc].d_dv; a.bdv = H->lev[lc].box[0]->d[0].v;
+    return 0;
+}
+
+// Copier::exchange of one or two cell fields of level l
+int hier_ff(suhmo_hier *H, int l, int f0, int f1, bool corners, hipStream_t st)
+{
+    if (l == 0) return 0;                                   // the base canvas: a neighbour's cell IS the ghost
+    HLev &V = H->lev[l];
+    int rc;
+    if ((rc = ensure_field(H, l, f0)) || (f1 >= 0 && (rc = ensure_field(H, l, f1))) || (rc = refresh_tables(H, l, st))) return rc;
+    if (V.ff_side.n) hipLaunchKernelGGL(k_ff, g1(V.ff_side.n), dim3(256), 0, st, V.ff_side.d, (int)V.ff_side.n, V.d_fp, f0, f1);
+    if (corners && V.ff_corner.n) hipLaunchKernelGGL(k_ff, g1(V.ff_corner.n), dim3(256), 0, st, V.ff_corner.d, (int)V.ff_corner.n, V.d_fp, f0, f1);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// QuadCFInterp: coarse-fine ghosts of field ff of level l <- field fc of level l-1
+int hier_cf(suhmo_hier *H, int l, int ff, int fc, hipStream_t st)
+{
+    if (l == 0) return 0;
+    HLev &V = H->lev[l];
+    int rc;
+    CoarseArgs ca;
+    if ((rc = ensure_field(H, l, ff)) || (rc = ensure_field(H, l - 1, fc)) || (rc = refresh_tables(H, l, st)) || (rc = coarse_args(H, l - 1, st, ca))) return rc;
+    if (V.cf.n) hipLaunchKernelGGL(k_cf, g1(V.cf.n), dim3(256), 0, st, V.cf.d, (int)V.cf.n, V.d_fp, ff, ca.tab, ca.base, ca.use_base, fc);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int hier_pwl(suhmo_hier *H, int l, int ff, int fc, hipStream_t st)
+{
+    if (l == 0) return 0;
+    HLev &V = H->lev[l];
+    int rc;
+    CoarseArgs ca;
+    if ((rc = ensure_field(H, l, ff)) || (rc = ensure_field(H, l - 1, fc)) || (rc = refresh_tables(H, l, st)) || (rc = coarse_args(H, l - 1, st, ca))) return rc;
+    if (V.pwl.n) hipLaunchKernelGGL(k_pwl, g1(V.pwl.n), dim3(256), 0, st, V.pwl.d, (int)V.pwl.n, V.d_fp, ff, ca.tab, ca.base, ca.use_base, fc);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// FORT_AVERAGE of field ff of level l into the covered cells of field fc of level l-1 (mode 0) / covered cells <- val (mode 1)
+int hier_avg(suhmo_hier *H, int l, int ff, int fc, int mode, double val, hipStream_t st)
+{
+    HLev &V = H->lev[l];
+    int rc;
+    CoarseArgs ca;
+    if ((rc = ensure_field(H, l, ff)) || (rc = ensure_field(H, l - 1, fc)) || (rc = refresh_tables(H, l, st)) || (rc = coarse_args(H, l - 1, st, ca))) return rc;
+    if (fc == SUHMO_F_PHI) for (suhmo_level *L : H->lev[l - 1].box) L->d[0].phi_fresh = 0;
+    if (V.avg.n) {
+        dim3 grd((V.avg_w + 63) / 64, (V.avg_h + 3) / 4, (unsigned)V.avg.n);
+        hipLaunchKernelGGL(k_avg, grd, dim3(64, 4), 0, st, V.avg.d, V.d_fp, V.d_dv, ff, ca.tab, ca.dv, ca.base, ca.bdv, ca.use_base, fc, mode, val);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// AMRProlongS_2 (:1143-1206): PHI of level l += PROLONG_2_NL(field_c of level l-1), the coarse field gathered per box with
+// its physical-BC ghosts (inhomogeneous in FAS mode)
+int hier_prolong2(suhmo_hier *H, int l, int field_c, hipStream_t st)
+{
+    HLev &V = H->lev[l];
+    int rc;
+    CoarseArgs ca;
+    if ((rc = ensure_field(H, l - 1, field_c)) || (rc = refresh_tables(H, l, st)) || (rc = coarse_args(H, l - 1, st, ca))) return rc;
+    if (V.wing.n) {
+        dim3 grd((V.wing_w + 63) / 64, (V.wing_h + 3) / 4, (unsigned)V.wing.n);
+        hipLaunchKernelGGL(k_win_gather, grd, dim3(64, 4), 0, st, V.wing.d, V.winbuf, ca.tab, ca.dv, ca.base, ca.bdv, ca.use_base, field_c, V.d_win, V.d_wing_box);
+    }
+    const int nb = (int)V.box.size();
+    int maxp = 0, maxx = 0, maxy = 0;
+    for (const Win &w : V.win) maxp = std::max(maxp, 2 * (w.nx - 2) + 2 * (w.ny - 2));
+    for (suhmo_level *L : V.box) { maxx = std::max(maxx, L->d[0].v.nx); maxy = std::max(maxy, L->d[0].v.ny); L->d[0].phi_fresh = 0; }
+    hipLaunchKernelGGL(k_win_bc, dim3((maxp + 255) / 256, nb), dim3(256), 0, st, V.d_win, nb, V.winbuf, ca.bdv);
+    hipLaunchKernelGGL(k_prolong2_win, dim3((maxx + 63) / 64, (maxy + 3) / 4, nb), dim3(64, 4), 0, st, V.d_win, V.winbuf, V.d_fp, V.d_dv);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// reflux (src/VCAMRNonLinearPoissonOp.cpp:555-652): field_c of level l-1 (holding L(phi)) += the flux mismatch on the
+// coarse-fine faces of level l
+int hier_reflux(suhmo_hier *H, int l, int field_c, hipStream_t st)
+{
+    HLev &V = H->lev[l];
+    int rc;
+    CoarseArgs ca;
+    if ((rc = ensure_field(H, l - 1, field_c)) || (rc = refresh_tables(H, l, st)) || (rc = coarse_args(H, l - 1, st, ca))) return rc;
+    const DV &vc = H->lev[l - 1].box[0]->d[0].v;
+    if (V.targets.n)
+        hipLaunchKernelGGL(k_reflux, g1(V.targets.n), dim3(256), 0, st, V.targets.d, (int)V.targets.n, V.faces.d, V.d_fp, V.d_dv, ca.tab, ca.base,
+                           ca.use_base, field_c, vc.dx, vc.dy, vc.beta);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ operator methods of a level
+// relax: levelGSRB x sweeps (src/VCAMRNonLinearPoissonOp.cpp:654-760): per colour pass exchange, then the pass on every box
+int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
+{
+    if (l == 0) return suhmo_level_gsrb(base_of(H), 0, sweeps, s);
+    HLev &V = H->lev[l];
+    int rc;
+    for (int it = 0; it < sweeps; it++)
+        for (int pass = 0; pass < 2; pass++) {
+            if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
+            for (suhmo_level *L : V.box) if ((rc = suhmo_gsrb_colour_pass(L, 0, pass, HST(s)))) return rc;
+        }
+    if (sweeps > 0) {
+        if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
+        for (suhmo_level *L : V.box) if ((rc = suhmo_level_fill_ghosts(L, 0, SUHMO_F_PHI, 1, s))) return rc;      // :757-759
+    }
+    return 0;
+}
+int hier_apply(suhmo_hier *H, int l, suhmo_stream_t s)        // applyOpI, inhomogeneous: LPHI
+{
+    int rc;
+    if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
+    for (suhmo_level *L : H->lev[l].box) if ((rc = suhmo_level_apply_op(L, 0, 0, s))) return rc;
+    return 0;
+}
+int hier_level_residual(suhmo_hier *H, int l, suhmo_stream_t s)   // residualI: RES
+{
+    int rc;
+    if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
+    for (suhmo_level *L : H->lev[l].box) if ((rc = suhmo_level_residual(L, 0, s))) return rc;
+    return 0;
+}
+int hier_axby(suhmo_hier *H, int l, int dst, int x, int y, double a, double b, suhmo_stream_t s)
+{
+    int rc;
+    for (suhmo_level *L : H->lev[l].box) if ((rc = suhmo_level_axby(L, 0, dst, x, y, a, b, s))) return rc;
+    return 0;
+}
+int hier_copy(suhmo_hier *H, int l, int dst, int src, suhmo_stream_t s)
+{
+    int rc;
+    if ((rc = ensure_field(H, l, dst)) || (rc = ensure_field(H, l, src))) return rc;
+    for (suhmo_level *L : H->lev[l].box)
+        HIPCHK(hipMemcpyAsync(L->d[0].fp.f[dst], L->d[0].fp.f[src], L->d[0].elems * sizeof(double), hipMemcpyDeviceToDevice, HST(s)));
+    if (dst == SUHMO_F_PHI) for (suhmo_level *L : H->lev[l].box) L->d[0].phi_fresh = 0;
+    return 0;
+}
+// head of level l: its coarse-fine ghosts from level l-1
+int cf_phi(suhmo_hier *H, int l, suhmo_stream_t s) { return hier_cf(H, l, SUHMO_F_PHI, SUHMO_F_PHI, HST(s)); }
+
+// cell-centred gradient of level l (compGradientCC) with its domain-side ghosts
+int hier_grad_cc(suhmo_hier *H, int l, suhmo_stream_t s)
+{
+    int rc;
+    if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;              // UpdateOperator :47
+    for (suhmo_level *L : H->lev[l].box) if ((rc = suhmo_grad_cc(L, 0, HST(s)))) return rc;
+    return 0;
+}
+// UpdateOperator of level l >= 1 with its coarser level (src/VCAMRNonLinearPoissonOp.cpp:34-64, src/AmrHydro.cpp:1415-1539)
+int hier_update_operator(suhmo_hier *H, int l, suhmo_stream_t s)
+{
+    int rc;
+    if ((rc = cf_phi(H, l - 1, s))) return rc;                    // the coarser level's own coarse-fine ghosts (its gradient reads them)
+    if ((rc = hier_grad_cc(H, l, s))) return rc;
+    if ((rc = hier_grad_cc(H, l - 1, s))) return rc;
+    if ((rc = hier_cf(H, l, SUHMO_F_GRADX, SUHMO_F_GRADX, HST(s)))) return rc;
+    if ((rc = hier_cf(H, l, SUHMO_F_GRADY, SUHMO_F_GRADY, HST(s)))) return rc;
+    if ((rc = hier_ff(H, l, SUHMO_F_GRADX, SUHMO_F_GRADY, true, HST(s)))) return rc;  // lvlgradH.exchange() src/AmrHydro.cpp:1490
+    for (suhmo_level *L : H->lev[l].box) if ((rc = suhmo_re_bcoef_unfused(L, 0, HST(s)))) return rc;
+    return 0;
+}
+// RES of level l-1 = rhs - [applyOpI(phi) + reflux from level l]; LPHI of level l-1 keeps the plain L(phi)
+int composite_residual(suhmo_hier *H, int l, suhmo_stream_t s)
+{
+    int rc;
+    if ((rc = cf_phi(H, l - 1, s))) return rc;
+    if ((rc = hier_apply(H, l - 1, s))) return rc;
+    if ((rc = hier_copy(H, l - 1, SUHMO_F_RES, SUHMO_F_LPHI, s))) return rc;
+    if ((rc = cf_phi(H, l, s))) return rc;
+    if ((rc = hier_reflux(H, l, SUHMO_F_RES, HST(s)))) return rc;
+    return hier_axby(H, l - 1, SUHMO_F_RES, SUHMO_F_RES, SUHMO_F_RHS, -1.0, 1.0, s);
+}
+int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stream_t s)
+{
+    if (l == 0) return suhmo_level_vcycle(base_of(H), sp, s);
+    int rc;
+    if ((rc = cf_phi(H, l, s))) return rc;
+    if (sp->bcoeff_otf && (rc = hier_update_operator(H, l, s))) return rc;
+    if ((rc = hier_gsrb(H, l, sp->num_smooth, s))) return rc;                                 // relaxNF
+    if ((rc = hier_avg(H, l, SUHMO_F_PHI, SUHMO_F_PHI, 0, 0.0, HST(s)))) return rc;           // AMRRestrictS(skip_res)
+    if ((rc = cf_phi(H, l, s))) return rc;
+    if ((rc = hier_level_residual(H, l, s))) return rc;
+    if ((rc = composite_residual(H, l, s))) return rc;
+    if ((rc = hier_avg(H, l, SUHMO_F_RES, SUHMO_F_RES, 0, 0.0, HST(s)))) return rc;
+    if ((rc = hier_copy(H, l - 1, SUHMO_F_RHS0, SUHMO_F_RHS, s))) return rc;
+    if ((rc = hier_axby(H, l - 1, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
+    if ((rc = hier_copy(H, l - 1, SUHMO_F_PHIOLD, SUHMO_F_PHI, s))) return rc;
+    if ((rc = vcycle_amr(H, l - 1, sp, s))) return rc;
+    if ((rc = hier_copy(H, l - 1, SUHMO_F_RHS, SUHMO_F_RHS0, s))) return rc;
+    if ((rc = hier_axby(H, l - 1, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) return rc;
+    if ((rc = hier_prolong2(H, l, SUHMO_F_CORR, HST(s)))) return rc;                          // AMRProlongS_2
+    if ((rc = cf_phi(H, l, s))) return rc;
+    return hier_gsrb(H, l, sp->num_smooth, s);
+}
+int check_hier(const suhmo_hier *H) { ARG(H && H->nlev >= 1); return 0; }
+}  // namespace
+
+// ------------------------------------------------------------------ C-ABI
+extern "C" int suhmo_hier_destroy(suhmo_hier_t *H)
+{
+    if (!H) return 0;
+    (void)hipSetDevice(H->device);
+    (void)hipDeviceSynchronize();
+    if (H->gap) { (void)suhmo_hier_destroy(H->gap); H->gap = nullptr; }
+    for (int l = 0; l < 8; l++) {
+        HLev &V = H->lev[l];
+        for (suhmo_level *L : V.box) (void)suhmo_level_destroy(L);
+        V.ff_side.release(); V.ff_corner.release(); V.cf.release(); V.pwl.release(); V.avg.release(); V.wing.release();
+        V.targets.release(); V.faces.release();
+        if (V.winbuf) (void)hipFree(V.winbuf);
+        if (V.d_win) (void)hipFree(V.d_win);
+        if (V.d_wing_box) (void)hipFree(V.d_wing_box);
+        if (V.d_fp) (void)hipFree(V.d_fp);
+        if (V.d_dv) (void)hipFree(V.d_dv);
+    }
+    delete H;
+    return 0;
+}
+
+extern "C" int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *base, int nlev, const int *nbox, const int *boxes)
+{
+    ARG(out && base && nlev >= 1 && nlev <= 8);
+    ARG(nlev == 1 || (nbox && boxes));
+    ARG(base->j0 == 0 && base->ny == base->ny_global && base->i0 == 0 && (base->nx_global == 0 || base->nx_global == base->nx));
+    suhmo_hier *H = new suhmo_hier();
+    H->nlev = nlev; H->device = base->device; H->bc = base->bc;
+    suhmo_level *B = nullptr;
+    int rc = suhmo_level_create(&B, base);
+    if (rc) { delete H; return rc; }
+    H->lev[0].l = 0; H->lev[0].nxd = base->nx; H->lev[0].nyd = base->ny; H->lev[0].box.push_back(B);
+    const int *q = boxes;
+    for (int l = 1; l < nlev; l++) {
+        HLev &V = H->lev[l];
+        V.l = l; V.nxd = H->lev[l - 1].nxd * 2; V.nyd = H->lev[l - 1].nyd * 2;
+        if (nbox[l] < 1) { suhmo_set_error("hier: level %d has no box", l); suhmo_hier_destroy(H); return -1; }
+        V.b4.assign(q, q + 4 * (size_t)nbox[l]);
+        q += 4 * (size_t)nbox[l];
+        long cells = 0;
+        for (int k = 0; k < nbox[l]; k++) {
+            const int *b = &V.b4[4 * k];
+            if ((b[0] & 1) || (b[1] & 1) || !(b[2] & 1) || !(b[3] & 1) || b[0] < 0 || b[1] < 0 || b[2] >= V.nxd || b[3] >= V.nyd || b[2] < b[0] || b[3] < b[1]) {
+                suhmo_set_error("hier: box %d of level %d is not a coarse-aligned box of the refined domain", k, l); suhmo_hier_destroy(H); return -1; }
+            cells += (long)(b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+        }
+        V.index.build(V.b4, V.nxd, V.nyd);
+        {   // disjoint: every cell of every box is found in that box
+            long seen = 0;
+            for (int k = 0; k < nbox[l]; k++) {
+                const int *b = &V.b4[4 * k];
+                for (int c = 0; c < 4; c++) {                       // overlap of rectangles shows at a corner of one of them
+                    int i = (c & 1) ? b[2] : b[0], j = (c & 2) ? b[3] : b[1];
+                    size_t qb = (size_t)(j / V.index.bs) * V.index.nbx + i / V.index.bs;
+                    for (int p = V.index.start[qb]; p < V.index.start[qb + 1]; p++) {
+                        const int o = V.index.items[p];
+                        const int *ob = &V.b4[4 * o];
+                        if (o != k && i >= ob[0] && i <= ob[2] && j >= ob[1] && j <= ob[3]) seen = -1;
+                    }
+                }
+                // a box may also cross another without containing a corner: compare against every box sharing a bucket
+                for (int by = b[1] / V.index.bs; by <= b[3] / V.index.bs && seen >= 0; by++)
+                    for (int bx = b[0] / V.index.bs; bx <= b[2] / V.index.bs; bx++) {
+                        size_t qb = (size_t)by * V.index.nbx + bx;
+                        for (int p = V.index.start[qb]; p < V.index.start[qb + 1]; p++) {
+                            const int o = V.index.items[p];
+                            const int *ob = &V.b4[4 * o];
+                            if (o != k && std::max(b[0], ob[0]) <= std::min(b[2], ob[2]) && std::max(b[1], ob[1]) <= std::min(b[3], ob[3])) seen = -1;
+                        }
+                    }
+                if (seen < 0) break;
+            }
+            if (seen < 0) { suhmo_set_error("hier: boxes of level %d overlap", l); suhmo_hier_destroy(H); return -1; }
+        }
+        for (int k = 0; k < nbox[l]; k++) {
+            const int *b = &V.b4[4 * k];
+            suhmo_level_desc_t d = *base;
+            d.nx = b[2] - b[0] + 1; d.ny = b[3] - b[1] + 1;
+            d.i0 = b[0]; d.nx_global = V.nxd; d.j0 = b[1]; d.ny_global = V.nyd;
+            d.dx = base->dx / (double)(1 << l); d.dy = base->dy / (double)(1 << l);
+            d.nbox = 0; d.boxes = nullptr; d.max_box = std::max(d.nx, d.ny);
+            d.halo_rows = 1; d.patch_j0 = 0; d.patch_ny = 0;
+            suhmo_level *L = nullptr;
+            rc = suhmo_level_create(&L, &d);
+            if (rc) { suhmo_hier_destroy(H); return rc; }
+            L->gsrb_variant = 0; L->gsrb_tile = 0;               // in-place colour passes: the canvases of a box never move
+            V.box.push_back(L);
+        }
+        (void)cells;
+    }
+    static const int need[] = {SUHMO_F_LPHI, SUHMO_F_GRADX, SUHMO_F_GRADY, SUHMO_F_RE, SUHMO_F_RHS0, SUHMO_F_PHIOLD, SUHMO_F_CORR};
+    for (int l = 0; l < nlev; l++) for (int f : need) if ((rc = ensure_field(H, l, f))) { suhmo_hier_destroy(H); return rc; }
+    for (int l = 1; l < nlev; l++) {
+        if ((rc = build_plans(H, l))) { suhmo_hier_destroy(H); return rc; }
+        if ((rc = refresh_tables(H, l, nullptr))) { suhmo_hier_destroy(H); return rc; }
+    }
+    *out = H;
+    return 0;
+}
+extern "C" int suhmo_hier_num_levels(const suhmo_hier_t *H) { return H ? H->nlev : -1; }
+extern "C" int suhmo_hier_num_boxes(const suhmo_hier_t *H, int l) { return (H && l >= 0 && l < H->nlev) ? (int)H->lev[l].box.size() : -1; }
+extern "C" suhmo_level_t *suhmo_hier_box(suhmo_hier_t *H, int l, int k)
+{
+    if (!H || l < 0 || l >= H->nlev || k < 0 || k >= (int)H->lev[l].box.size()) return nullptr;
+    return H->lev[l].box[k];
+}
+extern "C" int suhmo_hier_exchange(suhmo_hier_t *H, int l, int field, int corners, suhmo_stream_t s)
+{
+    int rc = check_hier(H); if (rc) return rc;
+    ARG(l >= 0 && l < H->nlev && field >= 0 && field < SUHMO_F_COUNT);
+    HIPCHK(hipSetDevice(H->device));
+    return hier_ff(H, l, field, -1, corners != 0, HST(s));
+}
+extern "C" int suhmo_hier_cf_interp(suhmo_hier_t *H, int l, int field_f, int field_c, suhmo_stream_t s)
+{
+    int rc = check_hier(H); if (rc) return rc;
+    ARG(l >= 1 && l < H->nlev && field_f >= 0 && field_f < SUHMO_F_COUNT && field_c >= 0 && field_c < SUHMO_F_COUNT);
+    HIPCHK(hipSetDevice(H->device));
+    return hier_cf(H, l, field_f, field_c, HST(s));
+}
+extern "C" int suhmo_hier_pwl_fill(suhmo_hier_t *H, int l, int field_f, int field_c, suhmo_stream_t s)
+{
+    int rc = check_hier(H); if (rc) return rc;
+    ARG(l >= 1 && l < H->nlev && field_f >= 0 && field_f < SUHMO_F_COUNT && field_c >= 0 && field_c < SUHMO_F_COUNT);
+    HIPCHK(hipSetDevice(H->device));
+    return hier_pwl(H, l, field_f, field_c, HST(s));
+}
+extern "C" int suhmo_hier_average(suhmo_hier_t *H, int l, int field_f, int field_c, suhmo_stream_t s)
+{
+    int rc = check_hier(H); if (rc) return rc;
+    ARG(l >= 1 && l < H->nlev && field_f >= 0 && field_f < SUHMO_F_COUNT && field_c >= 0 && field_c < SUHMO_F_COUNT);
+    HIPCHK(hipSetDevice(H->device));
+    return hier_avg(H, l, field_f, field_c, 0, 0.0, HST(s));
+}
+extern "C" int suhmo_hier_gsrb(suhmo_hier_t *H, int l, int sweeps, suhmo_stream_t s)
+{
+    int rc = check_hier(H); if (rc) return rc;
+    ARG(l >= 0 && l < H->nlev && sweeps >= 0);
+    HIPCHK(hipSetDevice(H->device));
+    return hier_gsrb(H, l, sweeps, s);
+}
+extern "C" int suhmo_hier_update_operator(suhmo_hier_t *H, int l, suhmo_stream_t s)
+{
+    int rc = check_hier(H); if (rc) return rc;
+    ARG(l >= 0 && l < H->nlev);
+    HIPCHK(hipSetDevice(H->device));
+    if (l == 0) return suhmo_level_update_operator(base_of(H), 0, s);
+    return hier_update_operator(H, l, s);
+}
+// composite residual of the hierarchy (RES of every level, covered cells zeroed) and its max norm (AMRNorm :1222-1264)
+extern "C" int suhmo_hier_residual(suhmo_hier_t *H, double *norm, suhmo_stream_t s)
+{
+    int rc = check_hier(H); if (rc) return rc;
+    HIPCHK(hipSetDevice(H->device));
+    const int top = H->nlev - 1;
+    if ((rc = cf_phi(H, top, s))) return rc;
+    if ((rc = hier_level_residual(H, top, s))) return rc;                                  // AMRResidualNF on the finest level
+    for (int l = top; l >= 1; l--) if ((rc = composite_residual(H, l, s))) return rc;
+    for (int l = top; l >= 1; l--) if ((rc = hier_avg(H, l, SUHMO_F_RES, SUHMO_F_RES, 1, 0.0, HST(s)))) return rc;
+    if (norm) {
+        double m = 0.0;
+        for (int l = 0; l <= top; l++)
+            for (suhmo_level *L : H->lev[l].box) { double a = 0.0; if ((rc = suhmo_level_norm(L, 0, SUHMO_F_RES, 0, &a, s))) return rc; if (a > m) m = a; }
+        *norm = m;
+    }
+    return 0;
+}
+extern "C" int suhmo_hier_vcycle(suhmo_hier_t *H, const suhmo_solver_params_t *sp, suhmo_stream_t s)
+{
+    int rc = check_hier(H); if (rc) return rc;
+    ARG(sp);
+    HIPCHK(hipSetDevice(H->device));
+    return vcycle_amr(H, H->nlev - 1, sp, s);
+}
+extern "C" int suhmo_hier_solve(suhmo_hier_t *H, const suhmo_solver_params_t *sp, int *iters, double *hist, suhmo_stream_t s)
+{
+    ARG(sp);
+    int rc;
+    if (H && H->nlev == 1) return suhmo_level_solve(base_of(H), sp, iters, hist, s);
+    double rnorm = 0.0;
+    if ((rc = suhmo_hier_residual(H, &rnorm, s))) return rc;
+    double initial_rnorm = rnorm, norm_last = 2.0 * initial_rnorm;
+    int iter = 0;
+    if (hist) hist[0] = rnorm;
+    bool goNorm = rnorm > sp->norm_thresh, goRedu = rnorm > sp->eps * initial_rnorm, goIter = iter < sp->max_iter;
+    bool goHang = iter < sp->imin || rnorm < (1.0 - sp->hang) * norm_last, goMin = iter < sp->iter_min;
+    while (goMin || (goIter && goRedu && goHang && goNorm)) {
+        norm_last = rnorm;
+        if ((rc = suhmo_hier_vcycle(H, sp, s))) return rc;
+        if ((rc = suhmo_hier_residual(H, &rnorm, s))) return rc;
+        iter++;
+        if (hist) hist[iter] = rnorm;
+        goNorm = rnorm > sp->norm_thresh; goRedu = rnorm > sp->eps * initial_rnorm; goIter = iter < sp->max_iter;
+        goHang = iter < sp->imin || rnorm < (1.0 - sp->hang) * norm_last; goMin = iter < sp->iter_min;
+    }
+    if (iters) *iters = iter;
+    return 0;
+}

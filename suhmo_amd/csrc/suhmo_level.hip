@@ -53,8 +53,8 @@ static void make_dv(DV &v, const suhmo_level_desc_t &d, int depth)
     bool whole = (d.j0 == 0 && d.ny == d.ny_global);
     v.ext[0] = (!whole) && (d.j0 > 0 || d.bc.periodic[1]);
     v.ext[1] = (!whole) && (d.j0 + d.ny < d.ny_global || d.bc.periodic[1]);
-    v.cfx[0] = v.i0 > 0;
-    v.cfx[1] = v.i0 + v.nx < v.nxg;
+    v.cfx[0] = v.i0 > 0 || (v.per[0] && v.nx < v.nxg);     // a box that does not span a periodic domain keeps stored ghost columns there
+    v.cfx[1] = v.i0 + v.nx < v.nxg || (v.per[0] && v.nx < v.nxg);
     if (d.nx_global > 0) {               // AMR patch: rank boundaries only inside the patch's own row range
         const int pj0 = d.patch_ny > 0 ? d.patch_j0 : d.j0, pj1 = d.patch_ny > 0 ? d.patch_j0 + d.patch_ny : d.j0 + d.ny;
         v.rk[0] = d.j0 > pj0; v.rk[1] = d.j0 + d.ny < pj1;

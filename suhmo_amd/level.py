@@ -253,3 +253,89 @@ class HipAmr:
     def close(self):
         for lv in reversed(self.levels):
             lv.close()
+
+
+class _BoxView(HipLevel):
+    """A box of a hierarchy: the level handle belongs to the hierarchy (never destroyed from here)."""
+
+    def __init__(self, h, nx, ny, dx, dy, stream):
+        self.h, self.nx, self.ny, self.dx, self.dy, self.stream = C.c_void_p(h), nx, ny, dx, dy, stream
+        self.ndepth = capi.lib().suhmo_level_num_depths(self.h)
+        self._hooks = None
+
+    def close(self):
+        self.h = None
+
+
+class HipHier:
+    """Base level + levels that are unions of boxes (boxes[l-1] = list of (lo0, lo1, hi0, hi1) in the index space of
+    level l), the reference's DisjointBoxLayout per AMR level: suhmo_hier_* (suhmo_amd/csrc/suhmo_hier.hip)."""
+
+    def __init__(self, nx0, ny0, dx0, dy0, bc, phys, boxes, alpha=0.0, beta=-1.0, max_box=64, device=0):
+        self.boxes = [[tuple(int(v) for v in b) for b in bl] for bl in boxes]
+        self.nlev = 1 + len(self.boxes)
+        d = capi.LevelDesc()
+        d.nx, d.ny, d.j0, d.ny_global, d.dx, d.dy = nx0, ny0, 0, ny0, dx0, dy0
+        d.nbox, d.boxes, d.max_box, d.alpha, d.beta = 0, None, max_box, alpha, beta
+        d.bc, d.phys, d.device, d.halo_rows = _bc(bc), _phys(phys), device, 1
+        nbox = (C.c_int * self.nlev)(0, *[len(bl) for bl in self.boxes])
+        flat = [v for bl in self.boxes for b in bl for v in b]
+        arr = (C.c_int * max(len(flat), 1))(*flat)
+        h = C.c_void_p()
+        check(capi.lib().suhmo_hier_create(C.byref(h), C.byref(d), self.nlev, nbox, arr))
+        self.h = h
+        self.stream = C.c_void_p(0)
+        self.level = [[_BoxView(capi.lib().suhmo_hier_box(h, 0, 0), nx0, ny0, dx0, dy0, self.stream)]]
+        for l, bl in enumerate(self.boxes, start=1):
+            self.level.append([_BoxView(capi.lib().suhmo_hier_box(h, l, k), b[2] - b[0] + 1, b[3] - b[1] + 1, dx0 / 2 ** l, dy0 / 2 ** l,
+                                        self.stream) for k, b in enumerate(bl)])
+        self.coarse = self.level[0][0]
+
+    def set_inputs(self, fs):
+        """fs as suhmo_amd.synthetic.amrm_fields returns it"""
+        self.coarse.set_inputs(fs[0])
+        self.coarse.build_mg_coefficients()
+        for l in range(1, self.nlev):
+            for k, f in enumerate(fs[l]):
+                self.level[l][k].set_inputs(f)
+
+    def level_array(self, l, field):
+        nx, ny = self.coarse.nx << l, self.coarse.ny << l
+        out = np.full((ny, nx), np.nan)
+        for k, (lo0, lo1, hi0, hi1) in enumerate(self.boxes[l - 1]):
+            out[lo1:hi1 + 1, lo0:hi0 + 1] = self.level[l][k].get(field)
+        return out
+
+    def exchange(self, l, field, corners=False): check(capi.lib().suhmo_hier_exchange(self.h, l, field, int(corners), self.stream))
+    def cf_interp(self, l, field_f=F_PHI, field_c=F_PHI): check(capi.lib().suhmo_hier_cf_interp(self.h, l, field_f, field_c, self.stream))
+    def pwl_fill(self, l, field_f, field_c): check(capi.lib().suhmo_hier_pwl_fill(self.h, l, field_f, field_c, self.stream))
+    def average(self, l, field_f, field_c): check(capi.lib().suhmo_hier_average(self.h, l, field_f, field_c, self.stream))
+    def gsrb(self, l, sweeps): check(capi.lib().suhmo_hier_gsrb(self.h, l, sweeps, self.stream))
+    def update_operator(self, l): check(capi.lib().suhmo_hier_update_operator(self.h, l, self.stream))
+
+    def residual(self):
+        r = C.c_double()
+        check(capi.lib().suhmo_hier_residual(self.h, C.cast(C.pointer(r), C.POINTER(C.c_double)), self.stream))
+        return r.value
+
+    def vcycle(self, sp):
+        s = solver_params(sp)
+        check(capi.lib().suhmo_hier_vcycle(self.h, C.byref(s), self.stream))
+
+    def solve(self, sp):
+        s = solver_params(sp)
+        hist = np.zeros(s.max_iter + 2)
+        n = C.c_int()
+        check(capi.lib().suhmo_hier_solve(self.h, C.byref(s), C.byref(n), hist.ctypes.data_as(C.POINTER(C.c_double)), self.stream))
+        return n.value, hist[: n.value + 1]
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib().suhmo_hier_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,135 @@
+"""AMR levels that are unions of boxes on the GPU (suhmo_amd/csrc/suhmo_hier.hip) against the oracle's amrm.c on the same
+inputs, BITWISE: fine-fine exchange, coarse-fine interpolation with coverage-aware stencils, the fine operator update,
+the composite residual (reflux over box unions), AMR FAS V-cycles and the solve history on base + 3 levels with an L-shaped
+union (re-entrant corner), a disjoint box and a box on the domain side; the same level cut into more boxes gives the same
+bits; one box per level equals the nested-patch code (suhmo_amr_*)."""
+import numpy as np
+import pytest
+
+from suhmo_amd import synthetic as sy
+
+pytestmark = pytest.mark.gpu
+BC = dict(type=[[0, 0], [1, 0]], value=[[0.0, 0.0], [0.0, 0.0]], periodic=[0, 1])     # 2lev_base/input.hydro:8-13,76
+BC_NP = dict(type=[[0, 1], [1, 0]], value=[[0.0, 0.0], [0.0, 0.0]], periodic=[0, 0])  # run_C_3lev/input.hydro: no periodic side
+BC_V = dict(type=[[0, 1], [1, 0]], value=[[3.0, 0.01], [-0.02, 7.0]], periodic=[0, 0])
+ONE = ([(16, 8, 47, 23)], [(44, 22, 75, 41)])
+CUT = ([(16, 8, 31, 23), (32, 8, 47, 15), (32, 16, 47, 23)], [(44, 22, 59, 41), (60, 22, 75, 41)])
+UNION = ([(16, 8, 31, 23), (32, 8, 47, 15), (0, 2, 11, 13)],
+         [(36, 20, 59, 27), (36, 28, 51, 43), (4, 8, 15, 19)],
+         [(80, 44, 103, 51), (12, 20, 23, 31)])
+MASKPH = dict(sy.CFG3_PHYS, use_mask_gradients=1, cutOffbr=0.008, maxOffbr=0.012, cutOffB=1)
+
+
+def pair(oracle, boxes, bc, ph=sy.CFG3_PHYS, nx0=64, ny0=16, **kw):
+    from suhmo_amd import level
+    fs = sy.amrm_fields(nx0, ny0, boxes, **kw)
+    O = oracle.OracleAmrM(nx0, ny0, fs[0]["dx"], fs[0]["dy"], bc, ph, boxes, max_box=32, nthreads=2)
+    O.set_inputs(fs)
+    G = level.HipHier(nx0, ny0, fs[0]["dx"], fs[0]["dy"], bc, ph, boxes, max_box=32)
+    G.set_inputs(fs)
+    return O, G, fs
+
+
+def eq(a, b, what):
+    assert np.array_equal(a, b), (what, float(np.nanmax(np.abs(a - b))))
+
+
+def uncovered(O, l, k):
+    """cells of box k of level l that no box of level l + 1 covers (the device zeroes RES under finer levels, AMRNorm)"""
+    lo0, lo1, hi0, hi1 = O.boxes[l - 1][k]
+    m = np.ones((hi1 - lo1 + 1, hi0 - lo0 + 1), dtype=bool)
+    if l < O.nlev - 1:
+        for (f0, f1, g0, g1) in O.boxes[l]:
+            a0, a1, c0, c1 = max(f0 // 2, lo0), min(g0 // 2, hi0), max(f1 // 2, lo1), min(g1 // 2, hi1)
+            if a0 <= a1 and c0 <= c1:
+                m[c0 - lo1:c1 - lo1 + 1, a0 - lo0:a1 - lo0 + 1] = False
+    return m
+
+
+def same_levels(O, G, oracle, fields, what, skip_covered=False):
+    from suhmo_amd import level
+    for l in range(1, O.nlev):
+        for k in range(len(O.boxes[l - 1])):
+            for fo, fg in fields:
+                a, b = O.box_get(l, k, fo), G.level[l][k].get(fg)
+                if skip_covered:
+                    m = uncovered(O, l, k)
+                    a, b = a[m], b[m]
+                eq(a, b, (what, l, k, fo))
+    eq(O.coarse.get(oracle.F_PHI), G.coarse.get(level.F_PHI), (what, "base phi"))
+
+
+@pytest.mark.parametrize("bc,ph", [(BC_NP, sy.CFG3_PHYS), (BC_V, MASKPH)], ids=["cfg5-bc", "values-mask"])
+def test_hier_pieces_bitwise(oracle, bc, ph):
+    from suhmo_amd.level import F_PHI, F_RES, F_BX, F_BY
+    O, G, fs = pair(oracle, UNION, bc, ph)
+    for l in (1, 2, 3):
+        O.cf_interp_phi(l); O.exchange(l, oracle.F_PHI)
+        G.cf_interp(l); G.exchange(l, F_PHI)
+        for k in range(len(UNION[l - 1])):
+            a, b = O.box_get(l, k, oracle.F_PHI, ghosted=True), G.level[l][k].get(F_PHI, ghosted=True)
+            eq(a[1:-1, :], b[1:-1, :], ("ghosts x", l, k)); eq(a[:, 1:-1], b[:, 1:-1], ("ghosts y", l, k))
+    for l in (1, 2, 3):
+        O.update_operator(l); G.update_operator(l)
+    same_levels(O, G, oracle, ((oracle.F_BX, F_BX), (oracle.F_BY, F_BY)), "update_operator")
+    O.coarse.update_operator(); G.coarse.update_operator()
+    ro, rg = O.residual(), G.residual()
+    assert ro == rg, (ro, rg)
+    same_levels(O, G, oracle, ((oracle.F_RES, F_RES),), "residual", skip_covered=True)
+    for l in (1, 2, 3):
+        O.gsrb(l, 2); G.gsrb(l, 2)
+    same_levels(O, G, oracle, ((oracle.F_PHI, F_PHI),), "gsrb")
+    O.close(); G.close()
+
+
+@pytest.mark.parametrize("name,boxes,bc,ph", [("union-4lev", UNION, BC_NP, sy.CFG3_PHYS), ("union-4lev-values-mask", UNION, BC_V, MASKPH),
+                                              ("cut-periodic", CUT, BC, sy.CFG3_PHYS)], ids=lambda v: v if isinstance(v, str) else "")
+def test_hier_vcycle_and_solve_bitwise(oracle, name, boxes, bc, ph):
+    from suhmo_amd.level import F_PHI, F_RES, F_BX
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-9, norm_thresh=1e-14, max_iter=6, imin=30)
+    O, G, fs = pair(oracle, boxes, bc, ph)
+    O.vcycle(sp); G.vcycle(sp)
+    same_levels(O, G, oracle, ((oracle.F_PHI, F_PHI), (oracle.F_BX, F_BX)), "vcycle")
+    no, ho = O.solve(sp)
+    ng, hg = G.solve(sp)
+    assert no == ng and np.array_equal(ho, hg), (ho, hg)
+    same_levels(O, G, oracle, ((oracle.F_PHI, F_PHI),), "solve")
+    same_levels(O, G, oracle, ((oracle.F_RES, F_RES),), "solve residual", skip_covered=True)
+    O.close(); G.close()
+
+
+def test_cutting_a_level_into_boxes_changes_no_bit_on_the_device(oracle):
+    from suhmo_amd import level
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-9, norm_thresh=1e-14, max_iter=3, imin=30)
+    res = []
+    for boxes in (ONE, CUT):
+        fs = sy.amrm_fields(64, 16, boxes)
+        G = level.HipHier(64, 16, fs[0]["dx"], fs[0]["dy"], BC, sy.CFG3_PHYS, boxes, max_box=32)
+        G.set_inputs(fs)
+        n, h = G.solve(sp)
+        res.append((n, h, [G.level_array(l, level.F_PHI) for l in (1, 2)], G.coarse.get(level.F_PHI)))
+        G.close()
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert np.array_equal(res[0][3], res[1][3])
+
+
+def test_one_box_per_level_equals_the_nested_patch_code(oracle):
+    from suhmo_amd import level
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-9, norm_thresh=1e-14, max_iter=4, imin=30)
+    fs = sy.amrm_fields(64, 16, ONE)
+    H = level.HipHier(64, 16, fs[0]["dx"], fs[0]["dy"], BC, sy.CFG3_PHYS, ONE, max_box=32)
+    H.set_inputs(fs)
+    A = level.HipAmr(64, 16, fs[0]["dx"], fs[0]["dy"], BC, sy.CFG3_PHYS, ((8, 4, 23, 11), (22, 11, 37, 20)), max_box=32)
+    A.levels[0].set_inputs(fs[0]); A.levels[0].build_mg_coefficients()
+    for l in (1, 2):
+        A.levels[l].set_inputs(fs[l][0])
+    assert H.residual() == A.residual()
+    nh, hh = H.solve(sp)
+    na, ha = A.solve(sp)
+    assert nh == na and np.array_equal(hh, ha)
+    for l in (1, 2):
+        assert np.array_equal(H.level[l][0].get(level.F_PHI), A.levels[l].get(level.F_PHI))
+    assert np.array_equal(H.coarse.get(level.F_PHI), A.levels[0].get(level.F_PHI))
+    H.close(); A.close()
