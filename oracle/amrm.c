@@ -144,6 +144,7 @@ void or_amrm_destroy(OrAmrM *A)
     }
     free(A);
 }
+int or_amrm_owner(const OrAmrM *A, int l, int i, int j) { return owner_of(A, &A->lv[l], i, j); }   /* with the periodic wrap */
 int or_amrm_num_boxes(const OrAmrM *A, int l) { return l == 0 ? 1 : A->lv[l].nbox; }
 void or_amrm_box(const OrAmrM *A, int l, int k, int *b4)
 {
@@ -220,13 +221,13 @@ static OrBox whole_domain(const LvM *V) { OrBox b = {0, 0, V->nxd - 1, V->nyd - 
 /* ---------------- Copier::exchange of a 1-ghost cell field of level l >= 1 ---------------- */
 /* every ghost cell of every box that another box of the level (or a periodic image) holds takes that box's value;
  * corners = 0: the operator's copier (exchangeDefine + trimEdges, :912-913: no corner cells) */
-static void exchange(OrAmrM *A, int l, int field, int corners)
+void or_amrm_exchange_fabs(OrAmrM *A, int l, OrFab **fabs, int corners)
 {
     LvM *V = &A->lv[l];
     if (l == 0) return;
     for (int k = 0; k < V->nbox; k++) {
         Bx *P = &V->b[k];
-        OrFab *f = bx_field(P, field);
+        OrFab *f = fabs[k];
         for (int j = P->vb.lo1 - 1; j <= P->vb.hi1 + 1; j++)
             for (int i = P->vb.lo0 - 1; i <= P->vb.hi0 + 1; i++) {
                 int gx = i < P->vb.lo0 || i > P->vb.hi0, gy = j < P->vb.lo1 || j > P->vb.hi1;
@@ -236,10 +237,19 @@ static void exchange(OrAmrM *A, int l, int field, int corners)
                 if (!wrap_cell(A, V, &iw, &jw)) continue;
                 int o = V->owner[(size_t)jw * V->nxd + iw];
                 if (o < 0) continue;
-                const OrFab *s = bx_field(&V->b[o], field);
+                const OrFab *s = fabs[o];
                 for (int c = 0; c < f->ncomp; c++) AT(f, i, j, c) = AT(s, iw, jw, c);
             }
     }
+}
+static void exchange(OrAmrM *A, int l, int field, int corners)
+{
+    LvM *V = &A->lv[l];
+    if (l == 0) return;
+    OrFab **fabs = (OrFab **)malloc(sizeof(OrFab *) * (size_t)V->nbox);
+    for (int k = 0; k < V->nbox; k++) fabs[k] = bx_field(&V->b[k], field);
+    or_amrm_exchange_fabs(A, l, fabs, corners);
+    free(fabs);
 }
 
 /* ---------------- box operator methods, as amrn.c ---------------- */
@@ -346,13 +356,13 @@ static double cdom(const OrAmrM *A, const LvM *C, const double *c, int i, int j)
 }
 /* coarse-fine ghost cells (sides, no corners) of component comp of `field` of every box of level l <- coarse (domain
  * array of level l-1, valid cells) */
-static void cf_interp(OrAmrM *A, int l, int field, int comp, const double *coarse)
+void or_amrm_cf_interp_fabs(OrAmrM *A, int l, OrFab **fabs, int comp, const double *coarse)
 {
     const LvM *F = &A->lv[l], *C = &A->lv[l - 1];
     const double c_s = 8.0 / 15.0, c_b = 2.0 / 3.0, c_a = -0.2;
     for (int k = 0; k < F->nbox; k++) {
         Bx *P = &F->b[k];
-        OrFab *f = bx_field(P, field);
+        OrFab *f = fabs[k];
         for (int dir = 0; dir < 2; dir++) {
             int tdir = 1 - dir;
             int ndomf = dir == 0 ? F->nxd : F->nyd;
@@ -390,6 +400,14 @@ static void cf_interp(OrAmrM *A, int l, int field, int comp, const double *coars
             }
         }
     }
+}
+static void cf_interp(OrAmrM *A, int l, int field, int comp, const double *coarse)
+{
+    LvM *V = &A->lv[l];
+    OrFab **fabs = (OrFab **)malloc(sizeof(OrFab *) * (size_t)V->nbox);
+    for (int k = 0; k < V->nbox; k++) fabs[k] = bx_field(&V->b[k], field);
+    or_amrm_cf_interp_fabs(A, l, fabs, comp, coarse);
+    free(fabs);
 }
 /* head of level l: coarse-fine ghosts from level l-1 (no-op on the base level) */
 static void cf_interp_phi(OrAmrM *A, int l)

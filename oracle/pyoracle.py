@@ -136,6 +136,15 @@ def lib():
         L.or_amr_vcycle.argtypes = [C.c_void_p, C.POINTER(OrSolverParams)]
         L.or_amr_solve.restype = C.c_int
         L.or_amr_solve.argtypes = [C.c_void_p, C.POINTER(OrSolverParams), dp]
+        L.or_amrm_model_create.restype = C.c_void_p
+        L.or_amrm_model_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(OrBC), C.POINTER(OrPhys),
+                                           C.POINTER(OrModelParams), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.or_amrm_model_destroy.argtypes = [C.c_void_p]
+        L.or_amrm_model_gap_solver_layout.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.or_amrm_model_field.restype = dp
+        L.or_amrm_model_field.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.or_amrm_model_timestep.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.or_amrm_model_moulin_source.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, C.c_double, dp]
         ip = C.POINTER(C.c_int)
         L.or_amrm_create.restype = C.c_void_p
         L.or_amrm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(OrBC), C.POINTER(OrPhys),
@@ -615,3 +624,61 @@ class OracleAmrM:
             lib().or_amrm_destroy(self.h)
             self.h = None
             self.coarse.close()
+
+
+class OracleAmrMModel:
+    """Hydrology time loop on a hierarchy whose levels are unions of boxes (boxes[l-1] = list of (lo0, lo1, hi0, hi1) in the
+    index space of level l): oracle/amr_step_m.c"""
+
+    def __init__(self, nx0, ny0, dx0, dy0, bc, phys, model, boxes, max_box=64, nthreads=1):
+        self.level = OracleLevel(nx0, ny0, dx0, dy0, bc, phys, 0.0, -1.0, max_box, nthreads)
+        self.boxes = [[(0, 0, nx0 - 1, ny0 - 1)]] + [[tuple(int(v) for v in b) for b in bl] for bl in boxes]
+        self.nlev = len(self.boxes)
+        self._mp = make_model_params(model)
+        nbox = (C.c_int * self.nlev)(*[len(bl) for bl in self.boxes])
+        flat = [v for bl in self.boxes[1:] for b in bl for v in b]
+        arr = (C.c_int * max(len(flat), 1))(*flat)
+        self.h = lib().or_amrm_model_create(self.level.h, nx0, ny0, dx0, dy0, C.byref(self.level._bc), C.byref(self.level._ph),
+                                            C.byref(self._mp), self.nlev, nbox, arr)
+        if not self.h:
+            self.level.close()
+            raise ValueError("boxes misaligned, overlapping or not properly nested")
+        self.level.set(F_ACOEF, np.zeros((ny0, nx0)))
+        lib().or_amrm_model_gap_solver_layout(self.h, max_box, nthreads)
+
+    def field(self, l, k, fid):
+        lo0, lo1, hi0, hi1 = self.boxes[l][k]
+        nx, ny = hi0 - lo0 + 1, hi1 - lo1 + 1
+        p = lib().or_amrm_model_field(self.h, l, k, fid)
+        shape = {OM_QWX: (ny, nx + 1), OM_QWY: (ny + 1, nx)}.get(fid, (ny + 2, nx + 2))
+        return np.ctypeslib.as_array(p, shape=shape)
+
+    def set_state(self, l, k, f):
+        for key, fid in (("head", OM_H), ("B", OM_B), ("Pi", OM_PI), ("zb", OM_ZB), ("mask", OM_MASK)):
+            self.field(l, k, fid)[:] = f[key]
+
+    def set_states(self, sts):
+        """sts as suhmo_amd.synthetic.shmip_amrm_states returns it"""
+        for l, bl in enumerate(sts):
+            for k, st in enumerate(bl):
+                self.set_state(l, k, st)
+
+    def moulin_source(self, positions, sigma, flux, time_factor=1.0):
+        pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1)
+        sg, fl = np.ascontiguousarray(sigma, dtype=np.float64), np.ascontiguousarray(flux, dtype=np.float64)
+        integ = np.zeros(sg.size)
+        lib().or_amrm_model_moulin_source(self.h, sg.size, _dp(pos), _dp(sg), _dp(fl), float(time_factor), _dp(integ))
+        return integ
+
+    def timestep(self, dt):
+        pi, nv = C.c_int(), C.c_int()
+        rc = lib().or_amrm_model_timestep(self.h, dt, C.byref(pi), C.byref(nv))
+        if rc:
+            raise RuntimeError("AMR time step failed (rc %d)" % rc)
+        return pi.value, nv.value
+
+    def close(self):
+        if self.h:
+            lib().or_amrm_model_destroy(self.h)
+            self.h = None
+            self.level.close()

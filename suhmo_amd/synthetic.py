@@ -151,6 +151,21 @@ def shmip_amr_states(nx0, ny0, patches, lx=1.0e5, ly=2.0e4, ice_height=5000.0, s
     return out
 
 
+def shmip_amrm_states(nx0, ny0, boxes, **kw):
+    """shmip_amr_states for a hierarchy whose levels >= 1 are unions of boxes (boxes[l-1] = list of (lo0, lo1, hi0, hi1) in
+    the index space of level l): [[level-0 state], [states of the boxes of level 1], ...]; the fields are analytic functions
+    of (x, y), so a ghost cell of a box holds the neighbour's value or the function's own."""
+    out = [[shmip_amr_states(nx0, ny0, (), **kw)[0]]]
+    for l, bl in enumerate(boxes, start=1):
+        lev = []
+        for (lo0, lo1, hi0, hi1) in bl:
+            # a one-patch hierarchy whose patch is this box: patch boxes are given in the cells of the level below
+            chain = [(0, 0, (nx0 << k) - 1, (ny0 << k) - 1) for k in range(l - 1)] + [(lo0 // 2, lo1 // 2, hi0 // 2, hi1 // 2)]
+            lev.append(shmip_amr_states(nx0, ny0, chain, **kw)[-1])
+        out.append(lev)
+    return out
+
+
 def shmip_postproc_table(dx, dy, qwx, cd, src, mR, Pw, Pi, mask, rho_w=1000.0):
     """The SHMIP cross-section table of AmrHydro::timeStepFAS (src/AmrHydro.cpp:3647-4102), columns of
     exec/*_SHMIP/*/results/postproc.dat: x[km], Ylength, discharge, dischargeEFF, dischargeINEFF,
