@@ -91,6 +91,7 @@ enum {
     SUHMO_F_MSRC,        /* moulin source term, m/s (suhmo_level_moulin_source) */
     SUHMO_F_DCX, SUHMO_F_DCY, SUHMO_F_DTERM,   /* diffusion coefficient of the gap height on x / y faces, div(D grad b) */
     SUHMO_F_ZS,          /* ice surface height (m_iceheight), input of suhmo_level_time_varying_recharge */
+    SUHMO_F_COVER,       /* hierarchies of box unions: 1 where a finer level covers the cell, else 0 (norms, Picard test, moulin integrals) */
     SUHMO_F_COUNT
 };
 
@@ -359,6 +360,14 @@ int suhmo_hier_update_operator(suhmo_hier_t *H, int level, suhmo_stream_t s);
 int suhmo_hier_residual(suhmo_hier_t *H, double *norm, suhmo_stream_t s);
 int suhmo_hier_vcycle(suhmo_hier_t *H, const suhmo_solver_params_t *sp, suhmo_stream_t s);
 int suhmo_hier_solve(suhmo_hier_t *H, const suhmo_solver_params_t *sp, int *iters, double *resid_hist, suhmo_stream_t s);
+/* suhmo_amr_timestep / suhmo_amr_moulin_source on a hierarchy of box unions (AmrHydro::timeStepFAS with m_finest_level > 0,
+ * Calc_moulin_integral over all levels): the phases of suhmo_level_timestep on every box, exchange() between the boxes of a
+ * level after every ghost fill, PiecewiseLinearFillPatch / QuadCFInterp from the level below, SolveForHead_nl = suhmo_hier_solve,
+ * gap height by forward Euler or (use_impl_diff) SolveForGap_nl over a second hierarchy of the same boxes. */
+int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *mp, double dt, int cur_step, int *picard_iters, int *vcycles,
+                        suhmo_stream_t s);
+int suhmo_hier_moulin_source(suhmo_hier_t *H, int n_moulins, const double *positions, const double *sigma, const double *flux,
+                             double time_factor, double *integrals, suhmo_stream_t s);
 
 /* timing helper: average device time (ms) of the depth-0 GSRB sweep kernel launches since the last reset, measured with
  * HIP events on the launch stream.  suhmo_level_profile_read: the plain K-sweep launches (k_gsrb_fused<K, ., ., false>);

@@ -23,7 +23,7 @@
 //
 // Cycle = suhmo_amr.hip's, arithmetic = oracle/amrm.c, bit for bit.  [Chombo] pieces are
 // restated from upstream Chombo 3.2 (fork not vendored): unpinned against the reference.
-#include "suhmo_common.h"
+#include "suhmo_hier.h"
 #include <algorithm>
 #include <map>
 
@@ -120,6 +120,7 @@ struct suhmo_hier {
     int nlev = 0, device = 0;
     HLev lev[8];
     suhmo_bc_t bc;
+    suhmo_level_desc_t base_desc;
     suhmo_hier *gap = nullptr; double gap_dt = 0.0;        // implicit gap-height operator of the time step, owned
 };
 
@@ -761,7 +762,7 @@ extern "C" int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *b
     ARG(nlev == 1 || (nbox && boxes));
     ARG(base->j0 == 0 && base->ny == base->ny_global && base->i0 == 0 && (base->nx_global == 0 || base->nx_global == base->nx));
     suhmo_hier *H = new suhmo_hier();
-    H->nlev = nlev; H->device = base->device; H->bc = base->bc;
+    H->nlev = nlev; H->device = base->device; H->bc = base->bc; H->base_desc = *base; H->base_desc.boxes = nullptr; H->base_desc.nbox = 0;
     suhmo_level *B = nullptr;
     int rc = suhmo_level_create(&B, base);
     if (rc) { delete H; return rc; }
@@ -830,9 +831,41 @@ extern "C" int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *b
         if ((rc = build_plans(H, l))) { suhmo_hier_destroy(H); return rc; }
         if ((rc = refresh_tables(H, l, nullptr))) { suhmo_hier_destroy(H); return rc; }
     }
+    // SUHMO_F_COVER: 1 under a finer level, 0 elsewhere
+    for (int l = 0; l < nlev; l++) for (suhmo_level *L : H->lev[l].box) if ((rc = suhmo_level_set_value(L, 0, SUHMO_F_COVER, 0.0, nullptr))) { suhmo_hier_destroy(H); return rc; }
+    for (int l = 1; l < nlev; l++) if ((rc = hier_avg(H, l, SUHMO_F_COVER, SUHMO_F_COVER, 1, 1.0, nullptr))) { suhmo_hier_destroy(H); return rc; }
+    HIPCHK(hipDeviceSynchronize());
     *out = H;
     return 0;
 }
+// internal interface for the time step (suhmo_step.hip)
+int suhmo_hier_nlev_(const suhmo_hier *H) { return H->nlev; }
+const std::vector<suhmo_level *> &suhmo_hier_boxes_(suhmo_hier *H, int l) { return H->lev[l].box; }
+int suhmo_hier_device_(const suhmo_hier *H) { return H->device; }
+int suhmo_hier_ff_(suhmo_hier *H, int l, int f0, int f1, bool corners, hipStream_t st) { return hier_ff(H, l, f0, f1, corners, st); }
+int suhmo_hier_cf_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st) { return hier_cf(H, l, ff, fc, st); }
+int suhmo_hier_pwl_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st) { return hier_pwl(H, l, ff, fc, st); }
+int suhmo_hier_avg_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st) { return hier_avg(H, l, ff, fc, 0, 0.0, st); }
+int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, suhmo_hier **gap)
+{
+    if (!H->gap || H->gap_dt != dt) {
+        if (H->gap) { suhmo_hier_destroy(H->gap); H->gap = nullptr; }
+        suhmo_level_desc_t d = H->base_desc;
+        const suhmo_level *B = H->lev[0].box[0];
+        d.boxes = B->boxes.data(); d.nbox = (int)(B->boxes.size() / 4);
+        for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) { d.bc.type[a][b] = 1; d.bc.value[a][b] = 0.0; }
+        d.phys.use_NL = 0; d.alpha = 1.0; d.beta = dt * mp->diffFactor;
+        std::vector<int> nbox(H->nlev, 0), flat;
+        for (int l = 1; l < H->nlev; l++) { nbox[l] = (int)H->lev[l].box.size(); flat.insert(flat.end(), H->lev[l].b4.begin(), H->lev[l].b4.end()); }
+        int rc = suhmo_hier_create(&H->gap, &d, H->nlev, nbox.data(), flat.data()); if (rc) return rc;
+        H->gap_dt = dt;
+        for (int l = 0; l < H->nlev; l++)
+            for (suhmo_level *L : H->gap->lev[l].box) if ((rc = suhmo_level_set_value(L, 0, SUHMO_F_ACOEF, 1.0, nullptr))) return rc;   // aCoeff_GH :1820-1828
+    }
+    *gap = H->gap;
+    return 0;
+}
+
 extern "C" int suhmo_hier_num_levels(const suhmo_hier_t *H) { return H ? H->nlev : -1; }
 extern "C" int suhmo_hier_num_boxes(const suhmo_hier_t *H, int l) { return (H && l >= 0 && l < H->nlev) ? (int)H->lev[l].box.size() : -1; }
 extern "C" suhmo_level_t *suhmo_hier_box(suhmo_hier_t *H, int l, int k)

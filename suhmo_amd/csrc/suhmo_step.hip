@@ -14,7 +14,7 @@
 // a field (b, mR, grad h, RHS halos for the redundant halo-row relaxation) the strip's exchange hook is called, the
 // Picard test is MAX all-reduced; the moulin integrals are evaluated redundantly over the whole domain (analytic
 // integrand, no data), so the result does not depend on the partition bit for bit.
-#include "suhmo_common.h"
+#include "suhmo_hier.h"
 #include <cmath>
 
 // Qw on x- and y-faces: B_ec, Re_ec by CellToEdge (half*(cell + lower cell)), grad h by NEWMACGRAD
@@ -175,7 +175,7 @@ static int exchange1(suhmo_level *L, int f, hipStream_t st) { return suhmo_excha
 // max |(h_lagged - h) / maxHead| is the second divided by |maxHead| afterwards: a correctly rounded division by a fixed
 // divisor is monotone and sign-symmetric, so the maximum of the quotients is the quotient of the maximum, bit for bit.
 __global__ __launch_bounds__(256) void k_picard2_partial(DV v, const double *__restrict__ h, const double *__restrict__ hl,
-                                                         double *__restrict__ partial, Excl ex)
+                                                         double *__restrict__ partial, Excl ex, const double *__restrict__ cover = nullptr)
 {
     __shared__ double sm0[256], sm1[256];
     int tid = threadIdx.y * blockDim.x + threadIdx.x;
@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) void k_picard2_partial(DV v, const double *__r
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.nx; i += gridDim.x * blockDim.x) {
             if (i >= ex.i0 && i < ex.i1 && j >= ex.j0 && j < ex.j1) continue;
             int idx = cidx(v, i, j);
+            if (cover && cover[idx] != 0.0) continue;          // hierarchy of box unions: SUHMO_F_COVER
             a0 = fmax(a0, h[idx]);
             a1 = fmax(a1, fabs(hl[idx] - h[idx]));
         }
@@ -211,11 +212,11 @@ __global__ void k_max2_final(const double *__restrict__ partial, int n, double *
 }
 // max h and max |hl - h| over the level's cells (local to the rank)
 static int picard_maxima(suhmo_level *L, const double *h, const double *hl, double *maxh, double *maxd, hipStream_t st,
-                         Excl ex = Excl{0, 0, 0, 0})
+                         Excl ex = Excl{0, 0, 0, 0}, const double *cover = nullptr)
 {
     Depth &D = L->d[0];
     dim3 grd(std::min((D.v.nx + 63) / 64, 32), std::min((D.v.ny + 3) / 4, 128));
-    hipLaunchKernelGGL(k_picard2_partial, grd, dim3(64, 4), 0, st, D.v, h, hl, L->scratch + 2, ex);
+    hipLaunchKernelGGL(k_picard2_partial, grd, dim3(64, 4), 0, st, D.v, h, hl, L->scratch + 2, ex, cover);
     hipLaunchKernelGGL(k_max2_final, dim3(1), dim3(256), 0, st, L->scratch + 2, (int)(grd.x * grd.y), L->scratch, suhmo_host_slot(L));
     int rc = suhmo_readback(L, st, maxh, maxd); if (rc) return rc;
     return 0;
@@ -568,6 +569,142 @@ extern "C" int suhmo_amr_timestep(suhmo_level_t **lv, int nlev, const suhmo_mode
     return 0;
 }
 
+// ------------------------------------------------------------------ the time step on a hierarchy of box unions
+// oracle/amr_step_m.c: suhmo_amr_timestep with every level's rectangle replaced by its boxes; after every fill of data ghosts
+// the reference's exchange() is the fine-fine copy between the boxes of the level (suhmo_hier.hip).
+namespace {
+#define BOXES(l) for (suhmo_level *L : suhmo_hier_boxes_(H, l))
+int hier_chain(suhmo_hier *H, int l, hipStream_t st)
+{
+    int rc;
+    if ((rc = suhmo_hier_cf_(H, l, SUHMO_F_PHI, SUHMO_F_PHI, st))) return rc;                  // inside compGradientMAC
+    if ((rc = suhmo_hier_ff_(H, l, SUHMO_F_PHI, -1, false, st))) return rc;
+    BOXES(l) if ((rc = suhmo_grad_cc(L, 0, st))) return rc;
+    if ((rc = suhmo_hier_cf_(H, l, SUHMO_F_GRADX, SUHMO_F_GRADX, st))) return rc;              // :1650-1659
+    if ((rc = suhmo_hier_cf_(H, l, SUHMO_F_GRADY, SUHMO_F_GRADY, st))) return rc;
+    if ((rc = suhmo_hier_ff_(H, l, SUHMO_F_GRADX, SUHMO_F_GRADY, true, st))) return rc;
+    BOXES(l) if ((rc = suhmo_re_cells(L, 0, st))) return rc;
+    if ((rc = suhmo_hier_pwl_(H, l, SUHMO_F_RE, SUHMO_F_RE, st))) return rc;                   // :2711-2721
+    if ((rc = suhmo_hier_ff_(H, l, SUHMO_F_RE, -1, true, st))) return rc;
+    BOXES(l) {
+        Depth &D = L->d[0];
+        hipLaunchKernelGGL(k_qw_faces, dim3((D.v.nx + 1 + 63) / 64, (D.v.ny + 1 + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, L->ph);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// ghosts of b of level l: PiecewiseLinearFillPatch on coarse-fine cells, exchange between the boxes, copies on domain sides
+int hier_gap_ghosts(suhmo_hier *H, int l, hipStream_t st)
+{
+    int rc;
+    if ((rc = suhmo_hier_pwl_(H, l, SUHMO_F_B, SUHMO_F_B, st))) return rc;
+    if ((rc = suhmo_hier_ff_(H, l, SUHMO_F_B, -1, true, st))) return rc;
+    BOXES(l) if ((rc = suhmo_copy_ghosts(L, 0, SUHMO_F_B, st))) return rc;
+    return 0;
+}
+}  // namespace
+
+extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *mp, double dt, int cur_step,
+                                   int *picard_iters, int *vcycles, suhmo_stream_t s)
+{
+    ARG(H && mp); ARG(dt > 0 && cur_step >= 1);
+    if (mp->use_impl_diff && mp->diffFactor == 0.0) { suhmo_set_error("use_ImplDiff with diffFactor = 0"); return -1; }
+    const int nlev = suhmo_hier_nlev_(H);
+    HIPCHK(hipSetDevice(suhmo_hier_device_(H)));
+    hipStream_t st = (hipStream_t)s;
+    int rc;
+    static const int need[] = {SUHMO_F_MR, SUHMO_F_PW, SUHMO_F_QWX, SUHMO_F_QWY, SUHMO_F_HLAG, SUHMO_F_CD, SUHMO_F_GRADX, SUHMO_F_GRADY, SUHMO_F_RE};
+    for (int l = 0; l < nlev; l++) BOXES(l) {
+        for (int f : need) if (!suhmo_field(L, 0, f)) { suhmo_set_error("field allocation failed"); return -2; }
+        if (mp->use_moulin_source && !L->d[0].fp.f[SUHMO_F_MSRC]) { suhmo_set_error("use_moulin_source without a moulin source term (suhmo_hier_moulin_source)"); return -1; }
+    }
+    suhmo_level *base = suhmo_hier_boxes_(H, 0)[0];
+    // [I]
+    for (int l = 0; l < nlev; l++) if ((rc = hier_gap_ghosts(H, l, st))) return rc;
+    if ((rc = suhmo_build_mg_coefficients(base, false, st))) return rc;         // bCoef: re-averaged by every V-cycle (bcoeff_otf)
+    suhmo_solver_params_t sp;
+    sp.num_smooth = 4; sp.num_bottom = 16; sp.max_iter = 100; sp.iter_min = 2; sp.imin = 5;
+    sp.eps = 1.0e-7; sp.hang = 0.01; sp.norm_thresh = 1.0e-7; sp.bcoeff_otf = 1; sp.max_depth = -1;
+    if (cur_step < 50) { sp.num_bottom = 10; sp.eps = 1.0e-10; sp.hang = 0.0001; sp.imin = 20; }
+    bool converged = false;
+    int ite_idx = 0, cur_picard = 0, nv = 0;
+    while (!converged) {
+        for (int l = 0; l < nlev; l++) {
+            if ((rc = hier_gap_ghosts(H, l, st))) return rc;
+            if ((rc = suhmo_hier_pwl_(H, l, SUHMO_F_MR, SUHMO_F_MR, st))) return rc;
+            if ((rc = suhmo_hier_ff_(H, l, SUHMO_F_MR, -1, true, st))) return rc;               // levelmR.exchange() :2513
+            BOXES(l) { Depth &D = L->d[0];
+                HIPCHK(hipMemcpyAsync(D.fp.f[SUHMO_F_HLAG], D.fp.f[SUHMO_F_PHI], D.elems * sizeof(double), hipMemcpyDeviceToDevice, st)); }
+        }
+        for (int l = 0; l < nlev; l++) if ((rc = hier_chain(H, l, st))) return rc;
+        for (int l = 0; l < nlev; l++) BOXES(l) {
+            Depth &D = L->d[0];
+            if (mp->diffFactor != 0.0 && (rc = diffusion_terms(L, mp, st))) return rc;
+            hipLaunchKernelGGL(k_melt<0>, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, L->ph, *mp, dt);
+            HIPCHK(hipGetLastError());
+        }
+        int it = 0;
+        if ((rc = suhmo_hier_solve(H, &sp, &it, nullptr, s))) return rc;
+        nv += it;
+        for (int l = nlev - 1; l > 0; l--) if ((rc = suhmo_hier_avg_(H, l, SUHMO_F_PHI, SUHMO_F_PHI, st))) return rc;   // CoarseAverage :3138-3141
+        double maxHead = -1.0e300, maxd = 0.0, res = 0.0;
+        for (int l = 0; l < nlev; l++) BOXES(l) {
+            double m = 0.0, d = 0.0;
+            const double *cover = l < nlev - 1 ? L->d[0].fp.f[SUHMO_F_COVER] : nullptr;
+            if ((rc = picard_maxima(L, L->d[0].fp.f[SUHMO_F_PHI], L->d[0].fp.f[SUHMO_F_HLAG], &m, &d, st, Excl{0, 0, 0, 0}, cover))) return rc;
+            maxHead = std::max(maxHead, m); maxd = std::max(maxd, d);
+        }
+        res = picard_quotient(maxd, maxHead);
+        if (ite_idx > 100) { suhmo_set_error("does not converge (Picard iterations > 100)"); return -6; }
+        if (cur_step < 2) { if (res < 0.05 && cur_picard > 2) converged = true; }
+        else if (cur_step < 50) { if (res < 0.05) converged = true; }
+        else { if (res < mp->eps_picard) converged = true; }
+        ite_idx++; cur_picard++;
+    }
+    // [III] level by level: the coarse gap height is already updated when the fine ghost cells are filled
+    for (int l = 0; l < nlev; l++) {
+        if ((rc = hier_chain(H, l, st))) return rc;
+        BOXES(l) {
+            Depth &D = L->d[0];
+            hipLaunchKernelGGL(k_melt<1>, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, L->ph, *mp, dt);
+        }
+        HIPCHK(hipGetLastError());
+        if (mp->use_impl_diff) continue;                               // b stays, RES = b + dt RHS
+        if ((rc = hier_gap_ghosts(H, l, st))) return rc;
+    }
+    if (mp->use_impl_diff) {                                           // SolveForGap_nl over the hierarchy :3425-3455
+        suhmo_hier *G = nullptr;
+        if ((rc = suhmo_hier_gap_(H, mp, dt, &G))) return rc;
+        for (int l = 0; l < nlev; l++) {
+            const auto &hb = suhmo_hier_boxes_(H, l), &gb = suhmo_hier_boxes_(G, l);
+            for (size_t k = 0; k < hb.size(); k++) {
+                Depth &D = hb[k]->d[0], &GD = gb[k]->d[0];
+                if (GD.elems != D.elems) { suhmo_set_error("internal: gap hierarchy geometry"); return -4; }
+                const size_t bytes = D.elems * sizeof(double);
+                HIPCHK(hipMemcpyAsync(GD.fp.f[SUHMO_F_PHI], D.fp.f[SUHMO_F_B], bytes, hipMemcpyDeviceToDevice, st));      // initial guess = b :3382-3385
+                HIPCHK(hipMemcpyAsync(GD.fp.f[SUHMO_F_RHS], D.fp.f[SUHMO_F_RES], bytes, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(GD.fp.f[SUHMO_F_BX], D.fp.f[SUHMO_F_DCX], bytes, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(GD.fp.f[SUHMO_F_BY], D.fp.f[SUHMO_F_DCY], bytes, hipMemcpyDeviceToDevice, st));
+                GD.phi_fresh = 0;
+            }
+        }
+        if ((rc = suhmo_level_build_mg_coefficients(suhmo_hier_boxes_(G, 0)[0], s))) return rc;
+        suhmo_solver_params_t spg;
+        gap_solver_params(spg, cur_step);
+        if ((rc = suhmo_hier_solve(G, &spg, nullptr, nullptr, s))) return rc;
+        for (int l = 0; l < nlev; l++) {
+            const auto &hb = suhmo_hier_boxes_(H, l), &gb = suhmo_hier_boxes_(G, l);
+            for (size_t k = 0; k < hb.size(); k++)
+                HIPCHK(hipMemcpyAsync(hb[k]->d[0].fp.f[SUHMO_F_B], gb[k]->d[0].fp.f[SUHMO_F_PHI], hb[k]->d[0].elems * sizeof(double), hipMemcpyDeviceToDevice, st));
+            if ((rc = hier_gap_ghosts(H, l, st))) return rc;
+        }
+    }
+    if (picard_iters) *picard_iters = ite_idx;
+    if (vcycles) *vcycles = nv;
+    return 0;
+}
+#undef BOXES
+
 // ------------------------------------------------------------------ moulin source term
 // Calc_moulin_integral / Calc_moulin_source_term_distributed (src/AmrHydro.cpp:1866-2066).  The n x N array of the
 // reference (one component per moulin) is never stored: pass 1 integrates every Gaussian (per-tile partial sums in a
@@ -593,14 +730,17 @@ __device__ __forceinline__ double moulin_cell(double xc, double yc, double dx, d
          + v[0] * v[1] * MS[3] + v[1] * v[1] * MS[4] + v[2] * v[1] * MS[5]
          + v[0] * v[2] * MS[6] + v[1] * v[2] * MS[7] + v[2] * v[2] * MS[8];
 }
-__global__ __launch_bounds__(256) void k_moulin_partial(DV v, int n, const double *__restrict__ mo, double *__restrict__ partial, Excl ex)
+__global__ __launch_bounds__(256) void k_moulin_partial(DV v, int n, const double *__restrict__ mo, double *__restrict__ partial, Excl ex,
+                                                        const double *__restrict__ cover = nullptr)
 {
     __shared__ double sm[256];
     const int tid = threadIdx.y * 16 + threadIdx.x;
     const int i = blockIdx.x * 16 + threadIdx.x, j = blockIdx.y * 16 + threadIdx.y;
-    const bool in = i < v.nx && j < v.ny && !(i >= ex.i0 && i < ex.i1 && j >= ex.j0 && j < ex.j1);   // covered by a finer level: 0
+    bool in = i < v.nx && j < v.ny && !(i >= ex.i0 && i < ex.i1 && j >= ex.j0 && j < ex.j1);   // covered by a finer level: 0
+    if (in && cover && cover[cidx(v, i, j)] != 0.0) in = false;
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-    const double tx0 = (blockIdx.x * 16) * v.dx, tx1 = (blockIdx.x * 16 + 16) * v.dx, ty0 = (blockIdx.y * 16) * v.dy, ty1 = (blockIdx.y * 16 + 16) * v.dy;
+    const double tx0 = (v.i0 + blockIdx.x * 16) * v.dx, tx1 = (v.i0 + blockIdx.x * 16 + 16) * v.dx;      // the tile in physical coordinates (a patch / box
+    const double ty0 = (v.j0 + blockIdx.y * 16) * v.dy, ty1 = (v.j0 + blockIdx.y * 16 + 16) * v.dy;      // starts at (i0, j0) of its level)
     for (int m = 0; m < n; m++) {
         const double mx = mo[3 * m], my = mo[3 * m + 1], sg = mo[3 * m + 2];
         double ddx = mx < tx0 ? tx0 - mx : (mx > tx1 ? mx - tx1 : 0.0), ddy = my < ty0 ? ty0 - my : (my > ty1 ? my - ty1 : 0.0);
@@ -626,11 +766,12 @@ __global__ void k_moulin_final(const double *__restrict__ partial, int nblk, int
     if (tid == 0) integ[m] = sm[0];
 }
 __global__ __launch_bounds__(256) void k_moulin_src(DV v, int n, const double *__restrict__ mo, const double *__restrict__ flux,
-                                                    const double *__restrict__ integ, double tf, double *__restrict__ out, Excl ex)
+                                                    const double *__restrict__ integ, double tf, double *__restrict__ out, Excl ex,
+                                                    const double *__restrict__ cover = nullptr)
 {
     const int i = blockIdx.x * 16 + threadIdx.x, j = blockIdx.y * 16 + threadIdx.y;
     if (i >= v.nx || j >= v.ny) return;
-    if (i >= ex.i0 && i < ex.i1 && j >= ex.j0 && j < ex.j1) { out[cidx(v, i, j)] = 0.0; return; }   // filled by the average of the finer level
+    if ((i >= ex.i0 && i < ex.i1 && j >= ex.j0 && j < ex.j1) || (cover && cover[cidx(v, i, j)] != 0.0)) { out[cidx(v, i, j)] = 0.0; return; }   // filled by the average of the finer level
     double sum = 0.0;
     for (int m = 0; m < n; m++) {
         bool z;
@@ -750,6 +891,61 @@ extern "C" int suhmo_amr_moulin_source(suhmo_level_t **lv, int nlev, const int *
     return 0;
 }
 
+
+// suhmo_amr_moulin_source on a hierarchy of box unions (oracle/amr_step_m.c:or_amrm_model_moulin_source): finest level first,
+// box after box; cells under a finer level (SUHMO_F_COVER) do not count and get the finer level's average afterwards
+extern "C" int suhmo_hier_moulin_source(suhmo_hier_t *H, int n, const double *positions, const double *sigma, const double *flux,
+                                        double time_factor, double *integrals, suhmo_stream_t s)
+{
+    ARG(H && n >= 1 && positions && sigma && flux);
+    const int nlev = suhmo_hier_nlev_(H);
+    HIPCHK(hipSetDevice(suhmo_hier_device_(H)));
+    hipStream_t st = (hipStream_t)s;
+    int rc;
+    std::vector<double> h(4 * (size_t)n), total((size_t)n, 0.0), part((size_t)n);
+    for (int m = 0; m < n; m++) {
+        ARG(sigma[m] > 0.0);
+        h[3 * m] = positions[2 * m]; h[3 * m + 1] = positions[2 * m + 1]; h[3 * m + 2] = sigma[m]; h[3 * (size_t)n + m] = flux[m];
+    }
+    size_t maxblk = 0;
+    for (int l = 0; l < nlev; l++) for (suhmo_level *L : suhmo_hier_boxes_(H, l)) {
+        if (!suhmo_field(L, 0, SUHMO_F_MSRC)) { suhmo_set_error("field allocation failed"); return -2; }
+        maxblk = std::max(maxblk, (size_t)((L->d[0].v.nx + 15) / 16) * ((L->d[0].v.ny + 15) / 16));
+    }
+    double *dev = nullptr;
+    HIPCHK(hipMalloc(&dev, (5 * (size_t)n + maxblk * n) * sizeof(double)));
+    double *mo = dev, *fl = dev + 3 * (size_t)n, *integ = dev + 4 * (size_t)n, *partial = dev + 5 * (size_t)n;
+    hipError_t e = hipMemcpyAsync(dev, h.data(), 4 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
+    for (int l = nlev - 1; l >= 0 && e == hipSuccess; l--)             // finest first (:1891)
+        for (suhmo_level *L : suhmo_hier_boxes_(H, l)) {
+            const DV &v = L->d[0].v;
+            dim3 blk(16, 16), grd((v.nx + 15) / 16, (v.ny + 15) / 16);
+            const double *cover = l < nlev - 1 ? L->d[0].fp.f[SUHMO_F_COVER] : nullptr;
+            hipLaunchKernelGGL(k_moulin_partial, grd, blk, 0, st, v, n, mo, partial, Excl{0, 0, 0, 0}, cover);
+            hipLaunchKernelGGL(k_moulin_final, dim3(n), dim3(256), 0, st, partial, (int)(grd.x * grd.y), n, integ);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(part.data(), integ, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) break;
+            for (int m = 0; m < n; m++) total[m] += part[m];
+        }
+    if (e == hipSuccess) e = hipMemcpyAsync(integ, total.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
+    for (int l = 0; l < nlev && e == hipSuccess; l++)
+        for (suhmo_level *L : suhmo_hier_boxes_(H, l)) {
+            const DV &v = L->d[0].v;
+            dim3 blk(16, 16), grd((v.nx + 15) / 16, (v.ny + 15) / 16);
+            const double *cover = l < nlev - 1 ? L->d[0].fp.f[SUHMO_F_COVER] : nullptr;
+            hipLaunchKernelGGL(k_moulin_src, grd, blk, 0, st, v, n, mo, fl, integ, time_factor, L->d[0].fp.f[SUHMO_F_MSRC], Excl{0, 0, 0, 0}, cover);
+            e = hipGetLastError();
+            if (e != hipSuccess) break;
+        }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dev);
+    if (e != hipSuccess) { suhmo_set_error("moulin source: %s", hipGetErrorString(e)); return -2; }
+    for (int l = nlev - 1; l > 0; l--) if ((rc = suhmo_hier_avg_(H, l, SUHMO_F_MSRC, SUHMO_F_MSRC, st))) return rc;
+    if (integrals) for (int m = 0; m < n; m++) integrals[m] = total[m];
+    return 0;
+}
 
 // COMPUTE_TIMEVARYINGRECHARGE (src/AmrHydroF.ChF:346-373) on the ghosted box of the source term
 __global__ void k_time_varying_recharge(DV v, const double *__restrict__ zs, double *__restrict__ out, double TK, double background)

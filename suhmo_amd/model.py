@@ -139,3 +139,51 @@ class HipAmrModel:
 
     def close(self):
         self.amr.close()
+
+
+class HipHierModel:
+    """The time loop on a hierarchy whose levels are unions of boxes (boxes[l-1] = list of (lo0, lo1, hi0, hi1) in the index
+    space of level l): suhmo_hier_timestep / suhmo_hier_moulin_source; head and gap height of every box stay in HBM."""
+
+    FIELDS = HipModel.FIELDS
+
+    def __init__(self, nx0, ny0, dx0, dy0, bc, phys, model, boxes, max_box=64, device=0):
+        self.hier = lv.HipHier(nx0, ny0, dx0, dy0, bc, phys, boxes, alpha=0.0, beta=-1.0, max_box=max_box, device=device)
+        self.level = self.hier.level
+        self.model = dict(model)
+        self._mp = model_params(model)
+        self.cur_step = 0
+
+    def set_state(self, l, k, f):
+        """f: dict with ghosted arrays head, B, Pi, zb, mask of box k of level l (fine-fine / coarse-fine ghost cells: anything)"""
+        L = self.level[l][k]
+        L.set(lv.F_PHI, f["head"][1:-1, 1:-1])
+        L.set(lv.F_ACOEF, np.zeros((L.ny, L.nx)))
+        for key, fid in (("B", lv.F_B), ("Pi", lv.F_PI), ("zb", lv.F_ZB), ("mask", lv.F_MASK)):
+            L.set(fid, f[key], ghosted=True)
+
+    def set_states(self, sts):
+        for l, bl in enumerate(sts):
+            for k, st in enumerate(bl):
+                self.set_state(l, k, st)
+
+    def timestep(self, dt):
+        self.cur_step += 1
+        pi, nv = C.c_int(), C.c_int()
+        check(capi.lib().suhmo_hier_timestep(self.hier.h, C.byref(self._mp), float(dt), self.cur_step, C.byref(pi), C.byref(nv),
+                                             self.hier.stream))
+        return pi.value, nv.value
+
+    def moulin_source(self, positions, sigma, flux, time_factor=1.0):
+        pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1)
+        sg, fl = np.ascontiguousarray(sigma, dtype=np.float64), np.ascontiguousarray(flux, dtype=np.float64)
+        integ = np.zeros(sg.size)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        check(capi.lib().suhmo_hier_moulin_source(self.hier.h, sg.size, dp(pos), dp(sg), dp(fl), float(time_factor), dp(integ), self.hier.stream))
+        return integ
+
+    def get(self, l, k, name, ghosted=False):
+        return self.level[l][k].get(self.FIELDS[name], ghosted=ghosted)
+
+    def close(self):
+        self.hier.close()

@@ -1,0 +1,78 @@
+"""The time step on hierarchies whose levels are unions of boxes (suhmo_hier_timestep / suhmo_hier_moulin_source) against
+oracle/amr_step_m.c on the same inputs: BITWISE on every box of base + 3 levels (an L-shaped union, a disjoint box, a box on
+the domain side) over several steps, explicit and with moulins + diffusion + the implicit gap-height solve (cfg4 / cfg5
+physics); one box per level equals the nested-patch step (suhmo_amr_timestep)."""
+import numpy as np
+import pytest
+
+from suhmo_amd import synthetic as sy
+
+pytestmark = pytest.mark.gpu
+ONE = ([(32, 16, 95, 47)], [(80, 44, 159, 83)])
+ONE_PATCHES = ((16, 8, 47, 23), (40, 22, 79, 41))
+CUT = ([(32, 16, 63, 47), (64, 16, 95, 31), (64, 32, 95, 47)], [(80, 44, 119, 83), (120, 44, 159, 83)])
+UNION = ([(32, 16, 63, 47), (64, 16, 95, 31), (0, 4, 23, 27)],
+         [(72, 40, 119, 55), (72, 56, 103, 87), (8, 16, 31, 39)],
+         [(160, 88, 207, 103), (24, 40, 47, 63)])
+MOULINS = dict(positions=[(30.0e3, 9.0e3), (42.0e3, 5.5e3), (8.0e3, 4.0e3)], sigma=[900.0, 700.0, 800.0], flux=[8.0, 5.0, 3.0])
+B5ISH = dict(diffFactor=1.0, use_impl_diff=1, use_moulin_source=1, distributed_input=7.93e-11)
+
+CASES = [("union-explicit", UNION, dict(), 3), ("union-diffusion", UNION, dict(diffFactor=1.0), 2),
+         ("union-moulins-implicit", UNION, B5ISH, 3), ("cut-moulins-implicit", CUT, B5ISH, 2)]
+
+
+def make(oracle, boxes, m, nx0=64, ny0=32):
+    from suhmo_amd import model
+    sts = sy.shmip_amrm_states(nx0, ny0, boxes, rough=0.5)
+    O = oracle.OracleAmrMModel(nx0, ny0, sts[0][0]["dx"], sts[0][0]["dy"], sy.A3_BC, sy.A3_PHYS, m, boxes, max_box=16, nthreads=2)
+    G = model.HipHierModel(nx0, ny0, sts[0][0]["dx"], sts[0][0]["dy"], sy.A3_BC, sy.A3_PHYS, m, boxes, max_box=16)
+    O.set_states(sts); G.set_states(sts)
+    return O, G, sts
+
+
+@pytest.mark.parametrize("name,boxes,mpo,nsteps", CASES, ids=[c[0] for c in CASES])
+def test_hier_timestep_bitwise(oracle, name, boxes, mpo, nsteps):
+    from suhmo_amd import level as lv
+    m = dict(sy.A3_MODEL, **mpo)
+    O, G, sts = make(oracle, boxes, m)
+    if m.get("use_moulin_source"):
+        io, ig = O.moulin_source(**MOULINS), G.moulin_source(**MOULINS)
+        assert np.max(np.abs(io - ig)) <= 1e-13 * np.max(io)
+        for l in range(O.nlev):
+            for k in range(len(O.boxes[l])):
+                a, b = np.array(O.field(l, k, oracle.OM_MSRC))[1:-1, 1:-1], G.get(l, k, "msrc")
+                assert np.max(np.abs(a - b)) <= 1e-13 * max(np.max(np.abs(a)), 1e-300), (l, k)
+                G.level[l][k].set(lv.F_MSRC, a)       # continue from identical source terms (two exp libraries)
+    v = lambda a: np.array(a)[1:-1, 1:-1]
+    for step in range(nsteps):
+        co, cg = O.timestep(m["dt"]), G.timestep(m["dt"])
+        assert co == cg, (step, co, cg)
+        for l in range(O.nlev):
+            for k in range(len(O.boxes[l])):
+                for nm, fid in (("head", oracle.OM_H), ("B", oracle.OM_B), ("mR", oracle.OM_MR), ("Pw", oracle.OM_PW), ("rhs_h", oracle.OM_RHSH),
+                                ("Re", oracle.OM_RE)):
+                    a, b = v(O.field(l, k, fid)), G.get(l, k, nm)
+                    assert np.array_equal(a, b, equal_nan=True), (name, step, l, k, nm, float(np.nanmax(np.abs(a - b))))
+                for nm, fid in (("qwx", oracle.OM_QWX), ("qwy", oracle.OM_QWY)):
+                    a, b = np.array(O.field(l, k, fid)), G.get(l, k, nm)
+                    assert np.array_equal(a, b, equal_nan=True), (name, step, l, k, nm)
+                a, b = np.array(O.field(l, k, oracle.OM_B)), G.get(l, k, "B", ghosted=True)
+                assert np.array_equal(a[1:-1, :], b[1:-1, :]) and np.array_equal(a[:, 1:-1], b[:, 1:-1]), (name, step, l, k, "B ghosts")
+    O.close(); G.close()
+
+
+def test_one_box_per_level_equals_the_nested_patch_step(oracle):
+    from suhmo_amd import model
+    m = dict(sy.A3_MODEL, diffFactor=1.0, use_impl_diff=1)
+    sts = sy.shmip_amrm_states(64, 32, ONE, rough=0.5)
+    H = model.HipHierModel(64, 32, sts[0][0]["dx"], sts[0][0]["dy"], sy.A3_BC, sy.A3_PHYS, m, ONE, max_box=16)
+    A = model.HipAmrModel(64, 32, sts[0][0]["dx"], sts[0][0]["dy"], sy.A3_BC, sy.A3_PHYS, m, ONE_PATCHES, max_box=16)
+    H.set_states(sts)
+    for l in range(3):
+        A.set_state(l, sts[l][0])
+    for step in range(2):
+        assert H.timestep(m["dt"]) == A.timestep(m["dt"])
+        for l in range(3):
+            for nm in ("head", "B", "mR", "qwx"):
+                assert np.array_equal(H.get(l, 0, nm), A.get(l, nm)), (step, l, nm)
+    H.close(); A.close()
