@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_PER_CELL_SWEEP = 72.0    # phi r+w, rhs, bx, by, B, Pi, zb, mask
+PMC_FILE = "r02_pmc_traffic_gsrb.json"   # HBM bytes per launch of the depth-0 kernel, from this round's rocprofv3 --pmc passes
 LX = 1.0e5                     # width of the synthetic domain in metres (SHMIP-A: 100 km)
 
 
@@ -36,14 +37,17 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--sweeps-only", type=int, default=0, help="also time this many bare GSRB sweeps")
     ap.add_argument("--no-side", action="store_true", help="skip the side figures of the smaller BASELINE configurations")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank holds cells x cells; strong: the level of cells x cells is cut into --gpus row strips")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))                     # plain `python bench.py --gpus N`: this process starts the N ranks itself
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        sys.exit("bench.py: WORLD_SIZE = %d but --gpus %d" % (world, args.gpus))
 
     import numpy as np
     from suhmo_amd import capi, level, synthetic as sy
@@ -59,12 +63,16 @@ def main():
         dist.init_process_group(os.environ.get("SUHMO_DIST_BACKEND", "nccl"))
     assert capi.lib().suhmo_device_count() > 0, "no GPU visible: the product path has no CPU fallback"
 
-    ny_global = n * world
+    strong = args.scaling == "strong"
+    if strong:
+        assert n % world == 0 and (n // world) % 64 == 0, "strong scaling: --cells must split into 64-row boxes per rank"
+    rows = n // world if strong else n                  # rows of this rank's strip
+    ny_global = n if strong else n * world
     # square cells (100 km across n columns, as many metres per row): on them the cycle being timed is a contractive solver
     # (SHMIP-A's own 20 km width over n rows would make the cells 5 : 1, where point relaxation stalls: same arithmetic per
     # cycle, but not a solve anybody would run)
-    f = sy.shmip_fields(n, n, ly=LX * ny_global / n, j0=rank * n, ny_total=ny_global)
-    G = level.HipLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64, j0=rank * n,
+    f = sy.shmip_fields(n, rows, ly=LX * ny_global / n, j0=rank * rows, ny_total=ny_global)
+    G = level.HipLevel(n, rows, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64, j0=rank * rows,
                        ny_global=ny_global, device=local_rank, halo_rows=int(os.environ.get("SUHMO_HALO_ROWS", "24")) if world > 1 else 1)
     G.set_inputs(f)
     if world > 1:
@@ -85,11 +93,13 @@ def main():
         G.vcycle(sp)
     sync()
     G.profile(True)
+    msgs0 = G.rccl_exchanges() if world > 1 else 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         G.vcycle(sp)
     sync()
     t1 = time.perf_counter()
+    msgs = (G.rccl_exchanges() - msgs0) / args.steps if world > 1 else 0.0
     elapsed = t1 - t0
     if dist is not None:
         import torch
@@ -102,7 +112,7 @@ def main():
     G.profile(False)
 
     sweeps_depth0 = 2 * sp["num_smooth"]
-    cells = n * n
+    cells = n * rows                                    # cells of this rank's strip
     ms_per_step = 1e3 * elapsed / args.steps
     vps = args.steps / elapsed
     # GSRB sweeps at every depth: 8 per depth + bottom, geometric in cells
@@ -118,11 +128,11 @@ def main():
     # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc cannot run inside this process:
     # collected with tools/pmc_any.sh on the same workload, corrected as MI355X_MICROARCH.md prescribes, committed)
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_gsrb.json")
-    if gsrb_launches and os.path.exists(pmc):
+    pmc = os.path.join(ROOT, "profiles", PMC_FILE)
+    if gsrb_launches and os.path.exists(pmc) and world == 1:     # the PMC passes were taken on the single-GPU workload only
         pj = json.load(open(pmc))
         if pj.get("cells") == cells and abs(sweeps_timed / gsrb_launches - pj.get("sweeps_per_launch", 0)) < 1e-9:
-            traffic, traffic_src = pj["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic_gsrb.json"
+            traffic, traffic_src = pj["hbm_bytes_per_launch"], "profiles/" + PMC_FILE
     launch_ms = gsrb_ms / max(gsrb_launches, 1)
     alg_bytes_launch = BYTES_PER_CELL_SWEEP * cells * sweeps_timed / max(gsrb_launches, 1)
 
@@ -133,7 +143,9 @@ def main():
         rbytes = (BYTES_PER_CELL_SWEEP * rst_cells / rst_launches) + 76.0 * cells
         extra["gsrb_plus_restrict_launch"] = {"kernel": "k_gsrb_fused<2, false, 64, true> (2 sweeps + restriction in one pass)", "avg_launch_ms": rl,
                                               "launches_timed": rst_launches, "algorithmic_bytes_per_launch": rbytes,
-                                              "achieved_GBs": rbytes / (rl * 1e-3) / 1e9, "frac_of_peak": rbytes / (rl * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                              "algorithmic_GBs": rbytes / (rl * 1e-3) / 1e9,
+                                              "note": "algorithmic bytes of 2 sweeps + a separate restriction pass; the fused launch moves far less, "
+                                                      "so this is an effective rate, not HBM utilisation"}
     if args.sweeps_only:
         sync()
         G.profile(True)
@@ -162,20 +174,26 @@ def main():
             "metric": "multigrid V-cycles/s (FAS head solve) + GSRB cell-updates/s; achieved HBM GB/s vs peak",
             # whole-job aggregate: a unit is one V-cycle over one GPU's batch of n x n cells; a step runs one on every GPU
             # (weak scaling: the level is world x as large), so value = world x steps / time
-            "value": vps * world, "unit": "V-cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": vps * (1 if strong else world), "unit": "V-cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "SHMIP-A head solve, %dx%d cells per GPU (square cells of %.1f m), single AMR level, 64x64 boxes, "
                                    "%d MG depths, 4+4 GSRB sweeps per depth, %d bottom (BASELINE north_star: 4096^2 single-level)"
-                                   % (n, n, LX / n, ndepth, sp["num_bottom"]),
+                                   % (n, rows, LX / n, ndepth, sp["num_bottom"]),
                        "global_cells": [n, ny_global], "partition": "row strips, 1 per GPU" if world > 1 else "none",
-                       "unit_of_value": "V-cycles over %dx%d cells (one per GPU per step; the level of %dx%d cells completes %.4g V-cycles/s)"
-                                        % (n, n, n, ny_global, vps)},
+                       "unit_of_value": "V-cycles over %dx%d cells (%s; the level of %dx%d cells completes %.4g V-cycles/s)"
+                                        % (n, n, "the whole level, cut into strips" if strong else "one per GPU per step", n, ny_global, vps),
+                       "halo_message_groups_per_vcycle_per_rank": msgs if world > 1 else None},
             "residual_max_norm": {"before_warmup": res_before, "after_timed_cycles": res_after, "cycles": args.warmup + args.steps},
-            "gsrb_cell_updates_per_s": updates_per_vcycle * vps * world,
+            "gsrb_cell_updates_per_s": updates_per_vcycle * vps * world,   # per-rank strip updates x ranks (strong and weak alike)
             "gsrb_depth0_cell_updates_per_s_kernel": cells / (sweep_ms * 1e-3) * world if gsrb_launches else None,
             "roofline": {"bound": "hbm", "kernel": "GSRB sweep (red+black) at depth 0", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "frac_note": "algorithmic bytes (72 B per cell per sweep) / time / peak, SURVEY 8(d); the kernel does K = 2 sweeps per "
+                                      "pass over HBM, so this is an effective rate: physical_frac is the HBM utilisation",
+                         # HBM bytes the launch really moved (PMC) / time / peak, and the bound of a K-sweep blocked launch (72 B per cell ONCE) / time / peak
+                         "physical_frac": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "blocked_bound_frac": (BYTES_PER_CELL_SWEEP * cells / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if gsrb_launches else None,
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": launch_ms,
                          "algorithmic_bytes_per_cell_sweep": BYTES_PER_CELL_SWEEP,
@@ -186,6 +204,27 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes here (fresh children; this parent never
+    touches the GPU and never execs), one per GPU, rendezvous on 127.0.0.1; rank 0's JSON line is the output."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def side_configs(sy, level, sp, args):
@@ -262,6 +301,32 @@ def side_configs(sy, level, sp, args):
     out["amr3_timestep_1024x256_base_63_moulins"] = {"steps_per_s": 1.0 / dt, "ms_per_step": 1e3 * dt, "amr_vcycles_per_step": nv / 20.0,
                                                      "cells_per_level": [int(st_["nx"] * st_["ny"]) for st_ in sts]}
     A.close()
+    # cfg5 as the reference grids it (exec/AMR_multiMoulins/run_C_3lev: 63 moulins on 100 km x 100 km, dino bed without its unseeded
+    # noise, diffusion + implicit gap-height solve): base + 3 AMR levels, every level a union of boxes around the moulins
+    for tag, nb in (("cfg5_multimoulins_256_base_3_amr_levels", 256), ("cfg5_multimoulins_4096_base_3_amr_levels", 4096)):
+        if nb > 256 and args.n < 4096:
+            continue
+        bc, ph, mm, mo = sy.multimoulins_setup()
+        boxes = sy.boxes_around(mo["positions"], nb, nb, 4, 1.0e5, 1.0e5)
+        sts = sy.mountain_amrm_states(nb, nb, boxes)
+        H = model.HipHierModel(nb, nb, sts[0][0]["dx"], sts[0][0]["dy"], bc, ph, mm, boxes, max_box=64)
+        H.set_states(sts)
+        H.moulin_source(**mo)
+        nwarm, nstep = (3, 5) if nb > 256 else (5, 10)
+        for _ in range(nwarm):
+            H.timestep(mm["dt"])
+        H.level[0][0].synchronize()
+        t0 = time.perf_counter()
+        nv = npi = 0
+        for _ in range(nstep):
+            a, b = H.timestep(mm["dt"])
+            npi += a; nv += b
+        H.level[0][0].synchronize()
+        dt = (time.perf_counter() - t0) / nstep
+        out[tag] = {"steps_per_s": 1.0 / dt, "ms_per_step": 1e3 * dt, "picard_iterations_per_step": npi / nstep, "amr_vcycles_per_step": nv / nstep,
+                    "boxes_per_level": [1] + [len(bl) for bl in boxes],
+                    "cells_per_level": [nb * nb] + [int(sum((b[2] - b[0] + 1) * (b[3] - b[1] + 1) for b in bl)) for bl in boxes]}
+        H.close()
     return out
 
 

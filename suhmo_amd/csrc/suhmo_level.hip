@@ -1501,7 +1501,12 @@ extern "C" int suhmo_level_norm(suhmo_level_t *L, int depth, int field, int ord,
     hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, st, L->scratch + 1, np, ord, L->scratch, suhmo_host_slot(L));
     double r = 0.0;
     { int rc = suhmo_readback(L, st, &r); if (rc) return rc; }
-    if (ord == 2) r = sqrt(r);
+    if (ord == 2) {
+        // the reference's norm() sums over the ranks (src/AMRNonLinearPoissonOp.cpp:1222-1264); the all-reduce hook of a strip is
+        // MAX-only, and the solver only uses the max norm: refuse rather than return a rank-dependent number
+        if (L->ex && (D.v.rk[0] || D.v.rk[1])) { suhmo_set_error("l2 norm on a rank strip is not built (the hook reduces MAX only); use ord 0"); return -5; }
+        r = sqrt(r);
+    }
     if (L->ar && ord == 0) { int rc = L->ar(L->user, &r); if (rc) return rc; }
     *out = r;
     return 0;

@@ -167,18 +167,19 @@ int exchange_hook(void *user, suhmo_level_t *L, int depth, const int *fields, in
             pl.unpack_hi[q] = f == SUHMO_F_BY ? v.ny + 1 : v.ny;
         }
         dim3 blk(64, 4), grd((v.nx + 1 + 63) / 64, (rows + 3) / 4, 2 * pl.n);
-        hipLaunchKernelGGL(k_pack_multi, grd, blk, 0, st, v, pl, rows, S->lo >= 0 ? B[0] : nullptr, S->hi >= 0 ? B[1] : nullptr);
-        HIPCHK(hipGetLastError());
         const size_t cnt = n * pl.n;
+        bool queue_it = false;
         if (S->batching) {
-            // one message per depth in a batch (the staging buffers are per depth); anything else flushes first
+            // one message per depth in a batch (the staging buffers are per depth).  A second message of a depth must not be
+            // packed over the queued one: flush what is queued BEFORE packing, then send this one on its own
             bool clash = nfields > MAXF;
             for (const Pending &q : S->queue) clash = clash || q.depth == depth;
-            if (!clash) { S->queue.push_back(Pending{depth, pl, cnt, rows}); S->exchanges++; continue; }
-            int rc = flush(S, L, st); if (rc) return rc;
-            hipLaunchKernelGGL(k_pack_multi, grd, blk, 0, st, v, pl, rows, S->lo >= 0 ? B[0] : nullptr, S->hi >= 0 ? B[1] : nullptr);   // buffers were reused
-            HIPCHK(hipGetLastError());
+            if (clash) { int rc = flush(S, L, st); if (rc) return rc; }
+            else queue_it = true;
         }
+        hipLaunchKernelGGL(k_pack_multi, grd, blk, 0, st, v, pl, rows, S->lo >= 0 ? B[0] : nullptr, S->hi >= 0 ? B[1] : nullptr);
+        HIPCHK(hipGetLastError());
+        if (queue_it) { S->queue.push_back(Pending{depth, pl, cnt, rows}); S->exchanges++; continue; }
         // order matters when lo == hi (2 ranks, periodic; or a rank that is its own neighbour):
         // to-hi before to-lo, from-lo before from-hi
         NCCLCHK(g.GroupStart());
@@ -294,6 +295,36 @@ extern "C" int suhmo_level_attach_rccl(suhmo_level_t *L, const void *id128, int 
             if (hipMalloc(&S->buf[d][k], cap) != hipSuccess) { suhmo_set_error("halo buffer allocation failed"); suhmo_level_detach_rccl(L); return -2; }
     }
     if (hipMalloc(&S->dscalar, sizeof(double)) != hipSuccess) { suhmo_level_detach_rccl(L); return -2; }
+    // Every rank derives the number, order and size of its halo messages from its own strip (rows, halo depth, MG depths,
+    // kernel selection): neighbours that disagree would post different ncclSend / ncclRecv sequences and hang or corrupt.
+    // Agree now: MAX all-reduce of (x, -x) of every deciding quantity; max(x) != -max(-x) = a rank differs.
+    {
+        const DV &v0 = L->d[0].v;
+        const double desc[] = {(double)v0.nx, (double)v0.ny, (double)v0.gy, (double)L->ndepth, (double)L->gsrb_variant, (double)L->fused_min_cells,
+                               (double)L->tile_max_cells, (double)L->gsrb_tile, (double)L->tile_t, (double)L->tile_s, (double)L->fused_nt,
+                               (double)L->fused_hc, (double)L->fused_restrict, (double)L->tile_strips, (double)L->tile_chunks,
+                               (double)L->fas_rhs_in_relax, (double)L->strips_rhs_local, (double)L->bcoef_fused, (double)v0.nxg, (double)v0.nyg};
+        const int K = (int)(sizeof(desc) / sizeof(desc[0]));
+        static const char *names[] = {"nx", "ny (rows per strip: the level must be cut into EQUAL strips)", "halo_rows", "multigrid depths", "SUHMO_GSRB_VARIANT",
+                                      "SUHMO_FUSED_MIN_CELLS", "SUHMO_TILE_MAX_CELLS", "SUHMO_GSRB_TILE", "SUHMO_TILE_T", "SUHMO_TILE_S", "SUHMO_FUSED_NT",
+                                      "SUHMO_FUSED_HC", "SUHMO_FUSED_RESTRICT", "SUHMO_TILE_STRIPS", "SUHMO_TILE_CHUNKS", "SUHMO_FAS_RHS_IN_RELAX",
+                                      "SUHMO_STRIPS_RHS_LOCAL", "SUHMO_BCOEF_FUSED", "nx_global", "ny_global"};
+        double h[2 * 32], *dbuf = nullptr;
+        for (int k = 0; k < K; k++) { h[2 * k] = desc[k]; h[2 * k + 1] = -desc[k]; }
+        bool ok = hipMalloc(&dbuf, 2 * K * sizeof(double)) == hipSuccess
+                  && hipMemcpyAsync(dbuf, h, 2 * K * sizeof(double), hipMemcpyHostToDevice, S->st) == hipSuccess
+                  && g.AllReduce(dbuf, dbuf, 2 * K, ncclFloat64, ncclMax, S->comm, S->st) == ncclSuccess
+                  && hipMemcpyAsync(h, dbuf, 2 * K * sizeof(double), hipMemcpyDeviceToHost, S->st) == hipSuccess
+                  && hipStreamSynchronize(S->st) == hipSuccess;
+        if (dbuf) (void)hipFree(dbuf);
+        if (!ok) { suhmo_set_error("attach: the consistency all-reduce failed"); suhmo_level_detach_rccl(L); return -7; }
+        for (int k = 0; k < K; k++)
+            if (h[2 * k] != -h[2 * k + 1]) {
+                suhmo_set_error("attach: the ranks of this communicator disagree on %s (here %g, over the ranks %g .. %g)", names[k], desc[k], -h[2 * k + 1], h[2 * k]);
+                suhmo_level_detach_rccl(L);
+                return -8;
+            }
+    }
     L->ex = exchange_hook; L->ar = allreduce_hook; L->user = S; L->ex_begin = begin_hook; L->ex_end = end_hook;
     return 0;
 }

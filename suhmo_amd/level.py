@@ -166,6 +166,14 @@ class HipLevel:
     def synchronize(self):
         check(capi.lib().suhmo_level_synchronize(self.h, self.stream))
 
+    def rccl_exchanges(self):
+        """halo message groups this strip has sent so far (native transport), or the calls of the Python exchanger"""
+        n = capi.lib().suhmo_level_rccl_exchanges(self.h)
+        if n >= 0:
+            return n
+        ex = getattr(self, "_exchanger", None)
+        return getattr(ex, "calls", 0)
+
     # ---- profiling of the relax kernel (HIP events on the launch stream)
     def profile(self, on=True):
         check(capi.lib().suhmo_level_profile_reset(self.h))

@@ -309,3 +309,118 @@ def valley_initial_state(nx, ny, gamma, lx=6000.0, ly=1500.0, gap_init=0.01):
     head = np.where(head < 0.0, 0.0, head)                 # ValleyIBC::resetCovered
     mask = np.where(Pi > 0.0, 1.0, -1.0)
     return dict(nx=nx, ny=ny, dx=dx, dy=dy, head=head, B=B, Pi=Pi, zb=zb, mask=mask)
+
+
+# ---- cfg5: exec/AMR_multiMoulins (problem_type = dino: src/MountainSetupIBC.cpp), 63 moulins on 100 km x 100 km
+def multimoulins_inputs():
+    """moulin table and physics keys of exec/AMR_multiMoulins/run_C_3lev/input.hydro (tests/golden/multimoulins_inputs.json)"""
+    import json, os
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "multimoulins_inputs.json")
+    return json.load(open(here))
+
+
+def multimoulins_setup():
+    """(bc, phys, model, moulins) of cfg5 as the reference's input file states them"""
+    c = multimoulins_inputs()
+    bc = dict(type=[[int(c["lo_bc"][0]), int(c["hi_bc"][0])], [int(c["lo_bc"][1]), int(c["hi_bc"][1])]],
+              value=[[0.0, 0.0], [0.0, 0.0]], periodic=[0, 0])
+    phys = dict(A3_PHYS, A=c["A"], omega=c["turbulentParam"], nu=c["WaterViscosity"], cutOffbr=c["cutOffbr"], maxOffbr=c["maxOffbr"])
+    model = dict(A3_MODEL, G=c["GeoFlux"], L=c["LatHeat"], ct=c["ct"], cw=c["cw"], ub=tuple(c["SlidingVelocity"]), br=c["br"], lr=c["lr"],
+                 diffFactor=c["diffFactor"], distributed_input=c["distributed_input"], eps_picard=c["eps_PicardIte"], basal_friction=1,
+                 use_moulin_source=1, use_impl_diff=1, dt=c["fixed_dt"])
+    n = c["n_moulins"]
+    moulins = dict(positions=np.array(c["positions"]).reshape(n, 2), sigma=np.array(c["sigma"]), flux=np.array(c["flux"]))
+    return bc, phys, model, moulins
+
+
+def mountain_state(nx, ny, i0, j0, nxg, nyg, lx=1.0e5, ly=1.0e5, gap_init=0.01):
+    """MountainIBC::initializeData (src/MountainSetupIBC.cpp:151-323) on the ghosted box [i0-1, i0+nx] x [j0-1, j0+ny] of a level of
+    nxg x nyg cells, WITHOUT the bed noise: the reference adds dist2(generator) from an unseeded std::default_random_engine
+    drawn in per-box iteration order (:174, :270), which is not reproducible across decompositions."""
+    dx, dy = lx / nxg, ly / nyg
+    i = np.arange(i0 - 1, i0 + nx + 1, dtype=np.float64)
+    j = np.arange(j0 - 1, j0 + ny + 1, dtype=np.float64)
+    X, Y = np.meshgrid((i + 0.5) * dx, (j + 0.5) * dy)
+    ax, by, cst = 1.5e-3, -1.5e-3, 100.0
+    step_1 = np.maximum(ax * X + by * Y + cst, 0.0)
+    iceH = 2.0 * (ax * X + by * Y + cst + 100.0)
+
+    def finger(angle, x0, y0, a_max, s_gauss, sigma_fn):
+        ca, sa = np.cos(angle * 3.14159 / 180.0), np.sin(angle * 3.14159 / 180.0)
+        xb, yb = X - x0, Y - y0
+        xt, yt = xb * ca + yb * sa, -xb * sa + yb * ca
+        a_g = a_max * np.exp(-0.5 / (s_gauss * s_gauss) * yt * yt)
+        sg = sigma_fn(yt)
+        return a_g * np.exp(-0.5 / (sg * sg) * xt * xt)
+    step_2 = finger(35.0, 100000.0, 0.0, 250.0, 50000.0, lambda yt: 12000.0 - 3000.0 * np.minimum(1.0 - (50000.0 - yt) / 50000.0, 1.0))
+    step_3 = finger(90.0, 85000.0, 0.0, 250.0, 30000.0, lambda yt: 10000.0)
+    step_4 = finger(60.0, 55000.0, 0.0, 100.0, 20000.0, lambda yt: 5000.0)
+    step_5 = finger(2.0, 100000.0, 20000.0, 300.0, 35000.0, lambda yt: 6000.0)
+    zb = np.maximum(step_1 + step_2 + step_3 + step_4 + step_5, 0.0)
+    Pi = RHO_I * GRAV * np.maximum(iceH, 0.0)
+    B = np.where(Pi == 0.0, 1.0e-16, gap_init)
+    head = Pi * 0.5 * (1.0 / (RHO_W * GRAV)) + zb
+    mask = np.where(Pi > 0.0, 1.0, -1.0)
+    return dict(nx=nx, ny=ny, dx=dx, dy=dy, i0=i0, j0=j0, nxg=nxg, nyg=nyg, head=np.ascontiguousarray(head), B=np.ascontiguousarray(B),
+                Pi=np.ascontiguousarray(Pi), zb=np.ascontiguousarray(zb), mask=np.ascontiguousarray(mask))
+
+
+def mountain_amrm_states(nx0, ny0, boxes, **kw):
+    """mountain_state on every box of a hierarchy (boxes[l-1] = boxes of level l in its own index space)"""
+    out = [[mountain_state(nx0, ny0, 0, 0, nx0, ny0, **kw)]]
+    for l, bl in enumerate(boxes, start=1):
+        out.append([mountain_state(hi0 - lo0 + 1, hi1 - lo1 + 1, lo0, lo1, nx0 << l, ny0 << l, **kw) for (lo0, lo1, hi0, hi1) in bl])
+    return out
+
+
+def boxes_around(points, nx0, ny0, nlev, lx, ly, radius_cells=(6, 5, 4), block=4, max_box=64, nest=2):
+    """A fixed multi-box hierarchy around `points` (the reference regrids by tagging melt rate / gap height, i.e. around the
+    moulins and the channels that leave them, src/AmrHydro.cpp:4176-4604; regridding is out of scope, a grids file is an input:
+    AmrHydro.grids_file :1119-1122).  Level l >= 1 covers the cells of level l-1 within radius_cells[l-1] cells of a point,
+    restricted to what level l-1 holds minus `nest` cells (proper nesting), snapped to blocks of `block` cells of level l-1 and cut
+    into disjoint rectangles of at most max_box fine cells per side.  Returns boxes[l-1] = list of (lo0, lo1, hi0, hi1) in the
+    index space of level l."""
+    out = []
+    nx, ny = nx0, ny0
+    allowed = np.ones((ny, nx), dtype=bool)                  # cells of level l-1 that may be refined
+    for l in range(1, nlev):
+        dx, dy = lx / nx, ly / ny
+        tag = np.zeros((ny, nx), dtype=bool)
+        r = radius_cells[min(l - 1, len(radius_cells) - 1)]
+        for (px, py) in points:
+            ic, jc = int(px / dx), int(py / dy)
+            tag[max(jc - r, 0):min(jc + r + 1, ny), max(ic - r, 0):min(ic + r + 1, nx)] = True
+        # snap to blocks; a block is refined only if all of it may be
+        nbx, nby = nx // block, ny // block
+        tb = tag[:nby * block, :nbx * block].reshape(nby, block, nbx, block).any(axis=(1, 3))
+        ab = allowed[:nby * block, :nbx * block].reshape(nby, block, nbx, block).all(axis=(1, 3))
+        tb &= ab
+        mb = max(1, max_box // (2 * block))                    # blocks per box side
+        boxes, used = [], np.zeros_like(tb)
+        for J in range(nby):
+            for I in range(nbx):
+                if not tb[J, I] or used[J, I]:
+                    continue
+                w = 1
+                while I + w < nbx and w < mb and tb[J, I + w] and not used[J, I + w]:
+                    w += 1
+                h = 1
+                while J + h < nby and h < mb and tb[J + h, I:I + w].all() and not used[J + h, I:I + w].any():
+                    h += 1
+                used[J:J + h, I:I + w] = True
+                boxes.append((2 * I * block, 2 * J * block, 2 * (I + w) * block - 1, 2 * (J + h) * block - 1))
+        if not boxes:
+            break
+        out.append(boxes)
+        # cells of level l that may be refined further: held by level l and `nest` + 1 cells away from its edge
+        nx, ny = 2 * nx, 2 * ny
+        held = np.zeros((ny, nx), dtype=bool)
+        for (lo0, lo1, hi0, hi1) in boxes:
+            held[lo1:hi1 + 1, lo0:hi0 + 1] = True
+        allowed = held.copy()
+        m = 2 * nest + 2                                       # in cells of level l: 2 coarse cells of margin + the interpolation stencil
+        pad = np.pad(held, m, constant_values=True)            # the domain boundary needs no margin
+        for dj in range(-m, m + 1):
+            for di in range(-m, m + 1):
+                allowed &= pad[m + dj:m + dj + ny, m + di:m + di + nx]
+    return out

@@ -1,0 +1,72 @@
+"""cfg5 of BASELINE.json (exec/AMR_multiMoulins: 63 moulins on 100 km x 100 km, dino bed of MountainSetupIBC without its
+unseeded noise, diffusion + implicit gap-height solve, transient head + gap height) on base + 3 AMR levels whose levels are
+unions of boxes around the moulins: the device hierarchy against oracle/amr_step_m.c, BITWISE over the first steps on a
+64 x 64 base; on the reference's own 256 x 256 base (run_C_3lev/input.hydro:67) the step runs, the moulins deliver their flux
+over the composite grid and the covered cells hold the average of the finer level."""
+import numpy as np
+import pytest
+
+from suhmo_amd import synthetic as sy
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cfg5_physics_on_four_levels_bitwise(oracle):
+    from suhmo_amd import model, level as lv
+    bc, ph, m, mo = sy.multimoulins_setup()
+    nx0 = ny0 = 64
+    boxes = sy.boxes_around(mo["positions"], nx0, ny0, 4, 1.0e5, 1.0e5)
+    assert len(boxes) == 3 and all(len(bl) >= 3 for bl in boxes)
+    sts = sy.mountain_amrm_states(nx0, ny0, boxes)
+    O = oracle.OracleAmrMModel(nx0, ny0, sts[0][0]["dx"], sts[0][0]["dy"], bc, ph, m, boxes, max_box=16, nthreads=4)
+    G = model.HipHierModel(nx0, ny0, sts[0][0]["dx"], sts[0][0]["dy"], bc, ph, m, boxes, max_box=16)
+    O.set_states(sts); G.set_states(sts)
+    io, ig = O.moulin_source(**mo), G.moulin_source(**mo)
+    assert np.max(np.abs(io - ig)) <= 1e-12 * np.max(io)
+    for l in range(O.nlev):
+        for k in range(len(O.boxes[l])):
+            a, b = np.array(O.field(l, k, oracle.OM_MSRC))[1:-1, 1:-1], G.get(l, k, "msrc")
+            assert np.max(np.abs(a - b)) <= 1e-12 * max(np.max(np.abs(a)), 1e-300), (l, k)
+            G.level[l][k].set(lv.F_MSRC, a)           # continue from identical source terms (two exp libraries)
+    v = lambda a: np.array(a)[1:-1, 1:-1]
+    for step in range(2):
+        co, cg = O.timestep(m["dt"]), G.timestep(m["dt"])
+        assert co == cg, (step, co, cg)
+        for l in range(O.nlev):
+            for k in range(len(O.boxes[l])):
+                for nm, fid in (("head", oracle.OM_H), ("B", oracle.OM_B), ("mR", oracle.OM_MR), ("Re", oracle.OM_RE)):
+                    a, b = v(O.field(l, k, fid)), G.get(l, k, nm)
+                    assert np.array_equal(a, b, equal_nan=True), (step, l, k, nm, float(np.nanmax(np.abs(a - b))))
+    O.close(); G.close()
+
+
+def test_cfg5_on_the_reference_base_grid():
+    from suhmo_amd import model
+    bc, ph, m, mo = sy.multimoulins_setup()
+    nx0 = ny0 = 256                                     # AmrHydro.num_cells of run_C_3lev/input.hydro
+    boxes = sy.boxes_around(mo["positions"], nx0, ny0, 4, 1.0e5, 1.0e5)
+    sts = sy.mountain_amrm_states(nx0, ny0, boxes)
+    G = model.HipHierModel(nx0, ny0, sts[0][0]["dx"], sts[0][0]["dy"], bc, ph, m, boxes, max_box=64)
+    G.set_states(sts)
+    integ = G.moulin_source(**mo)
+    assert np.all(integ > 0)
+    total = 0.0
+    for l in range(4):
+        for k, b in enumerate(G.hier.boxes[l - 1] if l else [(0, 0, nx0 - 1, ny0 - 1)]):
+            src = G.get(l, k, "msrc")
+            cov = np.zeros(src.shape, dtype=bool)
+            if l < 3:
+                for (f0, f1, g0, g1) in G.hier.boxes[l]:
+                    a0, a1, c0, c1 = max(f0 // 2, b[0]), min(g0 // 2, b[2]), max(f1 // 2, b[1]), min(g1 // 2, b[3])
+                    if a0 <= a1 and c0 <= c1:
+                        cov[c0 - b[1]:c1 - b[1] + 1, a0 - b[0]:a1 - b[0] + 1] = True
+            total += src[~cov].sum() * sts[l][0]["dx"] * sts[l][0]["dy"]
+    assert abs(total - mo["flux"].sum()) < 1e-9 * mo["flux"].sum()
+    for step in range(2):
+        pi, nv = G.timestep(m["dt"])
+        assert 1 <= pi <= 30 and nv >= 2
+    for l in range(4):
+        for k in range(len(G.level[l])):
+            for nm in ("head", "B", "mR"):
+                assert np.all(np.isfinite(G.get(l, k, nm)))
+    G.close()

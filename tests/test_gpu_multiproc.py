@@ -1,0 +1,55 @@
+"""N > 1 as separate processes.  (a) `python bench.py --gpus 2` with no launcher: the parent starts its two rank processes
+itself (it never touches the GPU) and rank 0's JSON line comes back -- rehearsed here with the gloo backend, both ranks on
+the one GPU of the test box, weak and strong scaling.  (b) two ranks over the real nccl (= RCCL) backend, one GPU each, stepping
+SHMIP A3 bit for bit against the single-process run: skipped unless the box has two GPUs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_starts_its_own_ranks(scaling):
+    env = dict(os.environ, SUHMO_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cells", "512", "--steps", "3", "--warmup", "1",
+                        "--no-cpu", "--no-side", "--scaling", scaling], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["value"] > 0
+    assert out["config"]["global_cells"] == ([512, 1024] if scaling == "weak" else [512, 512])
+    assert out["config"]["halo_message_groups_per_vcycle_per_rank"] > 0
+    assert out["roofline"]["traffic"] is None            # the PMC passes belong to the single-GPU workload
+    assert out["residual_max_norm"]["after_timed_cycles"] < out["residual_max_norm"]["before_warmup"]
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cells", "256", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-side"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b"WORLD_SIZE" in p.stderr
+
+
+def test_two_ranks_over_nccl_bitwise():
+    from suhmo_amd import capi
+    if capi.lib().suhmo_device_count() < 2:
+        pytest.skip("needs two GPUs (ncclSend / ncclRecv between distinct devices)")
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SUHMO_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "shmip_dist.py"), "--case", "A3", "--scale", "2", "--steps", "6", "--check"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    assert "BITWISE EQUAL" in logs[0]
