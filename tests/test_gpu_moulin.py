@@ -123,3 +123,26 @@ def test_moulin_source_pinned_by_the_channelized_convergence_table():
         # relative to the CPU library's) shows in the fourth / second digit; the oracle matches all six rows to five
         tol = 6e-5 if nx <= 256 else (1e-3 if nx == 512 else 5e-2)
         assert abs(got[nx] - ref[nx]) <= tol * ref[nx], (nx, got[nx], ref[nx])
+
+
+def test_amr_moulin_source_against_the_2_and_3_level_convergence_tables():
+    """device twin of tests/test_oracle_timeloop.py::test_amr_moulin_source_pinned_by_the_2_and_3_level_convergence_tables: the
+    composite moulin source term of suhmo_hier_moulin_source on the grids inferred from the reference's own tables reproduces the
+    RHS_moulin column of exec/0_convergence_channelized/CONV_ANA/results/convergence_data_{2Levels,3Levels}.dat: 5 digits in the
+    rows above the noise floor of two exp libraries"""
+    import os, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "..", "tools"))
+    import convergence_channelized as cc
+    grids = cc.amr_grids()
+    checked = 0
+    for name in ("2Levels", "3Levels"):
+        ref = {int(float(r[0])): r[5] for r in np.loadtxt(os.path.join(here, "golden", "convergence_channelized_%s_reference.dat" % name))}
+        for case, rects in grids[name].items():
+            nx0 = int(case)
+            if ref[nx0] < 1e-9:
+                continue                                # differences of 1e-10 and below: the two exp libraries differ there
+            e = cc.amr_moulin_error(nx0, rects, "hip")
+            assert abs(e - ref[nx0]) <= 6e-5 * ref[nx0], (name, nx0, e, ref[nx0])
+            checked += 1
+    assert checked == 5

@@ -124,3 +124,28 @@ def test_oracle_moulin_source_pinned_by_the_channelized_convergence_table():
     assert sorted(got) == sorted(ref)
     for nx in ref:
         assert abs(got[nx] - ref[nx]) <= 6e-5 * ref[nx], (nx, got[nx], ref[nx])
+
+
+def test_amr_moulin_source_pinned_by_the_2_and_3_level_convergence_tables():
+    """exec/0_convergence_channelized/CONV_ANA/results/convergence_data_{2Levels,3Levels}.dat, column RHS_moulin: composite L2
+    difference between the moulin source term of an AMR run (base + 1 or 2 levels) and the single-level run 2 (3) refinements
+    finer.  The column needs no solve, only the grids -- which those runs got from tagging the melt rate; tools/infer_amr_grids.py
+    finds them from the column itself: ONE region (x in [0, 20] m, y in [4, 12] m = the channel from the moulin to the outflow,
+    snapped to the runs' 4 m blocks; [2, 14] m with the 2 m blocks of the coarsest run) reproduces five rows of the 2-level table
+    and, as the second AMR level, two rows of the 3-level table.  This pins Calc_moulin_integral / Calc_moulin_source_term_distributed
+    over a hierarchy (src/AmrHydro.cpp:1866-2066: finest level first, cells under a finer level do not count) -- oracle/amr_step_m.c
+    -- against the reference's own output: 5 digits in six rows, 3.5 digits in the row at the 1e-12 noise floor.  (Rows 128 and
+    256 of the 3-level table: grids not inferable, not used.)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "tools"))
+    import convergence_channelized as cc
+    grids = cc.amr_grids()
+    for name in ("2Levels", "3Levels"):
+        ref = {int(float(r[0])): r[5] for r in np.loadtxt(os.path.join(GOLD, "convergence_channelized_%s_reference.dat" % name))}
+        for case, rects in grids[name].items():
+            nx0 = int(case)
+            if nx0 > 256:
+                continue                                # 2048 x 512 exact level: kept for the device test
+            e = cc.amr_moulin_error(nx0, rects, "oracle")
+            tol = 6e-5 if ref[nx0] > 1e-11 else 1e-3
+            assert abs(e - ref[nx0]) <= tol * ref[nx0], (name, nx0, e, ref[nx0])

@@ -110,6 +110,114 @@ def moulin_table(which="hip", max_level=7):
     return res
 
 
+def amr_grids():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "convergence_channelized_amr_grids.json")))
+
+
+def amr_boxes(nx0, rects):
+    """physical rectangles (x0, x1, y0, y1), one per AMR level -> boxes[l-1] = [(lo0, lo1, hi0, hi1)] in the index space of level l"""
+    out = []
+    for l, (x0, x1, y0, y1) in enumerate(rects, start=1):
+        dx = LX / (nx0 << l)
+        out.append([(int(round(x0 / dx)), int(round(y0 / dx)), int(round(x1 / dx)) - 1, int(round(y1 / dx)) - 1)])
+    return out
+
+
+def amr_moulin_error(nx0, rects, which="oracle"):
+    """RHS_moulin entry of CONV_ANA/results/convergence_data_{2,3}Levels.dat: composite L2 difference (ChomboCompare: cells under a
+    finer level do not count, the exact solution averaged to each level) between the moulin source term of the hierarchy
+    (base nx0 x nx0/4 + len(rects) AMR levels) and the single level len(rects) + 1 refinements finer"""
+    boxes = amr_boxes(nx0, rects)
+    nlev = 1 + len(boxes)
+    nxe = nx0 << (nlev)
+    if which == "oracle":
+        from oracle import pyoracle as po
+        A = po.OracleAmrMModel(nx0, nx0 // 4, LX / nx0, LY / (nx0 // 4), BC, PHYS, MODEL, boxes, max_box=16, nthreads=2)
+        A.moulin_source(*MOULIN, 1.0)
+        get = lambda l, k: np.array(A.field(l, k, po.OM_MSRC))[1:-1, 1:-1]
+        ex, _ = po.moulin_source(nxe, nxe // 4, LX / nxe, LY / (nxe // 4), MOULIN[0], MOULIN[1], MOULIN[2], 1.0)
+    else:
+        from suhmo_amd import model
+        A = model.HipHierModel(nx0, nx0 // 4, LX / nx0, LY / (nx0 // 4), BC, PHYS, MODEL, boxes, max_box=16)
+        A.moulin_source(*MOULIN, 1.0)
+        get = lambda l, k: A.get(l, k, "msrc")
+        E = model.HipModel(nxe, nxe // 4, LX / nxe, LY / (nxe // 4), BC, PHYS, MODEL, max_box=min(64, nxe // 4))
+        E.moulin_source(*MOULIN, 1.0)
+        ex = E.get("msrc")
+        E.close()
+    allb = [[(0, 0, nx0 - 1, nx0 // 4 - 1)]] + boxes
+    tot = 0.0
+    for l in range(nlev):
+        nx = nx0 << l
+        r = nxe // nx
+        avg = ex.reshape(ex.shape[0] // r, r, ex.shape[1] // r, r).mean(axis=(1, 3))
+        dx = LX / nx
+        for k, (lo0, lo1, hi0, hi1) in enumerate(allb[l]):
+            e = get(l, k) - avg[lo1:hi1 + 1, lo0:hi0 + 1]
+            cov = np.zeros(e.shape, bool)
+            if l + 1 < nlev:
+                for (f0, f1, g0, g1) in allb[l + 1]:
+                    a0, a1, c0, c1 = max(f0 // 2, lo0), min(g0 // 2, hi0), max(f1 // 2, lo1), min(g1 // 2, hi1)
+                    if a0 <= a1 and c0 <= c1:
+                        cov[c0 - lo1:c1 - lo1 + 1, a0 - lo0:a1 - lo0 + 1] = True
+            tot += float(np.sum(e[~cov] ** 2)) * dx * dx
+    A.close()
+    return float(np.sqrt(tot))
+
+
+def amr_run(nx0, rects, main_steps=3000, total_steps=7200):
+    """{k}lev_base / {k}lev_base2levs on the device with the inferred (fixed) grids: the reference restarts the AMR run from the
+    single-level checkpoint after the ramp (3000 steps) and regrids every 250 steps; here the hierarchy exists from the start --
+    both end in the same steady channel.  Returns per level and box the fields ChomboCompare reads."""
+    from suhmo_amd import model
+    boxes = amr_boxes(nx0, rects)
+    ny0 = nx0 // 4
+    m = dict(MODEL)
+    H = model.HipHierModel(nx0, ny0, LX / nx0, LY / ny0, BC, PHYS, m, boxes, max_box=min(64, ny0))
+    allb = [[(0, 0, nx0 - 1, ny0 - 1)]] + boxes
+    for l, bl in enumerate(allb):
+        for k, (lo0, lo1, hi0, hi1) in enumerate(bl):
+            nx = nx0 << l
+            full = basic_state(nx, nx // 4)
+            st = {key: (np.ascontiguousarray(v[lo1:hi1 + 3, lo0:hi0 + 3]) if isinstance(v, np.ndarray) else v) for key, v in full.items()}
+            H.set_state(l, k, st)
+            H.level[l][k].set(model.lv.F_MR, np.full((hi1 - lo1 + 1, hi0 - lo0 + 1), m["G"] / m["L"]))
+    H.moulin_source(*MOULIN, 1.0)
+    for k in range(total_steps):
+        H._mp.ramp = float(ramp(k * m["dt"])) if k < main_steps else 1.0
+        H.timestep(m["dt"])
+    out = [[{nm: H.get(l, k, nm) for nm in ("head", "B", "Pw", "Re")} for k in range(len(bl))] for l, bl in enumerate(allb)]
+    H.close()
+    return out, allb
+
+
+def amr_errors(nx0, rects, exact):
+    """composite L2 errors (head, gapHeight, Pw, Re) of the AMR run against the single-level solution `exact` (dict of arrays)"""
+    sol, allb = amr_run(nx0, rects)
+    nxe = exact["head"].shape[1]
+    res = {}
+    for nm in ("head", "B", "Pw", "Re"):
+        tot = 0.0
+        for l, bl in enumerate(allb):
+            nx = nx0 << l
+            r = nxe // nx
+            ex = exact[nm]
+            avg = ex.reshape(ex.shape[0] // r, r, ex.shape[1] // r, r).mean(axis=(1, 3))
+            dx = LX / nx
+            for k, (lo0, lo1, hi0, hi1) in enumerate(bl):
+                e = sol[l][k][nm] - avg[lo1:hi1 + 1, lo0:hi0 + 1]
+                cov = np.zeros(e.shape, bool)
+                if l + 1 < len(allb):
+                    for (f0, f1, g0, g1) in allb[l + 1]:
+                        a0, a1, c0, c1 = max(f0 // 2, lo0), min(g0 // 2, hi0), max(f1 // 2, lo1), min(g1 // 2, hi1)
+                        if a0 <= a1 and c0 <= c1:
+                            cov[c0 - lo1:c1 - lo1 + 1, a0 - lo0:a1 - lo0 + 1] = True
+                tot += float(np.sum(e[~cov] ** 2)) * dx * dx
+        res[nm] = float(np.sqrt(tot))
+    return res
+
+
 def table(max_level=7, log=None, which="hip", phys=None):
     sol, dxs = {}, {}
     for lev in range(1, max_level + 1):
@@ -131,6 +239,20 @@ def table(max_level=7, log=None, which="hip", phys=None):
 
 if __name__ == "__main__":
     args = sys.argv[1:]
+    if args and args[0] == "amr":                       # convergence_channelized.py amr [2Levels|3Levels] [case ...]
+        name = args[1] if len(args) > 1 else "2Levels"
+        grids = amr_grids()[name]
+        ref = {int(float(r[0])): r[1:] for r in np.loadtxt(os.path.join(ROOT, "tests", "golden", "convergence_channelized_%s_reference.dat" % name))}
+        for case in (args[2:] or sorted(grids, key=int)):
+            nx0 = int(case)
+            nlev = 1 + len(grids[case])
+            lev_exact = int(np.log2(nx0 // 32)) + 1 + nlev
+            t0 = time.time()
+            exact, _ = run(lev_exact, "hip")
+            e = amr_errors(nx0, grids[case], exact)
+            print("%s %d (exact = %dlev): head %.5g gapHeight %.5g Pw %.5g Re %.5g   [%.0f s]" % (name, nx0, lev_exact, e["head"], e["B"], e["Pw"], e["Re"], time.time() - t0))
+            print("   ref  head %.5g gapHeight %.5g Pw %.5g Re %.5g   ratio" % tuple(ref[nx0][:4]), [round(a / b, 4) for a, b in zip((e["head"], e["B"], e["Pw"], e["Re"]), ref[nx0][:4])], flush=True)
+        sys.exit(0)
     which, mg = "hip", 0
     if "--oracle" in args:
         which = "oracle"; args.remove("--oracle")
