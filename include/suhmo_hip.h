@@ -104,6 +104,13 @@ int suhmo_device_count(void);
 int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t *desc);
 int suhmo_level_destroy(suhmo_level_t *L);
 int suhmo_level_num_depths(const suhmo_level_t *L);
+/* Kernel selection of a level (defaults are chosen by level size and shape; the SUHMO_<KEY> environment variables read when
+ * the level is created override them for A/B runs): key = gsrb_variant (-1 auto, 0 colour passes / tiles, 1, 2 = sweeps per
+ * streaming pass), gsrb_tile, tile_t (0, 16, 32), tile_s, tile_max_cells, tile_chunks, tile_strips, fused_min_cells, fused_hc,
+ * fused_nt (64, 256), fused_restrict, fas_rhs_in_relax, strips_rhs_local, bcoef_fused, graph_max_cells, poll_readback.
+ * On rank strips every rank must make the same choices (suhmo_level_attach_rccl checks). */
+int suhmo_level_set_option(suhmo_level_t *L, const char *key, long value);
+int suhmo_level_get_option(const suhmo_level_t *L, const char *key, long *value);
 int suhmo_level_synchronize(suhmo_level_t *L, suhmo_stream_t s);
 
 /* LevelData<FArrayBox> / LevelData<FluxBox> traffic, box by box (DataIterator order =

@@ -148,6 +148,9 @@ void or_level_destroy(OrLevel *L)
     for (int dep = 0; dep < L->ndepth; dep++) depth_free(&L->d[dep]);
     free(L);
 }
+/* solver.cut_solve_outside_domain of the coming solves (src/AmrHydro.cpp:872; the SHMIP post-processing inputs leave it at its
+ * default 0 for their two steps, exec/E_SHMIP/E1/input.hydro_pp) */
+void or_level_set_cutoffb(OrLevel *L, int v) { L->ph.cutOffB = v; }
 int or_level_num_depths(const OrLevel *L) { return L->ndepth; }
 int or_level_num_boxes(const OrLevel *L) { return L->d[0].nbox; }
 

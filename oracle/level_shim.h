@@ -61,6 +61,7 @@ OrLevel *or_level_create(int nx, int ny, double dx, double dy, int max_box,
 void or_level_destroy(OrLevel *L);
 int  or_level_num_depths(const OrLevel *L);
 int  or_level_num_boxes(const OrLevel *L);
+void or_level_set_cutoffb(OrLevel *L, int v);
 
 /* Copy a global array into / out of the per-box storage of depth `depth`.
  * Cell fields: `ghosted` != 0 means the global array is (ny+2) x (nx+2) and ghost

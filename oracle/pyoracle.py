@@ -136,6 +136,7 @@ def lib():
         L.or_amr_vcycle.argtypes = [C.c_void_p, C.POINTER(OrSolverParams)]
         L.or_amr_solve.restype = C.c_int
         L.or_amr_solve.argtypes = [C.c_void_p, C.POINTER(OrSolverParams), dp]
+        L.or_model_set_cutoffb.argtypes = [C.c_void_p, C.c_int]
         L.or_amrm_model_create.restype = C.c_void_p
         L.or_amrm_model_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(OrBC), C.POINTER(OrPhys),
                                            C.POINTER(OrModelParams), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]

@@ -60,7 +60,8 @@ double *or_model_field(OrModel *M, int id)
     return (id >= 0 && id < OM_NCELL) ? M->c[id] : NULL;
 }
 int or_model_step_index(const OrModel *M) { return M->cur_step; }
-void or_model_set_ramp(OrModel *M, double ramp) { M->mp.ramp = ramp; }      /* suhmo.ramp factor of the coming step (:2448-2467) */
+void or_model_set_ramp(OrModel *M, double ramp) { M->mp.ramp = ramp; }
+void or_model_set_cutoffb(OrModel *M, int v) { M->ph.cutOffB = v; if (M->L) or_level_set_cutoffb(M->L, v); }   /* solver.cut_solve_outside_domain */      /* suhmo.ramp factor of the coming step (:2448-2467) */
 void or_model_gap_solver_layout(OrModel *M, int max_box, int nthreads) { M->G_max_box = max_box; M->G_nthreads = nthreads; }
 
 void or_model_set_patch(OrModel *M, int i0, int j0, int nxg, int nyg)

@@ -20,12 +20,12 @@
 //                        (all 2K half-sweeps done) is streamed out.  Halos of 2K cells are
 //                        recomputed redundantly, output goes to a second phi buffer (ping-
 //                        pong) so no workgroup ever reads a neighbour's updated cell.
-#include "suhmo_common.h"
+#include "suhmo_hier.h"
 #include <type_traits>
 
 // ---- variant 0: one thread per active-colour cell ----
 template <bool HAS_ALPHA>
-__global__ __launch_bounds__(256) void k_gsrb_pass_simple(DV v, FP fp, suhmo_phys_t ph, int pass, int jlo, int jhi)
+__device__ __forceinline__ void d_gsrb_pass_simple(const DV &v, const FP &fp, suhmo_phys_t ph, int pass, int jlo, int jhi)
 {
     // rows [jlo, jhi]: the strip's own rows plus, on rank boundaries, the halo rows that are
     // still fresh enough to be advanced redundantly (one exchange then feeds several passes)
@@ -50,6 +50,17 @@ __global__ __launch_bounds__(256) void k_gsrb_pass_simple(DV v, FP fp, suhmo_phy
     double denom = 1.0e-16 + lam + dnl;                      // ...OpF.ChF:154
     phi[idx] = c + (fp.f[SUHMO_F_RHS][idx] - lofphi) / denom; // :156
 }
+template <bool HAS_ALPHA>
+__global__ __launch_bounds__(256) void k_gsrb_pass_simple(DV v, FP fp, suhmo_phys_t ph, int pass, int jlo, int jhi)
+{
+    d_gsrb_pass_simple<HAS_ALPHA>(v, fp, ph, pass, jlo, jhi);
+}
+// every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
+template <bool HAS_ALPHA>
+__global__ __launch_bounds__(256) void k_gsrb_pass_simple_m(const DV *__restrict__ vt, const FP *__restrict__ ft, suhmo_phys_t ph, int pass)
+{
+    d_gsrb_pass_simple<HAS_ALPHA>(vt[blockIdx.z], ft[blockIdx.z], ph, pass, 0, vt[blockIdx.z].ny - 1);
+}
 
 static void launch_simple(suhmo_level *L, int depth, int pass, int ext_rows, hipStream_t st)
 {
@@ -69,6 +80,15 @@ int suhmo_gsrb_colour_pass(suhmo_level *L, int depth, int pass, hipStream_t st)
     launch_simple(L, depth, pass, 0, st);
     HIPCHK(hipGetLastError());
     L->d[depth].phi_fresh = 0;
+    return 0;
+}
+
+int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int pass, hipStream_t st)
+{
+    dim3 blk(64, 4), grd(((m.maxnx + 1) / 2 + 63) / 64, (m.maxny + 3) / 4, m.nbox);
+    if (has_alpha) hipLaunchKernelGGL(k_gsrb_pass_simple_m<true>, grd, blk, 0, st, m.dv, m.fp, ph, pass);
+    else hipLaunchKernelGGL(k_gsrb_pass_simple_m<false>, grd, blk, 0, st, m.dv, m.fp, ph, pass);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -11,3 +11,18 @@ int suhmo_hier_pwl_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st);      
 int suhmo_hier_avg_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st);                   // CoarseAverage into level l-1
 // the hierarchy of SolveForGap_nl: the same boxes, alpha = 1, beta = dt diffFactor, Neumann-0 sides, no nonlinear term
 int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, suhmo_hier **gap);
+
+// every box of a level in ONE launch (blockIdx.z = box): device tables of the boxes' views and field pointers
+struct suhmo_multi { const DV *dv; const FP *fp; int nbox, maxnx, maxny; double *red; /* reduction scratch, 64 nbox + 16 doubles */ };
+int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int pass, hipStream_t st);      // suhmo_gsrb.hip
+int suhmo_multi_fill_ghosts(const suhmo_multi &m, int field, int homog, hipStream_t st);                                  // suhmo_level.hip ...
+int suhmo_multi_apply(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int mode, hipStream_t st);            // mode 0: LPHI, 1: RES
+int suhmo_multi_grad_cc(const suhmo_multi &m, int hasMask, hipStream_t st);
+int suhmo_multi_re(const suhmo_multi &m, const suhmo_phys_t &ph, hipStream_t st);
+int suhmo_multi_bcoef_faces(const suhmo_multi &m, const suhmo_phys_t &ph, hipStream_t st);
+int suhmo_multi_coef_ghosts(const suhmo_multi &m, int field, hipStream_t st);
+int suhmo_multi_axby(const suhmo_multi &m, int fd, int fx, int fy, double a, double b, hipStream_t st);
+int suhmo_multi_copy(const suhmo_multi &m, int fd, int fs, hipStream_t st);                                               // valid cells + ghost ring
+int suhmo_multi_norm_max(const suhmo_multi &m, suhmo_level *slot, int field, double *out, hipStream_t st);                // max |x| over the valid cells of all boxes
+int suhmo_hier_multi_(suhmo_hier *H, int l, hipStream_t st, suhmo_multi *m);       // l >= 1
+int suhmo_hier_ensure_(suhmo_hier *H, int l, int field);                            // allocate a field on every box of a level

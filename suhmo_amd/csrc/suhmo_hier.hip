@@ -113,6 +113,7 @@ struct HLev {
     std::vector<Win> win; double *winbuf = nullptr; size_t winelems = 0; Win *d_win = nullptr; int *d_wing_box = nullptr;
     // field pointer / view tables of the boxes
     std::vector<FP> h_fp; FP *d_fp = nullptr; DV *d_dv = nullptr;
+    double *d_red = nullptr; int maxnx = 0, maxny = 0;            // reduction scratch (64 nbox + 16 doubles), largest box
 };
 }  // namespace
 
@@ -521,6 +522,8 @@ int refresh_tables(suhmo_hier *H, int l, hipStream_t st)
         for (size_t k = 0; k < nb; k++) dv[k] = V.box[k]->d[0].v;
         HIPCHK(hipMalloc(&V.d_dv, nb * sizeof(DV)));
         HIPCHK(hipMemcpy(V.d_dv, dv.data(), nb * sizeof(DV), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc(&V.d_red, (64 * nb + 16) * sizeof(double)));
+        for (size_t k = 0; k < nb; k++) { V.maxnx = std::max(V.maxnx, dv[k].nx); V.maxny = std::max(V.maxny, dv[k].ny); }
     }
     return 0;
 }
@@ -539,6 +542,17 @@ int coarse_args(suhmo_hier *H, int lc, hipStream_t st, CoarseArgs &a)
     a.tab = H->lev[lc].d_fp; a.dv = H->lev[lc].d_dv; a.bdv = H->lev[lc].box[0]->d[0].v;
     return 0;
 }
+
+// all boxes of level l >= 1 as one launch target
+int multi_of(suhmo_hier *H, int l, hipStream_t st, suhmo_multi &m)
+{
+    int rc = refresh_tables(H, l, st); if (rc) return rc;
+    HLev &V = H->lev[l];
+    m.dv = V.d_dv; m.fp = V.d_fp; m.nbox = (int)V.box.size(); m.maxnx = V.maxnx; m.maxny = V.maxny; m.red = V.d_red;
+    return 0;
+}
+inline const suhmo_phys_t &phys_of(suhmo_hier *H, int l) { return H->lev[l].box[0]->ph; }
+inline bool has_alpha(suhmo_hier *H, int l) { return H->lev[l].box[0]->d[0].v.alpha != 0.0; }
 
 // Copier::exchange of one or two cell fields of level l
 int hier_ff(suhmo_hier *H, int l, int f0, int f1, bool corners, hipStream_t st)
@@ -632,47 +646,57 @@ int hier_reflux(suhmo_hier *H, int l, int field_c, hipStream_t st)
 int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
 {
     if (l == 0) return suhmo_level_gsrb(base_of(H), 0, sweeps, s);
-    HLev &V = H->lev[l];
     int rc;
+    suhmo_multi m;
+    if ((rc = multi_of(H, l, HST(s), m))) return rc;
     for (int it = 0; it < sweeps; it++)
         for (int pass = 0; pass < 2; pass++) {
             if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
-            for (suhmo_level *L : V.box) if ((rc = suhmo_gsrb_colour_pass(L, 0, pass, HST(s)))) return rc;
+            if ((rc = suhmo_multi_colour_pass(m, phys_of(H, l), has_alpha(H, l), pass, HST(s)))) return rc;
         }
     if (sweeps > 0) {
         if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
-        for (suhmo_level *L : V.box) if ((rc = suhmo_level_fill_ghosts(L, 0, SUHMO_F_PHI, 1, s))) return rc;      // :757-759
+        if ((rc = suhmo_multi_fill_ghosts(m, SUHMO_F_PHI, 1, HST(s)))) return rc;                                  // :757-759
     }
     return 0;
 }
 int hier_apply(suhmo_hier *H, int l, suhmo_stream_t s)        // applyOpI, inhomogeneous: LPHI
 {
+    if (l == 0) return suhmo_level_apply_op(base_of(H), 0, 0, s);
     int rc;
-    if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
-    for (suhmo_level *L : H->lev[l].box) if ((rc = suhmo_level_apply_op(L, 0, 0, s))) return rc;
-    return 0;
+    suhmo_multi m;
+    if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s))) || (rc = ensure_field(H, l, SUHMO_F_LPHI)) || (rc = multi_of(H, l, HST(s), m))) return rc;
+    return suhmo_multi_apply(m, phys_of(H, l), has_alpha(H, l), 0, HST(s));
 }
 int hier_level_residual(suhmo_hier *H, int l, suhmo_stream_t s)   // residualI: RES
 {
+    if (l == 0) return suhmo_level_residual(base_of(H), 0, s);
     int rc;
-    if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
-    for (suhmo_level *L : H->lev[l].box) if ((rc = suhmo_level_residual(L, 0, s))) return rc;
-    return 0;
+    suhmo_multi m;
+    if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s))) || (rc = multi_of(H, l, HST(s), m))) return rc;
+    return suhmo_multi_apply(m, phys_of(H, l), has_alpha(H, l), 1, HST(s));
 }
 int hier_axby(suhmo_hier *H, int l, int dst, int x, int y, double a, double b, suhmo_stream_t s)
 {
+    if (l == 0) return suhmo_level_axby(base_of(H), 0, dst, x, y, a, b, s);
     int rc;
-    for (suhmo_level *L : H->lev[l].box) if ((rc = suhmo_level_axby(L, 0, dst, x, y, a, b, s))) return rc;
-    return 0;
+    suhmo_multi m;
+    if ((rc = ensure_field(H, l, dst)) || (rc = ensure_field(H, l, x)) || (rc = ensure_field(H, l, y)) || (rc = multi_of(H, l, HST(s), m))) return rc;
+    return suhmo_multi_axby(m, dst, x, y, a, b, HST(s));
 }
 int hier_copy(suhmo_hier *H, int l, int dst, int src, suhmo_stream_t s)
 {
     int rc;
     if ((rc = ensure_field(H, l, dst)) || (rc = ensure_field(H, l, src))) return rc;
-    for (suhmo_level *L : H->lev[l].box)
-        HIPCHK(hipMemcpyAsync(L->d[0].fp.f[dst], L->d[0].fp.f[src], L->d[0].elems * sizeof(double), hipMemcpyDeviceToDevice, HST(s)));
     if (dst == SUHMO_F_PHI) for (suhmo_level *L : H->lev[l].box) L->d[0].phi_fresh = 0;
-    return 0;
+    if (l == 0) {
+        suhmo_level *L = base_of(H);
+        HIPCHK(hipMemcpyAsync(L->d[0].fp.f[dst], L->d[0].fp.f[src], L->d[0].elems * sizeof(double), hipMemcpyDeviceToDevice, HST(s)));
+        return 0;
+    }
+    suhmo_multi m;
+    if ((rc = multi_of(H, l, HST(s), m))) return rc;
+    return suhmo_multi_copy(m, dst, src, HST(s));
 }
 // head of level l: its coarse-fine ghosts from level l-1
 int cf_phi(suhmo_hier *H, int l, suhmo_stream_t s) { return hier_cf(H, l, SUHMO_F_PHI, SUHMO_F_PHI, HST(s)); }
@@ -680,10 +704,12 @@ int cf_phi(suhmo_hier *H, int l, suhmo_stream_t s) { return hier_cf(H, l, SUHMO_
 // cell-centred gradient of level l (compGradientCC) with its domain-side ghosts
 int hier_grad_cc(suhmo_hier *H, int l, suhmo_stream_t s)
 {
+    if (l == 0) return suhmo_grad_cc(base_of(H), 0, HST(s));
     int rc;
+    suhmo_multi m;
     if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;              // UpdateOperator :47
-    for (suhmo_level *L : H->lev[l].box) if ((rc = suhmo_grad_cc(L, 0, HST(s)))) return rc;
-    return 0;
+    if ((rc = ensure_field(H, l, SUHMO_F_GRADX)) || (rc = ensure_field(H, l, SUHMO_F_GRADY)) || (rc = ensure_field(H, l, SUHMO_F_RE)) || (rc = multi_of(H, l, HST(s), m))) return rc;
+    return suhmo_multi_grad_cc(m, phys_of(H, l).use_mask_gradients, HST(s));
 }
 // UpdateOperator of level l >= 1 with its coarser level (src/VCAMRNonLinearPoissonOp.cpp:34-64, src/AmrHydro.cpp:1415-1539)
 int hier_update_operator(suhmo_hier *H, int l, suhmo_stream_t s)
@@ -695,8 +721,10 @@ int hier_update_operator(suhmo_hier *H, int l, suhmo_stream_t s)
     if ((rc = hier_cf(H, l, SUHMO_F_GRADX, SUHMO_F_GRADX, HST(s)))) return rc;
     if ((rc = hier_cf(H, l, SUHMO_F_GRADY, SUHMO_F_GRADY, HST(s)))) return rc;
     if ((rc = hier_ff(H, l, SUHMO_F_GRADX, SUHMO_F_GRADY, true, HST(s)))) return rc;  // lvlgradH.exchange() src/AmrHydro.cpp:1490
-    for (suhmo_level *L : H->lev[l].box) if ((rc = suhmo_re_bcoef_unfused(L, 0, HST(s)))) return rc;
-    return 0;
+    suhmo_multi m;
+    if ((rc = multi_of(H, l, HST(s), m))) return rc;
+    if ((rc = suhmo_multi_re(m, phys_of(H, l), HST(s)))) return rc;
+    return suhmo_multi_bcoef_faces(m, phys_of(H, l), HST(s));
 }
 // RES of level l-1 = rhs - [applyOpI(phi) + reflux from level l]; LPHI of level l-1 keeps the plain L(phi)
 int composite_residual(suhmo_hier *H, int l, suhmo_stream_t s)
@@ -751,6 +779,7 @@ extern "C" int suhmo_hier_destroy(suhmo_hier_t *H)
         if (V.d_wing_box) (void)hipFree(V.d_wing_box);
         if (V.d_fp) (void)hipFree(V.d_fp);
         if (V.d_dv) (void)hipFree(V.d_dv);
+        if (V.d_red) (void)hipFree(V.d_red);
     }
     delete H;
     return 0;
@@ -846,6 +875,8 @@ int suhmo_hier_ff_(suhmo_hier *H, int l, int f0, int f1, bool corners, hipStream
 int suhmo_hier_cf_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st) { return hier_cf(H, l, ff, fc, st); }
 int suhmo_hier_pwl_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st) { return hier_pwl(H, l, ff, fc, st); }
 int suhmo_hier_avg_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st) { return hier_avg(H, l, ff, fc, 0, 0.0, st); }
+int suhmo_hier_multi_(suhmo_hier *H, int l, hipStream_t st, suhmo_multi *m) { return multi_of(H, l, st, *m); }
+int suhmo_hier_ensure_(suhmo_hier *H, int l, int field) { return ensure_field(H, l, field); }
 int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, suhmo_hier **gap)
 {
     if (!H->gap || H->gap_dt != dt) {
@@ -928,8 +959,13 @@ extern "C" int suhmo_hier_residual(suhmo_hier_t *H, double *norm, suhmo_stream_t
     for (int l = top; l >= 1; l--) if ((rc = hier_avg(H, l, SUHMO_F_RES, SUHMO_F_RES, 1, 0.0, HST(s)))) return rc;
     if (norm) {
         double m = 0.0;
-        for (int l = 0; l <= top; l++)
-            for (suhmo_level *L : H->lev[l].box) { double a = 0.0; if ((rc = suhmo_level_norm(L, 0, SUHMO_F_RES, 0, &a, s))) return rc; if (a > m) m = a; }
+        if ((rc = suhmo_level_norm(base_of(H), 0, SUHMO_F_RES, 0, &m, s))) return rc;
+        for (int l = 1; l <= top; l++) {
+            double a = 0.0;
+            suhmo_multi mv;
+            if ((rc = multi_of(H, l, HST(s), mv)) || (rc = suhmo_multi_norm_max(mv, base_of(H), SUHMO_F_RES, &a, HST(s)))) return rc;
+            if (a > m) m = a;
+        }
         *norm = m;
     }
     return 0;

@@ -1,7 +1,7 @@
 // suhmo_level.hip -- level canvas management, LevelData traffic and every operator
 // kernel except the GSRB relaxation (suhmo_gsrb.hip) and the FAS driver (suhmo_fas.hip).
 // gfx950 only.  Reference citations: file:line in the SUHMO checkout.
-#include "suhmo_common.h"
+#include "suhmo_hier.h"
 #include <cstdarg>
 #include <cmath>
 #include <initializer_list>
@@ -221,6 +221,48 @@ extern "C" int suhmo_level_set_bc(suhmo_level_t *L, const suhmo_bc_t *bc)
     return remake_views(L);
 }
 
+// Kernel selection of a level as an API (the SUHMO_* environment variables read at creation remain as an override for A/B
+// runs).  Keys = the variable names without the SUHMO_ prefix, lower case.  Captured V-cycle graphs are dropped: they carry
+// the old choice.
+static long *option_slot_long(suhmo_level *L, const char *key)
+{
+    if (!strcmp(key, "fused_min_cells")) return &L->fused_min_cells;
+    if (!strcmp(key, "tile_max_cells")) return &L->tile_max_cells;
+    if (!strcmp(key, "graph_max_cells")) return &L->graph_max_cells;
+    return nullptr;
+}
+static int *option_slot_int(suhmo_level *L, const char *key)
+{
+    static const struct { const char *k; int suhmo_level::*m; } tab[] = {
+        {"gsrb_variant", &suhmo_level::gsrb_variant}, {"fused_hc", &suhmo_level::fused_hc}, {"bcoef_fused", &suhmo_level::bcoef_fused},
+        {"fused_nt", &suhmo_level::fused_nt}, {"fused_restrict", &suhmo_level::fused_restrict}, {"strips_rhs_local", &suhmo_level::strips_rhs_local},
+        {"tile_strips", &suhmo_level::tile_strips}, {"tile_chunks", &suhmo_level::tile_chunks}, {"fas_rhs_in_relax", &suhmo_level::fas_rhs_in_relax},
+        {"tile_s", &suhmo_level::tile_s}, {"gsrb_tile", &suhmo_level::gsrb_tile}, {"tile_t", &suhmo_level::tile_t}, {"poll_readback", &suhmo_level::poll_readback}};
+    for (const auto &e : tab) if (!strcmp(key, e.k)) return &(L->*(e.m));
+    return nullptr;
+}
+extern "C" int suhmo_level_set_option(suhmo_level_t *L, const char *key, long value)
+{
+    ARG(L && key);
+    if (long *p = option_slot_long(L, key)) { *p = value; suhmo_level_drop_graphs(L); return 0; }
+    if (int *p = option_slot_int(L, key)) {
+        if (!strcmp(key, "tile_t") && value != 0 && value != 16 && value != 32) { suhmo_set_error("tile_t: 0 (by size), 16 or 32"); return -1; }
+        if (!strcmp(key, "fused_nt") && value != 64 && value != 256) { suhmo_set_error("fused_nt: 64 or 256"); return -1; }
+        if (!strcmp(key, "poll_readback") && value && !L->hscratch_dev) { suhmo_set_error("poll_readback: no device address of the host slot"); return -1; }
+        *p = (int)value; suhmo_level_drop_graphs(L); return 0;
+    }
+    suhmo_set_error("unknown option '%s'", key);
+    return -1;
+}
+extern "C" int suhmo_level_get_option(const suhmo_level_t *L, const char *key, long *value)
+{
+    ARG(L && key && value);
+    if (long *p = option_slot_long(const_cast<suhmo_level *>(L), key)) { *value = *p; return 0; }
+    if (int *p = option_slot_int(const_cast<suhmo_level *>(L), key)) { *value = *p; return 0; }
+    suhmo_set_error("unknown option '%s'", key);
+    return -1;
+}
+
 extern "C" int suhmo_level_num_depths(const suhmo_level_t *L) { return L ? L->ndepth : -1; }
 extern "C" int suhmo_level_synchronize(suhmo_level_t *L, suhmo_stream_t s)
 {
@@ -398,7 +440,7 @@ static inline dim3 grid2d(int nx, int ny) { return dim3((nx + 63) / 64, (ny + 3)
 
 // exchange (periodic wrap) + mixBCValues into the stored ghost ring of a cell field
 // (src/AmrHydro.cpp:248-309).  One thread per perimeter cell.
-__global__ void k_fill_ghosts(DV v, double *__restrict__ p, int homog)
+__device__ __forceinline__ void d_fill_ghosts(const DV &v, double *__restrict__ p, int homog)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 2 * v.ny) {                       // x sides
@@ -420,6 +462,15 @@ __global__ void k_fill_ghosts(DV v, double *__restrict__ p, int homog)
         if (side) p[idx + v.P] = phiN(v, p, idx, j, c, homog); else p[idx - v.P] = phiS(v, p, idx, j, c, homog);
     }
 }
+__global__ void k_fill_ghosts(DV v, double *__restrict__ p, int homog)
+{
+    d_fill_ghosts(v, p, homog);
+}
+// every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
+__global__ void k_fill_ghosts_m(const DV *__restrict__ vt, const FP *__restrict__ ft, int field, int homog)
+{
+    d_fill_ghosts(vt[blockIdx.z], ft[blockIdx.z].f[field], homog);
+}
 
 extern "C" int suhmo_level_fill_ghosts(suhmo_level_t *L, int depth, int field, int homogeneous, suhmo_stream_t s)
 {
@@ -436,7 +487,7 @@ extern "C" int suhmo_level_fill_ghosts(suhmo_level_t *L, int depth, int field, i
 // VCNLCOMPUTEOP2D / VCNLCOMPUTERES2D with BC, NL fused.  MODE 0: LPHI = L(phi); 1: RES = rhs - L(phi);
 // 2: the FAS right-hand side of a coarse depth in one pass: LPHI = L(phi), RHS = axby(RES, LPHI, 1, 1), PHIOLD = phi
 template <bool HAS_ALPHA, int MODE>
-__global__ __launch_bounds__(256) void k_apply(DV v, FP fp, suhmo_phys_t ph, int homog, int halo = 0, int hcomp = 0)
+__device__ __forceinline__ void d_apply(const DV &v, const FP &fp, suhmo_phys_t ph, int homog, int halo, int hcomp)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - halo;     // MODE 2 on a rank strip: the halo rows only copy phi
@@ -465,6 +516,17 @@ __global__ __launch_bounds__(256) void k_apply(DV v, FP fp, suhmo_phys_t ph, int
         fp.f[SUHMO_F_RHS][idx] = 1.0 * fp.f[SUHMO_F_RES][idx] + 1.0 * lofphi;
         fp.f[SUHMO_F_PHIOLD][idx] = c;
     }
+}
+template <bool HAS_ALPHA, int MODE>
+__global__ __launch_bounds__(256) void k_apply(DV v, FP fp, suhmo_phys_t ph, int homog, int halo = 0, int hcomp = 0)
+{
+    d_apply<HAS_ALPHA, MODE>(v, fp, ph, homog, halo, hcomp);
+}
+// every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
+template <bool HAS_ALPHA, int MODE>
+__global__ __launch_bounds__(256) void k_apply_m(const DV *__restrict__ vt, const FP *__restrict__ ft, suhmo_phys_t ph, int homog)
+{
+    d_apply<HAS_ALPHA, MODE>(vt[blockIdx.z], ft[blockIdx.z], ph, homog, 0, 0);
 }
 
 static int exchange_fields(suhmo_level *L, int depth, std::initializer_list<int> fields, hipStream_t st)
@@ -764,7 +826,7 @@ extern "C" int suhmo_level_prolong_bilinear(suhmo_level_t *L, int depth, suhmo_s
 // ------------------------------------------------------------------ bCoef update (WFlx_level)
 // step 1: cell-centred gradient = EdgeToCell(NEWMACGRAD) (util/Gradient.cpp:96-127, :623;
 // util/GradientF.ChF:57-70)
-__global__ __launch_bounds__(256) void k_gradcc(DV v, FP fp, int hasMask)
+__device__ __forceinline__ void d_gradcc(const DV &v, const FP &fp, int hasMask)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
     if (i >= v.nx || j >= v.ny) return;
@@ -785,9 +847,18 @@ __global__ __launch_bounds__(256) void k_gradcc(DV v, FP fp, int hasMask)
     fp.f[SUHMO_F_GRADX][idx] = 0.5 * (gW + gE);
     fp.f[SUHMO_F_GRADY][idx] = 0.5 * (gS + gN);
 }
+__global__ __launch_bounds__(256) void k_gradcc(DV v, FP fp, int hasMask)
+{
+    d_gradcc(v, fp, hasMask);
+}
+// every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
+__global__ __launch_bounds__(256) void k_gradcc_m(const DV *__restrict__ vt, const FP *__restrict__ ft, int hasMask)
+{
+    d_gradcc(vt[blockIdx.z], ft[blockIdx.z], hasMask);
+}
 // step 2: ghosts of the gradient: exchange (periodic wrap) + ExtrapGhostCells
 // (src/AmrHydro.cpp:1490-1491, util/ExtrapGhostCells.cpp:94-180, util/ExtrapBCF.ChF:21-29)
-__global__ void k_grad_ghosts(DV v, double *__restrict__ gx, double *__restrict__ gy)
+__device__ __forceinline__ void d_grad_ghosts(const DV &v, double *__restrict__ gx, double *__restrict__ gy)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     double *g2[2] = {gx, gy};
@@ -812,8 +883,17 @@ __global__ void k_grad_ghosts(DV v, double *__restrict__ gx, double *__restrict_
         }
     }
 }
+__global__ void k_grad_ghosts(DV v, double *__restrict__ gx, double *__restrict__ gy)
+{
+    d_grad_ghosts(v, gx, gy);
+}
+// every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
+__global__ void k_grad_ghosts_m(const DV *__restrict__ vt, const FP *__restrict__ ft)
+{
+    d_grad_ghosts(vt[blockIdx.z], ft[blockIdx.z].f[SUHMO_F_GRADX], ft[blockIdx.z].f[SUHMO_F_GRADY]);
+}
 // step 3: COMPUTERE on the ghosted box (src/AmrHydro.cpp:1495-1505, src/AmrHydroF.ChF:92-109)
-__global__ __launch_bounds__(256) void k_re(DV v, FP fp, suhmo_phys_t ph)
+__device__ __forceinline__ void d_re(const DV &v, const FP &fp, suhmo_phys_t ph)
 {
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1, j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
     if (i > v.nx || j > v.ny) return;
@@ -824,6 +904,15 @@ __global__ __launch_bounds__(256) void k_re(DV v, FP fp, suhmo_phys_t ph)
     double sg = sqrt(gx * gx + gy * gy);
     double discr = 1.0 + 4.0 * ph.omega * (B * B * B * ph.grav * sg) / (12.0 * ph.nu * ph.nu);
     fp.f[SUHMO_F_RE][idx] = (-1.0 + sqrt(discr)) / (2.0 * ph.omega);
+}
+__global__ __launch_bounds__(256) void k_re(DV v, FP fp, suhmo_phys_t ph)
+{
+    d_re(v, fp, ph);
+}
+// every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
+__global__ __launch_bounds__(256) void k_re_m(const DV *__restrict__ vt, const FP *__restrict__ ft, suhmo_phys_t ph)
+{
+    d_re(vt[blockIdx.z], ft[blockIdx.z], ph);
 }
 // step 4: CellToEdge(Re), CellToEdge(B), setup_iceMask_EC, COMPUTEBCOEFF
 // (src/AmrHydro.cpp:1512-1537, src/HydroIBC.cpp:139-184, src/AmrHydroF.ChF:212-228)
@@ -839,7 +928,7 @@ __device__ __forceinline__ double bcoef_face(const suhmo_phys_t &ph, double Rc, 
     if (mec < 0.0 && ph.cutOffB > 0) return 0.0;
     return num_q / denom_q;
 }
-__global__ __launch_bounds__(256) void k_bcoef_faces(DV v, FP fp, suhmo_phys_t ph)
+__device__ __forceinline__ void d_bcoef_faces(const DV &v, const FP &fp, suhmo_phys_t ph)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
     if (i > v.nx || j > v.ny) return;
@@ -851,6 +940,15 @@ __global__ __launch_bounds__(256) void k_bcoef_faces(DV v, FP fp, suhmo_phys_t p
         int jg = j + v.j0;
         fp.f[SUHMO_F_BY][idx] = bcoef_face(ph, Re[idx], Re[idx - v.P], B[idx], B[idx - v.P], m[idx], m[idx - v.P], jg == 0 || jg == v.nyg);
     }
+}
+__global__ __launch_bounds__(256) void k_bcoef_faces(DV v, FP fp, suhmo_phys_t ph)
+{
+    d_bcoef_faces(v, fp, ph);
+}
+// every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
+__global__ __launch_bounds__(256) void k_bcoef_faces_m(const DV *__restrict__ vt, const FP *__restrict__ ft, suhmo_phys_t ph)
+{
+    d_bcoef_faces(vt[blockIdx.z], ft[blockIdx.z], ph);
 }
 
 // ---- fused WFlx_level: one kernel = steps 1-4 above on a tile staged in LDS.
@@ -1246,7 +1344,7 @@ __global__ __launch_bounds__(256) void k_average_cells_all(DV vf, AvgAll a, int 
     C.c[q][(jc + C.gy) * C.P + SUHMO_XOFF + ic] = m;
 }
 // ghosts of coarse B / Pi / zb / mask: periodic wrap or Neumann copy (NeumBCForB :1309-1341)
-__global__ void k_coef_ghosts(DV v, double *__restrict__ p)
+__device__ __forceinline__ void d_coef_ghosts(const DV &v, double *__restrict__ p)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 2 * v.ny) {
@@ -1263,6 +1361,15 @@ __global__ void k_coef_ghosts(DV v, double *__restrict__ p)
         if (side == 0) { int idx = cidx(v, i, 0); p[idx - v.P] = v.per[1] ? p[idx + (v.ny - 1) * v.P] : p[idx]; }
         else { int idx = cidx(v, i, v.ny - 1); p[idx + v.P] = v.per[1] ? p[idx - (v.ny - 1) * v.P] : p[idx]; }
     }
+}
+__global__ void k_coef_ghosts(DV v, double *__restrict__ p)
+{
+    d_coef_ghosts(v, p);
+}
+// every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
+__global__ void k_coef_ghosts_m(const DV *__restrict__ vt, const FP *__restrict__ ft, int field)
+{
+    d_coef_ghosts(vt[blockIdx.z], ft[blockIdx.z].f[field]);
 }
 __global__ void k_coef_ghosts_all(DV v0, AvgAll a)        // B, Pi, zb, mask of every coarse depth (blockIdx.y = (depth - 1) * 4 + field - 1)
 {
@@ -1388,12 +1495,21 @@ extern "C" int suhmo_level_get_flux(suhmo_level_t *L, int depth, int dir, int re
 }
 
 // LevelDataOps::axby / setVal on valid cells
-__global__ void k_axby(DV v, double *__restrict__ dst, const double *__restrict__ x, const double *__restrict__ y, double a, double b)
+__device__ __forceinline__ void d_axby(const DV &v, double *__restrict__ dst, const double *__restrict__ x, const double *__restrict__ y, double a, double b)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
     if (i >= v.nx || j >= v.ny) return;
     int idx = cidx(v, i, j);
     dst[idx] = a * x[idx] + b * y[idx];
+}
+__global__ void k_axby(DV v, double *__restrict__ dst, const double *__restrict__ x, const double *__restrict__ y, double a, double b)
+{
+    d_axby(v, dst, x, y, a, b);
+}
+// every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
+__global__ void k_axby_m(const DV *__restrict__ vt, const FP *__restrict__ ft, int fd, int fx, int fy, double a, double b)
+{
+    d_axby(vt[blockIdx.z], ft[blockIdx.z].f[fd], ft[blockIdx.z].f[fx], ft[blockIdx.z].f[fy], a, b);
 }
 __global__ void k_setval(DV v, double *__restrict__ dst, double val)
 {
@@ -1510,6 +1626,94 @@ extern "C" int suhmo_level_norm(suhmo_level_t *L, int depth, int field, int ord,
     if (L->ar && ord == 0) { int rc = L->ar(L->user, &r); if (rc) return rc; }
     *out = r;
     return 0;
+}
+
+// ------------------------------------------------------------------ every box of a multi-box AMR level in one launch
+__global__ void k_copy_m(const DV *__restrict__ vt, const FP *__restrict__ ft, int fd, int fs)
+{
+    const DV &v = vt[blockIdx.z];
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1, j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+    if (i > v.nx || j > v.ny) return;
+    int idx = cidx(v, i, j);
+    ft[blockIdx.z].f[fd][idx] = ft[blockIdx.z].f[fs][idx];
+}
+__global__ __launch_bounds__(256) void k_norm_max_partial_m(const DV *__restrict__ vt, const FP *__restrict__ ft, int field, double *__restrict__ partial)
+{
+    __shared__ double sm[256];
+    const DV &v = vt[blockIdx.z];
+    const double *__restrict__ x = ft[blockIdx.z].f[field];
+    int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    double acc = 0.0;
+    for (int j = blockIdx.y * blockDim.y + threadIdx.y; j < v.ny; j += gridDim.y * blockDim.y)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.nx; i += gridDim.x * blockDim.x) acc = fmax(acc, fabs(x[cidx(v, i, j)]));
+    sm[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = fmax(sm[tid], sm[tid + s]); __syncthreads(); }
+    if (tid == 0) partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = sm[0];
+}
+static inline dim3 grid_m(const suhmo_multi &m, int ex = 0, int ey = 0) { return dim3((m.maxnx + ex + 63) / 64, (m.maxny + ey + 3) / 4, m.nbox); }
+int suhmo_multi_fill_ghosts(const suhmo_multi &m, int field, int homog, hipStream_t st)
+{
+    int n = 2 * m.maxny + 2 * m.maxnx;
+    hipLaunchKernelGGL(k_fill_ghosts_m, dim3((n + 255) / 256, 1, m.nbox), dim3(256), 0, st, m.dv, m.fp, field, homog);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int suhmo_multi_apply(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int mode, hipStream_t st)
+{
+    if (has_alpha) { if (mode == 0) hipLaunchKernelGGL((k_apply_m<true, 0>), grid_m(m), BLK2D, 0, st, m.dv, m.fp, ph, 0);
+                     else hipLaunchKernelGGL((k_apply_m<true, 1>), grid_m(m), BLK2D, 0, st, m.dv, m.fp, ph, 0); }
+    else { if (mode == 0) hipLaunchKernelGGL((k_apply_m<false, 0>), grid_m(m), BLK2D, 0, st, m.dv, m.fp, ph, 0);
+           else hipLaunchKernelGGL((k_apply_m<false, 1>), grid_m(m), BLK2D, 0, st, m.dv, m.fp, ph, 0); }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int suhmo_multi_grad_cc(const suhmo_multi &m, int hasMask, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_gradcc_m, grid_m(m), BLK2D, 0, st, m.dv, m.fp, hasMask);
+    int n = 2 * m.maxny + 2 * m.maxnx;
+    hipLaunchKernelGGL(k_grad_ghosts_m, dim3((n + 255) / 256, 1, m.nbox), dim3(256), 0, st, m.dv, m.fp);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int suhmo_multi_re(const suhmo_multi &m, const suhmo_phys_t &ph, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_re_m, grid_m(m, 2, 2), BLK2D, 0, st, m.dv, m.fp, ph);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int suhmo_multi_bcoef_faces(const suhmo_multi &m, const suhmo_phys_t &ph, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_bcoef_faces_m, grid_m(m, 1, 1), BLK2D, 0, st, m.dv, m.fp, ph);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int suhmo_multi_coef_ghosts(const suhmo_multi &m, int field, hipStream_t st)
+{
+    int n = 2 * m.maxny + 2 * m.maxnx;
+    hipLaunchKernelGGL(k_coef_ghosts_m, dim3((n + 255) / 256, 1, m.nbox), dim3(256), 0, st, m.dv, m.fp, field);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int suhmo_multi_axby(const suhmo_multi &m, int fd, int fx, int fy, double a, double b, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_axby_m, grid_m(m), BLK2D, 0, st, m.dv, m.fp, fd, fx, fy, a, b);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int suhmo_multi_copy(const suhmo_multi &m, int fd, int fs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_copy_m, grid_m(m, 2, 2), BLK2D, 0, st, m.dv, m.fp, fd, fs);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int suhmo_multi_norm_max(const suhmo_multi &m, suhmo_level *slot, int field, double *out, hipStream_t st)
+{
+    dim3 grd(std::min((m.maxnx + 63) / 64, 4), std::min((m.maxny + 3) / 4, 16), m.nbox);
+    hipLaunchKernelGGL(k_norm_max_partial_m, grd, BLK2D, 0, st, m.dv, m.fp, field, m.red);
+    hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, st, m.red, (int)(grd.x * grd.y * grd.z), 0, slot->scratch, suhmo_host_slot(slot));
+    HIPCHK(hipGetLastError());
+    return suhmo_readback(slot, st, out);
 }
 
 // ------------------------------------------------------------------ multi-GPU strip halos

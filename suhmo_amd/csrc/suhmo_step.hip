@@ -48,7 +48,7 @@ __device__ __forceinline__ double face_grad_zb(const DV &v, const double *__rest
     return g;
 }
 
-__global__ __launch_bounds__(256) void k_qw_faces(DV v, FP fp, suhmo_phys_t ph)
+__device__ __forceinline__ void d_qw_faces(const DV &v, const FP &fp, suhmo_phys_t ph)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
     if (i > v.nx || j > v.ny) return;
@@ -70,10 +70,19 @@ __global__ __launch_bounds__(256) void k_qw_faces(DV v, FP fp, suhmo_phys_t ph)
         fp.f[SUHMO_F_QWY][idx] = num_q / denom_q;
     }
 }
+__global__ __launch_bounds__(256) void k_qw_faces(DV v, FP fp, suhmo_phys_t ph)
+{
+    d_qw_faces(v, fp, ph);
+}
+// every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
+__global__ __launch_bounds__(256) void k_qw_faces_m(const DV *__restrict__ vt, const FP *__restrict__ ft, suhmo_phys_t ph)
+{
+    d_qw_faces(vt[blockIdx.z], ft[blockIdx.z], ph);
+}
 
 // MODE 0: melt rate + RHS_h (Picard iteration).  MODE 1: melt rate + gap-height RHS + forward Euler.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_melt(DV v, FP fp, suhmo_phys_t ph, suhmo_model_params_t mp, double dt)
+__device__ __forceinline__ void d_melt(const DV &v, const FP &fp, suhmo_phys_t ph, suhmo_model_params_t mp, double dt)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
     if (i >= v.nx || j >= v.ny) return;
@@ -126,6 +135,17 @@ __global__ __launch_bounds__(256) void k_melt(DV v, FP fp, suhmo_phys_t ph, suhm
         if (mp.use_impl_diff) fp.f[SUHMO_F_RES][idx] = RHS;    // right-hand side of the implicit solve (RES is free here)
         else fp.f[SUHMO_F_B][idx] = RHS * dt + b;              // old b == b: the gap height is untouched during [II]
     }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_melt(DV v, FP fp, suhmo_phys_t ph, suhmo_model_params_t mp, double dt)
+{
+    d_melt<MODE>(v, fp, ph, mp, dt);
+}
+// every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_melt_m(const DV *__restrict__ vt, const FP *__restrict__ ft, suhmo_phys_t ph, suhmo_model_params_t mp, double dt)
+{
+    d_melt<MODE>(vt[blockIdx.z], ft[blockIdx.z], ph, mp, dt);
 }
 
 // max over valid cells (signed) and max |(a - b) / s|: Picard convergence test, :3169-3185
@@ -241,7 +261,7 @@ static int lagged_chain(suhmo_level *L, hipStream_t st)
 
 // ---- diffusion of the gap height (suhmo.diffFactor != 0)
 // ghosts of the melt rate: exchange + ExtrapGhostCells (:2513,:2526); only the edges are read (CellToEdge)
-__global__ void k_extrap_ghosts(DV v, double *__restrict__ g)
+__device__ __forceinline__ void d_extrap_ghosts(const DV &v, double *__restrict__ g)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 2 * v.ny) {
@@ -259,8 +279,17 @@ __global__ void k_extrap_ghosts(DV v, double *__restrict__ g)
         else { int idx = cidx(v, i, v.ny - 1); g[idx + v.P] = v.per[1] ? g[idx - (v.ny - 1) * v.P] : 2.0 * g[idx] - g[idx - v.P]; }
     }
 }
+__global__ void k_extrap_ghosts(DV v, double *__restrict__ g)
+{
+    d_extrap_ghosts(v, g);
+}
+// every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
+__global__ void k_extrap_ghosts_m(const DV *__restrict__ vt, const FP *__restrict__ ft, int field)
+{
+    d_extrap_ghosts(vt[blockIdx.z], ft[blockIdx.z].f[field]);
+}
 // dCoeff: CellToEdge(mR), CellToEdge(b), setup_iceMask_EC, COMPUTEDCOEFF (src/AmrHydro.cpp:1831-1862, ...F.ChF:241-265)
-__global__ __launch_bounds__(256) void k_dcoef_faces(DV v, FP fp, suhmo_phys_t ph, double rho_i)
+__device__ __forceinline__ void d_dcoef_faces(const DV &v, const FP &fp, suhmo_phys_t ph, double rho_i)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
     if (i > v.nx || j > v.ny) return;
@@ -278,8 +307,17 @@ __global__ __launch_bounds__(256) void k_dcoef_faces(DV v, FP fp, suhmo_phys_t p
         fp.f[dir == 0 ? SUHMO_F_DCX : SUHMO_F_DCY][idx] = d;
     }
 }
+__global__ __launch_bounds__(256) void k_dcoef_faces(DV v, FP fp, suhmo_phys_t ph, double rho_i)
+{
+    d_dcoef_faces(v, fp, ph, rho_i);
+}
+// every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
+__global__ __launch_bounds__(256) void k_dcoef_faces_m(const DV *__restrict__ vt, const FP *__restrict__ ft, suhmo_phys_t ph, double rho_i)
+{
+    d_dcoef_faces(vt[blockIdx.z], ft[blockIdx.z], ph, rho_i);
+}
 // COMPUTEDIFTERM2D (src/AmrHydroF.ChF:289-343) of the gap height with its copied ghosts
-__global__ __launch_bounds__(256) void k_difterm(DV v, FP fp)
+__device__ __forceinline__ void d_difterm(const DV &v, FP fp)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
     if (i >= v.nx || j >= v.ny) return;
@@ -289,6 +327,15 @@ __global__ __launch_bounds__(256) void k_difterm(DV v, FP fp)
     fp.f[SUHMO_F_DTERM][idx] =
         (dx_[idx + 1] * (B[idx + 1] - B[idx]) * dxinv0 - dx_[idx] * (B[idx] - B[idx - 1]) * dxinv0
          + dy_[idx + v.P] * (B[idx + v.P] - B[idx]) * dxinv1 - dy_[idx] * (B[idx] - B[idx - v.P]) * dxinv1);
+}
+__global__ __launch_bounds__(256) void k_difterm(DV v, FP fp)
+{
+    d_difterm(v, fp);
+}
+// every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
+__global__ __launch_bounds__(256) void k_difterm_m(const DV *__restrict__ vt, const FP *__restrict__ ft)
+{
+    d_difterm(vt[blockIdx.z], ft[blockIdx.z]);
 }
 static int diffusion_terms(suhmo_level *L, const suhmo_model_params_t *mp, hipStream_t st)
 {
@@ -571,25 +618,61 @@ extern "C" int suhmo_amr_timestep(suhmo_level_t **lv, int nlev, const suhmo_mode
 
 // ------------------------------------------------------------------ the time step on a hierarchy of box unions
 // oracle/amr_step_m.c: suhmo_amr_timestep with every level's rectangle replaced by its boxes; after every fill of data ghosts
-// the reference's exchange() is the fine-fine copy between the boxes of the level (suhmo_hier.hip).
+// the reference's exchange() is the fine-fine copy between the boxes of the level (suhmo_hier.hip).  Every phase of a level
+// >= 1 is ONE launch over all its boxes (blockIdx.z = box, device tables of views and field pointers).
 namespace {
-#define BOXES(l) for (suhmo_level *L : suhmo_hier_boxes_(H, l))
+__global__ __launch_bounds__(256) void k_picard2_partial_m(const DV *__restrict__ vt, const FP *__restrict__ ft, int use_cover, double *__restrict__ partial)
+{
+    __shared__ double sm0[256], sm1[256];
+    const DV &v = vt[blockIdx.z];
+    const double *__restrict__ h = ft[blockIdx.z].f[SUHMO_F_PHI], *__restrict__ hl = ft[blockIdx.z].f[SUHMO_F_HLAG];
+    const double *__restrict__ cover = use_cover ? ft[blockIdx.z].f[SUHMO_F_COVER] : nullptr;
+    int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    double a0 = -1.0e300, a1 = 0.0;
+    for (int j = blockIdx.y * blockDim.y + threadIdx.y; j < v.ny; j += gridDim.y * blockDim.y)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.nx; i += gridDim.x * blockDim.x) {
+            int idx = cidx(v, i, j);
+            if (cover && cover[idx] != 0.0) continue;
+            a0 = fmax(a0, h[idx]);
+            a1 = fmax(a1, fabs(hl[idx] - h[idx]));
+        }
+    sm0[tid] = a0; sm1[tid] = a1;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { sm0[tid] = fmax(sm0[tid], sm0[tid + s]); sm1[tid] = fmax(sm1[tid], sm1[tid + s]); }
+        __syncthreads();
+    }
+    if (tid == 0) { int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; partial[2 * b] = sm0[0]; partial[2 * b + 1] = sm1[0]; }
+}
+inline dim3 grid_m(const suhmo_multi &m, int ex = 0, int ey = 0) { return dim3((m.maxnx + ex + 63) / 64, (m.maxny + ey + 3) / 4, m.nbox); }
+// a level of the hierarchy as a launch target: level 0 = the base handle, level l >= 1 = all its boxes at once
+struct LevT { suhmo_level *base; suhmo_multi m; };
+int lev_target(suhmo_hier *H, int l, hipStream_t st, LevT &t)
+{
+    t.base = nullptr;
+    if (l == 0) { t.base = suhmo_hier_boxes_(H, 0)[0]; return 0; }
+    return suhmo_hier_multi_(H, l, st, &t.m);
+}
 int hier_chain(suhmo_hier *H, int l, hipStream_t st)
 {
     int rc;
+    LevT t;
+    if ((rc = lev_target(H, l, st, t))) return rc;
+    const suhmo_phys_t &ph = suhmo_hier_boxes_(H, l)[0]->ph;
     if ((rc = suhmo_hier_cf_(H, l, SUHMO_F_PHI, SUHMO_F_PHI, st))) return rc;                  // inside compGradientMAC
     if ((rc = suhmo_hier_ff_(H, l, SUHMO_F_PHI, -1, false, st))) return rc;
-    BOXES(l) if ((rc = suhmo_grad_cc(L, 0, st))) return rc;
+    if (t.base) rc = suhmo_grad_cc(t.base, 0, st); else rc = suhmo_multi_grad_cc(t.m, ph.use_mask_gradients, st);
+    if (rc) return rc;
     if ((rc = suhmo_hier_cf_(H, l, SUHMO_F_GRADX, SUHMO_F_GRADX, st))) return rc;              // :1650-1659
     if ((rc = suhmo_hier_cf_(H, l, SUHMO_F_GRADY, SUHMO_F_GRADY, st))) return rc;
     if ((rc = suhmo_hier_ff_(H, l, SUHMO_F_GRADX, SUHMO_F_GRADY, true, st))) return rc;
-    BOXES(l) if ((rc = suhmo_re_cells(L, 0, st))) return rc;
+    if (t.base) rc = suhmo_re_cells(t.base, 0, st); else rc = suhmo_multi_re(t.m, ph, st);
+    if (rc) return rc;
     if ((rc = suhmo_hier_pwl_(H, l, SUHMO_F_RE, SUHMO_F_RE, st))) return rc;                   // :2711-2721
     if ((rc = suhmo_hier_ff_(H, l, SUHMO_F_RE, -1, true, st))) return rc;
-    BOXES(l) {
-        Depth &D = L->d[0];
-        hipLaunchKernelGGL(k_qw_faces, dim3((D.v.nx + 1 + 63) / 64, (D.v.ny + 1 + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, L->ph);
-    }
+    if (t.base) { Depth &D = t.base->d[0];
+        hipLaunchKernelGGL(k_qw_faces, dim3((D.v.nx + 1 + 63) / 64, (D.v.ny + 1 + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, ph); }
+    else hipLaunchKernelGGL(k_qw_faces_m, grid_m(t.m, 1, 1), dim3(64, 4), 0, st, t.m.dv, t.m.fp, ph);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -597,10 +680,59 @@ int hier_chain(suhmo_hier *H, int l, hipStream_t st)
 int hier_gap_ghosts(suhmo_hier *H, int l, hipStream_t st)
 {
     int rc;
+    LevT t;
+    if ((rc = lev_target(H, l, st, t))) return rc;
     if ((rc = suhmo_hier_pwl_(H, l, SUHMO_F_B, SUHMO_F_B, st))) return rc;
     if ((rc = suhmo_hier_ff_(H, l, SUHMO_F_B, -1, true, st))) return rc;
-    BOXES(l) if ((rc = suhmo_copy_ghosts(L, 0, SUHMO_F_B, st))) return rc;
+    if (t.base) return suhmo_copy_ghosts(t.base, 0, SUHMO_F_B, st);
+    return suhmo_multi_coef_ghosts(t.m, SUHMO_F_B, st);
+}
+// lagged diffusion terms (diffusion_terms of one level) and RHS_h / the gap-height right-hand side of a whole level
+int hier_melt(suhmo_hier *H, int l, const suhmo_model_params_t *mp, double dt, int final_, bool diffusion, hipStream_t st)
+{
+    int rc;
+    LevT t;
+    if ((rc = lev_target(H, l, st, t))) return rc;
+    const suhmo_phys_t &ph = suhmo_hier_boxes_(H, l)[0]->ph;
+    if (t.base) {
+        suhmo_level *L = t.base;
+        Depth &D = L->d[0];
+        if (diffusion && (rc = diffusion_terms(L, mp, st))) return rc;
+        if (final_) hipLaunchKernelGGL(k_melt<1>, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, ph, *mp, dt);
+        else hipLaunchKernelGGL(k_melt<0>, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, ph, *mp, dt);
+    } else {
+        const suhmo_multi &m = t.m;
+        if (diffusion) {
+            for (int f : {SUHMO_F_DCX, SUHMO_F_DCY, SUHMO_F_DTERM}) if ((rc = suhmo_hier_ensure_(H, l, f))) return rc;
+            if ((rc = lev_target(H, l, st, t))) return rc;                       // the tables after the allocation
+            int n = 2 * m.maxny + 2 * m.maxnx;
+            hipLaunchKernelGGL(k_extrap_ghosts_m, dim3((n + 255) / 256, 1, m.nbox), dim3(256), 0, st, m.dv, m.fp, (int)SUHMO_F_MR);
+            hipLaunchKernelGGL(k_dcoef_faces_m, grid_m(m, 1, 1), dim3(64, 4), 0, st, m.dv, m.fp, ph, mp->rho_i);
+            hipLaunchKernelGGL(k_difterm_m, grid_m(m), dim3(64, 4), 0, st, m.dv, m.fp);
+        }
+        if (final_) hipLaunchKernelGGL(k_melt_m<1>, grid_m(m), dim3(64, 4), 0, st, m.dv, m.fp, ph, *mp, dt);
+        else hipLaunchKernelGGL(k_melt_m<0>, grid_m(m), dim3(64, 4), 0, st, m.dv, m.fp, ph, *mp, dt);
+    }
+    HIPCHK(hipGetLastError());
     return 0;
+}
+// max h and max |h_lagged - h| over the cells of level l no finer level covers
+int hier_picard_maxima(suhmo_hier *H, int l, bool covered, double *maxh, double *maxd, hipStream_t st)
+{
+    int rc;
+    LevT t;
+    if ((rc = lev_target(H, l, st, t))) return rc;
+    suhmo_level *slot = suhmo_hier_boxes_(H, 0)[0];
+    if (t.base) {
+        suhmo_level *L = t.base;
+        return picard_maxima(L, L->d[0].fp.f[SUHMO_F_PHI], L->d[0].fp.f[SUHMO_F_HLAG], maxh, maxd, st, Excl{0, 0, 0, 0}, covered ? L->d[0].fp.f[SUHMO_F_COVER] : nullptr);
+    }
+    const suhmo_multi &m = t.m;
+    dim3 grd(std::min((m.maxnx + 63) / 64, 4), std::min((m.maxny + 3) / 4, 8), m.nbox);       // 2 values per block: 64 nbox doubles
+    hipLaunchKernelGGL(k_picard2_partial_m, grd, dim3(64, 4), 0, st, m.dv, m.fp, covered ? 1 : 0, m.red);
+    hipLaunchKernelGGL(k_max2_final, dim3(1), dim3(256), 0, st, m.red, (int)(grd.x * grd.y * grd.z), slot->scratch, suhmo_host_slot(slot));
+    HIPCHK(hipGetLastError());
+    return suhmo_readback(slot, st, maxh, maxd);
 }
 }  // namespace
 
@@ -614,9 +746,10 @@ extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *
     hipStream_t st = (hipStream_t)s;
     int rc;
     static const int need[] = {SUHMO_F_MR, SUHMO_F_PW, SUHMO_F_QWX, SUHMO_F_QWY, SUHMO_F_HLAG, SUHMO_F_CD, SUHMO_F_GRADX, SUHMO_F_GRADY, SUHMO_F_RE};
-    for (int l = 0; l < nlev; l++) BOXES(l) {
-        for (int f : need) if (!suhmo_field(L, 0, f)) { suhmo_set_error("field allocation failed"); return -2; }
-        if (mp->use_moulin_source && !L->d[0].fp.f[SUHMO_F_MSRC]) { suhmo_set_error("use_moulin_source without a moulin source term (suhmo_hier_moulin_source)"); return -1; }
+    for (int l = 0; l < nlev; l++) {
+        for (int f : need) if ((rc = suhmo_hier_ensure_(H, l, f))) return rc;
+        if (mp->use_moulin_source) for (suhmo_level *L : suhmo_hier_boxes_(H, l))
+            if (!L->d[0].fp.f[SUHMO_F_MSRC]) { suhmo_set_error("use_moulin_source without a moulin source term (suhmo_hier_moulin_source)"); return -1; }
     }
     suhmo_level *base = suhmo_hier_boxes_(H, 0)[0];
     // [I]
@@ -633,25 +766,20 @@ extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *
             if ((rc = hier_gap_ghosts(H, l, st))) return rc;
             if ((rc = suhmo_hier_pwl_(H, l, SUHMO_F_MR, SUHMO_F_MR, st))) return rc;
             if ((rc = suhmo_hier_ff_(H, l, SUHMO_F_MR, -1, true, st))) return rc;               // levelmR.exchange() :2513
-            BOXES(l) { Depth &D = L->d[0];
+            if (l == 0) { Depth &D = base->d[0];
                 HIPCHK(hipMemcpyAsync(D.fp.f[SUHMO_F_HLAG], D.fp.f[SUHMO_F_PHI], D.elems * sizeof(double), hipMemcpyDeviceToDevice, st)); }
+            else { suhmo_multi m; if ((rc = suhmo_hier_multi_(H, l, st, &m)) || (rc = suhmo_multi_copy(m, SUHMO_F_HLAG, SUHMO_F_PHI, st))) return rc; }
         }
         for (int l = 0; l < nlev; l++) if ((rc = hier_chain(H, l, st))) return rc;
-        for (int l = 0; l < nlev; l++) BOXES(l) {
-            Depth &D = L->d[0];
-            if (mp->diffFactor != 0.0 && (rc = diffusion_terms(L, mp, st))) return rc;
-            hipLaunchKernelGGL(k_melt<0>, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, L->ph, *mp, dt);
-            HIPCHK(hipGetLastError());
-        }
+        for (int l = 0; l < nlev; l++) if ((rc = hier_melt(H, l, mp, dt, 0, mp->diffFactor != 0.0, st))) return rc;
         int it = 0;
         if ((rc = suhmo_hier_solve(H, &sp, &it, nullptr, s))) return rc;
         nv += it;
         for (int l = nlev - 1; l > 0; l--) if ((rc = suhmo_hier_avg_(H, l, SUHMO_F_PHI, SUHMO_F_PHI, st))) return rc;   // CoarseAverage :3138-3141
         double maxHead = -1.0e300, maxd = 0.0, res = 0.0;
-        for (int l = 0; l < nlev; l++) BOXES(l) {
+        for (int l = 0; l < nlev; l++) {
             double m = 0.0, d = 0.0;
-            const double *cover = l < nlev - 1 ? L->d[0].fp.f[SUHMO_F_COVER] : nullptr;
-            if ((rc = picard_maxima(L, L->d[0].fp.f[SUHMO_F_PHI], L->d[0].fp.f[SUHMO_F_HLAG], &m, &d, st, Excl{0, 0, 0, 0}, cover))) return rc;
+            if ((rc = hier_picard_maxima(H, l, l < nlev - 1, &m, &d, st))) return rc;
             maxHead = std::max(maxHead, m); maxd = std::max(maxd, d);
         }
         res = picard_quotient(maxd, maxHead);
@@ -664,11 +792,7 @@ extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *
     // [III] level by level: the coarse gap height is already updated when the fine ghost cells are filled
     for (int l = 0; l < nlev; l++) {
         if ((rc = hier_chain(H, l, st))) return rc;
-        BOXES(l) {
-            Depth &D = L->d[0];
-            hipLaunchKernelGGL(k_melt<1>, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, L->ph, *mp, dt);
-        }
-        HIPCHK(hipGetLastError());
+        if ((rc = hier_melt(H, l, mp, dt, 1, false, st))) return rc;
         if (mp->use_impl_diff) continue;                               // b stays, RES = b + dt RHS
         if ((rc = hier_gap_ghosts(H, l, st))) return rc;
     }
@@ -703,7 +827,6 @@ extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *
     if (vcycles) *vcycles = nv;
     return 0;
 }
-#undef BOXES
 
 // ------------------------------------------------------------------ moulin source term
 // Calc_moulin_integral / Calc_moulin_source_term_distributed (src/AmrHydro.cpp:1866-2066).  The n x N array of the

@@ -166,6 +166,15 @@ class HipLevel:
     def synchronize(self):
         check(capi.lib().suhmo_level_synchronize(self.h, self.stream))
 
+    def set_option(self, key, value):
+        """kernel selection (suhmo_level_set_option): e.g. set_option("gsrb_tile", 0)"""
+        check(capi.lib().suhmo_level_set_option(self.h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_long()
+        check(capi.lib().suhmo_level_get_option(self.h, key.encode(), C.byref(v)))
+        return v.value
+
     def rccl_exchanges(self):
         """halo message groups this strip has sent so far (native transport), or the calls of the Python exchanger"""
         n = capi.lib().suhmo_level_rccl_exchanges(self.h)

@@ -368,3 +368,26 @@ def test_full_size_properties(hip):
     G.restrict_r()
     assert np.all(G.get(hip.F_PHI, depth=1) == 2.5)
     assert G.ndepth == 6
+
+
+def test_kernel_selection_through_the_option_api(oracle):
+    """suhmo_level_set_option replaces the SUHMO_* environment variables as the way to pick kernels: the same V-cycle on colour
+    passes, tiles and the streaming kernel gives the same bits; unknown keys and bad values are refused"""
+    from suhmo_amd import level, capi
+    f = sy.shmip_fields(256, 256, ly=1.0e5)
+    res = []
+    for opts in (dict(), dict(gsrb_tile=0, gsrb_variant=0), dict(gsrb_variant=2, fused_min_cells=0), dict(tile_t=16, tile_s=2)):
+        G = level.HipLevel(256, 256, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64)
+        for k, v in opts.items():
+            G.set_option(k, v)
+            assert G.get_option(k) == v
+        G.set_inputs(f); G.build_mg_coefficients()
+        G.vcycle(sy.SOLVER_DEFAULT); G.vcycle(sy.SOLVER_DEFAULT)
+        res.append(G.get(level.F_PHI))
+        with pytest.raises(capi.SuhmoError):
+            G.set_option("no_such_knob", 1)
+        with pytest.raises(capi.SuhmoError):
+            G.set_option("tile_t", 24)
+        G.close()
+    for r in res[1:]:
+        assert np.array_equal(res[0], r)

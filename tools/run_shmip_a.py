@@ -41,6 +41,11 @@ def main():
         k = sys.argv.index("--mask-gradients")
         mask_grad = int(sys.argv[k + 1])
         del sys.argv[k:k + 2]
+    pp_cutoffb = None
+    if "--pp-cutoffb" in sys.argv:                      # solver.cut_solve_outside_domain of the 2 post-processing steps (suite E: input.hydro_pp drops the key -> 0)
+        k = sys.argv.index("--pp-cutoffb")
+        pp_cutoffb = int(sys.argv[k + 1])
+        del sys.argv[k:k + 2]
     which = sys.argv[1] if len(sys.argv) > 1 else "oracle"
     case = sys.argv[2] if len(sys.argv) > 2 else "A3"
     binp = None
@@ -74,6 +79,8 @@ def main():
             M.field(po.OM_MSRC)[1:-1, 1:-1] = src
         tot_p = tot_v = 0
         for k in range(nsteps):
+            if pp_cutoffb is not None and k == nsteps - 2:
+                po.lib().or_model_set_cutoffb(M.h, pp_cutoffb)
             p, v = M.timestep(m["dt"]); tot_p += p; tot_v += v
             if (k + 1) % 1000 == 0:
                 print("step %d  picard %d  vcycles %d  %.0f s" % (k + 1, tot_p, tot_v, time.time() - t0), flush=True)
