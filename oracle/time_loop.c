@@ -263,7 +263,13 @@ static void solve_gap_implicit(OrModel *M, double dt, const double *rhs_valid)
         OrBC nb = M->bc;
         for (int d = 0; d < 2; d++) for (int s = 0; s < 2; s++) { nb.type[d][s] = 1; nb.value[d][s] = 0.0; }
         OrPhys lp = M->ph; lp.use_NL = 0;
-        M->G = or_level_create(nx, ny, M->dx, M->dy, M->G_max_box, &nb, &lp, 1.0, dt * M->mp.diffFactor, M->G_nthreads);
+        double bsign = 1.0;
+        {   /* diagnosis knob (DESIGN.md "suite E"): sign of beta in the stand-in for VCAMRPoissonOp2.  +1: alpha a phi - beta div(D grad phi)
+             * (diffusion, the convention of VCAMRNonLinearPoissonOp); -1: upstream Chombo's alpha a phi + beta div(b grad phi) */
+            const char *e = getenv("SUHMO_ORACLE_GAP_BETA_SIGN");
+            if (e) bsign = atof(e);
+        }
+        M->G = or_level_create(nx, ny, M->dx, M->dy, M->G_max_box, &nb, &lp, 1.0, bsign * dt * M->mp.diffFactor, M->G_nthreads);
         M->G_dt = dt;
         double *one = (double *)malloc(sizeof(double) * (size_t)nx * ny);
         for (size_t k = 0; k < (size_t)nx * ny; k++) one[k] = 1.0;
@@ -283,7 +289,13 @@ static void solve_gap_implicit(OrModel *M, double dt, const double *rhs_valid)
     sp.eps = 1.0e-7; sp.hang = 1.0e-6; sp.norm_thresh = 1.0e-7; sp.bcoeff_otf = 0; sp.max_depth = -1;
     (void)or_level_solve(M->G, &sp, NULL);
     or_level_get(M->G, 0, OR_F_PHI, tmp, 0);
-    for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) CC(M->c[OM_B], i, j) = tmp[(size_t)j * nx + i];
+    {   /* diagnosis knob (DESIGN.md "suite E"): cells without ice keep their gap height through the implicit solve (no diffusion of b
+         * across the ice margin).  Unset = the restated source: D >= 5e-6 on margin faces (COMPUTEDCOEFF cuts only faces with IMec < 0) */
+        const char *e = getenv("SUHMO_ORACLE_GAP_FREEZE_ICEFREE");
+        int freeze = e && atoi(e);
+        for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++)
+            if (!(freeze && CC(M->c[OM_MASK], i, j) < 0.0)) CC(M->c[OM_B], i, j) = tmp[(size_t)j * nx + i];
+    }
     free(tmp);
 }
 

@@ -164,3 +164,32 @@ def test_convergence_distributed_reference_table(hipmodel):
     for nx in ref:
         for k, (a, b) in enumerate(zip(got[nx], ref[nx])):
             assert abs(a - b) <= 6e-5 * abs(b), (nx, ("head", "gapHeight", "Pw", "Re")[k], a, b)      # 5 significant digits
+
+
+@pytest.mark.parametrize("case", ["E1", "E4"])
+def test_suite_e_masked_margin_on_the_device(oracle, hipmodel, case):
+    """SHMIP suite E (valley glacier, oblique ice margin: ice mask, cut_solve_outside_domain, masked gradients, use_mask_rhs_b,
+    diffusion + implicit gap-height solve, exec/E_SHMIP/E<k>/input.hydro) -- the configuration whose tables pin the masked
+    branches of the oracle (tests/test_oracle_timeloop.py): the device steps it bit for bit with the oracle (source as it is on
+    both sides), 40 steps from the reference's initial state, ice-free cells and margin faces included."""
+    m = sy.shmip_e_model(case)
+    st = sy.valley_initial_state(m["nx"], m["ny"], sy.E_GAMMA[case], m["lx"], m["ly"])
+    phys = dict(sy.E_PHYS, cutOffB=sy.E_CUTOFFB[case])
+    O = oracle.OracleModel(m["nx"], m["ny"], st["dx"], st["dy"], sy.A3_BC, phys, m, max_box=64, nthreads=8)
+    G = hipmodel.HipModel(m["nx"], m["ny"], st["dx"], st["dy"], sy.A3_BC, phys, m, max_box=64)
+    O.set_state(st); G.set_state(st)
+    from suhmo_amd import level as lv
+    O.field(oracle.OM_MR)[:] = m["G"] / m["L"]
+    G.level.set(lv.F_MR, np.full((m["ny"], m["nx"]), m["G"] / m["L"]))
+    v = lambda a: np.array(a)[1:-1, 1:-1]
+    mask = v(O.field(oracle.OM_MASK))
+    assert (mask < 0).sum() > 1000 and (mask > 0).sum() > 1000
+    for k in range(40):
+        co, cg = O.timestep(m["dt"]), G.timestep(m["dt"])
+        assert co == cg, (k, co, cg)
+    for nm, fid in (("head", oracle.OM_H), ("B", oracle.OM_B), ("mR", oracle.OM_MR), ("Pw", oracle.OM_PW), ("Re", oracle.OM_RE)):
+        a, b = v(O.field(fid)), G.get(nm)
+        assert np.array_equal(a, b, equal_nan=True), (case, nm, float(np.nanmax(np.abs(a - b))))
+    for nm, fid in (("qwx", oracle.OM_QWX), ("qwy", oracle.OM_QWY)):
+        assert np.array_equal(np.array(O.field(fid)), G.get(nm), equal_nan=True), (case, nm)
+    O.close(); G.close()
