@@ -53,3 +53,30 @@ def test_two_ranks_over_nccl_bitwise():
     logs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     assert "BITWISE EQUAL" in logs[0]
+
+
+@pytest.mark.parametrize("tool,args,world", [("amr_shmip_dist.py", ["--case", "B5", "--steps", "6", "--check"], 2),
+                                             ("shmip_dist.py", ["--case", "B3", "--scale", "1", "--steps", "6", "--check"], 4)])
+def test_rank_strips_as_processes(tool, args, world):
+    """cfg4: SHMIP B5 (100 moulins, diffusion, implicit gap-height solve) on a 3-level AMR hierarchy cut into the strips of 2
+    processes, and B3 single-level on 4 processes (gloo, all ranks on the one GPU of the test box): every level's head, gap
+    height and melt rate equal the single-process run bit for bit (the tool's --check)"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SUHMO_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", tool)] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=600)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("timed out")
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-2000:] for l in logs)
+    assert "BITWISE EQUAL" in logs[0]

@@ -391,3 +391,52 @@ def test_kernel_selection_through_the_option_api(oracle):
         G.close()
     for r in res[1:]:
         assert np.array_equal(res[0], r)
+
+
+def test_cfg2_shmip_a3_on_1024x1024_bitwise(oracle):
+    """configs[1] of BASELINE.json literally: SHMIP A3 (100 km x 20 km, steady distributed source) on a 1024 x 1024 single level
+    with 64 x 64 boxes -- operator update, two V-cycles and the residual history of a short solve against the oracle, bit for bit"""
+    from suhmo_amd import level
+    f = sy.shmip_fields(1024, 1024)
+    O = oracle.OracleLevel(1024, 1024, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, 0.0, -1.0, 64, 8)
+    G = level.HipLevel(1024, 1024, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64)
+    O.set_inputs(f); G.set_inputs(f)
+    O.build_mg_coefficients(); G.build_mg_coefficients()
+    assert O.ndepth == G.ndepth == 6
+    sp = dict(sy.SOLVER_DEFAULT, max_iter=3, imin=10, eps=1e-12, norm_thresh=1e-30)
+    O.vcycle(sp); G.vcycle(sp)
+    assert np.array_equal(O.get(oracle.F_PHI), G.get(level.F_PHI))
+    assert np.array_equal(O.get(oracle.F_BX), G.get(level.F_BX)) and np.array_equal(O.get(oracle.F_BY), G.get(level.F_BY))
+    no, ho = O.solve(sp)
+    ng, hg = G.solve(sp)
+    assert no == ng == 3 and np.array_equal(ho, hg), (ho, hg)
+    assert np.array_equal(O.get(oracle.F_PHI), G.get(level.F_PHI))
+    O.close(); G.close()
+
+
+def test_single_precision_literals_of_the_fortran_kernels(oracle):
+    """The .ChF kernels spell g and rho_w g as 9.8 and 1000.0 * 9.8 (src/AmrHydroF.ChF:45-52, 103, 217): a build whose Fortran
+    compiler does not promote real literals to real*8 computes with float(9.8) = 9.80000019073486328125.  Both the library and
+    the oracle take g and rho_w g as parameters: the nonlinear terms, the operator update (Re, bCoef) and a V-cycle with the
+    single-precision-literal values are bitwise equal too, and differ from the double-literal results (1000.0 * 9.8 is 9800 exactly
+    in single precision too, so only the terms with a bare 9.8 move: dNL, Re, bCoef)."""
+    from suhmo_amd import level
+    g32 = float(np.float32(9.8))
+    ph32 = dict(sy.RANDOM_PHYS, grav=g32, rho_w_g=float(np.float32(1000.0) * np.float32(9.8)))
+    f = sy.random_fields(96, 64)
+    out = {}
+    for name, ph in (("f64", sy.RANDOM_PHYS), ("f32", ph32)):
+        O = oracle.OracleLevel(96, 64, f["dx"], f["dy"], sy.RANDOM_BC, ph, 0.0, -1.0, 32, 2)
+        G = level.HipLevel(96, 64, f["dx"], f["dy"], sy.RANDOM_BC, ph, max_box=32)
+        O.set_inputs(f); G.set_inputs(f)
+        O.build_mg_coefficients(); G.build_mg_coefficients()
+        O.nonlinear(); G.nonlinear()
+        assert np.array_equal(O.get(oracle.F_NL), G.get(level.F_NL)) and np.array_equal(O.get(oracle.F_DNL), G.get(level.F_DNL))
+        O.update_operator(); G.update_operator()
+        assert np.array_equal(O.get(oracle.F_BX), G.get(level.F_BX)) and np.array_equal(O.get(oracle.F_BY), G.get(level.F_BY))
+        O.vcycle(sy.SOLVER_DEFAULT); G.vcycle(sy.SOLVER_DEFAULT)
+        assert np.array_equal(O.get(oracle.F_PHI), G.get(level.F_PHI))
+        out[name] = (G.get(level.F_DNL), G.get(level.F_BX), G.get(level.F_PHI))
+        O.close(); G.close()
+    assert not np.array_equal(out["f64"][0], out["f32"][0]) and not np.array_equal(out["f64"][1], out["f32"][1])
+    assert np.max(np.abs(out["f64"][2] - out["f32"][2])) < 1e-5 * np.max(np.abs(out["f64"][2]))

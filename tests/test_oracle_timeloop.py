@@ -40,7 +40,9 @@ PIN_TOL = {"A": 5e-6, "B": 5e-7, "E": 1.2e-5}
 # COMPUTEBCOEFF's cutOffB, the masked gradients and ValleyIBC are thereby pinned by the reference's own output.
 ECASES = ["E1", "E2", "E3", "E4", "E5"]
 # SOURCE AS IT IS ("run" runs, what the HIP path implements): differs by those two settings only
-ASIS_TOL = {0: 1e-6, 1: 0.0, 2: 8e-3, 5: 1e-5, 6: 2e-3, 7: 2e-3}
+ASIS_TOL = {0: 1e-6, 1: 0.0, 2: 8e-3, 3: 7.5e-2, 4: 7.5e-2, 5: 1e-5, 6: 2e-3, 7: 2e-3}
+# columns 3 and 4 (the channelised / distributed parts of the discharge) are held to the discharge's scale: the channelisation degree
+# RHS_A / (RHS_A + RHS_B) shifts with the melt share, which moves up to 7.1 % of the discharge from one part to the other (B2)
 
 
 def check_against_reference(table, case, variant):
@@ -54,8 +56,8 @@ def check_against_reference(table, case, variant):
             assert err <= tol * sc, (case, c, err / sc)
         return
     for c, t in ASIS_TOL.items():
-        sel = slice(1, None) if c == 2 else slice(None)     # row 0: the masked boundary-face gradient, see above
-        sc = np.max(np.abs(ref[sel, c]))
+        sel = slice(1, None) if c in (2, 3, 4) else slice(None)     # row 0: the masked boundary-face gradient, see above
+        sc = np.max(np.abs(ref[sel, 2 if c in (3, 4) else c]))
         err = np.max(np.abs(table[sel, c] - ref[sel, c]))
         assert err <= t * sc, (case, variant, c, err / sc)
 
