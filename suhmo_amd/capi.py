@@ -8,7 +8,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libsuhmo_hip.so")
+LIB_PATH = os.environ.get("SUHMO_LIB") or os.path.join(CSRC, "libsuhmo_hip.so")     # SUHMO_LIB: another build of the same library (A/B runs)
 _LIB = None
 
 

@@ -1,0 +1,66 @@
+"""The checkpoint library (libsuhmo_chk.so: Chombo HDF5 layout of AmrHydro::writeCheckpointFile, src/AmrHydro.cpp:5670-5842) on
+the host alone: every symbol of include/suhmo_chk.h is exported, a three-level multi-box state goes through a file and comes
+back bit for bit with its header, box lists and ghost cells, and the file has the datasets Chombo's reader looks for."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def chk():
+    from suhmo_amd import checkpoint
+    checkpoint.build()
+    return checkpoint
+
+
+def test_header_symbols_are_exported(chk):
+    hdr = open(os.path.join(ROOT, "include", "suhmo_chk.h")).read()
+    declared = sorted(set(re.findall(r"\b(suhmo_chk_[a-z_]+)\s*\(", hdr)))
+    L = C.CDLL(chk.LIB_PATH)
+    assert declared == sorted(chk.SYMBOLS)
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def make_levels(rng):
+    boxes = [[(0, 0, 31, 15)], [(8, 4, 23, 11), (24, 4, 39, 19), (40, 20, 47, 27)], [(20, 10, 35, 21)]]
+    levels = []
+    for l, bl in enumerate(boxes):
+        data = {name: [rng.normal(size=(b[3] - b[1] + 3, b[2] - b[0] + 3)) for b in bl] for name, _ in __import__("suhmo_amd.checkpoint", fromlist=["FIELDS"]).FIELDS}
+        levels.append(dict(dx=100.0 / 2 ** l, dy=50.0 / 2 ** l, domain=(0, 0, (32 << l) - 1, (16 << l) - 1), boxes=bl, data=data))
+    return levels
+
+
+def test_round_trip(chk, tmp_path):
+    levels = make_levels(np.random.default_rng(3))
+    path = str(tmp_path / "chk000123.2d.hdf5")
+    chk.write_levels(path, levels, step=123, time=442800.0, dt=3600.0, periodic=(0, 1))
+    hdr, back = chk.read_levels(path)
+    assert hdr == dict(max_level=2, finest_level=2, current_step=123, time=442800.0, dt=3600.0, cfl=0.5, is_periodic=(0, 1))
+    assert len(back) == 3
+    for a, b in zip(levels, back):
+        assert a["boxes"] == b["boxes"] and a["domain"] == b["domain"] and a["dx"] == b["dx"] and a["dy"] == b["dy"]
+        for name in a["data"]:
+            for x, y in zip(a["data"][name], b["data"][name]):
+                assert np.array_equal(x, y), name
+    assert back[0]["ref_ratio"] == 2 and back[1]["ref_ratio"] == 2 and back[2]["ref_ratio"] == 0
+
+
+def test_file_layout_is_chombos(chk, tmp_path):
+    h5dump = "/opt/conda/bin/h5dump"
+    if not os.path.exists(h5dump):
+        pytest.skip("no h5dump in this image")
+    path = str(tmp_path / "chk.hdf5")
+    chk.write_levels(path, make_levels(np.random.default_rng(4)), step=7, time=1.0, dt=2.0)
+    out = subprocess.run([h5dump, "-n", "1", path], stdout=subprocess.PIPE, check=True).stdout.decode()
+    for need in ("/Chombo_global", "/level_0/boxes", "/level_1/headData:datatype=0", "/level_1/headData:offsets=0", "/level_1/headData_attributes",
+                 "/level_2/iceMaskData:datatype=0", "/level_0/meltRateData_attributes"):
+        assert need in out, need
+    for attr in ("max_level", "finest_level", "current_step", "time", "dt", "num_comps", "component_0010", "is_periodic_1"):
+        assert re.search(r"attribute\s+/%s\b" % attr, out), attr
