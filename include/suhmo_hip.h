@@ -376,6 +376,14 @@ int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *mp, double 
 int suhmo_hier_moulin_source(suhmo_hier_t *H, int n_moulins, const double *positions, const double *sigma, const double *flux,
                              double time_factor, double *integrals, suhmo_stream_t s);
 
+/* Named timers with the reference's CH_TIME labels (src/VCAMRNonLinearPoissonOp.cpp:40,69,103,277,390,660; CH_TIMER_REPORT at
+ * exec/A_SHMIP/Suhmo.cpp:136).  mode 0 off (default; env SUHMO_TIMERS), 1 host wall time per scope, 2 with the device synchronised at
+ * both ends of a scope (the time of the kernels it launched; serialises, for profiling only).  suhmo_timers_report writes
+ * "label calls total[s] mean[us]" lines, most expensive first, and returns the bytes the full report needs. */
+int suhmo_timers_enable(int mode);
+int suhmo_timers_reset(void);
+long suhmo_timers_report(char *buf, long size);
+
 /* timing helper: average device time (ms) of the depth-0 GSRB sweep kernel launches since the last reset, measured with
  * HIP events on the launch stream.  suhmo_level_profile_read: the plain K-sweep launches (k_gsrb_fused<K, ., ., false>);
  * suhmo_level_profile_read_restricting: the launches that end a pre-smoothing and also restrict (k_gsrb_fused<K, ., ., true>:

@@ -267,8 +267,12 @@ int or_amr_model_timestep(OrAmrModel *S, double dt, int *picard_iters, int *vcyc
                 if (l == 0) or_level_set(S->base, 0, pass == 0 ? OR_F_PHI : OR_F_RHS, tmp[l], 0);
                 else or_amr_patch_io(S->A, l, pass == 0 ? OR_F_PHI : OR_F_RHS, tmp[l], 0, 1);
             }
-            if (l == 0) { or_level_set(S->base, 0, OR_F_B, M->c[OM_B], 1); or_level_build_mg_coefficients(S->base); }
-            else or_amr_patch_io(S->A, l, OR_F_B, M->c[OM_B], 1, 1);
+            double *bx = (double *)malloc(sizeof(double) * (size_t)(M->nx + 1) * M->ny), *by = (double *)malloc(sizeof(double) * (size_t)M->nx * (M->ny + 1));
+            or_model_bcoef(M, bx, by);                                /* aCoeff_bCoeff :3087-3102 */
+            if (l == 0) { or_level_set(S->base, 0, OR_F_B, M->c[OM_B], 1); or_level_set(S->base, 0, OR_F_BX, bx, 0); or_level_set(S->base, 0, OR_F_BY, by, 0);
+                          or_level_build_mg_coefficients(S->base); }
+            else { or_amr_patch_io(S->A, l, OR_F_B, M->c[OM_B], 1, 1); or_amr_patch_io(S->A, l, OR_F_BX, bx, 0, 1); or_amr_patch_io(S->A, l, OR_F_BY, by, 0, 1); }
+            free(bx); free(by);
         }
         nv += or_amr_solve(S->A, &sp, NULL);
         for (int l = 0; l < n; l++) {

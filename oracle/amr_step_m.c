@@ -294,6 +294,12 @@ int or_amrm_model_timestep(OrAmrMModel *S, double dt, int *picard_iters, int *vc
                 to_solver(S, S->A, S->base, l, k, pass == 0 ? OR_F_PHI : OR_F_RHS, tmp, 0);
             }
             to_solver(S, S->A, S->base, l, k, OR_F_B, M->c[OM_B], 1);
+            {
+                double *bx = (double *)malloc(sizeof(double) * (size_t)(M->nx + 1) * M->ny), *by = (double *)malloc(sizeof(double) * (size_t)M->nx * (M->ny + 1));
+                or_model_bcoef(M, bx, by);                            /* aCoeff_bCoeff :3087-3102 */
+                to_solver(S, S->A, S->base, l, k, OR_F_BX, bx, 0); to_solver(S, S->A, S->base, l, k, OR_F_BY, by, 0);
+                free(bx); free(by);
+            }
             if (l == 0) or_level_build_mg_coefficients(S->base);
         }
         nv += or_amrm_solve(S->A, &sp, NULL);

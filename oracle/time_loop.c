@@ -192,6 +192,29 @@ void or_model_qw(OrModel *M)
 }
 
 static void grad_re_qw(OrModel *M) { or_model_grad(M); or_model_re(M); or_model_qw(M); }
+/* aCoeff_bCoeff (src/AmrHydro.cpp:1781-1817, called at :3087-3102 before SolveForHead_nl): the bCoef the solver's operators are
+ * DEFINED with -- COMPUTEBCOEFF of the lagged B_ec and Re_ec with the edge ice mask.  The first residual of the solve (and the
+ * stopping rule's initial norm) sees it; every V-cycle then updates it from the head (bcoeff_otf).  bx: ny x (nx+1), by: (ny+1) x nx */
+void or_model_bcoef(const OrModel *M, double *bx, double *by)
+{
+    const double *IM = M->c[OM_MASK];
+    for (int dir = 0; dir < 2; dir++) {
+        int ii = dir == 0, jj = dir == 1;
+        for (int j = 0; j < M->ny + jj; j++)
+            for (int i = 0; i < M->nx + ii; i++) {
+                double m = CC(IM, i, j), mm1 = CC(IM, i - ii, j - jj), mec;
+                if (fabs(m - mm1) < 1e-10) mec = (m > 0.0) ? 1.0 : -1.0; else mec = 0.0;
+                int idx = dir == 0 ? i + M->i0 : j + M->j0;
+                if (idx == 0 || idx == (dir == 0 ? M->nxg : M->nyg)) mec = 0.0;
+                double b = dir == 0 ? FX(M->bxf, i, j) : FY(M->byf, i, j), re = dir == 0 ? FX(M->rxf, i, j) : FY(M->ryf, i, j);
+                double num_q = -(b * b * b * M->ph.grav);
+                double denom_q = 12.0 * M->ph.nu * (1.0 + M->ph.omega * re);
+                double v = (mec < 0.0 && M->ph.cutOffB > 0) ? 0.0 : num_q / denom_q;
+                if (dir == 0) bx[(size_t)j * (M->nx + 1) + i] = v; else by[(size_t)j * M->nx + i] = v;
+            }
+    }
+}
+
 
 /* COMPUTESCAPROD + EdgeToCell + Calc_meltingRate (:2954-2979, :2174-2252) on valid cells */
 static void melting_rate(OrModel *M)
@@ -421,6 +444,12 @@ int or_model_timestep(OrModel *M, double dt, int *picard_iters, int *vcycles_tot
         for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) tmp[(size_t)j * nx + i] = CC(rhs, i, j);
         or_level_set(M->L, 0, OR_F_RHS, tmp, 0);
         or_level_set(M->L, 0, OR_F_B, B, 1);
+        {
+            double *bx = (double *)malloc(sizeof(double) * (size_t)(nx + 1) * ny), *by = (double *)malloc(sizeof(double) * (size_t)nx * (ny + 1));
+            or_model_bcoef(M, bx, by);                                           /* aCoeff_bCoeff :3087-3102 */
+            or_level_set(M->L, 0, OR_F_BX, bx, 0); or_level_set(M->L, 0, OR_F_BY, by, 0);
+            free(bx); free(by);
+        }
         or_level_build_mg_coefficients(M->L);
         nv += or_level_solve(M->L, &sp, NULL);
         or_level_get(M->L, 0, OR_F_PHI, tmp, 0);

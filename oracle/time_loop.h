@@ -61,6 +61,7 @@ void or_model_begin_iteration(OrModel *M);              /* ghosts of h and b, la
 void or_model_grad(OrModel *M);                         /* compute_grad_head: faces, cells, domain-side ghosts */
 void or_model_re(OrModel *M);                           /* COMPUTERE on the ghosted box */
 void or_model_qw(OrModel *M);                           /* Re_ec, COMPUTEQW */
+void or_model_bcoef(const OrModel *M, double *bx, double *by);   /* aCoeff_bCoeff: bCoef the solver is defined with */
 void or_model_rhs_h(OrModel *M);                        /* source, lagged diffusion, melt rate, RHS_h */
 void or_model_solver_params(const OrModel *M, OrSolverParams *sp);
 int or_model_picard_converged(const OrModel *M, double res, int cur_picard);

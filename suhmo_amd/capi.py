@@ -74,7 +74,7 @@ SYMBOLS = [
     "suhmo_level_set_alpha_beta", "suhmo_level_set_bc", "suhmo_amr2_reflux", "suhmo_amr2_pwl_fill", "suhmo_amr_timestep", "suhmo_level_time_varying_recharge", "suhmo_amr_moulin_source", "suhmo_amr2_prolong_pc", "suhmo_amr2_finer_operator_changed",
     "suhmo_hier_create", "suhmo_hier_destroy", "suhmo_hier_num_levels", "suhmo_hier_num_boxes", "suhmo_hier_box", "suhmo_hier_exchange",
     "suhmo_hier_cf_interp", "suhmo_hier_pwl_fill", "suhmo_hier_average", "suhmo_hier_gsrb", "suhmo_hier_update_operator",
-    "suhmo_hier_residual", "suhmo_hier_vcycle", "suhmo_hier_solve", "suhmo_hier_timestep", "suhmo_hier_moulin_source", "suhmo_level_set_option", "suhmo_level_get_option",
+    "suhmo_hier_residual", "suhmo_hier_vcycle", "suhmo_hier_solve", "suhmo_hier_timestep", "suhmo_hier_moulin_source", "suhmo_level_set_option", "suhmo_level_get_option", "suhmo_timers_enable", "suhmo_timers_reset", "suhmo_timers_report",
 ]
 
 
@@ -174,6 +174,9 @@ def lib():
     L.suhmo_hier_solve.argtypes = [vp, C.POINTER(SolverParams), ip, dp, vp]
     L.suhmo_hier_timestep.argtypes = [vp, C.POINTER(ModelParams), C.c_double, ci, ip, ip, vp]
     L.suhmo_hier_moulin_source.argtypes = [vp, ci, dp, dp, dp, C.c_double, dp, vp]
+    L.suhmo_timers_enable.argtypes = [ci]
+    L.suhmo_timers_report.argtypes = [C.c_char_p, C.c_long]
+    L.suhmo_timers_report.restype = C.c_long
     L.suhmo_level_set_option.argtypes = [vp, C.c_char_p, C.c_long]
     L.suhmo_level_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_long)]
     L.suhmo_level_profile_reset.argtypes = [vp]
@@ -187,3 +190,11 @@ def lib():
 def check(rc):
     if rc != 0:
         raise SuhmoError("libsuhmo_hip: rc=%d: %s" % (rc, lib().suhmo_last_error().decode()))
+
+
+def timers_report():
+    """CH_TIMER_REPORT: the named timers as text (enable with lib().suhmo_timers_enable(1 | 2) or SUHMO_TIMERS)"""
+    n = lib().suhmo_timers_report(None, 0)
+    buf = C.create_string_buffer(n)
+    lib().suhmo_timers_report(buf, n)
+    return buf.value.decode()

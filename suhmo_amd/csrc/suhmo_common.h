@@ -175,6 +175,11 @@ struct suhmo_level {
 };
 
 void suhmo_set_error(const char *fmt, ...);
+// Named scoped timers with the reference's CH_TIME labels (src/VCAMRNonLinearPoissonOp.cpp:40,69,103,277,390,660; report =
+// CH_TIMER_REPORT, exec/A_SHMIP/Suhmo.cpp:136).  Off by default (one relaxed load per scope); suhmo_timers_enable(1): host wall
+// time per scope, (2): the device is synchronised at both ends, so the time includes the kernels the scope launched.
+struct SuhmoTimer { const char *name; double t0; int mode; explicit SuhmoTimer(const char *n); ~SuhmoTimer(); };
+#define SUHMO_TIME(label) SuhmoTimer suhmo_tm_(label)
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     suhmo_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return -2; } } while (0)
 #define ARG(cond) do { if (!(cond)) { suhmo_set_error("%s:%d bad argument: %s", __FILE__, __LINE__, #cond); return -1; } } while (0)

@@ -163,6 +163,7 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
 
 extern "C" int suhmo_level_vcycle(suhmo_level_t *L, const suhmo_solver_params_t *sp, suhmo_stream_t s)
 {
+    SUHMO_TIME("AMRFASMultiGrid::VCycle");
     ARG(L && sp);
     HIPCHK(hipSetDevice(L->device));
     int nd = eff_depths(L, sp);
@@ -178,6 +179,7 @@ extern "C" int suhmo_level_vcycle(suhmo_level_t *L, const suhmo_solver_params_t 
 
 extern "C" int suhmo_level_solve(suhmo_level_t *L, const suhmo_solver_params_t *sp, int *iters, double *hist, suhmo_stream_t s)
 {
+    SUHMO_TIME("AMRFASMultiGrid::solve");
     ARG(L && sp);
     HIPCHK(hipSetDevice(L->device));
     int rc;

@@ -569,6 +569,7 @@ int hier_ff(suhmo_hier *H, int l, int f0, int f1, bool corners, hipStream_t st)
 // QuadCFInterp: coarse-fine ghosts of field ff of level l <- field fc of level l-1
 int hier_cf(suhmo_hier *H, int l, int ff, int fc, hipStream_t st)
 {
+    SUHMO_TIME("QuadCFInterp::coarseFineInterp");
     if (l == 0) return 0;
     HLev &V = H->lev[l];
     int rc;
@@ -629,6 +630,7 @@ int hier_prolong2(suhmo_hier *H, int l, int field_c, hipStream_t st)
 // coarse-fine faces of level l
 int hier_reflux(suhmo_hier *H, int l, int field_c, hipStream_t st)
 {
+    SUHMO_TIME("VCAMRNonLinearPoissonOp::reflux");
     HLev &V = H->lev[l];
     int rc;
     CoarseArgs ca;
@@ -645,6 +647,7 @@ int hier_reflux(suhmo_hier *H, int l, int field_c, hipStream_t st)
 // relax: levelGSRB x sweeps (src/VCAMRNonLinearPoissonOp.cpp:654-760): per colour pass exchange, then the pass on every box
 int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
 {
+    SUHMO_TIME("AMRNonLinearPoissonOp::relaxNF");
     if (l == 0) return suhmo_level_gsrb(base_of(H), 0, sweeps, s);
     int rc;
     suhmo_multi m;
@@ -714,6 +717,7 @@ int hier_grad_cc(suhmo_hier *H, int l, suhmo_stream_t s)
 // UpdateOperator of level l >= 1 with its coarser level (src/VCAMRNonLinearPoissonOp.cpp:34-64, src/AmrHydro.cpp:1415-1539)
 int hier_update_operator(suhmo_hier *H, int l, suhmo_stream_t s)
 {
+    SUHMO_TIME("VCAMRNonLinearPoissonOp::UpdateOperator(AMR)");
     int rc;
     if ((rc = cf_phi(H, l - 1, s))) return rc;                    // the coarser level's own coarse-fine ghosts (its gradient reads them)
     if ((rc = hier_grad_cc(H, l, s))) return rc;
@@ -950,6 +954,7 @@ extern "C" int suhmo_hier_update_operator(suhmo_hier_t *H, int l, suhmo_stream_t
 // composite residual of the hierarchy (RES of every level, covered cells zeroed) and its max norm (AMRNorm :1222-1264)
 extern "C" int suhmo_hier_residual(suhmo_hier_t *H, double *norm, suhmo_stream_t s)
 {
+    SUHMO_TIME("AMRNonLinearPoissonOp::AMRResidual");
     int rc = check_hier(H); if (rc) return rc;
     HIPCHK(hipSetDevice(H->device));
     const int top = H->nlev - 1;
@@ -972,6 +977,7 @@ extern "C" int suhmo_hier_residual(suhmo_hier_t *H, double *norm, suhmo_stream_t
 }
 extern "C" int suhmo_hier_vcycle(suhmo_hier_t *H, const suhmo_solver_params_t *sp, suhmo_stream_t s)
 {
+    SUHMO_TIME("AMRFASMultiGrid::VCycle(AMR)");
     int rc = check_hier(H); if (rc) return rc;
     ARG(sp);
     HIPCHK(hipSetDevice(H->device));
@@ -979,6 +985,7 @@ extern "C" int suhmo_hier_vcycle(suhmo_hier_t *H, const suhmo_solver_params_t *s
 }
 extern "C" int suhmo_hier_solve(suhmo_hier_t *H, const suhmo_solver_params_t *sp, int *iters, double *hist, suhmo_stream_t s)
 {
+    SUHMO_TIME("AMRFASMultiGrid::solve(AMR)");
     ARG(sp);
     int rc;
     if (H && H->nlev == 1) return suhmo_level_solve(base_of(H), sp, iters, hist, s);

@@ -2,6 +2,7 @@
 // kernel except the GSRB relaxation (suhmo_gsrb.hip) and the FAS driver (suhmo_fas.hip).
 // gfx950 only.  Reference citations: file:line in the SUHMO checkout.
 #include "suhmo_hier.h"
+#include <algorithm>
 #include <cstdarg>
 #include <cmath>
 #include <initializer_list>
@@ -12,6 +13,57 @@ void suhmo_set_error(const char *fmt, ...)
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 extern "C" const char *suhmo_last_error(void) { return g_err; }
+// ------------------------------------------------------------------ named timers (CH_TIME / CH_TIMER_REPORT)
+#include <atomic>
+#include <chrono>
+#include <map>
+#include <mutex>
+namespace {
+std::atomic<int> g_timer_mode{-1};
+std::mutex g_timer_mu;
+struct TimerRec { long count = 0; double total = 0.0; };
+std::map<std::string, TimerRec> g_timers;
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline int timer_mode()
+{
+    int m = g_timer_mode.load(std::memory_order_relaxed);
+    if (m < 0) { const char *e = getenv("SUHMO_TIMERS"); m = e ? atoi(e) : 0; g_timer_mode.store(m); }
+    return m;
+}
+}  // namespace
+SuhmoTimer::SuhmoTimer(const char *n) : name(n), t0(0.0), mode(timer_mode())
+{
+    if (!mode) return;
+    if (mode >= 2) (void)hipDeviceSynchronize();
+    t0 = now_s();
+}
+SuhmoTimer::~SuhmoTimer()
+{
+    if (!mode) return;
+    if (mode >= 2) (void)hipDeviceSynchronize();
+    double dt = now_s() - t0;
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    TimerRec &r = g_timers[name];
+    r.count++; r.total += dt;
+}
+extern "C" int suhmo_timers_enable(int mode) { g_timer_mode.store(mode < 0 ? 0 : mode); return 0; }
+extern "C" int suhmo_timers_reset(void) { std::lock_guard<std::mutex> lk(g_timer_mu); g_timers.clear(); return 0; }
+// "label  calls  total [s]  mean [us]" per line, most expensive first; returns the number of bytes the full report needs
+extern "C" long suhmo_timers_report(char *buf, long size)
+{
+    std::vector<std::pair<std::string, TimerRec>> v;
+    { std::lock_guard<std::mutex> lk(g_timer_mu); v.assign(g_timers.begin(), g_timers.end()); }
+    std::sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return a.second.total > b.second.total; });
+    std::string out;
+    char line[256];
+    for (auto &e : v) {
+        snprintf(line, sizeof(line), "%-56s %10ld %14.6f %12.2f\n", e.first.c_str(), e.second.count, e.second.total, 1e6 * e.second.total / std::max(1L, e.second.count));
+        out += line;
+    }
+    if (buf && size > 0) { long n = std::min<long>(size - 1, (long)out.size()); memcpy(buf, out.data(), n); buf[n] = 0; }
+    return (long)out.size() + 1;
+}
+
 extern "C" int suhmo_device_count(void)
 {
     int n = 0;
@@ -561,6 +613,7 @@ int suhmo_ensure_phi_halo(suhmo_level *L, int depth, int need, hipStream_t st)
 
 extern "C" int suhmo_level_apply_op(suhmo_level_t *L, int depth, int homogeneous, suhmo_stream_t s)
 {
+    SUHMO_TIME("VCAMRNonLinearPoissonOp::applyOpI");
     ARG(L); ARG(depth >= 0 && depth < L->ndepth);
     HIPCHK(hipSetDevice(L->device));
     Depth &D = L->d[depth];
@@ -587,6 +640,7 @@ int suhmo_fas_coarse_rhs(suhmo_level *L, int depth, hipStream_t st, int hcomp)
 
 extern "C" int suhmo_level_residual(suhmo_level_t *L, int depth, suhmo_stream_t s)
 {
+    SUHMO_TIME("VCAMRNonLinearPoissonOp::residualI");
     ARG(L); ARG(depth >= 0 && depth < L->ndepth);
     HIPCHK(hipSetDevice(L->device));
     Depth &D = L->d[depth];
@@ -639,6 +693,7 @@ extern "C" int suhmo_level_compute_lambda(suhmo_level_t *L, int depth, suhmo_str
 
 extern "C" int suhmo_level_gsrb(suhmo_level_t *L, int depth, int sweeps, suhmo_stream_t s)
 {
+    SUHMO_TIME("VCAMRNonLinearPoissonOp::levelGSRB");
     ARG(L); ARG(depth >= 0 && depth < L->ndepth); ARG(sweeps >= 0);
     HIPCHK(hipSetDevice(L->device));
     int rc = suhmo_launch_gsrb(L, depth, sweeps, 0, (hipStream_t)s);
@@ -714,6 +769,7 @@ static int restrict_residual_impl(suhmo_level *L, int depth, bool also_phi, hipS
 }
 extern "C" int suhmo_level_restrict_residual(suhmo_level_t *L, int depth, suhmo_stream_t s)
 {
+    SUHMO_TIME("VCAMRNonLinearPoissonOp::restrictResidual");
     ARG(L); ARG(depth >= 0 && depth + 1 < L->ndepth);
     HIPCHK(hipSetDevice(L->device));
     return restrict_residual_impl(L, depth, false, (hipStream_t)s);
@@ -755,6 +811,7 @@ __global__ void k_prolong(DV v, double *__restrict__ phi, DV vc, const double *_
 }
 extern "C" int suhmo_level_prolong_increment(suhmo_level_t *L, int depth, suhmo_stream_t s)
 {
+    SUHMO_TIME("AMRNonLinearPoissonOp::prolongIncrement");
     ARG(L); ARG(depth >= 0 && depth + 1 < L->ndepth);
     HIPCHK(hipSetDevice(L->device));
     Depth &D = L->d[depth], &C = L->d[depth + 1];
@@ -1097,6 +1154,7 @@ __global__ __launch_bounds__(256) void k_bcoef_fused(DV v, FP fp, suhmo_phys_t p
 
 extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_stream_t s)
 {
+    SUHMO_TIME("VCAMRNonLinearPoissonOp::UpdateOperator");
     ARG(L); ARG(depth >= 0 && depth < L->ndepth);
     HIPCHK(hipSetDevice(L->device));
     hipStream_t st = (hipStream_t)s;
@@ -1147,6 +1205,15 @@ int suhmo_re_bcoef_unfused(suhmo_level *L, int depth, hipStream_t st)
     return 0;
 }
 
+// aCoeff_bCoeff (src/AmrHydro.cpp:1781-1817, called at :3087-3102): the bCoef the solver's operators are defined with, from the
+// lagged Re and gap height of the time step (RE, B with their ghosts) -- the first residual of a solve sees it
+int suhmo_bcoef_faces(suhmo_level *L, int depth, hipStream_t st)
+{
+    Depth &D = L->d[depth];
+    hipLaunchKernelGGL(k_bcoef_faces, grid2d(D.v.nx + 1, D.v.ny + 1), BLK2D, 0, st, D.v, D.fp, L->ph);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 int suhmo_re_cells(suhmo_level *L, int depth, hipStream_t st)      // COMPUTERE on the ghosted box (time step on a hierarchy)
 {
     Depth &D = L->d[depth];
@@ -1258,6 +1325,7 @@ __global__ __launch_bounds__(256) void k_average_faces_y_all(DV vf, const double
 
 extern "C" int suhmo_level_average_operator(suhmo_level_t *L, int depth, suhmo_stream_t s)
 {
+    SUHMO_TIME("VCAMRNonLinearPoissonOp::AverageOperator");
     ARG(L); ARG(depth >= 0 && depth < L->ndepth);
     if (depth == 0) return 0;
     HIPCHK(hipSetDevice(L->device));
@@ -1607,6 +1675,7 @@ int suhmo_readback(suhmo_level *L, hipStream_t st, double *out, double *out2)
 }
 extern "C" int suhmo_level_norm(suhmo_level_t *L, int depth, int field, int ord, double *out, suhmo_stream_t s)
 {
+    SUHMO_TIME("AMRNonLinearPoissonOp::norm");
     CHECK_DF(L, depth, field); ARG(out); ARG(ord == 0 || ord == 2);
     HIPCHK(hipSetDevice(L->device));
     hipStream_t st = (hipStream_t)s;

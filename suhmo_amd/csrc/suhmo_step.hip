@@ -248,6 +248,7 @@ static inline double picard_quotient(double maxd, double maxHead) { return maxd 
 int suhmo_grad_re(suhmo_level *L, int depth, hipStream_t st);      // suhmo_level.hip
 int suhmo_grad_cc(suhmo_level *L, int depth, hipStream_t st);
 int suhmo_re_cells(suhmo_level *L, int depth, hipStream_t st);
+int suhmo_bcoef_faces(suhmo_level *L, int depth, hipStream_t st);
 int suhmo_copy_ghosts(suhmo_level *L, int depth, int field, hipStream_t st);
 
 static int lagged_chain(suhmo_level *L, hipStream_t st)
@@ -400,6 +401,7 @@ static int solve_gap_implicit(suhmo_level *L, const suhmo_model_params_t *mp, do
 extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t *mp, double dt, int cur_step,
                                     int *picard_iters, int *vcycles, suhmo_stream_t s)
 {
+    SUHMO_TIME("AmrHydro::timeStepFAS");
     ARG(L && mp); ARG(dt > 0 && cur_step >= 1);
     if (mp->use_impl_diff && mp->diffFactor == 0.0) { suhmo_set_error("use_ImplDiff with diffFactor = 0"); return -1; }
     Depth &D = L->d[0];
@@ -427,6 +429,7 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
     while (!converged) {                                           // [II]
         HIPCHK(hipMemcpyAsync(D.fp.f[SUHMO_F_HLAG], D.fp.f[SUHMO_F_PHI], D.elems * sizeof(double), hipMemcpyDeviceToDevice, st));
         if ((rc = lagged_chain(L, st))) return rc;
+        if ((rc = suhmo_bcoef_faces(L, 0, st))) return rc;                          // aCoeff_bCoeff :3087-3102
         if (mp->diffFactor != 0.0 && (rc = diffusion_terms(L, mp, st))) return rc;   // lagged melt rate :2548-2551, :2982-2992
         hipLaunchKernelGGL(k_melt<0>, grd, blk, 0, st, D.v, D.fp, L->ph, *mp, dt);
         HIPCHK(hipGetLastError());
@@ -509,6 +512,7 @@ int suhmo_amr_check_hierarchy(suhmo_level_t **lv, int nlev);      // suhmo_amr.h
 extern "C" int suhmo_amr_timestep(suhmo_level_t **lv, int nlev, const suhmo_model_params_t *mp, double dt, int cur_step,
                                   int *picard_iters, int *vcycles, suhmo_stream_t s)
 {
+    SUHMO_TIME("AmrHydro::timeStepFAS");
     ARG(lv && mp && nlev >= 1 && nlev <= 8 && lv[0]); ARG(dt > 0 && cur_step >= 1);
     if (mp->use_impl_diff && mp->diffFactor == 0.0) { suhmo_set_error("use_ImplDiff with diffFactor = 0"); return -1; }
     int rc = suhmo_amr_check_hierarchy(lv, nlev); if (rc) return rc;
@@ -548,6 +552,7 @@ extern "C" int suhmo_amr_timestep(suhmo_level_t **lv, int nlev, const suhmo_mode
         for (int l = 0; l < nlev; l++) {
             if (!lv[l]) continue;
             Depth &D = lv[l]->d[0];
+            if ((rc = suhmo_bcoef_faces(lv[l], 0, st))) return rc;                      // aCoeff_bCoeff :3087-3102
             if (mp->diffFactor != 0.0 && (rc = diffusion_terms(lv[l], mp, st))) return rc;
             hipLaunchKernelGGL(k_melt<0>, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, lv[l]->ph, *mp, dt);
             HIPCHK(hipGetLastError());
@@ -739,6 +744,7 @@ int hier_picard_maxima(suhmo_hier *H, int l, bool covered, double *maxh, double 
 extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *mp, double dt, int cur_step,
                                    int *picard_iters, int *vcycles, suhmo_stream_t s)
 {
+    SUHMO_TIME("AmrHydro::timeStepFAS");
     ARG(H && mp); ARG(dt > 0 && cur_step >= 1);
     if (mp->use_impl_diff && mp->diffFactor == 0.0) { suhmo_set_error("use_ImplDiff with diffFactor = 0"); return -1; }
     const int nlev = suhmo_hier_nlev_(H);
@@ -771,6 +777,12 @@ extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *
             else { suhmo_multi m; if ((rc = suhmo_hier_multi_(H, l, st, &m)) || (rc = suhmo_multi_copy(m, SUHMO_F_HLAG, SUHMO_F_PHI, st))) return rc; }
         }
         for (int l = 0; l < nlev; l++) if ((rc = hier_chain(H, l, st))) return rc;
+        for (int l = 0; l < nlev; l++) {                                                        // aCoeff_bCoeff :3087-3102
+            LevT t;
+            if ((rc = lev_target(H, l, st, t))) return rc;
+            if (t.base) rc = suhmo_bcoef_faces(t.base, 0, st); else rc = suhmo_multi_bcoef_faces(t.m, suhmo_hier_boxes_(H, l)[0]->ph, st);
+            if (rc) return rc;
+        }
         for (int l = 0; l < nlev; l++) if ((rc = hier_melt(H, l, mp, dt, 0, mp->diffFactor != 0.0, st))) return rc;
         int it = 0;
         if ((rc = suhmo_hier_solve(H, &sp, &it, nullptr, s))) return rc;
@@ -908,6 +920,7 @@ __global__ __launch_bounds__(256) void k_moulin_src(DV v, int n, const double *_
 extern "C" int suhmo_level_moulin_source(suhmo_level_t *L, int n, const double *positions, const double *sigma,
                                          const double *flux, double time_factor, double *integrals, suhmo_stream_t s)
 {
+    SUHMO_TIME("AmrHydro::Calc_moulin_source_term_distributed");
     ARG(L && n >= 1 && positions && sigma && flux);
     HIPCHK(hipSetDevice(L->device));
     hipStream_t st = (hipStream_t)s;

@@ -440,3 +440,22 @@ def test_single_precision_literals_of_the_fortran_kernels(oracle):
         O.close(); G.close()
     assert not np.array_equal(out["f64"][0], out["f32"][0]) and not np.array_equal(out["f64"][1], out["f32"][1])
     assert np.max(np.abs(out["f64"][2] - out["f32"][2])) < 1e-5 * np.max(np.abs(out["f64"][2]))
+
+
+def test_named_timers_report_the_reference_labels():
+    """CH_TIME equivalent: with the timers on, a solve reports the reference's scope names (src/VCAMRNonLinearPoissonOp.cpp:40, 69, 103, 660)"""
+    from suhmo_amd import level, capi
+    f = sy.shmip_fields(128, 64)
+    G = level.HipLevel(128, 64, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=32)
+    G.set_inputs(f); G.build_mg_coefficients()
+    capi.lib().suhmo_timers_reset(); capi.lib().suhmo_timers_enable(2)
+    try:
+        G.solve(dict(sy.SOLVER_DEFAULT, max_iter=2)); G.gsrb(1); G.residual()
+        rep = capi.timers_report()
+    finally:
+        capi.lib().suhmo_timers_enable(0)
+    for label in ("AMRFASMultiGrid::solve", "AMRFASMultiGrid::VCycle", "VCAMRNonLinearPoissonOp::levelGSRB", "VCAMRNonLinearPoissonOp::residualI"):
+        assert label in rep, rep
+    first = rep.splitlines()[0].split()
+    assert first[0] == "AMRFASMultiGrid::solve" and int(first[1]) == 1 and float(first[2]) > 0.0
+    G.close()
