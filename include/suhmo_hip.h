@@ -351,9 +351,21 @@ int suhmo_amr_moulin_source(suhmo_level_t **levels, int nlev, const int *patch_b
  * Copier::exchange, src/VCAMRNonLinearPoissonOp.cpp:912-913), coarse-fine (suhmo_hier_cf_interp = QuadCFInterp with the
  * tangential stencil restricted to coarse cells the level does not cover, suhmo_hier_pwl_fill = PiecewiseLinearFillPatch)
  * or domain ghosts (physical BC).  The cycle is suhmo_amr_vcycle's; with one box per level the
- * results equal suhmo_amr_*'s bit for bit.  Single process (no rank strips yet). */
+ * results equal suhmo_amr_*'s bit for bit.
+ * ONE PROCESS PER GPU: `base` may describe a rank's STRIP of level 0 (j0 / ny / ny_global as for suhmo_level_create, equal
+ * strips, rank = j0 / ny; halo_rows as the strip needs them).  Level 0 -- where the cells are -- is then partitioned as a
+ * single level is (halo rows over suhmo_level_attach_rccl / suhmo_level_set_hooks on suhmo_hier_box(H, 0, 0)); the boxes of
+ * the levels >= 1 are held and relaxed by EVERY rank (the reference's load balancer spreads them; they are a few per cent
+ * of the cells of the configurations the reference ships, exec/AMR_multiMoulins/run_C_3lev).  Level 1 reads level 0 through
+ * an all-gather of exactly the coarse cells its stencils touch (suhmo_hier_attach_rccl, or suhmo_hier_set_allgather for a
+ * host transport) and writes only this rank's rows.  Results are the single-process bits. */
 typedef struct suhmo_hier suhmo_hier_t;
 int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *base, int nlev, const int *nbox, const int *boxes);
+/* all-gather of `count` doubles per rank (device buffers; recv holds world x count, rank-major), enqueued on / ordered with s */
+typedef int (*suhmo_hier_allgather_fn)(void *user, const double *send, long count, double *recv, suhmo_stream_t s);
+int suhmo_hier_set_allgather(suhmo_hier_t *H, suhmo_hier_allgather_fn fn, void *user);
+int suhmo_hier_attach_rccl(suhmo_hier_t *H);    /* after suhmo_level_attach_rccl on the base strip: ncclAllGather on its communicator */
+long suhmo_hier_gathers(const suhmo_hier_t *H); /* all-gathers issued so far */
 int suhmo_hier_destroy(suhmo_hier_t *H);
 int suhmo_hier_num_levels(const suhmo_hier_t *H);
 int suhmo_hier_num_boxes(const suhmo_hier_t *H, int level);

@@ -52,6 +52,7 @@ class LevelDesc(C.Structure):
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p)
 
 # every symbol include/suhmo_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -74,7 +75,8 @@ SYMBOLS = [
     "suhmo_level_set_alpha_beta", "suhmo_level_set_bc", "suhmo_amr2_reflux", "suhmo_amr2_pwl_fill", "suhmo_amr_timestep", "suhmo_level_time_varying_recharge", "suhmo_amr_moulin_source", "suhmo_amr2_prolong_pc", "suhmo_amr2_finer_operator_changed",
     "suhmo_hier_create", "suhmo_hier_destroy", "suhmo_hier_num_levels", "suhmo_hier_num_boxes", "suhmo_hier_box", "suhmo_hier_exchange",
     "suhmo_hier_cf_interp", "suhmo_hier_pwl_fill", "suhmo_hier_average", "suhmo_hier_gsrb", "suhmo_hier_update_operator",
-    "suhmo_hier_residual", "suhmo_hier_vcycle", "suhmo_hier_solve", "suhmo_hier_timestep", "suhmo_hier_moulin_source", "suhmo_level_set_option", "suhmo_level_get_option", "suhmo_timers_enable", "suhmo_timers_reset", "suhmo_timers_report",
+    "suhmo_hier_residual", "suhmo_hier_vcycle", "suhmo_hier_solve", "suhmo_hier_timestep", "suhmo_hier_moulin_source",
+    "suhmo_hier_set_allgather", "suhmo_hier_attach_rccl", "suhmo_hier_gathers", "suhmo_level_set_option", "suhmo_level_get_option", "suhmo_timers_enable", "suhmo_timers_reset", "suhmo_timers_report",
 ]
 
 
@@ -174,6 +176,10 @@ def lib():
     L.suhmo_hier_solve.argtypes = [vp, C.POINTER(SolverParams), ip, dp, vp]
     L.suhmo_hier_timestep.argtypes = [vp, C.POINTER(ModelParams), C.c_double, ci, ip, ip, vp]
     L.suhmo_hier_moulin_source.argtypes = [vp, ci, dp, dp, dp, C.c_double, dp, vp]
+    L.suhmo_hier_set_allgather.argtypes = [vp, ALLGATHER_FN, vp]
+    L.suhmo_hier_attach_rccl.argtypes = [vp]
+    L.suhmo_hier_gathers.argtypes = [vp]
+    L.suhmo_hier_gathers.restype = C.c_long
     L.suhmo_timers_enable.argtypes = [ci]
     L.suhmo_timers_report.argtypes = [C.c_char_p, C.c_long]
     L.suhmo_timers_report.restype = C.c_long

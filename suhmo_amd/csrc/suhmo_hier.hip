@@ -123,6 +123,22 @@ struct suhmo_hier {
     suhmo_bc_t bc;
     suhmo_level_desc_t base_desc;
     suhmo_hier *gap = nullptr; double gap_dt = 0.0;        // implicit gap-height operator of the time step, owned
+    // ---- level 0 cut into rank strips (one process per GPU): a rank holds its own rows of level 0 and ALL boxes of the finer
+    // levels.  What level 1 reads of level 0 (coarse-fine stencils, linear fill, correction windows, reflux) comes from a
+    // SHADOW: canvases with the geometry of the whole level 0, kept current only at the cells the plans read (`need`, sorted
+    // by row, so the cells a rank owns are one segment); one all-gather refreshes a field (or several) before a plan runs.
+    // What level 1 writes into level 0 (averages, reflux) is clipped to the rank's own rows when the plans are built.
+    int rank = 0, world = 1;
+    DV vglob;                                              // level 0 as one canvas (= the base view when it is not cut)
+    FP shadow{};
+    size_t shadow_elems = 0;
+    DevVec<int> need; DevVec<int2> need_rl;                // offsets in vglob; (owner rank, position in the owner's segment)
+    std::vector<int> seg;                                  // need[seg[r] .. seg[r+1]) are rows of rank r
+    long cnt_max = 0;                                      // longest segment: every rank contributes cnt_max doubles per field
+    double *xs = nullptr, *xr = nullptr; size_t xcap = 0;  // staging of the all-gather
+    suhmo_hier_allgather_fn ag = nullptr; void *ag_user = nullptr;
+    long gathers = 0;
+    DevVec<RectEnt> cover_full;                            // coarsen(boxes of level 1) in the shadow: COVER of the whole level 0
 };
 
 namespace {
@@ -145,10 +161,12 @@ inline Ref cell_ref(const suhmo_hier *H, const HLev &V, int i, int j)
     if (!wrap_cell(H, V, i, j)) return r;
     int o = V.l == 0 ? 0 : V.index.find(i, j);
     if (o < 0) return r;
-    const DV &v = V.box[o]->d[0].v;
+    const DV &v = V.l == 0 ? H->vglob : V.box[o]->d[0].v;
     r.b = o; r.off = cidx(v, i - v.i0, j - v.j0);
     return r;
 }
+inline bool dist_base(const suhmo_hier *H) { return H->world > 1; }
+inline suhmo_level *base_of(suhmo_hier *H) { return H->lev[0].box[0]; }
 inline Ref local_ref(const HLev &V, int k, int il, int jl) { return Ref{k, cidx(V.box[k]->d[0].v, il, jl)}; }
 
 // ------------------------------------------------------------------ kernels over the plans
@@ -290,12 +308,12 @@ __global__ void k_prolong2_win(const Win *__restrict__ wins, const double *__res
 }
 // [Chombo] LevelFluxRegister (oracle/amrm.c:reflux): one thread per coarse cell next to coarse-fine faces
 __global__ void k_reflux(const Target *__restrict__ tg, int n, const Face *__restrict__ faces, const FP *__restrict__ ftab, const DV *__restrict__ fdv,
-                         const FP *__restrict__ ctab, FP cbase, int use_base, int field_c, double dxc, double dyc, double beta)
+                         const FP *__restrict__ ctab, FP cbase, FP cdst, int use_base, int field_c, double dxc, double dyc, double beta)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     Target T = tg[t];
-    double *lof = fptr(ctab, cbase, use_base, T.t.b, field_c);
+    double *lof = fptr(ctab, cdst, use_base, T.t.b, field_c);          // cdst: the level itself; cbase: where its cells are read (the shadow of a cut level 0)
     const double rscale = 1.0 / (dxc * dyc);
     double acc = lof[T.t.off];
     for (int m = 0; m < T.count; m++) {
@@ -332,6 +350,13 @@ int build_plans(suhmo_hier *H, int l)
     std::vector<WinEnt> wing; std::vector<int> wing_box;
     F.win.resize(nb);
     size_t wtot = 0;
+    // level 0 cut into rank strips: its cells are read through the shadow (offsets in H->vglob, collected in `needv`) and
+    // written in the rank's own rows only
+    const bool cut = C.l == 0 && dist_base(H);
+    const DV sv = C.l == 0 ? base_of(H)->d[0].v : DV{};
+    std::vector<int> needv;
+    std::vector<RectEnt> cover_full;
+    auto note = [&](const Ref &r) { if (cut && r.b >= 0) needv.push_back(r.off); };
     auto good_cell = [&](int I, int J) -> bool {          // coarse cell (I,J) of level l-1 good for tangential stencils?
         if (!wrap_cell(H, C, I, J)) return false;
         return F.index.find(2 * I, 2 * J) < 0;
@@ -368,6 +393,7 @@ int build_plans(suhmo_hier *H, int l)
                                 if (r.b < 0) { suhmo_set_error("hier: level %d is not properly nested in level %d (linear fill stencil)", l, l - 1); return -1; }
                             }
                             p.c[(jj + 1) * 3 + (ii + 1)] = r;
+                            note(r);
                         }
                     p.sx = (I - 1 >= 0 && I + 1 <= C.nxd - 1) ? 0 : (I - 1 < 0 ? 1 : 2);
                     p.sy = (J - 1 >= 0 && J + 1 <= C.nyd - 1) ? 0 : (J - 1 < 0 ? 1 : 2);
@@ -391,6 +417,7 @@ int build_plans(suhmo_hier *H, int l)
                 for (int m = 0; m < 3; m++) {
                     e.c[m] = m < nneed ? cref(need[m]) : Ref{0, 0};
                     if (m < nneed && e.c[m].b < 0) { suhmo_set_error("hier: level %d is not properly nested in level %d (coarse-fine stencil)", l, l - 1); return -1; }
+                    if (m < nneed) note(e.c[m]);
                 }
                 cf.push_back(e);
             }
@@ -417,6 +444,11 @@ int build_plans(suhmo_hier *H, int l)
             return 0;
         };
         int rc = split(ci0, cj0, ci1, cj1, [&](int o, int a0, int c0, int a1, int c1) {
+            if (cut) {                                                  // the rows of this rank's strip
+                cover_full.push_back(RectEnt{k, 0, 0, cidx(H->vglob, a0, c0), a1 - a0 + 1, c1 - c0 + 1});
+                c0 = std::max(c0, sv.j0); c1 = std::min(c1, sv.j0 + sv.ny - 1);
+                if (c0 > c1) return;
+            }
             const DV &vc = C.box[o]->d[0].v;
             avg.push_back(RectEnt{k, o, cidx(v, 2 * a0 - b[0], 2 * c0 - b[1]), cidx(vc, a0 - vc.i0, c0 - vc.j0), a1 - a0 + 1, c1 - c0 + 1});
         });
@@ -433,7 +465,8 @@ int build_plans(suhmo_hier *H, int l)
                 int J0 = std::max(w.j0, sy * C.nyd), J1 = std::min(w.j0 + w.ny - 1, sy * C.nyd + C.nyd - 1);
                 if (I0 > I1 || J0 > J1) continue;
                 rc = split(I0 - sx * C.nxd, J0 - sy * C.nyd, I1 - sx * C.nxd, J1 - sy * C.nyd, [&](int o, int a0, int c0, int a1, int c1) {
-                    const DV &vc = C.box[o]->d[0].v;
+                    const DV &vc = C.l == 0 ? H->vglob : C.box[o]->d[0].v;
+                    if (cut) for (int J = c0; J <= c1; J++) for (int I = a0; I <= a1; I++) needv.push_back(cidx(vc, I, J));
                     wing.push_back(WinEnt{o, cidx(vc, a0 - vc.i0, c0 - vc.j0), (c0 + sy * C.nyd - w.j0) * w.nx + (a0 + sx * C.nxd - w.i0), a1 - a0 + 1, c1 - c0 + 1});
                     wing_box.push_back(k);
                 });
@@ -463,6 +496,7 @@ int build_plans(suhmo_hier *H, int l)
                     f.hi = dir == 0 ? cell_ref(H, C, Fc, T) : cell_ref(H, C, T, Fc);
                     f.lo = dir == 0 ? cell_ref(H, C, Fc - 1, T) : cell_ref(H, C, T, Fc - 1);
                     if (f.hi.b < 0 || f.lo.b < 0) { suhmo_set_error("hier: level %d is not properly nested in level %d (reflux)", l, l - 1); return -1; }
+                    note(f.hi); note(f.lo);
                     f.bq = f.hi;                                                       // the face is the low face of its high-side cell
                     Ref t = side == 0 ? f.lo : f.hi;
                     auto key = std::make_pair(t.b, t.off);
@@ -475,8 +509,30 @@ int build_plans(suhmo_hier *H, int l)
     std::vector<Target> targets; std::vector<Face> faces;
     for (auto &key : order) {
         auto &fv = by_target[key];
-        targets.push_back(Target{Ref{key.first, key.second}, (int)faces.size(), (int)fv.size()});
+        Ref t{key.first, key.second};
+        if (cut) {                                                      // a cell of the shadow -> the same cell of this rank's strip, or none
+            const int J = t.off / H->vglob.P - H->vglob.gy, I = t.off % H->vglob.P - SUHMO_XOFF;
+            if (J < sv.j0 || J >= sv.j0 + sv.ny) continue;
+            t.off = cidx(sv, I, J - sv.j0);
+        }
+        targets.push_back(Target{t, (int)faces.size(), (int)fv.size()});
         faces.insert(faces.end(), fv.begin(), fv.end());
+    }
+    if (cut) {
+        std::sort(needv.begin(), needv.end());
+        needv.erase(std::unique(needv.begin(), needv.end()), needv.end());
+        const int N = (int)needv.size();
+        std::vector<int2> rl(N);
+        H->seg.assign(H->world + 1, 0);
+        for (int t = 0; t < N; t++) {
+            const int J = needv[t] / H->vglob.P - H->vglob.gy;
+            const int r = J / sv.ny;
+            H->seg[r + 1]++;
+            rl[t].x = r;
+        }
+        for (int r = 0; r < H->world; r++) { H->cnt_max = std::max<long>(H->cnt_max, H->seg[r + 1]); H->seg[r + 1] += H->seg[r]; }
+        for (int t = 0; t < N; t++) rl[t].y = t - H->seg[rl[t].x];
+        if (H->need.upload(needv) || H->need_rl.upload(rl) || H->cover_full.upload(cover_full)) { suhmo_set_error("hier: plan upload failed"); return -2; }
     }
     int rc = 0;
     rc |= F.ff_side.upload(ffs); rc |= F.ff_corner.upload(ffc); rc |= F.cf.upload(cf); rc |= F.pwl.upload(pwl);
@@ -499,7 +555,6 @@ int build_plans(suhmo_hier *H, int l)
 // ------------------------------------------------------------------ tables, launches of the plans
 namespace {
 #define HST(s) ((hipStream_t)(s))
-inline suhmo_level *base_of(suhmo_hier *H) { return H->lev[0].box[0]; }
 inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 // device table of the boxes' field pointers (levels >= 1).  The boxes relax in place, so a pointer changes only when a
@@ -532,12 +587,79 @@ int ensure_field(suhmo_hier *H, int l, int field)
     for (suhmo_level *L : H->lev[l].box) if (!suhmo_field(L, 0, field)) { suhmo_set_error("field allocation failed"); return -2; }
     return 0;
 }
-// coarse-side arguments of a kernel that reads / writes level l-1
-struct CoarseArgs { const FP *tab; const DV *dv; FP base; DV bdv; int use_base; };
+// ---- shadow of a level 0 cut into rank strips
+constexpr int XF = 4;                                    // fields per all-gather
+struct FList { const double *src[XF]; double *dst[XF]; int n; };
+__global__ void k_need_pack(const int *__restrict__ need, int first, int n, int shift, FList fl, double *__restrict__ buf, long stride)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int off = need[first + t] - shift;             // the cell in this rank's strip canvas (same pitch, same ghost rows)
+    for (int f = 0; f < fl.n; f++) buf[f * stride + t] = fl.src[f][off];
+}
+__global__ void k_need_unpack(const int *__restrict__ need, const int2 *__restrict__ rl, int n, FList fl, const double *__restrict__ buf, long stride)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int2 q = rl[t];
+    const int off = need[t];
+    for (int f = 0; f < fl.n; f++) fl.dst[f][off] = buf[((long)q.x * fl.n + f) * stride + q.y];
+}
+double *shadow_field(suhmo_hier *H, int field)
+{
+    if (!H->shadow.f[field]) {
+        double *p = nullptr;
+        if (hipMalloc(&p, H->shadow_elems * sizeof(double)) != hipSuccess) return nullptr;
+        (void)hipMemset(p, 0, H->shadow_elems * sizeof(double));
+        H->shadow.f[field] = p;
+    }
+    return H->shadow.f[field];
+}
+// the shadow's copies of `fields` of level 0 <- the owners' current values (collective over the ranks of level 0)
+int refresh_base(suhmo_hier *H, const int *fields, int nf, hipStream_t st)
+{
+    if (!dist_base(H) || H->nlev < 2) return 0;
+    SUHMO_TIME("hier: all-gather of the coarse cells level 1 reads");
+    if (!H->ag) { suhmo_set_error("hier: level 0 is a rank strip and no all-gather is attached (suhmo_hier_attach_rccl / suhmo_hier_set_allgather)"); return -1; }
+    ARG(nf >= 1 && nf <= XF);
+    suhmo_level *B = base_of(H);
+    FList fl;
+    fl.n = nf;
+    for (int f = 0; f < nf; f++) {
+        fl.src[f] = suhmo_field(B, 0, fields[f]); fl.dst[f] = shadow_field(H, fields[f]);
+        if (!fl.src[f] || !fl.dst[f]) { suhmo_set_error("field allocation failed"); return -2; }
+    }
+    const long stride = H->cnt_max, count = stride * nf;
+    const size_t cap = (size_t)stride * XF;
+    if (!H->xs) {
+        HIPCHK(hipMalloc(&H->xs, std::max<size_t>(1, cap) * sizeof(double)));
+        HIPCHK(hipMalloc(&H->xr, std::max<size_t>(1, cap * H->world) * sizeof(double)));
+        HIPCHK(hipMemset(H->xs, 0, std::max<size_t>(1, cap) * sizeof(double)));
+    }
+    const int first = H->seg[H->rank], mine = H->seg[H->rank + 1] - first;
+    const DV &sv = B->d[0].v;
+    if (mine) hipLaunchKernelGGL(k_need_pack, g1(mine), dim3(256), 0, st, H->need.d, first, mine, sv.j0 * sv.P, fl, H->xs, stride);
+    HIPCHK(hipGetLastError());
+    int rc = H->ag(H->ag_user, H->xs, count, H->xr, (suhmo_stream_t)st);
+    if (rc) return rc;
+    H->gathers++;
+    if (H->need.n) hipLaunchKernelGGL(k_need_unpack, g1(H->need.n), dim3(256), 0, st, H->need.d, H->need_rl.d, (int)H->need.n, fl, H->xr, stride);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+inline int refresh_base1(suhmo_hier *H, int field, hipStream_t st) { return refresh_base(H, &field, 1, st); }
+
+// coarse-side arguments of a kernel that reads / writes level l-1.  base / bdv: where the cells of level 0 are READ (the shadow
+// of a cut level 0); dst / ddv: where they are written (the level, or this rank's strip of it)
+struct CoarseArgs { const FP *tab; const DV *dv; FP base; DV bdv; FP dst; DV ddv; int use_base; };
 int coarse_args(suhmo_hier *H, int lc, hipStream_t st, CoarseArgs &a)
 {
     memset(&a, 0, sizeof(a));
-    if (lc == 0) { a.base = base_of(H)->d[0].fp; a.bdv = base_of(H)->d[0].v; a.use_base = 1; return 0; }
+    if (lc == 0) {
+        a.dst = base_of(H)->d[0].fp; a.ddv = base_of(H)->d[0].v; a.use_base = 1;
+        if (dist_base(H)) { a.base = H->shadow; a.bdv = H->vglob; } else { a.base = a.dst; a.bdv = a.ddv; }
+        return 0;
+    }
     int rc = refresh_tables(H, lc, st); if (rc) return rc;
     a.tab = H->lev[lc].d_fp; a.dv = H->lev[lc].d_dv; a.bdv = H->lev[lc].box[0]->d[0].v;
     return 0;
@@ -574,7 +696,9 @@ int hier_cf(suhmo_hier *H, int l, int ff, int fc, hipStream_t st)
     HLev &V = H->lev[l];
     int rc;
     CoarseArgs ca;
-    if ((rc = ensure_field(H, l, ff)) || (rc = ensure_field(H, l - 1, fc)) || (rc = refresh_tables(H, l, st)) || (rc = coarse_args(H, l - 1, st, ca))) return rc;
+    if ((rc = ensure_field(H, l, ff)) || (rc = ensure_field(H, l - 1, fc)) || (rc = refresh_tables(H, l, st))) return rc;
+    if (l == 1 && (rc = refresh_base1(H, fc, st))) return rc;
+    if ((rc = coarse_args(H, l - 1, st, ca))) return rc;
     if (V.cf.n) hipLaunchKernelGGL(k_cf, g1(V.cf.n), dim3(256), 0, st, V.cf.d, (int)V.cf.n, V.d_fp, ff, ca.tab, ca.base, ca.use_base, fc);
     HIPCHK(hipGetLastError());
     return 0;
@@ -585,7 +709,9 @@ int hier_pwl(suhmo_hier *H, int l, int ff, int fc, hipStream_t st)
     HLev &V = H->lev[l];
     int rc;
     CoarseArgs ca;
-    if ((rc = ensure_field(H, l, ff)) || (rc = ensure_field(H, l - 1, fc)) || (rc = refresh_tables(H, l, st)) || (rc = coarse_args(H, l - 1, st, ca))) return rc;
+    if ((rc = ensure_field(H, l, ff)) || (rc = ensure_field(H, l - 1, fc)) || (rc = refresh_tables(H, l, st))) return rc;
+    if (l == 1 && (rc = refresh_base1(H, fc, st))) return rc;
+    if ((rc = coarse_args(H, l - 1, st, ca))) return rc;
     if (V.pwl.n) hipLaunchKernelGGL(k_pwl, g1(V.pwl.n), dim3(256), 0, st, V.pwl.d, (int)V.pwl.n, V.d_fp, ff, ca.tab, ca.base, ca.use_base, fc);
     HIPCHK(hipGetLastError());
     return 0;
@@ -600,7 +726,7 @@ int hier_avg(suhmo_hier *H, int l, int ff, int fc, int mode, double val, hipStre
     if (fc == SUHMO_F_PHI) for (suhmo_level *L : H->lev[l - 1].box) L->d[0].phi_fresh = 0;
     if (V.avg.n) {
         dim3 grd((V.avg_w + 63) / 64, (V.avg_h + 3) / 4, (unsigned)V.avg.n);
-        hipLaunchKernelGGL(k_avg, grd, dim3(64, 4), 0, st, V.avg.d, V.d_fp, V.d_dv, ff, ca.tab, ca.dv, ca.base, ca.bdv, ca.use_base, fc, mode, val);
+        hipLaunchKernelGGL(k_avg, grd, dim3(64, 4), 0, st, V.avg.d, V.d_fp, V.d_dv, ff, ca.tab, ca.dv, ca.dst, ca.ddv, ca.use_base, fc, mode, val);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -612,7 +738,9 @@ int hier_prolong2(suhmo_hier *H, int l, int field_c, hipStream_t st)
     HLev &V = H->lev[l];
     int rc;
     CoarseArgs ca;
-    if ((rc = ensure_field(H, l - 1, field_c)) || (rc = refresh_tables(H, l, st)) || (rc = coarse_args(H, l - 1, st, ca))) return rc;
+    if ((rc = ensure_field(H, l - 1, field_c)) || (rc = refresh_tables(H, l, st))) return rc;
+    if (l == 1 && (rc = refresh_base1(H, field_c, st))) return rc;
+    if ((rc = coarse_args(H, l - 1, st, ca))) return rc;
     if (V.wing.n) {
         dim3 grd((V.wing_w + 63) / 64, (V.wing_h + 3) / 4, (unsigned)V.wing.n);
         hipLaunchKernelGGL(k_win_gather, grd, dim3(64, 4), 0, st, V.wing.d, V.winbuf, ca.tab, ca.dv, ca.base, ca.bdv, ca.use_base, field_c, V.d_win, V.d_wing_box);
@@ -634,10 +762,12 @@ int hier_reflux(suhmo_hier *H, int l, int field_c, hipStream_t st)
     HLev &V = H->lev[l];
     int rc;
     CoarseArgs ca;
-    if ((rc = ensure_field(H, l - 1, field_c)) || (rc = refresh_tables(H, l, st)) || (rc = coarse_args(H, l - 1, st, ca))) return rc;
+    if ((rc = ensure_field(H, l - 1, field_c)) || (rc = refresh_tables(H, l, st))) return rc;
+    if (l == 1) { const int fl[3] = {SUHMO_F_PHI, SUHMO_F_BX, SUHMO_F_BY}; if ((rc = refresh_base(H, fl, 3, st))) return rc; }
+    if ((rc = coarse_args(H, l - 1, st, ca))) return rc;
     const DV &vc = H->lev[l - 1].box[0]->d[0].v;
     if (V.targets.n)
-        hipLaunchKernelGGL(k_reflux, g1(V.targets.n), dim3(256), 0, st, V.targets.d, (int)V.targets.n, V.faces.d, V.d_fp, V.d_dv, ca.tab, ca.base,
+        hipLaunchKernelGGL(k_reflux, g1(V.targets.n), dim3(256), 0, st, V.targets.d, (int)V.targets.n, V.faces.d, V.d_fp, V.d_dv, ca.tab, ca.base, ca.dst,
                            ca.use_base, field_c, vc.dx, vc.dy, vc.beta);
     HIPCHK(hipGetLastError());
     return 0;
@@ -755,6 +885,7 @@ int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stre
     if ((rc = hier_avg(H, l, SUHMO_F_RES, SUHMO_F_RES, 0, 0.0, HST(s)))) return rc;
     if ((rc = hier_copy(H, l - 1, SUHMO_F_RHS0, SUHMO_F_RHS, s))) return rc;
     if ((rc = hier_axby(H, l - 1, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
+    if (l == 1 && dist_base(H) && (rc = suhmo_level_exchange(base_of(H), 0, SUHMO_F_RHS, s))) return rc;      // rank strips: rhs halo rows (relaxed redundantly)
     if ((rc = hier_copy(H, l - 1, SUHMO_F_PHIOLD, SUHMO_F_PHI, s))) return rc;
     if ((rc = vcycle_amr(H, l - 1, sp, s))) return rc;
     if ((rc = hier_copy(H, l - 1, SUHMO_F_RHS, SUHMO_F_RHS0, s))) return rc;
@@ -773,6 +904,10 @@ extern "C" int suhmo_hier_destroy(suhmo_hier_t *H)
     (void)hipSetDevice(H->device);
     (void)hipDeviceSynchronize();
     if (H->gap) { (void)suhmo_hier_destroy(H->gap); H->gap = nullptr; }
+    for (int f = 0; f < SUHMO_F_COUNT; f++) if (H->shadow.f[f]) (void)hipFree(H->shadow.f[f]);
+    H->need.release(); H->need_rl.release(); H->cover_full.release();
+    if (H->xs) (void)hipFree(H->xs);
+    if (H->xr) (void)hipFree(H->xr);
     for (int l = 0; l < 8; l++) {
         HLev &V = H->lev[l];
         for (suhmo_level *L : V.box) (void)suhmo_level_destroy(L);
@@ -793,13 +928,23 @@ extern "C" int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *b
 {
     ARG(out && base && nlev >= 1 && nlev <= 8);
     ARG(nlev == 1 || (nbox && boxes));
-    ARG(base->j0 == 0 && base->ny == base->ny_global && base->i0 == 0 && (base->nx_global == 0 || base->nx_global == base->nx));
+    ARG(base->i0 == 0 && (base->nx_global == 0 || base->nx_global == base->nx));
+    const bool cut = !(base->j0 == 0 && base->ny == base->ny_global);
+    if (cut && (base->ny_global % base->ny || base->j0 % base->ny)) { suhmo_set_error("hier: level 0 must be cut into EQUAL rank strips"); return -1; }
     suhmo_hier *H = new suhmo_hier();
+    if (cut) { H->world = base->ny_global / base->ny; H->rank = base->j0 / base->ny; }
     H->nlev = nlev; H->device = base->device; H->bc = base->bc; H->base_desc = *base; H->base_desc.boxes = nullptr; H->base_desc.nbox = 0;
     suhmo_level *B = nullptr;
     int rc = suhmo_level_create(&B, base);
     if (rc) { delete H; return rc; }
-    H->lev[0].l = 0; H->lev[0].nxd = base->nx; H->lev[0].nyd = base->ny; H->lev[0].box.push_back(B);
+    H->lev[0].l = 0; H->lev[0].nxd = base->nx; H->lev[0].nyd = base->ny_global; H->lev[0].box.push_back(B);
+    H->vglob = B->d[0].v;
+    if (cut) {
+        DV &g = H->vglob;
+        g.ny = g.nyg; g.j0 = 0; g.rows = g.ny + 2 * g.gy;
+        g.ext[0] = g.ext[1] = g.rk[0] = g.rk[1] = 0;
+        H->shadow_elems = (size_t)g.P * (size_t)(g.rows + 1);
+    }
     const int *q = boxes;
     for (int l = 1; l < nlev; l++) {
         HLev &V = H->lev[l];
@@ -867,6 +1012,20 @@ extern "C" int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *b
     // SUHMO_F_COVER: 1 under a finer level, 0 elsewhere
     for (int l = 0; l < nlev; l++) for (suhmo_level *L : H->lev[l].box) if ((rc = suhmo_level_set_value(L, 0, SUHMO_F_COVER, 0.0, nullptr))) { suhmo_hier_destroy(H); return rc; }
     for (int l = 1; l < nlev; l++) if ((rc = hier_avg(H, l, SUHMO_F_COVER, SUHMO_F_COVER, 1, 1.0, nullptr))) { suhmo_hier_destroy(H); return rc; }
+    if (cut && nlev > 1) {                                  // COVER of the whole level 0 (geometry only): the moulin integrals run over all of it
+        if (!shadow_field(H, SUHMO_F_COVER)) { suhmo_set_error("field allocation failed"); suhmo_hier_destroy(H); return -2; }
+        HLev &V = H->lev[1];
+        if (H->cover_full.n) {
+            int w = 0, h = 0;
+            std::vector<RectEnt> tmp(H->cover_full.n);
+            HIPCHK(hipMemcpy(tmp.data(), H->cover_full.d, tmp.size() * sizeof(RectEnt), hipMemcpyDeviceToHost));
+            for (auto &e : tmp) { w = std::max(w, e.w); h = std::max(h, e.h); }
+            dim3 grd((w + 63) / 64, (h + 3) / 4, (unsigned)H->cover_full.n);
+            hipLaunchKernelGGL(k_avg, grd, dim3(64, 4), 0, nullptr, H->cover_full.d, V.d_fp, V.d_dv, (int)SUHMO_F_COVER, (const FP *)nullptr, (const DV *)nullptr,
+                               H->shadow, H->vglob, 1, (int)SUHMO_F_COVER, 1, 1.0);
+            HIPCHK(hipGetLastError());
+        }
+    }
     HIPCHK(hipDeviceSynchronize());
     *out = H;
     return 0;
@@ -881,6 +1040,12 @@ int suhmo_hier_pwl_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st) { retu
 int suhmo_hier_avg_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st) { return hier_avg(H, l, ff, fc, 0, 0.0, st); }
 int suhmo_hier_multi_(suhmo_hier *H, int l, hipStream_t st, suhmo_multi *m) { return multi_of(H, l, st, *m); }
 int suhmo_hier_ensure_(suhmo_hier *H, int l, int field) { return ensure_field(H, l, field); }
+const double *suhmo_hier_base_cover_(suhmo_hier *H, DV *whole)
+{
+    if (!dist_base(H)) return nullptr;
+    *whole = H->vglob;
+    return H->shadow.f[SUHMO_F_COVER];
+}
 int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, suhmo_hier **gap)
 {
     if (!H->gap || H->gap_dt != dt) {
@@ -894,6 +1059,8 @@ int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, su
         for (int l = 1; l < H->nlev; l++) { nbox[l] = (int)H->lev[l].box.size(); flat.insert(flat.end(), H->lev[l].b4.begin(), H->lev[l].b4.end()); }
         int rc = suhmo_hier_create(&H->gap, &d, H->nlev, nbox.data(), flat.data()); if (rc) return rc;
         H->gap_dt = dt;
+        H->gap->ag = H->ag; H->gap->ag_user = H->ag_user;                                  // same strips, same ranks
+        { suhmo_level *G0 = H->gap->lev[0].box[0]; G0->ex = B->ex; G0->ar = B->ar; G0->user = B->user; G0->ex_begin = B->ex_begin; G0->ex_end = B->ex_end; }
         for (int l = 0; l < H->nlev; l++)
             for (suhmo_level *L : H->gap->lev[l].box) if ((rc = suhmo_level_set_value(L, 0, SUHMO_F_ACOEF, 1.0, nullptr))) return rc;   // aCoeff_GH :1820-1828
     }
@@ -901,6 +1068,22 @@ int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, su
     return 0;
 }
 
+extern "C" int suhmo_hier_set_allgather(suhmo_hier_t *H, suhmo_hier_allgather_fn fn, void *user)
+{
+    ARG(H);
+    H->ag = fn; H->ag_user = user;
+    if (H->gap) { H->gap->ag = fn; H->gap->ag_user = user; }
+    return 0;
+}
+int suhmo_rccl_allgather_hook(void *user, const double *send, long count, double *recv, suhmo_stream_t s);   // suhmo_rccl.hip; user = the level's Strip
+extern "C" int suhmo_hier_attach_rccl(suhmo_hier_t *H)
+{
+    ARG(H);
+    suhmo_level *B = base_of(H);
+    if (!B->rccl) { suhmo_set_error("hier: attach the base strip first (suhmo_level_attach_rccl on suhmo_hier_box(H, 0, 0))"); return -1; }
+    return suhmo_hier_set_allgather(H, suhmo_rccl_allgather_hook, B->rccl);
+}
+extern "C" long suhmo_hier_gathers(const suhmo_hier_t *H) { return H ? H->gathers + (H->gap ? H->gap->gathers : 0) : -1; }
 extern "C" int suhmo_hier_num_levels(const suhmo_hier_t *H) { return H ? H->nlev : -1; }
 extern "C" int suhmo_hier_num_boxes(const suhmo_hier_t *H, int l) { return (H && l >= 0 && l < H->nlev) ? (int)H->lev[l].box.size() : -1; }
 extern "C" suhmo_level_t *suhmo_hier_box(suhmo_hier_t *H, int l, int k)

@@ -25,6 +25,7 @@ struct Fns {
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 } g;
 
@@ -206,6 +207,15 @@ int allreduce_hook(void *user, double *value)
 }
 }  // namespace
 
+// all-gather of the coarse cells a hierarchy's level 1 reads of a level 0 cut into strips (suhmo_hier.hip), on the kernels' stream
+int suhmo_rccl_allgather_hook(void *user, const double *send, long count, double *recv, suhmo_stream_t s)
+{
+    Strip *S = (Strip *)user;
+    NCCLCHK(g.AllGather(send, recv, (size_t)count, ncclFloat64, S->comm, (hipStream_t)s));
+    S->exchanges++;
+    return 0;
+}
+
 // RCCL must sit on the SAME HIP runtime instance as this library (streams and buffers cross the call): a
 // process can hold two (ROCm's and the copy PyTorch ships, whichever was mapped first serves us).  With no
 // explicit path, take the librccl that lives next to the libamdhip64 this library is bound to.
@@ -238,7 +248,7 @@ extern "C" int suhmo_rccl_load(const char *path)
     if (!g.field) { suhmo_set_error("librccl lacks %s", name); return -7; } } while (0)
     SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
     SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
-    SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
+    SYM(AllReduce, "ncclAllReduce"); SYM(AllGather, "ncclAllGather"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     g.dl = dl;
     return 0;

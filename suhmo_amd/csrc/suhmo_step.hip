@@ -689,7 +689,7 @@ int hier_gap_ghosts(suhmo_hier *H, int l, hipStream_t st)
     if ((rc = lev_target(H, l, st, t))) return rc;
     if ((rc = suhmo_hier_pwl_(H, l, SUHMO_F_B, SUHMO_F_B, st))) return rc;
     if ((rc = suhmo_hier_ff_(H, l, SUHMO_F_B, -1, true, st))) return rc;
-    if (t.base) return suhmo_copy_ghosts(t.base, 0, SUHMO_F_B, st);
+    if (t.base) { if ((rc = suhmo_copy_ghosts(t.base, 0, SUHMO_F_B, st))) return rc; return exchange1(t.base, SUHMO_F_B, st); }   // rank strips: halo rows
     return suhmo_multi_coef_ghosts(t.m, SUHMO_F_B, st);
 }
 // lagged diffusion terms (diffusion_terms of one level) and RHS_h / the gap-height right-hand side of a whole level
@@ -730,7 +730,12 @@ int hier_picard_maxima(suhmo_hier *H, int l, bool covered, double *maxh, double 
     suhmo_level *slot = suhmo_hier_boxes_(H, 0)[0];
     if (t.base) {
         suhmo_level *L = t.base;
-        return picard_maxima(L, L->d[0].fp.f[SUHMO_F_PHI], L->d[0].fp.f[SUHMO_F_HLAG], maxh, maxd, st, Excl{0, 0, 0, 0}, covered ? L->d[0].fp.f[SUHMO_F_COVER] : nullptr);
+        if ((rc = picard_maxima(L, L->d[0].fp.f[SUHMO_F_PHI], L->d[0].fp.f[SUHMO_F_HLAG], maxh, maxd, st, Excl{0, 0, 0, 0}, covered ? L->d[0].fp.f[SUHMO_F_COVER] : nullptr))) return rc;
+        if (L->ar && (L->d[0].v.rk[0] || L->d[0].v.rk[1])) {                     // computeMax over the ranks of level 0
+            if ((rc = L->ar(L->user, maxh))) return rc;
+            if ((rc = L->ar(L->user, maxd))) return rc;
+        }
+        return 0;
     }
     const suhmo_multi &m = t.m;
     dim3 grd(std::min((m.maxnx + 63) / 64, 4), std::min((m.maxny + 3) / 4, 8), m.nbox);       // 2 values per block: 64 nbox doubles
@@ -758,6 +763,7 @@ extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *
             if (!L->d[0].fp.f[SUHMO_F_MSRC]) { suhmo_set_error("use_moulin_source without a moulin source term (suhmo_hier_moulin_source)"); return -1; }
     }
     suhmo_level *base = suhmo_hier_boxes_(H, 0)[0];
+    if ((base->d[0].v.rk[0] || base->d[0].v.rk[1]) && !(base->ex && base->ar)) { suhmo_set_error("time step on rank strips needs the exchange hooks on level 0"); return -1; }
     // [I]
     for (int l = 0; l < nlev; l++) if ((rc = hier_gap_ghosts(H, l, st))) return rc;
     if ((rc = suhmo_build_mg_coefficients(base, false, st))) return rc;         // bCoef: re-averaged by every V-cycle (bcoeff_otf)
@@ -770,6 +776,7 @@ extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *
     while (!converged) {
         for (int l = 0; l < nlev; l++) {
             if ((rc = hier_gap_ghosts(H, l, st))) return rc;
+            if (l == 0 && (rc = exchange1(base, SUHMO_F_MR, st))) return rc;                    // rank strips: levelmR.exchange() :2513
             if ((rc = suhmo_hier_pwl_(H, l, SUHMO_F_MR, SUHMO_F_MR, st))) return rc;
             if ((rc = suhmo_hier_ff_(H, l, SUHMO_F_MR, -1, true, st))) return rc;               // levelmR.exchange() :2513
             if (l == 0) { Depth &D = base->d[0];
@@ -784,6 +791,7 @@ extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *
             if (rc) return rc;
         }
         for (int l = 0; l < nlev; l++) if ((rc = hier_melt(H, l, mp, dt, 0, mp->diffFactor != 0.0, st))) return rc;
+        if ((rc = exchange1(base, SUHMO_F_RHS, st))) return rc;                                 // rank strips: halo rows relaxed redundantly
         int it = 0;
         if ((rc = suhmo_hier_solve(H, &sp, &it, nullptr, s))) return rc;
         nv += it;
@@ -824,6 +832,8 @@ extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *
                 GD.phi_fresh = 0;
             }
         }
+        {   static const int halo_fields[] = {SUHMO_F_RHS, SUHMO_F_ACOEF, SUHMO_F_BX, SUHMO_F_BY};          // rank strips
+            if ((rc = suhmo_exchange_list(suhmo_hier_boxes_(G, 0)[0], 0, halo_fields, 4, st))) return rc; }
         if ((rc = suhmo_level_build_mg_coefficients(suhmo_hier_boxes_(G, 0)[0], s))) return rc;
         suhmo_solver_params_t spg;
         gap_solver_params(spg, cur_step);
@@ -1046,17 +1056,21 @@ extern "C" int suhmo_hier_moulin_source(suhmo_hier_t *H, int n, const double *po
     size_t maxblk = 0;
     for (int l = 0; l < nlev; l++) for (suhmo_level *L : suhmo_hier_boxes_(H, l)) {
         if (!suhmo_field(L, 0, SUHMO_F_MSRC)) { suhmo_set_error("field allocation failed"); return -2; }
-        maxblk = std::max(maxblk, (size_t)((L->d[0].v.nx + 15) / 16) * ((L->d[0].v.ny + 15) / 16));
+        maxblk = std::max(maxblk, (size_t)((L->d[0].v.nx + 15) / 16) * (((l == 0 ? L->d[0].v.nyg : L->d[0].v.ny) + 15) / 16));
     }
     double *dev = nullptr;
     HIPCHK(hipMalloc(&dev, (5 * (size_t)n + maxblk * n) * sizeof(double)));
     double *mo = dev, *fl = dev + 3 * (size_t)n, *integ = dev + 4 * (size_t)n, *partial = dev + 5 * (size_t)n;
     hipError_t e = hipMemcpyAsync(dev, h.data(), 4 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
+    DV whole;
+    const double *whole_cover = suhmo_hier_base_cover_(H, &whole);     // level 0 cut into rank strips: every rank integrates all of it (geometry only)
     for (int l = nlev - 1; l >= 0 && e == hipSuccess; l--)             // finest first (:1891)
         for (suhmo_level *L : suhmo_hier_boxes_(H, l)) {
-            const DV &v = L->d[0].v;
+            const bool cutbase = l == 0 && (L->d[0].v.rk[0] || L->d[0].v.rk[1]);
+            DV v = L->d[0].v;
+            if (cutbase) { v.ny = v.nyg; v.j0 = 0; }
             dim3 blk(16, 16), grd((v.nx + 15) / 16, (v.ny + 15) / 16);
-            const double *cover = l < nlev - 1 ? L->d[0].fp.f[SUHMO_F_COVER] : nullptr;
+            const double *cover = l < nlev - 1 ? (cutbase ? whole_cover : L->d[0].fp.f[SUHMO_F_COVER]) : nullptr;
             hipLaunchKernelGGL(k_moulin_partial, grd, blk, 0, st, v, n, mo, partial, Excl{0, 0, 0, 0}, cover);
             hipLaunchKernelGGL(k_moulin_final, dim3(n), dim3(256), 0, st, partial, (int)(grd.x * grd.y), n, integ);
             e = hipGetLastError();

@@ -288,19 +288,22 @@ class HipHier:
     """Base level + levels that are unions of boxes (boxes[l-1] = list of (lo0, lo1, hi0, hi1) in the index space of
     level l), the reference's DisjointBoxLayout per AMR level: suhmo_hier_* (suhmo_amd/csrc/suhmo_hier.hip)."""
 
-    def __init__(self, nx0, ny0, dx0, dy0, bc, phys, boxes, alpha=0.0, beta=-1.0, max_box=64, device=0):
+    def __init__(self, nx0, ny0, dx0, dy0, bc, phys, boxes, alpha=0.0, beta=-1.0, max_box=64, device=0, j0=0, ny_global=None, halo_rows=1):
+        """ny0 rows of level 0 starting at row j0 of ny_global: this rank's strip (one process per GPU; the boxes of the finer
+        levels are given whole on every rank); default: the whole level"""
         self.boxes = [[tuple(int(v) for v in b) for b in bl] for bl in boxes]
         self.nlev = 1 + len(self.boxes)
         d = capi.LevelDesc()
-        d.nx, d.ny, d.j0, d.ny_global, d.dx, d.dy = nx0, ny0, 0, ny0, dx0, dy0
+        d.nx, d.ny, d.j0, d.ny_global, d.dx, d.dy = nx0, ny0, j0, (ny0 if ny_global is None else ny_global), dx0, dy0
         d.nbox, d.boxes, d.max_box, d.alpha, d.beta = 0, None, max_box, alpha, beta
-        d.bc, d.phys, d.device, d.halo_rows = _bc(bc), _phys(phys), device, 1
+        d.bc, d.phys, d.device, d.halo_rows = _bc(bc), _phys(phys), device, halo_rows
         nbox = (C.c_int * self.nlev)(0, *[len(bl) for bl in self.boxes])
         flat = [v for bl in self.boxes for b in bl for v in b]
         arr = (C.c_int * max(len(flat), 1))(*flat)
         h = C.c_void_p()
         check(capi.lib().suhmo_hier_create(C.byref(h), C.byref(d), self.nlev, nbox, arr))
         self.h = h
+        self.j0, self.ny_global = j0, int(d.ny_global)
         self.stream = C.c_void_p(0)
         self.level = [[_BoxView(capi.lib().suhmo_hier_box(h, 0, 0), nx0, ny0, dx0, dy0, self.stream)]]
         for l, bl in enumerate(self.boxes, start=1):
@@ -317,11 +320,14 @@ class HipHier:
                 self.level[l][k].set_inputs(f)
 
     def level_array(self, l, field):
-        nx, ny = self.coarse.nx << l, self.coarse.ny << l
+        nx, ny = self.coarse.nx << l, self.ny_global << l
         out = np.full((ny, nx), np.nan)
         for k, (lo0, lo1, hi0, hi1) in enumerate(self.boxes[l - 1]):
             out[lo1:hi1 + 1, lo0:hi0 + 1] = self.level[l][k].get(field)
         return out
+
+    def gathers(self):
+        return int(capi.lib().suhmo_hier_gathers(self.h))
 
     def exchange(self, l, field, corners=False): check(capi.lib().suhmo_hier_exchange(self.h, l, field, int(corners), self.stream))
     def cf_interp(self, l, field_f=F_PHI, field_c=F_PHI): check(capi.lib().suhmo_hier_cf_interp(self.h, l, field_f, field_c, self.stream))

@@ -95,6 +95,26 @@ class StripExchanger:
             raise capi.SuhmoError("exchange of the coefficient halos failed")
 
 
+class HierGather:
+    """The all-gather hook of a hierarchy whose level 0 is cut into rank strips (suhmo_hier_set_allgather) over a host
+    transport; keep a reference alive as long as the hierarchy.  The native path is suhmo_hier_attach_rccl."""
+
+    def __init__(self, hier, transport, rank):
+        self.tr, self.rank, self.calls = transport, rank, 0
+        self._fn = capi.ALLGATHER_FN(self._gather)
+        check(capi.lib().suhmo_hier_set_allgather(hier.h, self._fn, None))
+
+    def _gather(self, user, send, count, recv, stream):
+        try:
+            self.tr.allgather(self.rank, send, count, recv)
+            self.calls += 1
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return -9
+
+
 class TorchDistTransport:
     """torch.distributed point-to-point; buffers are torch tensors on `device`."""
 
@@ -182,6 +202,15 @@ class ThreadTransport:
         m = max(self.vals)
         self.barrier.wait()
         return m
+
+    def allgather(self, rank, send, count, recv):
+        self._hip.hipDeviceSynchronize()
+        self.box[(rank, "ag")] = send
+        self.barrier.wait()
+        for r in range(self.world):
+            assert self._hip.hipMemcpy(C.c_void_p(recv + r * count * 8), C.c_void_p(self.box[(r, "ag")]), count * 8, 3) == 0
+        self._hip.hipDeviceSynchronize()
+        self.barrier.wait()
 
 
 STATIC_FIELDS = (1, 2, 3, 4, 5, 6, 7, 8)    # RHS, ACOEF, B, PI, ZB, MASK, BX, BY: caller-provided at depth 0
