@@ -129,6 +129,7 @@ struct suhmo_hier {
     // by row, so the cells a rank owns are one segment); one all-gather refreshes a field (or several) before a plan runs.
     // What level 1 writes into level 0 (averages, reflux) is clipped to the rank's own rows when the plans are built.
     int rank = 0, world = 1;
+    bool shadowed = false;                                 // world > 1, or env SUHMO_HIER_SHADOW=1 (tests: the whole path on one rank)
     DV vglob;                                              // level 0 as one canvas (= the base view when it is not cut)
     FP shadow{};
     size_t shadow_elems = 0;
@@ -165,7 +166,7 @@ inline Ref cell_ref(const suhmo_hier *H, const HLev &V, int i, int j)
     r.b = o; r.off = cidx(v, i - v.i0, j - v.j0);
     return r;
 }
-inline bool dist_base(const suhmo_hier *H) { return H->world > 1; }
+inline bool dist_base(const suhmo_hier *H) { return H->shadowed; }
 inline suhmo_level *base_of(suhmo_hier *H) { return H->lev[0].box[0]; }
 inline Ref local_ref(const HLev &V, int k, int il, int jl) { return Ref{k, cidx(V.box[k]->d[0].v, il, jl)}; }
 
@@ -933,13 +934,15 @@ extern "C" int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *b
     if (cut && (base->ny_global % base->ny || base->j0 % base->ny)) { suhmo_set_error("hier: level 0 must be cut into EQUAL rank strips"); return -1; }
     suhmo_hier *H = new suhmo_hier();
     if (cut) { H->world = base->ny_global / base->ny; H->rank = base->j0 / base->ny; }
+    H->shadowed = cut;
+    if (const char *e = getenv("SUHMO_HIER_SHADOW")) if (atoi(e) != 0) H->shadowed = true;
     H->nlev = nlev; H->device = base->device; H->bc = base->bc; H->base_desc = *base; H->base_desc.boxes = nullptr; H->base_desc.nbox = 0;
     suhmo_level *B = nullptr;
     int rc = suhmo_level_create(&B, base);
     if (rc) { delete H; return rc; }
     H->lev[0].l = 0; H->lev[0].nxd = base->nx; H->lev[0].nyd = base->ny_global; H->lev[0].box.push_back(B);
     H->vglob = B->d[0].v;
-    if (cut) {
+    if (H->shadowed) {
         DV &g = H->vglob;
         g.ny = g.nyg; g.j0 = 0; g.rows = g.ny + 2 * g.gy;
         g.ext[0] = g.ext[1] = g.rk[0] = g.rk[1] = 0;
@@ -1012,7 +1015,7 @@ extern "C" int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *b
     // SUHMO_F_COVER: 1 under a finer level, 0 elsewhere
     for (int l = 0; l < nlev; l++) for (suhmo_level *L : H->lev[l].box) if ((rc = suhmo_level_set_value(L, 0, SUHMO_F_COVER, 0.0, nullptr))) { suhmo_hier_destroy(H); return rc; }
     for (int l = 1; l < nlev; l++) if ((rc = hier_avg(H, l, SUHMO_F_COVER, SUHMO_F_COVER, 1, 1.0, nullptr))) { suhmo_hier_destroy(H); return rc; }
-    if (cut && nlev > 1) {                                  // COVER of the whole level 0 (geometry only): the moulin integrals run over all of it
+    if (H->shadowed && nlev > 1) {                          // COVER of the whole level 0 (geometry only): the moulin integrals run over all of it
         if (!shadow_field(H, SUHMO_F_COVER)) { suhmo_set_error("field allocation failed"); suhmo_hier_destroy(H); return -2; }
         HLev &V = H->lev[1];
         if (H->cover_full.n) {

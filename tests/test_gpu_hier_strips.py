@@ -150,3 +150,29 @@ def test_hier_solve_on_strips_bitwise():
             for k in range(len(ref[l])):
                 assert np.array_equal(out[r][2][l][k], ref[l][k]), (r, l, k)
     assert np.array_equal(np.vstack([out[r][2][0][0] for r in range(world)]), ref[0][0])
+
+
+def test_native_allgather_single_rank(monkeypatch):
+    """The shadow path over the native transport: SUHMO_HIER_SHADOW=1 routes level 1's reads of an uncut level 0 through the
+    pack kernel, ncclAllGather (one rank) on the kernels' stream and the unpack kernel; the time step must not change a bit."""
+    from suhmo_amd import capi, model, multigpu
+    m = dict(sy.A3_MODEL, **B5ISH)
+    sts = sy.shmip_amrm_states(64, 32, UNION, rough=0.5)
+    res = []
+    for shadow in (0, 1):
+        monkeypatch.setenv("SUHMO_HIER_SHADOW", str(shadow))
+        G = model.HipHierModel(64, 32, sts[0][0]["dx"], sts[0][0]["dy"], sy.A3_BC, sy.A3_PHYS, m, UNION, max_box=MB)
+        G.set_states(sts)
+        if shadow:
+            multigpu.attach_rccl(G.level[0][0], 0, 1)
+            capi.check(capi.lib().suhmo_hier_attach_rccl(G.hier.h))
+        integ = G.moulin_source(**MOULINS)
+        counts = [G.timestep(m["dt"]) for _ in range(2)]
+        res.append((counts, integ, [[{nm: G.get(l, k, nm) for nm in NAMES} for k in range(len(G.level[l]))] for l in range(len(sts))], G.hier.gathers()))
+        G.close()
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+    assert res[0][3] == 0 and res[1][3] > 50
+    for l in range(len(sts)):
+        for k in range(len(sts[l])):
+            for nm in NAMES:
+                assert np.array_equal(res[0][2][l][k][nm], res[1][2][l][k][nm], equal_nan=True), (l, k, nm)
