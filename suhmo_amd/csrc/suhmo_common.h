@@ -131,6 +131,7 @@ struct VGraph {                 // a V-cycle captured for one set of solver para
     int key[4]; hipGraphExec_t exec;
     double *p0[SUHMO_MAXDEPTH], *a0[SUHMO_MAXDEPTH];     // PHI / second canvas of every depth when the cycle starts ...
     double *p1[SUHMO_MAXDEPTH], *a1[SUHMO_MAXDEPTH];     // ... and when it ends (an odd number of out-of-place launches on a depth swaps them)
+    double *rhs;                                         // right-hand-side canvas of depth 0 the cycle was captured with
 };
 struct ProfEv { hipEvent_t a, b; long cells; int restricts; };   // restricts: the launch also did the restriction (RST)
 

@@ -117,7 +117,7 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
     auto at_start = [&](const VGraph &g) {
         if (memcmp(g.key, key, sizeof(key))) return false;
         for (int d = 0; d < L->ndepth; d++) if (L->d[d].fp.f[SUHMO_F_PHI] != g.p0[d] || L->d[d].phi_alt != g.a0[d]) return false;
-        return true;
+        return L->d[0].fp.f[SUHMO_F_RHS] == g.rhs;                       // an AMR cycle runs level 0 on a second right-hand-side canvas (suhmo_hier.hip)
     };
     for (const VGraph &g : L->vgraphs)
         if (at_start(g)) {
@@ -134,6 +134,7 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
     VGraph g; memcpy(g.key, key, sizeof(key)); g.exec = nullptr;
     for (int d = 0; d < SUHMO_MAXDEPTH; d++) { g.p0[d] = g.a0[d] = g.p1[d] = g.a1[d] = nullptr; }
     for (int d = 0; d < L->ndepth; d++) { g.p0[d] = L->d[d].fp.f[SUHMO_F_PHI]; g.a0[d] = L->d[d].phi_alt; }
+    g.rhs = L->d[0].fp.f[SUHMO_F_RHS];
     HIPCHK(hipStreamSynchronize((hipStream_t)s));                        // the private stream starts from a quiescent state
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamBeginCapture(L->gstream, hipStreamCaptureModeThreadLocal);

@@ -24,8 +24,12 @@
 #include <type_traits>
 
 // ---- variant 0: one thread per active-colour cell ----
+// PUSH (boxes of a multi-box level): a cell on the side of its box also stores its new value into the ghost cell of the box
+// across that side (push[pbase + side cell] = {box, canvas offset}, box < 0: none), so the next colour pass needs no
+// Copier::exchange launch in between: a ghost cell of colour c is read only by the pass of the other colour.
 template <bool HAS_ALPHA>
-__device__ __forceinline__ void d_gsrb_pass_simple(const DV &v, const FP &fp, suhmo_phys_t ph, int pass, int jlo, int jhi)
+__device__ __forceinline__ void d_gsrb_pass_simple(const DV &v, const FP &fp, suhmo_phys_t ph, int pass, int jlo, int jhi,
+                                                   const FP *__restrict__ ft = nullptr, const int2 *__restrict__ push = nullptr)
 {
     // rows [jlo, jhi]: the strip's own rows plus, on rank boundaries, the halo rows that are
     // still fresh enough to be advanced redundantly (one exchange then feeds several passes)
@@ -48,7 +52,14 @@ __device__ __forceinline__ void d_gsrb_pass_simple(const DV &v, const FP &fp, su
     double lofphi = lofphi_cell(v, aterm, c, e, w, n, s, bxE, bxW, byN, byS, nl);
     double lam = lambda_cell(v, aterm, bxE, bxW, byN, byS);
     double denom = 1.0e-16 + lam + dnl;                      // ...OpF.ChF:154
-    phi[idx] = c + (fp.f[SUHMO_F_RHS][idx] - lofphi) / denom; // :156
+    const double pnew = c + (fp.f[SUHMO_F_RHS][idx] - lofphi) / denom; // :156
+    phi[idx] = pnew;
+    if (push) {                                               // sides in the order W, E (ny cells each), S, N (nx cells each)
+        if (i == 0) { int2 q = push[j]; if (q.x >= 0) ft[q.x].f[SUHMO_F_PHI][q.y] = pnew; }
+        if (i == v.nx - 1) { int2 q = push[v.ny + j]; if (q.x >= 0) ft[q.x].f[SUHMO_F_PHI][q.y] = pnew; }
+        if (j == 0) { int2 q = push[2 * v.ny + i]; if (q.x >= 0) ft[q.x].f[SUHMO_F_PHI][q.y] = pnew; }
+        if (j == v.ny - 1) { int2 q = push[2 * v.ny + v.nx + i]; if (q.x >= 0) ft[q.x].f[SUHMO_F_PHI][q.y] = pnew; }
+    }
 }
 template <bool HAS_ALPHA>
 __global__ __launch_bounds__(256) void k_gsrb_pass_simple(DV v, FP fp, suhmo_phys_t ph, int pass, int jlo, int jhi)
@@ -57,9 +68,10 @@ __global__ __launch_bounds__(256) void k_gsrb_pass_simple(DV v, FP fp, suhmo_phy
 }
 // every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
 template <bool HAS_ALPHA>
-__global__ __launch_bounds__(256) void k_gsrb_pass_simple_m(const DV *__restrict__ vt, const FP *__restrict__ ft, suhmo_phys_t ph, int pass)
+__global__ __launch_bounds__(256) void k_gsrb_pass_simple_m(const DV *__restrict__ vt, const FP *__restrict__ ft, suhmo_phys_t ph, int pass,
+                                                            const int2 *__restrict__ push, const int *__restrict__ pbase)
 {
-    d_gsrb_pass_simple<HAS_ALPHA>(vt[blockIdx.z], ft[blockIdx.z], ph, pass, 0, vt[blockIdx.z].ny - 1);
+    d_gsrb_pass_simple<HAS_ALPHA>(vt[blockIdx.z], ft[blockIdx.z], ph, pass, 0, vt[blockIdx.z].ny - 1, ft, push ? push + pbase[blockIdx.z] : nullptr);
 }
 
 static void launch_simple(suhmo_level *L, int depth, int pass, int ext_rows, hipStream_t st)
@@ -83,11 +95,12 @@ int suhmo_gsrb_colour_pass(suhmo_level *L, int depth, int pass, hipStream_t st)
     return 0;
 }
 
-int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int pass, hipStream_t st)
+int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int pass, hipStream_t st, bool push)
 {
     dim3 blk(64, 4), grd(((m.maxnx + 1) / 2 + 63) / 64, (m.maxny + 3) / 4, m.nbox);
-    if (has_alpha) hipLaunchKernelGGL(k_gsrb_pass_simple_m<true>, grd, blk, 0, st, m.dv, m.fp, ph, pass);
-    else hipLaunchKernelGGL(k_gsrb_pass_simple_m<false>, grd, blk, 0, st, m.dv, m.fp, ph, pass);
+    const int2 *pp = push ? (const int2 *)m.push : nullptr;
+    if (has_alpha) hipLaunchKernelGGL(k_gsrb_pass_simple_m<true>, grd, blk, 0, st, m.dv, m.fp, ph, pass, pp, m.pbase);
+    else hipLaunchKernelGGL(k_gsrb_pass_simple_m<false>, grd, blk, 0, st, m.dv, m.fp, ph, pass, pp, m.pbase);
     HIPCHK(hipGetLastError());
     return 0;
 }

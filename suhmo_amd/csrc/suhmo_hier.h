@@ -13,10 +13,12 @@ int suhmo_hier_avg_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st);      
 int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, suhmo_hier **gap);
 
 // every box of a level in ONE launch (blockIdx.z = box): device tables of the boxes' views and field pointers
-struct suhmo_multi { const DV *dv; const FP *fp; int nbox, maxnx, maxny; double *red; /* reduction scratch, 64 nbox + 16 doubles */ };
-int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int pass, hipStream_t st);      // suhmo_gsrb.hip
+struct suhmo_multi { const DV *dv; const FP *fp; int nbox, maxnx, maxny; double *red; /* reduction scratch, 64 nbox + 16 doubles */
+                     const void *push; const int *pbase; /* fine-fine ghost cells a side cell feeds (int2 {box, offset}), first entry of every box */ };
+int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int pass, hipStream_t st, bool push = false);      // suhmo_gsrb.hip
 int suhmo_multi_fill_ghosts(const suhmo_multi &m, int field, int homog, hipStream_t st);                                  // suhmo_level.hip ...
-int suhmo_multi_apply(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int mode, hipStream_t st);            // mode 0: LPHI, 1: RES
+int suhmo_multi_apply(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int mode, hipStream_t st);            // mode 0: LPHI, 1: RES, 3: both
+int suhmo_apply_and_residual(suhmo_level *L, int depth, hipStream_t st);                                                  // LPHI and RES = rhs - LPHI in one pass
 int suhmo_multi_grad_cc(const suhmo_multi &m, int hasMask, hipStream_t st);
 int suhmo_multi_re(const suhmo_multi &m, const suhmo_phys_t &ph, hipStream_t st);
 int suhmo_multi_bcoef_faces(const suhmo_multi &m, const suhmo_phys_t &ph, hipStream_t st);

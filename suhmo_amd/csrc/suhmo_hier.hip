@@ -105,6 +105,7 @@ struct HLev {
     BoxIndex index;
     // plans (device)
     DevVec<CopyEnt> ff_side, ff_corner;
+    DevVec<int2> push; DevVec<int> pbase;            // ff_side seen from the source cell (the colour passes push, suhmo_gsrb.hip)
     DevVec<CfEnt> cf;
     DevVec<PwlEnt> pwl;
     DevVec<RectEnt> avg; int avg_w = 0, avg_h = 0;
@@ -129,6 +130,7 @@ struct suhmo_hier {
     // by row, so the cells a rank owns are one segment); one all-gather refreshes a field (or several) before a plan runs.
     // What level 1 writes into level 0 (averages, reflux) is clipped to the rank's own rows when the plans are built.
     int rank = 0, world = 1;
+    bool push_ghosts = true;                               // env SUHMO_HIER_PUSH=0: an exchange launch before every colour pass instead
     bool shadowed = false;                                 // world > 1, or env SUHMO_HIER_SHADOW=1 (tests: the whole path on one rank)
     DV vglob;                                              // level 0 as one canvas (= the base view when it is not cut)
     FP shadow{};
@@ -309,14 +311,16 @@ __global__ void k_prolong2_win(const Win *__restrict__ wins, const double *__res
 }
 // [Chombo] LevelFluxRegister (oracle/amrm.c:reflux): one thread per coarse cell next to coarse-fine faces
 __global__ void k_reflux(const Target *__restrict__ tg, int n, const Face *__restrict__ faces, const FP *__restrict__ ftab, const DV *__restrict__ fdv,
-                         const FP *__restrict__ ctab, FP cbase, FP cdst, int use_base, int field_c, double dxc, double dyc, double beta)
+                         const FP *__restrict__ ctab, FP cbase, FP cdst, int use_base, int field_c, double dxc, double dyc, double beta, int residual)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     Target T = tg[t];
-    double *lof = fptr(ctab, cdst, use_base, T.t.b, field_c);          // cdst: the level itself; cbase: where its cells are read (the shadow of a cut level 0)
+    // cdst: the level itself; cbase: where its cells are read (the shadow of a cut level 0).  residual: the register is added to
+    // LPHI's value and field_c <- rhs - that (the axby of the composite residual, for the cells the reflux reaches)
+    double *lof = fptr(ctab, cdst, use_base, T.t.b, field_c);
     const double rscale = 1.0 / (dxc * dyc);
-    double acc = lof[T.t.off];
+    double acc = residual ? fptr(ctab, cdst, use_base, T.t.b, SUHMO_F_LPHI)[T.t.off] : lof[T.t.off];
     for (int m = 0; m < T.count; m++) {
         Face f = faces[T.first + m];
         const double dxd = f.dir == 0 ? dxc : dyc, tsize = f.dir == 0 ? dyc : dxc;
@@ -336,7 +340,7 @@ __global__ void k_reflux(const Target *__restrict__ tg, int n, const Face *__res
         }
         acc = acc + sign * rscale * reg;
     }
-    lof[T.t.off] = acc;
+    lof[T.t.off] = residual ? -1.0 * acc + 1.0 * fptr(ctab, cdst, use_base, T.t.b, SUHMO_F_RHS)[T.t.off] : acc;
 }
 
 // ------------------------------------------------------------------ plan building (host)
@@ -536,6 +540,27 @@ int build_plans(suhmo_hier *H, int l)
         if (H->need.upload(needv) || H->need_rl.upload(rl) || H->cover_full.upload(cover_full)) { suhmo_set_error("hier: plan upload failed"); return -2; }
     }
     int rc = 0;
+    {   // the side copies by source cell: per box W, E (ny entries each), S, N (nx each)
+        std::vector<int> pbase(nb);
+        size_t tot = 0;
+        for (int k = 0; k < nb; k++) { const DV &v = F.box[k]->d[0].v; pbase[k] = (int)tot; tot += 2 * (size_t)(v.nx + v.ny); }
+        std::vector<int2> push(tot, int2{-1, 0});
+        for (const CopyEnt &e : ffs) {
+            const DV &vo = F.box[e.s.b]->d[0].v, &vk = F.box[e.d.b]->d[0].v;
+            const int js = e.s.off / vo.P - vo.gy, is = e.s.off % vo.P - SUHMO_XOFF;      // the source cell in its box
+            const int jd = e.d.off / vk.P - vk.gy, id = e.d.off % vk.P - SUHMO_XOFF;      // the ghost cell in its box
+            int slot;
+            if (id < 0) slot = vo.ny + js;                  // a W ghost is fed by a cell on the E side of its box
+            else if (id >= vk.nx) slot = js;
+            else if (jd < 0) slot = 2 * vo.ny + vo.nx + is; // an S ghost by a cell on the N side
+            else slot = 2 * vo.ny + is;
+            const bool ok = (id < 0 ? is == vo.nx - 1 : id >= vk.nx ? is == 0 : jd < 0 ? js == vo.ny - 1 : js == 0);
+            int2 &q = push[pbase[e.s.b] + slot];
+            if (!ok || q.x >= 0) { suhmo_set_error("hier: internal: fine-fine copy without a unique source side cell"); return -4; }
+            q = int2{e.d.b, e.d.off};
+        }
+        rc |= F.push.upload(push); rc |= F.pbase.upload(pbase);
+    }
     rc |= F.ff_side.upload(ffs); rc |= F.ff_corner.upload(ffc); rc |= F.cf.upload(cf); rc |= F.pwl.upload(pwl);
     rc |= F.avg.upload(avg); rc |= F.wing.upload(wing); rc |= F.targets.upload(targets); rc |= F.faces.upload(faces);
     if (rc) { suhmo_set_error("hier: plan upload failed"); return -2; }
@@ -672,6 +697,7 @@ int multi_of(suhmo_hier *H, int l, hipStream_t st, suhmo_multi &m)
     int rc = refresh_tables(H, l, st); if (rc) return rc;
     HLev &V = H->lev[l];
     m.dv = V.d_dv; m.fp = V.d_fp; m.nbox = (int)V.box.size(); m.maxnx = V.maxnx; m.maxny = V.maxny; m.red = V.d_red;
+    m.push = V.push.d; m.pbase = V.pbase.d;
     return 0;
 }
 inline const suhmo_phys_t &phys_of(suhmo_hier *H, int l) { return H->lev[l].box[0]->ph; }
@@ -757,7 +783,7 @@ int hier_prolong2(suhmo_hier *H, int l, int field_c, hipStream_t st)
 }
 // reflux (src/VCAMRNonLinearPoissonOp.cpp:555-652): field_c of level l-1 (holding L(phi)) += the flux mismatch on the
 // coarse-fine faces of level l
-int hier_reflux(suhmo_hier *H, int l, int field_c, hipStream_t st)
+int hier_reflux(suhmo_hier *H, int l, int field_c, hipStream_t st, int residual = 0)
 {
     SUHMO_TIME("VCAMRNonLinearPoissonOp::reflux");
     HLev &V = H->lev[l];
@@ -769,7 +795,7 @@ int hier_reflux(suhmo_hier *H, int l, int field_c, hipStream_t st)
     const DV &vc = H->lev[l - 1].box[0]->d[0].v;
     if (V.targets.n)
         hipLaunchKernelGGL(k_reflux, g1(V.targets.n), dim3(256), 0, st, V.targets.d, (int)V.targets.n, V.faces.d, V.d_fp, V.d_dv, ca.tab, ca.base, ca.dst,
-                           ca.use_base, field_c, vc.dx, vc.dy, vc.beta);
+                           ca.use_base, field_c, vc.dx, vc.dy, vc.beta, residual);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -783,15 +809,14 @@ int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
     int rc;
     suhmo_multi m;
     if ((rc = multi_of(H, l, HST(s), m))) return rc;
+    // exchange() before every colour pass (:692, :751): once here, then every pass pushes its new side cells into the ghost
+    // cells they feed
+    if (sweeps > 0 && (rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
     for (int it = 0; it < sweeps; it++)
-        for (int pass = 0; pass < 2; pass++) {
-            if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
-            if ((rc = suhmo_multi_colour_pass(m, phys_of(H, l), has_alpha(H, l), pass, HST(s)))) return rc;
-        }
-    if (sweeps > 0) {
-        if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
-        if ((rc = suhmo_multi_fill_ghosts(m, SUHMO_F_PHI, 1, HST(s)))) return rc;                                  // :757-759
-    }
+        for (int pass = 0; pass < 2; pass++)
+            if ((rc = suhmo_multi_colour_pass(m, phys_of(H, l), has_alpha(H, l), pass, HST(s), H->push_ghosts))) return rc;
+            else if (!H->push_ghosts && (rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
+    if (sweeps > 0 && (rc = suhmo_multi_fill_ghosts(m, SUHMO_F_PHI, 1, HST(s)))) return rc;                        // :757-759
     return 0;
 }
 int hier_apply(suhmo_hier *H, int l, suhmo_stream_t s)        // applyOpI, inhomogeneous: LPHI
@@ -865,12 +890,18 @@ int hier_update_operator(suhmo_hier *H, int l, suhmo_stream_t s)
 int composite_residual(suhmo_hier *H, int l, suhmo_stream_t s)
 {
     int rc;
+    // one pass writes LPHI and rhs - LPHI; the cells next to the coarse-fine faces then get rhs - (LPHI + flux mismatch): the
+    // values of copy, reflux, axby(RES, RHS, -1, 1) over the whole level, without two of its three passes
     if ((rc = cf_phi(H, l - 1, s))) return rc;
-    if ((rc = hier_apply(H, l - 1, s))) return rc;
-    if ((rc = hier_copy(H, l - 1, SUHMO_F_RES, SUHMO_F_LPHI, s))) return rc;
+    if (l - 1 == 0) rc = suhmo_apply_and_residual(base_of(H), 0, HST(s));
+    else {
+        suhmo_multi m;
+        if ((rc = hier_ff(H, l - 1, SUHMO_F_PHI, -1, false, HST(s))) || (rc = ensure_field(H, l - 1, SUHMO_F_LPHI)) || (rc = multi_of(H, l - 1, HST(s), m))) return rc;
+        rc = suhmo_multi_apply(m, phys_of(H, l - 1), has_alpha(H, l - 1), 3, HST(s));
+    }
+    if (rc) return rc;
     if ((rc = cf_phi(H, l, s))) return rc;
-    if ((rc = hier_reflux(H, l, SUHMO_F_RES, HST(s)))) return rc;
-    return hier_axby(H, l - 1, SUHMO_F_RES, SUHMO_F_RES, SUHMO_F_RHS, -1.0, 1.0, s);
+    return hier_reflux(H, l, SUHMO_F_RES, HST(s), 1);
 }
 int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stream_t s)
 {
@@ -884,12 +915,16 @@ int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stre
     if ((rc = hier_level_residual(H, l, s))) return rc;
     if ((rc = composite_residual(H, l, s))) return rc;
     if ((rc = hier_avg(H, l, SUHMO_F_RES, SUHMO_F_RES, 0, 0.0, HST(s)))) return rc;
-    if ((rc = hier_copy(H, l - 1, SUHMO_F_RHS0, SUHMO_F_RHS, s))) return rc;
+    // the right-hand side of level l-1 is set aside while its FAS problem runs: two canvases trade places on level 0 (its
+    // pointers travel by value), a copy on a level of boxes (their pointers sit in a device table)
+    if (l - 1 == 0) std::swap(base_of(H)->d[0].fp.f[SUHMO_F_RHS], base_of(H)->d[0].fp.f[SUHMO_F_RHS0]);
+    else if ((rc = hier_copy(H, l - 1, SUHMO_F_RHS0, SUHMO_F_RHS, s))) return rc;
     if ((rc = hier_axby(H, l - 1, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
     if (l == 1 && dist_base(H) && (rc = suhmo_level_exchange(base_of(H), 0, SUHMO_F_RHS, s))) return rc;      // rank strips: rhs halo rows (relaxed redundantly)
     if ((rc = hier_copy(H, l - 1, SUHMO_F_PHIOLD, SUHMO_F_PHI, s))) return rc;
     if ((rc = vcycle_amr(H, l - 1, sp, s))) return rc;
-    if ((rc = hier_copy(H, l - 1, SUHMO_F_RHS, SUHMO_F_RHS0, s))) return rc;
+    if (l - 1 == 0) std::swap(base_of(H)->d[0].fp.f[SUHMO_F_RHS], base_of(H)->d[0].fp.f[SUHMO_F_RHS0]);
+    else if ((rc = hier_copy(H, l - 1, SUHMO_F_RHS, SUHMO_F_RHS0, s))) return rc;
     if ((rc = hier_axby(H, l - 1, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) return rc;
     if ((rc = hier_prolong2(H, l, SUHMO_F_CORR, HST(s)))) return rc;                          // AMRProlongS_2
     if ((rc = cf_phi(H, l, s))) return rc;
@@ -912,7 +947,7 @@ extern "C" int suhmo_hier_destroy(suhmo_hier_t *H)
     for (int l = 0; l < 8; l++) {
         HLev &V = H->lev[l];
         for (suhmo_level *L : V.box) (void)suhmo_level_destroy(L);
-        V.ff_side.release(); V.ff_corner.release(); V.cf.release(); V.pwl.release(); V.avg.release(); V.wing.release();
+        V.ff_side.release(); V.ff_corner.release(); V.push.release(); V.pbase.release(); V.cf.release(); V.pwl.release(); V.avg.release(); V.wing.release();
         V.targets.release(); V.faces.release();
         if (V.winbuf) (void)hipFree(V.winbuf);
         if (V.d_win) (void)hipFree(V.d_win);
@@ -936,6 +971,7 @@ extern "C" int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *b
     if (cut) { H->world = base->ny_global / base->ny; H->rank = base->j0 / base->ny; }
     H->shadowed = cut;
     if (const char *e = getenv("SUHMO_HIER_SHADOW")) if (atoi(e) != 0) H->shadowed = true;
+    if (const char *e = getenv("SUHMO_HIER_PUSH")) H->push_ghosts = atoi(e) != 0;
     H->nlev = nlev; H->device = base->device; H->bc = base->bc; H->base_desc = *base; H->base_desc.boxes = nullptr; H->base_desc.nbox = 0;
     suhmo_level *B = nullptr;
     int rc = suhmo_level_create(&B, base);

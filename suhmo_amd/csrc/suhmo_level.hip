@@ -538,6 +538,7 @@ extern "C" int suhmo_level_fill_ghosts(suhmo_level_t *L, int depth, int field, i
 
 // VCNLCOMPUTEOP2D / VCNLCOMPUTERES2D with BC, NL fused.  MODE 0: LPHI = L(phi); 1: RES = rhs - L(phi);
 // 2: the FAS right-hand side of a coarse depth in one pass: LPHI = L(phi), RHS = axby(RES, LPHI, 1, 1), PHIOLD = phi
+// 3: LPHI = L(phi) and RES = axby(LPHI, RHS, -1, 1) in one pass (the composite residual of an AMR level, suhmo_hier.hip)
 template <bool HAS_ALPHA, int MODE>
 __device__ __forceinline__ void d_apply(const DV &v, const FP &fp, suhmo_phys_t ph, int homog, int halo, int hcomp)
 {
@@ -563,6 +564,7 @@ __device__ __forceinline__ void d_apply(const DV &v, const FP &fp, suhmo_phys_t 
     double lofphi = lofphi_cell(v, aterm, c, e, w, n, s, bxE, bxW, byN, byS, nl);
     if (MODE == 0) fp.f[SUHMO_F_LPHI][idx] = lofphi;
     else if (MODE == 1) fp.f[SUHMO_F_RES][idx] = fp.f[SUHMO_F_RHS][idx] - lofphi;
+    else if (MODE == 3) { fp.f[SUHMO_F_LPHI][idx] = lofphi; fp.f[SUHMO_F_RES][idx] = -1.0 * lofphi + 1.0 * fp.f[SUHMO_F_RHS][idx]; }
     else {
         fp.f[SUHMO_F_LPHI][idx] = lofphi;
         fp.f[SUHMO_F_RHS][idx] = 1.0 * fp.f[SUHMO_F_RES][idx] + 1.0 * lofphi;
@@ -621,6 +623,19 @@ extern "C" int suhmo_level_apply_op(suhmo_level_t *L, int depth, int homogeneous
     int rc = suhmo_ensure_phi_halo(L, depth, 1, (hipStream_t)s); if (rc) return rc;
     if (D.v.alpha != 0.0) hipLaunchKernelGGL((k_apply<true, 0>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, L->ph, homogeneous);
     else hipLaunchKernelGGL((k_apply<false, 0>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, D.fp, L->ph, homogeneous);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// applyOpI (inhomogeneous) and the residual of it in one pass: LPHI = L(phi), RES = rhs - L(phi)
+int suhmo_apply_and_residual(suhmo_level *L, int depth, hipStream_t st)
+{
+    SUHMO_TIME("VCAMRNonLinearPoissonOp::applyOpI");
+    Depth &D = L->d[depth];
+    if (!suhmo_field(L, depth, SUHMO_F_LPHI) || !suhmo_field(L, depth, SUHMO_F_RES)) return -2;
+    int rc = suhmo_ensure_phi_halo(L, depth, 1, st); if (rc) return rc;
+    if (D.v.alpha != 0.0) hipLaunchKernelGGL((k_apply<true, 3>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, st, D.v, D.fp, L->ph, 0);
+    else hipLaunchKernelGGL((k_apply<false, 3>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, st, D.v, D.fp, L->ph, 0);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1731,9 +1746,11 @@ int suhmo_multi_fill_ghosts(const suhmo_multi &m, int field, int homog, hipStrea
 int suhmo_multi_apply(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int mode, hipStream_t st)
 {
     if (has_alpha) { if (mode == 0) hipLaunchKernelGGL((k_apply_m<true, 0>), grid_m(m), BLK2D, 0, st, m.dv, m.fp, ph, 0);
-                     else hipLaunchKernelGGL((k_apply_m<true, 1>), grid_m(m), BLK2D, 0, st, m.dv, m.fp, ph, 0); }
+                     else if (mode == 1) hipLaunchKernelGGL((k_apply_m<true, 1>), grid_m(m), BLK2D, 0, st, m.dv, m.fp, ph, 0);
+                     else hipLaunchKernelGGL((k_apply_m<true, 3>), grid_m(m), BLK2D, 0, st, m.dv, m.fp, ph, 0); }
     else { if (mode == 0) hipLaunchKernelGGL((k_apply_m<false, 0>), grid_m(m), BLK2D, 0, st, m.dv, m.fp, ph, 0);
-           else hipLaunchKernelGGL((k_apply_m<false, 1>), grid_m(m), BLK2D, 0, st, m.dv, m.fp, ph, 0); }
+           else if (mode == 1) hipLaunchKernelGGL((k_apply_m<false, 1>), grid_m(m), BLK2D, 0, st, m.dv, m.fp, ph, 0);
+           else hipLaunchKernelGGL((k_apply_m<false, 3>), grid_m(m), BLK2D, 0, st, m.dv, m.fp, ph, 0); }
     HIPCHK(hipGetLastError());
     return 0;
 }
