@@ -111,7 +111,7 @@ struct HLev {
     DevVec<RectEnt> avg; int avg_w = 0, avg_h = 0;
     DevVec<WinEnt> wing; int wing_w = 0, wing_h = 0;
     DevVec<Target> targets; DevVec<Face> faces;
-    std::vector<Win> win; double *winbuf = nullptr; size_t winelems = 0; Win *d_win = nullptr; int *d_wing_box = nullptr;
+    std::vector<Win> win; double *winbuf = nullptr, *winold = nullptr; size_t winelems = 0; Win *d_win = nullptr; int *d_wing_box = nullptr;
     // field pointer / view tables of the boxes
     std::vector<FP> h_fp; FP *d_fp = nullptr; DV *d_dv = nullptr;
     double *d_red = nullptr; int maxnx = 0, maxny = 0;            // reduction scratch (64 nbox + 16 doubles), largest box
@@ -254,8 +254,11 @@ __global__ void k_avg(const RectEnt *__restrict__ e, const FP *__restrict__ ftab
     s = s + f[b]; s = s + f[b + 1]; s = s + f[b + Pf]; s = s + f[b + Pf + 1];
     c[q.coff + J * Pc + I] = s * 0.25;
 }
+// old != NULL: the window gets c - old (the correction phi - phi_saved, as axby(phi, saved, 1, -1) states it), old being an earlier
+// gather of the same cells
 __global__ void k_win_gather(const WinEnt *__restrict__ e, double *__restrict__ wbuf, const FP *__restrict__ ctab, const DV *__restrict__ cdv,
-                             FP cbase, DV cbdv, int use_base, int fc, const Win *__restrict__ wins, const int *__restrict__ went_box)
+                             FP cbase, DV cbdv, int use_base, int fc, const Win *__restrict__ wins, const int *__restrict__ went_box,
+                             const double *__restrict__ old = nullptr)
 {
     WinEnt q = e[blockIdx.z];
     int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y * blockDim.y + threadIdx.y;
@@ -263,7 +266,9 @@ __global__ void k_win_gather(const WinEnt *__restrict__ e, double *__restrict__ 
     const int Pc = use_base ? cbdv.P : cdv[q.cb].P;
     const double *c = fptr(ctab, cbase, use_base, q.cb, fc);
     const Win w = wins[went_box[blockIdx.z]];
-    wbuf[w.base + q.woff + (size_t)J * w.nx + I] = c[q.coff + J * Pc + I];
+    const size_t o = w.base + q.woff + (size_t)J * w.nx + I;
+    const double cv = c[q.coff + J * Pc + I];
+    wbuf[o] = old ? 1.0 * cv + -1.0 * old[o] : cv;
 }
 // physical BC of the coarse level on the window of every fine box (m_bc on a_temp, AMRProlongS_2 :1160-1166), along the
 // coarsened box's own extent only: the corner cells beyond it are never written (value 0)
@@ -760,7 +765,28 @@ int hier_avg(suhmo_hier *H, int l, int ff, int fc, int mode, double val, hipStre
 }
 // AMRProlongS_2 (:1143-1206): PHI of level l += PROLONG_2_NL(field_c of level l-1), the coarse field gathered per box with
 // its physical-BC ghosts (inhomogeneous in FAS mode)
-int hier_prolong2(suhmo_hier *H, int l, int field_c, hipStream_t st)
+// minus_saved: the coarse field is field_c minus what hier_window_save kept of it (the correction of a FAS cycle: only the
+// windows of it are ever formed)
+int hier_window_save(suhmo_hier *H, int l, int field_c, hipStream_t st)
+{
+    HLev &V = H->lev[l];
+    int rc;
+    CoarseArgs ca;
+    if ((rc = ensure_field(H, l - 1, field_c)) || (rc = refresh_tables(H, l, st))) return rc;
+    if (l == 1 && (rc = refresh_base1(H, field_c, st))) return rc;
+    if ((rc = coarse_args(H, l - 1, st, ca))) return rc;
+    if (!V.winold) {
+        HIPCHK(hipMalloc(&V.winold, std::max<size_t>(1, V.winelems) * sizeof(double)));
+        HIPCHK(hipMemsetAsync(V.winold, 0, std::max<size_t>(1, V.winelems) * sizeof(double), st));
+    }
+    if (V.wing.n) {
+        dim3 grd((V.wing_w + 63) / 64, (V.wing_h + 3) / 4, (unsigned)V.wing.n);
+        hipLaunchKernelGGL(k_win_gather, grd, dim3(64, 4), 0, st, V.wing.d, V.winold, ca.tab, ca.dv, ca.base, ca.bdv, ca.use_base, field_c, V.d_win, V.d_wing_box);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int hier_prolong2(suhmo_hier *H, int l, int field_c, hipStream_t st, bool minus_saved = false)
 {
     HLev &V = H->lev[l];
     int rc;
@@ -770,7 +796,8 @@ int hier_prolong2(suhmo_hier *H, int l, int field_c, hipStream_t st)
     if ((rc = coarse_args(H, l - 1, st, ca))) return rc;
     if (V.wing.n) {
         dim3 grd((V.wing_w + 63) / 64, (V.wing_h + 3) / 4, (unsigned)V.wing.n);
-        hipLaunchKernelGGL(k_win_gather, grd, dim3(64, 4), 0, st, V.wing.d, V.winbuf, ca.tab, ca.dv, ca.base, ca.bdv, ca.use_base, field_c, V.d_win, V.d_wing_box);
+        hipLaunchKernelGGL(k_win_gather, grd, dim3(64, 4), 0, st, V.wing.d, V.winbuf, ca.tab, ca.dv, ca.base, ca.bdv, ca.use_base, field_c, V.d_win, V.d_wing_box,
+                           minus_saved ? V.winold : nullptr);
     }
     const int nb = (int)V.box.size();
     int maxp = 0, maxx = 0, maxy = 0;
@@ -921,12 +948,16 @@ int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stre
     else if ((rc = hier_copy(H, l - 1, SUHMO_F_RHS0, SUHMO_F_RHS, s))) return rc;
     if ((rc = hier_axby(H, l - 1, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
     if (l == 1 && dist_base(H) && (rc = suhmo_level_exchange(base_of(H), 0, SUHMO_F_RHS, s))) return rc;      // rank strips: rhs halo rows (relaxed redundantly)
-    if ((rc = hier_copy(H, l - 1, SUHMO_F_PHIOLD, SUHMO_F_PHI, s))) return rc;
+    // the head of level l-1 before its FAS problem: level 1 reads the correction of level 0 only through the windows of its boxes,
+    // so only those cells are kept (and only their differences formed); a level of boxes keeps a copy
+    if (l - 1 == 0) rc = hier_window_save(H, l, SUHMO_F_PHI, HST(s)); else rc = hier_copy(H, l - 1, SUHMO_F_PHIOLD, SUHMO_F_PHI, s);
+    if (rc) return rc;
     if ((rc = vcycle_amr(H, l - 1, sp, s))) return rc;
     if (l - 1 == 0) std::swap(base_of(H)->d[0].fp.f[SUHMO_F_RHS], base_of(H)->d[0].fp.f[SUHMO_F_RHS0]);
     else if ((rc = hier_copy(H, l - 1, SUHMO_F_RHS, SUHMO_F_RHS0, s))) return rc;
-    if ((rc = hier_axby(H, l - 1, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) return rc;
-    if ((rc = hier_prolong2(H, l, SUHMO_F_CORR, HST(s)))) return rc;                          // AMRProlongS_2
+    if (l - 1 == 0) rc = hier_prolong2(H, l, SUHMO_F_PHI, HST(s), true);                      // AMRProlongS_2 of phi - phi_saved
+    else if (!(rc = hier_axby(H, l - 1, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) rc = hier_prolong2(H, l, SUHMO_F_CORR, HST(s));
+    if (rc) return rc;
     if ((rc = cf_phi(H, l, s))) return rc;
     return hier_gsrb(H, l, sp->num_smooth, s);
 }
@@ -950,6 +981,7 @@ extern "C" int suhmo_hier_destroy(suhmo_hier_t *H)
         V.ff_side.release(); V.ff_corner.release(); V.push.release(); V.pbase.release(); V.cf.release(); V.pwl.release(); V.avg.release(); V.wing.release();
         V.targets.release(); V.faces.release();
         if (V.winbuf) (void)hipFree(V.winbuf);
+        if (V.winold) (void)hipFree(V.winold);
         if (V.d_win) (void)hipFree(V.d_win);
         if (V.d_wing_box) (void)hipFree(V.d_wing_box);
         if (V.d_fp) (void)hipFree(V.d_fp);
