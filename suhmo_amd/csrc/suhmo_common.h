@@ -167,6 +167,9 @@ struct suhmo_level {
     int fused_hc;               // rows per chunk of the fused kernel (0 = auto); env SUHMO_FUSED_HC
     int strips_rhs_local;       // rank strips: R phi and RES travel together, the coarse right-hand side of the halo rows is computed locally
                                 // (env SUHMO_STRIPS_RHS_LOCAL, default 1)
+    int overlap_halo;           // rank strips, streaming kernel: the halo exchange travels on a second stream while the chunks that do not
+                                // read halo rows relax; the two end chunks follow (env SUHMO_OVERLAP_HALO, default 1)
+    hipStream_t xstream; hipEvent_t xev[2]; long overlapped;   // ... its stream and events; launches that overlapped so far
     int tile_strips;            // tile kernel on rank strips (env SUHMO_TILE_STRIPS, default 1)
     int tile_chunks;            // a level that is one tile relaxes all its sweeps in one launch (env SUHMO_TILE_CHUNKS, default 1)
     int fas_rhs_in_relax;       // coarse FAS right-hand side formed by the first tile relax of the depth (env SUHMO_FAS_RHS_IN_RELAX, default 1)

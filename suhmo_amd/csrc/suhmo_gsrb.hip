@@ -114,6 +114,8 @@ struct FusedGeom {
     int jbeg, jend; // rows written: [jbeg, jend) = the strip's rows plus, on rank boundaries, the halo rows that
                     // stay valid after this launch (advanced redundantly so the next launch needs no exchange)
     int wrap_y;   // rows outside [0, ny) are periodic images (single-rank periodic y)
+    int nchl, chunk0, chunk1, edges;   // chunks of THIS launch: nchl of them starting at chunk0, or (edges) all but [chunk0, chunk1) --
+                               // a rank strip relaxes its inner chunks while the halo rows travel, the end chunks afterwards
     // FAS prolongIncrement fused into the load of phi (PROLONGNL, AMRNonLinearPoissonOpF.ChF:619-627):
     // phi(i,j) += phi_c(i/2,j/2) - phi_c_old(i/2,j/2)
     const double *pc, *pco; int Pc, gyc;
@@ -152,7 +154,8 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
     // contiguous range of tiles (adjacent chunks of one strip share 2K halo rows in its L2).
     int b = blockIdx.x, q = g.ntiles / 8, rem = g.ntiles % 8, xcd = b % 8;
     int tile = xcd * q + (xcd < rem ? xcd : rem) + b / 8;
-    int strip = tile / g.nchunks, chunk = tile % g.nchunks;
+    int strip = tile / g.nchl, chunk = tile % g.nchl;
+    chunk = g.edges ? (chunk < g.chunk0 ? chunk : g.chunk1 + (chunk - g.chunk0)) : g.chunk0 + chunk;
 
     const int t = threadIdx.x;
     const int c0 = strip * g.W;
@@ -326,8 +329,10 @@ static bool fused_ok(const suhmo_level *L, const Depth &D, int K)
     return true;
 }
 
+// part 0: the whole level.  Rank strips with the exchange in flight: part 1 = the chunks that read no halo row (returns 1 and
+// launches nothing when the geometry has none), part 2 = the first and the last chunk, then the canvases trade places.
 template <int K, int NT, bool RST = false>
-static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st)
+static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st, int part = 0)
 {
     Depth &D = L->d[depth];
     const DV &v = D.v;
@@ -368,7 +373,19 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st)
         if (g.Hc > nrows) g.Hc = nrows;
         g.nchunks = (nrows + g.Hc - 1) / g.Hc;
     }
-    g.ntiles = g.nstrips * g.nchunks;
+    g.nchl = g.nchunks; g.chunk0 = 0; g.chunk1 = g.nchunks; g.edges = 0;
+    if (part) {
+        // inner chunks [c0, c1): their rows and the 2K (+1) rows either side that they read are the strip's own (a side that is a
+        // physical boundary has no halo rows to wait for)
+        int c0 = 0, c1 = g.nchunks;
+        if (v.ext[0]) while (c0 < g.nchunks && g.jbeg + c0 * g.Hc - 2 * K - EY < 0) c0++;
+        if (v.ext[1]) while (c1 > c0 && std::min(g.jbeg + c1 * g.Hc, g.jend) - 1 + 2 * K + EY > v.ny - 1) c1--;
+        const bool ok = c1 > c0 && c1 - c0 < g.nchunks;
+        if (!ok) { if (part == 1) return 1; }
+        else if (part == 1) { g.chunk0 = c0; g.chunk1 = c1; g.nchl = c1 - c0; }
+        else { g.edges = 1; g.chunk0 = c0; g.chunk1 = c1; g.nchl = g.nchunks - (c1 - c0); }
+    }
+    g.ntiles = g.nstrips * g.nchl;
     bool selfper = v.per[1] && !(v.ext[0] || v.ext[1]);
     g.wrap_y = selfper;
     g.ylo = v.ext[0] ? g.jbeg - 2 * K - EY : (selfper ? -2 * K - EY : 0);
@@ -378,7 +395,7 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st)
     if (D.prolong_pending) {
         Depth &C = L->d[depth + 1];
         g.pc = C.fp.f[SUHMO_F_PHI]; g.pco = C.fp.f[SUHMO_F_PHIOLD]; g.Pc = C.v.P; g.gyc = C.v.gy;
-        D.prolong_pending = 0;
+        if (part != 1) D.prolong_pending = 0;
     }
     g.rres = g.rphi = nullptr; g.rP = g.rgy = 0;
     if (RST) {
@@ -390,7 +407,7 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st)
         hipLaunchKernelGGL((k_gsrb_fused<K, true, NT, false>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
     else
         hipLaunchKernelGGL((k_gsrb_fused<K, false, NT, RST>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
-    std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
+    if (part != 1) std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
     return 0;
 }
 
@@ -878,28 +895,46 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
                 if (ext) { F = E; D.phi_fresh = F; }
             }
         } else {
-            if (ext && F < 2 * K) {
-                int rc = suhmo_ensure_phi_halo(L, depth, 2 * K, st); if (rc) return rc;
+            const int nt = L->fused_nt ? L->fused_nt : ((long)D.v.nx * D.v.ny >= 8000000L ? 256 : 64);   // 0 = by size
+            bool rst = may_restrict && nt == 64 && K == 2 && it + K == sweeps;
+            // rank strip: 2K current halo rows, one more when the launch also restricts (one exchange instead of the restriction's own)
+            const int need = 2 * K + (rst && ext ? 1 : 0);
+            bool flying = false;                                           // the exchange is in flight on the second stream
+            if (ext && F < need) {
+                if (L->overlap_halo && !D.prolong_pending && D.v.ny >= 6 * need) {
+                    if (!L->xstream) {
+                        HIPCHK(hipStreamCreateWithFlags(&L->xstream, hipStreamNonBlocking));
+                        HIPCHK(hipEventCreateWithFlags(&L->xev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&L->xev[1], hipEventDisableTiming));
+                    }
+                    HIPCHK(hipEventRecord(L->xev[0], st));                 // the rows that travel are final
+                    HIPCHK(hipStreamWaitEvent(L->xstream, L->xev[0], 0));
+                    int rc2 = suhmo_ensure_phi_halo(L, depth, need, L->xstream); if (rc2) return rc2;
+                    HIPCHK(hipEventRecord(L->xev[1], L->xstream));
+                    flying = true;
+                } else { int rc2 = suhmo_ensure_phi_halo(L, depth, need, st); if (rc2) return rc2; }
                 F = D.phi_fresh;
                 if (F < 2 * K) { suhmo_set_error("internal: halo shallower than 2K"); return -4; }
             }
             int want = 2 * (sweeps - it - K) + tail;
             int E = ext ? (F - 2 * K < want ? F - 2 * K : want) : 0;
-            int rc;
-            const int nt = L->fused_nt ? L->fused_nt : ((long)D.v.nx * D.v.ny >= 8000000L ? 256 : 64);   // 0 = by size
-            bool rst = may_restrict && nt == 64 && K == 2 && it + K == sweeps;
+            int rc = 0;
             if (rst && ext) {
-                if (F < 2 * K + 1) {                                       // one exchange instead of the restriction's own
-                    int rc2 = suhmo_ensure_phi_halo(L, depth, 2 * K + 1, st); if (rc2) return rc2;
-                    F = D.phi_fresh;
-                }
                 if (F < 2 * K + 1) rst = false;
                 else { E = F - 2 * K - 1 < want ? F - 2 * K - 1 : want; E &= ~1; }
             }
-            if (rst) { rc = launch_fused<2, 64, true>(L, depth, E, st); *restricted = 1; }
-            else if (nt == 64) rc = (K == 2) ? launch_fused<2, 64>(L, depth, E, st) : launch_fused<1, 64>(L, depth, E, st);
-            else rc = (K == 2) ? launch_fused<2, 256>(L, depth, E, st) : launch_fused<1, 256>(L, depth, E, st);
+            auto launch = [&](int part) {
+                if (rst) return launch_fused<2, 64, true>(L, depth, E, st, part);
+                if (nt == 64) return (K == 2) ? launch_fused<2, 64>(L, depth, E, st, part) : launch_fused<1, 64>(L, depth, E, st, part);
+                return (K == 2) ? launch_fused<2, 256>(L, depth, E, st, part) : launch_fused<1, 256>(L, depth, E, st, part);
+            };
+            if (flying) {
+                rc = launch(1);                                            // the chunks that read no halo row: now
+                if (rc < 0) return rc;
+                HIPCHK(hipStreamWaitEvent(st, L->xev[1], 0));              // the halo rows have arrived
+                if (rc == 1) rc = launch(0); else { rc = launch(2); L->overlapped++; }
+            } else rc = launch(0);
             if (rc) return rc;
+            if (rst) *restricted = 1;
             if (ext) { F = E; D.phi_fresh = F; }
         }
         int done = TS ? TS * tchunks : K == 0 ? 1 : K;

@@ -154,6 +154,8 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     L->fas_rhs_in_relax = 1;
     L->tile_chunks = 1;
     L->tile_strips = 1;
+    L->overlap_halo = 1; L->xstream = nullptr; L->xev[0] = L->xev[1] = nullptr; L->overlapped = 0;
+    if (const char *e = getenv("SUHMO_OVERLAP_HALO")) L->overlap_halo = atoi(e);
     L->strips_rhs_local = 1;
     if (const char *e = getenv("SUHMO_STRIPS_RHS_LOCAL")) L->strips_rhs_local = atoi(e);
     if (const char *e = getenv("SUHMO_TILE_STRIPS")) L->tile_strips = atoi(e);
@@ -242,6 +244,7 @@ extern "C" int suhmo_level_destroy(suhmo_level_t *L)
     for (int dep = 0; dep < L->ndepth; dep++)
         if (L->d[dep].phi_alt) (void)hipFree(L->d[dep].phi_alt);
     for (auto &pe : L->prof) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    if (L->xstream) { (void)hipStreamDestroy(L->xstream); (void)hipEventDestroy(L->xev[0]); (void)hipEventDestroy(L->xev[1]); }
     (void)hipFree(L->scratch);
     (void)hipHostFree(L->hscratch);
     delete L;
@@ -288,7 +291,7 @@ static int *option_slot_int(suhmo_level *L, const char *key)
     static const struct { const char *k; int suhmo_level::*m; } tab[] = {
         {"gsrb_variant", &suhmo_level::gsrb_variant}, {"fused_hc", &suhmo_level::fused_hc}, {"bcoef_fused", &suhmo_level::bcoef_fused},
         {"fused_nt", &suhmo_level::fused_nt}, {"fused_restrict", &suhmo_level::fused_restrict}, {"strips_rhs_local", &suhmo_level::strips_rhs_local},
-        {"tile_strips", &suhmo_level::tile_strips}, {"tile_chunks", &suhmo_level::tile_chunks}, {"fas_rhs_in_relax", &suhmo_level::fas_rhs_in_relax},
+        {"tile_strips", &suhmo_level::tile_strips}, {"overlap_halo", &suhmo_level::overlap_halo}, {"tile_chunks", &suhmo_level::tile_chunks}, {"fas_rhs_in_relax", &suhmo_level::fas_rhs_in_relax},
         {"tile_s", &suhmo_level::tile_s}, {"gsrb_tile", &suhmo_level::gsrb_tile}, {"tile_t", &suhmo_level::tile_t}, {"poll_readback", &suhmo_level::poll_readback}};
     for (const auto &e : tab) if (!strcmp(key, e.k)) return &(L->*(e.m));
     return nullptr;
@@ -311,6 +314,7 @@ extern "C" int suhmo_level_get_option(const suhmo_level_t *L, const char *key, l
     ARG(L && key && value);
     if (long *p = option_slot_long(const_cast<suhmo_level *>(L), key)) { *value = *p; return 0; }
     if (int *p = option_slot_int(const_cast<suhmo_level *>(L), key)) { *value = *p; return 0; }
+    if (!strcmp(key, "overlapped_launches")) { *value = L->overlapped; return 0; }       // read-only counter (overlap_halo)
     suhmo_set_error("unknown option '%s'", key);
     return -1;
 }

@@ -115,11 +115,14 @@ def test_strips_gsrb_and_operators(case, variant, halo, monkeypatch):
 
 
 @pytest.mark.parametrize("world,halo,fused", [(2, 4, 0), (4, 4, 0), (2, 16, 0), (4, 9, 0), (2, 16, 1), (4, 12, 1), (2, 24, 0), (2, 24, 1), (4, 24, 1), (2, 1, 0),
-                                              (2, 24, "no-tile"), (4, 12, "no-tile"), (2, 24, "rhs-exchanged"), (2, 24, "copy-readback")])
+                                              (2, 24, "no-tile"), (4, 12, "no-tile"), (2, 24, "rhs-exchanged"), (2, 24, "copy-readback"),
+                                              (2, 16, "overlap"), (4, 12, "overlap"), (2, 16, "no-overlap")])
 def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
     """strips of 2 / 4 ranks against the oracle's whole level, bitwise.  Halo >= 10 rows: the tile kernel relaxes the strips
     (halo rows advanced redundantly), R phi + RES travel together and the halo rows' right-hand side is computed locally; the
-    named variants keep the paths they replace covered (colour passes, exchanged RHS, copy + synchronise read-back)"""
+    named variants keep the paths they replace covered (colour passes, exchanged RHS, copy + synchronise read-back).
+    "overlap": streaming kernel with chunks tall enough that the halo exchange travels on the second stream while the inner
+    chunks relax, the two end chunks after it (what a 4096^2 strip does); "no-overlap": the same launches, exchange first"""
     from suhmo_amd import level as lv
     if fused == 1:
         monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "4000")     # fused K=2 launches down to 64 x 64 strips
@@ -130,6 +133,11 @@ def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
         monkeypatch.setenv("SUHMO_STRIPS_RHS_LOCAL", "0")
     elif fused == "copy-readback":
         monkeypatch.setenv("SUHMO_POLL_READBACK", "0")
+    elif fused in ("overlap", "no-overlap"):
+        monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "4000")
+        monkeypatch.setenv("SUHMO_GSRB_TILE", "0")
+        monkeypatch.setenv("SUHMO_FUSED_HC", "16" if world == 4 else "32")
+        monkeypatch.setenv("SUHMO_OVERLAP_HALO", "1" if fused == "overlap" else "0")
     f = sy.shmip_fields(256, 256)
     bc, ph = sy.A3_BC, sy.A3_PHYS
     sp = dict(sy.SOLVER_DEFAULT, eps=1e-10, norm_thresh=1e-13, max_iter=4, imin=4)
@@ -139,9 +147,13 @@ def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
         G.vcycle(sp)
         p1 = G.get(lv.F_PHI)
         n, hist = G.solve(sp)
-        return p1, G.get(lv.F_PHI), n, hist, G.ndepth
+        return p1, G.get(lv.F_PHI), n, hist, G.ndepth, G.get_option("overlapped_launches")
 
     parts = run_strips(world, f, bc, ph, 0.0, -1.0, body, halo=halo, max_box=64)
+    if fused == "overlap":
+        assert all(p[5] > 0 for p in parts), [p[5] for p in parts]
+    elif fused == "no-overlap":
+        assert all(p[5] == 0 for p in parts)
     O = oracle.OracleLevel(256, 256, f["dx"], f["dy"], bc, ph, 0.0, -1.0, 64, 4)
     O.set_inputs(f)
     O.build_mg_coefficients()
