@@ -15,8 +15,30 @@ def main():
     ap.add_argument("--warm", type=int, default=60)
     ap.add_argument("--timers", action="store_true")
     ap.add_argument("--amr", action="store_true")
+    ap.add_argument("--vcycle", action="store_true", help="V-cycles and residual norms alone on the 320 x 64 level")
     a = ap.parse_args()
     m = sy.A3_MODEL
+    if a.vcycle:
+        from suhmo_amd import level
+        f = sy.shmip_fields(m["nx"], m["ny"], lx=m["lx"], ly=m["ly"])
+        G = level.HipLevel(m["nx"], m["ny"], f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64)
+        G.set_inputs(f); G.build_mg_coefficients()
+        sp = dict(sy.SOLVER_DEFAULT)
+        for _ in range(20):
+            G.vcycle(sp)
+        G.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            G.vcycle(sp)
+        G.synchronize()
+        tv = (time.perf_counter() - t0) / a.steps
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            G.residual(); G.norm(level.F_RES, 0)
+        tn = (time.perf_counter() - t0) / a.steps
+        print("320x64: %.1f us per V-cycle (graph replay, %d depths), %.1f us per residual + max norm (read back)" % (1e6 * tv, G.ndepth, 1e6 * tn))
+        G.close()
+        return
     if not a.amr:
         st = sy.shmip_initial_state(m["nx"], m["ny"], m["lx"], m["ly"])
         M = model.HipModel(m["nx"], m["ny"], st["dx"], st["dy"], sy.A3_BC, sy.A3_PHYS, m, max_box=64)
