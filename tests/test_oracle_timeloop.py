@@ -206,3 +206,49 @@ def test_suite_e_live_pin_and_the_margin_leak():
     # the source as it is: gap height leaks into the ice-free cells next to the ice (here after 1500 of the 5000 steps)
     icefree = tables["mask"] < 0
     assert np.max(tables["pin_B"][icefree]) <= 1.0e-16 and np.max(tables["nofreeze_B"][icefree]) > 1.0e-4
+
+
+# SUITE F (the valley glacier of suite E under a seasonal temperature cycle, exec/F_SHMIP/F<k>: 8000 steps of 1 h to the steady state
+# of the background input, then 21960 steps of 2 h = five years with COMPUTE_TIMEVARYINGRECHARGE every step; the reference commits
+# the DAILY series of the mean effective pressure -- whole glacier and three bands --, the recharge and the discharge at the outlet:
+# 1830 rows).  This is the only TRANSIENT the reference holds results for: every other table is a steady state.  The run that wrote
+# the tables had, read off the numbers as for suites A / B / E: no melt term in RHS_h (discharge = ext + rho_w / rho_i melt in winter),
+# the masked gradients and the masked gap-height right-hand side ON although the F inputs do not set them (the first rows fit to
+# 1e-5 / 1e-7 only with both), the ice-free cells' gap height frozen (as suite E) -- and the SURFACE elevation in the iceHeight field
+# that the recharge's lapse rate reads, where the committed ValleyIBC ends with the ice thickness (src/ValleyIBC.cpp:299; the summer
+# recharge is 2.5 x larger with the thickness).  With these (tools/run_shmip_f.py --head-melt-coef 0 --freeze-icefree --mask-gradients 1
+# --mask-rhs-b 1 --zs surface) the oracle follows all five five-year series to print precision:
+FCASES = ["F1", "F2", "F3", "F4", "F5"]
+F_TOL = {2: 5e-7, 3: 5e-7, 4: 5e-7, 5: 5e-7, 6: 1e-6, 7: 3e-5}       # avgN, N_LB, N_MB, N_HB, recharge, discharge: of the column's scale
+
+
+@pytest.mark.parametrize("case", FCASES)
+def test_oracle_follows_the_suite_f_time_series(case):
+    import json
+    ref = np.loadtxt(os.path.join(GOLD, "shmip_%s_postproc_reference.dat" % case))
+    got = np.loadtxt(os.path.join(GOLD, "shmip_%s_oracle_pin_table.dat" % case))
+    meta = json.load(open(os.path.join(GOLD, "shmip_%s_oracle_pin.json" % case)))
+    assert ref.shape == (1830, 8) and got.shape[0] == 1830
+    assert (meta["head_melt_coef"], meta["mask_gradients"], meta["mask_rhs_b"], meta["freeze_icefree"], meta["zs"], meta["spinup_steps"]) == ("0", 1, 1, True, "surface", 8000)
+    assert np.array_equal(got[:, :2], ref[:, :2])                          # hours and days of the rows
+    for c, tol in F_TOL.items():
+        sc = np.max(np.abs(ref[:, c]))
+        assert np.max(np.abs(got[:, c] - ref[:, c])) <= tol * sc, (case, c, np.max(np.abs(got[:, c] - ref[:, c])) / sc)
+    assert ref[:, 7].max() > 800.0 * ref[0, 7]          # a transient it is: the discharge swings over three orders of magnitude within a year
+
+
+def test_suite_f_oracle_live():
+    """the oracle of today against the oracle that wrote the pin tables: the first 28 days of F1 without the spin-up (a committed
+    fixture of the oracle's own output), through tools/run_shmip_f.py as the tables were made"""
+    import subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "f1.json")
+        env = dict(os.environ, OMP_NUM_THREADS="4")
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", "run_shmip_f.py"), "oracle", "F1", "0.08", out, "--spinup-steps", "0", "--head-melt-coef", "0",
+                            "--freeze-icefree", "--mask-gradients", "1", "--mask-rhs-b", "1", "--zs", "surface"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode()[-2000:]
+        got = np.loadtxt(out.replace(".json", "_table.dat"))
+    want = np.loadtxt(os.path.join(GOLD, "shmip_F1_oracle_nospin_table.dat"))
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-300)) <= 1e-9         # %.10g in the file
