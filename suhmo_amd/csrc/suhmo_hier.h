@@ -25,6 +25,7 @@ int suhmo_multi_bcoef_faces(const suhmo_multi &m, const suhmo_phys_t &ph, hipStr
 int suhmo_multi_coef_ghosts(const suhmo_multi &m, int field, hipStream_t st);
 int suhmo_multi_axby(const suhmo_multi &m, int fd, int fx, int fy, double a, double b, hipStream_t st);
 int suhmo_multi_copy(const suhmo_multi &m, int fd, int fs, hipStream_t st);                                               // valid cells + ghost ring
+int suhmo_multi_copy_between(const suhmo_multi &dst, const suhmo_multi &src, const int *fd, const int *fs, int n, hipStream_t st);   // same boxes, two hierarchies
 int suhmo_multi_norm_max(const suhmo_multi &m, suhmo_level *slot, int field, double *out, hipStream_t st);                // max |x| over the valid cells of all boxes
 int suhmo_hier_multi_(suhmo_hier *H, int l, hipStream_t st, suhmo_multi *m);       // l >= 1
 int suhmo_hier_ensure_(suhmo_hier *H, int l, int field);                            // allocate a field on every box of a level

@@ -1725,6 +1725,16 @@ __global__ void k_copy_m(const DV *__restrict__ vt, const FP *__restrict__ ft, i
     int idx = cidx(v, i, j);
     ft[blockIdx.z].f[fd][idx] = ft[blockIdx.z].f[fs][idx];
 }
+// fields of the boxes of one hierarchy <- fields of the same boxes of another (the implicit gap-height operator's copy of a level)
+struct CopyPairs { int n, fd[4], fs[4]; };
+__global__ void k_copy_between_m(const DV *__restrict__ vt, const FP *__restrict__ fdst, const FP *__restrict__ fsrc, CopyPairs cp)
+{
+    const DV &v = vt[blockIdx.z];
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1, j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+    if (i > v.nx || j > v.ny) return;
+    int idx = cidx(v, i, j);
+    for (int q = 0; q < cp.n; q++) fdst[blockIdx.z].f[cp.fd[q]][idx] = fsrc[blockIdx.z].f[cp.fs[q]][idx];
+}
 __global__ __launch_bounds__(256) void k_norm_max_partial_m(const DV *__restrict__ vt, const FP *__restrict__ ft, int field, double *__restrict__ partial)
 {
     __shared__ double sm[256];
@@ -1794,6 +1804,16 @@ int suhmo_multi_axby(const suhmo_multi &m, int fd, int fx, int fy, double a, dou
 int suhmo_multi_copy(const suhmo_multi &m, int fd, int fs, hipStream_t st)
 {
     hipLaunchKernelGGL(k_copy_m, grid_m(m, 2, 2), BLK2D, 0, st, m.dv, m.fp, fd, fs);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int suhmo_multi_copy_between(const suhmo_multi &dst, const suhmo_multi &src, const int *fd, const int *fs, int n, hipStream_t st)
+{
+    if (n < 1 || n > 4 || dst.nbox != src.nbox) { suhmo_set_error("internal: copy between hierarchies"); return -4; }
+    CopyPairs cp;
+    cp.n = n;
+    for (int q = 0; q < n; q++) { cp.fd[q] = fd[q]; cp.fs[q] = fs[q]; }
+    hipLaunchKernelGGL(k_copy_between_m, grid_m(src, 2, 2), BLK2D, 0, st, src.dv, dst.fp, src.fp, cp);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -821,6 +821,16 @@ extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *
         if ((rc = suhmo_hier_gap_(H, mp, dt, &G))) return rc;
         for (int l = 0; l < nlev; l++) {
             const auto &hb = suhmo_hier_boxes_(H, l), &gb = suhmo_hier_boxes_(G, l);
+            if (l > 0) {                                               // all boxes of a level: one launch
+                static const int fd[4] = {SUHMO_F_PHI, SUHMO_F_RHS, SUHMO_F_BX, SUHMO_F_BY}, fs[4] = {SUHMO_F_B, SUHMO_F_RES, SUHMO_F_DCX, SUHMO_F_DCY};
+                for (int f : fs) if ((rc = suhmo_hier_ensure_(H, l, f))) return rc;
+                for (int f : fd) if ((rc = suhmo_hier_ensure_(G, l, f))) return rc;
+                suhmo_multi mh, mg;
+                if ((rc = suhmo_hier_multi_(H, l, st, &mh)) || (rc = suhmo_hier_multi_(G, l, st, &mg))) return rc;
+                if ((rc = suhmo_multi_copy_between(mg, mh, fd, fs, 4, st))) return rc;                                     // initial guess = b :3382-3385
+                for (suhmo_level *L : gb) L->d[0].phi_fresh = 0;
+                continue;
+            }
             for (size_t k = 0; k < hb.size(); k++) {
                 Depth &D = hb[k]->d[0], &GD = gb[k]->d[0];
                 if (GD.elems != D.elems) { suhmo_set_error("internal: gap hierarchy geometry"); return -4; }
@@ -840,8 +850,14 @@ extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *
         if ((rc = suhmo_hier_solve(G, &spg, nullptr, nullptr, s))) return rc;
         for (int l = 0; l < nlev; l++) {
             const auto &hb = suhmo_hier_boxes_(H, l), &gb = suhmo_hier_boxes_(G, l);
-            for (size_t k = 0; k < hb.size(); k++)
-                HIPCHK(hipMemcpyAsync(hb[k]->d[0].fp.f[SUHMO_F_B], gb[k]->d[0].fp.f[SUHMO_F_PHI], hb[k]->d[0].elems * sizeof(double), hipMemcpyDeviceToDevice, st));
+            if (l > 0) {
+                static const int fd[1] = {SUHMO_F_B}, fs[1] = {SUHMO_F_PHI};
+                suhmo_multi mh, mg;
+                if ((rc = suhmo_hier_multi_(H, l, st, &mh)) || (rc = suhmo_hier_multi_(G, l, st, &mg))) return rc;
+                if ((rc = suhmo_multi_copy_between(mh, mg, fd, fs, 1, st))) return rc;
+            } else
+                for (size_t k = 0; k < hb.size(); k++)
+                    HIPCHK(hipMemcpyAsync(hb[k]->d[0].fp.f[SUHMO_F_B], gb[k]->d[0].fp.f[SUHMO_F_PHI], hb[k]->d[0].elems * sizeof(double), hipMemcpyDeviceToDevice, st));
             if ((rc = hier_gap_ghosts(H, l, st))) return rc;
         }
     }
