@@ -158,6 +158,25 @@ class TorchDistTransport:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
+    def allgather(self, rank, send, count, recv):
+        """raw device pointers (the hierarchy's shadow refresh): staged through tensors the backend can move"""
+        torch = self.torch
+        key = ("ag", count)
+        if key not in self._ops:
+            world = self.dist.get_world_size(self.group)
+            self._ops[key] = (torch.empty(count, dtype=torch.float64, device=self.device),
+                              [torch.empty(count, dtype=torch.float64, device=self.device) for _ in range(world)])
+            import ctypes
+            self._hip = ctypes.CDLL("libamdhip64.so")
+            self._hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        ts, tr = self._ops[key]
+        torch.cuda.synchronize()
+        assert self._hip.hipMemcpy(ts.data_ptr(), send, count * 8, 3) == 0
+        self.dist.all_gather(tr, ts, group=self.group)
+        torch.cuda.synchronize()
+        for r, t in enumerate(tr):
+            assert self._hip.hipMemcpy(recv + r * count * 8, t.data_ptr(), count * 8, 3) == 0
+
 
 class ThreadTransport:
     """N ranks = N threads of one process sharing one GPU (test harness).  Buffers are raw
@@ -269,6 +288,19 @@ def attach(level, dist, rank, world, periodic_y=False):
     level._exchanger = ex
     ex.exchange_static()
     return ex
+
+
+def attach_hier(hier, dist, rank, world):
+    """A hierarchy of box unions whose level 0 is this rank's strip: halo rows of level 0 as attach() does, and the all-gather of
+    the coarse cells level 1 reads on the same transport (native RCCL: ncclAllGather on the strip's communicator).  COLLECTIVE."""
+    base = hier.level[0][0]
+    ex = attach(base, dist, rank, world, False)
+    if ex == base or getattr(base, "_exchanger", None) == "rccl":
+        check(capi.lib().suhmo_hier_attach_rccl(hier.h))
+        hier._gather = "rccl"
+    else:
+        hier._gather = HierGather(hier, ex.tr, rank)
+    return hier
 
 
 def attach_amr(levels, ranges, dist, rank, world):

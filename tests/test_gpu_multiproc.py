@@ -1,7 +1,8 @@
 """N > 1 as separate processes.  (a) `python bench.py --gpus 2` with no launcher: the parent starts its two rank processes
 itself (it never touches the GPU) and rank 0's JSON line comes back -- rehearsed here with the gloo backend, both ranks on
 the one GPU of the test box, weak and strong scaling.  (b) two ranks over the real nccl (= RCCL) backend, one GPU each, stepping
-SHMIP A3 bit for bit against the single-process run: skipped unless the box has two GPUs."""
+SHMIP A3 -- and cfg5 on a hierarchy of box unions (ncclAllGather of the coarse cells level 1 reads) -- bit for bit against the
+single-process run: skipped unless the box has two GPUs."""
 import json
 import os
 import subprocess
@@ -36,7 +37,9 @@ def test_bench_refuses_a_world_that_is_not_gpus():
     assert p.returncode != 0 and b"WORLD_SIZE" in p.stderr
 
 
-def test_two_ranks_over_nccl_bitwise():
+@pytest.mark.parametrize("tool,args", [("shmip_dist.py", ["--case", "A3", "--scale", "2", "--steps", "6", "--check"]),
+                                       ("hier_dist.py", ["--base", "256", "--steps", "2", "--check"])])
+def test_two_ranks_over_nccl_bitwise(tool, args):
     from suhmo_amd import capi
     if capi.lib().suhmo_device_count() < 2:
         pytest.skip("needs two GPUs (ncclSend / ncclRecv between distinct devices)")
@@ -48,18 +51,19 @@ def test_two_ranks_over_nccl_bitwise():
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    SUHMO_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "shmip_dist.py"), "--case", "A3", "--scale", "2", "--steps", "6", "--check"],
-                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", tool)] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     assert "BITWISE EQUAL" in logs[0]
 
 
 @pytest.mark.parametrize("tool,args,world", [("amr_shmip_dist.py", ["--case", "B5", "--steps", "6", "--check"], 2),
-                                             ("shmip_dist.py", ["--case", "B3", "--scale", "1", "--steps", "6", "--check"], 4)])
+                                             ("shmip_dist.py", ["--case", "B3", "--scale", "1", "--steps", "6", "--check"], 4),
+                                             ("hier_dist.py", ["--base", "256", "--steps", "2", "--check"], 2)])
 def test_rank_strips_as_processes(tool, args, world):
     """cfg4: SHMIP B5 (100 moulins, diffusion, implicit gap-height solve) on a 3-level AMR hierarchy cut into the strips of 2
-    processes, and B3 single-level on 4 processes (gloo, all ranks on the one GPU of the test box): every level's head, gap
+    processes, B3 single-level on 4 processes, and cfg5 (base 256^2 + 3 levels of ~65 boxes each, 63 moulins) with level 0 cut into
+    the strips of 2 processes and the boxes on both (gloo, all ranks on the one GPU of the test box): every level's head, gap
     height and melt rate equal the single-process run bit for bit (the tool's --check)"""
     import socket
     with socket.socket() as so:
