@@ -846,14 +846,6 @@ int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
     if (sweeps > 0 && (rc = suhmo_multi_fill_ghosts(m, SUHMO_F_PHI, 1, HST(s)))) return rc;                        // :757-759
     return 0;
 }
-int hier_apply(suhmo_hier *H, int l, suhmo_stream_t s)        // applyOpI, inhomogeneous: LPHI
-{
-    if (l == 0) return suhmo_level_apply_op(base_of(H), 0, 0, s);
-    int rc;
-    suhmo_multi m;
-    if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s))) || (rc = ensure_field(H, l, SUHMO_F_LPHI)) || (rc = multi_of(H, l, HST(s), m))) return rc;
-    return suhmo_multi_apply(m, phys_of(H, l), has_alpha(H, l), 0, HST(s));
-}
 int hier_level_residual(suhmo_hier *H, int l, suhmo_stream_t s)   // residualI: RES
 {
     if (l == 0) return suhmo_level_residual(base_of(H), 0, s);

@@ -148,48 +148,8 @@ __global__ __launch_bounds__(256) void k_melt_m(const DV *__restrict__ vt, const
     d_melt<MODE>(vt[blockIdx.z], ft[blockIdx.z], ph, mp, dt);
 }
 
-// max over valid cells (signed) and max |(a - b) / s|: Picard convergence test, :3169-3185
+// Picard convergence test, :3169-3185
 struct Excl { int i0, j0, i1, j1; };       // local cells [i0, i1) x [j0, j1) do not count (covered by a finer level)
-__global__ __launch_bounds__(256) void k_picard_partial(DV v, const double *__restrict__ h, const double *__restrict__ hl,
-                                                        double scale, int mode, double *__restrict__ partial, Excl ex)
-{
-    __shared__ double sm[256];
-    int tid = threadIdx.y * blockDim.x + threadIdx.x;
-    double acc = mode == 0 ? -1.0e300 : 0.0;
-    for (int j = blockIdx.y * blockDim.y + threadIdx.y; j < v.ny; j += gridDim.y * blockDim.y)
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.nx; i += gridDim.x * blockDim.x) {
-            if (i >= ex.i0 && i < ex.i1 && j >= ex.j0 && j < ex.j1) continue;
-            int idx = cidx(v, i, j);
-            double val = mode == 0 ? h[idx] : fabs((hl[idx] - h[idx]) / scale);
-            acc = fmax(acc, val);
-        }
-    sm[tid] = acc;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = fmax(sm[tid], sm[tid + s]); __syncthreads(); }
-    if (tid == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = sm[0];
-}
-__global__ void k_max_final(const double *__restrict__ partial, int n, double *__restrict__ out, HostSlot hs)
-{
-    __shared__ double sm[256];
-    int tid = threadIdx.x;
-    double acc = -1.0e300;
-    for (int k = tid; k < n; k += 256) acc = fmax(acc, partial[k]);
-    sm[tid] = acc;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = fmax(sm[tid], sm[tid + s]); __syncthreads(); }
-    if (tid == 0) { out[0] = sm[0]; suhmo_publish(hs, sm[0]); }
-}
-static int reduce_max(suhmo_level *L, const double *h, const double *hl, double scale, int mode, double *out, hipStream_t st,
-                      Excl ex = Excl{0, 0, 0, 0}, bool local_only = false)
-{
-    Depth &D = L->d[0];
-    dim3 grd(std::min((D.v.nx + 63) / 64, 32), std::min((D.v.ny + 3) / 4, 128));
-    hipLaunchKernelGGL(k_picard_partial, grd, dim3(64, 4), 0, st, D.v, h, hl, scale, mode, L->scratch + 1, ex);
-    hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, st, L->scratch + 1, (int)(grd.x * grd.y), L->scratch, suhmo_host_slot(L));
-    { int rc = suhmo_readback(L, st, out); if (rc) return rc; }
-    if (!local_only && L->ar && (D.v.ext[0] || D.v.ext[1])) { int rc = L->ar(L->user, out); if (rc) return rc; }   // computeMax / norm over all ranks
-    return 0;
-}
 static int exchange1(suhmo_level *L, int f, hipStream_t st) { return suhmo_exchange_list(L, 0, &f, 1, st); }
 // Both numbers of the Picard test in one pass and one read-back: max h and max |h_lagged - h|.  The reference's
 // max |(h_lagged - h) / maxHead| is the second divided by |maxHead| afterwards: a correctly rounded division by a fixed

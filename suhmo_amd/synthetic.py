@@ -166,6 +166,22 @@ def shmip_amrm_states(nx0, ny0, boxes, **kw):
     return out
 
 
+def wrap_ghosts(f, bc):
+    """periodic directions: caller-side ghost data must be the periodic image (what Chombo's
+    exchange would have put there), otherwise 'one box' and 'several ranks' see different input"""
+    for k in ("B", "Pi", "zb", "mask"):
+        a = f[k]
+        if bc["periodic"][1]:
+            a[0, :], a[-1, :] = a[-2, :].copy(), a[1, :].copy()
+        if bc["periodic"][0]:
+            a[:, 0], a[:, -1] = a[:, -2].copy(), a[:, 1].copy()
+    if "by" in f and bc["periodic"][1]:
+        f["by"][-1, :] = f["by"][0, :]        # the same physical face
+    if "bx" in f and bc["periodic"][0]:
+        f["bx"][:, -1] = f["bx"][:, 0]
+    return f
+
+
 def shmip_postproc_table(dx, dy, qwx, cd, src, mR, Pw, Pi, mask, rho_w=1000.0):
     """The SHMIP cross-section table of AmrHydro::timeStepFAS (src/AmrHydro.cpp:3647-4102), columns of
     exec/*_SHMIP/*/results/postproc.dat: x[km], Ylength, discharge, dischargeEFF, dischargeINEFF,

@@ -24,20 +24,7 @@ def split_fields(f, j0, ny):
     return s
 
 
-def wrap_ghosts(f, bc):
-    """periodic directions: caller-side ghost data must be the periodic image (what Chombo's
-    exchange would have put there), otherwise 'one box' and 'several ranks' see different input"""
-    for k in ("B", "Pi", "zb", "mask"):
-        a = f[k]
-        if bc["periodic"][1]:
-            a[0, :], a[-1, :] = a[-2, :].copy(), a[1, :].copy()
-        if bc["periodic"][0]:
-            a[:, 0], a[:, -1] = a[:, -2].copy(), a[:, 1].copy()
-    if "by" in f and bc["periodic"][1]:
-        f["by"][-1, :] = f["by"][0, :]        # the same physical face
-    if "bx" in f and bc["periodic"][0]:
-        f["bx"][:, -1] = f["bx"][:, 0]
-    return f
+wrap_ghosts = sy.wrap_ghosts
 
 
 def run_strips(world, f, bc, ph, alpha, beta, body, halo=4, max_box=32):

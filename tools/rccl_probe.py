@@ -16,7 +16,7 @@ print("vcycle ok, exchanges", capi.lib().suhmo_level_rccl_exchanges(S.h))
 
 # cost of the exchanges: 4096^2 whole periodic level vs the same level as a self-neighbour strip
 import time
-from tests_helpers import wrap_ghosts
+wrap_ghosts = sy.wrap_ghosts
 n = int(os.environ.get("PROBE_N", "4096"))
 f = wrap_ghosts(sy.shmip_fields(n, n), sy.CONV_BC)
 W = level.HipLevel(n, n, f["dx"], f["dy"], sy.CONV_BC, sy.A3_PHYS, 0.0, -1.0, 64)
