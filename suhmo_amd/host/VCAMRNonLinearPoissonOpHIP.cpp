@@ -25,8 +25,77 @@ HeadSolverParameters::HeadSolverParameters(int a_cur_step, bool a_bcoeff_otf)
 VCAMRNonLinearPoissonOpHIPFactory::VCAMRNonLinearPoissonOpHIPFactory() : m_level(nullptr), m_update_operator(true) {}
 VCAMRNonLinearPoissonOpHIPFactory::~VCAMRNonLinearPoissonOpHIPFactory()
 {
+    if (m_hier) suhmo_hier_destroy(m_hier);
     if (m_fine) suhmo_level_destroy(m_fine);
     if (m_level) suhmo_level_destroy(m_level);
+}
+
+// a LevelData of one AMR level of the hierarchy <-> the device: level 0 box by box into the base handle, a level >= 1 box k into
+// the level handle of that box (ghost cells included: a box of a union keeps its own ghost ring)
+static void hier_io(suhmo_hier_t *H, int l, int field, LevelData<FArrayBox> &ld, bool to_device)
+{
+    const DisjointBoxLayout &g = ld.disjointBoxLayout();
+    for (int k = 0; k < g.size(); k++) {
+        FArrayBox &f = ld[k];
+        const Box &fb = f.box();
+        if (l == 0) {
+            suhmo_level_t *B = suhmo_hier_box(H, 0, 0);
+            if (to_device) chk(suhmo_level_put_box(B, 0, field, k, f.dataPtr(), fb.lo[0], fb.lo[1], fb.hi[0], fb.hi[1], ld.ghost() > 0, nullptr), "hierarchy: put_box");
+            else chk(suhmo_level_get_box(B, 0, field, k, f.dataPtr(), fb.lo[0], fb.lo[1], fb.hi[0], fb.hi[1], nullptr), "hierarchy: get_box");
+        } else {
+            suhmo_level_t *B = suhmo_hier_box(H, l, k);
+            if (!B || ld.ghost() > 1) MayDay::Error("hierarchy: box / ghost width");
+            if (to_device) chk(suhmo_level_set_field(B, 0, field, f.dataPtr(), ld.ghost() > 0, 0, nullptr), "hierarchy: set_field");
+            else chk(suhmo_level_get_field(B, 0, field, f.dataPtr(), ld.ghost() > 0, 0, nullptr), "hierarchy: get_field");
+        }
+    }
+}
+
+void VCAMRNonLinearPoissonOpHIPFactory::defineHierarchy(const ProblemDomain &a_dom, const std::vector<DisjointBoxLayout> &a_grids, const RealVect &a_dx,
+                                                        const suhmo_bc_t &a_bc, const Real &a_alpha, const Real &a_beta, const suhmo_phys_t &a_phys,
+                                                        const std::vector<LevelData<FArrayBox> *> &a_aCoef, const std::vector<LevelData<FArrayBox> *> &a_B,
+                                                        const std::vector<LevelData<FArrayBox> *> &a_Pi, const std::vector<LevelData<FArrayBox> *> &a_zb,
+                                                        const std::vector<LevelData<FArrayBox> *> &a_iceMask, int a_device)
+{
+    const int nlev = (int)a_grids.size();
+    if (nlev < 1 || (int)a_aCoef.size() != nlev || (int)a_B.size() != nlev || (int)a_Pi.size() != nlev || (int)a_zb.size() != nlev || (int)a_iceMask.size() != nlev)
+        MayDay::Error("defineHierarchy: one layout and one set of coefficients per level");
+    if (m_hier) { suhmo_hier_destroy(m_hier); m_hier = nullptr; }
+    suhmo_level_desc_t d = {};
+    d.nx = a_dom.dom.size(0); d.ny = a_dom.dom.size(1); d.j0 = 0; d.ny_global = d.ny;
+    d.dx = a_dx[0]; d.dy = a_dx[1];
+    std::vector<int> base;
+    for (int k = 0; k < a_grids[0].size(); k++) { const Box &b = a_grids[0][k]; base.insert(base.end(), {b.lo[0], b.lo[1], b.hi[0], b.hi[1]}); }
+    d.nbox = a_grids[0].size(); d.boxes = base.data(); d.max_box = 0;
+    d.alpha = a_alpha; d.beta = a_beta; d.bc = a_bc; d.phys = a_phys; d.device = a_device; d.halo_rows = 1;
+    std::vector<int> nbox(nlev, 0), boxes;
+    for (int l = 1; l < nlev; l++) {
+        nbox[l] = a_grids[l].size();
+        for (int k = 0; k < a_grids[l].size(); k++) { const Box &b = a_grids[l][k]; boxes.insert(boxes.end(), {b.lo[0], b.lo[1], b.hi[0], b.hi[1]}); }
+    }
+    chk(suhmo_hier_create(&m_hier, &d, nlev, nbox.data(), boxes.data()), "VCAMRNonLinearPoissonOpHIPFactory::defineHierarchy");
+    m_hierGrids = a_grids;
+    for (int l = 0; l < nlev; l++) {
+        hier_io(m_hier, l, SUHMO_F_ACOEF, *a_aCoef[l], true); hier_io(m_hier, l, SUHMO_F_B, *a_B[l], true); hier_io(m_hier, l, SUHMO_F_PI, *a_Pi[l], true);
+        hier_io(m_hier, l, SUHMO_F_ZB, *a_zb[l], true); hier_io(m_hier, l, SUHMO_F_MASK, *a_iceMask[l], true);
+    }
+    chk(suhmo_level_build_mg_coefficients(suhmo_hier_box(m_hier, 0, 0), nullptr), "MGnewOp coefficient coarsening");
+}
+
+int VCAMRNonLinearPoissonOpHIPFactory::solveHierarchy(std::vector<LevelData<FArrayBox> *> &a_phi, const std::vector<LevelData<FArrayBox> *> &a_rhs,
+                                                      const HeadSolverParameters &a_sp, std::vector<Real> *a_hist)
+{
+    if (!m_hier || a_phi.size() != m_hierGrids.size() || a_rhs.size() != m_hierGrids.size()) MayDay::Error("solveHierarchy: defineHierarchy first, one phi and rhs per level");
+    for (size_t l = 0; l < a_phi.size(); l++) {
+        hier_io(m_hier, (int)l, SUHMO_F_PHI, *a_phi[l], true);
+        hier_io(m_hier, (int)l, SUHMO_F_RHS, *const_cast<LevelData<FArrayBox> *>(a_rhs[l]), true);
+    }
+    std::vector<Real> hist(a_sp.max_iter + 2, 0.0);
+    int iters = 0;
+    chk(suhmo_hier_solve(m_hier, &a_sp, &iters, hist.data(), nullptr), "AMRFASMultiGrid::solve (hierarchy of box unions)");
+    for (size_t l = 0; l < a_phi.size(); l++) hier_io(m_hier, (int)l, SUHMO_F_PHI, *a_phi[l], false);
+    if (a_hist) a_hist->assign(hist.begin(), hist.begin() + iters + 1);
+    return iters;
 }
 
 void VCAMRNonLinearPoissonOpHIPFactory::define(const ProblemDomain &a_dom, const DisjointBoxLayout &a_grids,

@@ -30,6 +30,16 @@ const double *or_amr2_coarse_residual(const OrAmr2 *A);
 }
 
 static int g_fail = 0;
+// oracle/amrm.c (test infrastructure; no public header): hierarchies whose levels are unions of boxes
+struct OrAmrM;
+extern "C" {
+OrAmrM *or_amrm_create(OrLevel *base, int nx0, int ny0, double dx0, double dy0, const OrBC *bc, const OrPhys *ph,
+                       double alpha, double beta, int nlev, const int *nbox, const int *boxes);
+void or_amrm_destroy(OrAmrM *A);
+void or_amrm_box_io(OrAmrM *A, int l, int k, int field, double *g, int ghosted, int set);
+int or_amrm_solve(OrAmrM *A, const OrSolverParams *sp, double *hist);
+}
+
 #define CHECK(cond, msg) do { if (!(cond)) { printf("FAIL: %s\n", msg); g_fail++; } else printf("ok:   %s\n", msg); } while (0)
 
 static double hashv(int k, double a, double b) { return a + (b - a) * (double)(((unsigned)k * 2654435761u) % 1000003u) / 1000003.0; }
@@ -416,6 +426,83 @@ int main()
         or_amr2_destroy(A);
     }
 
+
+    // ================= all AMR levels at once, as the reference's factory takes them: base + two levels that are unions of boxes
+    {
+        const int nlev = 3;
+        std::vector<std::vector<Box> > lb(nlev);
+        lb[0] = bx;
+        lb[1] = {Box(64, 32, 127, 95), Box(128, 32, 191, 63), Box(0, 8, 47, 55)};                 // an L-shaped union and a box on the domain side
+        lb[2] = {Box(144, 80, 239, 111), Box(144, 112, 207, 175), Box(16, 32, 63, 79)};
+        std::vector<DisjointBoxLayout> hg(nlev);
+        std::vector<LevelData<FArrayBox> > hphi(nlev), hrhs(nlev), ha(nlev), hB(nlev), hPi(nlev), hzb(nlev), hmask(nlev);
+        for (int l = 0; l < nlev; l++) {
+            ProblemDomain d; d.dom = Box(0, 0, (nx << l) - 1, (ny << l) - 1); d.periodic[0] = d.periodic[1] = false;
+            hg[l] = DisjointBoxLayout(lb[l], d);
+            hphi[l].define(hg[l], 1, 1); hrhs[l].define(hg[l], 1, 0); ha[l].define(hg[l], 1, 0);
+            hB[l].define(hg[l], 1, 1); hPi[l].define(hg[l], 1, 1); hzb[l].define(hg[l], 1, 1); hmask[l].define(hg[l], 1, 1);
+            const double ldx = dxv / (1 << l);
+            for (int k = 0; k < hg[l].size(); k++) {
+                const Box g = hg[l][k].grown(1);
+                for (int j = g.lo[1]; j <= g.hi[1]; j++)
+                    for (int i = g.lo[0]; i <= g.hi[0]; i++) {
+                        double x = (i + 0.5) * ldx;
+                        double H = 6.0 * (std::sqrt(x + 5000.0) - std::sqrt(5000.0)) + 1.0; if (H < 0) H = 0;
+                        hB[l][k](i, j) = 0.01 * (1.0 + 0.4 * std::sin(0.37 * i / (1 << l)) * std::cos(0.23 * j / (1 << l)));
+                        hPi[l][k](i, j) = 910.0 * 9.8 * H; hzb[l][k](i, j) = 0.0; hmask[l][k](i, j) = 1.0;
+                        hphi[l][k](i, j) = 101325.0 / 9800.0 + 1e-3 * hashv(i * (1000 - 23 * l) + j, -1.0, 1.0);
+                    }
+                const Box &v = hg[l][k];
+                for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++) { hrhs[l][k](i, j) = 5.79e-9; ha[l][k](i, j) = 0.0; }
+            }
+        }
+        auto ptrs = [&](std::vector<LevelData<FArrayBox> > &v) { std::vector<LevelData<FArrayBox> *> p; for (auto &x : v) p.push_back(&x); return p; };
+        VCAMRNonLinearPoissonOpHIPFactory hf;
+        hf.defineHierarchy(dom, hg, dx, bc, 0.0, -1.0, ph, ptrs(ha), ptrs(hB), ptrs(hPi), ptrs(hzb), ptrs(hmask));
+        // oracle twin: a fresh base level + the boxes
+        OrLevel *O2 = or_level_create(nx, ny, dxv, dyv, mb, &obc, &oph, 0.0, -1.0, 2);
+        { auto g = to_global(hphi[0], nx, ny, 0); or_level_set(O2, 0, OR_F_PHI, g.data(), 0); }
+        { auto g = to_global(hrhs[0], nx, ny, 0); or_level_set(O2, 0, OR_F_RHS, g.data(), 0); }
+        { auto g = to_global(ha[0], nx, ny, 0); or_level_set(O2, 0, OR_F_ACOEF, g.data(), 0); }
+        { auto g = to_global(hB[0], nx, ny, 1); or_level_set(O2, 0, OR_F_B, g.data(), 1); }
+        { auto g = to_global(hPi[0], nx, ny, 1); or_level_set(O2, 0, OR_F_PI, g.data(), 1); }
+        { auto g = to_global(hzb[0], nx, ny, 1); or_level_set(O2, 0, OR_F_ZB, g.data(), 1); }
+        { auto g = to_global(hmask[0], nx, ny, 1); or_level_set(O2, 0, OR_F_MASK, g.data(), 1); }
+        or_level_build_mg_coefficients(O2);
+        std::vector<int> nbox = {0, (int)lb[1].size(), (int)lb[2].size()}, flat;
+        for (int l = 1; l < nlev; l++) for (auto &b : lb[l]) flat.insert(flat.end(), {b.lo[0], b.lo[1], b.hi[0], b.hi[1]});
+        OrAmrM *M = or_amrm_create(O2, nx, ny, dxv, dyv, &obc, &oph, 0.0, -1.0, nlev, nbox.data(), flat.data());
+        for (int l = 1; l < nlev; l++)
+            for (int k = 0; k < hg[l].size(); k++) {
+                or_amrm_box_io(M, l, k, OR_F_PHI, hphi[l][k].dataPtr(), 1, 1); or_amrm_box_io(M, l, k, OR_F_B, hB[l][k].dataPtr(), 1, 1);
+                or_amrm_box_io(M, l, k, OR_F_PI, hPi[l][k].dataPtr(), 1, 1); or_amrm_box_io(M, l, k, OR_F_ZB, hzb[l][k].dataPtr(), 1, 1);
+                or_amrm_box_io(M, l, k, OR_F_MASK, hmask[l][k].dataPtr(), 1, 1);
+                or_amrm_box_io(M, l, k, OR_F_RHS, hrhs[l][k].dataPtr(), 0, 1); or_amrm_box_io(M, l, k, OR_F_ACOEF, ha[l][k].dataPtr(), 0, 1);
+            }
+        HeadSolverParameters hsp(100, true);
+        hsp.max_iter = 6;
+        OrSolverParams hosp; memcpy(&hosp, static_cast<suhmo_solver_params_t *>(&hsp), sizeof(hosp));
+        std::vector<Real> hh; std::vector<double> ohh(hsp.max_iter + 2, 0.0);
+        auto pphi = ptrs(hphi); std::vector<LevelData<FArrayBox> *> prhs = ptrs(hrhs);
+        int hn = hf.solveHierarchy(pphi, prhs, hsp, &hh);
+        int ohn = or_amrm_solve(M, &hosp, ohh.data());
+        CHECK(hn == ohn && hh.back() == ohh[ohn], "solveHierarchy (base + 2 levels of 3 boxes): V-cycle count and composite residual == oracle");
+        { std::vector<double> g0((size_t)nx * ny); or_level_get(O2, 0, OR_F_PHI, g0.data(), 0); CHECK(same_valid(hphi[0], g0, nx), "solveHierarchy: base-level head == oracle (bitwise)"); }
+        bool okb = true;
+        for (int l = 1; l < nlev; l++)
+            for (int k = 0; k < hg[l].size(); k++) {
+                const Box &v = hg[l][k];
+                std::vector<double> g((size_t)v.size(0) * v.size(1));
+                or_amrm_box_io(M, l, k, OR_F_PHI, g.data(), 0, 0);
+                for (int j = v.lo[1]; j <= v.hi[1]; j++) for (int i = v.lo[0]; i <= v.hi[0]; i++) {
+                    double a = hphi[l][k](i, j), b = g[(size_t)(j - v.lo[1]) * v.size(0) + (i - v.lo[0])];
+                    if (memcmp(&a, &b, 8)) okb = false;
+                }
+            }
+        CHECK(okb, "solveHierarchy: the head of every box of levels 1 and 2 == oracle (bitwise)");
+        or_amrm_destroy(M);
+        or_level_destroy(O2);
+    }
 
     or_level_destroy(O);
     printf(g_fail ? "RESULT: FAIL (%d)\n" : "RESULT: PASS\n", g_fail);

@@ -16,7 +16,7 @@ def build_exe():
     srcs = [os.path.join(ROOT, "tests", "host_cpp", "test_mirror.cpp"),
             os.path.join(ROOT, "suhmo_amd", "host", "VCAMRNonLinearPoissonOpHIP.cpp")]
     objs = []
-    for c in ("suhmo_oracle.c", "level_shim.c", "amr2.c"):
+    for c in ("suhmo_oracle.c", "level_shim.c", "amr2.c", "amrm.c"):
         o = os.path.join(ROOT, "tests", "host_cpp", c.replace(".c", ".o"))
         subprocess.check_call(["gcc", "-O2", "-std=c99", "-ffp-contract=off", "-fopenmp", "-c", os.path.join(ROOT, "oracle", c), "-o", o])
         objs.append(o)
