@@ -256,3 +256,11 @@ def test_suite_f_oracle_live():
     want = np.loadtxt(os.path.join(GOLD, "shmip_F1_oracle_nospin_table.dat"))
     assert got.shape == want.shape
     assert np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-300)) <= 1e-9         # %.10g in the file
+
+
+def test_pin_report_is_current():
+    """tests/golden/PIN_REPORT.txt (the one-page summary of what the committed oracle tables reproduce) is what tools/pin_report.py prints"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "pin_report.py")], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert out == open(os.path.join(GOLD, "PIN_REPORT.txt")).read()
