@@ -245,6 +245,12 @@ int suhmo_level_postproc_table(suhmo_level_t *L, const suhmo_model_params_t *mp,
  * the ranks (the reference: MPI_Allreduce, src/AmrHydro.cpp:3818-4013), and the table from the added sums */
 int suhmo_level_postproc_partial(suhmo_level_t *L, const suhmo_model_params_t *mp, double *sums, suhmo_stream_t s);
 int suhmo_postproc_finish(const double *sums, int nx, double dx, double *table);
+/* the temporal post-processing (AmrHydro.post_proc_shmip_temporal, src/AmrHydro.cpp:3778-3810, 4040-4053; the rows of
+ * exec/F_SHMIP/F<k>/results/postproc.dat) from the same column sums: out[6] = mean effective pressure [Pa] over the ice-covered
+ * cells, over the bands 600 m < x < 900 m, 3000 m < x < 3300 m, 5100 m < x < 5400 m (cell centres; NaN for an empty band), the recharge
+ * upstream of column 1 (external + melt) and the discharge through x-face 1.  suhmo_level_postproc_temporal: a whole level. */
+int suhmo_postproc_temporal(const double *sums, int nx, double dx, double *out);
+int suhmo_level_postproc_temporal(suhmo_level_t *L, const suhmo_model_params_t *mp, double *out, suhmo_stream_t s);
 
 /* setAlphaAndBeta (src/VCAMRNonLinearPoissonOp.cpp:462-469) and setBC (src/AMRNonLinearPoissonOp.cpp:1275-1278) of the
  * operator, for every multigrid depth of the level; setBC keeps the periodicity the level was created with */

@@ -71,7 +71,7 @@ SYMBOLS = [
     "suhmo_level_rccl_exchanges",
     "suhmo_amr2_cf_interp", "suhmo_amr2_average", "suhmo_amr2_fine_update_operator", "suhmo_amr2_residual",
     "suhmo_amr2_vcycle", "suhmo_amr2_solve", "suhmo_level_moulin_source", "suhmo_amr2_prolong2", "suhmo_amr2_set_covered",
-    "suhmo_amr_residual", "suhmo_amr_vcycle", "suhmo_amr_solve", "suhmo_level_postproc_table", "suhmo_level_postproc_partial", "suhmo_postproc_finish",
+    "suhmo_amr_residual", "suhmo_amr_vcycle", "suhmo_amr_solve", "suhmo_level_postproc_table", "suhmo_level_postproc_partial", "suhmo_postproc_finish", "suhmo_postproc_temporal", "suhmo_level_postproc_temporal",
     "suhmo_level_set_alpha_beta", "suhmo_level_set_bc", "suhmo_amr2_reflux", "suhmo_amr2_pwl_fill", "suhmo_amr_timestep", "suhmo_level_time_varying_recharge", "suhmo_amr_moulin_source", "suhmo_amr2_prolong_pc", "suhmo_amr2_finer_operator_changed",
     "suhmo_hier_create", "suhmo_hier_destroy", "suhmo_hier_num_levels", "suhmo_hier_num_boxes", "suhmo_hier_box", "suhmo_hier_exchange",
     "suhmo_hier_cf_interp", "suhmo_hier_pwl_fill", "suhmo_hier_average", "suhmo_hier_gsrb", "suhmo_hier_update_operator",
@@ -138,6 +138,8 @@ def lib():
     L.suhmo_level_postproc_table.argtypes = [vp, C.POINTER(ModelParams), dp, vp]
     L.suhmo_level_postproc_partial.argtypes = [vp, C.POINTER(ModelParams), dp, vp]
     L.suhmo_postproc_finish.argtypes = [dp, C.c_int, C.c_double, dp]
+    L.suhmo_postproc_temporal.argtypes = [dp, C.c_int, C.c_double, dp]
+    L.suhmo_level_postproc_temporal.argtypes = [vp, C.POINTER(ModelParams), dp, vp]
     L.suhmo_level_set_alpha_beta.argtypes = [vp, C.c_double, C.c_double]
     L.suhmo_level_set_bc.argtypes = [vp, C.POINTER(BC)]
     L.suhmo_amr2_reflux.argtypes = [vp, vp, C.c_int, vp]

@@ -1155,6 +1155,34 @@ extern "C" int suhmo_postproc_finish(const double *sums, int nx, double dx, doub
     }
     return 0;
 }
+// the "Time(h - d)" lines of the temporal post-processing (src/AmrHydro.cpp:3778-3810, 4040-4053) from the column sums
+extern "C" int suhmo_postproc_temporal(const double *sums, int nx, double dx, double *out)
+{
+    ARG(sums && out && nx > 1);
+    const double *h = sums;
+    const double lo[3] = {600.0, 3000.0, 5100.0}, hi[3] = {900.0, 3300.0, 5400.0};
+    double tot = 0.0, cnt = 0.0, bs[3] = {0.0, 0.0, 0.0}, bc[3] = {0.0, 0.0, 0.0}, rech = 0.0;
+    for (int i = 0; i < nx; i++) {
+        const double x = (i + 0.5) * dx;
+        tot += h[6 * (size_t)nx + i]; cnt += h[7 * (size_t)nx + i];
+        for (int b = 0; b < 3; b++) if (x > lo[b] && x < hi[b]) { bs[b] += h[6 * (size_t)nx + i]; bc[b] += h[7 * (size_t)nx + i]; }
+        if (i >= 1) rech += h[4 * (size_t)nx + i] + h[5 * (size_t)nx + i];
+    }
+    out[0] = tot / cnt;
+    for (int b = 0; b < 3; b++) out[1 + b] = bs[b] / bc[b];
+    out[4] = rech;
+    out[5] = -h[1 * (size_t)nx + 1];
+    return 0;
+}
+extern "C" int suhmo_level_postproc_temporal(suhmo_level_t *L, const suhmo_model_params_t *mp, double *out, suhmo_stream_t s)
+{
+    ARG(L && mp && out);
+    Depth &D = L->d[0];
+    if (D.v.ext[0] || D.v.ext[1]) { suhmo_set_error("rank strip: add the strips' suhmo_level_postproc_partial sums, then suhmo_postproc_temporal"); return -5; }
+    std::vector<double> h(8 * (size_t)D.v.nx);
+    int rc = suhmo_level_postproc_partial(L, mp, h.data(), s); if (rc) return rc;
+    return suhmo_postproc_temporal(h.data(), D.v.nx, D.v.dx, out);
+}
 extern "C" int suhmo_level_postproc_table(suhmo_level_t *L, const suhmo_model_params_t *mp, double *table, suhmo_stream_t s)
 {
     ARG(L && mp && table);

@@ -65,6 +65,12 @@ class HipModel:
     def get(self, name, ghosted=False):
         return self.level.get(self.FIELDS[name], ghosted=ghosted)
 
+    def postproc_temporal(self):
+        """the daily row of AmrHydro.post_proc_shmip_temporal (suhmo_level_postproc_temporal): avgN, N in the three bands, recharge, discharge"""
+        out = np.zeros(6)
+        check(capi.lib().suhmo_level_postproc_temporal(self.level.h, C.byref(self._mp), out.ctypes.data_as(C.POINTER(C.c_double)), self.level.stream))
+        return out
+
     def postproc_table_device(self):
         """SHMIP cross-section table reduced on the device (suhmo_level_postproc_table)"""
         t = np.zeros((self.nx, 8))

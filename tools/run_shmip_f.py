@@ -96,7 +96,7 @@ def main():
         M.level.set(lv.F_MR, np.full((ny, nx), m["G"] / m["L"]))          # thismeltRate = G / L (ValleyIBC::initializeData)
         set_src = lambda a: M.level.set(lv.F_MSRC, a, ghosted=True)
         recharge = None
-        fields = lambda: (M.get("qwx"), M.get("msrc"), M.get("mR"), M.get("Pw"), st["Pi"][1:-1, 1:-1], mask[1:-1, 1:-1])
+        fields = None                       # the daily row comes from the device (suhmo_level_postproc_temporal)
     tot_p = tot_v = 0
     # spin-up: the source term of a run without time variation is the background where there is ice (:2866-2876)
     set_src(np.where(mask > 0.0, BACKGROUND, 0.0))
@@ -114,7 +114,11 @@ def main():
             M.time_varying_recharge(zs, T_K, BACKGROUND)
         p, v_ = M.timestep(dt); tot_p += p; tot_v += v_
         if int(tm + dt) % 86400 == 0:
-            rows.append(daily_row(tm + dt, st["dx"], st["dy"], *fields()))
+            if which == "oracle":
+                rows.append(daily_row(tm + dt, st["dx"], st["dy"], *fields()))
+            else:
+                sums = M.postproc_partial()
+                rows.append([(tm + dt) / 3600.0, (tm + dt) / 86400.0] + list(M.postproc_temporal()) + [sums[4, 1:].sum(), sums[5, 1:].sum()])
         tm += dt
         if (k + 1) % 2000 == 0:
             print("step %d  picard %d  vcycles %d  %.0f s" % (k + 1, tot_p, tot_v, time.time() - t0), flush=True)
