@@ -51,3 +51,24 @@ def test_product_package_never_imports_oracle():
         for fn in files:
             if fn.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 assert not pat.search(open(os.path.join(dirpath, fn)).read()), (dirpath, fn)
+
+
+def test_postproc_host_halves_without_a_gpu(lib):
+    """suhmo_postproc_finish / suhmo_postproc_temporal are host arithmetic on column sums (what the ranks add up): the table and the
+    daily row of AmrHydro's post-processing (src/AmrHydro.cpp:3778-3810, 4023-4053) against a numpy restatement"""
+    import ctypes as C
+    import numpy as np
+    nx, dx = 256, 6000.0 / 256
+    rng = np.random.default_rng(3)
+    sums = rng.uniform(0.5, 2.0, size=(8, nx))
+    sums[7] = np.round(rng.uniform(10, 60, size=nx))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    out = np.zeros(6)
+    assert lib.suhmo_postproc_temporal(dp(sums), nx, dx, dp(out)) == 0
+    x = (np.arange(nx) + 0.5) * dx
+    band = lambda lo, hi: sums[6][(x > lo) & (x < hi)].sum() / sums[7][(x > lo) & (x < hi)].sum()
+    want = [sums[6].sum() / sums[7].sum(), band(600.0, 900.0), band(3000.0, 3300.0), band(5100.0, 5400.0), (sums[4] + sums[5])[1:].sum(), -sums[1][1]]
+    assert np.allclose(out, want, rtol=1e-13, atol=0)
+    table = np.zeros((nx, 8))
+    assert lib.suhmo_postproc_finish(dp(sums), nx, dx, dp(table)) == 0
+    assert np.allclose(table[:, 5], np.cumsum(sums[4][::-1])[::-1], rtol=1e-13) and np.allclose(table[:, 2], -sums[1])
