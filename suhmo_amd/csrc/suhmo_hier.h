@@ -29,4 +29,5 @@ int suhmo_multi_copy_between(const suhmo_multi &dst, const suhmo_multi &src, con
 int suhmo_multi_norm_max(const suhmo_multi &m, suhmo_level *slot, int field, double *out, hipStream_t st);                // max |x| over the valid cells of all boxes
 int suhmo_hier_multi_(suhmo_hier *H, int l, hipStream_t st, suhmo_multi *m);       // l >= 1
 int suhmo_hier_ensure_(suhmo_hier *H, int l, int field);                            // allocate a field on every box of a level
+void suhmo_hier_invalidate_(suhmo_hier *H);                                         // an entry point outside suhmo_hier.hip: the caller may have loaded new data
 const double *suhmo_hier_base_cover_(suhmo_hier *H, DV *whole);                     // level 0 cut into rank strips: COVER of the WHOLE level and its view; else NULL

@@ -141,6 +141,7 @@ struct suhmo_hier {
     double *xs = nullptr, *xr = nullptr; size_t xcap = 0;  // staging of the all-gather
     suhmo_hier_allgather_fn ag = nullptr; void *ag_user = nullptr;
     long gathers = 0;
+    bool phi_shadow_fresh = false;                         // the shadow's head is current: nothing has written level 0's head since its refresh
     DevVec<RectEnt> cover_full;                            // coarsen(boxes of level 1) in the shadow: COVER of the whole level 0
 };
 
@@ -650,6 +651,10 @@ double *shadow_field(suhmo_hier *H, int field)
 int refresh_base(suhmo_hier *H, const int *fields, int nf, hipStream_t st)
 {
     if (!dist_base(H) || H->nlev < 2) return 0;
+    // the head is read by several plans in a row (coarse-fine interpolation before every operator of level 1) while level 0 rests:
+    // one all-gather serves them.  Whatever writes level 0's head clears the flag (the average from level 1, its own V-cycle, a
+    // copy into it) and so does every entry point of the C-ABI (the caller may have loaded new data)
+    if (nf == 1 && fields[0] == SUHMO_F_PHI && H->phi_shadow_fresh) return 0;
     SUHMO_TIME("hier: all-gather of the coarse cells level 1 reads");
     if (!H->ag) { suhmo_set_error("hier: level 0 is a rank strip and no all-gather is attached (suhmo_hier_attach_rccl / suhmo_hier_set_allgather)"); return -1; }
     ARG(nf >= 1 && nf <= XF);
@@ -676,6 +681,7 @@ int refresh_base(suhmo_hier *H, const int *fields, int nf, hipStream_t st)
     H->gathers++;
     if (H->need.n) hipLaunchKernelGGL(k_need_unpack, g1(H->need.n), dim3(256), 0, st, H->need.d, H->need_rl.d, (int)H->need.n, fl, H->xr, stride);
     HIPCHK(hipGetLastError());
+    for (int f = 0; f < nf; f++) if (fields[f] == SUHMO_F_PHI) H->phi_shadow_fresh = true;
     return 0;
 }
 inline int refresh_base1(suhmo_hier *H, int field, hipStream_t st) { return refresh_base(H, &field, 1, st); }
@@ -756,6 +762,7 @@ int hier_avg(suhmo_hier *H, int l, int ff, int fc, int mode, double val, hipStre
     CoarseArgs ca;
     if ((rc = ensure_field(H, l, ff)) || (rc = ensure_field(H, l - 1, fc)) || (rc = refresh_tables(H, l, st)) || (rc = coarse_args(H, l - 1, st, ca))) return rc;
     if (fc == SUHMO_F_PHI) for (suhmo_level *L : H->lev[l - 1].box) L->d[0].phi_fresh = 0;
+    if (fc == SUHMO_F_PHI && l == 1) H->phi_shadow_fresh = false;
     if (V.avg.n) {
         dim3 grd((V.avg_w + 63) / 64, (V.avg_h + 3) / 4, (unsigned)V.avg.n);
         hipLaunchKernelGGL(k_avg, grd, dim3(64, 4), 0, st, V.avg.d, V.d_fp, V.d_dv, ff, ca.tab, ca.dv, ca.dst, ca.ddv, ca.use_base, fc, mode, val);
@@ -832,7 +839,7 @@ int hier_reflux(suhmo_hier *H, int l, int field_c, hipStream_t st, int residual 
 int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
 {
     SUHMO_TIME("AMRNonLinearPoissonOp::relaxNF");
-    if (l == 0) return suhmo_level_gsrb(base_of(H), 0, sweeps, s);
+    if (l == 0) { H->phi_shadow_fresh = false; return suhmo_level_gsrb(base_of(H), 0, sweeps, s); }
     int rc;
     suhmo_multi m;
     if ((rc = multi_of(H, l, HST(s), m))) return rc;
@@ -867,6 +874,7 @@ int hier_copy(suhmo_hier *H, int l, int dst, int src, suhmo_stream_t s)
     int rc;
     if ((rc = ensure_field(H, l, dst)) || (rc = ensure_field(H, l, src))) return rc;
     if (dst == SUHMO_F_PHI) for (suhmo_level *L : H->lev[l].box) L->d[0].phi_fresh = 0;
+    if (dst == SUHMO_F_PHI && l == 0) H->phi_shadow_fresh = false;
     if (l == 0) {
         suhmo_level *L = base_of(H);
         HIPCHK(hipMemcpyAsync(L->d[0].fp.f[dst], L->d[0].fp.f[src], L->d[0].elems * sizeof(double), hipMemcpyDeviceToDevice, HST(s)));
@@ -924,7 +932,7 @@ int composite_residual(suhmo_hier *H, int l, suhmo_stream_t s)
 }
 int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stream_t s)
 {
-    if (l == 0) return suhmo_level_vcycle(base_of(H), sp, s);
+    if (l == 0) { H->phi_shadow_fresh = false; return suhmo_level_vcycle(base_of(H), sp, s); }
     int rc;
     if ((rc = cf_phi(H, l, s))) return rc;
     if (sp->bcoeff_otf && (rc = hier_update_operator(H, l, s))) return rc;
@@ -953,7 +961,7 @@ int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stre
     if ((rc = cf_phi(H, l, s))) return rc;
     return hier_gsrb(H, l, sp->num_smooth, s);
 }
-int check_hier(const suhmo_hier *H) { ARG(H && H->nlev >= 1); return 0; }
+int check_hier(suhmo_hier *H) { ARG(H && H->nlev >= 1); H->phi_shadow_fresh = false; return 0; }     // every C-ABI entry: the caller may have loaded new data
 }  // namespace
 
 // ------------------------------------------------------------------ C-ABI
@@ -1103,6 +1111,7 @@ int suhmo_hier_pwl_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st) { retu
 int suhmo_hier_avg_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st) { return hier_avg(H, l, ff, fc, 0, 0.0, st); }
 int suhmo_hier_multi_(suhmo_hier *H, int l, hipStream_t st, suhmo_multi *m) { return multi_of(H, l, st, *m); }
 int suhmo_hier_ensure_(suhmo_hier *H, int l, int field) { return ensure_field(H, l, field); }
+void suhmo_hier_invalidate_(suhmo_hier *H) { H->phi_shadow_fresh = false; if (H->gap) H->gap->phi_shadow_fresh = false; }
 const double *suhmo_hier_base_cover_(suhmo_hier *H, DV *whole)
 {
     if (!dist_base(H)) return nullptr;

@@ -714,6 +714,7 @@ extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *
     if (mp->use_impl_diff && mp->diffFactor == 0.0) { suhmo_set_error("use_ImplDiff with diffFactor = 0"); return -1; }
     const int nlev = suhmo_hier_nlev_(H);
     HIPCHK(hipSetDevice(suhmo_hier_device_(H)));
+    suhmo_hier_invalidate_(H);
     hipStream_t st = (hipStream_t)s;
     int rc;
     static const int need[] = {SUHMO_F_MR, SUHMO_F_PW, SUHMO_F_QWX, SUHMO_F_QWY, SUHMO_F_HLAG, SUHMO_F_CD, SUHMO_F_GRADX, SUHMO_F_GRADY, SUHMO_F_RE};
