@@ -133,3 +133,29 @@ def test_one_box_per_level_equals_the_nested_patch_code(oracle):
         assert np.array_equal(H.level[l][0].get(level.F_PHI), A.levels[l].get(level.F_PHI))
     assert np.array_equal(H.coarse.get(level.F_PHI), A.levels[0].get(level.F_PHI))
     H.close(); A.close()
+
+
+def test_hier_refuses_layouts_the_reference_could_not_have():
+    """suhmo_hier_create checks what BRMeshRefine guarantees: coarse-aligned boxes inside the refined domain, disjoint, properly nested
+    (coarsen(box) grown by the stencils lies in the level below); and a level 0 cut into rank strips refuses to run without its
+    all-gather.  Every refusal is an error code with a message, never a wrong result."""
+    from suhmo_amd import capi, level as lv
+    mk = lambda boxes, **kw: lv.HipHier(64, 32, 1.0, 1.0, sy.A3_BC, sy.A3_PHYS, boxes, max_box=16, **kw)
+    bad = {"odd lower corner": [[(33, 16, 63, 47)]],
+           "outside the refined domain": [[(32, 16, 129, 47)]],
+           "overlapping boxes": [[(32, 16, 63, 47), (48, 32, 79, 63)]],
+           "level 2 not inside level 1": [[(32, 16, 63, 47)], [(56, 24, 135, 71)]],
+           "level 2 touching the edge of level 1 (no room for the coarse-fine stencil)": [[(32, 16, 63, 47)], [(64, 32, 95, 63)]]}
+    for what, boxes in bad.items():
+        with pytest.raises(capi.SuhmoError) as e:
+            mk(boxes)
+        assert "hier" in str(e.value) or "box" in str(e.value), (what, str(e.value))
+    ok = mk([[(32, 16, 63, 47)], [(72, 40, 119, 87)]])
+    ok.close()
+    # a strip of level 0 without the all-gather attached: the first plan that reads level 0 says so
+    H = mk([[(32, 16, 63, 47)]], j0=0, ny_global=64)
+    H.level[0][0].set_inputs(sy.amrm_fields(64, 32, [[(32, 16, 63, 47)]])[0])
+    with pytest.raises(capi.SuhmoError) as e:
+        H.cf_interp(1)
+    assert "all-gather" in str(e.value)
+    H.close()
