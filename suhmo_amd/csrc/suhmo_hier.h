@@ -7,6 +7,7 @@ const std::vector<suhmo_level *> &suhmo_hier_boxes_(suhmo_hier *H, int l);
 int suhmo_hier_device_(const suhmo_hier *H);
 int suhmo_hier_ff_(suhmo_hier *H, int l, int f0, int f1, bool corners, hipStream_t st);      // Copier::exchange between the boxes of a level
 int suhmo_hier_cf_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st);                    // QuadCFInterp from level l-1
+int suhmo_hier_cf2_(suhmo_hier *H, int l, int ff0, int fc0, int ff1, int fc1, hipStream_t st);   // two fields over the same stencils, one launch
 int suhmo_hier_pwl_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st);                   // PiecewiseLinearFillPatch from level l-1
 int suhmo_hier_avg_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st);                   // CoarseAverage into level l-1
 // the hierarchy of SolveForGap_nl: the same boxes, alpha = 1, beta = dt diffFactor, Neumann-0 sides, no nonlinear term

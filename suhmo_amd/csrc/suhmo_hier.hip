@@ -187,14 +187,16 @@ __global__ void k_ff(const CopyEnt *__restrict__ e, int n, const FP *__restrict_
     if (f1 >= 0) tab[c.d.b].f[f1][c.d.off] = tab[c.s.b].f[f1][c.s.off];
 }
 // [Chombo] QuadCFInterp (oracle/amrm.c:cf_interp)
-__global__ void k_cf(const CfEnt *__restrict__ e, int n, const FP *__restrict__ ftab, int ff, const FP *__restrict__ ctab, FP cbase,
-                     int use_base, int fc)
+__global__ void k_cf(const CfEnt *__restrict__ e, int n, const FP *__restrict__ ftab, int ff0, const FP *__restrict__ ctab, FP cbase,
+                     int use_base, int fc0, int ff1, int fc1)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     CfEnt q = e[t];
     const double c_s = 8.0 / 15.0, c_b = 2.0 / 3.0, c_a = -0.2;
     const double xt = q.xsign ? 0.25 : -0.25;
+  for (int pass = 0; pass < (ff1 >= 0 ? 2 : 1); pass++) {          // one or two fields over the same stencils (the two gradient components)
+    const int ff = pass ? ff1 : ff0, fc = pass ? fc1 : fc0;
 #define CVAL(m) fptr(ctab, cbase, use_base, q.c[m].b, fc)[q.c[m].off]
     double c0, d1 = 0.0, d2 = 0.0;
     if (q.kind == 0) { double cm = CVAL(0), cp = CVAL(2); c0 = CVAL(1); d1 = 0.5 * (cp - cm); d2 = cp - 2.0 * c0 + cm; }
@@ -207,6 +209,7 @@ __global__ void k_cf(const CfEnt *__restrict__ e, int n, const FP *__restrict__ 
     double phistar = c0 + xt * d1 + (0.5 * xt * xt) * d2;
     double *f = ftab[q.f.b].f[ff];
     f[q.f.off] = c_s * phistar + c_b * f[q.f.off + q.step] + c_a * f[q.f.off + 2 * q.step];
+  }
 }
 // [Chombo] PiecewiseLinearFillPatch (oracle/amr_step.c:or_pwl_fill)
 __global__ void k_pwl(const PwlEnt *__restrict__ e, int n, const FP *__restrict__ ftab, int ff, const FP *__restrict__ ctab, FP cbase,
@@ -727,7 +730,7 @@ int hier_ff(suhmo_hier *H, int l, int f0, int f1, bool corners, hipStream_t st)
     return 0;
 }
 // QuadCFInterp: coarse-fine ghosts of field ff of level l <- field fc of level l-1
-int hier_cf(suhmo_hier *H, int l, int ff, int fc, hipStream_t st)
+int hier_cf(suhmo_hier *H, int l, int ff, int fc, hipStream_t st, int ff1 = -1, int fc1 = -1)
 {
     SUHMO_TIME("QuadCFInterp::coarseFineInterp");
     if (l == 0) return 0;
@@ -735,9 +738,10 @@ int hier_cf(suhmo_hier *H, int l, int ff, int fc, hipStream_t st)
     int rc;
     CoarseArgs ca;
     if ((rc = ensure_field(H, l, ff)) || (rc = ensure_field(H, l - 1, fc)) || (rc = refresh_tables(H, l, st))) return rc;
-    if (l == 1 && (rc = refresh_base1(H, fc, st))) return rc;
+    if (ff1 >= 0 && ((rc = ensure_field(H, l, ff1)) || (rc = ensure_field(H, l - 1, fc1)) || (rc = refresh_tables(H, l, st)))) return rc;
+    if (l == 1) { const int fl[2] = {fc, fc1}; if ((rc = refresh_base(H, fl, ff1 >= 0 ? 2 : 1, st))) return rc; }
     if ((rc = coarse_args(H, l - 1, st, ca))) return rc;
-    if (V.cf.n) hipLaunchKernelGGL(k_cf, g1(V.cf.n), dim3(256), 0, st, V.cf.d, (int)V.cf.n, V.d_fp, ff, ca.tab, ca.base, ca.use_base, fc);
+    if (V.cf.n) hipLaunchKernelGGL(k_cf, g1(V.cf.n), dim3(256), 0, st, V.cf.d, (int)V.cf.n, V.d_fp, ff, ca.tab, ca.base, ca.use_base, fc, ff1, fc1);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -905,8 +909,7 @@ int hier_update_operator(suhmo_hier *H, int l, suhmo_stream_t s)
     if ((rc = cf_phi(H, l - 1, s))) return rc;                    // the coarser level's own coarse-fine ghosts (its gradient reads them)
     if ((rc = hier_grad_cc(H, l, s))) return rc;
     if ((rc = hier_grad_cc(H, l - 1, s))) return rc;
-    if ((rc = hier_cf(H, l, SUHMO_F_GRADX, SUHMO_F_GRADX, HST(s)))) return rc;
-    if ((rc = hier_cf(H, l, SUHMO_F_GRADY, SUHMO_F_GRADY, HST(s)))) return rc;
+    if ((rc = hier_cf(H, l, SUHMO_F_GRADX, SUHMO_F_GRADX, HST(s), SUHMO_F_GRADY, SUHMO_F_GRADY))) return rc;
     if ((rc = hier_ff(H, l, SUHMO_F_GRADX, SUHMO_F_GRADY, true, HST(s)))) return rc;  // lvlgradH.exchange() src/AmrHydro.cpp:1490
     suhmo_multi m;
     if ((rc = multi_of(H, l, HST(s), m))) return rc;
@@ -1107,6 +1110,7 @@ const std::vector<suhmo_level *> &suhmo_hier_boxes_(suhmo_hier *H, int l) { retu
 int suhmo_hier_device_(const suhmo_hier *H) { return H->device; }
 int suhmo_hier_ff_(suhmo_hier *H, int l, int f0, int f1, bool corners, hipStream_t st) { return hier_ff(H, l, f0, f1, corners, st); }
 int suhmo_hier_cf_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st) { return hier_cf(H, l, ff, fc, st); }
+int suhmo_hier_cf2_(suhmo_hier *H, int l, int ff0, int fc0, int ff1, int fc1, hipStream_t st) { return hier_cf(H, l, ff0, fc0, st, ff1, fc1); }
 int suhmo_hier_pwl_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st) { return hier_pwl(H, l, ff, fc, st); }
 int suhmo_hier_avg_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st) { return hier_avg(H, l, ff, fc, 0, 0.0, st); }
 int suhmo_hier_multi_(suhmo_hier *H, int l, hipStream_t st, suhmo_multi *m) { return multi_of(H, l, st, *m); }

@@ -628,8 +628,7 @@ int hier_chain(suhmo_hier *H, int l, hipStream_t st)
     if ((rc = suhmo_hier_ff_(H, l, SUHMO_F_PHI, -1, false, st))) return rc;
     if (t.base) rc = suhmo_grad_cc(t.base, 0, st); else rc = suhmo_multi_grad_cc(t.m, ph.use_mask_gradients, st);
     if (rc) return rc;
-    if ((rc = suhmo_hier_cf_(H, l, SUHMO_F_GRADX, SUHMO_F_GRADX, st))) return rc;              // :1650-1659
-    if ((rc = suhmo_hier_cf_(H, l, SUHMO_F_GRADY, SUHMO_F_GRADY, st))) return rc;
+    if ((rc = suhmo_hier_cf2_(H, l, SUHMO_F_GRADX, SUHMO_F_GRADX, SUHMO_F_GRADY, SUHMO_F_GRADY, st))) return rc;   // :1650-1659
     if ((rc = suhmo_hier_ff_(H, l, SUHMO_F_GRADX, SUHMO_F_GRADY, true, st))) return rc;
     if (t.base) rc = suhmo_re_cells(t.base, 0, st); else rc = suhmo_multi_re(t.m, ph, st);
     if (rc) return rc;
