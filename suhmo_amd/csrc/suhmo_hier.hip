@@ -104,7 +104,7 @@ struct HLev {
     std::vector<int> b4;
     BoxIndex index;
     // plans (device)
-    DevVec<CopyEnt> ff_side, ff_corner;
+    DevVec<CopyEnt> ff_side, ff_all;                 // ff_all = sides, then corners (the default copier's exchange in one launch)
     DevVec<int2> push; DevVec<int> pbase;            // ff_side seen from the source cell (the colour passes push, suhmo_gsrb.hip)
     DevVec<CfEnt> cf;
     DevVec<PwlEnt> pwl;
@@ -570,7 +570,8 @@ int build_plans(suhmo_hier *H, int l)
         }
         rc |= F.push.upload(push); rc |= F.pbase.upload(pbase);
     }
-    rc |= F.ff_side.upload(ffs); rc |= F.ff_corner.upload(ffc); rc |= F.cf.upload(cf); rc |= F.pwl.upload(pwl);
+    rc |= F.ff_side.upload(ffs);
+    { std::vector<CopyEnt> all(ffs); all.insert(all.end(), ffc.begin(), ffc.end()); rc |= F.ff_all.upload(all); } rc |= F.cf.upload(cf); rc |= F.pwl.upload(pwl);
     rc |= F.avg.upload(avg); rc |= F.wing.upload(wing); rc |= F.targets.upload(targets); rc |= F.faces.upload(faces);
     if (rc) { suhmo_set_error("hier: plan upload failed"); return -2; }
     F.avg_w = F.avg_h = F.wing_w = F.wing_h = 0;
@@ -724,8 +725,9 @@ int hier_ff(suhmo_hier *H, int l, int f0, int f1, bool corners, hipStream_t st)
     HLev &V = H->lev[l];
     int rc;
     if ((rc = ensure_field(H, l, f0)) || (f1 >= 0 && (rc = ensure_field(H, l, f1))) || (rc = refresh_tables(H, l, st))) return rc;
-    if (V.ff_side.n) hipLaunchKernelGGL(k_ff, g1(V.ff_side.n), dim3(256), 0, st, V.ff_side.d, (int)V.ff_side.n, V.d_fp, f0, f1);
-    if (corners && V.ff_corner.n) hipLaunchKernelGGL(k_ff, g1(V.ff_corner.n), dim3(256), 0, st, V.ff_corner.d, (int)V.ff_corner.n, V.d_fp, f0, f1);
+    // (a corner ghost's source is a valid cell, never a ghost: sides and corners do not depend on each other)
+    const DevVec<CopyEnt> &list = corners ? V.ff_all : V.ff_side;
+    if (list.n) hipLaunchKernelGGL(k_ff, g1(list.n), dim3(256), 0, st, list.d, (int)list.n, V.d_fp, f0, f1);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -981,7 +983,7 @@ extern "C" int suhmo_hier_destroy(suhmo_hier_t *H)
     for (int l = 0; l < 8; l++) {
         HLev &V = H->lev[l];
         for (suhmo_level *L : V.box) (void)suhmo_level_destroy(L);
-        V.ff_side.release(); V.ff_corner.release(); V.push.release(); V.pbase.release(); V.cf.release(); V.pwl.release(); V.avg.release(); V.wing.release();
+        V.ff_side.release(); V.ff_all.release(); V.push.release(); V.pbase.release(); V.cf.release(); V.pwl.release(); V.avg.release(); V.wing.release();
         V.targets.release(); V.faces.release();
         if (V.winbuf) (void)hipFree(V.winbuf);
         if (V.winold) (void)hipFree(V.winold);
