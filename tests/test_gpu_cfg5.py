@@ -70,3 +70,46 @@ def test_cfg5_on_the_reference_base_grid():
             for nm in ("head", "B", "mR"):
                 assert np.all(np.isfinite(G.get(l, k, nm)))
     G.close()
+
+
+@pytest.mark.timeout(600)
+def test_cfg5_at_the_north_star_size_properties():
+    """BASELINE north_star: 4096^2 base + 3 AMR levels (boxes around the 63 moulins of exec/AMR_multiMoulins), transient head + gap
+    height.  No oracle finishes this size in test time; what must hold at any size: the moulin source term delivers the moulins'
+    flux over the composite grid; after a step the head of level l under level l+1 IS the average of the finer head (CoarseAverage,
+    src/AmrHydro.cpp:3138-3141), bit for bit; every field and the composite residual stay finite, the Picard loop converges."""
+    from suhmo_amd import level as lv, model
+    bc, ph, m, mo = sy.multimoulins_setup()
+    nb = 4096
+    boxes = sy.boxes_around(mo["positions"], nb, nb, 4, 1.0e5, 1.0e5)
+    sts = sy.mountain_amrm_states(nb, nb, boxes)
+    G = model.HipHierModel(nb, nb, sts[0][0]["dx"], sts[0][0]["dy"], bc, ph, m, boxes, max_box=64)
+    G.set_states(sts)
+    G.moulin_source(**mo)
+    total = 0.0
+    for l in range(4):
+        for k, b in enumerate(G.hier.boxes[l - 1] if l else [(0, 0, nb - 1, nb - 1)]):
+            src = G.get(l, k, "msrc")
+            cov = np.zeros(src.shape, dtype=bool)
+            if l < 3:
+                for (f0, f1, g0, g1) in G.hier.boxes[l]:
+                    a0, a1, c0, c1 = max(f0 // 2, b[0]), min(g0 // 2, b[2]), max(f1 // 2, b[1]), min(g1 // 2, b[3])
+                    if a0 <= a1 and c0 <= c1:
+                        cov[c0 - b[1]:c1 - b[1] + 1, a0 - b[0]:a1 - b[0] + 1] = True
+            total += src[~cov].sum() * sts[l][0]["dx"] * sts[l][0]["dy"]
+    assert abs(total - mo["flux"].sum()) < 1e-9 * mo["flux"].sum()
+    pi, nv = G.timestep(m["dt"])
+    assert 1 <= pi <= 30 and nv >= 2
+    assert np.isfinite(G.hier.residual())
+    # CoarseAverage: level 0 under the boxes of level 1
+    h0 = G.get(0, 0, "head")
+    for k, (f0, f1, g0, g1) in enumerate(G.hier.boxes[0][:8]):
+        hf = G.get(1, k, "head")
+        s = 0.0 + hf[0::2, 0::2]
+        s = s + hf[0::2, 1::2]; s = s + hf[1::2, 0::2]; s = s + hf[1::2, 1::2]      # FORT_AVERAGE's visiting order: (0,0), (1,0), (0,1), (1,1)
+        assert np.array_equal(h0[f1 // 2:g1 // 2 + 1, f0 // 2:g0 // 2 + 1], s * 0.25), k
+    for l in range(4):
+        for k in range(min(len(G.level[l]), 6)):
+            for nm in ("head", "B", "mR"):
+                assert np.all(np.isfinite(G.get(l, k, nm)))
+    G.close()
