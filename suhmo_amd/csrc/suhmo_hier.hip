@@ -141,6 +141,9 @@ struct suhmo_hier {
     double *xs = nullptr, *xr = nullptr; size_t xcap = 0;  // staging of the all-gather
     suhmo_hier_allgather_fn ag = nullptr; void *ag_user = nullptr;
     long gathers = 0;
+    // coarse-fine ghosts of the head of level l are current while neither level l's nor level l-1's head has been written since they
+    // were interpolated: phi_ver[l] counts the writes, cf_seen[l] = the two versions the ghosts were made from
+    unsigned long phi_ver[8] = {1, 1, 1, 1, 1, 1, 1, 1}, cf_seen[8][2] = {};
     bool phi_shadow_fresh = false;                         // the shadow's head is current: nothing has written level 0's head since its refresh
     DevVec<RectEnt> cover_full;                            // coarsen(boxes of level 1) in the shadow: COVER of the whole level 0
 };
@@ -767,7 +770,7 @@ int hier_avg(suhmo_hier *H, int l, int ff, int fc, int mode, double val, hipStre
     int rc;
     CoarseArgs ca;
     if ((rc = ensure_field(H, l, ff)) || (rc = ensure_field(H, l - 1, fc)) || (rc = refresh_tables(H, l, st)) || (rc = coarse_args(H, l - 1, st, ca))) return rc;
-    if (fc == SUHMO_F_PHI) for (suhmo_level *L : H->lev[l - 1].box) L->d[0].phi_fresh = 0;
+    if (fc == SUHMO_F_PHI) { for (suhmo_level *L : H->lev[l - 1].box) L->d[0].phi_fresh = 0; H->phi_ver[l - 1]++; }
     if (fc == SUHMO_F_PHI && l == 1) H->phi_shadow_fresh = false;
     if (V.avg.n) {
         dim3 grd((V.avg_w + 63) / 64, (V.avg_h + 3) / 4, (unsigned)V.avg.n);
@@ -816,6 +819,7 @@ int hier_prolong2(suhmo_hier *H, int l, int field_c, hipStream_t st, bool minus_
     int maxp = 0, maxx = 0, maxy = 0;
     for (const Win &w : V.win) maxp = std::max(maxp, 2 * (w.nx - 2) + 2 * (w.ny - 2));
     for (suhmo_level *L : V.box) { maxx = std::max(maxx, L->d[0].v.nx); maxy = std::max(maxy, L->d[0].v.ny); L->d[0].phi_fresh = 0; }
+    H->phi_ver[l]++;
     hipLaunchKernelGGL(k_win_bc, dim3((maxp + 255) / 256, nb), dim3(256), 0, st, V.d_win, nb, V.winbuf, ca.bdv);
     hipLaunchKernelGGL(k_prolong2_win, dim3((maxx + 63) / 64, (maxy + 3) / 4, nb), dim3(64, 4), 0, st, V.d_win, V.winbuf, V.d_fp, V.d_dv);
     HIPCHK(hipGetLastError());
@@ -845,10 +849,11 @@ int hier_reflux(suhmo_hier *H, int l, int field_c, hipStream_t st, int residual 
 int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
 {
     SUHMO_TIME("AMRNonLinearPoissonOp::relaxNF");
-    if (l == 0) { H->phi_shadow_fresh = false; return suhmo_level_gsrb(base_of(H), 0, sweeps, s); }
+    if (l == 0) { H->phi_shadow_fresh = false; H->phi_ver[0]++; return suhmo_level_gsrb(base_of(H), 0, sweeps, s); }
     int rc;
     suhmo_multi m;
     if ((rc = multi_of(H, l, HST(s), m))) return rc;
+    if (sweeps > 0) H->phi_ver[l]++;
     // exchange() before every colour pass (:692, :751): once here, then every pass pushes its new side cells into the ghost
     // cells they feed
     if (sweeps > 0 && (rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
@@ -879,7 +884,7 @@ int hier_copy(suhmo_hier *H, int l, int dst, int src, suhmo_stream_t s)
 {
     int rc;
     if ((rc = ensure_field(H, l, dst)) || (rc = ensure_field(H, l, src))) return rc;
-    if (dst == SUHMO_F_PHI) for (suhmo_level *L : H->lev[l].box) L->d[0].phi_fresh = 0;
+    if (dst == SUHMO_F_PHI) { for (suhmo_level *L : H->lev[l].box) L->d[0].phi_fresh = 0; H->phi_ver[l]++; }
     if (dst == SUHMO_F_PHI && l == 0) H->phi_shadow_fresh = false;
     if (l == 0) {
         suhmo_level *L = base_of(H);
@@ -891,7 +896,14 @@ int hier_copy(suhmo_hier *H, int l, int dst, int src, suhmo_stream_t s)
     return suhmo_multi_copy(m, dst, src, HST(s));
 }
 // head of level l: its coarse-fine ghosts from level l-1
-int cf_phi(suhmo_hier *H, int l, suhmo_stream_t s) { return hier_cf(H, l, SUHMO_F_PHI, SUHMO_F_PHI, HST(s)); }
+int cf_phi(suhmo_hier *H, int l, suhmo_stream_t s)
+{
+    if (l == 0) return 0;
+    if (H->cf_seen[l][0] == H->phi_ver[l] && H->cf_seen[l][1] == H->phi_ver[l - 1]) return 0;       // the ghosts are current
+    int rc = hier_cf(H, l, SUHMO_F_PHI, SUHMO_F_PHI, HST(s));
+    if (!rc) { H->cf_seen[l][0] = H->phi_ver[l]; H->cf_seen[l][1] = H->phi_ver[l - 1]; }
+    return rc;
+}
 
 // cell-centred gradient of level l (compGradientCC) with its domain-side ghosts
 int hier_grad_cc(suhmo_hier *H, int l, suhmo_stream_t s)
@@ -937,7 +949,7 @@ int composite_residual(suhmo_hier *H, int l, suhmo_stream_t s)
 }
 int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stream_t s)
 {
-    if (l == 0) { H->phi_shadow_fresh = false; return suhmo_level_vcycle(base_of(H), sp, s); }
+    if (l == 0) { H->phi_shadow_fresh = false; H->phi_ver[0]++; return suhmo_level_vcycle(base_of(H), sp, s); }
     int rc;
     if ((rc = cf_phi(H, l, s))) return rc;
     if (sp->bcoeff_otf && (rc = hier_update_operator(H, l, s))) return rc;
@@ -966,7 +978,13 @@ int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stre
     if ((rc = cf_phi(H, l, s))) return rc;
     return hier_gsrb(H, l, sp->num_smooth, s);
 }
-int check_hier(suhmo_hier *H) { ARG(H && H->nlev >= 1); H->phi_shadow_fresh = false; return 0; }     // every C-ABI entry: the caller may have loaded new data
+int check_hier(suhmo_hier *H)
+{
+    ARG(H && H->nlev >= 1);
+    H->phi_shadow_fresh = false;
+    for (int l = 0; l < 8; l++) H->phi_ver[l]++;
+    return 0;
+}     // every C-ABI entry: the caller may have loaded new data
 }  // namespace
 
 // ------------------------------------------------------------------ C-ABI
@@ -1117,7 +1135,12 @@ int suhmo_hier_pwl_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st) { retu
 int suhmo_hier_avg_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st) { return hier_avg(H, l, ff, fc, 0, 0.0, st); }
 int suhmo_hier_multi_(suhmo_hier *H, int l, hipStream_t st, suhmo_multi *m) { return multi_of(H, l, st, *m); }
 int suhmo_hier_ensure_(suhmo_hier *H, int l, int field) { return ensure_field(H, l, field); }
-void suhmo_hier_invalidate_(suhmo_hier *H) { H->phi_shadow_fresh = false; if (H->gap) H->gap->phi_shadow_fresh = false; }
+void suhmo_hier_invalidate_(suhmo_hier *H)
+{
+    H->phi_shadow_fresh = false;
+    for (int l = 0; l < 8; l++) H->phi_ver[l]++;
+    if (H->gap) suhmo_hier_invalidate_(H->gap);
+}
 const double *suhmo_hier_base_cover_(suhmo_hier *H, DV *whole)
 {
     if (!dist_base(H)) return nullptr;

@@ -18,9 +18,15 @@ print("setup %.2f s, boxes per level %s, cells %s" % (time.perf_counter() - t0, 
 for _ in range(3):
     H.timestep(mm["dt"])
 H.level[0][0].synchronize()
+if os.environ.get("SUHMO_TIMERS"):
+    from suhmo_amd import capi
+    capi.lib().suhmo_timers_reset()
 t0 = time.perf_counter()
 c = [H.timestep(mm["dt"]) for _ in range(nstep)]
 H.level[0][0].synchronize()
 dt = (time.perf_counter() - t0) / nstep
 print("base %d^2: %.2f ms per step, Picard %.1f, V-cycles %.1f per step" % (nb, 1e3 * dt, sum(a for a, _ in c) / nstep, sum(b for _, b in c) / nstep))
+if os.environ.get("SUHMO_TIMERS"):            # named scopes (mode 2: device time per scope; serialises)
+    from suhmo_amd import capi
+    print(capi.timers_report())
 H.close()
