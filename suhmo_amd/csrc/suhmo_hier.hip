@@ -143,7 +143,7 @@ struct suhmo_hier {
     long gathers = 0;
     // coarse-fine ghosts of the head of level l are current while neither level l's nor level l-1's head has been written since they
     // were interpolated: phi_ver[l] counts the writes, cf_seen[l] = the two versions the ghosts were made from
-    unsigned long phi_ver[8] = {1, 1, 1, 1, 1, 1, 1, 1}, cf_seen[8][2] = {};
+    unsigned long phi_ver[8] = {1, 1, 1, 1, 1, 1, 1, 1}, cf_seen[8][2] = {}, ff_seen[8] = {};    // ff_seen: likewise the fine-fine side ghosts
     bool phi_shadow_fresh = false;                         // the shadow's head is current: nothing has written level 0's head since its refresh
     DevVec<RectEnt> cover_full;                            // coarsen(boxes of level 1) in the shadow: COVER of the whole level 0
 };
@@ -728,6 +728,9 @@ int hier_ff(suhmo_hier *H, int l, int f0, int f1, bool corners, hipStream_t st)
     HLev &V = H->lev[l];
     int rc;
     if ((rc = ensure_field(H, l, f0)) || (f1 >= 0 && (rc = ensure_field(H, l, f1))) || (rc = refresh_tables(H, l, st))) return rc;
+    const bool head_sides = f0 == SUHMO_F_PHI && f1 < 0 && !corners;
+    if (head_sides && H->ff_seen[l] == H->phi_ver[l]) return 0;              // the side ghosts of the head are current
+    if (head_sides) H->ff_seen[l] = H->phi_ver[l];
     // (a corner ghost's source is a valid cell, never a ghost: sides and corners do not depend on each other)
     const DevVec<CopyEnt> &list = corners ? V.ff_all : V.ff_side;
     if (list.n) hipLaunchKernelGGL(k_ff, g1(list.n), dim3(256), 0, st, list.d, (int)list.n, V.d_fp, f0, f1);
@@ -853,15 +856,17 @@ int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
     int rc;
     suhmo_multi m;
     if ((rc = multi_of(H, l, HST(s), m))) return rc;
-    if (sweeps > 0) H->phi_ver[l]++;
-    // exchange() before every colour pass (:692, :751): once here, then every pass pushes its new side cells into the ghost
-    // cells they feed
+    // exchange() before every colour pass (:692, :751): once here (unless the side ghosts are current), then every pass pushes
+    // its new side cells into the ghost cells they feed
     if (sweeps > 0 && (rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
     for (int it = 0; it < sweeps; it++)
-        for (int pass = 0; pass < 2; pass++)
+        for (int pass = 0; pass < 2; pass++) {
             if ((rc = suhmo_multi_colour_pass(m, phys_of(H, l), has_alpha(H, l), pass, HST(s), H->push_ghosts))) return rc;
-            else if (!H->push_ghosts && (rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
+            H->phi_ver[l]++;
+            if (!H->push_ghosts && (rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
+        }
     if (sweeps > 0 && (rc = suhmo_multi_fill_ghosts(m, SUHMO_F_PHI, 1, HST(s)))) return rc;                        // :757-759
+    if (sweeps > 0 && H->push_ghosts) H->ff_seen[l] = H->phi_ver[l];          // every pass pushed its side cells: the ghosts are current
     return 0;
 }
 int hier_level_residual(suhmo_hier *H, int l, suhmo_stream_t s)   // residualI: RES

@@ -83,9 +83,12 @@ def test_hier_pieces_bitwise(oracle, bc, ph):
 
 
 @pytest.mark.parametrize("name,boxes,bc,ph", [("union-4lev", UNION, BC_NP, sy.CFG3_PHYS), ("union-4lev-values-mask", UNION, BC_V, MASKPH),
-                                              ("cut-periodic", CUT, BC, sy.CFG3_PHYS)], ids=lambda v: v if isinstance(v, str) else "")
-def test_hier_vcycle_and_solve_bitwise(oracle, name, boxes, bc, ph):
+                                              ("cut-periodic", CUT, BC, sy.CFG3_PHYS), ("union-4lev-exchange-per-pass", UNION, BC_NP, sy.CFG3_PHYS)],
+                         ids=lambda v: v if isinstance(v, str) else "")
+def test_hier_vcycle_and_solve_bitwise(oracle, name, boxes, bc, ph, monkeypatch):
     from suhmo_amd.level import F_PHI, F_RES, F_BX
+    if name.endswith("exchange-per-pass"):
+        monkeypatch.setenv("SUHMO_HIER_PUSH", "0")          # an exchange launch before every colour pass instead of the pushed side cells
     sp = dict(sy.SOLVER_DEFAULT, eps=1e-9, norm_thresh=1e-14, max_iter=6, imin=30)
     O, G, fs = pair(oracle, boxes, bc, ph)
     O.vcycle(sp); G.vcycle(sp)
