@@ -102,7 +102,9 @@ __global__ void k_amr_set_covered(DV vf, DV vc, double *__restrict__ c, double v
 // [Chombo] LevelFluxRegister (oracle/amr2.c:reflux): on every coarse-fine face the coarse flux is replaced by the
 // average of the two fine fluxes; L(phi) of the coarse cell outside the patch += sign * reg / (dx dy).
 // Fluxes as VCAMRNonLinearPoissonOp::getFlux (:792-841).  One thread per coarse face of the patch boundary.
-__global__ void k_amr_reflux(DV vf, FP ff, DV vc, FP fc, double *__restrict__ lofphi)
+// residual != 0: lofphi is the composite residual, already rhs - L(phi) everywhere; the cell gets rhs - (L(phi) + register), what
+// copy -> reflux -> axby(-1, 1) leaves there
+__global__ void k_amr_reflux(DV vf, FP ff, DV vc, FP fc, double *__restrict__ lofphi, int residual = 0)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int ncx = vf.nx / 2, ncy = vf.ny / 2, ci0 = vf.i0 / 2, cj0 = vf.j0 / 2;
@@ -131,7 +133,8 @@ __global__ void k_amr_reflux(DV vf, FP ff, DV vc, FP fc, double *__restrict__ lo
         reg = reg + (tsize * Ff) * 0.5;
     }
     int oidx = dir == 0 ? cidx(vc, outside - vc.i0, T - vc.j0) : cidx(vc, T - vc.i0, outside - vc.j0);
-    lofphi[oidx] = lofphi[oidx] + sign * rscale * reg;
+    if (residual) lofphi[oidx] = -1.0 * (fc.f[SUHMO_F_LPHI][oidx] + sign * rscale * reg) + 1.0 * fc.f[SUHMO_F_RHS][oidx];
+    else lofphi[oidx] = lofphi[oidx] + sign * rscale * reg;
 }
 
 // PROLONG_2_NL (src/AMRNonLinearPoissonOpF.ChF:660-705) from the coarse LEVEL's correction canvas (its ghost ring
@@ -458,6 +461,7 @@ extern "C" int suhmo_amr2_solve(suhmo_level_t *C, suhmo_level_t *F, const suhmo_
 // Rank strips: a rank holds of every level the rows of its own physical slab, so levels[l] may be NULL on a rank the
 // patch of level l does not reach.  Such a rank still runs the coarse half of every pair it has a coarse strip of (the
 // FAS right-hand side res' + L(phi) replaces rhs on the WHOLE coarse level) and every base-level collective.
+int suhmo_apply_and_residual(suhmo_level *L, int depth, hipStream_t st);      // suhmo_level.hip: LPHI and RES = rhs - LPHI in one pass
 namespace {
 // head of level l: coarse-fine ghosts from level l-1.  A rank with a strip of level l-1 but none of level l MIRRORS the
 // halo demand the interpolation puts on level l-1, so that every rank of that level's communicator runs the same sequence
@@ -476,18 +480,18 @@ int composite_residual(suhmo_level_t **lv, int l, suhmo_stream_t s)
     if (!C) return 0;
     hipStream_t st = (hipStream_t)s;
     int rc;
+    // one pass writes L(phi) and rhs - L(phi); the reflux kernel rewrites the cells next to the coarse-fine faces (as suhmo_hier.hip)
     if ((rc = cf_phi(lv, l - 1, s))) return rc;
-    if ((rc = suhmo_level_apply_op(C, 0, 0, s))) return rc;
-    double *res = suhmo_field(C, 0, SUHMO_F_RES), *lphi = suhmo_field(C, 0, SUHMO_F_LPHI);
-    HIPCHK(hipMemcpyAsync(res, lphi, C->d[0].elems * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if ((rc = suhmo_apply_and_residual(C, 0, st))) return rc;
+    double *res = suhmo_field(C, 0, SUHMO_F_RES);
     if ((rc = cf_phi(lv, l, s))) return rc;
     if (F) {
         const DV &vf = F->d[0].v, &vc = C->d[0].v;
         int n = vf.ny + vf.nx;
-        hipLaunchKernelGGL(k_amr_reflux, dim3((n + 255) / 256), dim3(256), 0, st, vf, F->d[0].fp, vc, C->d[0].fp, res);
+        hipLaunchKernelGGL(k_amr_reflux, dim3((n + 255) / 256), dim3(256), 0, st, vf, F->d[0].fp, vc, C->d[0].fp, res, 1);
         HIPCHK(hipGetLastError());
     }
-    return suhmo_level_axby(C, 0, SUHMO_F_RES, SUHMO_F_RES, SUHMO_F_RHS, -1.0, 1.0, s);
+    return 0;
 }
 int vcycle_amr(suhmo_level_t **lv, int l, const suhmo_solver_params_t *sp, suhmo_stream_t s)
 {
