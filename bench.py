@@ -190,7 +190,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "GSRB sweep (red+black) at depth 0", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "frac_note": "algorithmic bytes (72 B per cell per sweep) / time / peak, SURVEY 8(d); the kernel does K = 2 sweeps per "
-                                      "pass over HBM, so this is an effective rate: physical_frac is the HBM utilisation",
+                                      "pass over HBM and skips the ice-mask array when the V-cycle's UpdateOperator found no negative cell, so this "
+                                      "is an effective rate that can exceed 1: physical_frac is the HBM utilisation",
                          # HBM bytes the launch really moved (PMC) / time / peak, and the bound of a K-sweep blocked launch (72 B per cell ONCE) / time / peak
                          "physical_frac": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "blocked_bound_frac": (BYTES_PER_CELL_SWEEP * cells / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if gsrb_launches else None,

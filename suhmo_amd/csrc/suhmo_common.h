@@ -167,6 +167,10 @@ struct suhmo_level {
     int fused_hc;               // rows per chunk of the fused kernel (0 = auto); env SUHMO_FUSED_HC
     int strips_rhs_local;       // rank strips: R phi and RES travel together, the coarse right-hand side of the halo rows is computed locally
                                 // (env SUHMO_STRIPS_RHS_LOCAL, default 1)
+    int skip_mask;              // the streaming relaxation skips the ice-mask array in a V-cycle whose UpdateOperator found no negative cell
+                                // (env SUHMO_SKIP_MASK, default 1)
+    int mask_reported;          // the last suhmo_level_update_operator(depth 0) made that report
+    unsigned mask_epoch, maskflag_epoch;   // number of the last k_bcoef_fused call on depth 0; the call whose report is current (0: none)
     int overlap_halo;           // rank strips, streaming kernel: the halo exchange travels on a second stream while the chunks that do not
                                 // read halo rows relax; the two end chunks follow (env SUHMO_OVERLAP_HALO, default 1)
     hipStream_t xstream; hipEvent_t xev[2]; long overlapped;   // ... its stream and events; launches that overlapped so far

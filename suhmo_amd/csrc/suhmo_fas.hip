@@ -92,9 +92,12 @@ static int vcycle_body(suhmo_level *L, const suhmo_solver_params_t *sp, int nd, 
     int rc;
     if (sp->bcoeff_otf) {
         if ((rc = suhmo_level_update_operator(L, 0, s))) return rc;
+        if (L->mask_reported) L->maskflag_epoch = L->mask_epoch;                   // the relaxations of THIS cycle may rely on the report
         if ((rc = suhmo_average_operator_all(L, nd, (hipStream_t)s))) return rc;   // AverageOperator on every depth > 0
-    }
-    return fas_cycle(L, 0, sp, nd, s);
+    } else L->maskflag_epoch = 0;
+    rc = fas_cycle(L, 0, sp, nd, s);
+    L->maskflag_epoch = 0;                  // the report on the ice mask (k_bcoef_fused) holds for this cycle only: the caller may load another mask
+    return rc;
 }
 
 // Small levels are launch-bound (a 1024^2 V-cycle is ~170 dependent launches of a few microseconds each): the cycle is a

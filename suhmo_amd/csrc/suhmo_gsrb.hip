@@ -114,6 +114,7 @@ struct FusedGeom {
     int jbeg, jend; // rows written: [jbeg, jend) = the strip's rows plus, on rank boundaries, the halo rows that
                     // stay valid after this launch (advanced redundantly so the next launch needs no exchange)
     int wrap_y;   // rows outside [0, ny) are periodic images (single-rank periodic y)
+    const unsigned *negflag; unsigned mask_epoch;   // *negflag == mask_epoch: the ice mask has a negative cell (k_bcoef_fused of this V-cycle); NULL: read the mask
     int nchl, chunk0, chunk1, edges;   // chunks of THIS launch: nchl of them starting at chunk0, or (edges) all but [chunk0, chunk1) --
                                // a rank strip relaxes its inner chunks while the halo rows travel, the end chunks afterwards
     // FAS prolongIncrement fused into the load of phi (PROLONGNL, AMRNonLinearPoissonOpF.ChF:619-627):
@@ -189,6 +190,9 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
     const bool xbc = !v.per[0] && (c0 - HX <= 0 || c0 + g.W + HX >= v.nx);
     const bool ybc = !v.per[1] && (jmin <= 0 || jmax >= v.ny - 1);
     double2 pnext = make_double2(0.0, 0.0);
+    // the mask array is 8 of the 80 bytes a cell costs per launch and only its sign is used: when this V-cycle's UpdateOperator saw
+    // no negative cell the loads are skipped (uniform)
+    const bool usemask = !g.negflag || *g.negflag == g.mask_epoch;
 
     int sr = 0;                            // LDS ring slot of row r
     for (int r = jmin - 1; r <= jB - 1 + 2 * K + EY; r++) {
@@ -208,7 +212,8 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
             int idx = cidx(v, im, wrapj(r));
 #define LD2(dst, p, ix) { double2 t_ = ld2(p, ix); dst[0] = t_.x; dst[1] = t_.y; }
             LD2(cf0.rhs, f_rhs, idx); LD2(cf0.B, f_B, idx); LD2(cf0.Pi, f_Pi, idx);
-            LD2(cf0.zb, f_zb, idx); LD2(cf0.mask, f_mask, idx);
+            LD2(cf0.zb, f_zb, idx);
+            if (usemask) { LD2(cf0.mask, f_mask, idx); } else { cf0.mask[0] = 1.0; cf0.mask[1] = 1.0; }
             if (HAS_ALPHA) LD2(cf0.a, f_a, idx);
             LD2(cf0.byS, f_by, idx); LD2(cf0.byN, f_by, idx + v.P);
             double2 bxp = ld2(f_bx, idx);
@@ -396,6 +401,10 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st,
         Depth &C = L->d[depth + 1];
         g.pc = C.fp.f[SUHMO_F_PHI]; g.pco = C.fp.f[SUHMO_F_PHIOLD]; g.Pc = C.v.P; g.gyc = C.v.gy;
         if (part != 1) D.prolong_pending = 0;
+    }
+    g.negflag = nullptr; g.mask_epoch = 0;
+    if (depth == 0 && L->skip_mask && L->maskflag_epoch && L->maskflag_epoch == L->mask_epoch && !(v.ext[0] || v.ext[1])) {
+        g.negflag = (const unsigned *)(L->scratch + L->scratch_elems - 1); g.mask_epoch = L->mask_epoch;
     }
     g.rres = g.rphi = nullptr; g.rP = g.rgy = 0;
     if (RST) {

@@ -221,6 +221,9 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     }
     L->scratch_elems = 16384;
     HIPCHK(hipMalloc(&L->scratch, L->scratch_elems * sizeof(double)));
+    HIPCHK(hipMemset(L->scratch, 0, L->scratch_elems * sizeof(double)));                   // (its last word: the negative-mask report of k_bcoef_fused)
+    L->mask_epoch = 0; L->maskflag_epoch = 0; L->mask_reported = 0; L->skip_mask = 1;
+    if (const char *e = getenv("SUHMO_SKIP_MASK")) L->skip_mask = atoi(e);
     HIPCHK(hipHostMalloc(&L->hscratch, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     memset(L->hscratch, 0, 64 * sizeof(double));
     L->hscratch_dev = nullptr; L->hseq = 0; L->poll_readback = 1;
@@ -291,7 +294,7 @@ static int *option_slot_int(suhmo_level *L, const char *key)
     static const struct { const char *k; int suhmo_level::*m; } tab[] = {
         {"gsrb_variant", &suhmo_level::gsrb_variant}, {"fused_hc", &suhmo_level::fused_hc}, {"bcoef_fused", &suhmo_level::bcoef_fused},
         {"fused_nt", &suhmo_level::fused_nt}, {"fused_restrict", &suhmo_level::fused_restrict}, {"strips_rhs_local", &suhmo_level::strips_rhs_local},
-        {"tile_strips", &suhmo_level::tile_strips}, {"overlap_halo", &suhmo_level::overlap_halo}, {"tile_chunks", &suhmo_level::tile_chunks}, {"fas_rhs_in_relax", &suhmo_level::fas_rhs_in_relax},
+        {"tile_strips", &suhmo_level::tile_strips}, {"overlap_halo", &suhmo_level::overlap_halo}, {"skip_mask", &suhmo_level::skip_mask}, {"tile_chunks", &suhmo_level::tile_chunks}, {"fas_rhs_in_relax", &suhmo_level::fas_rhs_in_relax},
         {"tile_s", &suhmo_level::tile_s}, {"gsrb_tile", &suhmo_level::gsrb_tile}, {"tile_t", &suhmo_level::tile_t}, {"poll_readback", &suhmo_level::poll_readback}};
     for (const auto &e : tab) if (!strcmp(key, e.k)) return &(L->*(e.m));
     return nullptr;
@@ -1042,7 +1045,8 @@ __global__ __launch_bounds__(256) void k_bcoef_faces_m(const DV *__restrict__ vt
 // INTERIOR: the tile and its two-cell halo lie inside the level -- no boundary condition, no wrap, no missing cell: the
 // same expressions without the case distinctions (most tiles; uniform per workgroup)
 template <bool INTERIOR>
-__device__ __forceinline__ void bcoef_tile(const DV &v, const FP &fp, const suhmo_phys_t &ph, int hasMask, double *sphi, double *sB, double *sM)
+__device__ __forceinline__ void bcoef_tile(const DV &v, const FP &fp, const suhmo_phys_t &ph, int hasMask, double *sphi, double *sB, double *sM,
+                                           unsigned *negflag, unsigned epoch)
 {
     constexpr int PW = BT_X + 4, PH = BT_Y + 4;     // phi tile: cells [i0-2, i0+BT_X+1] x [j0-2, j0+BT_Y+1]
     constexpr int RW = BT_X + 2, RH = BT_Y + 2;     // Re tile:  cells [i0-1, i0+BT_X]   x [j0-1, j0+BT_Y]
@@ -1086,15 +1090,20 @@ __device__ __forceinline__ void bcoef_tile(const DV &v, const FP &fp, const suhm
     const bool xi = xin(i);
     double Br[NK];
     bool hasB[NK];
+    bool neg = false;
 #pragma unroll
     for (int k = 0; k < NK; k++) {
         const int lj = ty + 4 * k, j = j0 - 1 + lj;
         hasB[k] = INTERIOR || (i >= -1 && i <= v.nx && j >= -v.gy && j <= v.ny + v.gy - 1 && !((i < 0 || i >= v.nx) && (j < 0 || j >= v.ny)));
         double b = 0.0, m = 0.0;
         if (hasB[k]) { int idx = cidx(v, i, j); b = Bf[idx]; m = mk[idx]; }
+        neg = neg || (m < 0.0 && i >= 0 && i < v.nx && j >= 0 && j < v.ny);      // (no branch here: the loads of the unrolled rows stay batched)
         Br[k] = b;
         sB[lj * RW + tx] = b; sM[lj * RW + tx] = m;
     }
+    // this pass sees the ice mask of every cell of the level anyway: it leaves word whether any is negative, so that the relaxation
+    // launches of the same V-cycle may skip reading the array (suhmo_gsrb.hip; COMPUTENONLINEARTERMS only asks mask < 0)
+    if (negflag && neg) *negflag = epoch;
     __syncthreads();
     // cell-centred gradient of the cell at phi-tile position p (k_gradcc); (gi, gj) = its indices
     auto gradcc = [&](int p, int gi, int gj, double &gx, double &gy) {
@@ -1162,13 +1171,13 @@ __device__ __forceinline__ void bcoef_tile(const DV &v, const FP &fp, const suhm
         }
     }
 }
-__global__ __launch_bounds__(256) void k_bcoef_fused(DV v, FP fp, suhmo_phys_t ph, int hasMask)
+__global__ __launch_bounds__(256) void k_bcoef_fused(DV v, FP fp, suhmo_phys_t ph, int hasMask, unsigned *negflag, unsigned epoch)
 {
     __shared__ double sphi[(BT_X + 4) * (BT_Y + 4)], sB[(BT_X + 2) * (BT_Y + 2)], sM[(BT_X + 2) * (BT_Y + 2)];
     const int i0 = blockIdx.x * BT_X, j0 = blockIdx.y * BT_Y;
     const bool interior = i0 - 2 >= 0 && i0 + BT_X + 1 <= v.nx - 1 && j0 - 2 >= 0 && j0 + BT_Y + 1 <= v.ny - 1;
-    if (interior) bcoef_tile<true>(v, fp, ph, hasMask, sphi, sB, sM);
-    else bcoef_tile<false>(v, fp, ph, hasMask, sphi, sB, sM);
+    if (interior) bcoef_tile<true>(v, fp, ph, hasMask, sphi, sB, sM, negflag, epoch);
+    else bcoef_tile<false>(v, fp, ph, hasMask, sphi, sB, sM, negflag, epoch);
 }
 
 extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_stream_t s)
@@ -1185,8 +1194,18 @@ extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_st
     int rc = suhmo_ensure_phi_halo(L, depth, fused ? 2 : 1, st); if (rc) return rc;
     if (fused) {
         dim3 grd((D.v.nx + BT_X - 1) / BT_X, (D.v.ny + BT_Y - 1) / BT_Y);   // the last tile column / row also owns the E / N faces
-        hipLaunchKernelGGL(k_bcoef_fused, grd, dim3(64, 4), 0, st, D.v, D.fp, L->ph, L->ph.use_mask_gradients);
+        // depth 0 of a whole level: the kernel also reports (device word = this call's number) whether the ice mask has a negative cell
+        // (the V-cycle that called takes the report up, suhmo_fas.hip: it holds until that cycle ends, not across calls of this entry point)
+        unsigned *flag = nullptr;
+        if (depth == 0) { L->maskflag_epoch = 0; L->mask_reported = 0; }
+        if (depth == 0 && L->skip_mask && !(D.v.ext[0] || D.v.ext[1])) {
+            flag = (unsigned *)(L->scratch + L->scratch_elems - 1);
+            if (++L->mask_epoch == 0) L->mask_epoch = 1;
+            L->mask_reported = 1;
+        }
+        hipLaunchKernelGGL(k_bcoef_fused, grd, dim3(64, 4), 0, st, D.v, D.fp, L->ph, L->ph.use_mask_gradients, flag, L->mask_epoch);
     } else {
+        if (depth == 0) { L->maskflag_epoch = 0; L->mask_reported = 0; }
         if (!suhmo_field(L, depth, SUHMO_F_GRADX) || !suhmo_field(L, depth, SUHMO_F_GRADY) || !suhmo_field(L, depth, SUHMO_F_RE)) return -2;
         hipLaunchKernelGGL(k_gradcc, grid2d(D.v.nx, D.v.ny), BLK2D, 0, st, D.v, D.fp, L->ph.use_mask_gradients);
         rc = exchange_fields(L, depth, {SUHMO_F_GRADX, SUHMO_F_GRADY}, st); if (rc) return rc;
