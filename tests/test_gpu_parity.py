@@ -459,3 +459,25 @@ def test_named_timers_report_the_reference_labels():
     first = rep.splitlines()[0].split()
     assert first[0] == "AMRFASMultiGrid::solve" and int(first[1]) == 1 and float(first[2]) > 0.0
     G.close()
+
+
+def test_mask_report_follows_the_mask(oracle, hip, monkeypatch):
+    """the streaming relaxation skips the ice-mask array when the V-cycle's UpdateOperator found no negative cell (a device word
+    written by k_bcoef_fused, valid for that cycle only): a mask that turns negative between two cycles is seen by the next one"""
+    monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "1")
+    monkeypatch.setenv("SUHMO_GSRB_TILE", "0")
+    f = sy.shmip_fields(512, 256)
+    f.pop("bx", None); f.pop("by", None)
+    assert (f["mask"][1:-1, 1:-1] > 0).all()          # (the ghost column beyond x = 0 is -1: the kernel's report looks at valid cells only)
+    O, G = pair(oracle, hip, f, sy.A3_BC, sy.A3_PHYS, 0.0, -1.0, 64)
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-10, norm_thresh=1e-13, max_iter=3, imin=6)
+    masks = [f["mask"].copy() for _ in range(3)]
+    masks[1][60:140, 200:330] = -1.0                  # an ice-free island appears ...
+    masks[2][:] = f["mask"]                           # ... and is gone again
+    for k, m in enumerate(masks):
+        O.set(oracle.F_MASK, m, ghosted=True); G.set(hip.F_MASK, m, ghosted=True)
+        O.build_mg_coefficients(); G.build_mg_coefficients()
+        for it in range(2):
+            O.vcycle(sp); G.vcycle(sp)
+            assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI)), (k, it)
+    assert G.get_option("skip_mask") == 1
