@@ -435,6 +435,7 @@ struct TileGeom {
     int frhs;                                // first relaxation of a coarse FAS depth: rhs = res + L(phi) is formed here
     int jbeg, jend;                          // rows written: the level's, plus on a rank strip the halo rows that stay current for the next launch
     int chunks;                              // level = one tile: this many times S sweeps in the launch (halo images refreshed in LDS)
+    int order;                               // workgroup -> tile: 0 as launched, 1 / 2 XCD-aware (see k_gsrb_tile)
 };
 struct PairCoef { double rhs0, rhs1, B0, B1, Pi0, Pi1, zb0, zb1, mk0, mk1, a0, a1, byS0, byS1, byN0, byN1, bx0, bx1, bx2; };
 
@@ -453,7 +454,19 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
     constexpr int LX = TX + 2 * HX, LY = TY + 2 * HY, NP = LX / 2, NPAIR = NP * LY, NK = (NPAIR + 255) / 256;
     __shared__ double lds[LY * LX];
     __shared__ double lq[RST ? TY * TX : 1];                  // RST: (rhs - L(phi)) / 4 of the tile's cells
-    const int tx = blockIdx.x % g.ntx, ty = blockIdx.x / g.ntx;
+    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: every XCD takes a contiguous run of the tile list, so
+    // that the tiles in flight on it are neighbours and the halo cells they share (2.25 x the tile's own at S = 4) are read from HBM
+    // once.  order 2 lists the tiles in panels of 8 tile rows, column by column: the 64 tiles an XCD holds at a time form a square.
+    int tl = blockIdx.x;
+    if (g.order) {
+        const int nt = g.ntx * g.nty, q8 = nt / 8, rem = nt % 8, xcd = tl % 8;
+        tl = xcd * q8 + (xcd < rem ? xcd : rem) + tl / 8;
+    }
+    int tx = tl % g.ntx, ty = tl / g.ntx;
+    if (g.order == 2) {
+        const int pan = tl / (8 * g.ntx), r = tl - pan * 8 * g.ntx, hp = (g.nty - 8 * pan < 8) ? g.nty - 8 * pan : 8;
+        tx = r / hp; ty = 8 * pan + r % hp;
+    }
     const int tj0 = g.jbeg + ty * TY;                         // first row the tile writes
     const int gx0 = tx * TX - HX, gy0 = tj0 - HY;             // domain cell of LDS cell (0, 0)
     const int t = threadIdx.x;
@@ -729,6 +742,7 @@ static int launch_tile(suhmo_level *L, int depth, int chunks, int ext_rows, hipS
         D.prolong_pending = 0;
     }
     g.chunks = chunks;
+    g.order = L->tile_order;
     g.frhs = 0;
     if (D.rhs_pending) {
         if (!suhmo_field(L, depth, SUHMO_F_LPHI) || !suhmo_field(L, depth, SUHMO_F_PHIOLD)) return -2;
