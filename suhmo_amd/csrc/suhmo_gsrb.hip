@@ -869,7 +869,7 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
         int K = pick_K(L, D, variant, sweeps - it);   // sweeps done by the next launch (0 = simple path, 1 sweep)
         int TS = (K == 0 && tile_ok(L, D)) ? (sweeps - it >= 4 && L->tile_s >= 4 ? 4 : sweeps - it >= 2 && L->tile_s >= 2 ? 2 : 1) : 0;   // sweeps of a tile launch
         int tE = 0;                                            // rank strip: halo rows the tile launch advances redundantly
-        bool trst = TS && restricted && L->fused_restrict && depth + 1 < L->ndepth && !(D.v.ny & 1) && !(D.v.j0 & 1);
+        bool trst = TS && restricted && L->fused_restrict && (L->tile_restrict == 1 || (L->tile_restrict == 2 && ext)) && depth + 1 < L->ndepth && !(D.v.ny & 1) && !(D.v.j0 & 1);
         if (TS && ext) {
             // rank strip: the tile's halo rows beyond the strip are the neighbour's cells: 2S of them must be current (one more
             // when the launch also restricts); they are advanced redundantly and stale afterwards

@@ -153,7 +153,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     L->tile_max_cells = 8000000;
     L->fas_rhs_in_relax = 1;
     L->tile_chunks = 1;
-    L->tile_order = 2;
+    L->tile_order = 2; L->tile_restrict = 2;
     L->tile_strips = 1;
     L->overlap_halo = 1; L->xstream = nullptr; L->xev[0] = L->xev[1] = nullptr; L->overlapped = 0;
     if (const char *e = getenv("SUHMO_OVERLAP_HALO")) L->overlap_halo = atoi(e);
@@ -161,6 +161,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     if (const char *e = getenv("SUHMO_STRIPS_RHS_LOCAL")) L->strips_rhs_local = atoi(e);
     if (const char *e = getenv("SUHMO_TILE_STRIPS")) L->tile_strips = atoi(e);
     if (const char *e = getenv("SUHMO_TILE_CHUNKS")) L->tile_chunks = atoi(e);
+    if (const char *e = getenv("SUHMO_TILE_RESTRICT")) L->tile_restrict = atoi(e);
     if (const char *e = getenv("SUHMO_TILE_ORDER")) { L->tile_order = atoi(e); if (L->tile_order < 0 || L->tile_order > 2) L->tile_order = 0; }
     if (const char *e = getenv("SUHMO_FAS_RHS_IN_RELAX")) L->fas_rhs_in_relax = atoi(e);
     if (const char *e = getenv("SUHMO_TILE_MAX_CELLS")) L->tile_max_cells = atol(e);
@@ -296,7 +297,7 @@ static int *option_slot_int(suhmo_level *L, const char *key)
     static const struct { const char *k; int suhmo_level::*m; } tab[] = {
         {"gsrb_variant", &suhmo_level::gsrb_variant}, {"fused_hc", &suhmo_level::fused_hc}, {"bcoef_fused", &suhmo_level::bcoef_fused},
         {"fused_nt", &suhmo_level::fused_nt}, {"fused_restrict", &suhmo_level::fused_restrict}, {"strips_rhs_local", &suhmo_level::strips_rhs_local},
-        {"tile_strips", &suhmo_level::tile_strips}, {"overlap_halo", &suhmo_level::overlap_halo}, {"skip_mask", &suhmo_level::skip_mask}, {"tile_chunks", &suhmo_level::tile_chunks}, {"tile_order", &suhmo_level::tile_order}, {"fas_rhs_in_relax", &suhmo_level::fas_rhs_in_relax},
+        {"tile_strips", &suhmo_level::tile_strips}, {"overlap_halo", &suhmo_level::overlap_halo}, {"skip_mask", &suhmo_level::skip_mask}, {"tile_chunks", &suhmo_level::tile_chunks}, {"tile_order", &suhmo_level::tile_order}, {"tile_restrict", &suhmo_level::tile_restrict}, {"fas_rhs_in_relax", &suhmo_level::fas_rhs_in_relax},
         {"tile_s", &suhmo_level::tile_s}, {"gsrb_tile", &suhmo_level::gsrb_tile}, {"tile_t", &suhmo_level::tile_t}, {"poll_readback", &suhmo_level::poll_readback}};
     for (const auto &e : tab) if (!strcmp(key, e.k)) return &(L->*(e.m));
     return nullptr;
