@@ -767,11 +767,12 @@ static int launch_tile(suhmo_level *L, int depth, int chunks, int ext_rows, hipS
     std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
     return 0;
 }
-// tile edge: 16 below 200 k cells (enough workgroups for the chip; also the shorter launch on tiny levels), 32 above
+// tile edge: 16 below 600 k cells (enough workgroups for the chip -- 512^2 is 256 tiles of 32, one per CU: 6.4 us per sweep against
+// 5.7 on 1024 tiles of 16; also the shorter launch on tiny levels), 32 above (1024^2: 15.0 against 17.2)
 static int tile_edge(const suhmo_level *L, const DV &v)
 {
     if (L->tile_t) return L->tile_t;
-    return ((long)v.nx * v.ny >= 200000L) ? 32 : 16;
+    return ((long)v.nx * v.ny >= 600000L) ? 32 : 16;
 }
 // a level that is ONE tile (16-wide, or 32-wide when there are sweeps enough to pay for the larger region) can take all its
 // sweeps in one launch; returns the tile edge to use or 0
