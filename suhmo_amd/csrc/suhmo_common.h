@@ -178,8 +178,8 @@ struct suhmo_level {
     int tile_chunks;            // a level that is one tile relaxes all its sweeps in one launch (env SUHMO_TILE_CHUNKS, default 1)
     int fas_rhs_in_relax;       // coarse FAS right-hand side formed by the first tile relax of the depth (env SUHMO_FAS_RHS_IN_RELAX, default 1)
     long tile_max_cells;        // auto mode: levels below this many cells relax on the tile kernel (env SUHMO_TILE_MAX_CELLS)
-    int tile_restrict;          // the tile kernel's last pre-smoothing launch also restricts: 0 never (a separate kernel restricts), 1 always, 2 on rank strips only
-                                // (default: on one GPU the separate kernel is faster, profiles/r02_h_*; env SUHMO_TILE_RESTRICT)
+    int tile_restrict;          // the tile kernel's last pre-smoothing launch also restricts: 0 never (a separate kernel restricts: faster on one GPU and
+                                // on a rank strip alike, profiles/r02_h_tile_restrict_ab.txt), 1 always, 2 on rank strips only (env SUHMO_TILE_RESTRICT, default 0)
     int tile_order;             // workgroup -> tile map of the tile kernel: 0 as launched, 1 a contiguous run of tiles per XCD, 2 the same in panels of 8 tile rows (env SUHMO_TILE_ORDER)
     int gsrb_tile, tile_t, tile_s;      // cache-resident depths: S sweeps per launch on LDS tiles (env SUHMO_GSRB_TILE, default 1); tile edge 16 / 32
                                 // (env SUHMO_TILE_T, 0 = by size)

@@ -153,7 +153,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     L->tile_max_cells = 8000000;
     L->fas_rhs_in_relax = 1;
     L->tile_chunks = 1;
-    L->tile_order = 2; L->tile_restrict = 2;
+    L->tile_order = 2; L->tile_restrict = 0;
     L->tile_strips = 1;
     L->overlap_halo = 1; L->xstream = nullptr; L->xev[0] = L->xev[1] = nullptr; L->overlapped = 0;
     if (const char *e = getenv("SUHMO_OVERLAP_HALO")) L->overlap_halo = atoi(e);

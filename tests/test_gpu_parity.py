@@ -288,7 +288,7 @@ def test_vcycle_on_tile_kernels(oracle, hip, case, tile, fused_restrict, tile_t,
     relaxation or by its own kernel) and with the tile kernel off (colour passes): all bitwise the oracle's"""
     monkeypatch.setenv("SUHMO_GSRB_TILE", str(tile))
     monkeypatch.setenv("SUHMO_FUSED_RESTRICT", str(fused_restrict))
-    monkeypatch.setenv("SUHMO_TILE_RESTRICT", str(fused_restrict))      # (default: only on rank strips)
+    monkeypatch.setenv("SUHMO_TILE_RESTRICT", str(fused_restrict))      # (default 0: a separate kernel)
     monkeypatch.setenv("SUHMO_TILE_T", str(tile_t))
     monkeypatch.setenv("SUHMO_FAS_RHS_IN_RELAX", str(rhs_in_relax))
     monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "100000000")

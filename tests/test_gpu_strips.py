@@ -103,7 +103,7 @@ def test_strips_gsrb_and_operators(case, variant, halo, monkeypatch):
 
 @pytest.mark.parametrize("world,halo,fused", [(2, 4, 0), (4, 4, 0), (2, 16, 0), (4, 9, 0), (2, 16, 1), (4, 12, 1), (2, 24, 0), (2, 24, 1), (4, 24, 1), (2, 1, 0),
                                               (2, 24, "no-tile"), (4, 12, "no-tile"), (2, 24, "rhs-exchanged"), (2, 24, "copy-readback"),
-                                              (2, 16, "overlap"), (4, 12, "overlap"), (2, 16, "no-overlap"), (2, 24, "separate-restriction"), (4, 12, "separate-restriction")])
+                                              (2, 16, "overlap"), (4, 12, "overlap"), (2, 16, "no-overlap"), (2, 24, "fused-restriction"), (4, 12, "fused-restriction")])
 def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
     """strips of 2 / 4 ranks against the oracle's whole level, bitwise.  Halo >= 10 rows: the tile kernel relaxes the strips
     (halo rows advanced redundantly), R phi + RES travel together and the halo rows' right-hand side is computed locally; the
@@ -118,8 +118,8 @@ def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
         monkeypatch.setenv("SUHMO_TILE_STRIPS", "0")
     elif fused == "rhs-exchanged":
         monkeypatch.setenv("SUHMO_STRIPS_RHS_LOCAL", "0")
-    elif fused == "separate-restriction":
-        monkeypatch.setenv("SUHMO_TILE_RESTRICT", "0")
+    elif fused == "fused-restriction":
+        monkeypatch.setenv("SUHMO_TILE_RESTRICT", "1")       # the tile launch that ends the pre-smoothing also restricts (default: its own kernel)
     elif fused == "copy-readback":
         monkeypatch.setenv("SUHMO_POLL_READBACK", "0")
     elif fused in ("overlap", "no-overlap"):
