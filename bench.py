@@ -165,9 +165,20 @@ def main():
     if world == 1 and not args.no_side:
         extra["other_configs"] = side_configs(sy, level, sp, args)
 
-    cpu = None
+    cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(sy, n if n <= 4096 else 4096, sp)
+        cpu, phi_cpu, ncyc = cpu_baseline(sy, n if n <= 4096 else 4096, sp)
+        if n <= 4096:
+            # the level that was just timed, reloaded with the same inputs, against the checker after the same number of cycles:
+            # bit for bit at the size the headline is quoted on (outside the timed region)
+            G.set_inputs(f); G.build_mg_coefficients()
+            for _ in range(ncyc):
+                G.vcycle(sp)
+            phi_gpu = G.get(level.F_PHI)
+            parity = bool(np.array_equal(phi_gpu, phi_cpu))
+            if not parity:
+                sys.exit("bench.py: the HIP V-cycles differ from the CPU restatement at %dx%d: max |d| = %g" % (n, n, float(np.max(np.abs(phi_gpu - phi_cpu)))))
+            del phi_gpu, phi_cpu
 
     if rank == 0:
         out = {
@@ -189,6 +200,7 @@ def main():
             "gsrb_depth0_cell_updates_per_s_kernel": cells / (sweep_ms * 1e-3) * world if gsrb_launches else None,
             "roofline": {"bound": "hbm", "kernel": "GSRB sweep (red+black) at depth 0", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "frac_is": "effective (temporal blocking: K = 2 sweeps per pass over HBM); HBM utilisation = physical_frac",
                          "frac_note": "algorithmic bytes (72 B per cell per sweep) / time / peak, SURVEY 8(d); the kernel does K = 2 sweeps per "
                                       "pass over HBM and skips the ice-mask array when the V-cycle's UpdateOperator found no negative cell, so this "
                                       "is an effective rate that can exceed 1: physical_frac is the HBM utilisation",
@@ -200,6 +212,8 @@ def main():
                          "algorithmic_bytes_per_cell_sweep": BYTES_PER_CELL_SWEEP,
                          "avg_sweep_ms": sweep_ms, "sweeps_timed": sweeps_timed, "launches_timed": gsrb_launches},
             "cpu_baseline": cpu,
+            # head after the cpu_baseline's V-cycles: HIP level == CPU restatement, np.array_equal, at this very size (None: no CPU leg)
+            "parity_at_bench_size": parity,
         }
         out.update(extra)
         print(json.dumps(out))
@@ -365,6 +379,7 @@ def cpu_baseline(sy, n, sp):
     for _ in range(reps):
         O.vcycle(sp)
     dt = time.perf_counter() - t0
+    phi = O.get(po.F_PHI)
     t0 = time.perf_counter()
     O.gsrb(2)
     dts = time.perf_counter() - t0
@@ -372,7 +387,7 @@ def cpu_baseline(sy, n, sp):
     return {"value": reps / dt, "unit": "V-cycles/s", "cores": cores, "kind": "port",
             "sample": "%d V-cycles of the same %dx%d workload (after 1 warm-up), CPU restatement of the "
                       "reference path (oracle level shim, 64^2 boxes, OpenMP over boxes)" % (reps, n, n),
-            "gsrb_cell_updates_per_s": 2 * n * n / dts}
+            "gsrb_cell_updates_per_s": 2 * n * n / dts}, phi, 1 + reps
 
 
 if __name__ == "__main__":

@@ -210,6 +210,17 @@ typedef struct suhmo_model_params {
     int use_moulin_source;             /* suhmo.n_moulins > 0: RHS_h += MSRC * ramp + distributed_input (:3060-3066) */
     double ramp;                       /* suhmo.ramp factor of this step (:2448-2467); 1 when off */
     int use_impl_diff;                 /* solver.use_ImplDiff: gap height by the implicit VC Helmholtz solve (:593-662) */
+    /* Run-state settings (0, 0 = the committed source).  The reference's committed result tables (exec/{A,B,E,F}_SHMIP/.../
+     * results/postproc.dat) were written by a code state that differs from the committed source in these two places -- read off the
+     * tables themselves, DESIGN.md section 4 -- so a run that is to be diffed against those tables sets them:
+     *   head_melt_off       1: RHS_h without the melt term mR (1/rho_w - 1/rho_i) (src/AmrHydro.cpp:3046-3048; the term is
+     *                       multiplied by 0.0, as the test oracle's knob does)
+     *   freeze_icefree_gap  1: the gap height of cells without ice (iceMask < 0) is left as it is by the implicit gap-height
+     *                       solve (SolveForGap_nl, :593-662, :3425-3455; CalcRHS_gapHeightFAS :2069-2171 with use_mask_rhs_b already
+     *                       keeps it in the explicit update)
+     * The third setting of suite F, the surface elevation in the field the lapse rate reads (src/ValleyIBC.cpp:299 ends with the
+     * ice thickness), is data: load SUHMO_F_ZS with whichever field the run is to use. */
+    int head_melt_off, freeze_icefree_gap;
 } suhmo_model_params_t;
 /* cur_step = AmrHydro::m_cur_step after its increment (1 for the first step): selects the solver
  * parameters and the Picard stopping rule.  picard_iters / vcycles: totals of this step. */

@@ -33,7 +33,8 @@ class OrModelParams(C.Structure):
                 ("br", C.c_double), ("lr", C.c_double), ("diffFactor", C.c_double),
                 ("distributed_input", C.c_double), ("eps_picard", C.c_double),
                 ("basal_friction", C.c_int), ("use_mask_rhs_b", C.c_int), ("use_moulin_source", C.c_int),
-                ("ramp", C.c_double), ("use_impl_diff", C.c_int)]
+                ("ramp", C.c_double), ("use_impl_diff", C.c_int),
+                ("head_melt_off", C.c_int), ("freeze_icefree_gap", C.c_int)]
 
 
 class OrSolverParams(C.Structure):
@@ -318,7 +319,8 @@ def make_model_params(m):
     return OrModelParams(m["rho_i"], m["rho_w"], m["gravity"], m["G"], m["L"], m["ct"], m["cw"], m["ub"][0], m["ub"][1],
                          m["br"], m["lr"], m["diffFactor"], m["distributed_input"], m["eps_picard"],
                          int(m["basal_friction"]), int(m.get("use_mask_rhs_b", 0)), int(m.get("use_moulin_source", 0)),
-                         float(m.get("ramp", 1.0)), int(m.get("use_impl_diff", 0)))
+                         float(m.get("ramp", 1.0)), int(m.get("use_impl_diff", 0)),
+                         int(m.get("head_melt_off", 0)), int(m.get("freeze_icefree_gap", 0)))
 
 
 class OracleModel:

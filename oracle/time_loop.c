@@ -315,7 +315,7 @@ static void solve_gap_implicit(OrModel *M, double dt, const double *rhs_valid)
     {   /* diagnosis knob (DESIGN.md "suite E"): cells without ice keep their gap height through the implicit solve (no diffusion of b
          * across the ice margin).  Unset = the restated source: D >= 5e-6 on margin faces (COMPUTEDCOEFF cuts only faces with IMec < 0) */
         const char *e = getenv("SUHMO_ORACLE_GAP_FREEZE_ICEFREE");
-        int freeze = e && atoi(e);
+        int freeze = (e && atoi(e)) || M->mp.freeze_icefree_gap;
         for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++)
             if (!(freeze && CC(M->c[OM_MASK], i, j) < 0.0)) CC(M->c[OM_B], i, j) = tmp[(size_t)j * nx + i];
     }
@@ -367,6 +367,7 @@ void or_model_rhs_h(OrModel *M)                                              /* 
          * term of RHS_h; unset = the reference's source as it is */
         const char *e = getenv("SUHMO_ORACLE_HEAD_MELT_COEF");
         if (e) rho_coef *= atof(e);
+        else if (p->head_melt_off) rho_coef *= 0.0;
     }
     double ub_norm = sqrt(p->ub0 * p->ub0 + p->ub1 * p->ub1);                /* magVel, SqrtIBC.cpp:280-281 */
     for (int j = 0; j < ny; j++)

@@ -17,6 +17,10 @@ typedef struct OrModelParams {
     int use_moulin_source;              /* suhmo.n_moulins > 0: RHS_h += msrc * ramp + distributed_input (:3060-3066) */
     double ramp;                        /* suhmo.ramp (:2448-2467), 1 when off */
     int use_impl_diff;                  /* solver.use_ImplDiff: gap height by the implicit VC Helmholtz solve (:593-662, :3376-3455) */
+    /* run-state settings of the reference's committed result tables; 0, 0 = the committed source.  The
+     * environment knobs SUHMO_ORACLE_HEAD_MELT_COEF / SUHMO_ORACLE_GAP_FREEZE_ICEFREE the committed pin runs were made with do the same */
+    int head_melt_off;                  /* RHS_h without the melt term (:3046-3048): the term times 0.0 */
+    int freeze_icefree_gap;             /* cells with iceMask < 0 keep their gap height through SolveForGap_nl */
 } OrModelParams;
 
 enum { OM_H = 0, OM_B, OM_BOLD, OM_PI, OM_ZB, OM_MASK, OM_MR, OM_PW, OM_SRC, OM_RHSH, OM_CD,

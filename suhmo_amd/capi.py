@@ -39,7 +39,8 @@ class ModelParams(C.Structure):
                 ("br", C.c_double), ("lr", C.c_double), ("diffFactor", C.c_double),
                 ("distributed_input", C.c_double), ("eps_picard", C.c_double),
                 ("basal_friction", C.c_int), ("use_mask_rhs_b", C.c_int), ("use_moulin_source", C.c_int),
-                ("ramp", C.c_double), ("use_impl_diff", C.c_int)]
+                ("ramp", C.c_double), ("use_impl_diff", C.c_int),
+                ("head_melt_off", C.c_int), ("freeze_icefree_gap", C.c_int)]
 
 
 class LevelDesc(C.Structure):

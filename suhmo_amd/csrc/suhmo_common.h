@@ -172,7 +172,8 @@ struct suhmo_level {
     int mask_reported;          // the last suhmo_level_update_operator(depth 0) made that report
     unsigned mask_epoch, maskflag_epoch;   // number of the last k_bcoef_fused call on depth 0; the call whose report is current (0: none)
     int overlap_halo;           // rank strips, streaming kernel: the halo exchange travels on a second stream while the chunks that do not
-                                // read halo rows relax; the two end chunks follow (env SUHMO_OVERLAP_HALO, default 1)
+                                // read halo rows relax; the two end chunks follow (env SUHMO_OVERLAP_HALO; 1 = default: with the native, stream-ordered
+                                // RCCL transport only; 2 = with any hook, the caller vouches that it orders against the stream it is given; 0 = off)
     hipStream_t xstream; hipEvent_t xev[2]; long overlapped;   // ... its stream and events; launches that overlapped so far
     int tile_strips;            // tile kernel on rank strips (env SUHMO_TILE_STRIPS, default 1)
     int tile_chunks;            // a level that is one tile relaxes all its sweeps in one launch (env SUHMO_TILE_CHUNKS, default 1)

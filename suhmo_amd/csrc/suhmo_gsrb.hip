@@ -925,7 +925,10 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
             const int need = 2 * K + (rst && ext ? 1 : 0);
             bool flying = false;                                           // the exchange is in flight on the second stream
             if (ext && F < need) {
-                if (L->overlap_halo && !D.prolong_pending && D.v.ny >= 6 * need) {
+                // only the native transport is stream-ordered (its pack / send / recv / unpack are enqueued on the stream the hook is
+                // given); a host transport (torch.distributed, gloo, threads) orders against other streams or the whole device:
+                // overlap_halo = 1 overlaps with the native transport only, 2 = the caller vouches for its hook
+                if ((L->overlap_halo == 2 || (L->overlap_halo && L->rccl)) && !D.prolong_pending && D.v.ny >= 6 * need) {
                     if (!L->xstream) {
                         HIPCHK(hipStreamCreateWithFlags(&L->xstream, hipStreamNonBlocking));
                         HIPCHK(hipEventCreateWithFlags(&L->xev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&L->xev[1], hipEventDisableTiming));

@@ -313,12 +313,13 @@ extern "C" int suhmo_level_attach_rccl(suhmo_level_t *L, const void *id128, int 
         const double desc[] = {(double)v0.nx, (double)v0.ny, (double)v0.gy, (double)L->ndepth, (double)L->gsrb_variant, (double)L->fused_min_cells,
                                (double)L->tile_max_cells, (double)L->gsrb_tile, (double)L->tile_t, (double)L->tile_s, (double)L->fused_nt,
                                (double)L->fused_hc, (double)L->fused_restrict, (double)L->tile_strips, (double)L->tile_chunks,
-                               (double)L->fas_rhs_in_relax, (double)L->strips_rhs_local, (double)L->bcoef_fused, (double)v0.nxg, (double)v0.nyg, (double)L->tile_restrict};
+                               (double)L->fas_rhs_in_relax, (double)L->strips_rhs_local, (double)L->bcoef_fused, (double)v0.nxg, (double)v0.nyg, (double)L->tile_restrict,
+                               (double)L->overlap_halo};
         const int K = (int)(sizeof(desc) / sizeof(desc[0]));
         static const char *names[] = {"nx", "ny (rows per strip: the level must be cut into EQUAL strips)", "halo_rows", "multigrid depths", "SUHMO_GSRB_VARIANT",
                                       "SUHMO_FUSED_MIN_CELLS", "SUHMO_TILE_MAX_CELLS", "SUHMO_GSRB_TILE", "SUHMO_TILE_T", "SUHMO_TILE_S", "SUHMO_FUSED_NT",
                                       "SUHMO_FUSED_HC", "SUHMO_FUSED_RESTRICT", "SUHMO_TILE_STRIPS", "SUHMO_TILE_CHUNKS", "SUHMO_FAS_RHS_IN_RELAX",
-                                      "SUHMO_STRIPS_RHS_LOCAL", "SUHMO_BCOEF_FUSED", "nx_global", "ny_global", "SUHMO_TILE_RESTRICT"};
+                                      "SUHMO_STRIPS_RHS_LOCAL", "SUHMO_BCOEF_FUSED", "nx_global", "ny_global", "SUHMO_TILE_RESTRICT", "SUHMO_OVERLAP_HALO"};
         double h[2 * 32], *dbuf = nullptr;
         for (int k = 0; k < K; k++) { h[2 * k] = desc[k]; h[2 * k + 1] = -desc[k]; }
         bool ok = hipMalloc(&dbuf, 2 * K * sizeof(double)) == hipSuccess

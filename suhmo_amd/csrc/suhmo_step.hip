@@ -111,6 +111,7 @@ __device__ __forceinline__ void d_melt(const DV &v, const FP &fp, suhmo_phys_t p
     const double ub_norm = sqrt(mp.ub0 * mp.ub0 + mp.ub1 * mp.ub1);
     if (MODE == 0) {                                           // RHS_h, :3044-3077
         double rho_coef = (1.0 / mp.rho_w - 1.0 / mp.rho_i);
+        if (mp.head_melt_off) rho_coef *= 0.0;                 // run-state setting of the reference's committed tables (suhmo_hip.h)
         double r = m * rho_coef;
         if (b < mp.br) r -= ub_norm * (mp.br - b) / mp.lr;
         if (mp.use_moulin_source) r += fp.f[SUHMO_F_MSRC][idx] * mp.ramp + mp.distributed_input;   // :3060-3066
@@ -146,6 +147,32 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_melt_m(const DV *__restrict__ vt, const FP *__restrict__ ft, suhmo_phys_t ph, suhmo_model_params_t mp, double dt)
 {
     d_melt<MODE>(vt[blockIdx.z], ft[blockIdx.z], ph, mp, dt);
+}
+
+// run-state setting freeze_icefree_gap (suhmo_hip.h): cells without ice keep their gap height through SolveForGap_nl -- the solved
+// value of such a cell is replaced by the old one before the solution is copied back (valid cells; the ghosts are refilled afterwards)
+__device__ __forceinline__ void d_keep_icefree(const DV &v, const double *__restrict__ mk, const double *__restrict__ bold, double *__restrict__ sol)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || j >= v.ny) return;
+    int idx = cidx(v, i, j);
+    if (mk[idx] < 0.0) sol[idx] = bold[idx];
+}
+__global__ __launch_bounds__(256) void k_keep_icefree(DV v, const double *__restrict__ mk, const double *__restrict__ bold, double *__restrict__ sol)
+{
+    d_keep_icefree(v, mk, bold, sol);
+}
+__global__ __launch_bounds__(256) void k_keep_icefree_m(const DV *__restrict__ vt, const FP *__restrict__ fh, const FP *__restrict__ fg)
+{
+    d_keep_icefree(vt[blockIdx.z], fh[blockIdx.z].f[SUHMO_F_MASK], fh[blockIdx.z].f[SUHMO_F_B], fg[blockIdx.z].f[SUHMO_F_PHI]);
+}
+static int keep_icefree(suhmo_level *L, suhmo_level *G, hipStream_t st)
+{
+    Depth &D = L->d[0];
+    hipLaunchKernelGGL(k_keep_icefree, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp.f[SUHMO_F_MASK], D.fp.f[SUHMO_F_B],
+                       G->d[0].fp.f[SUHMO_F_PHI]);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // Picard convergence test, :3169-3185
@@ -354,6 +381,7 @@ static int solve_gap_implicit(suhmo_level *L, const suhmo_model_params_t *mp, do
     suhmo_solver_params_t sp;
     gap_solver_params(sp, cur_step);
     if ((rc = suhmo_level_solve(G, &sp, nullptr, nullptr, (suhmo_stream_t)st))) return rc;
+    if (mp->freeze_icefree_gap && (rc = keep_icefree(L, G, st))) return rc;
     HIPCHK(hipMemcpyAsync(L->d[0].fp.f[SUHMO_F_B], G->d[0].fp.f[SUHMO_F_PHI], L->d[0].elems * sizeof(double), hipMemcpyDeviceToDevice, st));
     return 0;
 }
@@ -572,6 +600,7 @@ extern "C" int suhmo_amr_timestep(suhmo_level_t **lv, int nlev, const suhmo_mode
         for (int l = 0; l < nlev; l++) {
             if (!lv[l]) continue;
             Depth &D = lv[l]->d[0];
+            if (mp->freeze_icefree_gap && (rc = keep_icefree(lv[l], gaps[l], st))) return rc;
             HIPCHK(hipMemcpyAsync(D.fp.f[SUHMO_F_B], gaps[l]->d[0].fp.f[SUHMO_F_PHI], D.elems * sizeof(double), hipMemcpyDeviceToDevice, st));
             if ((rc = amr_gap_ghosts(lv, nlev, l, st))) return rc;
         }
@@ -814,10 +843,16 @@ extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *
                 static const int fd[1] = {SUHMO_F_B}, fs[1] = {SUHMO_F_PHI};
                 suhmo_multi mh, mg;
                 if ((rc = suhmo_hier_multi_(H, l, st, &mh)) || (rc = suhmo_hier_multi_(G, l, st, &mg))) return rc;
+                if (mp->freeze_icefree_gap) {
+                    hipLaunchKernelGGL(k_keep_icefree_m, grid_m(mh), dim3(64, 4), 0, st, mh.dv, mh.fp, mg.fp);
+                    HIPCHK(hipGetLastError());
+                }
                 if ((rc = suhmo_multi_copy_between(mh, mg, fd, fs, 1, st))) return rc;
             } else
-                for (size_t k = 0; k < hb.size(); k++)
+                for (size_t k = 0; k < hb.size(); k++) {
+                    if (mp->freeze_icefree_gap && (rc = keep_icefree(hb[k], gb[k], st))) return rc;
                     HIPCHK(hipMemcpyAsync(hb[k]->d[0].fp.f[SUHMO_F_B], gb[k]->d[0].fp.f[SUHMO_F_PHI], hb[k]->d[0].elems * sizeof(double), hipMemcpyDeviceToDevice, st));
+                }
             if ((rc = hier_gap_ghosts(H, l, st))) return rc;
         }
     }

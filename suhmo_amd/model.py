@@ -15,7 +15,8 @@ def model_params(m):
     return capi.ModelParams(m["rho_i"], m["rho_w"], m["gravity"], m["G"], m["L"], m["ct"], m["cw"], ub[0], ub[1],
                             m["br"], m["lr"], m.get("diffFactor", 0.0), m["distributed_input"], m["eps_picard"],
                             int(m.get("basal_friction", 1)), int(m.get("use_mask_rhs_b", 0)),
-                            int(m.get("use_moulin_source", 0)), float(m.get("ramp", 1.0)), int(m.get("use_impl_diff", 0)))
+                            int(m.get("use_moulin_source", 0)), float(m.get("ramp", 1.0)), int(m.get("use_impl_diff", 0)),
+                            int(m.get("head_melt_off", 0)), int(m.get("freeze_icefree_gap", 0)))
 
 
 class HipModel:

@@ -145,12 +145,15 @@ class TorchDistTransport:
             if tag is not None:
                 self._ops[tag] = ops      # buffers are fixed per (depth, fields): build the op list once
         if ops:
-            host_staged = self.dist.get_backend() != "nccl" and self.device.type == "cuda"   # gloo moves device tensors through the host on its own streams
-            if host_staged:
+            # torch.distributed orders its transfers against torch's current stream only (nccl) or moves device tensors through the
+            # host on streams of its own (gloo); the library's pack / unpack kernels run on the stream the hook was called with:
+            # fence the device on both sides.  (The stream-ordered, overlapping transport is the native one, suhmo_rccl.hip.)
+            fence = self.device.type == "cuda"
+            if fence:
                 self.torch.cuda.synchronize()
             for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
-            if host_staged:
+            if fence:
                 self.torch.cuda.synchronize()
 
     def allreduce_max(self, rank, v):

@@ -1,7 +1,7 @@
 """cfg5 of BASELINE.json (exec/AMR_multiMoulins: 63 moulins on 100 km x 100 km, dino bed of MountainSetupIBC without its
 unseeded noise, diffusion + implicit gap-height solve, transient head + gap height) on base + 3 AMR levels whose levels are
 unions of boxes around the moulins: the device hierarchy against oracle/amr_step_m.c, BITWISE over the first steps on a
-64 x 64 base; on the reference's own 256 x 256 base (run_C_3lev/input.hydro:67) the step runs, the moulins deliver their flux
+64 x 64 base and on the reference's own 256 x 256 base (run_C_3lev/input.hydro:67), where also the moulins deliver their flux
 over the composite grid and the covered cells hold the average of the finer level."""
 import numpy as np
 import pytest
@@ -11,15 +11,18 @@ from suhmo_amd import synthetic as sy
 pytestmark = pytest.mark.gpu
 
 
-def test_cfg5_physics_on_four_levels_bitwise(oracle):
+@pytest.mark.parametrize("nb,max_box", [(64, 16), (256, 64)], ids=["base-64", "base-256-reference-grid"])
+def test_cfg5_physics_on_four_levels_bitwise(oracle, nb, max_box):
+    """base-256 = AmrHydro.num_cells and max_box_size of exec/AMR_multiMoulins/run_C_3lev/input.hydro:64-72 (base + 3 levels of 70 / 73 / 63 boxes):
+    2 steps, every box of every level bit for bit"""
     from suhmo_amd import model, level as lv
     bc, ph, m, mo = sy.multimoulins_setup()
-    nx0 = ny0 = 64
+    nx0 = ny0 = nb
     boxes = sy.boxes_around(mo["positions"], nx0, ny0, 4, 1.0e5, 1.0e5)
     assert len(boxes) == 3 and all(len(bl) >= 3 for bl in boxes)
     sts = sy.mountain_amrm_states(nx0, ny0, boxes)
-    O = oracle.OracleAmrMModel(nx0, ny0, sts[0][0]["dx"], sts[0][0]["dy"], bc, ph, m, boxes, max_box=16, nthreads=4)
-    G = model.HipHierModel(nx0, ny0, sts[0][0]["dx"], sts[0][0]["dy"], bc, ph, m, boxes, max_box=16)
+    O = oracle.OracleAmrMModel(nx0, ny0, sts[0][0]["dx"], sts[0][0]["dy"], bc, ph, m, boxes, max_box=max_box, nthreads=8)
+    G = model.HipHierModel(nx0, ny0, sts[0][0]["dx"], sts[0][0]["dy"], bc, ph, m, boxes, max_box=max_box)
     O.set_states(sts); G.set_states(sts)
     io, ig = O.moulin_source(**mo), G.moulin_source(**mo)
     assert np.max(np.abs(io - ig)) <= 1e-12 * np.max(io)

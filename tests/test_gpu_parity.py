@@ -3,6 +3,8 @@ and compared with the CPU oracle on the same seeded inputs.  Bar: BITWISE equali
 every fp64 field (both sides are compiled with FP contraction off and follow the
 reference's expression association); the only tolerance is on the l2 norm, whose
 summation order differs (1e-12 relative, stated below)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -369,6 +371,31 @@ def test_full_size_properties(hip):
     G.restrict_r()
     assert np.all(G.get(hip.F_PHI, depth=1) == 2.5)
     assert G.ndepth == 6
+
+
+def test_bench_size_vcycle_bitwise(oracle, hip):
+    """The headline configuration at its own size: bench.py's workload (4096 x 4096 cells on square cells of 24.4 m, 64^2 boxes,
+    6 depths, kernel options as the library picks them -- the occupancy-derived chunk height, one-wave strips, the restricting
+    launch, the mask skip, the tile kernel at depths 1-5) against the oracle: two V-cycles, the head after each and every coarse
+    residual after the second, bit for bit."""
+    n = 4096
+    f = sy.shmip_fields(n, n, ly=1.0e5)
+    f.pop("bx", None); f.pop("by", None)
+    O = oracle.OracleLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64, nthreads=min(16, os.cpu_count() or 1))
+    G = hip.HipLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=64)
+    O.set_inputs(f); G.set_inputs(f)
+    O.build_mg_coefficients(); G.build_mg_coefficients()
+    assert G.ndepth == 6
+    sp = dict(sy.SOLVER_DEFAULT)
+    for k in range(2):
+        O.vcycle(sp); G.vcycle(sp)
+        a, b = G.get(hip.F_PHI), O.get(oracle.F_PHI)
+        assert np.array_equal(a, b), (k, float(np.max(np.abs(a - b))))
+    for d in range(1, G.ndepth):
+        assert np.array_equal(G.get(hip.F_RES, depth=d), O.get(oracle.F_RES, depth=d)), ("coarse residual", d)
+    O.residual(); G.residual()
+    assert np.array_equal(G.get(hip.F_RES), O.get(oracle.F_RES))
+    O.close(); G.close()
 
 
 def test_kernel_selection_through_the_option_api(oracle):

@@ -126,7 +126,7 @@ def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
         monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "4000")
         monkeypatch.setenv("SUHMO_GSRB_TILE", "0")
         monkeypatch.setenv("SUHMO_FUSED_HC", "16" if world == 4 else "32")
-        monkeypatch.setenv("SUHMO_OVERLAP_HALO", "1" if fused == "overlap" else "0")
+        monkeypatch.setenv("SUHMO_OVERLAP_HALO", "2" if fused == "overlap" else "0")   # 2: also with a host transport (this one fences the device); 1 = native RCCL only
     f = sy.shmip_fields(256, 256)
     bc, ph = sy.A3_BC, sy.A3_PHYS
     sp = dict(sy.SOLVER_DEFAULT, eps=1e-10, norm_thresh=1e-13, max_iter=4, imin=4)

@@ -228,3 +228,128 @@ def test_suite_e_masked_margin_on_the_device(oracle, hipmodel, case):
     for nm, fid in (("qwx", oracle.OM_QWX), ("qwy", oracle.OM_QWY)):
         assert np.array_equal(np.array(O.field(fid)), G.get(nm), equal_nan=True), (case, nm)
     O.close(); G.close()
+
+
+# ---- the DEVICE path against the reference's committed result tables, with the run-state settings those tables were written
+# with as model options of the C-ABI (suhmo_model_params_t.head_melt_off / freeze_icefree_gap, phys.use_mask_gradients; DESIGN.md
+# section 4).  Tolerances = the oracle pin's (tests/test_oracle_timeloop.PIN_TOL, tests/golden/PIN_REPORT.txt), not ASIS_TOL.
+PIN_RUNS = {"A3": dict(mask_gradients=1), "B5": dict(mask_gradients=1), "E1": dict(freeze=1)}
+
+
+@pytest.mark.parametrize("case", ["A3", "B5", "E1"])
+def test_device_reproduces_the_reference_table(hipmodel, oracle, case):
+    """exec/A_SHMIP/A3, exec/B_SHMIP/B5, exec/E_SHMIP/E1 results/postproc.dat (320 / 256 rows x 8 columns) from a run of the HIP
+    path alone: 10002 (E1: 5002) steps on the device, every column and row to the print precision of the table (5e-6 / 5e-7 /
+    1.2e-5 of the column scales), and on the trajectory of the oracle's committed pin run (same Picard / V-cycle totals, table to 1e-9)."""
+    import json
+    from suhmo_amd import level as lv
+    from test_oracle_timeloop import check_against_reference
+    binp = None
+    if case[0] == "B":
+        binp = json.load(open(os.path.join(GOLD, "shmip_B_inputs.json")))[case]
+        m = sy.shmip_b_model(case, binp)
+    elif case[0] == "E":
+        m = sy.shmip_e_model(case)
+    else:
+        m = sy.shmip_a_model(case)
+    m = dict(m, head_melt_off=1, freeze_icefree_gap=PIN_RUNS[case].get("freeze", 0))
+    if case[0] == "E":
+        st = sy.valley_initial_state(m["nx"], m["ny"], sy.E_GAMMA[case], m["lx"], m["ly"])
+        phys = dict(sy.E_PHYS, cutOffB=sy.E_CUTOFFB[case])
+    else:
+        st = sy.shmip_initial_state(m["nx"], m["ny"], m["lx"], m["ly"])
+        phys = dict(sy.A3_PHYS, use_mask_gradients=1)                 # the tables' run had it on (inputs of suites A / B say off)
+    G = hipmodel.HipModel(m["nx"], m["ny"], st["dx"], st["dy"], sy.A3_BC, phys, m, max_box=64)
+    G.set_state(st)
+    G.level.set(lv.F_MR, np.full((m["ny"], m["nx"]), m["G"] / m["L"]))
+    src = None
+    if binp:
+        src, _ = oracle.moulin_source(m["nx"], m["ny"], st["dx"], st["dy"], np.array(binp["positions"]).reshape(-1, 2), binp["sigma"], binp["flux"], 1.0)
+        G.level.set(lv.F_MSRC, src)
+    tot_p = tot_v = 0
+    for k in range(m["max_step"] + 2):
+        p, nv = G.timestep(m["dt"])
+        tot_p += p
+        tot_v += nv
+    if binp:
+        mask = G.get("mask")
+        table = sy.shmip_postproc_table(st["dx"], st["dy"], G.get("qwx"), G.get("cd", ghosted=True), np.where(mask > 0.0, src * m["ramp"] + m["distributed_input"], 0.0),
+                                        G.get("mR"), G.get("Pw"), G.get("Pi"), mask, m["rho_w"])
+    else:
+        table = G.postproc_table()
+    G.close()
+    check_against_reference(table, case, "pin")                                  # the reference's own numbers
+    orc = np.loadtxt(os.path.join(GOLD, "shmip_%s_oracle_pin_table.dat" % case))
+    run = json.load(open(os.path.join(GOLD, "shmip_%s_oracle_pin.json" % case)))
+    assert (tot_p, tot_v) == (run["picard_total"], run["vcycles_total"])
+    scale = np.max(np.abs(orc), axis=0)
+    assert np.all(np.abs(table - orc) <= 1e-9 * scale), np.max(np.abs(table - orc) / scale, axis=0)
+
+
+# F1: largest deviation of the oracle's pin run from the reference per column (PIN_REPORT.txt): 2.3e-7, 2.8e-7, 2.1e-7, 1.9e-7, 4.3e-7, 1.3e-5
+F_PIN_TOL = {2: 1e-6, 3: 1e-6, 4: 1e-6, 5: 1e-6, 6: 1e-6, 7: 3e-5}
+
+
+def test_device_reproduces_the_reference_five_year_series(hipmodel):
+    """exec/F_SHMIP/F1/results/postproc.dat, 1830 daily rows of a five-year seasonal cycle, from a run of the HIP path alone with the
+    run-state settings of the table as model options / inputs / data (no melt term in RHS_h, masked gradients and masked gap-height
+    right-hand side, ice-free gap height frozen, surface elevation as the lapse-rate field): every day and column to print precision."""
+    import json, subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "f1.json")
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", "run_shmip_f.py"), "hip", "F1", "5", out, "--zs", "surface", "--head-melt-coef", "0",
+                            "--mask-gradients", "1", "--mask-rhs-b", "1", "--freeze-icefree"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert p.returncode == 0, p.stdout.decode()[-3000:]
+        got, res = np.loadtxt(out.replace(".json", "_table.dat")), json.load(open(out))
+    ref = np.loadtxt(os.path.join(GOLD, "shmip_F1_postproc_reference.dat"))
+    assert got.shape[0] == ref.shape[0] == 1830
+    for c, tol in F_PIN_TOL.items():
+        sc = np.max(np.abs(ref[:, c]))
+        assert np.max(np.abs(got[:, c] - ref[:, c])) <= tol * sc, (c, float(np.max(np.abs(got[:, c] - ref[:, c])) / sc))
+    orc = np.loadtxt(os.path.join(GOLD, "shmip_F1_oracle_pin_table.dat"))
+    run = json.load(open(os.path.join(GOLD, "shmip_F1_oracle_pin.json")))
+    assert (res["picard_total"], res["vcycles_total"]) == (run["picard_total"], run["vcycles_total"])
+    scale = np.max(np.abs(orc), axis=0)
+    assert np.all(np.abs(got - orc) <= 1e-9 * scale), np.max(np.abs(got - orc) / scale, axis=0)
+
+
+def test_run_state_options_bitwise(oracle, hipmodel):
+    """head_melt_off and freeze_icefree_gap on both sides (model options, no environment): 30 steps of suite E1 (ice margin, implicit gap
+    solve) bit for bit; the ice-free cells keep their gap height, and without the option they do not."""
+    case = "E1"
+    m = dict(sy.shmip_e_model(case), head_melt_off=1, freeze_icefree_gap=1)
+    st = sy.valley_initial_state(m["nx"], m["ny"], sy.E_GAMMA[case], m["lx"], m["ly"])
+    phys = dict(sy.E_PHYS, cutOffB=sy.E_CUTOFFB[case])
+    from suhmo_amd import level as lv
+    O = oracle.OracleModel(m["nx"], m["ny"], st["dx"], st["dy"], sy.A3_BC, phys, m, max_box=64, nthreads=8)
+    G = hipmodel.HipModel(m["nx"], m["ny"], st["dx"], st["dy"], sy.A3_BC, phys, m, max_box=64)
+    G2 = hipmodel.HipModel(m["nx"], m["ny"], st["dx"], st["dy"], sy.A3_BC, phys, dict(m, freeze_icefree_gap=0), max_box=64)
+    for M in (O, G, G2):
+        M.set_state(st)
+    O.field(oracle.OM_MR)[:] = m["G"] / m["L"]
+    for M in (G, G2):
+        M.level.set(lv.F_MR, np.full((m["ny"], m["nx"]), m["G"] / m["L"]))
+    v = lambda a: np.array(a)[1:-1, 1:-1]
+    for k in range(30):
+        co, cg = O.timestep(m["dt"]), G.timestep(m["dt"])
+        G2.timestep(m["dt"])
+        assert co == cg, (k, co, cg)
+    for nm, fid in (("head", oracle.OM_H), ("B", oracle.OM_B), ("mR", oracle.OM_MR), ("rhs_h", oracle.OM_RHSH)):
+        a, b = v(O.field(fid)), G.get(nm)
+        assert np.array_equal(a, b, equal_nan=True), (nm, float(np.nanmax(np.abs(a - b))))
+    icefree = st["mask"][1:-1, 1:-1] < 0
+    assert np.array_equal(G.get("B")[icefree], st["B"][1:-1, 1:-1][icefree])
+    assert not np.array_equal(G2.get("B")[icefree], st["B"][1:-1, 1:-1][icefree])
+    for M in (O, G, G2):
+        M.close()
+
+
+def test_iteration_pattern_of_the_tutorial_run_on_the_device(hipmodel, oracle):
+    """the tutorial run of docs/GettingStarted.md (exec/0_convergence_channelized/1lev: 32 x 8, 3000 steps, ramped moulin) on the device:
+    the Picard / FAS iteration counts of every step equal the oracle's, and meet what the reference says about them as far as the
+    reconstructed cycle does (tests/test_oracle_timeloop.check_tutorial_pattern)"""
+    from test_oracle_timeloop import tutorial_iteration_counts, check_tutorial_pattern
+    pg, po_ = tutorial_iteration_counts("hip"), tutorial_iteration_counts("oracle")
+    assert np.array_equal(pg, po_), np.where(np.any(pg != po_, axis=1))[0][:5]
+    check_tutorial_pattern(pg)

@@ -55,7 +55,8 @@ def main():
     cutoffb = opt("--cutoffb", int)
     spin = opt("--spinup-steps", int)
     zs_kind = opt("--zs") or "thickness"
-    if opt("--freeze-icefree", flag=True):
+    freeze = opt("--freeze-icefree", flag=True)
+    if freeze:
         os.environ["SUHMO_ORACLE_GAP_FREEZE_ICEFREE"] = "1"
     if coef is not None:
         os.environ["SUHMO_ORACLE_HEAD_MELT_COEF"] = coef
@@ -66,6 +67,11 @@ def main():
     m = dict(F_MODEL)
     if mask_rhs_b is not None:
         m["use_mask_rhs_b"] = mask_rhs_b
+    if which == "hip":                                                     # the device path: model options (suhmo_model_params_t), no environment
+        if coef is not None:
+            assert float(coef) == 0.0, "the device path has the model option head_melt_off only"
+            m["head_melt_off"] = 1
+        m["freeze_icefree_gap"] = int(freeze)
     phys = dict(sy.A3_PHYS, A=2.5e-25, use_mask_gradients=mask_grad or 0, cutOffB=cutoffb or 0)
     nx, ny = m["nx"], m["ny"]
     st = sy.valley_initial_state(nx, ny, 0.05, m["lx"], m["ly"])
