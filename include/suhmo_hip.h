@@ -107,7 +107,8 @@ int suhmo_level_num_depths(const suhmo_level_t *L);
 /* Kernel selection of a level (defaults are chosen by level size and shape; the SUHMO_<KEY> environment variables read when
  * the level is created override them for A/B runs): key = gsrb_variant (-1 auto, 0 colour passes / tiles, 1, 2 = sweeps per
  * streaming pass), gsrb_tile, tile_t (0, 16, 32), tile_s, tile_max_cells, tile_chunks, tile_strips, fused_min_cells, fused_hc,
- * fused_nt (64, 256), fused_restrict, fas_rhs_in_relax, strips_rhs_local, bcoef_fused, graph_max_cells, poll_readback.
+ * fused_nt (64, 256), fused_restrict, fas_rhs_in_relax, strips_rhs_local, bcoef_fused, graph_max_cells, poll_readback, overlap_halo,
+ * agg_min_cells, fas_rhs_fused.
  * On rank strips every rank must make the same choices (suhmo_level_attach_rccl checks). */
 int suhmo_level_set_option(suhmo_level_t *L, const char *key, long value);
 int suhmo_level_get_option(const suhmo_level_t *L, const char *key, long *value);
@@ -179,6 +180,9 @@ int suhmo_level_get_flux(suhmo_level_t *L, int depth, int dir, int ref, double *
 /* norm over valid cells (AMRNonLinearPoissonOp::norm, :660-666): ord 0 max-abs, 2 l2 */
 int suhmo_level_norm(suhmo_level_t *L, int depth, int field, int ord, double *out,
                      suhmo_stream_t s);
+/* dotProduct (src/AMRNonLinearPoissonOp.cpp:519-551): sum over the valid cells of x * y (device reduction; over all ranks of a strip
+ * partition through the reduce hook; the summation order differs from the reference's box-by-box sum: 1e-12 relative) */
+int suhmo_level_dot(suhmo_level_t *L, int depth, int x, int y, double *out, suhmo_stream_t s);
 /* LevelDataOps vector ops (:629-688): dst = a*x + b*y ; dst += scale*x ; set value */
 int suhmo_level_axby(suhmo_level_t *L, int depth, int dst, int x, int y, double a, double b,
                      suhmo_stream_t s);
@@ -282,6 +286,21 @@ typedef int (*suhmo_exchange_fn)(void *user, suhmo_level_t *L, int depth, const 
 typedef int (*suhmo_allreduce_max_fn)(void *user, double *value);
 int suhmo_level_set_hooks(suhmo_level_t *L, suhmo_exchange_fn ex, suhmo_allreduce_max_fn ar,
                           void *user);
+/* general reduction over the ranks of a strip partition: n values in place, op 0 = MAX, 1 = SUM (what the reference does with
+ * MPI_Allreduce inside norm(), dotProduct() and computeMax, src/AMRNonLinearPoissonOp.cpp:660-666, 1222-1264; src/AmrHydro.cpp:3169-3185).
+ * Optional: with only the MAX hook of suhmo_level_set_hooks, suhmo_level_norm(ord 2) and suhmo_level_dot on a strip return -5.
+ * `user` is the pointer given to suhmo_level_set_hooks.  suhmo_level_attach_rccl installs a device-resident equivalent
+ * (ncclAllReduce on the kernels' stream, the result read back through pinned memory: no stream synchronisation). */
+typedef int (*suhmo_allreduce_fn)(void *user, double *values, int n, int op);
+int suhmo_level_set_reduce_hook(suhmo_level_t *L, suhmo_allreduce_fn fn);
+/* all-gather of `count` doubles per rank (device buffers; recv holds world x count, rank-major, ranks in ascending j0), enqueued on /
+ * ordered with s.  With it attached, the multigrid depths whose strip holds fewer than `agg_min_cells` cells (option, default 65536;
+ * SURVEY.md 8e) are AGGLOMERATED: every rank runs them redundantly on a copy of the whole level, fed by two all-gathers per V-cycle,
+ * instead of exchanging halo rows per relaxation (suhmo_amd/csrc/suhmo_agg.hip).  suhmo_level_attach_rccl installs ncclAllGather.
+ * suhmo_level_agglomerated_depth: first agglomerated depth, 0 = none. */
+typedef int (*suhmo_allgather_fn)(void *user, const double *send, long count, double *recv, suhmo_stream_t s);
+int suhmo_level_set_allgather(suhmo_level_t *L, suhmo_allgather_fn fn, void *user);
+int suhmo_level_agglomerated_depth(const suhmo_level_t *L);
 /* LevelData::exchange of one field across the strip's rank boundaries (calls the hook; a
  * no-op for a single-process level).  Used by the host after it loads coefficient fields. */
 int suhmo_level_exchange(suhmo_level_t *L, int depth, int field, suhmo_stream_t s);
@@ -378,8 +397,14 @@ int suhmo_amr_moulin_source(suhmo_level_t **levels, int nlev, const int *patch_b
  * host transport) and writes only this rank's rows.  Results are the single-process bits. */
 typedef struct suhmo_hier suhmo_hier_t;
 int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *base, int nlev, const int *nbox, const int *boxes);
+/* the same with options, "key=value,key=value" (NULL = defaults): shadow = 1 routes level 1's reads of an UNCUT level 0 through the
+ * pack / all-gather / unpack path of rank strips (tests of that path on one rank); push_ghosts = 0: an exchange launch before every
+ * colour pass instead of side cells pushed by the pass.  push_ghosts can also be changed later (suhmo_hier_set_option). */
+int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc_t *base, int nlev, const int *nbox, const int *boxes, const char *options);
+int suhmo_hier_set_option(suhmo_hier_t *H, const char *key, long value);
+int suhmo_hier_get_option(const suhmo_hier_t *H, const char *key, long *value);
 /* all-gather of `count` doubles per rank (device buffers; recv holds world x count, rank-major), enqueued on / ordered with s */
-typedef int (*suhmo_hier_allgather_fn)(void *user, const double *send, long count, double *recv, suhmo_stream_t s);
+typedef suhmo_allgather_fn suhmo_hier_allgather_fn;
 int suhmo_hier_set_allgather(suhmo_hier_t *H, suhmo_hier_allgather_fn fn, void *user);
 int suhmo_hier_attach_rccl(suhmo_hier_t *H);    /* after suhmo_level_attach_rccl on the base strip: ncclAllGather on its communicator */
 long suhmo_hier_gathers(const suhmo_hier_t *H); /* all-gathers issued so far */

@@ -53,6 +53,7 @@ class LevelDesc(C.Structure):
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)      # values, n, op (0 MAX, 1 SUM)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p)
 
 # every symbol include/suhmo_hip.h declares (tests check the library exports all of them)
@@ -78,6 +79,8 @@ SYMBOLS = [
     "suhmo_hier_cf_interp", "suhmo_hier_pwl_fill", "suhmo_hier_average", "suhmo_hier_gsrb", "suhmo_hier_update_operator",
     "suhmo_hier_residual", "suhmo_hier_vcycle", "suhmo_hier_solve", "suhmo_hier_timestep", "suhmo_hier_moulin_source",
     "suhmo_hier_set_allgather", "suhmo_hier_attach_rccl", "suhmo_hier_gathers", "suhmo_level_set_option", "suhmo_level_get_option", "suhmo_timers_enable", "suhmo_timers_reset", "suhmo_timers_report",
+    "suhmo_level_set_reduce_hook", "suhmo_level_dot", "suhmo_level_set_allgather", "suhmo_level_agglomerated_depth",
+    "suhmo_hier_create_opts", "suhmo_hier_set_option", "suhmo_hier_get_option",
 ]
 
 
@@ -126,6 +129,10 @@ def lib():
     L.suhmo_level_pack_rows.argtypes = [vp, ci, ci, ci, ci, vp, vp]
     L.suhmo_level_unpack_rows.argtypes = [vp, ci, ci, ci, ci, vp, vp]
     L.suhmo_level_set_hooks.argtypes = [vp, EXCHANGE_FN, ALLREDUCE_FN, vp]
+    L.suhmo_level_set_reduce_hook.argtypes = [vp, REDUCE_FN]
+    L.suhmo_level_set_allgather.argtypes = [vp, ALLGATHER_FN, vp]
+    L.suhmo_level_agglomerated_depth.argtypes = [vp]
+    L.suhmo_level_dot.argtypes = [vp, ci, ci, ci, dp, vp]
     L.suhmo_level_exchange.argtypes = [vp, ci, ci, vp]
     L.suhmo_level_halo_info.argtypes = [vp, ci] + [C.POINTER(ci)] * 5
     L.suhmo_level_timestep.argtypes = [vp, C.POINTER(ModelParams), C.c_double, ci, C.POINTER(ci), C.POINTER(ci), vp]
@@ -163,6 +170,9 @@ def lib():
     L.suhmo_amr2_solve.argtypes = [vp, vp, C.POINTER(SolverParams), C.POINTER(ci), dp, vp]
     ip = C.POINTER(ci)
     L.suhmo_hier_create.argtypes = [C.POINTER(vp), C.POINTER(LevelDesc), ci, ip, ip]
+    L.suhmo_hier_create_opts.argtypes = [C.POINTER(vp), C.POINTER(LevelDesc), ci, ip, ip, C.c_char_p]
+    L.suhmo_hier_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+    L.suhmo_hier_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_long)]
     L.suhmo_hier_destroy.argtypes = [vp]
     L.suhmo_hier_num_levels.argtypes = [vp]
     L.suhmo_hier_num_boxes.argtypes = [vp, ci]

@@ -150,6 +150,8 @@ struct suhmo_level {
     size_t scratch_elems;
     suhmo_exchange_fn ex;
     suhmo_allreduce_max_fn ar;
+    suhmo_allreduce_fn ar2;                            // n values, MAX or SUM, on the host (suhmo_level_set_reduce_hook)
+    int (*ard)(void *user, double *dev_values, int n, int op, suhmo_stream_t s);   // the same in place on DEVICE values, enqueued on s (native transport)
     void *user;
     int (*ex_begin)(void *user);                       // optional: open / close a batch of exchanges that
     int (*ex_end)(void *user, suhmo_level *L, suhmo_stream_t s);   // travel as ONE message group (native transport)
@@ -157,6 +159,13 @@ struct suhmo_level {
     std::vector<VGraph> vgraphs; int vgraph_seen[4]; hipStream_t gstream;
     suhmo_level *gap; double gap_dt;   // implicit gap-height operator of the time step (suhmo_step.hip), owned
     void *rccl;                 // native transport state (suhmo_rccl.hip), owned by the level
+    // agglomeration of the coarse depths of a rank strip (suhmo_agg.hip): from depth agg_depth on (0 = none) the cycle runs on `agg`, a
+    // handle of the WHOLE level at that depth held by every rank; all-gather transport ag (suhmo_level_set_allgather / attach_rccl)
+    long agg_min_cells;         // depths whose strip holds fewer cells are agglomerated (env SUHMO_AGG_MIN_CELLS, default 65536, 0 = off)
+    int agg_depth, agg_world, agg_rank;
+    suhmo_level *agg;
+    suhmo_allgather_fn ag; void *ag_user;
+    double *agg_send, *agg_recv; size_t agg_cap; long agg_gathers;
     int prof_on;
     std::vector<ProfEv> prof;
     int gsrb_variant;           // kernel selection (see suhmo_gsrb.hip); env SUHMO_GSRB_VARIANT
@@ -165,6 +174,8 @@ struct suhmo_level {
     int fused_nt;               // threads per workgroup of the fused kernel: 256 or 64 (env SUHMO_FUSED_NT)
     int fused_restrict;         // the last pre-smoothing launch also restricts (env SUHMO_FUSED_RESTRICT, default 1)
     int fused_hc;               // rows per chunk of the fused kernel (0 = auto); env SUHMO_FUSED_HC
+    int fas_rhs_fused;          // coarse FAS right-hand side rhs = res + L(R phi), the copy of R phi and L(phi) in ONE pass (k_apply<., 2>) instead of
+                                // copy + applyOp + axby (env SUHMO_FAS_RHS_FUSED, default 1)
     int strips_rhs_local;       // rank strips: R phi and RES travel together, the coarse right-hand side of the halo rows is computed locally
                                 // (env SUHMO_STRIPS_RHS_LOCAL, default 1)
     int skip_mask;              // the streaming relaxation skips the ice-mask array in a V-cycle whose UpdateOperator found no negative cell
@@ -210,6 +221,11 @@ int suhmo_fas_coarse_rhs(suhmo_level *L, int depth, hipStream_t st, int hcomp = 
 struct HostSlot { double *val; unsigned long long *flag; unsigned long long seq; };
 HostSlot suhmo_host_slot(suhmo_level *L);                                           // suhmo_level.hip; call right before the launch
 int suhmo_readback(suhmo_level *L, hipStream_t st, double *out, double *out2 = nullptr);   // after the launch; out2: a second value (scratch[1] / val[1])
+// n = 1 or 2 values a reduction's last kernel left in L->scratch[0..n-1] (launched with suhmo_reduce_slot(L)): combined over the ranks of a
+// strip partition (op 0 MAX, 1 SUM) and brought to the host.  On a strip with the native transport the all-reduce runs on the device, on
+// the kernels' stream, and a publishing kernel follows; with host hooks the local values are read back first.
+HostSlot suhmo_reduce_slot(suhmo_level *L);                                         // = suhmo_host_slot, or an empty slot when the values still travel
+int suhmo_reduce_finish(suhmo_level *L, hipStream_t st, int n, int op, double *out, double *out2 = nullptr);
 __device__ __forceinline__ void suhmo_publish(const HostSlot &h, double v)
 {
     if (!h.val) return;
@@ -217,5 +233,12 @@ __device__ __forceinline__ void suhmo_publish(const HostSlot &h, double v)
     __hip_atomic_store(h.flag, h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 int suhmo_build_mg_coefficients(suhmo_level *L, bool with_faces, hipStream_t st);   // suhmo_level.hip
+// suhmo_agg.hip: agglomeration of the coarse multigrid depths of a rank strip
+int suhmo_agg_setup(suhmo_level *L);
+void suhmo_agg_release(suhmo_level *L);
+int suhmo_agg_gather_static(suhmo_level *L, bool with_faces, hipStream_t st);
+int suhmo_agg_gather_faces(suhmo_level *L, int nd, hipStream_t st);
+int suhmo_agg_gather_state(suhmo_level *L, hipStream_t st);
+int suhmo_agg_scatter(suhmo_level *L, hipStream_t st);
 int suhmo_exchange_list(suhmo_level *L, int depth, const int *fields, int n, hipStream_t st);   // LevelData::exchange across rank boundaries
 static inline int suhmo_halo_rows(const DV &v) { return v.gy < v.ny ? v.gy : v.ny; }

@@ -57,7 +57,23 @@ static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, i
                                                                                   //  row, the prolongation below the rest)
     if (!restricted && (rc = suhmo_restrict_both(L, dep, (hipStream_t)s))) return rc;   // RES[dep+1] and PHI[dep+1] = R(phi); the fused
                                                                                   //  relaxation may have written them already
-    static const bool one_pass_rhs = !(getenv("SUHMO_FAS_RHS_FUSED") && atoi(getenv("SUHMO_FAS_RHS_FUSED")) == 0);
+    if (L->agg && dep + 1 == L->agg_depth) {
+        // rank strips, agglomerated depths (suhmo_agg.hip): R phi and RES of every rank's rows -> the whole-level copy A every rank
+        // holds; A forms its right-hand side and runs the rest of the cycle without a message; this rank's rows and halo rows of
+        // phi and R phi come back, so the prolongation below needs no exchange either
+        suhmo_level *A = L->agg;
+        const int ndA = nd - L->agg_depth;
+        if ((rc = suhmo_agg_gather_state(L, (hipStream_t)s))) return rc;
+        const int next_sweeps = ndA == 1 ? sp->num_bottom : S;
+        if (suhmo_gsrb_can_fuse_rhs(A, 0, next_sweeps)) A->d[0].rhs_pending = 1;
+        else if ((rc = suhmo_fas_coarse_rhs(A, 0, (hipStream_t)s))) return rc;
+        if ((rc = fas_cycle(A, 0, sp, ndA, s))) return rc;
+        if ((rc = suhmo_agg_scatter(L, (hipStream_t)s))) return rc;
+        if (suhmo_gsrb_can_fuse_prolong(L, dep, S)) L->d[dep].prolong_pending = 1;
+        else if ((rc = suhmo_prolong_with_halo(L, dep, (hipStream_t)s))) return rc;
+        return relax(L, dep, S, tail_post, s, dep == 0);
+    }
+    const bool one_pass_rhs = L->fas_rhs_fused != 0;
     // rank strips: R phi and RES travel in one message group and the right-hand side of the halo rows is computed here from them,
     // bit for bit what the neighbour computes for its own rows: the exchange of RHS disappears
     const bool rhs_local = L->ex && (C.v.rk[0] || C.v.rk[1]) && one_pass_rhs && L->desc.nx_global == 0 && L->strips_rhs_local

@@ -26,6 +26,7 @@
 #include "suhmo_hier.h"
 #include <algorithm>
 #include <map>
+#include <string>
 
 int suhmo_grad_cc(suhmo_level *L, int depth, hipStream_t st);          // suhmo_level.hip
 int suhmo_re_bcoef_unfused(suhmo_level *L, int depth, hipStream_t st);
@@ -130,8 +131,9 @@ struct suhmo_hier {
     // by row, so the cells a rank owns are one segment); one all-gather refreshes a field (or several) before a plan runs.
     // What level 1 writes into level 0 (averages, reflux) is clipped to the rank's own rows when the plans are built.
     int rank = 0, world = 1;
-    bool push_ghosts = true;                               // env SUHMO_HIER_PUSH=0: an exchange launch before every colour pass instead
-    bool shadowed = false;                                 // world > 1, or env SUHMO_HIER_SHADOW=1 (tests: the whole path on one rank)
+    bool push_ghosts = true;                               // option push_ghosts = 0: an exchange launch before every colour pass instead
+    bool shadowed = false;                                 // world > 1, or creation option shadow = 1 (tests: the whole path on one rank)
+    std::string options;                                   // as given to suhmo_hier_create_opts (the gap hierarchy is created with the same)
     DV vglob;                                              // level 0 as one canvas (= the base view when it is not cut)
     FP shadow{};
     size_t shadow_elems = 0;
@@ -1022,6 +1024,22 @@ extern "C" int suhmo_hier_destroy(suhmo_hier_t *H)
 
 extern "C" int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *base, int nlev, const int *nbox, const int *boxes)
 {
+    return suhmo_hier_create_opts(out, base, nlev, nbox, boxes, nullptr);
+}
+// value of `key` in a "key=value,key=value" list; dflt when absent
+static long hier_opt(const char *opts, const char *key, long dflt)
+{
+    if (!opts) return dflt;
+    const size_t n = strlen(key);
+    for (const char *p = opts; *p;) {
+        while (*p == ',' || *p == ' ') p++;
+        if (!strncmp(p, key, n) && p[n] == '=') return atol(p + n + 1);
+        while (*p && *p != ',') p++;
+    }
+    return dflt;
+}
+extern "C" int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc_t *base, int nlev, const int *nbox, const int *boxes, const char *options)
+{
     ARG(out && base && nlev >= 1 && nlev <= 8);
     ARG(nlev == 1 || (nbox && boxes));
     ARG(base->i0 == 0 && (base->nx_global == 0 || base->nx_global == base->nx));
@@ -1030,9 +1048,10 @@ extern "C" int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *b
     suhmo_hier *H = new suhmo_hier();
     if (cut) { H->world = base->ny_global / base->ny; H->rank = base->j0 / base->ny; }
     H->shadowed = cut;
-    if (const char *e = getenv("SUHMO_HIER_SHADOW")) if (atoi(e) != 0) H->shadowed = true;
-    if (const char *e = getenv("SUHMO_HIER_PUSH")) H->push_ghosts = atoi(e) != 0;
+    if (hier_opt(options, "shadow", 0) != 0) H->shadowed = true;          // an uncut level 0 read through the shadow path all the same (tests)
+    H->push_ghosts = hier_opt(options, "push_ghosts", 1) != 0;
     H->nlev = nlev; H->device = base->device; H->bc = base->bc; H->base_desc = *base; H->base_desc.boxes = nullptr; H->base_desc.nbox = 0;
+    if (options) H->options = options;
     suhmo_level *B = nullptr;
     int rc = suhmo_level_create(&B, base);
     if (rc) { delete H; return rc; }
@@ -1163,10 +1182,11 @@ int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, su
         d.phys.use_NL = 0; d.alpha = 1.0; d.beta = dt * mp->diffFactor;
         std::vector<int> nbox(H->nlev, 0), flat;
         for (int l = 1; l < H->nlev; l++) { nbox[l] = (int)H->lev[l].box.size(); flat.insert(flat.end(), H->lev[l].b4.begin(), H->lev[l].b4.end()); }
-        int rc = suhmo_hier_create(&H->gap, &d, H->nlev, nbox.data(), flat.data()); if (rc) return rc;
+        int rc = suhmo_hier_create_opts(&H->gap, &d, H->nlev, nbox.data(), flat.data(), H->options.c_str()); if (rc) return rc;
         H->gap_dt = dt;
         H->gap->ag = H->ag; H->gap->ag_user = H->ag_user;                                  // same strips, same ranks
-        { suhmo_level *G0 = H->gap->lev[0].box[0]; G0->ex = B->ex; G0->ar = B->ar; G0->user = B->user; G0->ex_begin = B->ex_begin; G0->ex_end = B->ex_end; }
+        { suhmo_level *G0 = H->gap->lev[0].box[0]; G0->ex = B->ex; G0->ar = B->ar; G0->ar2 = B->ar2; G0->ard = B->ard; G0->user = B->user; G0->ex_begin = B->ex_begin; G0->ex_end = B->ex_end;
+          G0->ag = B->ag; G0->ag_user = B->ag_user; G0->agg_min_cells = B->agg_min_cells; if ((rc = suhmo_agg_setup(G0))) return rc; }
         for (int l = 0; l < H->nlev; l++)
             for (suhmo_level *L : H->gap->lev[l].box) if ((rc = suhmo_level_set_value(L, 0, SUHMO_F_ACOEF, 1.0, nullptr))) return rc;   // aCoeff_GH :1820-1828
     }
@@ -1174,6 +1194,26 @@ int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, su
     return 0;
 }
 
+extern "C" int suhmo_hier_set_option(suhmo_hier_t *H, const char *key, long value)
+{
+    ARG(H && key);
+    if (!strcmp(key, "push_ghosts")) {
+        H->push_ghosts = value != 0;
+        for (int l = 0; l < 8; l++) H->ff_seen[l] = 0;
+        if (H->gap) return suhmo_hier_set_option(H->gap, key, value);
+        return 0;
+    }
+    suhmo_set_error("unknown hierarchy option '%s' (push_ghosts; shadow is a creation option of suhmo_hier_create_opts)", key);
+    return -1;
+}
+extern "C" int suhmo_hier_get_option(const suhmo_hier_t *H, const char *key, long *value)
+{
+    ARG(H && key && value);
+    if (!strcmp(key, "push_ghosts")) { *value = H->push_ghosts; return 0; }
+    if (!strcmp(key, "shadow")) { *value = H->shadowed; return 0; }
+    suhmo_set_error("unknown hierarchy option '%s'", key);
+    return -1;
+}
 extern "C" int suhmo_hier_set_allgather(suhmo_hier_t *H, suhmo_hier_allgather_fn fn, void *user)
 {
     ARG(H);

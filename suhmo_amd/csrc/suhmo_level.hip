@@ -141,7 +141,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     HIPCHK(hipSetDevice(desc->device));
     suhmo_level *L = new suhmo_level();
     L->desc = *desc; L->ph = desc->phys; L->device = desc->device;
-    L->ex = nullptr; L->ar = nullptr; L->user = nullptr; L->ex_begin = nullptr; L->ex_end = nullptr; L->rccl = nullptr; L->gap = nullptr; L->gap_dt = 0.0; L->prof_on = 0; L->gsrb_variant = -1; L->fused_hc = 0;
+    L->ex = nullptr; L->ar = nullptr; L->ar2 = nullptr; L->ard = nullptr; L->user = nullptr; L->ex_begin = nullptr; L->ex_end = nullptr; L->rccl = nullptr; L->gap = nullptr; L->gap_dt = 0.0; L->prof_on = 0; L->gsrb_variant = -1; L->fused_hc = 0;
     if (const char *e = getenv("SUHMO_GSRB_VARIANT")) L->gsrb_variant = atoi(e);
     if (const char *e = getenv("SUHMO_FUSED_HC")) L->fused_hc = atoi(e);
     L->bcoef_fused = 1;
@@ -159,6 +159,11 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     if (const char *e = getenv("SUHMO_OVERLAP_HALO")) L->overlap_halo = atoi(e);
     L->strips_rhs_local = 1;
     if (const char *e = getenv("SUHMO_STRIPS_RHS_LOCAL")) L->strips_rhs_local = atoi(e);
+    L->fas_rhs_fused = 1;
+    if (const char *e = getenv("SUHMO_FAS_RHS_FUSED")) L->fas_rhs_fused = atoi(e) != 0;
+    L->agg_min_cells = 65536; L->agg_depth = 0; L->agg_world = 1; L->agg_rank = 0; L->agg = nullptr; L->ag = nullptr; L->ag_user = nullptr;
+    L->agg_send = L->agg_recv = nullptr; L->agg_cap = 0; L->agg_gathers = 0;
+    if (const char *e = getenv("SUHMO_AGG_MIN_CELLS")) L->agg_min_cells = atol(e);
     if (const char *e = getenv("SUHMO_TILE_STRIPS")) L->tile_strips = atoi(e);
     if (const char *e = getenv("SUHMO_TILE_CHUNKS")) L->tile_chunks = atoi(e);
     if (const char *e = getenv("SUHMO_TILE_RESTRICT")) L->tile_restrict = atoi(e);
@@ -243,6 +248,7 @@ extern "C" int suhmo_level_destroy(suhmo_level_t *L)
     (void)hipDeviceSynchronize();
     if (L->rccl) (void)suhmo_level_detach_rccl(L);
     if (L->gap) { (void)suhmo_level_destroy(L->gap); L->gap = nullptr; }
+    suhmo_agg_release(L);
     suhmo_level_drop_graphs(L);
     for (int dep = 0; dep < L->ndepth; dep++)
         for (int f = 0; f < SUHMO_F_COUNT; f++)
@@ -290,6 +296,7 @@ static long *option_slot_long(suhmo_level *L, const char *key)
     if (!strcmp(key, "fused_min_cells")) return &L->fused_min_cells;
     if (!strcmp(key, "tile_max_cells")) return &L->tile_max_cells;
     if (!strcmp(key, "graph_max_cells")) return &L->graph_max_cells;
+    if (!strcmp(key, "agg_min_cells")) return &L->agg_min_cells;
     return nullptr;
 }
 static int *option_slot_int(suhmo_level *L, const char *key)
@@ -297,7 +304,7 @@ static int *option_slot_int(suhmo_level *L, const char *key)
     static const struct { const char *k; int suhmo_level::*m; } tab[] = {
         {"gsrb_variant", &suhmo_level::gsrb_variant}, {"fused_hc", &suhmo_level::fused_hc}, {"bcoef_fused", &suhmo_level::bcoef_fused},
         {"fused_nt", &suhmo_level::fused_nt}, {"fused_restrict", &suhmo_level::fused_restrict}, {"strips_rhs_local", &suhmo_level::strips_rhs_local},
-        {"tile_strips", &suhmo_level::tile_strips}, {"overlap_halo", &suhmo_level::overlap_halo}, {"skip_mask", &suhmo_level::skip_mask}, {"tile_chunks", &suhmo_level::tile_chunks}, {"tile_order", &suhmo_level::tile_order}, {"tile_restrict", &suhmo_level::tile_restrict}, {"fas_rhs_in_relax", &suhmo_level::fas_rhs_in_relax},
+        {"tile_strips", &suhmo_level::tile_strips}, {"overlap_halo", &suhmo_level::overlap_halo}, {"skip_mask", &suhmo_level::skip_mask}, {"tile_chunks", &suhmo_level::tile_chunks}, {"tile_order", &suhmo_level::tile_order}, {"tile_restrict", &suhmo_level::tile_restrict}, {"fas_rhs_in_relax", &suhmo_level::fas_rhs_in_relax}, {"fas_rhs_fused", &suhmo_level::fas_rhs_fused},
         {"tile_s", &suhmo_level::tile_s}, {"gsrb_tile", &suhmo_level::gsrb_tile}, {"tile_t", &suhmo_level::tile_t}, {"poll_readback", &suhmo_level::poll_readback}};
     for (const auto &e : tab) if (!strcmp(key, e.k)) return &(L->*(e.m));
     return nullptr;
@@ -305,7 +312,11 @@ static int *option_slot_int(suhmo_level *L, const char *key)
 extern "C" int suhmo_level_set_option(suhmo_level_t *L, const char *key, long value)
 {
     ARG(L && key);
-    if (long *p = option_slot_long(L, key)) { *p = value; suhmo_level_drop_graphs(L); return 0; }
+    if (long *p = option_slot_long(L, key)) {
+        *p = value; suhmo_level_drop_graphs(L);
+        if (!strcmp(key, "agg_min_cells")) return suhmo_agg_setup(L);     // (every rank of the partition must set the same value)
+        return 0;
+    }
     if (int *p = option_slot_int(L, key)) {
         if (!strcmp(key, "tile_t") && value != 0 && value != 16 && value != 32) { suhmo_set_error("tile_t: 0 (by size), 16 or 32"); return -1; }
         if (!strcmp(key, "fused_nt") && value != 64 && value != 256) { suhmo_set_error("fused_nt: 64 or 256"); return -1; }
@@ -321,6 +332,7 @@ extern "C" int suhmo_level_get_option(const suhmo_level_t *L, const char *key, l
     if (long *p = option_slot_long(const_cast<suhmo_level *>(L), key)) { *value = *p; return 0; }
     if (int *p = option_slot_int(const_cast<suhmo_level *>(L), key)) { *value = *p; return 0; }
     if (!strcmp(key, "overlapped_launches")) { *value = L->overlapped; return 0; }       // read-only counter (overlap_halo)
+    if (!strcmp(key, "agg_gathers")) { *value = L->agg_gathers; return 0; }              // read-only counter (agglomeration)
     suhmo_set_error("unknown option '%s'", key);
     return -1;
 }
@@ -335,7 +347,21 @@ extern "C" int suhmo_level_synchronize(suhmo_level_t *L, suhmo_stream_t s)
 extern "C" int suhmo_level_set_hooks(suhmo_level_t *L, suhmo_exchange_fn ex, suhmo_allreduce_max_fn ar, void *user)
 {
     ARG(L);
-    L->ex = ex; L->ar = ar; L->user = user; L->ex_begin = nullptr; L->ex_end = nullptr;
+    L->ex = ex; L->ar = ar; L->ar2 = nullptr; L->ard = nullptr; L->user = user; L->ex_begin = nullptr; L->ex_end = nullptr;
+    return 0;
+}
+extern "C" int suhmo_level_set_allgather(suhmo_level_t *L, suhmo_allgather_fn fn, void *user)
+{
+    ARG(L);
+    HIPCHK(hipSetDevice(L->device));
+    L->ag = fn; L->ag_user = user;
+    return suhmo_agg_setup(L);
+}
+extern "C" int suhmo_level_agglomerated_depth(const suhmo_level_t *L) { return L ? L->agg_depth : -1; }
+extern "C" int suhmo_level_set_reduce_hook(suhmo_level_t *L, suhmo_allreduce_fn fn)
+{
+    ARG(L);
+    L->ar2 = fn;
     return 0;
 }
 
@@ -1384,7 +1410,7 @@ int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st)
     if (nd < 2) return 0;
     if (nd > 7 || F.v.nx % (1 << (nd - 1)) || F.v.ny % (1 << (nd - 1))) {     // generic fallback
         for (int k = 1; k < nd; k++) { int rc = suhmo_level_average_operator(L, k, (suhmo_stream_t)st); if (rc) return rc; }
-        return 0;
+        return suhmo_agg_gather_faces(L, nd, st);
     }
     AvgOut o;
     for (int d = 0; d < nd; d++) { o.bx[d] = L->d[d].fp.f[SUHMO_F_BX]; o.by[d] = L->d[d].fp.f[SUHMO_F_BY]; o.P[d] = L->d[d].v.P; o.gy[d] = L->d[d].v.gy; }
@@ -1396,11 +1422,11 @@ int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st)
     HIPCHK(hipGetLastError());
     // strips: the coarse face coefficients of all depths travel as one message group when the transport can batch
     if (L->ex_begin && L->ex) { int rc = L->ex_begin(L->user); if (rc) return rc; }
-    for (int k = 1; k < nd; k++) {
+    for (int k = 1; k < nd && !(L->agg && k >= L->agg_depth); k++) {
         int rc = exchange_fields(L, k, {SUHMO_F_BX, SUHMO_F_BY}, st); if (rc) return rc;
     }
     if (L->ex_end && L->ex) { int rc = L->ex_end(L->user, L, (suhmo_stream_t)st); if (rc) return rc; }
-    return 0;
+    return suhmo_agg_gather_faces(L, nd, st);       // agglomerated depths: every rank's rows of the coarse faces -> the whole-level copy
 }
 
 // MGnewOp coefficient coarsening: CoarseAverage (arithmetic) of aCoef, B, Pi, zb, iceMask from
@@ -1539,9 +1565,10 @@ int suhmo_build_mg_coefficients(suhmo_level *L, bool with_faces, hipStream_t st)
     for (int dep = 1; dep < nd; dep++) {
         int rc;
         if (with_faces && (rc = suhmo_level_average_operator(L, dep, (suhmo_stream_t)st))) return rc;
+        if (L->agg && dep >= L->agg_depth) continue;                  // agglomerated depths: no halo rows, the whole rows travel below
         rc = exchange_fields(L, dep, {SUHMO_F_ACOEF, SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB, SUHMO_F_MASK}, st); if (rc) return rc;
     }
-    return 0;
+    return suhmo_agg_gather_static(L, with_faces, st);
 }
 extern "C" int suhmo_level_build_mg_coefficients(suhmo_level_t *L, suhmo_stream_t s)
 {
@@ -1714,6 +1741,65 @@ int suhmo_readback(suhmo_level *L, hipStream_t st, double *out, double *out2)
     if (out2) *out2 = L->hscratch[1];
     return 0;
 }
+static inline bool on_strip(const suhmo_level *L) { const DV &v = L->d[0].v; return v.rk[0] || v.rk[1]; }
+__global__ void k_publish2(const double *__restrict__ v, HostSlot hs)
+{
+    if (hs.val) hs.val[1] = v[1];
+    suhmo_publish(hs, v[0]);
+}
+HostSlot suhmo_reduce_slot(suhmo_level *L)
+{
+    if (on_strip(L) && L->ard) return HostSlot{nullptr, nullptr, 0};       // published after the device all-reduce
+    return suhmo_host_slot(L);
+}
+int suhmo_reduce_finish(suhmo_level *L, hipStream_t st, int n, int op, double *out, double *out2)
+{
+    ARG(n == 1 || n == 2);
+    double v[2] = {0.0, 0.0};
+    int rc;
+    if (on_strip(L) && L->ard) {
+        if ((rc = L->ard(L->user, L->scratch, n, op, (suhmo_stream_t)st))) return rc;
+        hipLaunchKernelGGL(k_publish2, dim3(1), dim3(1), 0, st, L->scratch, suhmo_host_slot(L));
+        HIPCHK(hipGetLastError());
+        if ((rc = suhmo_readback(L, st, &v[0], &v[1]))) return rc;
+    } else {
+        if ((rc = suhmo_readback(L, st, &v[0], &v[1]))) return rc;
+        if (on_strip(L) && (L->ar || L->ar2)) {
+            if (L->ar2) { if ((rc = L->ar2(L->user, v, n, op))) return rc; }
+            else if (op == 0) { for (int k = 0; k < n; k++) if ((rc = L->ar(L->user, &v[k]))) return rc; }
+            else { suhmo_set_error("a SUM over the ranks of a strip needs suhmo_level_set_reduce_hook or the native transport (the hook of suhmo_level_set_hooks reduces MAX only)"); return -5; }
+        }
+    }
+    *out = v[0];
+    if (out2) *out2 = v[1];
+    return 0;
+}
+__global__ __launch_bounds__(256) void k_dot_partial(DV v, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ partial)
+{
+    __shared__ double sm[256];
+    int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    double acc = 0.0;
+    for (int j = blockIdx.y * blockDim.y + threadIdx.y; j < v.ny; j += gridDim.y * blockDim.y)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.nx; i += gridDim.x * blockDim.x) { int idx = cidx(v, i, j); acc += x[idx] * y[idx]; }
+    sm[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = sm[tid] + sm[tid + s]; __syncthreads(); }
+    if (tid == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = sm[0];
+}
+extern "C" int suhmo_level_dot(suhmo_level_t *L, int depth, int x, int y, double *out, suhmo_stream_t s)
+{
+    SUHMO_TIME("AMRNonLinearPoissonOp::dotProduct");
+    CHECK_DF(L, depth, x); CHECK_DF(L, depth, y); ARG(out);
+    HIPCHK(hipSetDevice(L->device));
+    hipStream_t st = (hipStream_t)s;
+    Depth &D = L->d[depth];
+    const double *px = suhmo_field(L, depth, x), *py = suhmo_field(L, depth, y);
+    if (!px || !py) { suhmo_set_error("field allocation failed"); return -2; }
+    dim3 grd(std::min((D.v.nx + 63) / 64, 32), std::min((D.v.ny + 3) / 4, 128));
+    hipLaunchKernelGGL(k_dot_partial, grd, BLK2D, 0, st, D.v, px, py, L->scratch + 2);
+    hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, st, L->scratch + 2, (int)(grd.x * grd.y), 2, L->scratch, suhmo_reduce_slot(L));
+    return suhmo_reduce_finish(L, st, 1, 1, out);
+}
 extern "C" int suhmo_level_norm(suhmo_level_t *L, int depth, int field, int ord, double *out, suhmo_stream_t s)
 {
     SUHMO_TIME("AMRNonLinearPoissonOp::norm");
@@ -1723,17 +1809,12 @@ extern "C" int suhmo_level_norm(suhmo_level_t *L, int depth, int field, int ord,
     Depth &D = L->d[depth];
     dim3 grd(std::min((D.v.nx + 63) / 64, 32), std::min((D.v.ny + 3) / 4, 128));
     int np = grd.x * grd.y;
-    hipLaunchKernelGGL(k_norm_partial, grd, BLK2D, 0, st, D.v, suhmo_field(L, depth, field), ord, L->scratch + 1);
-    hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, st, L->scratch + 1, np, ord, L->scratch, suhmo_host_slot(L));
+    hipLaunchKernelGGL(k_norm_partial, grd, BLK2D, 0, st, D.v, suhmo_field(L, depth, field), ord, L->scratch + 2);
+    hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, st, L->scratch + 2, np, ord, L->scratch, suhmo_reduce_slot(L));
     double r = 0.0;
-    { int rc = suhmo_readback(L, st, &r); if (rc) return rc; }
-    if (ord == 2) {
-        // the reference's norm() sums over the ranks (src/AMRNonLinearPoissonOp.cpp:1222-1264); the all-reduce hook of a strip is
-        // MAX-only, and the solver only uses the max norm: refuse rather than return a rank-dependent number
-        if (L->ex && (D.v.rk[0] || D.v.rk[1])) { suhmo_set_error("l2 norm on a rank strip is not built (the hook reduces MAX only); use ord 0"); return -5; }
-        r = sqrt(r);
-    }
-    if (L->ar && ord == 0) { int rc = L->ar(L->user, &r); if (rc) return rc; }
+    // the reference's norm() reduces over the ranks (src/AMRNonLinearPoissonOp.cpp:1222-1264): MAX for the max norm, SUM of the squares for l2
+    { int rc = suhmo_reduce_finish(L, st, 1, ord == 0 ? 0 : 1, &r); if (rc) return rc; }
+    if (ord == 2) r = sqrt(r);
     *out = r;
     return 0;
 }

@@ -205,6 +205,14 @@ int allreduce_hook(void *user, double *value)
     HIPCHK(hipStreamSynchronize(S->st));
     return 0;
 }
+// the same on device values, on the kernels' stream: n values in place, op 0 MAX / 1 SUM (suhmo_reduce_finish reads them back
+// through the pinned slot: no copy, no stream synchronisation)
+int reduce_dev_hook(void *user, double *dev_values, int n, int op, suhmo_stream_t s)
+{
+    Strip *S = (Strip *)user;
+    NCCLCHK(g.AllReduce(dev_values, dev_values, (size_t)n, ncclFloat64, op ? ncclSum : ncclMax, S->comm, (hipStream_t)s));
+    return 0;
+}
 }  // namespace
 
 // all-gather of the coarse cells a hierarchy's level 1 reads of a level 0 cut into strips (suhmo_hier.hip), on the kernels' stream
@@ -273,7 +281,8 @@ extern "C" int suhmo_level_detach_rccl(suhmo_level_t *L)
     for (int d = 0; d < SUHMO_MAXDEPTH; d++) for (int k = 0; k < 4; k++) if (S->buf[d][k]) (void)hipFree(S->buf[d][k]);
     if (S->dscalar) (void)hipFree(S->dscalar);
     if (S->comm && g.CommDestroy) (void)g.CommDestroy(S->comm);
-    if (L->user == S) { L->ex = nullptr; L->ar = nullptr; L->user = nullptr; L->ex_begin = nullptr; L->ex_end = nullptr; }
+    if (L->ag_user == S) { L->ag = nullptr; L->ag_user = nullptr; suhmo_agg_release(L); }
+    if (L->user == S) { L->ex = nullptr; L->ar = nullptr; L->ard = nullptr; L->user = nullptr; L->ex_begin = nullptr; L->ex_end = nullptr; }
     delete S;
     L->rccl = nullptr;
     return 0;
@@ -314,12 +323,12 @@ extern "C" int suhmo_level_attach_rccl(suhmo_level_t *L, const void *id128, int 
                                (double)L->tile_max_cells, (double)L->gsrb_tile, (double)L->tile_t, (double)L->tile_s, (double)L->fused_nt,
                                (double)L->fused_hc, (double)L->fused_restrict, (double)L->tile_strips, (double)L->tile_chunks,
                                (double)L->fas_rhs_in_relax, (double)L->strips_rhs_local, (double)L->bcoef_fused, (double)v0.nxg, (double)v0.nyg, (double)L->tile_restrict,
-                               (double)L->overlap_halo};
+                               (double)L->overlap_halo, (double)L->agg_min_cells, (double)L->fas_rhs_fused};
         const int K = (int)(sizeof(desc) / sizeof(desc[0]));
         static const char *names[] = {"nx", "ny (rows per strip: the level must be cut into EQUAL strips)", "halo_rows", "multigrid depths", "SUHMO_GSRB_VARIANT",
                                       "SUHMO_FUSED_MIN_CELLS", "SUHMO_TILE_MAX_CELLS", "SUHMO_GSRB_TILE", "SUHMO_TILE_T", "SUHMO_TILE_S", "SUHMO_FUSED_NT",
                                       "SUHMO_FUSED_HC", "SUHMO_FUSED_RESTRICT", "SUHMO_TILE_STRIPS", "SUHMO_TILE_CHUNKS", "SUHMO_FAS_RHS_IN_RELAX",
-                                      "SUHMO_STRIPS_RHS_LOCAL", "SUHMO_BCOEF_FUSED", "nx_global", "ny_global", "SUHMO_TILE_RESTRICT", "SUHMO_OVERLAP_HALO"};
+                                      "SUHMO_STRIPS_RHS_LOCAL", "SUHMO_BCOEF_FUSED", "nx_global", "ny_global", "SUHMO_TILE_RESTRICT", "SUHMO_OVERLAP_HALO", "SUHMO_AGG_MIN_CELLS", "SUHMO_FAS_RHS_FUSED"};
         double h[2 * 32], *dbuf = nullptr;
         for (int k = 0; k < K; k++) { h[2 * k] = desc[k]; h[2 * k + 1] = -desc[k]; }
         bool ok = hipMalloc(&dbuf, 2 * K * sizeof(double)) == hipSuccess
@@ -336,7 +345,10 @@ extern "C" int suhmo_level_attach_rccl(suhmo_level_t *L, const void *id128, int 
                 return -8;
             }
     }
-    L->ex = exchange_hook; L->ar = allreduce_hook; L->user = S; L->ex_begin = begin_hook; L->ex_end = end_hook;
+    L->ex = exchange_hook; L->ar = allreduce_hook; L->ard = reduce_dev_hook; L->user = S; L->ex_begin = begin_hook; L->ex_end = end_hook;
+    // coarse depths below agg_min_cells cells per strip: agglomerated (suhmo_agg.hip) -- when the communicator spans the whole level
+    // (a strip that is its own periodic neighbour, the one-GPU test harness, declares a level twice its size: not then)
+    if (world * L->d[0].v.ny == L->d[0].v.nyg) { L->ag = suhmo_rccl_allgather_hook; L->ag_user = S; return suhmo_agg_setup(L); }
     return 0;
 }
 

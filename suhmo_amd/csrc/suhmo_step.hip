@@ -218,15 +218,16 @@ __global__ void k_max2_final(const double *__restrict__ partial, int n, double *
     if (tid == 0) { out[0] = sm0[0]; out[1] = sm1[0]; if (hs.val) hs.val[1] = sm1[0]; suhmo_publish(hs, sm0[0]); }
 }
 // max h and max |hl - h| over the level's cells (local to the rank)
+// over_ranks: the maxima over all ranks of the level's strip partition (computeMax; one MAX all-reduce of both values)
 static int picard_maxima(suhmo_level *L, const double *h, const double *hl, double *maxh, double *maxd, hipStream_t st,
-                         Excl ex = Excl{0, 0, 0, 0}, const double *cover = nullptr)
+                         Excl ex = Excl{0, 0, 0, 0}, const double *cover = nullptr, bool over_ranks = false)
 {
     Depth &D = L->d[0];
     dim3 grd(std::min((D.v.nx + 63) / 64, 32), std::min((D.v.ny + 3) / 4, 128));
     hipLaunchKernelGGL(k_picard2_partial, grd, dim3(64, 4), 0, st, D.v, h, hl, L->scratch + 2, ex, cover);
-    hipLaunchKernelGGL(k_max2_final, dim3(1), dim3(256), 0, st, L->scratch + 2, (int)(grd.x * grd.y), L->scratch, suhmo_host_slot(L));
-    int rc = suhmo_readback(L, st, maxh, maxd); if (rc) return rc;
-    return 0;
+    hipLaunchKernelGGL(k_max2_final, dim3(1), dim3(256), 0, st, L->scratch + 2, (int)(grd.x * grd.y), L->scratch, over_ranks ? suhmo_reduce_slot(L) : suhmo_host_slot(L));
+    if (over_ranks) return suhmo_reduce_finish(L, st, 2, 0, maxh, maxd);
+    return suhmo_readback(L, st, maxh, maxd);
 }
 static inline double picard_quotient(double maxd, double maxHead) { return maxd == 0.0 ? 0.0 : maxd / fabs(maxHead); }
 
@@ -356,7 +357,11 @@ static int gap_level_prepare(suhmo_level *L, const suhmo_model_params_t *mp, dou
         if ((rc = suhmo_level_set_value(L->gap, 0, SUHMO_F_ACOEF, 1.0, (suhmo_stream_t)st))) return rc;       // aCoeff_GH :1820-1828
     }
     suhmo_level *G = L->gap;
-    G->ex = L->ex; G->ar = L->ar; G->user = L->user; G->ex_begin = L->ex_begin; G->ex_end = L->ex_end;       // same strip, same neighbours
+    G->ex = L->ex; G->ar = L->ar; G->ar2 = L->ar2; G->ard = L->ard; G->user = L->user; G->ex_begin = L->ex_begin; G->ex_end = L->ex_end;
+    if (G->ag != L->ag || G->ag_user != L->ag_user || G->agg_min_cells != L->agg_min_cells) {                // ... and the same agglomeration
+        G->ag = L->ag; G->ag_user = L->ag_user; G->agg_min_cells = L->agg_min_cells;
+        int rca = suhmo_agg_setup(G); if (rca) return rca;
+    }       // same strip, same neighbours
     Depth &GD = G->d[0];
     if (GD.elems != D.elems) { suhmo_set_error("internal: gap level geometry"); return -4; }
     const size_t bytes = D.elems * sizeof(double);
@@ -426,11 +431,7 @@ extern "C" int suhmo_level_timestep(suhmo_level_t *L, const suhmo_model_params_t
         if ((rc = suhmo_level_solve(L, &sp, &it, nullptr, s))) return rc;
         nv += it;
         double maxHead = 0.0, maxd = 0.0, res = 0.0;
-        if ((rc = picard_maxima(L, D.fp.f[SUHMO_F_PHI], D.fp.f[SUHMO_F_HLAG], &maxHead, &maxd, st))) return rc;
-        if (L->ar && (D.v.ext[0] || D.v.ext[1])) {                // computeMax / norm over all ranks
-            if ((rc = L->ar(L->user, &maxHead))) return rc;
-            if ((rc = L->ar(L->user, &maxd))) return rc;
-        }
+        if ((rc = picard_maxima(L, D.fp.f[SUHMO_F_PHI], D.fp.f[SUHMO_F_HLAG], &maxHead, &maxd, st, Excl{0, 0, 0, 0}, nullptr, true))) return rc;   // computeMax over all ranks
         res = picard_quotient(maxd, maxHead);
         if (ite_idx > 100) { suhmo_set_error("does not converge (Picard iterations > 100)"); return -6; }   // :3190-3195
         if (cur_step < 2) { if (res < 0.05 && cur_picard > 2) converged = true; }

@@ -151,6 +151,12 @@ class HipLevel:
         check(capi.lib().suhmo_level_norm(self.h, depth, field, ord, C.byref(r), self.stream))
         return r.value
 
+    def dot(self, x, y, depth=0):
+        """dotProduct (src/AMRNonLinearPoissonOp.cpp:519-551) over the valid cells, over all ranks of a strip partition"""
+        r = C.c_double()
+        check(capi.lib().suhmo_level_dot(self.h, depth, x, y, C.byref(r), self.stream))
+        return r.value
+
     def vcycle(self, sp):
         s = solver_params(sp)
         check(capi.lib().suhmo_level_vcycle(self.h, C.byref(s), self.stream))
@@ -288,9 +294,9 @@ class HipHier:
     """Base level + levels that are unions of boxes (boxes[l-1] = list of (lo0, lo1, hi0, hi1) in the index space of
     level l), the reference's DisjointBoxLayout per AMR level: suhmo_hier_* (suhmo_amd/csrc/suhmo_hier.hip)."""
 
-    def __init__(self, nx0, ny0, dx0, dy0, bc, phys, boxes, alpha=0.0, beta=-1.0, max_box=64, device=0, j0=0, ny_global=None, halo_rows=1):
+    def __init__(self, nx0, ny0, dx0, dy0, bc, phys, boxes, alpha=0.0, beta=-1.0, max_box=64, device=0, j0=0, ny_global=None, halo_rows=1, options=None):
         """ny0 rows of level 0 starting at row j0 of ny_global: this rank's strip (one process per GPU; the boxes of the finer
-        levels are given whole on every rank); default: the whole level"""
+        levels are given whole on every rank); default: the whole level.  options: "key=value,..." of suhmo_hier_create_opts (shadow, push_ghosts)"""
         self.boxes = [[tuple(int(v) for v in b) for b in bl] for bl in boxes]
         self.nlev = 1 + len(self.boxes)
         d = capi.LevelDesc()
@@ -301,7 +307,7 @@ class HipHier:
         flat = [v for bl in self.boxes for b in bl for v in b]
         arr = (C.c_int * max(len(flat), 1))(*flat)
         h = C.c_void_p()
-        check(capi.lib().suhmo_hier_create(C.byref(h), C.byref(d), self.nlev, nbox, arr))
+        check(capi.lib().suhmo_hier_create_opts(C.byref(h), C.byref(d), self.nlev, nbox, arr, options.encode() if options else None))
         self.h = h
         self.j0, self.ny_global = j0, int(d.ny_global)
         self.stream = C.c_void_p(0)

@@ -154,9 +154,9 @@ class HipHierModel:
 
     FIELDS = HipModel.FIELDS
 
-    def __init__(self, nx0, ny0, dx0, dy0, bc, phys, model, boxes, max_box=64, device=0, j0=0, ny_global=None, halo_rows=1):
+    def __init__(self, nx0, ny0, dx0, dy0, bc, phys, model, boxes, max_box=64, device=0, j0=0, ny_global=None, halo_rows=1, options=None):
         self.hier = lv.HipHier(nx0, ny0, dx0, dy0, bc, phys, boxes, alpha=0.0, beta=-1.0, max_box=max_box, device=device,
-                               j0=j0, ny_global=ny_global, halo_rows=halo_rows)
+                               j0=j0, ny_global=ny_global, halo_rows=halo_rows, options=options)
         self.level = self.hier.level
         self.model = dict(model)
         self._mp = model_params(model)

@@ -36,7 +36,14 @@ class StripExchanger:
         self._ex = capi.EXCHANGE_FN(self._exchange)
         self._ar = capi.ALLREDUCE_FN(self._allreduce)
         check(capi.lib().suhmo_level_set_hooks(level.h, self._ex, self._ar, None))
-        self.calls = 0
+        self._red = capi.REDUCE_FN(self._reduce)
+        check(capi.lib().suhmo_level_set_reduce_hook(level.h, self._red))
+        self.calls = self.gathers = 0
+        # all-gather over the ranks of the level: with it the coarse multigrid depths are agglomerated (suhmo_agg.hip); a sub-group
+        # of ranks (AMR patch strips) does not agglomerate
+        self._ag = capi.ALLGATHER_FN(self._allgather)
+        if peers is None and hasattr(transport, "allgather"):
+            check(capi.lib().suhmo_level_set_allgather(level.h, self._ag, None))
 
     def _geom(self, depth):
         g = [C.c_int() for _ in range(5)]
@@ -78,6 +85,27 @@ class StripExchanger:
     def _allreduce(self, user, pval):
         try:
             pval[0] = self.tr.allreduce_max(self.rank, float(pval[0]))
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return -9
+
+    def _allgather(self, user, send, count, recv, stream):
+        try:
+            self.tr.allgather(self.rank, send, count, recv)
+            self.gathers += 1
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return -9
+
+    def _reduce(self, user, pval, n, op):
+        try:
+            out = self.tr.allreduce(self.rank, [float(pval[k]) for k in range(n)], op)
+            for k in range(n):
+                pval[k] = out[k]
             return 0
         except Exception:
             import traceback
@@ -161,6 +189,12 @@ class TorchDistTransport:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
+    def allreduce(self, rank, vals, op):
+        """n values, op 0 MAX / 1 SUM"""
+        t = self.torch.tensor(vals, dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op else self.dist.ReduceOp.MAX, group=self.group)
+        return [float(x) for x in t.tolist()]
+
     def allgather(self, rank, send, count, recv):
         """raw device pointers (the hierarchy's shadow refresh): staged through tensors the backend can move"""
         torch = self.torch
@@ -224,6 +258,15 @@ class ThreadTransport:
         m = max(self.vals)
         self.barrier.wait()
         return m
+
+    def allreduce(self, rank, vals, op):
+        """n values, op 0 MAX / 1 SUM (in rank order: every rank gets the same bits)"""
+        self.box[(rank, "red")] = list(vals)
+        self.barrier.wait()
+        cols = list(zip(*[self.box[(r, "red")] for r in range(self.world)]))
+        out = [sum(c) if op else max(c) for c in cols]
+        self.barrier.wait()
+        return out
 
     def allgather(self, rank, send, count, recv):
         self._hip.hipDeviceSynchronize()

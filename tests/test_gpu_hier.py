@@ -20,12 +20,12 @@ UNION = ([(16, 8, 31, 23), (32, 8, 47, 15), (0, 2, 11, 13)],
 MASKPH = dict(sy.CFG3_PHYS, use_mask_gradients=1, cutOffbr=0.008, maxOffbr=0.012, cutOffB=1)
 
 
-def pair(oracle, boxes, bc, ph=sy.CFG3_PHYS, nx0=64, ny0=16, **kw):
+def pair(oracle, boxes, bc, ph=sy.CFG3_PHYS, nx0=64, ny0=16, options=None, **kw):
     from suhmo_amd import level
     fs = sy.amrm_fields(nx0, ny0, boxes, **kw)
     O = oracle.OracleAmrM(nx0, ny0, fs[0]["dx"], fs[0]["dy"], bc, ph, boxes, max_box=32, nthreads=2)
     O.set_inputs(fs)
-    G = level.HipHier(nx0, ny0, fs[0]["dx"], fs[0]["dy"], bc, ph, boxes, max_box=32)
+    G = level.HipHier(nx0, ny0, fs[0]["dx"], fs[0]["dy"], bc, ph, boxes, max_box=32, options=options)
     G.set_inputs(fs)
     return O, G, fs
 
@@ -85,12 +85,11 @@ def test_hier_pieces_bitwise(oracle, bc, ph):
 @pytest.mark.parametrize("name,boxes,bc,ph", [("union-4lev", UNION, BC_NP, sy.CFG3_PHYS), ("union-4lev-values-mask", UNION, BC_V, MASKPH),
                                               ("cut-periodic", CUT, BC, sy.CFG3_PHYS), ("union-4lev-exchange-per-pass", UNION, BC_NP, sy.CFG3_PHYS)],
                          ids=lambda v: v if isinstance(v, str) else "")
-def test_hier_vcycle_and_solve_bitwise(oracle, name, boxes, bc, ph, monkeypatch):
+def test_hier_vcycle_and_solve_bitwise(oracle, name, boxes, bc, ph):
     from suhmo_amd.level import F_PHI, F_RES, F_BX
-    if name.endswith("exchange-per-pass"):
-        monkeypatch.setenv("SUHMO_HIER_PUSH", "0")          # an exchange launch before every colour pass instead of the pushed side cells
+    # exchange-per-pass: an exchange launch before every colour pass instead of the pushed side cells (creation option of the hierarchy)
     sp = dict(sy.SOLVER_DEFAULT, eps=1e-9, norm_thresh=1e-14, max_iter=6, imin=30)
-    O, G, fs = pair(oracle, boxes, bc, ph)
+    O, G, fs = pair(oracle, boxes, bc, ph, options="push_ghosts=0" if name.endswith("exchange-per-pass") else None)
     O.vcycle(sp); G.vcycle(sp)
     same_levels(O, G, oracle, ((oracle.F_PHI, F_PHI), (oracle.F_BX, F_BX)), "vcycle")
     no, ho = O.solve(sp)

@@ -152,16 +152,15 @@ def test_hier_solve_on_strips_bitwise():
     assert np.array_equal(np.vstack([out[r][2][0][0] for r in range(world)]), ref[0][0])
 
 
-def test_native_allgather_single_rank(monkeypatch):
-    """The shadow path over the native transport: SUHMO_HIER_SHADOW=1 routes level 1's reads of an uncut level 0 through the
+def test_native_allgather_single_rank():
+    """The shadow path over the native transport: the creation option shadow=1 routes level 1's reads of an uncut level 0 through the
     pack kernel, ncclAllGather (one rank) on the kernels' stream and the unpack kernel; the time step must not change a bit."""
     from suhmo_amd import capi, model, multigpu
     m = dict(sy.A3_MODEL, **B5ISH)
     sts = sy.shmip_amrm_states(64, 32, UNION, rough=0.5)
     res = []
     for shadow in (0, 1):
-        monkeypatch.setenv("SUHMO_HIER_SHADOW", str(shadow))
-        G = model.HipHierModel(64, 32, sts[0][0]["dx"], sts[0][0]["dy"], sy.A3_BC, sy.A3_PHYS, m, UNION, max_box=MB)
+        G = model.HipHierModel(64, 32, sts[0][0]["dx"], sts[0][0]["dy"], sy.A3_BC, sy.A3_PHYS, m, UNION, max_box=MB, options="shadow=%d" % shadow)
         G.set_states(sts)
         if shadow:
             multigpu.attach_rccl(G.level[0][0], 0, 1)

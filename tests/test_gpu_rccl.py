@@ -43,7 +43,8 @@ def test_self_neighbour_vcycle_bitwise(nx, ny, variant, halo, monkeypatch):
     for fid in (F_PHI, F_RES, F_BX):
         assert np.array_equal(W.get(fid), S.get(fid)), fid
     assert np.array_equal(W.get(F_BY)[:-1], S.get(F_BY)[:-1])
-    assert W.norm(F_RES, 0) == S.norm(F_RES, 0)          # goes through the ncclAllReduce(MAX) hook
+    assert W.norm(F_RES, 0) == S.norm(F_RES, 0)          # goes through ncclAllReduce(MAX) on the device value, read back through the pinned slot
+    assert W.norm(F_RES, 2) == S.norm(F_RES, 2) and W.dot(F_RES, F_PHI) == S.dot(F_RES, F_PHI)     # ncclAllReduce(SUM); world = 1: the same bits
     n1, h1 = W.solve(dict(sp, max_iter=6))
     n2, h2 = S.solve(dict(sp, max_iter=6))
     assert n1 == n2 and np.array_equal(h1, h2)

@@ -153,3 +153,79 @@ def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
     assert all(p[2] == n for p in parts)
     assert np.array_equal(parts[0][3], hist)
     assert np.array_equal(np.vstack([p[1] for p in parts]), O.get(oracle.F_PHI))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_strips_l2_norm_and_dot_product(world):
+    """norm(ord 2) and dotProduct reduce with a SUM over the ranks (src/AMRNonLinearPoissonOp.cpp:660-666, 519-551, 1222-1264): on 2 / 4
+    thread ranks through the reduce hook (suhmo_level_set_reduce_hook) equal to the whole level to 1e-12 (different summation
+    order); with the MAX-only hook of suhmo_level_set_hooks alone the call is refused (rc -5), not answered per rank"""
+    from suhmo_amd import level as lv, capi
+    f = wrap_ghosts(sy.random_fields(128, 128, seed=41), sy.RANDOM_BC)
+
+    def body(G, rank):
+        G.residual()
+        return G.norm(lv.F_RES, 2), G.dot(lv.F_RES, lv.F_PHI), G.norm(lv.F_RES, 0)
+
+    ref = single(f, sy.RANDOM_BC, sy.RANDOM_PHYS, 0.0, -1.0, body)
+    parts = run_strips(world, f, sy.RANDOM_BC, sy.RANDOM_PHYS, 0.0, -1.0, body)
+    for p in parts:
+        assert abs(p[0] - ref[0]) <= 1e-12 * abs(ref[0]) and abs(p[1] - ref[1]) <= 1e-12 * abs(ref[1]) and p[2] == ref[2]
+    assert len({p[0] for p in parts}) == 1 and len({p[1] for p in parts}) == 1          # every rank holds the same bits
+    # numpy twin of the definition
+    G = lv.HipLevel(128, 128, f["dx"], f["dy"], sy.RANDOM_BC, sy.RANDOM_PHYS, 0.0, -1.0, 32)
+    G.set_inputs(f); G.residual()
+    r, p = G.get(lv.F_RES), G.get(lv.F_PHI)
+    assert abs(ref[0] - np.sqrt(np.sum(r * r))) <= 1e-12 * ref[0] and abs(ref[1] - np.sum(r * p)) <= 1e-12 * abs(np.sum(r * p))
+    G.close()
+
+    def body_max_only(G, rank):
+        check = capi.check
+        check(capi.lib().suhmo_level_set_reduce_hook(G.h, capi.REDUCE_FN(0)))           # back to the MAX-only hook
+        G.residual()
+        with pytest.raises(capi.SuhmoError):
+            G.norm(lv.F_RES, 2)
+        return G.norm(lv.F_RES, 0)
+
+    parts = run_strips(2, f, sy.RANDOM_BC, sy.RANDOM_PHYS, 0.0, -1.0, body_max_only)
+    assert parts[0] == parts[1] == ref[2]
+
+
+@pytest.mark.parametrize("world,n,agg_min_cells,expect_da", [(2, 256, 40000, 1), (4, 256, 2000, 2), (2, 256, 1000, 3), (4, 512, 70000, 1), (2, 256, 100, 5),
+                                                              (4, 256, 10, 0)])
+@pytest.mark.parametrize("periodic", [0, 1])
+def test_strips_agglomerated_coarse_depths(world, n, agg_min_cells, expect_da, periodic, oracle, monkeypatch):
+    """multigrid depths whose strip holds fewer than agg_min_cells cells run redundantly on a whole-level copy on every
+    rank (suhmo_agg.hip: all-gather of the coarse coefficients per build, of the coarse faces and of R phi + RES per V-cycle) -- from
+    depth 1, 2, 3, from the bottom depth only, and not at all: V-cycle and solve equal the oracle's whole level bit for bit, y-periodic
+    and not; the halo exchanges of the agglomerated depths are gone"""
+    from suhmo_amd import level as lv, capi
+    monkeypatch.setenv("SUHMO_AGG_MIN_CELLS", str(agg_min_cells))
+    bc = sy.CONV_BC if periodic else sy.A3_BC
+    f = wrap_ghosts(sy.shmip_fields(n, n, ly=1.0e5), bc)
+    ph = sy.A3_PHYS
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-10, norm_thresh=1e-13, max_iter=3, imin=4)
+
+    def body(G, rank):
+        da = capi.lib().suhmo_level_agglomerated_depth(G.h)
+        G.build_mg_coefficients()
+        G.vcycle(sp)
+        p1 = G.get(lv.F_PHI)
+        n_, hist = G.solve(sp)
+        return p1, G.get(lv.F_PHI), n_, hist, da, G.get_option("agg_gathers")
+
+    parts = run_strips(world, f, bc, ph, 0.0, -1.0, body, halo=24, max_box=64)
+    assert all(p[4] == expect_da for p in parts), [p[4] for p in parts]
+    if expect_da:
+        assert all(p[5] >= 3 for p in parts)               # coefficients + (faces, state) per V-cycle
+    else:
+        assert all(p[5] == 0 for p in parts)
+    O = oracle.OracleLevel(n, n, f["dx"], f["dy"], bc, ph, 0.0, -1.0, 64, 4)
+    O.set_inputs(f)
+    O.build_mg_coefficients()
+    O.vcycle(sp)
+    assert np.array_equal(np.vstack([p[0] for p in parts]), O.get(oracle.F_PHI))
+    n_, hist = O.solve(sp)
+    assert all(p[2] == n_ for p in parts)
+    assert np.array_equal(parts[0][3], hist)
+    assert np.array_equal(np.vstack([p[1] for p in parts]), O.get(oracle.F_PHI))
