@@ -399,7 +399,11 @@ typedef struct suhmo_hier suhmo_hier_t;
 int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *base, int nlev, const int *nbox, const int *boxes);
 /* the same with options, "key=value,key=value" (NULL = defaults): shadow = 1 routes level 1's reads of an UNCUT level 0 through the
  * pack / all-gather / unpack path of rank strips (tests of that path on one rank); push_ghosts = 0: an exchange launch before every
- * colour pass instead of side cells pushed by the pass.  push_ghosts can also be changed later (suhmo_hier_set_option). */
+ * colour pass instead of side cells pushed by the pass; incremental_residual = 0: every composite residual and coarse gradient of
+ * a cycle over the whole of level 0 (default 1: inside suhmo_hier_solve the residual evaluated for the stopping rule serves the next
+ * cycle except in the cells the average from level 1 changed, and level 0's gradient is evaluated only where level 1's coarse-fine
+ * interpolation reads it -- the same bits, two passes over level 0 less per cycle).  push_ghosts and incremental_residual can also
+ * be changed later (suhmo_hier_set_option). */
 int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc_t *base, int nlev, const int *nbox, const int *boxes, const char *options);
 int suhmo_hier_set_option(suhmo_hier_t *H, const char *key, long value);
 int suhmo_hier_get_option(const suhmo_hier_t *H, const char *key, long *value);

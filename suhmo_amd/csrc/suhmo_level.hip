@@ -576,10 +576,8 @@ extern "C" int suhmo_level_fill_ghosts(suhmo_level_t *L, int depth, int field, i
 // 2: the FAS right-hand side of a coarse depth in one pass: LPHI = L(phi), RHS = axby(RES, LPHI, 1, 1), PHIOLD = phi
 // 3: LPHI = L(phi) and RES = axby(LPHI, RHS, -1, 1) in one pass (the composite residual of an AMR level, suhmo_hier.hip)
 template <bool HAS_ALPHA, int MODE>
-__device__ __forceinline__ void d_apply(const DV &v, const FP &fp, suhmo_phys_t ph, int homog, int halo, int hcomp)
+__device__ __forceinline__ void d_apply_at(const DV &v, const FP &fp, suhmo_phys_t ph, int homog, int halo, int hcomp, int i, int j)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - halo;     // MODE 2 on a rank strip: the halo rows only copy phi
     if (i >= v.nx || j >= v.ny + halo) return;
     const double *__restrict__ phi = fp.f[SUHMO_F_PHI];
     int idx = cidx(v, i, j);
@@ -608,9 +606,26 @@ __device__ __forceinline__ void d_apply(const DV &v, const FP &fp, suhmo_phys_t 
     }
 }
 template <bool HAS_ALPHA, int MODE>
+__device__ __forceinline__ void d_apply(const DV &v, const FP &fp, suhmo_phys_t ph, int homog, int halo, int hcomp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - halo;     // MODE 2 on a rank strip: the halo rows only copy phi
+    d_apply_at<HAS_ALPHA, MODE>(v, fp, ph, homog, halo, hcomp, i, j);
+}
+template <bool HAS_ALPHA, int MODE>
 __global__ __launch_bounds__(256) void k_apply(DV v, FP fp, suhmo_phys_t ph, int homog, int halo = 0, int hcomp = 0)
 {
     d_apply<HAS_ALPHA, MODE>(v, fp, ph, homog, halo, hcomp);
+}
+// LPHI and RES = rhs - LPHI on a list of rectangles (x = first column, y = first row, z = columns, w = rows) of the level: the part of
+// a composite residual that has changed since the whole level was evaluated (suhmo_hier.hip); overlapping rectangles write the same values
+template <bool HAS_ALPHA>
+__global__ __launch_bounds__(256) void k_apply_rects(DV v, FP fp, suhmo_phys_t ph, const int4 *__restrict__ rects)
+{
+    const int4 r = rects[blockIdx.z];
+    const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y * blockDim.y + threadIdx.y;
+    if (a >= r.z || b >= r.w) return;
+    d_apply_at<HAS_ALPHA, 3>(v, fp, ph, 0, 0, 0, r.x + a, r.y + b);
 }
 // every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
 template <bool HAS_ALPHA, int MODE>
@@ -672,6 +687,20 @@ int suhmo_apply_and_residual(suhmo_level *L, int depth, hipStream_t st)
     int rc = suhmo_ensure_phi_halo(L, depth, 1, st); if (rc) return rc;
     if (D.v.alpha != 0.0) hipLaunchKernelGGL((k_apply<true, 3>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, st, D.v, D.fp, L->ph, 0);
     else hipLaunchKernelGGL((k_apply<false, 3>), grid2d(D.v.nx, D.v.ny), BLK2D, 0, st, D.v, D.fp, L->ph, 0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int suhmo_apply_and_residual_rects(suhmo_level *L, int depth, const int4 *d_rects, int n, int maxw, int maxh, hipStream_t st)
+{
+    SUHMO_TIME("VCAMRNonLinearPoissonOp::applyOpI");
+    Depth &D = L->d[depth];
+    if (!suhmo_field(L, depth, SUHMO_F_LPHI) || !suhmo_field(L, depth, SUHMO_F_RES)) return -2;
+    int rc = suhmo_ensure_phi_halo(L, depth, 1, st); if (rc) return rc;
+    if (!n) return 0;
+    dim3 grd((maxw + 63) / 64, (maxh + 3) / 4, n);
+    if (D.v.alpha != 0.0) hipLaunchKernelGGL((k_apply_rects<true>), grd, BLK2D, 0, st, D.v, D.fp, L->ph, d_rects);
+    else hipLaunchKernelGGL((k_apply_rects<false>), grd, BLK2D, 0, st, D.v, D.fp, L->ph, d_rects);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -934,9 +963,8 @@ extern "C" int suhmo_level_prolong_bilinear(suhmo_level_t *L, int depth, suhmo_s
 // ------------------------------------------------------------------ bCoef update (WFlx_level)
 // step 1: cell-centred gradient = EdgeToCell(NEWMACGRAD) (util/Gradient.cpp:96-127, :623;
 // util/GradientF.ChF:57-70)
-__device__ __forceinline__ void d_gradcc(const DV &v, const FP &fp, int hasMask)
+__device__ __forceinline__ void d_gradcc_at(const DV &v, const FP &fp, int hasMask, int i, int j)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
     if (i >= v.nx || j >= v.ny) return;
     const double *__restrict__ phi = fp.f[SUHMO_F_PHI];
     int idx = cidx(v, i, j);
@@ -955,9 +983,20 @@ __device__ __forceinline__ void d_gradcc(const DV &v, const FP &fp, int hasMask)
     fp.f[SUHMO_F_GRADX][idx] = 0.5 * (gW + gE);
     fp.f[SUHMO_F_GRADY][idx] = 0.5 * (gS + gN);
 }
+__device__ __forceinline__ void d_gradcc(const DV &v, const FP &fp, int hasMask)
+{
+    d_gradcc_at(v, fp, hasMask, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y * blockDim.y + threadIdx.y);
+}
 __global__ __launch_bounds__(256) void k_gradcc(DV v, FP fp, int hasMask)
 {
     d_gradcc(v, fp, hasMask);
+}
+// the same at a list of cells (x = i, y = j): the coarse cells a finer level's coarse-fine interpolation of the gradient reads
+__global__ __launch_bounds__(256) void k_gradcc_list(DV v, FP fp, int hasMask, const int2 *__restrict__ cells, int n)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    d_gradcc_at(v, fp, hasMask, cells[t].x, cells[t].y);
 }
 // every box of a multi-box AMR level in one launch (blockIdx.z = box; suhmo_hier.hip)
 __global__ __launch_bounds__(256) void k_gradcc_m(const DV *__restrict__ vt, const FP *__restrict__ ft, int hasMask)
@@ -1260,6 +1299,16 @@ int suhmo_grad_cc(suhmo_level *L, int depth, hipStream_t st)
     rc = exchange_fields(L, depth, {SUHMO_F_GRADX, SUHMO_F_GRADY}, st); if (rc) return rc;    // lvlgradH.exchange() :1490
     int n = 2 * D.v.ny + 2 * D.v.nx;
     hipLaunchKernelGGL(k_grad_ghosts, dim3((n + 255) / 256), dim3(256), 0, st, D.v, D.fp.f[SUHMO_F_GRADX], D.fp.f[SUHMO_F_GRADY]);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// GRADX / GRADY at the listed cells only (device list of (i, j)); nothing else of the two fields is touched
+int suhmo_grad_cc_list(suhmo_level *L, int depth, const int2 *d_cells, int n, hipStream_t st)
+{
+    Depth &D = L->d[depth];
+    if (!suhmo_field(L, depth, SUHMO_F_GRADX) || !suhmo_field(L, depth, SUHMO_F_GRADY) || !suhmo_field(L, depth, SUHMO_F_RE)) return -2;
+    int rc = suhmo_ensure_phi_halo(L, depth, 1, st); if (rc) return rc;
+    if (n) hipLaunchKernelGGL(k_gradcc_list, dim3((n + 255) / 256), dim3(256), 0, st, D.v, D.fp, L->ph.use_mask_gradients, d_cells, n);
     HIPCHK(hipGetLastError());
     return 0;
 }

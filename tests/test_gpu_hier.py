@@ -83,13 +83,16 @@ def test_hier_pieces_bitwise(oracle, bc, ph):
 
 
 @pytest.mark.parametrize("name,boxes,bc,ph", [("union-4lev", UNION, BC_NP, sy.CFG3_PHYS), ("union-4lev-values-mask", UNION, BC_V, MASKPH),
-                                              ("cut-periodic", CUT, BC, sy.CFG3_PHYS), ("union-4lev-exchange-per-pass", UNION, BC_NP, sy.CFG3_PHYS)],
+                                              ("cut-periodic", CUT, BC, sy.CFG3_PHYS), ("union-4lev-exchange-per-pass", UNION, BC_NP, sy.CFG3_PHYS),
+                                              ("union-4lev-whole-level-residuals", UNION, BC_NP, sy.CFG3_PHYS)],
                          ids=lambda v: v if isinstance(v, str) else "")
 def test_hier_vcycle_and_solve_bitwise(oracle, name, boxes, bc, ph):
     from suhmo_amd.level import F_PHI, F_RES, F_BX
     # exchange-per-pass: an exchange launch before every colour pass instead of the pushed side cells (creation option of the hierarchy)
     sp = dict(sy.SOLVER_DEFAULT, eps=1e-9, norm_thresh=1e-14, max_iter=6, imin=30)
-    O, G, fs = pair(oracle, boxes, bc, ph, options="push_ghosts=0" if name.endswith("exchange-per-pass") else None)
+    # whole-level-residuals: every composite residual and coarse gradient over all of level 0 (default: the solve loop's evaluation is
+    # reused by the next cycle except where level 1 was averaged down; the coarse gradient only where the interpolation reads it)
+    O, G, fs = pair(oracle, boxes, bc, ph, options="push_ghosts=0" if name.endswith("exchange-per-pass") else "incremental_residual=0" if name.endswith("whole-level-residuals") else None)
     O.vcycle(sp); G.vcycle(sp)
     same_levels(O, G, oracle, ((oracle.F_PHI, F_PHI), (oracle.F_BX, F_BX)), "vcycle")
     no, ho = O.solve(sp)

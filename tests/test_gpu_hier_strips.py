@@ -62,9 +62,11 @@ CASES = [("union-2-ranks", 2, UNION, dict(), 2), ("union-4-ranks", 4, UNION, dic
 
 
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("agg", [0, 600], ids=["", "coarse-depths-agglomerated"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_hier_timestep_on_strips_bitwise(case):
+def test_hier_timestep_on_strips_bitwise(case, agg, monkeypatch):
     from suhmo_amd import model
+    monkeypatch.setenv("SUHMO_AGG_MIN_CELLS", str(agg))      # > 0: the base strips' coarse multigrid depths run agglomerated (suhmo_agg.hip), also in the gap-height hierarchy
     name, world, boxes, mpo, nsteps = case
     nx0, ny0 = 64, 32
     m = dict(sy.A3_MODEL, **mpo)

@@ -96,9 +96,12 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("world,halo", [(2, 4), (4, 4), (2, 1), (4, 16)])
+@pytest.mark.parametrize("world,halo,agg", [(2, 4, 0), (4, 4, 0), (2, 1, 0), (4, 16, 0), (2, 4, 1500), (4, 16, 300)])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_timestep_on_strips_bitwise(case, world, halo):
+def test_timestep_on_strips_bitwise(case, world, halo, agg, monkeypatch):
+    """agg > 0: multigrid depths whose strip holds fewer cells run agglomerated on a whole-level copy (suhmo_agg.hip), the head
+    solve's and the implicit gap-height solve's alike"""
+    monkeypatch.setenv("SUHMO_AGG_MIN_CELLS", str(agg))
     name, nx, ny, bc, ph, mpo, holes, nsteps, nm = case
     m = dict(sy.A3_MODEL, **mpo)
     st = wrap(perturbed_state(nx, ny, 17, holes), bc)

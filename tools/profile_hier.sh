@@ -10,5 +10,6 @@ export TMPDIR=/tmp
 cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_hier${NB}_prof -- python3 $R/tools/hier_bench.py $NB $NS > $OUT/${TAG}_hier${NB}_under_rocprof.txt 2> $OUT/${TAG}_hier${NB}_prof.err || exit 1
 cp $(ls $OUT/${TAG}_hier${NB}_prof/*/*kernel_stats.csv | head -1) $OUT/${TAG}_hier${NB}_kernel_stats.csv
 cd $R && python3 tools/stats_by_grid.py $(ls $OUT/${TAG}_hier${NB}_prof/*/*kernel_trace.csv | head -1) $((NS + 3)) > $OUT/${TAG}_hier${NB}_kernel_stats_by_grid.txt 2>&1
+python3 tools/trace_around.py $(ls $OUT/${TAG}_hier${NB}_prof/*/*kernel_trace.csv | head -1) fillBufferAligned > $OUT/${TAG}_hier${NB}_around_fill.txt 2>&1
 rm -rf $OUT/${TAG}_hier${NB}_prof
 echo done
