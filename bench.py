@@ -24,7 +24,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_PER_CELL_SWEEP = 72.0    # phi r+w, rhs, bx, by, B, Pi, zb, mask
-PMC_FILE = "r02_pmc_traffic_gsrb.json"   # HBM bytes per launch of the depth-0 kernel, from this round's rocprofv3 --pmc passes
+PMC_FILE = "r03_pmc_traffic_gsrb.json"   # HBM bytes per launch of the depth-0 kernel, from this round's rocprofv3 --pmc passes
 LX = 1.0e5                     # width of the synthetic domain in metres (SHMIP-A: 100 km)
 
 
@@ -94,6 +94,7 @@ def main():
     sync()
     G.profile(True)
     msgs0 = G.rccl_exchanges() if world > 1 else 0
+    agg0 = G.get_option("agg_gathers") if world > 1 else 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         G.vcycle(sp)
@@ -194,7 +195,11 @@ def main():
                        "global_cells": [n, ny_global], "partition": "row strips, 1 per GPU" if world > 1 else "none",
                        "unit_of_value": "V-cycles over %dx%d cells (%s; the level of %dx%d cells completes %.4g V-cycles/s)"
                                         % (n, n, "the whole level, cut into strips" if strong else "one per GPU per step", n, ny_global, vps),
-                       "halo_message_groups_per_vcycle_per_rank": msgs if world > 1 else None},
+                       "halo_message_groups_per_vcycle_per_rank": msgs if world > 1 else None,
+                       # rank strips: multigrid depths from this one on run agglomerated on a whole-level copy (0 = none; suhmo_agg.hip),
+                       # fed by all-gathers that are counted among the message groups above
+                       "agglomerated_from_depth": int(capi.lib().suhmo_level_agglomerated_depth(G.h)) if world > 1 else None,
+                       "allgathers_per_vcycle_per_rank": (G.get_option("agg_gathers") - agg0) / args.steps if world > 1 else None},
             "residual_max_norm": {"before_warmup": res_before, "after_timed_cycles": res_after, "cycles": args.warmup + args.steps},
             "gsrb_cell_updates_per_s": updates_per_vcycle * vps * world,   # per-rank strip updates x ranks (strong and weak alike)
             "gsrb_depth0_cell_updates_per_s_kernel": cells / (sweep_ms * 1e-3) * world if gsrb_launches else None,

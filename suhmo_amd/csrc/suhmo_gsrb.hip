@@ -436,23 +436,38 @@ struct TileGeom {
     int jbeg, jend;                          // rows written: the level's, plus on a rank strip the halo rows that stay current for the next launch
     int chunks;                              // level = one tile: this many times S sweeps in the launch (halo images refreshed in LDS)
     int order;                               // workgroup -> tile: 0 as launched, 1 / 2 XCD-aware (see k_gsrb_tile)
+    int dbg;                                 // timing probes (builds with -DSUHMO_TILE_PROBE only, env SUHMO_TILE_DBG; tools/probes/tile_probe.sh): results are wrong on purpose
 };
-struct PairCoef { double rhs0, rhs1, B0, B1, Pi0, Pi1, zb0, zb1, mk0, mk1, a0, a1, byS0, byS1, byN0, byN1, bx0, bx1, bx2; };
+#ifdef SUHMO_TILE_PROBE
+#define TILE_DBG(bit) (g.dbg & (bit))
+#else
+#define TILE_DBG(bit) false
+#endif
+// (of the ice mask COMPUTENONLINEARTERMS uses the sign only: mneg bit 0 / 1 = the first / second cell of the pair is without ice)
+struct PairCoef { double rhs0, rhs1, B0, B1, Pi0, Pi1, zb0, zb1, a0, a1, byS0, byS1, byN0, byN1, bx0, bx1, bx2; int mneg; };
 
 // RST = true: the launch also restricts (as k_gsrb_fused<.., RST>): one more ring of final values around the tile (two columns,
 // pairs stay aligned), the residual quarters of the tile's cells go through LDS and one thread per coarse cell adds the four in
 // the reference's visiting order (RESTRICTRESVCNL2D + RESTRICTVCNL).  The 32-wide tile is 28 rows high then: the same number
 // of column pairs per thread, hence the same registers, as without the restriction.
 template <int T, bool RST> struct TileShape { static constexpr int TX = T, TY = (RST && T == 32) ? 28 : T; };
-
+// Threads per workgroup: 256 (5 column pairs per thread at T = 32, S = 4: 2 waves per SIMD).  Measured and dropped (profiles/r03_tile_*):
+// 384 threads (3 pairs per thread, 161-168 VGPRs, 3 waves per SIMD on paper) -- the six waves of a workgroup land 2 + 2 + 1 + 1 on the
+// four SIMDs, a second workgroup no longer fits beside the first, and the 2048^2 launch takes 266 us instead of 203.
+template <int S, int T, bool RST> struct TileThreads { static constexpr int NT = 256; };
 template <int S, int T, bool HAS_ALPHA, bool RST = false, bool CHUNKED = false>
-__global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__restrict__ pin, double *__restrict__ pout,
+__global__ __launch_bounds__((TileThreads<S, T, RST>::NT)) __attribute__((amdgpu_waves_per_eu((TileThreads<S, T, RST>::NT == 384 ? 3 : 2)))) void k_gsrb_tile(DV v, FP fp, const double *__restrict__ pin, double *__restrict__ pout,
                                                    suhmo_phys_t ph, TileGeom g)
 {
     constexpr int TX = TileShape<T, RST>::TX, TY = TileShape<T, RST>::TY;
     constexpr int HX = 2 * S + (RST ? 2 : 0), HY = 2 * S + (RST ? 1 : 0);
-    constexpr int LX = TX + 2 * HX, LY = TY + 2 * HY, NP = LX / 2, NPAIR = NP * LY, NK = (NPAIR + 255) / 256;
-    __shared__ double lds[LY * LX];
+    constexpr int LX = TX + 2 * HX, LY = TY + 2 * HY, NP = LX / 2, NPAIR = NP * LY;
+    constexpr int NT = TileThreads<S, T, RST>::NT, NK = (NPAIR + NT - 1) / NT;
+    // (a margin of one row + two cells either side: the straight-line pass below also evaluates the cells on the region's edge, whose
+    // results are dropped, and reads one cell beyond them)
+    constexpr int PAD = LX + 2;
+    __shared__ double lds_raw[LY * LX + 2 * PAD];
+    double *const lds = lds_raw + PAD;
     __shared__ double lq[RST ? TY * TX : 1];                  // RST: (rhs - L(phi)) / 4 of the tile's cells
     // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: every XCD takes a contiguous run of the tile list, so
     // that the tiles in flight on it are neighbours and the halo cells they share (2.25 x the tile's own at S = 4) are read from HBM
@@ -470,6 +485,17 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
     const int tj0 = g.jbeg + ty * TY;                         // first row the tile writes
     const int gx0 = tx * TX - HX, gy0 = tj0 - HY;             // domain cell of LDS cell (0, 0)
     const int t = threadIdx.x;
+    // thread -> column pairs: the pairs of a WAVE lie in rows of one parity (waves 0, 2: even rows of the region; 1, 3: odd rows), so
+    // which cell of its pairs a colour pass advances is the same for the whole wave: a scalar branch picks one of two straight-line
+    // bodies with the pair's coefficients addressed statically, instead of per-lane selects
+    const int par = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) & 1;
+    const int u0 = ((t >> 7) << 6) | (t & 63);                 // this thread among the NT / 2 of its parity
+    auto pair_pos = [&](const int k, int &ly, int &lx) -> bool {
+        const int u = u0 + (NT / 2) * k, r = u / NP;
+        ly = 2 * r + par; lx = 2 * (u - r * NP);
+        return ly < LY;
+    };
+    static_assert(LY % 2 == 0, "rows of the region come in pairs of parities");
     // a coarse-fine side takes precedence over the domain's periodicity (the patch does not wrap onto itself)
     const bool perx = v.per[0] && !v.cfx[0] && !v.cfx[1], pery = v.per[1] && !v.ext[0] && !v.ext[1];
     // sides of the LDS region that reach a physical boundary: nothing beyond them feeds the tile
@@ -482,15 +508,45 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
     // coefficients of the thread's pairs as NAMED variables (an array ends up in scratch memory)
     PairCoef cf0, cf1, cf2, cf3, cf4;
     bool lv0, lv1, lv2, lv3, lv4;                             // the pair lies in the domain (or is a periodic image of one that does)
-    static_assert(NK <= 5 && TX * TY / 4 <= 256, "tile too large for 256 threads");
+    static_assert(NK <= 5 && TX * TY / 4 <= NT, "tile too large for the workgroup");
 #define TILE_EACH(F) { F(0, cf0, lv0); if constexpr (NK > 1) F(1, cf1, lv1); if constexpr (NK > 2) F(2, cf2, lv2); \
                        if constexpr (NK > 3) F(3, cf3, lv3); if constexpr (NK > 4) F(4, cf4, lv4); }
+    bool special = false;                                     // a pair of this thread has a cell without ice or in a cut-off range of the gap height
+    // most tiles of a large level: the whole region lies in the level's own cells (uniform) -- the index logic of the general case
+    // (validity of every pair, periodic images, stored ghosts, halo rows) is 250 instructions per pair, 19 % of the launch at 2048^2
+    const bool inner = gx0 >= 0 && gx0 + LX <= v.nx && gy0 >= 0 && gy0 + LY <= v.ny && !TILE_DBG(1);
+    // the coefficients of a pair in the domain (and the FAS correction added to its phi, PROLONGNL)
+    auto ldcoef = [&](PairCoef &c, double2 &p2, const int idx, const int i, const int j) {
+        if (g.pc) {
+            const int ic = ((j >> 1) + g.gyc) * g.Pc + SUHMO_XOFF + (i >> 1);
+            const double corr = 1.0 * g.pc[ic] + (-1.0) * g.pco[ic];      // axby(1, -1), then PROLONGNL
+            p2.x = p2.x + corr; p2.y = p2.y + corr;
+        }
+        double2 d;
+        d = ld2(g.frhs ? fp.f[SUHMO_F_RES] : fp.f[SUHMO_F_RHS], idx); c.rhs0 = d.x; c.rhs1 = d.y;
+        d = ld2(fp.f[SUHMO_F_B], idx); c.B0 = d.x; c.B1 = d.y;
+        d = ld2(fp.f[SUHMO_F_PI], idx); c.Pi0 = d.x; c.Pi1 = d.y;
+        d = ld2(fp.f[SUHMO_F_ZB], idx); c.zb0 = d.x; c.zb1 = d.y;
+        d = ld2(fp.f[SUHMO_F_MASK], idx); c.mneg = (d.x < 0.0 ? 1 : 0) | (d.y < 0.0 ? 2 : 0);
+        if (HAS_ALPHA) { d = ld2(fp.f[SUHMO_F_ACOEF], idx); c.a0 = d.x; c.a1 = d.y; }
+        d = ld2(fp.f[SUHMO_F_BY], idx); c.byS0 = d.x; c.byS1 = d.y;
+        d = ld2(fp.f[SUHMO_F_BY], idx + v.P); c.byN0 = d.x; c.byN1 = d.y;
+        d = ld2(fp.f[SUHMO_F_BX], idx); c.bx0 = d.x; c.bx1 = d.y; c.bx2 = fp.f[SUHMO_F_BX][idx + 2];
+        special = special || c.mneg != 0 || ph.cutOffbr > c.B0 || ph.cutOffbr > c.B1 || ph.maxOffbr < c.B0 || ph.maxOffbr < c.B1;
+    };
     auto load = [&](const int k, PairCoef &c, bool &live) {
-        const int q = t + 256 * k;
         live = false;
-        if (q < NPAIR) {
-            const int ly = q / NP, lx = 2 * (q % NP);
+        int ly, lx;
+        if (pair_pos(k, ly, lx)) {
             int i = gx0 + lx, j = gy0 + ly;
+            if (inner) {                                      // the region lies in the level's own cells: no test, no wrap, no ghost
+                live = true;
+                const int idx = cidx(v, i, j);
+                double2 p2 = ld2(pin, idx);
+                ldcoef(c, p2, idx, i, j);
+                lds[ly * LX + lx] = p2.x; lds[ly * LX + lx + 1] = p2.y;
+                return;
+            }
             // (rank boundary of a strip: the rows beyond are the neighbour's cells, held in the canvas' halo rows with their
             //  coefficients; they are advanced redundantly like periodic images, without the wrap)
             const bool inx = perx || (i >= 0 && i < v.nx), iny = pery || (j >= 0 && j < v.ny) || (j < 0 && v.rk[0] && j >= g.jbeg - HY) || (j >= v.ny && v.rk[1] && j < g.jend + HY);   // (only the halo rows the written rows depend on: the canvas ends at gy)
@@ -498,6 +554,8 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
             const bool exi = inx || (i == -2 && v.cfx[0]) || (i == v.nx && v.cfx[1]);
             const bool exj = iny || (j == -1 && v.ext[0] && !v.rk[0]) || (j == v.ny && v.ext[1] && !v.rk[1]);
             double2 p2 = make_double2(0.0, 0.0);
+            if (exi && exj && TILE_DBG(1)) { live = inx && iny; p2 = make_double2(900.0 + 1.0e-3 * lx, 900.0 + 1.0e-3 * ly); }
+            else
             if (exi && exj) {
                 live = inx && iny;
                 if (perx) i = wrap(i, v.nx);
@@ -505,29 +563,23 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
                 const int idx = cidx(v, i, j);
                 p2 = ld2(pin, idx);
             }
-            if (live) {
-                const int idx = cidx(v, i, j);
-                if (g.pc) {
-                    const int ic = ((j >> 1) + g.gyc) * g.Pc + SUHMO_XOFF + (i >> 1);
-                    const double corr = 1.0 * g.pc[ic] + (-1.0) * g.pco[ic];      // axby(1, -1), then PROLONGNL
-                    p2.x = p2.x + corr; p2.y = p2.y + corr;
-                }
-                double2 d;
-                d = ld2(g.frhs ? fp.f[SUHMO_F_RES] : fp.f[SUHMO_F_RHS], idx); c.rhs0 = d.x; c.rhs1 = d.y;
-                d = ld2(fp.f[SUHMO_F_B], idx); c.B0 = d.x; c.B1 = d.y;
-                d = ld2(fp.f[SUHMO_F_PI], idx); c.Pi0 = d.x; c.Pi1 = d.y;
-                d = ld2(fp.f[SUHMO_F_ZB], idx); c.zb0 = d.x; c.zb1 = d.y;
-                d = ld2(fp.f[SUHMO_F_MASK], idx); c.mk0 = d.x; c.mk1 = d.y;
-                if (HAS_ALPHA) { d = ld2(fp.f[SUHMO_F_ACOEF], idx); c.a0 = d.x; c.a1 = d.y; }
-                d = ld2(fp.f[SUHMO_F_BY], idx); c.byS0 = d.x; c.byS1 = d.y;
-                d = ld2(fp.f[SUHMO_F_BY], idx + v.P); c.byN0 = d.x; c.byN1 = d.y;
-                d = ld2(fp.f[SUHMO_F_BX], idx); c.bx0 = d.x; c.bx1 = d.y; c.bx2 = fp.f[SUHMO_F_BX][idx + 2];
-            }
+            if (live && TILE_DBG(1)) {                        // probe: no global loads of the coefficients
+                c.rhs0 = c.rhs1 = 1.0e-9; c.B0 = c.B1 = 0.01; c.Pi0 = c.Pi1 = 9.0e6; c.zb0 = c.zb1 = 0.0; c.mneg = 0; c.a0 = c.a1 = 0.0;
+                c.byS0 = c.byS1 = c.byN0 = c.byN1 = c.bx0 = c.bx1 = c.bx2 = -1.0e-3;
+            } else
+            if (live) ldcoef(c, p2, cidx(v, i, j), i, j);
             lds[ly * LX + lx] = p2.x; lds[ly * LX + lx + 1] = p2.y;
         }
     };
     TILE_EACH(load);
-    __syncthreads();
+    // Straight-line passes (below) when nothing in the region needs a case distinction: no physical-boundary, coarse-fine or
+    // stored-ghost side in reach, every cell under ice and outside the cut-off ranges of COMPUTENONLINEARTERMS (workgroup-uniform)
+    // (only in the instantiation that relaxes the large depths: with aCoef, the restriction or the chunk loop on top the second loop
+    //  body costs the kernel its second wave per SIMD)
+    constexpr bool PLAIN_OK = !HAS_ALPHA && !RST && !CHUNKED;
+    const bool plain = PLAIN_OK && !__syncthreads_or(special ? 1 : 0) && ph.use_NL && !openW && !openE && !openS && !openN
+                       && !v.cfx[0] && !v.cfx[1] && !(v.ext[0] && !v.rk[0]) && !(v.ext[1] && !v.rk[1]);
+    if constexpr (!PLAIN_OK) __syncthreads();
 
     // The FAS right-hand side of a coarse depth, rhs = res + L(R phi) (applyOpMg + axby of the cycle, k_apply<., 2>), formed
     // from the restricted phi just loaded, for every cell the passes will advance; the tile's own cells also store it, L(phi)
@@ -535,9 +587,8 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
     if (g.frhs) {
         const int ylo = openS ? 0 : 1, yhi = openN ? LY - 1 : LY - 2;
         auto mkrhs = [&](const int k, PairCoef &q_, const bool live) {
-            const int q = t + 256 * k;
-            if (q < NPAIR && live) {
-                const int ly = q / NP, lx = 2 * (q % NP);
+            int ly, lx;
+            if (pair_pos(k, ly, lx) && live) {
                 const int i = gx0 + lx, j = gy0 + ly;
                 if (ly >= ylo && ly <= yhi) {
                     const double *row = lds + ly * LX;
@@ -557,7 +608,7 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
                             if (j == v.ny - 1 && !v.ext[1]) n = (v.bct[1][1] == 0) ? v.two_v[1][1] - c : c + v.neu[1][1];
                         }
                         double nl, dnl;
-                        nl_terms(ph, c, a ? q_.B1 : q_.B0, a ? q_.Pi1 : q_.Pi0, a ? q_.zb1 : q_.zb0, a ? q_.mk1 : q_.mk0, nl, dnl);
+                        nl_terms(ph, c, a ? q_.B1 : q_.B0, a ? q_.Pi1 : q_.Pi0, a ? q_.zb1 : q_.zb0, (q_.mneg >> a) & 1 ? -1.0 : 1.0, nl, dnl);
                         const double bxW = a ? q_.bx1 : q_.bx0, bxE = a ? q_.bx2 : q_.bx1;
                         double aterm = HAS_ALPHA ? v.alpha * (a ? q_.a1 : q_.a0) : v.alpha;
                         lo[a] = lofphi_cell(v, aterm, c, e, w, n, s_, bxE, bxW, a ? q_.byN1 : q_.byN0, a ? q_.byS1 : q_.byS0, nl);
@@ -586,9 +637,8 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
     for (int chunk = 0; chunk < (CHUNKED ? g.chunks : 1); chunk++) {
     if (CHUNKED && chunk > 0 && (perx || pery)) {
         auto refresh = [&](const int k, const PairCoef &, const bool live) {
-            const int q = t + 256 * k;
-            if (q < NPAIR && live) {
-                const int ly = q / NP, lx = 2 * (q % NP);
+            int ly, lx;
+            if (pair_pos(k, ly, lx) && live) {
                 const int i = gx0 + lx, j = gy0 + ly;
                 if (i < 0 || i >= v.nx || j < 0 || j >= v.ny) {
                     const int src = ((pery ? wrap(j, v.ny) : j) - gy0) * LX + ((perx ? wrap(i, v.nx) : i) - gx0);
@@ -600,14 +650,73 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
         TILE_EACH(refresh);
         __syncthreads();
     }
+    if constexpr (PLAIN_OK) { if (plain && !TILE_DBG(2)) {
+        // ---- the passes as straight-line code: every pair of the thread is evaluated (edge cells and idle slots too: their results
+        // land in the margin), all LDS reads of a pass come before its writes (a pass reads the other colour and its own
+        // centres only), nothing branches per lane: five independent updates the scheduler can interleave.  The expressions are
+        // those of the general pass with the case distinctions that cannot occur here taken out: the same bits.
+#pragma unroll 1
+        for (int p = 0; p < 2 * S; p++) {
+            const int lo = p + 1, xhi = LX - 2 - p, yhi = LY - 2 - p;
+            const int a_pass = (gy0 + par + v.j0 + p) & 1;    // scalar: the pairs of this wave share their rows' parity
+            // (the coefficients are loop-invariant: keep the compiler from hoisting products of them out of the pass loop into
+            //  registers that do not exist)
+#define TOUCH(c) asm volatile("" : "+v"(c.rhs0), "+v"(c.rhs1), "+v"(c.B0), "+v"(c.B1), "+v"(c.Pi0), "+v"(c.Pi1), "+v"(c.zb0), "+v"(c.zb1), \
+                              "+v"(c.byS0), "+v"(c.byS1), "+v"(c.byN0), "+v"(c.byN1), "+v"(c.bx0), "+v"(c.bx1), "+v"(c.bx2))
+            TOUCH(cf0); if constexpr (NK > 1) TOUCH(cf1); if constexpr (NK > 2) TOUCH(cf2); if constexpr (NK > 3) TOUCH(cf3); if constexpr (NK > 4) TOUCH(cf4);
+#undef TOUCH
+            double nv0 = 0.0, nv1 = 0.0, nv2 = 0.0, nv3 = 0.0, nv4 = 0.0;
+            int ad0 = -1, ad1 = -1, ad2 = -1, ad3 = -1, ad4 = -1;
+            auto upd = [&](const int k, const PairCoef &q_, auto a_tag, double &nv, int &ad) {
+                constexpr int A = decltype(a_tag)::value;
+                int ly, lx;
+                const bool ok = pair_pos(k, ly, lx);
+                if (!ok) { ly = par; lx = 0; }                // idle slot: any valid pair for the reads, a cell of the margin for the write
+                const int x = lx + A;
+                const double *row = lds + ly * LX;
+                const double2 pr = *reinterpret_cast<const double2 *>(row + lx);
+                const double c = A ? pr.y : pr.x;
+                const double w = A ? pr.x : row[lx - 1], e = A ? row[lx + 2] : pr.y;
+                const double s = row[x - LX], n = row[x + LX];
+                const double B = A ? q_.B1 : q_.B0;
+                const double N = (A ? q_.Pi1 : q_.Pi0) - ph.rho_w_g * (c - (A ? q_.zb1 : q_.zb0));      // nl_terms, no case applies
+                const double nl = -ph.A * B * N * N * N;
+                const double dnl = 3.0 * ph.A * B * 1000.0 * ph.grav * N * N;
+                const double bxW = A ? q_.bx1 : q_.bx0, bxE = A ? q_.bx2 : q_.bx1;
+                const double byN = A ? q_.byN1 : q_.byN0, byS = A ? q_.byS1 : q_.byS0;
+                const double aterm = HAS_ALPHA ? v.alpha * (A ? q_.a1 : q_.a0) : v.alpha;
+                const double lofphi = lofphi_cell(v, aterm, c, e, w, n, s, bxE, bxW, byN, byS, nl);
+                const double lam = lambda_cell(v, aterm, bxE, bxW, byN, byS);
+                const double denom = 1.0e-16 + lam + dnl;
+                const double cnew = c + ((A ? q_.rhs1 : q_.rhs0) - lofphi) / denom;
+                // (the result of a cell outside this pass's region goes to a cell of the margin: an unconditional store, so that the
+                //  compiler cannot sink the evaluation into a branch per pair, which would serialise the five updates again)
+                const bool in = ok && x >= lo && x <= xhi && ly >= lo && ly <= yhi;
+                nv = cnew;
+                ad = in ? ly * LX + x : -1;
+            };
+            if (a_pass) {
+                using A1 = std::integral_constant<int, 1>;
+                upd(0, cf0, A1(), nv0, ad0); if constexpr (NK > 1) upd(1, cf1, A1(), nv1, ad1); if constexpr (NK > 2) upd(2, cf2, A1(), nv2, ad2);
+                if constexpr (NK > 3) upd(3, cf3, A1(), nv3, ad3); if constexpr (NK > 4) upd(4, cf4, A1(), nv4, ad4);
+            } else {
+                using A0 = std::integral_constant<int, 0>;
+                upd(0, cf0, A0(), nv0, ad0); if constexpr (NK > 1) upd(1, cf1, A0(), nv1, ad1); if constexpr (NK > 2) upd(2, cf2, A0(), nv2, ad2);
+                if constexpr (NK > 3) upd(3, cf3, A0(), nv3, ad3); if constexpr (NK > 4) upd(4, cf4, A0(), nv4, ad4);
+            }
+            lds[ad0] = nv0; if constexpr (NK > 1) lds[ad1] = nv1; if constexpr (NK > 2) lds[ad2] = nv2;
+            if constexpr (NK > 3) lds[ad3] = nv3; if constexpr (NK > 4) lds[ad4] = nv4;
+            if (!TILE_DBG(4)) __syncthreads();
+        }
+    } }
+    if (!(PLAIN_OK && plain) && !TILE_DBG(2))
 #pragma unroll 1
     for (int p = 0; p < 2 * S; p++) {
         const int xlo = openW ? 0 : p + 1, xhi = openE ? LX - 1 : LX - 2 - p;
         const int ylo = openS ? 0 : p + 1, yhi = openN ? LY - 1 : LY - 2 - p;
         auto relax = [&](const int k, const PairCoef &q_, const bool live) {
-            const int q = t + 256 * k;
-            if (q < NPAIR && live) {
-                const int ly = q / NP, lx = 2 * (q % NP);
+            int ly, lx;
+            if (pair_pos(k, ly, lx) && live) {
                 const int j = gy0 + ly;
                 const int a = (j + v.j0 + p) & 1;             // which cell of the pair has this pass's colour
                 const int x = lx + a, i = gx0 + x;
@@ -625,7 +734,7 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
                         if (j == v.ny - 1 && !v.ext[1]) n = (v.bct[1][1] == 0) ? v.two_v[1][1] - c : c + v.neu[1][1];
                     }
                     double nl, dnl;
-                    nl_terms(ph, c, a ? q_.B1 : q_.B0, a ? q_.Pi1 : q_.Pi0, a ? q_.zb1 : q_.zb0, a ? q_.mk1 : q_.mk0, nl, dnl);
+                    nl_terms(ph, c, a ? q_.B1 : q_.B0, a ? q_.Pi1 : q_.Pi0, a ? q_.zb1 : q_.zb0, (q_.mneg >> a) & 1 ? -1.0 : 1.0, nl, dnl);
                     const double bxW = a ? q_.bx1 : q_.bx0, bxE = a ? q_.bx2 : q_.bx1;
                     const double byN = a ? q_.byN1 : q_.byN0, byS = a ? q_.byS1 : q_.byS0;
                     double aterm = HAS_ALPHA ? v.alpha * (a ? q_.a1 : q_.a0) : v.alpha;
@@ -645,10 +754,14 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
     const int wi0 = tx * TX - ((tx == 0 && v.cfx[0]) ? 1 : 0), wi1 = oi1 + ((oi1 == v.nx && v.cfx[1]) ? 1 : 0);
     const int wj0 = tj0 - ((ty == 0 && v.ext[0] && !v.rk[0]) ? 1 : 0), wj1 = oj1 + ((oj1 == v.ny && v.ext[1] && !v.rk[1]) ? 1 : 0);
     auto store = [&](const int k, const PairCoef &q_, const bool) {
-        const int q = t + 256 * k;
-        if (q < NPAIR) {
-            const int ly = q / NP, lx = 2 * (q % NP);
+        int ly, lx;
+        if (pair_pos(k, ly, lx) && !(TILE_DBG(8) && ly != 7)) {
             const int i = gx0 + lx, j = gy0 + ly;
+            if (inner && !RST) {                              // (the tile itself lies in the level too)
+                if (lx >= HX && lx < HX + TX && ly >= HY && ly < HY + TY)
+                    *reinterpret_cast<double2 *>(pout + cidx(v, i, j)) = make_double2(lds[ly * LX + lx], lds[ly * LX + lx + 1]);
+                return;
+            }
             // cells this tile writes: its own and, next to a coarse-fine side, the stored ghosts (the other canvas has to
             // carry them too)
             if (j >= wj0 && j < wj1) {
@@ -674,7 +787,7 @@ __global__ __launch_bounds__(256) void k_gsrb_tile(DV v, FP fp, const double *__
                             if (j == v.ny - 1 && !v.ext[1]) n = (v.bct[1][1] == 0) ? v.two_v[1][1] - c : c + v.neu[1][1];
                         }
                         double nl, dnl;
-                        nl_terms(ph, c, a ? q_.B1 : q_.B0, a ? q_.Pi1 : q_.Pi0, a ? q_.zb1 : q_.zb0, a ? q_.mk1 : q_.mk0, nl, dnl);
+                        nl_terms(ph, c, a ? q_.B1 : q_.B0, a ? q_.Pi1 : q_.Pi0, a ? q_.zb1 : q_.zb0, (q_.mneg >> a) & 1 ? -1.0 : 1.0, nl, dnl);
                         const double bxW = a ? q_.bx1 : q_.bx0, bxE = a ? q_.bx2 : q_.bx1;
                         double aterm = HAS_ALPHA ? v.alpha * (a ? q_.a1 : q_.a0) : v.alpha;
                         double lofphi = lofphi_cell(v, aterm, c, e, w, n, s_, bxE, bxW, a ? q_.byN1 : q_.byN0, a ? q_.byS1 : q_.byS0, nl);
@@ -743,6 +856,10 @@ static int launch_tile(suhmo_level *L, int depth, int chunks, int ext_rows, hipS
     }
     g.chunks = chunks;
     g.order = L->tile_order;
+    g.dbg = 0;
+#ifdef SUHMO_TILE_PROBE
+    if (const char *e = getenv("SUHMO_TILE_DBG")) g.dbg = atoi(e);
+#endif
     g.frhs = 0;
     if (D.rhs_pending) {
         if (!suhmo_field(L, depth, SUHMO_F_LPHI) || !suhmo_field(L, depth, SUHMO_F_PHIOLD)) return -2;
@@ -752,18 +869,18 @@ static int launch_tile(suhmo_level *L, int depth, int chunks, int ext_rows, hipS
     if constexpr (S == 4) {
         if (chunks > 1) {
             if (v.alpha != 0.0)
-                hipLaunchKernelGGL((k_gsrb_tile<S, T, true, RST, true>), dim3(g.ntx * g.nty), dim3(256), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+                hipLaunchKernelGGL((k_gsrb_tile<S, T, true, RST, true>), dim3(g.ntx * g.nty), dim3(TileThreads<S, T, RST>::NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
             else
-                hipLaunchKernelGGL((k_gsrb_tile<S, T, false, RST, true>), dim3(g.ntx * g.nty), dim3(256), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+                hipLaunchKernelGGL((k_gsrb_tile<S, T, false, RST, true>), dim3(g.ntx * g.nty), dim3(TileThreads<S, T, RST>::NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
             std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
             return 0;
         }
     }
     if (chunks > 1) { suhmo_set_error("internal: chunked tile launch with S != 4"); return -4; }
     if (v.alpha != 0.0)
-        hipLaunchKernelGGL((k_gsrb_tile<S, T, true, RST>), dim3(g.ntx * g.nty), dim3(256), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+        hipLaunchKernelGGL((k_gsrb_tile<S, T, true, RST>), dim3(g.ntx * g.nty), dim3(TileThreads<S, T, RST>::NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
     else
-        hipLaunchKernelGGL((k_gsrb_tile<S, T, false, RST>), dim3(g.ntx * g.nty), dim3(256), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+        hipLaunchKernelGGL((k_gsrb_tile<S, T, false, RST>), dim3(g.ntx * g.nty), dim3(TileThreads<S, T, RST>::NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
     std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
     return 0;
 }
