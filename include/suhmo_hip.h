@@ -294,7 +294,7 @@ int suhmo_level_set_hooks(suhmo_level_t *L, suhmo_exchange_fn ex, suhmo_allreduc
 typedef int (*suhmo_allreduce_fn)(void *user, double *values, int n, int op);
 int suhmo_level_set_reduce_hook(suhmo_level_t *L, suhmo_allreduce_fn fn);
 /* all-gather of `count` doubles per rank (device buffers; recv holds world x count, rank-major, ranks in ascending j0), enqueued on /
- * ordered with s.  With it attached, the multigrid depths whose strip holds fewer than `agg_min_cells` cells (option, default 65536;
+ * ordered with s.  With it attached, the multigrid depths whose strip holds fewer than `agg_min_cells` cells (option, default 100000;
  * SURVEY.md 8e) are AGGLOMERATED: every rank runs them redundantly on a copy of the whole level, fed by two all-gathers per V-cycle,
  * instead of exchanging halo rows per relaxation (suhmo_amd/csrc/suhmo_agg.hip).  suhmo_level_attach_rccl installs ncclAllGather.
  * suhmo_level_agglomerated_depth: first agglomerated depth, 0 = none. */

@@ -85,7 +85,12 @@ SYMBOLS = [
 
 
 def build(force=False):
-    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU).  With SUHMO_LIB set the library in use is
+    somebody else's build: nothing is compiled (the in-tree file would not be the one lib() loads)."""
+    if os.environ.get("SUHMO_LIB"):
+        if not os.path.exists(LIB_PATH):
+            raise SuhmoError("SUHMO_LIB = %s does not exist" % LIB_PATH)
+        return LIB_PATH
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "suhmo_hip.h"))
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):

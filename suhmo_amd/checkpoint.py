@@ -24,10 +24,34 @@ class Header(C.Structure):
                 ("cfl", C.c_double), ("is_periodic", C.c_int * 2)]
 
 
+def hdf5_prefix():
+    """installation prefix of an HDF5 C library (include/hdf5.h + lib/libhdf5.so): $HDF5_ROOT / $HDF5_DIR, h5cc, pkg-config, then the
+    image's /opt/conda and the usual system prefixes; None if there is none"""
+    import shutil
+    cands = [os.environ.get("HDF5_ROOT"), os.environ.get("HDF5_DIR")]
+    h5cc = shutil.which("h5cc")
+    if h5cc:
+        cands.append(os.path.dirname(os.path.dirname(os.path.realpath(h5cc))))
+    try:
+        out = subprocess.run(["pkg-config", "--variable=prefix", "hdf5"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=10).stdout.decode().strip()
+        cands.append(out or None)
+    except Exception:
+        pass
+    cands += ["/opt/conda", "/usr", "/usr/local"]
+    for c in cands:
+        if c and os.path.exists(os.path.join(c, "include", "hdf5.h")) and any(os.path.exists(os.path.join(c, "lib", n)) for n in ("libhdf5.so", "libhdf5.a")):
+            return c
+    return None
+
+
 def build(force=False):
+    """g++ against an HDF5 C library; raises RuntimeError when there is none (the checkpoint file is optional: the caller decides)"""
     src = [os.path.join(CSRC, "suhmo_chk.cpp"), os.path.join(os.path.dirname(_HERE), "include", "suhmo_chk.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
-        subprocess.check_call(["make", "-C", CSRC, "-B", "libsuhmo_chk.so"], stdout=subprocess.DEVNULL)
+        prefix = hdf5_prefix()
+        if prefix is None:
+            raise RuntimeError("no HDF5 C library found (set HDF5_ROOT): libsuhmo_chk.so not built")
+        subprocess.check_call(["make", "-C", CSRC, "-B", "libsuhmo_chk.so", "HDF5=" + prefix], stdout=subprocess.DEVNULL)
     return LIB_PATH
 
 
@@ -78,6 +102,14 @@ def write_levels(path, levels, step, time, dt, periodic=(0, 0), max_level=None, 
                 for a, b in zip(arrs, bx):
                     assert a.shape == (b[3] - b[1] + 3, b[2] - b[0] + 3), (name, a.shape, tuple(b))
                 _check(lib().suhmo_chk_write_field(h, l, name.encode(), 1, _ptrs(arrs)))
+        # levels the run allows but has not defined yet: the header of every level <= max_level (dx, prob_domain, ref_ratio), as
+        # AmrHydro::writeCheckpointFile writes them and readCheckpointFile expects them (src/AmrHydro.cpp:5798-5821)
+        for l in range(nlev, hdr.max_level + 1):
+            lv = levels[-1]
+            r = 2 ** (l - (nlev - 1))
+            d0 = [int(v) for v in lv["domain"]]
+            dom = (C.c_int * 4)(d0[0] * r, d0[1] * r, (d0[2] + 1) * r - 1, (d0[3] + 1) * r - 1)
+            _check(lib().suhmo_chk_write_level(h, l, lv["dx"] / r, lv["dy"] / r, 2 if l < hdr.max_level else 0, dom, 0, None))
     finally:
         lib().suhmo_chk_close(h)
 

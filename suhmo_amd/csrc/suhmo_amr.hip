@@ -518,6 +518,7 @@ int vcycle_amr(suhmo_level_t **lv, int l, const suhmo_solver_params_t *sp, suhmo
     if (F && (rc = suhmo_level_residual(F, 0, s))) return rc;                                  // res_l = rhs_l - L_l(phi_l)
     double *rhs0 = nullptr, *phiold = nullptr;
     size_t cbytes = 0;
+    SwapGuard rhs_aside;
     if (C) {
         Depth &DC = C->d[0];
         cbytes = DC.elems * sizeof(double);
@@ -527,15 +528,14 @@ int vcycle_amr(suhmo_level_t **lv, int l, const suhmo_solver_params_t *sp, suhmo
         if (F && (rc = suhmo_amr2_average(C, F, SUHMO_F_RES, SUHMO_F_RES, s))) return rc;
         // the right-hand side of level l-1 is set aside while its FAS problem runs: two canvases trade places (the captured V-cycle
         // graphs of a level check which one they were recorded with)
-        std::swap(DC.fp.f[SUHMO_F_RHS], DC.fp.f[SUHMO_F_RHS0]);
+        rhs_aside.arm(&DC.fp.f[SUHMO_F_RHS], &DC.fp.f[SUHMO_F_RHS0]);
         if ((rc = suhmo_level_axby(C, 0, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
         if ((rc = suhmo_level_exchange(C, 0, SUHMO_F_RHS, s))) return rc;                      // rank strips: rhs halo rows
         HIPCHK(hipMemcpyAsync(phiold, DC.fp.f[SUHMO_F_PHI], cbytes, hipMemcpyDeviceToDevice, st));
     }
     if ((rc = vcycle_amr(lv, l - 1, sp, s))) return rc;
     if (C) {
-        Depth &DC = C->d[0];
-        std::swap(DC.fp.f[SUHMO_F_RHS], DC.fp.f[SUHMO_F_RHS0]);                               // back: the halo rows never left
+        rhs_aside.back();                                                                     // the halo rows never left
         if ((rc = suhmo_level_axby(C, 0, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) return rc;
         if (F) {
             if ((rc = suhmo_amr2_prolong2(C, F, SUHMO_F_CORR, s))) return rc;                  // AMRProlongS_2

@@ -262,17 +262,24 @@ extern "C" int suhmo_chk_read_field(suhmo_chk_t *h, int level, const char *name,
     std::string base(name);
     std::vector<long long> off(L.nbox + 1, 0);
     int rc = 0;
+    // number of elements a dataset really holds (a truncated or foreign file must not overrun the buffers sized from the box list)
+    auto extent = [](hid_t d) -> long long { hid_t sp = H5Dget_space(d); long long n = sp >= 0 ? (long long)H5Sget_simple_extent_npoints(sp) : -1; if (sp >= 0) H5Sclose(sp); return n; };
     {
         hid_t d = H5Dopen2(g, (base + ":offsets=0").c_str(), H5P_DEFAULT);
-        if (d < 0 || H5Dread(d, H5T_NATIVE_LLONG, H5S_ALL, H5S_ALL, H5P_DEFAULT, off.data()) < 0) rc = fail("checkpoint file does not contain %s data", name);
+        if (d < 0) rc = fail("checkpoint file does not contain %s data", name);
+        else if (extent(d) != (long long)L.nbox + 1) rc = fail("%s: the offsets hold %lld entries, the level has %d boxes", name, extent(d), L.nbox);
+        else if (H5Dread(d, H5T_NATIVE_LLONG, H5S_ALL, H5S_ALL, H5P_DEFAULT, off.data()) < 0) rc = fail("checkpoint file does not contain %s data", name);
         if (d >= 0) H5Dclose(d);
     }
+    if (!rc && off[0] != 0) rc = fail("%s: the offsets do not start at 0", name);
     for (int k = 0; k < L.nbox && !rc; k++)
-        if (off[k + 1] - off[k] != box_pts(&L.boxes[4 * k], ghost)) rc = fail("%s: box %d does not have the size its ghost width implies", name, k);
+        if (off[k + 1] - off[k] != box_pts(&L.boxes[4 * k], ghost)) rc = fail("%s: box %d does not have the size its ghost width implies", name, k);   // (also: monotone, non-negative)
     if (!rc) {
         std::vector<double> flat((size_t)off[L.nbox]);
         hid_t d = H5Dopen2(g, (base + ":datatype=0").c_str(), H5P_DEFAULT);
-        if (d < 0 || H5Dread(d, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, flat.data()) < 0) rc = fail("checkpoint file does not contain %s data", name);
+        if (d < 0) rc = fail("checkpoint file does not contain %s data", name);
+        else if (extent(d) != off[L.nbox]) rc = fail("%s: the data set holds %lld values, the boxes need %lld", name, extent(d), off[L.nbox]);
+        else if (H5Dread(d, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, flat.data()) < 0) rc = fail("checkpoint file does not contain %s data", name);
         if (d >= 0) H5Dclose(d);
         for (int k = 0; k < L.nbox && !rc; k++) memcpy(fabs[k], &flat[(size_t)off[k]], sizeof(double) * (size_t)(off[k + 1] - off[k]));
     }

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <string>
 #include <vector>
 #include "../../include/suhmo_hip.h"
@@ -161,7 +162,7 @@ struct suhmo_level {
     void *rccl;                 // native transport state (suhmo_rccl.hip), owned by the level
     // agglomeration of the coarse depths of a rank strip (suhmo_agg.hip): from depth agg_depth on (0 = none) the cycle runs on `agg`, a
     // handle of the WHOLE level at that depth held by every rank; all-gather transport ag (suhmo_level_set_allgather / attach_rccl)
-    long agg_min_cells;         // depths whose strip holds fewer cells are agglomerated (env SUHMO_AGG_MIN_CELLS, default 65536, 0 = off)
+    long agg_min_cells;         // depths whose strip holds fewer cells are agglomerated (env SUHMO_AGG_MIN_CELLS, default 100000: at 4096^2 cells per strip the two deepest of six depths; 0 = off)
     int agg_depth, agg_world, agg_rank;
     suhmo_level *agg;
     suhmo_allgather_fn ag; void *ag_user;
@@ -208,6 +209,16 @@ struct SuhmoTimer { const char *name; double t0; int mode; explicit SuhmoTimer(c
 #define ARG(cond) do { if (!(cond)) { suhmo_set_error("%s:%d bad argument: %s", __FILE__, __LINE__, #cond); return -1; } } while (0)
 
 double *suhmo_field(suhmo_level *L, int depth, int field);   // lazily allocates
+// Two canvases of a level trade places while its FAS problem runs (the level's own right-hand side is set aside): whatever way the
+// scope is left -- an exchange or all-gather hook failing in between included -- they trade back, so a caller that catches the
+// error still holds the problem it posed
+struct SwapGuard {
+    double **a, **b; bool armed;
+    SwapGuard() : a(nullptr), b(nullptr), armed(false) {}
+    void arm(double **a_, double **b_) { a = a_; b = b_; std::swap(*a, *b); armed = true; }
+    void back() { if (armed) { std::swap(*a, *b); armed = false; } }
+    ~SwapGuard() { back(); }
+};
 int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st);      // suhmo_level.hip
 int suhmo_restrict_both(suhmo_level *L, int depth, hipStream_t st);                 // suhmo_level.hip
 bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps);           // suhmo_gsrb.hip

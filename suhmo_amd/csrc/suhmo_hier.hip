@@ -1010,7 +1010,8 @@ int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stre
     if ((rc = hier_avg(H, l, SUHMO_F_RES, SUHMO_F_RES, 0, 0.0, HST(s)))) return rc;
     // the right-hand side of level l-1 is set aside while its FAS problem runs: two canvases trade places on level 0 (its
     // pointers travel by value), a copy on a level of boxes (their pointers sit in a device table)
-    if (l - 1 == 0) std::swap(base_of(H)->d[0].fp.f[SUHMO_F_RHS], base_of(H)->d[0].fp.f[SUHMO_F_RHS0]);
+    SwapGuard rhs_aside;                                   // (trades back on every way out of this scope)
+    if (l - 1 == 0) rhs_aside.arm(&base_of(H)->d[0].fp.f[SUHMO_F_RHS], &base_of(H)->d[0].fp.f[SUHMO_F_RHS0]);
     else if ((rc = hier_copy(H, l - 1, SUHMO_F_RHS0, SUHMO_F_RHS, s))) return rc;
     if ((rc = hier_axby(H, l - 1, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
     if (l == 1 && dist_base(H) && (rc = suhmo_level_exchange(base_of(H), 0, SUHMO_F_RHS, s))) return rc;      // rank strips: rhs halo rows (relaxed redundantly)
@@ -1019,7 +1020,7 @@ int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stre
     if (l - 1 == 0) rc = hier_window_save(H, l, SUHMO_F_PHI, HST(s)); else rc = hier_copy(H, l - 1, SUHMO_F_PHIOLD, SUHMO_F_PHI, s);
     if (rc) return rc;
     if ((rc = vcycle_amr(H, l - 1, sp, s))) return rc;
-    if (l - 1 == 0) std::swap(base_of(H)->d[0].fp.f[SUHMO_F_RHS], base_of(H)->d[0].fp.f[SUHMO_F_RHS0]);
+    if (l - 1 == 0) rhs_aside.back();
     else if ((rc = hier_copy(H, l - 1, SUHMO_F_RHS, SUHMO_F_RHS0, s))) return rc;
     if (l - 1 == 0) rc = hier_prolong2(H, l, SUHMO_F_PHI, HST(s), true);                      // AMRProlongS_2 of phi - phi_saved
     else if (!(rc = hier_axby(H, l - 1, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) rc = hier_prolong2(H, l, SUHMO_F_CORR, HST(s));
@@ -1218,8 +1219,21 @@ const double *suhmo_hier_base_cover_(suhmo_hier *H, DV *whole)
 }
 int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, suhmo_hier **gap)
 {
-    if (!H->gap || H->gap_dt != dt) {
-        if (H->gap) { suhmo_hier_destroy(H->gap); H->gap = nullptr; }
+    if (H->gap && H->gap_dt != dt) {                       // a new time step size: beta = dt diffFactor of every operator; boxes, plans and tables stay
+        for (int l = 0; l < H->nlev; l++)
+            for (suhmo_level *L : H->gap->lev[l].box) { int rc = suhmo_level_set_alpha_beta(L, 1.0, dt * mp->diffFactor); if (rc) return rc; }
+        if (H->gap->lev[0].box[0]->agg) { int rc = suhmo_level_set_alpha_beta(H->gap->lev[0].box[0]->agg, 1.0, dt * mp->diffFactor); if (rc) return rc; }
+        HIPCHK(hipDeviceSynchronize());
+        for (int l = 1; l < H->nlev; l++) {                // the device copies of the boxes' views carry beta: uploaded again at the next use
+            HLev &V = H->gap->lev[l];
+            if (V.d_dv) { (void)hipFree(V.d_dv); V.d_dv = nullptr; }
+            if (V.d_red) { (void)hipFree(V.d_red); V.d_red = nullptr; }
+            V.h_fp.clear();
+        }
+        H->gap->vglob.beta = H->gap->lev[0].box[0]->d[0].v.beta;
+        H->gap_dt = dt;
+    }
+    if (!H->gap) {
         suhmo_level_desc_t d = H->base_desc;
         const suhmo_level *B = H->lev[0].box[0];
         d.boxes = B->boxes.data(); d.nbox = (int)(B->boxes.size() / 4);

@@ -161,7 +161,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     if (const char *e = getenv("SUHMO_STRIPS_RHS_LOCAL")) L->strips_rhs_local = atoi(e);
     L->fas_rhs_fused = 1;
     if (const char *e = getenv("SUHMO_FAS_RHS_FUSED")) L->fas_rhs_fused = atoi(e) != 0;
-    L->agg_min_cells = 65536; L->agg_depth = 0; L->agg_world = 1; L->agg_rank = 0; L->agg = nullptr; L->ag = nullptr; L->ag_user = nullptr;
+    L->agg_min_cells = 100000; L->agg_depth = 0; L->agg_world = 1; L->agg_rank = 0; L->agg = nullptr; L->ag = nullptr; L->ag_user = nullptr;
     L->agg_send = L->agg_recv = nullptr; L->agg_cap = 0; L->agg_gathers = 0;
     if (const char *e = getenv("SUHMO_AGG_MIN_CELLS")) L->agg_min_cells = atol(e);
     if (const char *e = getenv("SUHMO_TILE_STRIPS")) L->tile_strips = atoi(e);

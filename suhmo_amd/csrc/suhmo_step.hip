@@ -346,8 +346,12 @@ static int diffusion_terms(suhmo_level *L, const suhmo_model_params_t *mp, hipSt
 static int gap_level_prepare(suhmo_level *L, const suhmo_model_params_t *mp, double dt, hipStream_t st)
 {
     Depth &D = L->d[0];
-    if (!L->gap || L->gap_dt != dt) {
-        if (L->gap) { suhmo_level_destroy(L->gap); L->gap = nullptr; }
+    if (L->gap && L->gap_dt != dt) {                       // a new time step size: only beta = dt diffFactor changes
+        int rc = suhmo_level_set_alpha_beta(L->gap, 1.0, dt * mp->diffFactor); if (rc) return rc;
+        if (L->gap->agg && (rc = suhmo_level_set_alpha_beta(L->gap->agg, 1.0, dt * mp->diffFactor))) return rc;
+        L->gap_dt = dt;
+    }
+    if (!L->gap) {
         suhmo_level_desc_t d = L->desc;
         d.boxes = L->boxes.data(); d.nbox = (int)(L->boxes.size() / 4);
         for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) { d.bc.type[a][b] = 1; d.bc.value[a][b] = 0.0; }

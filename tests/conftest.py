@@ -25,7 +25,7 @@ def oracle():
 
 @pytest.fixture(autouse=True)
 def _strip_paths_not_agglomerated_by_default(monkeypatch):
-    """The small strips of the test cases would run every coarse multigrid depth agglomerated (suhmo_agg.hip, default threshold 65536
+    """The small strips of the test cases would run every coarse multigrid depth agglomerated (suhmo_agg.hip, default threshold 100000
     cells per strip) and leave the strips' own coarse-depth paths (tile kernel on strips, locally computed right-hand sides, halo
     bookkeeping) untested: off by default here; the tests of the agglomeration set their own threshold."""
     if "SUHMO_AGG_MIN_CELLS" not in os.environ:

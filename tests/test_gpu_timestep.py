@@ -38,6 +38,7 @@ CASES = [
      dict(use_mask_rhs_b=1, G=0.05), True, 2),
     ("dirichlet-values", 48, 16, dict(type=[[0, 0], [1, 1]], value=[[2.0, 900.0], [0.0, 0.0]], periodic=[0, 0]),
      sy.A3_PHYS, dict(basal_friction=0), False, 2),
+    ("implicit-gap-changing-dt", 64, 32, sy.A3_BC, sy.A3_PHYS, dict(diffFactor=1.0, use_impl_diff=1), False, 3),   # the gap operator takes a new beta per step size
 ]
 
 
@@ -52,8 +53,9 @@ def test_timestep_bitwise(oracle, hipmodel, name, nx, ny, bc, ph, mpo, holes, ns
     G.set_state(st)
     v = lambda a: np.array(a)[1:-1, 1:-1]
     for k in range(nsteps):
-        po, vo = O.timestep(m["dt"])
-        pg, vg = G.timestep(m["dt"])
+        dt = m["dt"] * (0.5 if k == 1 else 1.0)          # (a changing step size)
+        po, vo = O.timestep(dt)
+        pg, vg = G.timestep(dt)
         assert (po, vo) == (pg, vg), (k, po, vo, pg, vg)
         for nm, fid in (("head", oracle.OM_H), ("B", oracle.OM_B), ("mR", oracle.OM_MR), ("Pw", oracle.OM_PW),
                         ("cd", oracle.OM_CD), ("rhs_h", oracle.OM_RHSH)):
