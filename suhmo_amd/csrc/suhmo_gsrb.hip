@@ -495,6 +495,9 @@ __global__ __launch_bounds__((TileThreads<S, T, RST>::NT)) __attribute__((amdgpu
         ly = 2 * r + par; lx = 2 * (u - r * NP);
         return ly < LY;
     };
+    // (measured and dropped, profiles/r03_tile_probe.txt: the rows of a parity taken tile rows first, then the halo rows from the tile
+    //  outwards, so that the later slots of a thread hold halo rows only and the straight-line passes skip a slot as a whole once none of
+    //  its rows is advanced any more -- 34 slot-passes instead of 40, bitwise, and the launch takes the same 203 us)
     static_assert(LY % 2 == 0, "rows of the region come in pairs of parities");
     // a coarse-fine side takes precedence over the domain's periodicity (the patch does not wrap onto itself)
     const bool perx = v.per[0] && !v.cfx[0] && !v.cfx[1], pery = v.per[1] && !v.ext[0] && !v.ext[1];
@@ -674,10 +677,11 @@ __global__ __launch_bounds__((TileThreads<S, T, RST>::NT)) __attribute__((amdgpu
                 if (!ok) { ly = par; lx = 0; }                // idle slot: any valid pair for the reads, a cell of the margin for the write
                 const int x = lx + A;
                 const double *row = lds + ly * LX;
-                const double2 pr = *reinterpret_cast<const double2 *>(row + lx);
+                double2 pr; double wl, er, s, n;
+                if (TILE_DBG(32)) { pr = make_double2(q_.rhs0 + 900.0, q_.rhs1 + 900.0); wl = q_.Pi0 * 1.0e-4; er = q_.Pi1 * 1.0e-4; s = q_.zb0 + 900.0; n = q_.zb1 + 900.0; }   // probe: passes without LDS reads
+                else { pr = *reinterpret_cast<const double2 *>(row + lx); wl = row[lx - 1]; er = row[lx + 2]; s = row[x - LX]; n = row[x + LX]; }
                 const double c = A ? pr.y : pr.x;
-                const double w = A ? pr.x : row[lx - 1], e = A ? row[lx + 2] : pr.y;
-                const double s = row[x - LX], n = row[x + LX];
+                const double w = A ? pr.x : wl, e = A ? er : pr.y;
                 const double B = A ? q_.B1 : q_.B0;
                 const double N = (A ? q_.Pi1 : q_.Pi0) - ph.rho_w_g * (c - (A ? q_.zb1 : q_.zb0));      // nl_terms, no case applies
                 const double nl = -ph.A * B * N * N * N;
@@ -704,8 +708,11 @@ __global__ __launch_bounds__((TileThreads<S, T, RST>::NT)) __attribute__((amdgpu
                 upd(0, cf0, A0(), nv0, ad0); if constexpr (NK > 1) upd(1, cf1, A0(), nv1, ad1); if constexpr (NK > 2) upd(2, cf2, A0(), nv2, ad2);
                 if constexpr (NK > 3) upd(3, cf3, A0(), nv3, ad3); if constexpr (NK > 4) upd(4, cf4, A0(), nv4, ad4);
             }
+            if (TILE_DBG(64)) { cf0.rhs0 += nv0 * 1e-30; if constexpr (NK > 1) cf1.rhs0 += nv1 * 1e-30; if constexpr (NK > 2) cf2.rhs0 += nv2 * 1e-30;
+                                if constexpr (NK > 3) cf3.rhs0 += nv3 * 1e-30; if constexpr (NK > 4) cf4.rhs0 += nv4 * 1e-30; }   // probe: no LDS writes (results kept alive)
+            else {
             lds[ad0] = nv0; if constexpr (NK > 1) lds[ad1] = nv1; if constexpr (NK > 2) lds[ad2] = nv2;
-            if constexpr (NK > 3) lds[ad3] = nv3; if constexpr (NK > 4) lds[ad4] = nv4;
+            if constexpr (NK > 3) lds[ad3] = nv3; if constexpr (NK > 4) lds[ad4] = nv4; }
             if (!TILE_DBG(4)) __syncthreads();
         }
     } }

@@ -193,5 +193,14 @@ class HipHierModel:
     def get(self, l, k, name, ghosted=False):
         return self.level[l][k].get(self.FIELDS[name], ghosted=ghosted)
 
+    def postproc_table_device(self):
+        """SHMIP cross-section table of a run with AMR levels: the reference evaluates it on LEVEL 0 ("POST PROC -- 1 LEVEL",
+        m_amrGrids[0], src/AmrHydro.cpp:3643-3700; the finer levels enter through the averaged-down head, CoarseAverage :3138-3141) --
+        suhmo_level_postproc_table on the base handle of the hierarchy (whole level 0; on rank strips: postproc_partial per rank)"""
+        base = self.level[0][0]
+        t = np.zeros((base.nx, 8))
+        check(capi.lib().suhmo_level_postproc_table(base.h, C.byref(self._mp), t.ctypes.data_as(C.POINTER(C.c_double)), self.hier.stream))
+        return t
+
     def close(self):
         self.hier.close()

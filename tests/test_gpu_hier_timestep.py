@@ -100,3 +100,29 @@ def test_two_level_amr_run_against_the_reference_convergence_table(case):
     assert abs(e["B"] / ref[nx0][1] - 1.0) < 0.015, (e["B"], ref[nx0][1])
     assert abs(e["Re"] / ref[nx0][3] - 1.0) < 0.015, (e["Re"], ref[nx0][3])
     assert e["head"] < ref[nx0][0]
+
+
+def test_postproc_table_of_a_hierarchy(oracle):
+    """the SHMIP cross-section table of a run with AMR levels: the reference evaluates it on level 0 (src/AmrHydro.cpp:3643-3700, "POST PROC --
+    1 LEVEL") -- the device table of the hierarchy's base handle equals the host twin evaluated on the oracle's level-0 fields after the
+    same steps (sums in another order: 1e-12)"""
+    m = dict(sy.A3_MODEL, **B5ISH)
+    O, G, sts = make(oracle, UNION, m)
+    O.moulin_source(**MOULINS); G.moulin_source(**MOULINS)
+    from suhmo_amd import level as lv
+    for l in range(O.nlev):
+        for k in range(len(O.boxes[l])):
+            G.level[l][k].set(lv.F_MSRC, np.array(O.field(l, k, oracle.OM_MSRC))[1:-1, 1:-1])
+    for step in range(2):
+        assert O.timestep(m["dt"]) == G.timestep(m["dt"])
+    t = G.postproc_table_device()
+    g = lambda fid: np.array(O.field(0, 0, fid))
+    v = lambda a: a[1:-1, 1:-1]
+    mask = v(g(oracle.OM_MASK))
+    src = np.where(mask > 0.0, v(g(oracle.OM_MSRC)) * m.get("ramp", 1.0) + m["distributed_input"], 0.0)
+    ref = sy.shmip_postproc_table(sts[0][0]["dx"], sts[0][0]["dy"], g(oracle.OM_QWX), g(oracle.OM_CD), src, v(g(oracle.OM_MR)), v(g(oracle.OM_PW)),
+                                  v(g(oracle.OM_PI)), mask, m["rho_w"])
+    ok = np.isfinite(ref)
+    assert np.array_equal(ok, np.isfinite(t))
+    scale = np.max(np.where(ok, np.abs(ref), 0.0), axis=0)
+    assert np.all(np.where(ok, np.abs(t - ref), 0.0) <= 1e-12 * np.maximum(scale, 1e-300))
