@@ -312,6 +312,7 @@ class HipHier:
         self.j0, self.ny_global = j0, int(d.ny_global)
         self.stream = C.c_void_p(0)
         self.level = [[_BoxView(capi.lib().suhmo_hier_box(h, 0, 0), nx0, ny0, dx0, dy0, self.stream)]]
+        self.level[0][0].j0, self.level[0][0].ny_global = j0, self.ny_global          # (this rank's strip of level 0)
         for l, bl in enumerate(self.boxes, start=1):
             self.level.append([_BoxView(capi.lib().suhmo_hier_box(h, l, k), b[2] - b[0] + 1, b[3] - b[1] + 1, dx0 / 2 ** l, dy0 / 2 ** l,
                                         self.stream) for k, b in enumerate(bl)])

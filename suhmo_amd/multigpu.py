@@ -39,10 +39,11 @@ class StripExchanger:
         self._red = capi.REDUCE_FN(self._reduce)
         check(capi.lib().suhmo_level_set_reduce_hook(level.h, self._red))
         self.calls = self.gathers = 0
-        # all-gather over the ranks of the level: with it the coarse multigrid depths are agglomerated (suhmo_agg.hip); a sub-group
-        # of ranks (AMR patch strips) does not agglomerate
+        # all-gather over the ranks of the level: with it the coarse multigrid depths are agglomerated (suhmo_agg.hip); the strips of
+        # an AMR patch do not agglomerate (the library declines: a patch is not a whole level)
         self._ag = capi.ALLGATHER_FN(self._allgather)
-        if peers is None and hasattr(transport, "allgather"):
+        whole = getattr(level, "ny", 0) * world == getattr(level, "ny_global", -1)     # the `world` ranks of this exchanger hold the whole level in equal strips
+        if whole and hasattr(transport, "allgather"):
             check(capi.lib().suhmo_level_set_allgather(level.h, self._ag, None))
 
     def _geom(self, depth):

@@ -37,6 +37,10 @@ def run_strips(world, nx0, ny0, boxes, sts, m, nsteps, mou, mb, halo_rows=4):
                     G.set_state(l, k, st)
             ex = multigpu.StripExchanger(G.level[0][0], tr, rank, world, False)
             ex.exchange_static()
+            import os
+            from suhmo_amd import capi
+            da = capi.lib().suhmo_level_agglomerated_depth(G.level[0][0].h)
+            assert (da > 0) == (int(os.environ.get("SUHMO_AGG_MIN_CELLS", "0")) > 0), da      # the variant really runs what its name says
             ag = multigpu.HierGather(G.hier, tr, rank)
             integ = G.moulin_source(**mou) if mou else None
             msrc = [[G.get(l, k, "msrc") for k in range(len(G.level[l]))] for l in range(len(sts))] if mou else None

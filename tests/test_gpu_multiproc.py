@@ -57,10 +57,13 @@ def test_two_ranks_over_nccl_bitwise(tool, args):
     assert "BITWISE EQUAL" in logs[0]
 
 
-@pytest.mark.parametrize("tool,args,world", [("amr_shmip_dist.py", ["--case", "B5", "--steps", "6", "--check"], 2),
-                                             ("shmip_dist.py", ["--case", "B3", "--scale", "1", "--steps", "6", "--check"], 4),
-                                             ("hier_dist.py", ["--base", "256", "--steps", "2", "--check"], 2)])
-def test_rank_strips_as_processes(tool, args, world):
+@pytest.mark.parametrize("tool,args,world,agg", [("amr_shmip_dist.py", ["--case", "B5", "--steps", "6", "--check"], 2, 0),
+                                                 ("shmip_dist.py", ["--case", "B3", "--scale", "1", "--steps", "6", "--check"], 4, 0),
+                                                 ("hier_dist.py", ["--base", "256", "--steps", "2", "--check"], 2, 0),
+                                                 ("shmip_dist.py", ["--case", "B3", "--scale", "1", "--steps", "6", "--check"], 4, 3000),
+                                                 ("amr_shmip_dist.py", ["--case", "B5", "--steps", "6", "--check"], 2, 100000),
+                                                 ("hier_dist.py", ["--base", "256", "--steps", "2", "--check"], 2, 10000)])
+def test_rank_strips_as_processes(tool, args, world, agg):
     """cfg4: SHMIP B5 (100 moulins, diffusion, implicit gap-height solve) on a 3-level AMR hierarchy cut into the strips of 2
     processes, B3 single-level on 4 processes, and cfg5 (base 256^2 + 3 levels of ~65 boxes each, 63 moulins) with level 0 cut into
     the strips of 2 processes and the boxes on both (gloo, all ranks on the one GPU of the test box): every level's head, gap
@@ -72,7 +75,7 @@ def test_rank_strips_as_processes(tool, args, world):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   SUHMO_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+                   SUHMO_DIST_BACKEND="gloo", OMP_NUM_THREADS="1", SUHMO_AGG_MIN_CELLS=str(agg))    # agg > 0: coarse depths agglomerated (all-gather over gloo)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", tool)] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:

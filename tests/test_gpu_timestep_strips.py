@@ -52,6 +52,10 @@ def run(world, nx, ny, st, bc, ph, m, nsteps, halo, mou=None, max_box=16):
             G.set_state(split_state(st, j0, nyl))
             ex = multigpu.StripExchanger(G.level, tr, rank, world, bool(bc["periodic"][1]))
             ex.exchange_static()
+            import os
+            from suhmo_amd import capi
+            da = capi.lib().suhmo_level_agglomerated_depth(G.level.h)
+            assert (da > 0) == (int(os.environ.get("SUHMO_AGG_MIN_CELLS", "0")) > 0), da      # the variant really runs what its name says
             integ = G.moulin_source(*mou) if mou else None
             counts = [G.timestep(m["dt"]) for _ in range(nsteps)]
             out = {k: G.get(k) for k in NAMES}
