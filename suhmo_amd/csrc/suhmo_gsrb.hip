@@ -369,7 +369,9 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st,
         int nch = slots_k[K] / g.nstrips;
         if (nch < 1) nch = 1;
         g.Hc = (nrows + nch - 1) / nch;
-        if (g.Hc < 16 * K) g.Hc = 16 * K;
+        // (not shorter than 8K rows: the 4K-row pipeline fill.  The one-round height itself is the optimum where it is allowed: 2048^2,
+        //  19 rows: 45.1 us per sweep, 24 rows 51.4, 32 rows -- two rounds, the old lower bound -- 60.3, profiles/r03_stream2048.txt)
+        if (g.Hc < 8 * K) g.Hc = 8 * K;
         // cache-resident depths (about 1 M cells) are latency-bound: many short chunks beat few long ones
         // (profiles/r01_k_sweep_small_hc.log: 1024^2, K = 2: 22.3 us per sweep at 6 rows vs 28.1 for the colour passes)
         if ((long)v.nx * v.ny < 2000000L) g.Hc = 6;

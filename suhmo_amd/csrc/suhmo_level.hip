@@ -150,7 +150,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     if (const char *e = getenv("SUHMO_FUSED_NT")) L->fused_nt = atoi(e);
     L->fused_restrict = 1;
     L->gsrb_tile = 1; L->tile_t = 0; L->tile_s = 4;
-    L->tile_max_cells = 8000000;
+    L->tile_max_cells = 3000000;     // 2048^2 (4.2 M cells) streams: 45 us per sweep at its one-round chunk height against 51 on tiles (profiles/r03_stream2048.txt)
     L->fas_rhs_in_relax = 1;
     L->tile_chunks = 1;
     L->tile_order = 2; L->tile_restrict = 0;
