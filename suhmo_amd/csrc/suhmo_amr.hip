@@ -359,6 +359,7 @@ extern "C" int suhmo_amr2_finer_operator_changed(suhmo_level_t *C, suhmo_level_t
     hipLaunchKernelGGL(k_amr_average_faces, dim3((vf.nx / 2 + 1 + 63) / 64, (vf.ny / 2 + 1 + 3) / 4), dim3(64, 4), 0, (hipStream_t)s, vf,
                        F->d[0].fp.f[SUHMO_F_BX], F->d[0].fp.f[SUHMO_F_BY], vc, C->d[0].fp.f[SUHMO_F_BX], C->d[0].fp.f[SUHMO_F_BY]);
     HIPCHK(hipGetLastError());
+    C->coarse_mask_ok = 0;
     suhmo_level_drop_graphs(C);
     return 0;
 }

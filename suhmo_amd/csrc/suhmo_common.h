@@ -182,6 +182,8 @@ struct suhmo_level {
     int skip_mask;              // the streaming relaxation skips the ice-mask array in a V-cycle whose UpdateOperator found no negative cell
                                 // (env SUHMO_SKIP_MASK, default 1)
     int mask_reported;          // the last suhmo_level_update_operator(depth 0) made that report
+    int coarse_mask_ok;         // the ice masks of the depths > 0 are MGnewOp's averages of depth 0's current one (suhmo_build_mg_coefficients; any
+                                // write to the field clears it): the report about depth 0 then covers them (an average of non-negative cells)
     unsigned mask_epoch, maskflag_epoch;   // number of the last k_bcoef_fused call on depth 0; the call whose report is current (0: none)
     int overlap_halo;           // rank strips, streaming kernel: the halo exchange travels on a second stream while the chunks that do not
                                 // read halo rows relax; the two end chunks follow (env SUHMO_OVERLAP_HALO; 1 = default: with the native, stream-ordered
@@ -189,7 +191,7 @@ struct suhmo_level {
     hipStream_t xstream; hipEvent_t xev[2]; long overlapped;   // ... its stream and events; launches that overlapped so far
     int tile_strips;            // tile kernel on rank strips (env SUHMO_TILE_STRIPS, default 1)
     int tile_chunks;            // a level that is one tile relaxes all its sweeps in one launch (env SUHMO_TILE_CHUNKS, default 1)
-    int fas_rhs_in_relax;       // coarse FAS right-hand side formed by the first tile relax of the depth (env SUHMO_FAS_RHS_IN_RELAX, default 1)
+    int fas_rhs_in_relax;       // coarse FAS right-hand side formed by the first relax of the depth: bit 0 in the tile kernel, bit 1 in the streaming kernel (env SUHMO_FAS_RHS_IN_RELAX, default 3)
     long tile_max_cells;        // auto mode: levels below this many cells relax on the tile kernel (env SUHMO_TILE_MAX_CELLS)
     int tile_restrict;          // the tile kernel's last pre-smoothing launch also restricts: 0 never (a separate kernel restricts: faster on one GPU and
                                 // on a rank strip alike, profiles/r02_h_tile_restrict_ab.txt), 1 always, 2 on rank strips only (env SUHMO_TILE_RESTRICT, default 0)

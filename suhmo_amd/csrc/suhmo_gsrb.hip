@@ -122,6 +122,9 @@ struct FusedGeom {
     const double *pc, *pco; int Pc, gyc;
     // RST: restrictResidual + restrictR fused into the launch that finishes the pre-smoothing: coarse RES / PHI canvases
     double *rres, *rphi; int rP, rgy;
+    // FRHS: the first relaxation of a coarse FAS depth forms the depth's right-hand side rhs = res + L(R phi) itself (k_apply<., 2>'s
+    // expressions on the rows as they are loaded) and stores it, L(phi) and the copy of R phi the prolongation subtracts later
+    const double *fres; double *frhs, *flphi, *fphiold;
 };
 
 struct RowCoef {          // per-thread coefficients of its column pair in one row
@@ -143,10 +146,11 @@ __device__ __forceinline__ void copy_coef(RowCoef &d, const RowCoef &s)
 // visiting order, into the coarse cell of the thread's column pair (RESTRICTRESVCNL2D + RESTRICTVCNL, VCAMR...OpF.ChF:480-561,
 // 419-449): the separate pass over phi and the 8 coefficient arrays (75 B/cell) disappears.  Costs: one more ring row, one
 // more coefficient row, one more final row above and below the chunk and two more halo columns per side.
-template <int K, bool HAS_ALPHA, int NT, bool RST = false>
+template <int K, bool HAS_ALPHA, int NT, bool RST = false, bool FRHS = false>
 __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__restrict__ pin,
                                                    double *__restrict__ pout, suhmo_phys_t ph, FusedGeom g)
 {
+    static_assert(!(FRHS && (RST || HAS_ALPHA)), "the right-hand side is formed in the plain launch of an alpha = 0 operator");
     constexpr int LW = 2 * NT, R = 2 * K + 3 + (RST ? 1 : 0);
     constexpr int HX = 2 * K + (RST ? 2 : 0), EY = RST ? 1 : 0;
     __shared__ double lds[R * LW];
@@ -190,6 +194,7 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
     const bool xbc = !v.per[0] && (c0 - HX <= 0 || c0 + g.W + HX >= v.nx);
     const bool ybc = !v.per[1] && (jmin <= 0 || jmax >= v.ny - 1);
     double2 pnext = make_double2(0.0, 0.0);
+    double2 pprev = make_double2(0.0, 0.0);    // FRHS: this thread's pair of the row below the one whose L(phi) is formed, as loaded
     // the mask array is 8 of the 80 bytes a cell costs per launch and only its sign is used: when this V-cycle's UpdateOperator saw
     // no negative cell the loads are skipped (uniform)
     const bool usemask = !g.negflag || *g.negflag == g.mask_epoch;
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
         if (lcf) {
             int idx = cidx(v, im, wrapj(r));
 #define LD2(dst, p, ix) { double2 t_ = ld2(p, ix); dst[0] = t_.x; dst[1] = t_.y; }
-            LD2(cf0.rhs, f_rhs, idx); LD2(cf0.B, f_B, idx); LD2(cf0.Pi, f_Pi, idx);
+            LD2(cf0.rhs, (FRHS ? g.fres : f_rhs), idx); LD2(cf0.B, f_B, idx); LD2(cf0.Pi, f_Pi, idx);
             LD2(cf0.zb, f_zb, idx);
             if (usemask) { LD2(cf0.mask, f_mask, idx); } else { cf0.mask[0] = 1.0; cf0.mask[1] = 1.0; }
             if (HAS_ALPHA) LD2(cf0.a, f_a, idx);
@@ -220,6 +225,46 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
             cf0.bx0 = bxp.x; cf0.bx1 = bxp.y; cf0.bx2 = f_bx[idx + 2];
         }
         __syncthreads();                   // row r (written at the end of step r-1) is visible
+
+        // ---- 1b. FRHS: rows r-2 (this thread's own pair, kept in pprev), r-1 and r are still as loaded: L(phi) of row r-1, its
+        // right-hand side (used by the half-sweeps below: cf1 IS row r-1), and the three stores of k_apply<., 2> for the chunk's rows
+        if constexpr (FRHS) {
+            const int jf = r - 1;
+            if (cval && jf >= jmin && jf <= jmax) {
+                const int s0 = (sr - 1 + 2 * R) % R, sN = (s0 + 1) % R;
+                const double *row = lds + s0 * LW;
+                double lo[2], cc[2];
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    const int x = xl + a, i = im + a;
+                    double c = row[x];
+                    double w = row[(a == 0 && xl == 0) ? 0 : x - 1], e = row[(a == 1 && xl == LW - 2) ? LW - 1 : x + 1];
+                    double n = lds[sN * LW + x], s = a ? pprev.y : pprev.x;
+                    if (xbc) {
+                        if (i == 0) w = (v.bct[0][0] == 0) ? v.two_v[0][0] - c : c + v.neu[0][0];
+                        if (i == v.nx - 1) e = (v.bct[0][1] == 0) ? v.two_v[0][1] - c : c + v.neu[0][1];
+                    }
+                    if (ybc) {
+                        if (jf == 0 && !v.ext[0]) s = (v.bct[1][0] == 0) ? v.two_v[1][0] - c : c + v.neu[1][0];
+                        if (jf == v.ny - 1 && !v.ext[1]) n = (v.bct[1][1] == 0) ? v.two_v[1][1] - c : c + v.neu[1][1];
+                    }
+                    double nl, dnl;
+                    nl_terms(ph, c, cf1.B[a], cf1.Pi[a], cf1.zb[a], cf1.mask[a], nl, dnl);
+                    const double bxW = a ? cf1.bx1 : cf1.bx0, bxE = a ? cf1.bx2 : cf1.bx1;
+                    lo[a] = lofphi_cell(v, v.alpha, c, e, w, n, s, bxE, bxW, cf1.byN[a], cf1.byS[a], nl);
+                    cc[a] = c;
+                }
+                cf1.rhs[0] = 1.0 * cf1.rhs[0] + 1.0 * lo[0]; cf1.rhs[1] = 1.0 * cf1.rhs[1] + 1.0 * lo[1];
+                if (own && jf >= jA && jf < jB) {
+                    const int idx = cidx(v, i0, jf);
+                    *reinterpret_cast<double2 *>(g.flphi + idx) = make_double2(lo[0], lo[1]);
+                    *reinterpret_cast<double2 *>(g.frhs + idx) = make_double2(cf1.rhs[0], cf1.rhs[1]);
+                    *reinterpret_cast<double2 *>(g.fphiold + idx) = make_double2(cc[0], cc[1]);
+                }
+                pprev = make_double2(cc[0], cc[1]);            // row r-1 as loaded: the south neighbours of row r in the next step
+            }
+            __syncthreads();                                   // the half-sweep below overwrites cells of row r-1 that the neighbours read above
+        }
 
         // ---- 2. advance row r-m from half-sweep m-1 to m, m = 1..2K
         // One half-sweep of row r-m.  The colour offset `a` (which cell of the pair is updated)
@@ -405,7 +450,10 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st,
         if (part != 1) D.prolong_pending = 0;
     }
     g.negflag = nullptr; g.mask_epoch = 0;
-    if (depth == 0 && L->skip_mask && L->maskflag_epoch && L->maskflag_epoch == L->mask_epoch && !(v.ext[0] || v.ext[1])) {
+    // (the report is about depth 0's mask and, on a rank strip, the stored halo rows of every depth; the coarse masks are averages of
+    //  depth 0's, MGnewOp: none of them is negative either -- as long as nobody has written one since, coarse_mask_ok)
+    if (L->skip_mask && L->maskflag_epoch && L->maskflag_epoch == L->mask_epoch && (depth == 0 || L->coarse_mask_ok)
+        && (L->desc.nx_global == 0)) {
         g.negflag = (const unsigned *)(L->scratch + L->scratch_elems - 1); g.mask_epoch = L->mask_epoch;
     }
     g.rres = g.rphi = nullptr; g.rP = g.rgy = 0;
@@ -413,6 +461,18 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st,
         Depth &C = L->d[depth + 1];
         g.rres = C.fp.f[SUHMO_F_RES]; g.rphi = C.fp.f[SUHMO_F_PHI]; g.rP = C.v.P; g.rgy = C.v.gy;
         C.phi_fresh = 0;
+    }
+    g.fres = nullptr; g.frhs = g.flphi = g.fphiold = nullptr;
+    if (D.rhs_pending) {
+        // (suhmo_gsrb_can_fuse_rhs said yes for exactly this launch: whole level, two sweeps, one-wave workgroups, alpha = 0)
+        if constexpr (K == 2 && NT == 64 && !RST) {
+            if (part || v.alpha != 0.0 || v.ext[0] || v.ext[1]) { suhmo_set_error("internal: rhs_pending on a launch that cannot form it"); return -4; }
+            g.fres = D.fp.f[SUHMO_F_RES]; g.frhs = D.fp.f[SUHMO_F_RHS]; g.flphi = D.fp.f[SUHMO_F_LPHI]; g.fphiold = D.fp.f[SUHMO_F_PHIOLD];
+            D.rhs_pending = 0;
+            hipLaunchKernelGGL((k_gsrb_fused<2, false, 64, false, true>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+            std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
+            return 0;
+        } else { suhmo_set_error("internal: rhs_pending on a launch that cannot form it"); return -4; }
     }
     if (v.alpha != 0.0)
         hipLaunchKernelGGL((k_gsrb_fused<K, true, NT, false>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
@@ -948,13 +1008,19 @@ static int prolong_halo_rows(const suhmo_level *L, int depth)
     int R = D.phi_fresh < 2 * C.phi_fresh ? D.phi_fresh : 2 * C.phi_fresh;
     return R & ~1;
 }
-// the first relaxation of a coarse FAS depth can form its right-hand side itself (tile kernel only)
+// the first relaxation of a coarse FAS depth can form its right-hand side itself
 bool suhmo_gsrb_can_fuse_rhs(suhmo_level *L, int depth, int sweeps)
 {
     Depth &D = L->d[depth];
     if (sweeps < 1 || !L->fas_rhs_in_relax) return false;
     if (D.v.rk[0] || D.v.rk[1]) return false;                 // rank strips: k_apply<., 2> also copies the halo rows of R phi
-    return pick_K(L, D, pick_variant(L, D), sweeps) <= 0 && tile_ok(L, D);
+    const int K = pick_K(L, D, pick_variant(L, D), sweeps);
+    if (K <= 0) return (L->fas_rhs_in_relax & 1) && tile_ok(L, D);
+    // streaming kernel: the two-sweep launch of one-wave workgroups on a whole level (k_gsrb_fused<2, false, 64, false, true>);
+    // with only two sweeps to do that launch is the one that restricts
+    if (!(L->fas_rhs_in_relax & 2)) return false;
+    const int nt = L->fused_nt ? L->fused_nt : ((long)D.v.nx * D.v.ny >= 8000000L ? 256 : 64);
+    return K == 2 && nt == 64 && sweeps >= 4 && D.v.alpha == 0.0 && !(D.v.ext[0] || D.v.ext[1]);
 }
 bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps)
 {

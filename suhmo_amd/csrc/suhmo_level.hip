@@ -151,7 +151,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     L->fused_restrict = 1;
     L->gsrb_tile = 1; L->tile_t = 0; L->tile_s = 4;
     L->tile_max_cells = 3000000;     // 2048^2 (4.2 M cells) streams: 45 us per sweep at its one-round chunk height against 51 on tiles (profiles/r03_stream2048.txt)
-    L->fas_rhs_in_relax = 1;
+    L->fas_rhs_in_relax = 3;
     L->tile_chunks = 1;
     L->tile_order = 2; L->tile_restrict = 0;
     L->tile_strips = 1;
@@ -230,7 +230,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     L->scratch_elems = 16384;
     HIPCHK(hipMalloc(&L->scratch, L->scratch_elems * sizeof(double)));
     HIPCHK(hipMemset(L->scratch, 0, L->scratch_elems * sizeof(double)));                   // (its last word: the negative-mask report of k_bcoef_fused)
-    L->mask_epoch = 0; L->maskflag_epoch = 0; L->mask_reported = 0; L->skip_mask = 1;
+    L->mask_epoch = 0; L->maskflag_epoch = 0; L->mask_reported = 0; L->skip_mask = 1; L->coarse_mask_ok = 0;
     if (const char *e = getenv("SUHMO_SKIP_MASK")) L->skip_mask = atoi(e);
     HIPCHK(hipHostMalloc(&L->hscratch, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     memset(L->hscratch, 0, 64 * sizeof(double));
@@ -443,6 +443,7 @@ extern "C" int suhmo_level_set_field(suhmo_level_t *L, int depth, int field, con
     CHECK_DF(L, depth, field); ARG(src);
     HIPCHK(hipSetDevice(L->device));
     if (field == SUHMO_F_PHI) phi_changed(L, depth);
+    if (field == SUHMO_F_MASK) L->coarse_mask_ok = 0;
     return field_io(L, depth, field, (double *)src, ghosted, on_device, true, (hipStream_t)s);
 }
 extern "C" int suhmo_level_get_field(suhmo_level_t *L, int depth, int field, double *dst, int ghosted,
@@ -472,6 +473,7 @@ extern "C" int suhmo_level_put_box(suhmo_level_t *L, int depth, int field, int i
     hipStream_t st = (hipStream_t)s;
     const DV &v = L->d[depth].v;
     if (field == SUHMO_F_PHI) phi_changed(L, depth);
+    if (field == SUHMO_F_MASK) L->coarse_mask_ok = 0;
     int r[4]; box_region(L, depth, field, ibox, r);
     int j0 = v.j0;                         // fab indices are global: local j = global j - j0
     flo0 -= v.i0; fhi0 -= v.i0;            // ... and local i = global i - i0 (AMR patch)
@@ -1239,6 +1241,23 @@ __device__ __forceinline__ void bcoef_tile(const DV &v, const FP &fp, const suhm
         }
     }
 }
+// rank strip: the relaxation also reads the ice mask of its halo rows (the neighbours' cells, on every depth that streams); k_bcoef_fused
+// reports on the strip's own cells, this one on the stored halo rows of the depths [0, nd)
+struct MaskHalo { const double *m[SUHMO_MAXDEPTH]; int nx[SUHMO_MAXDEPTH], ny[SUHMO_MAXDEPTH], P[SUHMO_MAXDEPTH], gy[SUHMO_MAXDEPTH]; int nd, lo, hi; };
+__global__ __launch_bounds__(256) void k_mask_halo_report(MaskHalo h, unsigned *negflag, unsigned epoch)
+{
+    const int d = blockIdx.z, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= h.nd || i >= h.nx[d]) return;
+    const int g = h.gy[d];
+    bool neg = false;
+    for (int r = blockIdx.y; r < 2 * g; r += gridDim.y) {
+        const bool top = r >= g;
+        if (top ? !h.hi : !h.lo) continue;
+        const int j = top ? h.ny[d] + (r - g) : -1 - r;
+        neg = neg || h.m[d][(long)(j + g) * h.P[d] + SUHMO_XOFF + i] < 0.0;
+    }
+    if (neg) *negflag = epoch;
+}
 __global__ __launch_bounds__(256) void k_bcoef_fused(DV v, FP fp, suhmo_phys_t ph, int hasMask, unsigned *negflag, unsigned epoch)
 {
     __shared__ double sphi[(BT_X + 4) * (BT_Y + 4)], sB[(BT_X + 2) * (BT_Y + 2)], sM[(BT_X + 2) * (BT_Y + 2)];
@@ -1266,12 +1285,25 @@ extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_st
         // (the V-cycle that called takes the report up, suhmo_fas.hip: it holds until that cycle ends, not across calls of this entry point)
         unsigned *flag = nullptr;
         if (depth == 0) { L->maskflag_epoch = 0; L->mask_reported = 0; }
-        if (depth == 0 && L->skip_mask && !(D.v.ext[0] || D.v.ext[1])) {
+        if (depth == 0 && L->skip_mask) {
             flag = (unsigned *)(L->scratch + L->scratch_elems - 1);
             if (++L->mask_epoch == 0) L->mask_epoch = 1;
             L->mask_reported = 1;
         }
         hipLaunchKernelGGL(k_bcoef_fused, grd, dim3(64, 4), 0, st, D.v, D.fp, L->ph, L->ph.use_mask_gradients, flag, L->mask_epoch);
+        if (flag && (D.v.ext[0] || D.v.ext[1])) {
+            MaskHalo h;
+            h.nd = 0; h.lo = D.v.ext[0]; h.hi = D.v.ext[1];
+            const int last = L->coarse_mask_ok ? (L->agg ? L->agg_depth : L->ndepth) : 1;      // (agglomerated depths keep no halo rows)
+            int gmax = 1;
+            for (int k = 0; k < last && k < SUHMO_MAXDEPTH; k++) {
+                const Depth &Dk = L->d[k];
+                h.m[k] = Dk.fp.f[SUHMO_F_MASK]; h.nx[k] = Dk.v.nx; h.ny[k] = Dk.v.ny; h.P[k] = Dk.v.P; h.gy[k] = Dk.v.gy;
+                if (Dk.v.gy > gmax) gmax = Dk.v.gy;
+                h.nd = k + 1;
+            }
+            hipLaunchKernelGGL(k_mask_halo_report, dim3((D.v.nx + 255) / 256, 2 * gmax, h.nd), dim3(256), 0, st, h, flag, L->mask_epoch);
+        }
     } else {
         if (depth == 0) { L->maskflag_epoch = 0; L->mask_reported = 0; }
         if (!suhmo_field(L, depth, SUHMO_F_GRADX) || !suhmo_field(L, depth, SUHMO_F_GRADY) || !suhmo_field(L, depth, SUHMO_F_RE)) return -2;
@@ -1617,6 +1649,7 @@ int suhmo_build_mg_coefficients(suhmo_level *L, bool with_faces, hipStream_t st)
         if (L->agg && dep >= L->agg_depth) continue;                  // agglomerated depths: no halo rows, the whole rows travel below
         rc = exchange_fields(L, dep, {SUHMO_F_ACOEF, SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB, SUHMO_F_MASK}, st); if (rc) return rc;
     }
+    L->coarse_mask_ok = 1;
     return suhmo_agg_gather_static(L, with_faces, st);
 }
 extern "C" int suhmo_level_build_mg_coefficients(suhmo_level_t *L, suhmo_stream_t s)

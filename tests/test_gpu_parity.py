@@ -226,15 +226,17 @@ FUSED_VCYCLE_CASES = [
 
 
 @pytest.mark.parametrize("case", FUSED_VCYCLE_CASES, ids=[c[0] for c in FUSED_VCYCLE_CASES])
-@pytest.mark.parametrize("fused_restrict", [1, 0])
+@pytest.mark.parametrize("fused_restrict,rhs_in_relax", [(1, 3), (0, 3), (1, 0)], ids=["restrict+rhs", "rhs", "restrict"])
 @pytest.mark.parametrize("hc", [0, 6, 10])
-def test_vcycle_on_fused_kernels(oracle, hip, case, fused_restrict, hc, monkeypatch):
+def test_vcycle_on_fused_kernels(oracle, hip, case, fused_restrict, rhs_in_relax, hc, monkeypatch):
     """every depth on the streaming kernel (SUHMO_FUSED_MIN_CELLS = 1), with the restriction fused into the launch that
-    ends the pre-smoothing and with the separate restriction kernel: both bitwise equal to the oracle's V-cycle; chunk
-    heights 6 / 10 / automatic move the coarse cells' row pairs relative to the chunk boundaries"""
+    ends the pre-smoothing and with the separate restriction kernel, the FAS right-hand side of a coarse depth formed by the
+    first launch of its pre-smoothing or by its own kernel: all bitwise equal to the oracle's V-cycle; chunk heights
+    6 / 10 / automatic move the coarse cells' row pairs relative to the chunk boundaries"""
     monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "1")
     monkeypatch.setenv("SUHMO_GSRB_TILE", "0")
     monkeypatch.setenv("SUHMO_FUSED_RESTRICT", str(fused_restrict))
+    monkeypatch.setenv("SUHMO_FAS_RHS_IN_RELAX", str(rhs_in_relax))
     monkeypatch.setenv("SUHMO_FUSED_HC", str(hc))
     _, mk, bc, ph, alpha, beta, mb = case
     f = mk()
@@ -247,6 +249,9 @@ def test_vcycle_on_fused_kernels(oracle, hip, case, fused_restrict, hc, monkeypa
         assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI)), (k, float(np.max(np.abs(G.get(hip.F_PHI) - O.get(oracle.F_PHI)))))
     for d in range(1, G.ndepth):
         assert np.array_equal(G.get(hip.F_RES, depth=d), O.get(oracle.F_RES, depth=d)), ("coarse residual", d)
+        assert np.array_equal(G.get(hip.F_RHS, depth=d), O.get(oracle.F_RHS, depth=d)), ("coarse right-hand side", d)
+        assert np.array_equal(G.get(hip.F_PHIOLD, depth=d), O.get(oracle.F_PHIOLD, depth=d)), ("R phi kept for the prolongation", d)
+        assert np.array_equal(G.get(hip.F_PHI, depth=d), O.get(oracle.F_PHI, depth=d)), ("coarse phi", d)
     no, ho = O.solve(sp)
     ng, hg = G.solve(sp)
     assert ng == no and np.array_equal(hg, ho)

@@ -155,6 +155,42 @@ def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
     assert np.array_equal(np.vstack([p[1] for p in parts]), O.get(oracle.F_PHI))
 
 
+@pytest.mark.parametrize("where", ["none", "first-rows-of-rank-1", "inside-rank-1", "last-rows-of-rank-0"])
+@pytest.mark.parametrize("world", [2, 4])
+def test_strips_mask_report_covers_the_halo_rows(world, where, oracle, monkeypatch):
+    """a strip's streaming relaxation skips the ice-mask array when UpdateOperator's report found no negative cell among the strip's
+    own cells AND its stored halo rows on every depth (the neighbours' cells it reads): ice-free cells that sit only in a halo,
+    only deep inside another rank, or nowhere -- all bitwise the oracle's whole level"""
+    from suhmo_amd import level as lv
+    monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "4000")
+    monkeypatch.setenv("SUHMO_GSRB_TILE", "0")
+    f = sy.shmip_fields(256, 256)
+    f.pop("bx", None); f.pop("by", None)
+    ny = 256 // world
+    m = f["mask"]                                           # ghosted: row r of the array is cell row r - 1
+    if where == "first-rows-of-rank-1":
+        m[1 + ny:1 + ny + 2, 40:90] = -1.0
+    elif where == "inside-rank-1":
+        m[1 + ny + ny // 2:1 + ny + ny // 2 + 3, 100:180] = -1.0
+    elif where == "last-rows-of-rank-0":
+        m[1 + ny - 3:1 + ny, 10:200] = -1.0
+    bc, ph = sy.A3_BC, sy.A3_PHYS
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-10, norm_thresh=1e-13, max_iter=3, imin=3)
+
+    def body(G, rank):
+        G.build_mg_coefficients()
+        G.vcycle(sp); G.vcycle(sp)
+        return G.get(lv.F_PHI), G.get_option("skip_mask")
+
+    parts = run_strips(world, f, bc, ph, 0.0, -1.0, body, halo=16, max_box=64)
+    assert all(p[1] == 1 for p in parts)
+    O = oracle.OracleLevel(256, 256, f["dx"], f["dy"], bc, ph, 0.0, -1.0, 64, 4)
+    O.set_inputs(f)
+    O.build_mg_coefficients()
+    O.vcycle(sp); O.vcycle(sp)
+    assert np.array_equal(np.vstack([p[0] for p in parts]), O.get(oracle.F_PHI))
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_strips_l2_norm_and_dot_product(world):
     """norm(ord 2) and dotProduct reduce with a SUM over the ranks (src/AMRNonLinearPoissonOp.cpp:660-666, 519-551, 1222-1264): on 2 / 4
