@@ -403,7 +403,15 @@ int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *base, int nl
  * a cycle over the whole of level 0 (default 1: inside suhmo_hier_solve the residual evaluated for the stopping rule serves the next
  * cycle except in the cells the average from level 1 changed, and level 0's gradient is evaluated only where level 1's coarse-fine
  * interpolation reads it -- the same bits, two passes over level 0 less per cycle).  push_ghosts and incremental_residual can also
- * be changed later (suhmo_hier_set_option). */
+ * be changed later (suhmo_hier_set_option).
+ * partition_min_cells = n (rank strips; default 500000): a finer level with at least n cells PER RANK is dealt to the ranks, boxes in
+ * the order given cut into runs of about equal cell counts (the reference: LoadBalance(procIDs, grids), src/AmrHydro.cpp:4283, 4929).
+ * Owner computes: the colour passes, the operator and the residual of such a level run on the owner's boxes only, and the canvases
+ * they wrote travel to the other ranks' replicas in one all-gather per pass (the reference's own pattern: exchange() before every
+ * colour pass, src/VCAMRNonLinearPoissonOp.cpp:692); the light passes (coefficients, axby, copies, the plans between levels) stay
+ * replicated.  Below the threshold a pass over the level is shorter than the message, so every rank relaxes all boxes.  The same
+ * bits either way.  Read-only through suhmo_hier_get_option: partitioned_level_<l> (0 / 1), own_boxes_level_<l> (boxes of level l
+ * this rank relaxes), partition_gathers (all-gathers of canvases so far). */
 int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc_t *base, int nlev, const int *nbox, const int *boxes, const char *options);
 int suhmo_hier_set_option(suhmo_hier_t *H, const char *key, long value);
 int suhmo_hier_get_option(const suhmo_hier_t *H, const char *key, long *value);

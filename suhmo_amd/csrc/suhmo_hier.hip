@@ -101,6 +101,7 @@ struct BoxIndex {
     }
 };
 
+struct PartEnt { long off; int elems, owner; };
 struct HLev {
     int l = 0, nxd = 0, nyd = 0;
     std::vector<suhmo_level *> box;
@@ -121,6 +122,13 @@ struct HLev {
     // field pointer / view tables of the boxes
     std::vector<FP> h_fp; FP *d_fp = nullptr; DV *d_dv = nullptr;
     double *d_red = nullptr; int maxnx = 0, maxny = 0;            // reduction scratch (64 nbox + 16 doubles), largest box
+    // ---- owner computes (rank strips, option partition_min_cells): boxes own[r] .. own[r+1] belong to rank r.  The passes that carry the
+    // level's arithmetic (colour passes, operator / residual) run on the owner's boxes only; the canvases they wrote then travel to the
+    // other ranks' replicas in one all-gather (segment of rank r = the canvases of its boxes, one after the other: pent[k].off)
+    bool part = false;
+    std::vector<int> own;
+    DevVec<PartEnt> pent; long part_max = 0; int part_maxelems = 0;
+    double *ps = nullptr, *pr = nullptr;
 };
 }  // namespace
 
@@ -158,6 +166,9 @@ struct suhmo_hier {
     // pass through the level-0 V-cycle or an entry point of the C-ABI)
     unsigned long base_full_ver = 1, base_res_seen = 0;
     bool incremental = true;                               // option incremental_residual
+    long part_min_cells = 500000;                          // creation option partition_min_cells: a level of boxes with at least this many cells
+                                                           // PER RANK is relaxed by its owners (below it a pass is shorter than the message)
+    long part_gathers = 0;
     DevVec<RectEnt> cover_full;                            // coarsen(boxes of level 1) in the shadow: COVER of the whole level 0
 };
 
@@ -881,6 +892,95 @@ int hier_reflux(suhmo_hier *H, int l, int field_c, hipStream_t st, int residual 
 
 // ------------------------------------------------------------------ operator methods of a level
 // relax: levelGSRB x sweeps (src/VCAMRNonLinearPoissonOp.cpp:654-760): per colour pass exchange, then the pass on every box
+// ---- owner computes: canvases of the fields f0 (and f1) of the boxes [b0, b0 + gridDim.z) -> this rank's segment; every other rank's
+// segment -> the replicas of its boxes
+__global__ void k_part_pack(const PartEnt *__restrict__ e, int b0, const FP *__restrict__ tab, int f0, int f1, double *__restrict__ send, long stride)
+{
+    const int k = b0 + blockIdx.z;
+    const PartEnt q = e[k];
+    const double *__restrict__ a = tab[k].f[f0];
+    const double *__restrict__ b = f1 >= 0 ? tab[k].f[f1] : nullptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < q.elems; i += gridDim.x * blockDim.x) {
+        send[q.off + i] = a[i];
+        if (b) send[stride + q.off + i] = b[i];
+    }
+}
+__global__ void k_part_unpack(const PartEnt *__restrict__ e, int rank, const FP *__restrict__ tab, int f0, int f1, const double *__restrict__ recv, long stride, long rstride)
+{
+    const int k = blockIdx.z;
+    const PartEnt q = e[k];
+    if (q.owner == rank) return;
+    const double *__restrict__ src = recv + (long)q.owner * rstride + q.off;
+    double *__restrict__ a = tab[k].f[f0];
+    double *__restrict__ b = f1 >= 0 ? tab[k].f[f1] : nullptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < q.elems; i += gridDim.x * blockDim.x) {
+        a[i] = src[i];
+        if (b) b[i] = src[stride + i];
+    }
+}
+// the boxes of this rank as a table of their own (the kernels index the tables by blockIdx.z)
+inline bool part_mine(const suhmo_hier *H, const HLev &V, const suhmo_multi &m, suhmo_multi &mine)
+{
+    const int b0 = V.own[H->rank], n = V.own[H->rank + 1] - b0;
+    mine = m;
+    mine.dv = m.dv + b0; mine.fp = m.fp + b0; mine.nbox = n;
+    if (m.pbase) mine.pbase = m.pbase + b0;
+    return n > 0;
+}
+// what the owners wrote into the fields f0 (, f1) of level l -> every rank's replica (collective)
+int part_share(suhmo_hier *H, int l, int f0, int f1, hipStream_t st)
+{
+    HLev &V = H->lev[l];
+    SUHMO_TIME("hier: all-gather of the boxes' canvases (owner computes)");
+    if (!H->ag) { suhmo_set_error("hier: level %d is partitioned over the ranks and no all-gather is attached (suhmo_hier_attach_rccl / suhmo_hier_set_allgather)", l); return -1; }
+    const int nf = f1 >= 0 ? 2 : 1;
+    if (!V.ps) {
+        HIPCHK(hipMalloc(&V.ps, (size_t)std::max<long>(1, 2 * V.part_max) * sizeof(double)));
+        HIPCHK(hipMalloc(&V.pr, (size_t)std::max<long>(1, 2 * V.part_max) * H->world * sizeof(double)));
+        HIPCHK(hipMemsetAsync(V.ps, 0, (size_t)std::max<long>(1, 2 * V.part_max) * sizeof(double), st));
+    }
+    const int b0 = V.own[H->rank], mine = V.own[H->rank + 1] - b0;
+    const int gx = std::max(1, std::min(64, (V.part_maxelems + 1023) / 1024));
+    if (mine) hipLaunchKernelGGL(k_part_pack, dim3(gx, 1, mine), dim3(256), 0, st, V.pent.d, b0, V.d_fp, f0, f1, V.ps, V.part_max);
+    HIPCHK(hipGetLastError());
+    int rc = H->ag(H->ag_user, V.ps, (long)nf * V.part_max, V.pr, (suhmo_stream_t)st);
+    if (rc) return rc;
+    H->part_gathers++;
+    hipLaunchKernelGGL(k_part_unpack, dim3(gx, 1, (unsigned)V.box.size()), dim3(256), 0, st, V.pent.d, H->rank, V.d_fp, f0, f1, V.pr, V.part_max, (long)nf * V.part_max);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// LoadBalance(procIDs, grids) (src/AmrHydro.cpp:4283, 4929): here the boxes in the order given, cut into `world` runs of about equal cell
+// counts (a box goes to the rank its middle cell falls to): deterministic, contiguous, the same on every rank
+int part_setup(suhmo_hier *H, int l)
+{
+    HLev &V = H->lev[l];
+    const int nb = (int)V.box.size(), W = H->world;
+    long total = 0;
+    for (int k = 0; k < nb; k++) { const int *b = &V.b4[4 * k]; total += (long)(b[2] - b[0] + 1) * (b[3] - b[1] + 1); }
+    V.part = W > 1 && total >= H->part_min_cells * W;
+    if (!V.part) return 0;
+    std::vector<PartEnt> e(nb);
+    std::vector<int> owner(nb);
+    std::vector<long> seg(W, 0);
+    long before = 0;
+    int prev = 0;
+    for (int k = 0; k < nb; k++) {
+        const int *b = &V.b4[4 * k];
+        const long c = (long)(b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+        const int r = std::max(prev, std::min(W - 1, (int)(((before + c / 2) * W) / total)));
+        owner[k] = prev = r;
+        e[k].owner = r; e[k].elems = (int)V.box[k]->d[0].elems; e[k].off = seg[r];
+        seg[r] += e[k].elems;
+        V.part_maxelems = std::max(V.part_maxelems, e[k].elems);
+        before += c;
+    }
+    V.own.assign(W + 1, nb);
+    for (int r = 0; r < W; r++) V.own[r] = (int)(std::lower_bound(owner.begin(), owner.end(), r) - owner.begin());
+    V.part_max = *std::max_element(seg.begin(), seg.end());
+    return V.pent.upload(e);
+}
+
 int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
 {
     SUHMO_TIME("AMRNonLinearPoissonOp::relaxNF");
@@ -891,14 +991,21 @@ int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
     // exchange() before every colour pass (:692, :751): once here (unless the side ghosts are current), then every pass pushes
     // its new side cells into the ghost cells they feed
     if (sweeps > 0 && (rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
+    // owner computes: a pass relaxes this rank's boxes, the canvases travel, the exchange launch refreshes every replica's ghosts (a
+    // pushed ghost value would sit in the neighbour's canvas, which its owner sends): the reference's own pattern, exchange() + pass
+    HLev &V = H->lev[l];
+    const bool push = H->push_ghosts && !V.part;
+    suhmo_multi mine = m;
+    const bool any = V.part ? part_mine(H, V, m, mine) : true;
     for (int it = 0; it < sweeps; it++)
         for (int pass = 0; pass < 2; pass++) {
-            if ((rc = suhmo_multi_colour_pass(m, phys_of(H, l), has_alpha(H, l), pass, HST(s), H->push_ghosts))) return rc;
+            if (any && (rc = suhmo_multi_colour_pass(mine, phys_of(H, l), has_alpha(H, l), pass, HST(s), push))) return rc;
+            if (V.part && (rc = part_share(H, l, SUHMO_F_PHI, -1, HST(s)))) return rc;
             H->phi_ver[l]++;
-            if (!H->push_ghosts && (rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
+            if (!push && (rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
         }
     if (sweeps > 0 && (rc = suhmo_multi_fill_ghosts(m, SUHMO_F_PHI, 1, HST(s)))) return rc;                        // :757-759
-    if (sweeps > 0 && H->push_ghosts) H->ff_seen[l] = H->phi_ver[l];          // every pass pushed its side cells: the ghosts are current
+    if (sweeps > 0 && push) H->ff_seen[l] = H->phi_ver[l];          // every pass pushed its side cells: the ghosts are current
     return 0;
 }
 int hier_level_residual(suhmo_hier *H, int l, suhmo_stream_t s)   // residualI: RES
@@ -907,7 +1014,11 @@ int hier_level_residual(suhmo_hier *H, int l, suhmo_stream_t s)   // residualI: 
     int rc;
     suhmo_multi m;
     if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s))) || (rc = multi_of(H, l, HST(s), m))) return rc;
-    return suhmo_multi_apply(m, phys_of(H, l), has_alpha(H, l), 1, HST(s));
+    HLev &V = H->lev[l];
+    if (!V.part) return suhmo_multi_apply(m, phys_of(H, l), has_alpha(H, l), 1, HST(s));
+    suhmo_multi mine;
+    if (part_mine(H, V, m, mine) && (rc = suhmo_multi_apply(mine, phys_of(H, l), has_alpha(H, l), 1, HST(s)))) return rc;
+    return part_share(H, l, SUHMO_F_RES, -1, HST(s));
 }
 int hier_axby(suhmo_hier *H, int l, int dst, int x, int y, double a, double b, suhmo_stream_t s)
 {
@@ -990,7 +1101,11 @@ int composite_residual(suhmo_hier *H, int l, suhmo_stream_t s, bool whole_level_
     } else {
         suhmo_multi m;
         if ((rc = hier_ff(H, l - 1, SUHMO_F_PHI, -1, false, HST(s))) || (rc = ensure_field(H, l - 1, SUHMO_F_LPHI)) || (rc = multi_of(H, l - 1, HST(s), m))) return rc;
-        rc = suhmo_multi_apply(m, phys_of(H, l - 1), has_alpha(H, l - 1), 3, HST(s));
+        HLev &Vc = H->lev[l - 1];
+        suhmo_multi mine;
+        if (!Vc.part) rc = suhmo_multi_apply(m, phys_of(H, l - 1), has_alpha(H, l - 1), 3, HST(s));
+        else if (!part_mine(H, Vc, m, mine) || !(rc = suhmo_multi_apply(mine, phys_of(H, l - 1), has_alpha(H, l - 1), 3, HST(s))))
+            rc = part_share(H, l - 1, SUHMO_F_LPHI, SUHMO_F_RES, HST(s));
     }
     if (rc) return rc;
     if ((rc = cf_phi(H, l, s))) return rc;
@@ -1061,6 +1176,9 @@ extern "C" int suhmo_hier_destroy(suhmo_hier_t *H)
         if (V.d_fp) (void)hipFree(V.d_fp);
         if (V.d_dv) (void)hipFree(V.d_dv);
         if (V.d_red) (void)hipFree(V.d_red);
+        V.pent.release();
+        if (V.ps) (void)hipFree(V.ps);
+        if (V.pr) (void)hipFree(V.pr);
     }
     delete H;
     return 0;
@@ -1095,6 +1213,7 @@ extern "C" int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc
     if (hier_opt(options, "shadow", 0) != 0) H->shadowed = true;          // an uncut level 0 read through the shadow path all the same (tests)
     H->push_ghosts = hier_opt(options, "push_ghosts", 1) != 0;
     H->incremental = hier_opt(options, "incremental_residual", 1) != 0;
+    H->part_min_cells = std::max(1L, hier_opt(options, "partition_min_cells", H->part_min_cells));
     H->nlev = nlev; H->device = base->device; H->bc = base->bc; H->base_desc = *base; H->base_desc.boxes = nullptr; H->base_desc.nbox = 0;
     if (options) H->options = options;
     suhmo_level *B = nullptr;
@@ -1171,6 +1290,7 @@ extern "C" int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc
     for (int l = 1; l < nlev; l++) {
         if ((rc = build_plans(H, l))) { suhmo_hier_destroy(H); return rc; }
         if ((rc = refresh_tables(H, l, nullptr))) { suhmo_hier_destroy(H); return rc; }
+        if ((rc = part_setup(H, l))) { suhmo_hier_destroy(H); return rc; }
     }
     // SUHMO_F_COVER: 1 under a finer level, 0 elsewhere
     for (int l = 0; l < nlev; l++) for (suhmo_level *L : H->lev[l].box) if ((rc = suhmo_level_set_value(L, 0, SUHMO_F_COVER, 0.0, nullptr))) { suhmo_hier_destroy(H); return rc; }
@@ -1277,6 +1397,16 @@ extern "C" int suhmo_hier_get_option(const suhmo_hier_t *H, const char *key, lon
     if (!strcmp(key, "push_ghosts")) { *value = H->push_ghosts; return 0; }
     if (!strcmp(key, "incremental_residual")) { *value = H->incremental; return 0; }
     if (!strcmp(key, "shadow")) { *value = H->shadowed; return 0; }
+    if (!strcmp(key, "partition_min_cells")) { *value = H->part_min_cells; return 0; }
+    if (!strcmp(key, "partition_gathers")) { *value = H->part_gathers + (H->gap ? H->gap->part_gathers : 0); return 0; }
+    if (!strncmp(key, "partitioned_level_", 18) || !strncmp(key, "own_boxes_level_", 16)) {      // e.g. own_boxes_level_2: boxes of level 2 this rank relaxes
+        const bool own = key[0] == 'o';
+        const int l = atoi(key + (own ? 16 : 18));
+        if (l < 0 || l >= H->nlev) { suhmo_set_error("no level %d", l); return -1; }
+        const HLev &V = H->lev[l];
+        *value = own ? (V.part ? V.own[H->rank + 1] - V.own[H->rank] : (long)V.box.size()) : (V.part ? 1 : 0);
+        return 0;
+    }
     suhmo_set_error("unknown hierarchy option '%s'", key);
     return -1;
 }

@@ -336,6 +336,13 @@ class HipHier:
     def gathers(self):
         return int(capi.lib().suhmo_hier_gathers(self.h))
 
+    def get_option(self, key):
+        v = C.c_long()
+        check(capi.lib().suhmo_hier_get_option(self.h, key.encode(), C.byref(v)))
+        return int(v.value)
+
+    def set_option(self, key, value): check(capi.lib().suhmo_hier_set_option(self.h, key.encode(), int(value)))
+
     def exchange(self, l, field, corners=False): check(capi.lib().suhmo_hier_exchange(self.h, l, field, int(corners), self.stream))
     def cf_interp(self, l, field_f=F_PHI, field_c=F_PHI): check(capi.lib().suhmo_hier_cf_interp(self.h, l, field_f, field_c, self.stream))
     def pwl_fill(self, l, field_f, field_c): check(capi.lib().suhmo_hier_pwl_fill(self.h, l, field_f, field_c, self.stream))

@@ -21,7 +21,7 @@ def strip_state(st, r0, ny):
     return {k: (v[r0:r0 + ny + 2] if isinstance(v, np.ndarray) else v) for k, v in st.items()}
 
 
-def run_strips(world, nx0, ny0, boxes, sts, m, nsteps, mou, mb, halo_rows=4):
+def run_strips(world, nx0, ny0, boxes, sts, m, nsteps, mou, mb, halo_rows=4, options=None):
     from suhmo_amd import level as lv, model, multigpu
     n0 = ny0 // world
     tr = multigpu.ThreadTransport(world)
@@ -30,7 +30,7 @@ def run_strips(world, nx0, ny0, boxes, sts, m, nsteps, mou, mb, halo_rows=4):
     def worker(rank):
         try:
             G = model.HipHierModel(nx0, n0, sts[0][0]["dx"], sts[0][0]["dy"], sy.A3_BC, sy.A3_PHYS, m, boxes, max_box=mb,
-                                   j0=rank * n0, ny_global=ny0, halo_rows=halo_rows)
+                                   j0=rank * n0, ny_global=ny0, halo_rows=halo_rows, options=options)
             G.set_state(0, 0, strip_state(sts[0][0], rank * n0, n0))
             for l in range(1, len(sts)):
                 for k, st in enumerate(sts[l]):
@@ -46,7 +46,8 @@ def run_strips(world, nx0, ny0, boxes, sts, m, nsteps, mou, mb, halo_rows=4):
             msrc = [[G.get(l, k, "msrc") for k in range(len(G.level[l]))] for l in range(len(sts))] if mou else None
             counts = [G.timestep(m["dt"]) for _ in range(nsteps)]
             res = [[{nm: G.get(l, k, nm) for nm in NAMES} for k in range(len(G.level[l]))] for l in range(len(sts))]
-            out[rank] = (counts, res, integ, msrc, ag.calls, G.hier.gathers())
+            part = [(G.hier.get_option("partitioned_level_%d" % l), G.hier.get_option("own_boxes_level_%d" % l)) for l in range(1, len(sts))]
+            out[rank] = (counts, res, integ, msrc, ag.calls, G.hier.gathers() + G.hier.get_option("partition_gathers"), part, G.hier.get_option("partition_gathers"))
             G.close()
         except Exception as e:  # pragma: no cover
             import traceback
@@ -66,9 +67,11 @@ CASES = [("union-2-ranks", 2, UNION, dict(), 2), ("union-4-ranks", 4, UNION, dic
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("agg", [0, 600], ids=["", "coarse-depths-agglomerated"])
+@pytest.mark.parametrize("agg,part", [(0, 0), (600, 0), (0, 1), (600, 1)], ids=["", "coarse-depths-agglomerated", "boxes-partitioned", "agglomerated+partitioned"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_hier_timestep_on_strips_bitwise(case, agg, monkeypatch):
+def test_hier_timestep_on_strips_bitwise(case, agg, part, monkeypatch):
+    """part: the boxes of every finer level are dealt to the ranks (creation option partition_min_cells = 1: owner computes the colour
+    passes, the operator and the residual of its boxes, the canvases travel by all-gather) -- the same bits as every rank relaxing all of them"""
     from suhmo_amd import model
     monkeypatch.setenv("SUHMO_AGG_MIN_CELLS", str(agg))      # > 0: the base strips' coarse multigrid depths run agglomerated (suhmo_agg.hip), also in the gap-height hierarchy
     name, world, boxes, mpo, nsteps = case
@@ -84,7 +87,13 @@ def test_hier_timestep_on_strips_bitwise(case, agg, monkeypatch):
     ref_counts = [A.timestep(m["dt"]) for _ in range(nsteps)]
     ref = [[{nm: A.get(l, k, nm) for nm in NAMES} for k in range(len(A.level[l]))] for l in range(len(sts))]
     A.close()
-    out = run_strips(world, nx0, ny0, boxes, sts, m, nsteps, mou, mb)
+    out = run_strips(world, nx0, ny0, boxes, sts, m, nsteps, mou, mb, options="partition_min_cells=1" if part else None)
+    for l in range(1, len(sts)):
+        flags = [out[r][6][l - 1][0] for r in range(world)]
+        owned = [out[r][6][l - 1][1] for r in range(world)]
+        assert flags == [part] * world, flags
+        assert sum(owned) == (len(sts[l]) if part else world * len(sts[l])), owned     # every box has exactly one owner / is relaxed everywhere
+    assert all((out[r][7] > 0) == bool(part) for r in range(world))
     for r in range(world):
         assert out[r][0] == ref_counts, (r, out[r][0], ref_counts)
         assert out[r][4] == out[r][5] > 0                        # every all-gather went through the hook

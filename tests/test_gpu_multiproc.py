@@ -62,12 +62,15 @@ def test_two_ranks_over_nccl_bitwise(tool, args):
                                                  ("hier_dist.py", ["--base", "256", "--steps", "2", "--check"], 2, 0),
                                                  ("shmip_dist.py", ["--case", "B3", "--scale", "1", "--steps", "6", "--check"], 4, 3000),
                                                  ("amr_shmip_dist.py", ["--case", "B5", "--steps", "6", "--check"], 2, 100000),
-                                                 ("hier_dist.py", ["--base", "256", "--steps", "2", "--check"], 2, 10000)])
+                                                 ("hier_dist.py", ["--base", "256", "--steps", "2", "--check"], 2, 10000),
+                                                 ("hier_dist.py", ["--base", "256", "--steps", "2", "--check", "--partition-min-cells", "1"], 2, 0),
+                                                 ("hier_dist.py", ["--base", "256", "--steps", "1", "--check", "--partition-min-cells", "1"], 4, 10000)])
 def test_rank_strips_as_processes(tool, args, world, agg):
     """cfg4: SHMIP B5 (100 moulins, diffusion, implicit gap-height solve) on a 3-level AMR hierarchy cut into the strips of 2
     processes, B3 single-level on 4 processes, and cfg5 (base 256^2 + 3 levels of ~65 boxes each, 63 moulins) with level 0 cut into
-    the strips of 2 processes and the boxes on both (gloo, all ranks on the one GPU of the test box): every level's head, gap
-    height and melt rate equal the single-process run bit for bit (the tool's --check)"""
+    the strips of 2 processes and the boxes on both, or (--partition-min-cells 1) dealt to their owners on 2 and 4 processes
+    (gloo, all ranks on the one GPU of the test box): every level's head, gap height and melt rate equal the single-process
+    run bit for bit (the tool's --check)"""
     import socket
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))

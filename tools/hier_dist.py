@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--partition-min-cells", type=int, default=0,
+                    help="> 0: hierarchy option partition_min_cells (levels of boxes with at least that many cells per rank are relaxed by their owners; "
+                         "default: the library's 500000, i.e. cfg5's small levels stay replicated)")
     a = ap.parse_args()
     for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29536")):
         os.environ.setdefault(k, v)
@@ -36,7 +39,8 @@ def main():
     boxes = sy.boxes_around(mo["positions"], nb, nb, a.levels, 1.0e5, 1.0e5)
     sts = sy.mountain_amrm_states(nb, nb, boxes)
     dx, dy = sts[0][0]["dx"], sts[0][0]["dy"]
-    H = model.HipHierModel(nb, n0, dx, dy, bc, ph, mm, boxes, max_box=MB, device=dev, j0=rank * n0, ny_global=nb, halo_rows=4 if world > 1 else 1)
+    H = model.HipHierModel(nb, n0, dx, dy, bc, ph, mm, boxes, max_box=MB, device=dev, j0=rank * n0, ny_global=nb, halo_rows=4 if world > 1 else 1,
+                           options=("partition_min_cells=%d" % a.partition_min_cells) if a.partition_min_cells > 0 else None)
     s0 = {k: (v[rank * n0:rank * n0 + n0 + 2] if isinstance(v, np.ndarray) else v) for k, v in sts[0][0].items()}
     H.set_state(0, 0, s0)
     for l in range(1, len(sts)):
@@ -51,6 +55,10 @@ def main():
     torch.cuda.synchronize(); dist.barrier()
     dt = time.perf_counter() - t0
     ok = True
+    owned = [H.hier.get_option("own_boxes_level_%d" % l) for l in range(1, len(sts))]
+    parted = [H.hier.get_option("partitioned_level_%d" % l) for l in range(1, len(sts))]
+    owned_all = [None] * world
+    dist.all_gather_object(owned_all, owned)
     if a.check:
         mine = [[{nm: H.get(l, k, nm) for nm in NAMES} for k in range(len(H.level[l]))] for l in range(len(sts))]
         allv = [None] * world
@@ -68,11 +76,13 @@ def main():
             for l in range(1, len(sts)):
                 eq = all(np.array_equal(allv[r][l][k][nm], A.get(l, k, nm), equal_nan=True) for r in range(world) for k in range(len(sts[l])) for nm in NAMES)
                 ok = ok and eq
-                print("  level %d (%d boxes, on every rank) %s" % (l, len(sts[l]), "bitwise equal" if eq else "DIFFERS"), flush=True)
+                print("  level %d (%d boxes, %s) %s" % (l, len(sts[l]), "boxes relaxed per rank %s" % [o[l - 1] for o in owned_all] if parted[l - 1] else "relaxed on every rank",
+                                                      "bitwise equal" if eq else "DIFFERS"), flush=True)
             A.close()
     if rank == 0:
-        print("cfg5 physics on base %d^2 + %d levels of boxes %s, %d rank(s): %d steps in %.2f s (%.2f steps/s), %d Picard iterations, %d AMR V-cycles, %d all-gathers%s"
+        print("cfg5 physics on base %d^2 + %d levels of boxes %s, %d rank(s): %d steps in %.2f s (%.2f steps/s), %d Picard iterations, %d AMR V-cycles, %d all-gathers of coarse cells + %d of owners' boxes%s"
               % (nb, len(boxes), [len(b) for b in boxes], world, a.steps, dt, a.steps / dt, sum(c[0] for c in counts), sum(c[1] for c in counts), H.hier.gathers(),
+                 H.hier.get_option("partition_gathers"),
                  (" -> " + ("BITWISE EQUAL to the single-process hierarchy" if ok else "MISMATCH")) if a.check else ""), flush=True)
     H.close()
     dist.barrier()
