@@ -167,6 +167,7 @@ struct suhmo_level {
     suhmo_level *agg;
     suhmo_allgather_fn ag; void *ag_user;
     double *agg_send, *agg_recv; size_t agg_cap; long agg_gathers;
+    long frhs_stream, frhs_tile;   // launches that formed a coarse depth's FAS right-hand side themselves (streaming / tile kernel); read-only options
     int prof_on;
     std::vector<ProfEv> prof;
     int gsrb_variant;           // kernel selection (see suhmo_gsrb.hip); env SUHMO_GSRB_VARIANT
@@ -224,7 +225,7 @@ struct SwapGuard {
 int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st);      // suhmo_level.hip
 int suhmo_restrict_both(suhmo_level *L, int depth, hipStream_t st);                 // suhmo_level.hip
 bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps);           // suhmo_gsrb.hip
-bool suhmo_gsrb_can_fuse_rhs(suhmo_level *L, int depth, int sweeps);               // suhmo_gsrb.hip
+bool suhmo_gsrb_can_fuse_rhs(suhmo_level *L, int depth, int sweeps, bool rhs_local = false);               // suhmo_gsrb.hip
 int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream_t st, int *restricted = nullptr);   // suhmo_gsrb.hip; tail = halo
                                                     // rows worth keeping valid at exit; restricted: see there
 void suhmo_level_drop_graphs(suhmo_level *L);                                     // suhmo_fas.hip

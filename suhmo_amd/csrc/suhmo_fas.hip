@@ -85,7 +85,7 @@ static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, i
                                                                                                              // that it carries the halo rows too
     if (one_pass_rhs && (L->desc.nx_global == 0)) {
         const int next_sweeps = (dep + 1 == nd - 1) ? sp->num_bottom : S;
-        if (suhmo_gsrb_can_fuse_rhs(L, dep + 1, next_sweeps)) C.rhs_pending = 1;   // ... inside the first relaxation of the depth
+        if (suhmo_gsrb_can_fuse_rhs(L, dep + 1, next_sweeps, rhs_local)) C.rhs_pending = 1;   // ... inside the first relaxation of the depth
         else if ((rc = suhmo_fas_coarse_rhs(L, dep + 1, (hipStream_t)s, rhs_local ? suhmo_halo_rows(C.v) - 1 : 0))) return rc;   // PHIOLD = R phi,
                                                                                    // rhs_c = res_c + L_c(R phi): one pass
     } else {

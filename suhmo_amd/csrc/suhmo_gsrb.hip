@@ -255,10 +255,18 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
                     cc[a] = c;
                 }
                 cf1.rhs[0] = 1.0 * cf1.rhs[0] + 1.0 * lo[0]; cf1.rhs[1] = 1.0 * cf1.rhs[1] + 1.0 * lo[1];
-                if (own && jf >= jA && jf < jB) {
+                // rank strip: the end chunks also keep what they formed in the halo rows they only read (the later launches of the depth
+                // advance halo rows too and the prolongation corrects them): the right-hand side wherever both row neighbours were loaded,
+                // R phi in every loaded row -- the rows k_apply<., 2> serves with hcomp = halo - 1
+                const bool lo_end = v.ext[0] && chunk == 0, hi_end = v.ext[1] && chunk == g.nchunks - 1;
+                const int jP0 = lo_end ? jmin : jA, jP1 = hi_end ? jmax + 1 : jB;
+                const int jR0 = lo_end ? jmin + 1 : jA, jR1 = hi_end ? jmax : jB;
+                if (own && jf >= jP0 && jf < jP1) {
                     const int idx = cidx(v, i0, jf);
-                    *reinterpret_cast<double2 *>(g.flphi + idx) = make_double2(lo[0], lo[1]);
-                    *reinterpret_cast<double2 *>(g.frhs + idx) = make_double2(cf1.rhs[0], cf1.rhs[1]);
+                    if (jf >= jR0 && jf < jR1) {
+                        *reinterpret_cast<double2 *>(g.flphi + idx) = make_double2(lo[0], lo[1]);
+                        *reinterpret_cast<double2 *>(g.frhs + idx) = make_double2(cf1.rhs[0], cf1.rhs[1]);
+                    }
                     *reinterpret_cast<double2 *>(g.fphiold + idx) = make_double2(cc[0], cc[1]);
                 }
                 pprev = make_double2(cc[0], cc[1]);            // row r-1 as loaded: the south neighbours of row r in the next step
@@ -466,9 +474,10 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st,
     if (D.rhs_pending) {
         // (suhmo_gsrb_can_fuse_rhs said yes for exactly this launch: whole level, two sweeps, one-wave workgroups, alpha = 0)
         if constexpr (K == 2 && NT == 64 && !RST) {
-            if (part || v.alpha != 0.0 || v.ext[0] || v.ext[1]) { suhmo_set_error("internal: rhs_pending on a launch that cannot form it"); return -4; }
-            g.fres = D.fp.f[SUHMO_F_RES]; g.frhs = D.fp.f[SUHMO_F_RHS]; g.flphi = D.fp.f[SUHMO_F_LPHI]; g.fphiold = D.fp.f[SUHMO_F_PHIOLD];
-            D.rhs_pending = 0;
+            if (part || v.alpha != 0.0) { suhmo_set_error("internal: rhs_pending on a launch that cannot form it"); return -4; }
+            g.fres = D.fp.f[SUHMO_F_RES]; g.frhs = D.fp.f[SUHMO_F_RHS]; g.flphi = suhmo_field(L, depth, SUHMO_F_LPHI); g.fphiold = suhmo_field(L, depth, SUHMO_F_PHIOLD);
+            if (!g.flphi || !g.fphiold) return -2;
+            D.rhs_pending = 0; L->frhs_stream++;
             hipLaunchKernelGGL((k_gsrb_fused<2, false, 64, false, true>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
             std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
             return 0;
@@ -932,7 +941,7 @@ static int launch_tile(suhmo_level *L, int depth, int chunks, int ext_rows, hipS
     g.frhs = 0;
     if (D.rhs_pending) {
         if (!suhmo_field(L, depth, SUHMO_F_LPHI) || !suhmo_field(L, depth, SUHMO_F_PHIOLD)) return -2;
-        g.frhs = 1; D.rhs_pending = 0;
+        g.frhs = 1; D.rhs_pending = 0; L->frhs_tile++;
     }
     const double *pin = D.fp.f[SUHMO_F_PHI];
     if constexpr (S == 4) {
@@ -1009,18 +1018,21 @@ static int prolong_halo_rows(const suhmo_level *L, int depth)
     return R & ~1;
 }
 // the first relaxation of a coarse FAS depth can form its right-hand side itself
-bool suhmo_gsrb_can_fuse_rhs(suhmo_level *L, int depth, int sweeps)
+bool suhmo_gsrb_can_fuse_rhs(suhmo_level *L, int depth, int sweeps, bool rhs_local)
 {
     Depth &D = L->d[depth];
     if (sweeps < 1 || !L->fas_rhs_in_relax) return false;
-    if (D.v.rk[0] || D.v.rk[1]) return false;                 // rank strips: k_apply<., 2> also copies the halo rows of R phi
+    const bool strip = D.v.rk[0] || D.v.rk[1];                // rank strips: k_apply<., 2> also copies the halo rows of R phi
     const int K = pick_K(L, D, pick_variant(L, D), sweeps);
-    if (K <= 0) return (L->fas_rhs_in_relax & 1) && tile_ok(L, D);
+    if (K <= 0) return !strip && (L->fas_rhs_in_relax & 1) && tile_ok(L, D);
     // streaming kernel: the two-sweep launch of one-wave workgroups on a whole level (k_gsrb_fused<2, false, 64, false, true>);
     // with only two sweeps to do that launch is the one that restricts
     if (!(L->fas_rhs_in_relax & 2)) return false;
     const int nt = L->fused_nt ? L->fused_nt : ((long)D.v.nx * D.v.ny >= 8000000L ? 256 : 64);
-    return K == 2 && nt == 64 && sweeps >= 4 && D.v.alpha == 0.0 && !(D.v.ext[0] || D.v.ext[1]);
+    if (!(K == 2 && nt == 64 && sweeps >= 4 && D.v.alpha == 0.0)) return false;
+    if (!(D.v.ext[0] || D.v.ext[1])) return true;
+    // rank strip: R phi and RES have just arrived in all halo rows (the caller's rhs_local exchange); the launch then loads all of them
+    return strip && L->ex && rhs_local && L->desc.nx_global == 0 && D.phi_fresh >= D.v.gy && D.v.gy >= 2 * K + 1 && D.v.ny >= D.v.gy;
 }
 bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps)
 {
@@ -1135,6 +1147,7 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
                 if (F < 2 * K) { suhmo_set_error("internal: halo shallower than 2K"); return -4; }
             }
             int want = 2 * (sweeps - it - K) + tail;
+            if (D.rhs_pending && ext) want = F;                            // the launch that forms the right-hand side loads (and keeps) all halo rows
             int E = ext ? (F - 2 * K < want ? F - 2 * K : want) : 0;
             int rc = 0;
             if (rst && ext) {

@@ -163,6 +163,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     if (const char *e = getenv("SUHMO_FAS_RHS_FUSED")) L->fas_rhs_fused = atoi(e) != 0;
     L->agg_min_cells = 100000; L->agg_depth = 0; L->agg_world = 1; L->agg_rank = 0; L->agg = nullptr; L->ag = nullptr; L->ag_user = nullptr;
     L->agg_send = L->agg_recv = nullptr; L->agg_cap = 0; L->agg_gathers = 0;
+    L->frhs_stream = L->frhs_tile = 0;
     if (const char *e = getenv("SUHMO_AGG_MIN_CELLS")) L->agg_min_cells = atol(e);
     if (const char *e = getenv("SUHMO_TILE_STRIPS")) L->tile_strips = atoi(e);
     if (const char *e = getenv("SUHMO_TILE_CHUNKS")) L->tile_chunks = atoi(e);
@@ -333,6 +334,8 @@ extern "C" int suhmo_level_get_option(const suhmo_level_t *L, const char *key, l
     if (int *p = option_slot_int(const_cast<suhmo_level *>(L), key)) { *value = *p; return 0; }
     if (!strcmp(key, "overlapped_launches")) { *value = L->overlapped; return 0; }       // read-only counter (overlap_halo)
     if (!strcmp(key, "agg_gathers")) { *value = L->agg_gathers; return 0; }              // read-only counter (agglomeration)
+    if (!strcmp(key, "rhs_in_streaming_launches")) { *value = L->frhs_stream; return 0; }   // read-only counters (fas_rhs_in_relax)
+    if (!strcmp(key, "rhs_in_tile_launches")) { *value = L->frhs_tile; return 0; }
     suhmo_set_error("unknown option '%s'", key);
     return -1;
 }

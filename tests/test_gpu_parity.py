@@ -255,6 +255,8 @@ def test_vcycle_on_fused_kernels(oracle, hip, case, fused_restrict, rhs_in_relax
     no, ho = O.solve(sp)
     ng, hg = G.solve(sp)
     assert ng == no and np.array_equal(hg, ho)
+    if case[0] in ("wide-3strips", "allperiodic", "shmip-512"):          # (depth 1 is wide enough for the streaming kernel there, alpha = 0)
+        assert (G.get_option("rhs_in_streaming_launches") > 0) == (rhs_in_relax == 3), G.get_option("rhs_in_streaming_launches")
 
 
 TILE_CASES = CASES + FUSED_VCYCLE_CASES[1:] + [

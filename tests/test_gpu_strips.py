@@ -136,13 +136,17 @@ def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
         G.vcycle(sp)
         p1 = G.get(lv.F_PHI)
         n, hist = G.solve(sp)
-        return p1, G.get(lv.F_PHI), n, hist, G.ndepth, G.get_option("overlapped_launches")
+        return p1, G.get(lv.F_PHI), n, hist, G.ndepth, G.get_option("overlapped_launches"), G.get_option("rhs_in_streaming_launches")
 
     parts = run_strips(world, f, bc, ph, 0.0, -1.0, body, halo=halo, max_box=64)
     if fused == "overlap":
         assert all(p[5] > 0 for p in parts), [p[5] for p in parts]
     elif fused == "no-overlap":
         assert all(p[5] == 0 for p in parts)
+    if fused == 1 and halo >= 12:
+        # streaming kernel on the strips of every depth that is wide enough: the first launch of a coarse depth's pre-smoothing forms the
+        # depth's FAS right-hand side, in the strip's halo rows too (R phi and RES arrived together)
+        assert all(p[6] > 0 for p in parts), [p[6] for p in parts]
     O = oracle.OracleLevel(256, 256, f["dx"], f["dy"], bc, ph, 0.0, -1.0, 64, 4)
     O.set_inputs(f)
     O.build_mg_coefficients()
