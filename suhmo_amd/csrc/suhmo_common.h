@@ -133,6 +133,7 @@ struct VGraph {                 // a V-cycle captured for one set of solver para
     double *p0[SUHMO_MAXDEPTH], *a0[SUHMO_MAXDEPTH];     // PHI / second canvas of every depth when the cycle starts ...
     double *p1[SUHMO_MAXDEPTH], *a1[SUHMO_MAXDEPTH];     // ... and when it ends (an odd number of out-of-place launches on a depth swaps them)
     double *rhs;                                         // right-hand-side canvas of depth 0 the cycle was captured with
+    int rout_req, rout_done; const double *rout_rhs;     // the residual its last launch was asked to leave behind (resout_req, resout_rhs) and did
 };
 struct ProfEv { hipEvent_t a, b; long cells; int restricts; };   // restricts: the launch also did the restriction (RST)
 
@@ -167,6 +168,10 @@ struct suhmo_level {
     suhmo_level *agg;
     suhmo_allgather_fn ag; void *ag_user;
     double *agg_send, *agg_recv; size_t agg_cap; long agg_gathers;
+    // the solve loops ask the cycle to leave the residual of its final phi behind (suhmo_gsrb.hip, RM = 2): resout_req bit 0 RES, bit 1 LPHI
+    // too; resout_rhs: the right-hand side it is about (NULL: the level's); resout_armed: set by the cycle around its last relax of depth 0;
+    // resout_done: the launch did it (else the caller runs its own pass); read-only option residual_in_relax_launches counts them
+    int resout_req, resout_armed, resout_done; const double *resout_rhs; long resout_count;
     long frhs_stream, frhs_tile;   // launches that formed a coarse depth's FAS right-hand side themselves (streaming / tile kernel); read-only options
     int prof_on;
     std::vector<ProfEv> prof;
@@ -192,6 +197,7 @@ struct suhmo_level {
     hipStream_t xstream; hipEvent_t xev[2]; long overlapped;   // ... its stream and events; launches that overlapped so far
     int tile_strips;            // tile kernel on rank strips (env SUHMO_TILE_STRIPS, default 1)
     int tile_chunks;            // a level that is one tile relaxes all its sweeps in one launch (env SUHMO_TILE_CHUNKS, default 1)
+    int resid_in_relax;         // the solve loops' residual evaluation rides on the launch that ends the V-cycle (streaming kernel at depth 0; default 1)
     int fas_rhs_in_relax;       // coarse FAS right-hand side formed by the first relax of the depth: bit 0 in the tile kernel, bit 1 in the streaming kernel (env SUHMO_FAS_RHS_IN_RELAX, default 3)
     long tile_max_cells;        // auto mode: levels below this many cells relax on the tile kernel (env SUHMO_TILE_MAX_CELLS)
     int tile_restrict;          // the tile kernel's last pre-smoothing launch also restricts: 0 never (a separate kernel restricts: faster on one GPU and

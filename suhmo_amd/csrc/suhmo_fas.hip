@@ -27,7 +27,10 @@ static int eff_depths(const suhmo_level *L, const suhmo_solver_params_t *sp)
 // adjacent interior value), so only the relax that ends the cycle -- whose state the caller can observe -- fills it.
 static int relax(suhmo_level *L, int dep, int sweeps, int tail, suhmo_stream_t s, bool observable = false, int *restricted = nullptr)
 {
+    // the relax that ends the cycle (`observable`: depth 0, nothing follows) may leave the residual of the final phi behind for the solve loop
+    L->resout_armed = observable && dep == 0 && L->resout_req && L->resid_in_relax;
     int rc = suhmo_launch_gsrb(L, dep, sweeps, tail, (hipStream_t)s, restricted);
+    L->resout_armed = 0;
     if (rc) return rc;
     if (sweeps > 0 && observable) return suhmo_level_fill_ghosts(L, dep, SUHMO_F_PHI, 1, s);
     return 0;
@@ -136,6 +139,7 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
     auto at_start = [&](const VGraph &g) {
         if (memcmp(g.key, key, sizeof(key))) return false;
         for (int d = 0; d < L->ndepth; d++) if (L->d[d].fp.f[SUHMO_F_PHI] != g.p0[d] || L->d[d].phi_alt != g.a0[d]) return false;
+        if (g.rout_req != (L->resid_in_relax ? L->resout_req : 0) || g.rout_rhs != L->resout_rhs) return false;   // (what the last launch leaves behind)
         return L->d[0].fp.f[SUHMO_F_RHS] == g.rhs;                       // an AMR cycle runs level 0 on a second right-hand-side canvas (suhmo_hier.hip)
     };
     for (const VGraph &g : L->vgraphs)
@@ -143,6 +147,7 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
             if (!g.exec) return 0;                                       // known not to be capturable
             HIPCHK(hipGraphLaunch(g.exec, (hipStream_t)s));
             for (int d = 0; d < L->ndepth; d++) { L->d[d].fp.f[SUHMO_F_PHI] = g.p1[d]; L->d[d].phi_alt = g.a1[d]; }
+            if (g.rout_done) { L->resout_done = 1; L->resout_count++; }
             done = true;
             return 0;
         }
@@ -154,6 +159,8 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
     for (int d = 0; d < SUHMO_MAXDEPTH; d++) { g.p0[d] = g.a0[d] = g.p1[d] = g.a1[d] = nullptr; }
     for (int d = 0; d < L->ndepth; d++) { g.p0[d] = L->d[d].fp.f[SUHMO_F_PHI]; g.a0[d] = L->d[d].phi_alt; }
     g.rhs = L->d[0].fp.f[SUHMO_F_RHS];
+    g.rout_req = L->resid_in_relax ? L->resout_req : 0; g.rout_rhs = L->resout_rhs; g.rout_done = 0;
+    const int rout_before = L->resout_done; const long rout_count = L->resout_count;
     HIPCHK(hipStreamSynchronize((hipStream_t)s));                        // the private stream starts from a quiescent state
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamBeginCapture(L->gstream, hipStreamCaptureModeThreadLocal);
@@ -162,6 +169,8 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
         rc = vcycle_body(L, sp, nd, (suhmo_stream_t)L->gstream);
         e = hipStreamEndCapture(L->gstream, &graph);
     }
+    g.rout_done = L->resout_count != rout_count;                         // (nothing was executed during capture: the flags go back)
+    L->resout_done = rout_before; L->resout_count = rout_count;
     bool clean = true;                                                   // host-side state the cycle must leave behind: none pending
     for (int d = 0; d < L->ndepth; d++) {
         clean = clean && !L->d[d].prolong_pending && !L->d[d].rhs_pending;
@@ -177,6 +186,7 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
     if (!g.exec) return 0;                                               // run eagerly
     HIPCHK(hipGraphLaunch(g.exec, (hipStream_t)s));
     for (int d = 0; d < L->ndepth; d++) { L->d[d].fp.f[SUHMO_F_PHI] = g.p1[d]; L->d[d].phi_alt = g.a1[d]; }
+    if (g.rout_done) { L->resout_done = 1; L->resout_count++; }
     done = true;
     return 0;
 }
@@ -216,8 +226,13 @@ extern "C" int suhmo_level_solve(suhmo_level_t *L, const suhmo_solver_params_t *
     bool goMin = iter < sp->iter_min;
     while (goMin || (goIter && goRedu && goHang && goNorm)) {
         norm_last = rnorm;
-        if ((rc = suhmo_level_vcycle(L, sp, s))) return rc;
-        if ((rc = suhmo_level_residual(L, 0, s))) return rc;
+        // (the launch that ends the cycle leaves rhs - L(phi) of the final phi in RES when it can: the pass below is then not needed)
+        L->resout_req = 1; L->resout_rhs = nullptr; L->resout_done = 0;
+        rc = suhmo_level_vcycle(L, sp, s);
+        const bool have_res = L->resout_done != 0;
+        L->resout_req = 0; L->resout_done = 0;
+        if (rc) return rc;
+        if (!have_res && (rc = suhmo_level_residual(L, 0, s))) return rc;
         if ((rc = suhmo_level_norm(L, 0, SUHMO_F_RES, 0, &rnorm, s))) return rc;
         iter++;
         if (hist) hist[iter] = rnorm;

@@ -125,6 +125,10 @@ struct FusedGeom {
     // FRHS: the first relaxation of a coarse FAS depth forms the depth's right-hand side rhs = res + L(R phi) itself (k_apply<., 2>'s
     // expressions on the rows as they are loaded) and stores it, L(phi) and the copy of R phi the prolongation subtracts later
     const double *fres; double *frhs, *flphi, *fphiold;
+    // RM = 2: the launch that ends the cycle's post-smoothing leaves the residual of the final phi behind (the solve loop's residual
+    // evaluation, k_apply<., 1> / <., 3>): RES = rtrue - L(phi), optionally L(phi) too; rtrue = the right-hand side the CALLER's residual is
+    // about (inside an AMR cycle the level relaxes against its FAS right-hand side while the true one waits on the second canvas)
+    const double *ortrue; double *ores, *olphi;
 };
 
 struct RowCoef {          // per-thread coefficients of its column pair in one row
@@ -146,13 +150,15 @@ __device__ __forceinline__ void copy_coef(RowCoef &d, const RowCoef &s)
 // visiting order, into the coarse cell of the thread's column pair (RESTRICTRESVCNL2D + RESTRICTVCNL, VCAMR...OpF.ChF:480-561,
 // 419-449): the separate pass over phi and the 8 coefficient arrays (75 B/cell) disappears.  Costs: one more ring row, one
 // more coefficient row, one more final row above and below the chunk and two more halo columns per side.
-template <int K, bool HAS_ALPHA, int NT, bool RST = false, bool FRHS = false>
+template <int K, bool HAS_ALPHA, int NT, int RM = 0, bool FRHS = false>
 __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__restrict__ pin,
                                                    double *__restrict__ pout, suhmo_phys_t ph, FusedGeom g)
 {
-    static_assert(!(FRHS && (RST || HAS_ALPHA)), "the right-hand side is formed in the plain launch of an alpha = 0 operator");
-    constexpr int LW = 2 * NT, R = 2 * K + 3 + (RST ? 1 : 0);
-    constexpr int HX = 2 * K + (RST ? 2 : 0), EY = RST ? 1 : 0;
+    // RM: what the launch does with the final rows besides storing them: 0 nothing, 1 restricts (RST), 2 stores their residual (ROUT)
+    constexpr bool RST = RM == 1, ROUT = RM == 2, RR = RM != 0;
+    static_assert(!(FRHS && (RR || HAS_ALPHA)), "the right-hand side is formed in the plain launch of an alpha = 0 operator");
+    constexpr int LW = 2 * NT, R = 2 * K + 3 + (RR ? 1 : 0);
+    constexpr int HX = 2 * K + (RR ? 2 : 0), EY = RR ? 1 : 0;
     __shared__ double lds[R * LW];
 
     // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs; give every XCD a
@@ -323,13 +329,14 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
         }
 
         // ---- 2b. RST: rows r-2K-2 .. r-2K are final: residual of row r-2K-1, restricted
-        if constexpr (RST) {
+        if constexpr (RR) {
             const int jr = r - 2 * K - 1;
             if (own && jr >= jA && jr < jB && jr >= 0 && jr < v.ny) {    // (rank strips: halo rows are advanced, not restricted)
                 const RowCoef &q = (K >= 2) ? cf5 : cf3;
                 const int s0 = (sr - (2 * K + 1) + 2 * R) % R, sN = (s0 + 1) % R, sS = (s0 + R - 1) % R;
                 const double *row = lds + s0 * LW;
                 double acc = (jr & 1) ? racc : 0.0, accp = (jr & 1) ? raccp : 0.0;
+                double lo2[2] = {0.0, 0.0};
 #pragma unroll
                 for (int a = 0; a < 2; a++) {
                     const int x = xl + a, i = im + a;
@@ -348,10 +355,18 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
                     const double bxW = a ? q.bx1 : q.bx0, bxE = a ? q.bx2 : q.bx1;
                     double aterm = HAS_ALPHA ? v.alpha * q.a[a] : v.alpha;
                     double lofphi = lofphi_cell(v, aterm, c, e, w, n, s, bxE, bxW, q.byN[a], q.byS[a], nl);
-                    acc = acc + (q.rhs[a] - lofphi) / 4.0;
-                    accp = accp + c / 4.0;
+                    if constexpr (ROUT) lo2[a] = lofphi;
+                    else {
+                        acc = acc + (q.rhs[a] - lofphi) / 4.0;
+                        accp = accp + c / 4.0;
+                    }
                 }
-                if (jr & 1) {
+                if constexpr (ROUT) {
+                    const int idx = cidx(v, i0, jr);
+                    const double2 rt = *reinterpret_cast<const double2 *>(g.ortrue + idx);
+                    *reinterpret_cast<double2 *>(g.ores + idx) = make_double2(-1.0 * lo2[0] + 1.0 * rt.x, -1.0 * lo2[1] + 1.0 * rt.y);
+                    if (g.olphi) *reinterpret_cast<double2 *>(g.olphi + idx) = make_double2(lo2[0], lo2[1]);
+                } else if (jr & 1) {
                     const int ic = ((jr >> 1) + g.rgy) * g.rP + SUHMO_XOFF + (i0 >> 1);
                     g.rres[ic] = acc; g.rphi[ic] = accp;
                 } else { racc = acc; raccp = accp; }
@@ -369,9 +384,9 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
         // ---- 4. row r+1 enters the ring (its slot held row r-2K-2: no longer read), rotate
         sr = (sr + 1) % R;
         if (in_row) { lds[sr * LW + xl] = pnext.x; lds[sr * LW + xl + 1] = pnext.y; }
-        if constexpr (RST && K >= 2) copy_coef<HAS_ALPHA>(cf5, cf4);
+        if constexpr (RR && K >= 2) copy_coef<HAS_ALPHA>(cf5, cf4);
         if constexpr (K >= 2) { copy_coef<HAS_ALPHA>(cf4, cf3); copy_coef<HAS_ALPHA>(cf3, cf2); }
-        else if constexpr (RST) copy_coef<HAS_ALPHA>(cf3, cf2);
+        else if constexpr (RR) copy_coef<HAS_ALPHA>(cf3, cf2);
         copy_coef<HAS_ALPHA>(cf2, cf1);
         copy_coef<HAS_ALPHA>(cf1, cf0);
     }
@@ -389,9 +404,10 @@ static bool fused_ok(const suhmo_level *L, const Depth &D, int K)
 
 // part 0: the whole level.  Rank strips with the exchange in flight: part 1 = the chunks that read no halo row (returns 1 and
 // launches nothing when the geometry has none), part 2 = the first and the last chunk, then the canvases trade places.
-template <int K, int NT, bool RST = false>
+template <int K, int NT, int RM = 0>
 static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st, int part = 0)
 {
+    constexpr bool RST = RM == 1, RR = RM != 0;
     Depth &D = L->d[depth];
     const DV &v = D.v;
     if (!D.phi_alt) {
@@ -399,7 +415,7 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st,
         HIPCHK(hipMemsetAsync(D.phi_alt, 0, D.elems * sizeof(double), st));
     }
     FusedGeom g;
-    constexpr int HX = 2 * K + (RST ? 2 : 0), EY = RST ? 1 : 0;
+    constexpr int HX = 2 * K + (RR ? 2 : 0), EY = RR ? 1 : 0;
     const int maxW = 2 * NT - 2 * HX;
     g.nstrips = (v.nx + maxW - 1) / maxW;
     g.W = 2 * ((v.nx + 2 * g.nstrips - 1) / (2 * g.nstrips));
@@ -413,7 +429,7 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st,
             int nb = 0, ncu = 0, dev = 0;
             HIPCHK(hipGetDevice(&dev));
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_gsrb_fused<K, false, NT, RST>), NT, 0));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_gsrb_fused<K, false, NT, RM>), NT, 0));
             slots_k[K] = (nb > 0 ? nb : 1) * (ncu > 0 ? ncu : 256);
         }
         g.jbeg = v.ext[0] ? -ext_rows : 0;
@@ -471,9 +487,16 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st,
         C.phi_fresh = 0;
     }
     g.fres = nullptr; g.frhs = g.flphi = g.fphiold = nullptr;
+    g.ortrue = nullptr; g.ores = g.olphi = nullptr;
+    if (RM == 2) {
+        if (v.alpha != 0.0 || part) { suhmo_set_error("internal: residual output on a launch that cannot form it"); return -4; }
+        g.ortrue = L->resout_rhs ? L->resout_rhs : D.fp.f[SUHMO_F_RHS];
+        g.ores = D.fp.f[SUHMO_F_RES];
+        if (L->resout_req & 2) { g.olphi = suhmo_field(L, depth, SUHMO_F_LPHI); if (!g.olphi) return -2; }
+    }
     if (D.rhs_pending) {
         // (suhmo_gsrb_can_fuse_rhs said yes for exactly this launch: whole level, two sweeps, one-wave workgroups, alpha = 0)
-        if constexpr (K == 2 && NT == 64 && !RST) {
+        if constexpr (K == 2 && NT == 64 && !RR) {
             if (part || v.alpha != 0.0) { suhmo_set_error("internal: rhs_pending on a launch that cannot form it"); return -4; }
             g.fres = D.fp.f[SUHMO_F_RES]; g.frhs = D.fp.f[SUHMO_F_RHS]; g.flphi = suhmo_field(L, depth, SUHMO_F_LPHI); g.fphiold = suhmo_field(L, depth, SUHMO_F_PHIOLD);
             if (!g.flphi || !g.fphiold) return -2;
@@ -486,7 +509,7 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st,
     if (v.alpha != 0.0)
         hipLaunchKernelGGL((k_gsrb_fused<K, true, NT, false>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
     else
-        hipLaunchKernelGGL((k_gsrb_fused<K, false, NT, RST>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
+        hipLaunchKernelGGL((k_gsrb_fused<K, false, NT, RM>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
     if (part != 1) std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
     return 0;
 }
@@ -1154,8 +1177,13 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
                 if (F < 2 * K + 1) rst = false;
                 else { E = F - 2 * K - 1 < want ? F - 2 * K - 1 : want; E &= ~1; }
             }
+            // the launch that ends the cycle (armed by the cycle for its last relax of depth 0) also leaves the residual of the final phi
+            // behind: whole levels (same needs as the restricting launch: one more final row and column around a chunk)
+            const bool rout = L->resout_armed && depth == 0 && !restricted && nt == 64 && K == 2 && it + K == sweeps && D.v.alpha == 0.0
+                              && !(D.v.ext[0] || D.v.ext[1]) && L->desc.nx_global == 0 && !D.rhs_pending;
             auto launch = [&](int part) {
-                if (rst) return launch_fused<2, 64, true>(L, depth, E, st, part);
+                if (rout) return launch_fused<2, 64, 2>(L, depth, E, st, part);
+                if (rst) return launch_fused<2, 64, 1>(L, depth, E, st, part);
                 if (nt == 64) return (K == 2) ? launch_fused<2, 64>(L, depth, E, st, part) : launch_fused<1, 64>(L, depth, E, st, part);
                 return (K == 2) ? launch_fused<2, 256>(L, depth, E, st, part) : launch_fused<1, 256>(L, depth, E, st, part);
             };
@@ -1167,6 +1195,7 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
             } else rc = launch(0);
             if (rc) return rc;
             if (rst) *restricted = 1;
+            if (rout) { L->resout_done = 1; L->resout_count++; }
             if (ext) { F = E; D.phi_fresh = F; }
         }
         int done = TS ? TS * tchunks : K == 0 ? 1 : K;

@@ -165,6 +165,9 @@ struct suhmo_hier {
     // rectangles lev[1].dirty0.  base_full_ver counts every other write to level 0 (head, right-hand side, coefficients: all of them
     // pass through the level-0 V-cycle or an entry point of the C-ABI)
     unsigned long base_full_ver = 1, base_res_seen = 0;
+    // ... or were left behind by the launch that ended level 0's own V-cycle (suhmo_gsrb.hip, residual output): the solve loop's residual
+    // evaluation then needs no pass over level 0 at all
+    unsigned long base_fused_ver = 0;
     bool incremental = true;                               // option incremental_residual
     long part_min_cells = 500000;                          // creation option partition_min_cells: a level of boxes with at least this many cells
                                                            // PER RANK is relaxed by its owners (below it a pass is shorter than the message)
@@ -1094,7 +1097,9 @@ int composite_residual(suhmo_hier *H, int l, suhmo_stream_t s, bool whole_level_
     if ((rc = cf_phi(H, l - 1, s))) return rc;
     if (l - 1 == 0) {
         HLev &V1 = H->lev[1];
-        if (H->incremental && whole_level_follows && H->base_res_seen == H->base_full_ver)
+        if (!whole_level_follows && H->base_fused_ver == H->base_full_ver)
+            rc = 0;                                                           // L(phi) and rhs - L(phi) of the head as it is: written by the cycle's last launch
+        else if (H->incremental && whole_level_follows && H->base_res_seen == H->base_full_ver)
             rc = suhmo_apply_and_residual_rects(base_of(H), 0, V1.dirty0.d, (int)V1.dirty0.n, V1.dirty_w, V1.dirty_h, HST(s));   // only what the average changed
         else rc = suhmo_apply_and_residual(base_of(H), 0, HST(s));
         H->base_res_seen = whole_level_follows ? 0 : H->base_full_ver;       // (the solve loop's evaluation is the one the next cycle can build on)
@@ -1134,7 +1139,16 @@ int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stre
     // so only those cells are kept (and only their differences formed); a level of boxes keeps a copy
     if (l - 1 == 0) rc = hier_window_save(H, l, SUHMO_F_PHI, HST(s)); else rc = hier_copy(H, l - 1, SUHMO_F_PHIOLD, SUHMO_F_PHI, s);
     if (rc) return rc;
-    if ((rc = vcycle_amr(H, l - 1, sp, s))) return rc;
+    if (l - 1 == 0) {
+        // level 0's own V-cycle runs against the FAS right-hand side; its last launch is asked to leave L(phi) and TRUE rhs - L(phi) behind
+        // (the true right-hand side waits on the second canvas): what the solve loop's residual evaluation computes next
+        suhmo_level *B = base_of(H);
+        B->resout_req = 3; B->resout_rhs = B->d[0].fp.f[SUHMO_F_RHS0]; B->resout_done = 0;
+        rc = vcycle_amr(H, 0, sp, s);
+        if (!rc && B->resout_done) H->base_fused_ver = H->base_full_ver;
+        B->resout_req = 0; B->resout_rhs = nullptr; B->resout_done = 0;
+        if (rc) return rc;
+    } else if ((rc = vcycle_amr(H, l - 1, sp, s))) return rc;
     if (l - 1 == 0) rhs_aside.back();
     else if ((rc = hier_copy(H, l - 1, SUHMO_F_RHS, SUHMO_F_RHS0, s))) return rc;
     if (l - 1 == 0) rc = hier_prolong2(H, l, SUHMO_F_PHI, HST(s), true);                      // AMRProlongS_2 of phi - phi_saved

@@ -164,6 +164,8 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     L->agg_min_cells = 100000; L->agg_depth = 0; L->agg_world = 1; L->agg_rank = 0; L->agg = nullptr; L->ag = nullptr; L->ag_user = nullptr;
     L->agg_send = L->agg_recv = nullptr; L->agg_cap = 0; L->agg_gathers = 0;
     L->frhs_stream = L->frhs_tile = 0;
+    L->resout_req = L->resout_armed = L->resout_done = 0; L->resout_rhs = nullptr; L->resout_count = 0; L->resid_in_relax = 1;
+    if (const char *e = getenv("SUHMO_RESID_IN_RELAX")) L->resid_in_relax = atoi(e);
     if (const char *e = getenv("SUHMO_AGG_MIN_CELLS")) L->agg_min_cells = atol(e);
     if (const char *e = getenv("SUHMO_TILE_STRIPS")) L->tile_strips = atoi(e);
     if (const char *e = getenv("SUHMO_TILE_CHUNKS")) L->tile_chunks = atoi(e);
@@ -305,7 +307,7 @@ static int *option_slot_int(suhmo_level *L, const char *key)
     static const struct { const char *k; int suhmo_level::*m; } tab[] = {
         {"gsrb_variant", &suhmo_level::gsrb_variant}, {"fused_hc", &suhmo_level::fused_hc}, {"bcoef_fused", &suhmo_level::bcoef_fused},
         {"fused_nt", &suhmo_level::fused_nt}, {"fused_restrict", &suhmo_level::fused_restrict}, {"strips_rhs_local", &suhmo_level::strips_rhs_local},
-        {"tile_strips", &suhmo_level::tile_strips}, {"overlap_halo", &suhmo_level::overlap_halo}, {"skip_mask", &suhmo_level::skip_mask}, {"tile_chunks", &suhmo_level::tile_chunks}, {"tile_order", &suhmo_level::tile_order}, {"tile_restrict", &suhmo_level::tile_restrict}, {"fas_rhs_in_relax", &suhmo_level::fas_rhs_in_relax}, {"fas_rhs_fused", &suhmo_level::fas_rhs_fused},
+        {"tile_strips", &suhmo_level::tile_strips}, {"overlap_halo", &suhmo_level::overlap_halo}, {"skip_mask", &suhmo_level::skip_mask}, {"tile_chunks", &suhmo_level::tile_chunks}, {"tile_order", &suhmo_level::tile_order}, {"tile_restrict", &suhmo_level::tile_restrict}, {"fas_rhs_in_relax", &suhmo_level::fas_rhs_in_relax}, {"resid_in_relax", &suhmo_level::resid_in_relax}, {"fas_rhs_fused", &suhmo_level::fas_rhs_fused},
         {"tile_s", &suhmo_level::tile_s}, {"gsrb_tile", &suhmo_level::gsrb_tile}, {"tile_t", &suhmo_level::tile_t}, {"poll_readback", &suhmo_level::poll_readback}};
     for (const auto &e : tab) if (!strcmp(key, e.k)) return &(L->*(e.m));
     return nullptr;
@@ -336,6 +338,7 @@ extern "C" int suhmo_level_get_option(const suhmo_level_t *L, const char *key, l
     if (!strcmp(key, "agg_gathers")) { *value = L->agg_gathers; return 0; }              // read-only counter (agglomeration)
     if (!strcmp(key, "rhs_in_streaming_launches")) { *value = L->frhs_stream; return 0; }   // read-only counters (fas_rhs_in_relax)
     if (!strcmp(key, "rhs_in_tile_launches")) { *value = L->frhs_tile; return 0; }
+    if (!strcmp(key, "residual_in_relax_launches")) { *value = L->resout_count; return 0; }
     suhmo_set_error("unknown option '%s'", key);
     return -1;
 }

@@ -84,10 +84,20 @@ def test_hier_pieces_bitwise(oracle, bc, ph):
 
 @pytest.mark.parametrize("name,boxes,bc,ph", [("union-4lev", UNION, BC_NP, sy.CFG3_PHYS), ("union-4lev-values-mask", UNION, BC_V, MASKPH),
                                               ("cut-periodic", CUT, BC, sy.CFG3_PHYS), ("union-4lev-exchange-per-pass", UNION, BC_NP, sy.CFG3_PHYS),
-                                              ("union-4lev-whole-level-residuals", UNION, BC_NP, sy.CFG3_PHYS)],
+                                              ("union-4lev-whole-level-residuals", UNION, BC_NP, sy.CFG3_PHYS),
+                                              ("union-4lev-base-on-the-streaming-kernel", UNION, BC_NP, sy.CFG3_PHYS),
+                                              ("union-4lev-values-mask-base-on-the-streaming-kernel", UNION, BC_V, MASKPH),
+                                              ("union-4lev-base-on-the-streaming-kernel-own-residual-pass", UNION, BC_NP, sy.CFG3_PHYS)],
                          ids=lambda v: v if isinstance(v, str) else "")
-def test_hier_vcycle_and_solve_bitwise(oracle, name, boxes, bc, ph):
+def test_hier_vcycle_and_solve_bitwise(oracle, name, boxes, bc, ph, monkeypatch):
     from suhmo_amd.level import F_PHI, F_RES, F_BX
+    # base-on-the-streaming-kernel: level 0 relaxes with the streaming kernel (what a 4096^2 base does), whose last launch of level 0's own
+    # V-cycle leaves L(phi) and TRUE rhs - L(phi) behind for the solve loop's residual evaluation (-own-residual-pass: switched off)
+    streams = "base-on-the-streaming-kernel" in name
+    if streams:
+        monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "1")
+        monkeypatch.setenv("SUHMO_GSRB_TILE", "0")
+        monkeypatch.setenv("SUHMO_RESID_IN_RELAX", "0" if name.endswith("own-residual-pass") else "1")
     # exchange-per-pass: an exchange launch before every colour pass instead of the pushed side cells (creation option of the hierarchy)
     sp = dict(sy.SOLVER_DEFAULT, eps=1e-9, norm_thresh=1e-14, max_iter=6, imin=30)
     # whole-level-residuals: every composite residual and coarse gradient over all of level 0 (default: the solve loop's evaluation is
@@ -100,6 +110,8 @@ def test_hier_vcycle_and_solve_bitwise(oracle, name, boxes, bc, ph):
     assert no == ng and np.array_equal(ho, hg), (ho, hg)
     same_levels(O, G, oracle, ((oracle.F_PHI, F_PHI),), "solve")
     same_levels(O, G, oracle, ((oracle.F_RES, F_RES),), "solve residual", skip_covered=True)
+    if streams:
+        assert (G.coarse.get_option("residual_in_relax_launches") > 0) == (not name.endswith("own-residual-pass"))
     O.close(); G.close()
 
 

@@ -257,6 +257,9 @@ def test_vcycle_on_fused_kernels(oracle, hip, case, fused_restrict, rhs_in_relax
     assert ng == no and np.array_equal(hg, ho)
     if case[0] in ("wide-3strips", "allperiodic", "shmip-512"):          # (depth 1 is wide enough for the streaming kernel there, alpha = 0)
         assert (G.get_option("rhs_in_streaming_launches") > 0) == (rhs_in_relax == 3), G.get_option("rhs_in_streaming_launches")
+    # the solve loop's residual evaluation: left behind by the launch that ends each V-cycle (alpha = 0, two-sweep launches), its own pass otherwise
+    assert np.array_equal(G.get(hip.F_RES), O.get(oracle.F_RES)), "residual of the converged head"
+    assert (G.get_option("residual_in_relax_launches") > 0) == (alpha == 0.0), G.get_option("residual_in_relax_launches")
 
 
 TILE_CASES = CASES + FUSED_VCYCLE_CASES[1:] + [
@@ -403,6 +406,31 @@ def test_bench_size_vcycle_bitwise(oracle, hip):
     O.residual(); G.residual()
     assert np.array_equal(G.get(hip.F_RES), O.get(oracle.F_RES))
     O.close(); G.close()
+
+
+@pytest.mark.parametrize("case", FUSED_VCYCLE_CASES[:4], ids=[c[0] for c in FUSED_VCYCLE_CASES[:4]])
+def test_residual_left_behind_by_the_last_launch_equals_the_residual_pass(oracle, hip, case, monkeypatch):
+    """suhmo_level_solve with the residual riding on the cycle's last launch (level option resid_in_relax, default 1) and with the
+    separate pass: the same history, head and residual field, all the oracle's; chunk height 6 puts chunk seams everywhere"""
+    monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "1")
+    monkeypatch.setenv("SUHMO_GSRB_TILE", "0")
+    monkeypatch.setenv("SUHMO_FUSED_HC", "6")
+    _, mk, bc, ph, alpha, beta, mb = case
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-10, norm_thresh=1e-13, max_iter=4, imin=6)
+    got = []
+    for on in (1, 0):
+        f = mk()
+        f.pop("bx", None); f.pop("by", None)
+        O, G = pair(oracle, hip, f, bc, ph, alpha, beta, mb)
+        G.set_option("resid_in_relax", on)
+        O.build_mg_coefficients(); G.build_mg_coefficients()
+        no, ho = O.solve(sp)
+        ng, hg = G.solve(sp)
+        assert ng == no and np.array_equal(hg, ho), (on, hg, ho)
+        assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI)) and np.array_equal(G.get(hip.F_RES), O.get(oracle.F_RES)), on
+        assert (G.get_option("residual_in_relax_launches") > 0) == bool(on)
+        got.append(G.get(hip.F_RES))
+    assert np.array_equal(got[0], got[1])
 
 
 def test_kernel_selection_through_the_option_api(oracle):
