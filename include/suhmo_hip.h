@@ -108,7 +108,9 @@ int suhmo_level_num_depths(const suhmo_level_t *L);
  * the level is created override them for A/B runs): key = gsrb_variant (-1 auto, 0 colour passes / tiles, 1, 2 = sweeps per
  * streaming pass), gsrb_tile, tile_t (0, 16, 32), tile_s, tile_max_cells, tile_chunks, tile_strips, fused_min_cells, fused_hc,
  * fused_nt (64, 256), fused_restrict, fas_rhs_in_relax, strips_rhs_local, bcoef_fused, graph_max_cells, poll_readback, overlap_halo,
- * agg_min_cells, fas_rhs_fused.
+ * agg_min_cells, fas_rhs_fused, resid_in_relax (1: the residual the solve loops evaluate after every V-cycle is left behind by the cycle's
+ * last launch where the streaming kernel runs depth 0; 0: always a pass of its own).  Read-only counters: overlapped_launches, agg_gathers,
+ * rhs_in_streaming_launches, rhs_in_tile_launches, residual_in_relax_launches.
  * On rank strips every rank must make the same choices (suhmo_level_attach_rccl checks). */
 int suhmo_level_set_option(suhmo_level_t *L, const char *key, long value);
 int suhmo_level_get_option(const suhmo_level_t *L, const char *key, long *value);

@@ -221,11 +221,15 @@ double *suhmo_field(suhmo_level *L, int depth, int field);   // lazily allocates
 // Two canvases of a level trade places while its FAS problem runs (the level's own right-hand side is set aside): whatever way the
 // scope is left -- an exchange or all-gather hook failing in between included -- they trade back, so a caller that catches the
 // error still holds the problem it posed
+// every change of a field POINTER of any level (a field allocated on first use, phi canvases trading places) advances this count: tables of
+// pointers kept elsewhere (suhmo_hier.hip: the boxes of a level as one launch target) are compared again only after it moved
+void suhmo_fp_changed();
+unsigned long suhmo_fp_epoch();
 struct SwapGuard {
     double **a, **b; bool armed;
     SwapGuard() : a(nullptr), b(nullptr), armed(false) {}
-    void arm(double **a_, double **b_) { a = a_; b = b_; std::swap(*a, *b); armed = true; }
-    void back() { if (armed) { std::swap(*a, *b); armed = false; } }
+    void arm(double **a_, double **b_) { a = a_; b = b_; std::swap(*a, *b); armed = true; suhmo_fp_changed(); }
+    void back() { if (armed) { std::swap(*a, *b); armed = false; suhmo_fp_changed(); } }
     ~SwapGuard() { back(); }
 };
 int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st);      // suhmo_level.hip

@@ -146,7 +146,7 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
         if (at_start(g)) {
             if (!g.exec) return 0;                                       // known not to be capturable
             HIPCHK(hipGraphLaunch(g.exec, (hipStream_t)s));
-            for (int d = 0; d < L->ndepth; d++) { L->d[d].fp.f[SUHMO_F_PHI] = g.p1[d]; L->d[d].phi_alt = g.a1[d]; }
+            for (int d = 0; d < L->ndepth; d++) { L->d[d].fp.f[SUHMO_F_PHI] = g.p1[d]; L->d[d].phi_alt = g.a1[d]; } suhmo_fp_changed();
             if (g.rout_done) { L->resout_done = 1; L->resout_count++; }
             done = true;
             return 0;
@@ -185,7 +185,7 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
     L->vgraphs.push_back(g);
     if (!g.exec) return 0;                                               // run eagerly
     HIPCHK(hipGraphLaunch(g.exec, (hipStream_t)s));
-    for (int d = 0; d < L->ndepth; d++) { L->d[d].fp.f[SUHMO_F_PHI] = g.p1[d]; L->d[d].phi_alt = g.a1[d]; }
+    for (int d = 0; d < L->ndepth; d++) { L->d[d].fp.f[SUHMO_F_PHI] = g.p1[d]; L->d[d].phi_alt = g.a1[d]; } suhmo_fp_changed();
     if (g.rout_done) { L->resout_done = 1; L->resout_count++; }
     done = true;
     return 0;

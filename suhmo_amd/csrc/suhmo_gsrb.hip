@@ -502,7 +502,7 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st,
             if (!g.flphi || !g.fphiold) return -2;
             D.rhs_pending = 0; L->frhs_stream++;
             hipLaunchKernelGGL((k_gsrb_fused<2, false, 64, false, true>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
-            std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
+            { std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt); suhmo_fp_changed(); }
             return 0;
         } else { suhmo_set_error("internal: rhs_pending on a launch that cannot form it"); return -4; }
     }
@@ -510,7 +510,7 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st,
         hipLaunchKernelGGL((k_gsrb_fused<K, true, NT, false>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
     else
         hipLaunchKernelGGL((k_gsrb_fused<K, false, NT, RM>), dim3(g.ntiles), dim3(NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
-    if (part != 1) std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
+    if (part != 1) { std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt); suhmo_fp_changed(); }
     return 0;
 }
 
@@ -973,7 +973,7 @@ static int launch_tile(suhmo_level *L, int depth, int chunks, int ext_rows, hipS
                 hipLaunchKernelGGL((k_gsrb_tile<S, T, true, RST, true>), dim3(g.ntx * g.nty), dim3(TileThreads<S, T, RST>::NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
             else
                 hipLaunchKernelGGL((k_gsrb_tile<S, T, false, RST, true>), dim3(g.ntx * g.nty), dim3(TileThreads<S, T, RST>::NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
-            std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
+            { std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt); suhmo_fp_changed(); }
             return 0;
         }
     }
@@ -982,7 +982,7 @@ static int launch_tile(suhmo_level *L, int depth, int chunks, int ext_rows, hipS
         hipLaunchKernelGGL((k_gsrb_tile<S, T, true, RST>), dim3(g.ntx * g.nty), dim3(TileThreads<S, T, RST>::NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
     else
         hipLaunchKernelGGL((k_gsrb_tile<S, T, false, RST>), dim3(g.ntx * g.nty), dim3(TileThreads<S, T, RST>::NT), 0, st, v, D.fp, pin, D.phi_alt, L->ph, g);
-    std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt);
+    { std::swap(D.fp.f[SUHMO_F_PHI], D.phi_alt); suhmo_fp_changed(); }
     return 0;
 }
 // tile edge: 16 below 600 k cells (enough workgroups for the chip -- 512^2 is 256 tiles of 32, one per CU: 6.4 us per sweep against

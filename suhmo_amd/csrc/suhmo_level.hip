@@ -113,6 +113,10 @@ static void make_dv(DV &v, const suhmo_level_desc_t &d, int depth)
     } else { v.rk[0] = v.ext[0]; v.rk[1] = v.ext[1]; }
 }
 
+static std::atomic<unsigned long> g_fp_epoch{1};
+void suhmo_fp_changed() { g_fp_epoch.fetch_add(1, std::memory_order_relaxed); }
+unsigned long suhmo_fp_epoch() { return g_fp_epoch.load(std::memory_order_relaxed); }
+
 double *suhmo_field(suhmo_level *L, int depth, int field)
 {
     Depth &D = L->d[depth];
@@ -121,6 +125,7 @@ double *suhmo_field(suhmo_level *L, int depth, int field)
         if (hipMalloc(&p, D.elems * sizeof(double)) != hipSuccess) return nullptr;
         (void)hipMemset(p, 0, D.elems * sizeof(double));
         D.fp.f[field] = p;
+        suhmo_fp_changed();
     }
     return D.fp.f[field];
 }

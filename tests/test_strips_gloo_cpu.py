@@ -22,7 +22,7 @@ def free_port():
 def test_gloo_strips(tmp_path, world, periodic):
     out = tmp_path / "ok.txt"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(world),
-               OMP_NUM_THREADS="1")
+               OMP_NUM_THREADS="1", GLOO_SOCKET_IFNAME="lo")     # (rendezvous on 127.0.0.1: gloo must not try to resolve the hostname)
     procs = []
     for r in range(world):
         e = dict(env, RANK=str(r))

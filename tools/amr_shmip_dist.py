@@ -13,6 +13,9 @@ import sys
 import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("SUHMO_DUMP_AFTER"):          # tests: a rank still running after that many seconds prints where every thread waits
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ["SUHMO_DUMP_AFTER"]), exit=False)
 import numpy as np
 import torch
 import torch.distributed as dist

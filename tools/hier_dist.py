@@ -8,12 +8,18 @@ of the coarse cells level 1 reads, native RCCL on the "nccl" backend; SUHMO_DIST
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("SUHMO_DUMP_AFTER"):          # tests: a rank still running after that many seconds prints where every thread waits
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ["SUHMO_DUMP_AFTER"]), exit=False)
 import numpy as np
 import torch
 import torch.distributed as dist
 from suhmo_amd import model, multigpu, synthetic as sy
 
 NAMES = ("head", "B", "mR")
+
+
+t_start = time.perf_counter()
 
 
 def main():
@@ -48,6 +54,16 @@ def main():
             H.set_state(l, k, st)
     if world > 1:
         multigpu.attach_hier(H.hier, dist, rank, world)
+    if os.environ.get("SUHMO_DUMP_AFTER"):          # tests: how far has this rank come (twice, 20 s apart: hung or slow?)
+        import threading
+
+        def progress():
+            for k in range(2):
+                time.sleep(int(os.environ["SUHMO_DUMP_AFTER"]) - 30 + 20 * k)
+                print("rank %d after %.0f s: %d all-gathers of coarse cells, %d of owners' boxes, %d halo message groups, %d agglomeration gathers"
+                      % (rank, time.perf_counter() - t_start, H.hier.gathers(), H.hier.get_option("partition_gathers"),
+                         H.level[0][0].rccl_exchanges() if hasattr(H.level[0][0], "rccl_exchanges") else -1, H.level[0][0].get_option("agg_gathers")), flush=True)
+        threading.Thread(target=progress, daemon=True).start()
     integ = H.moulin_source(**mo)
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
