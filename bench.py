@@ -147,6 +147,20 @@ def main():
                                               "algorithmic_GBs": rbytes / (rl * 1e-3) / 1e9,
                                               "note": "algorithmic bytes of 2 sweeps + a separate restriction pass; the fused launch moves far less, "
                                                       "so this is an effective rate, not HBM utilisation"}
+    # one iteration of the solve loop the time step runs (AMRFASMultiGrid::solve: V-cycle, residual for the stopping rule, its max norm and
+    # the read-back the host decides on) -- outside the timed region, a side figure: the launch that ends the V-cycle leaves the residual behind
+    # where the streaming kernel runs depth 0
+    if not args.no_side:
+        k_it = 10
+        sp_it = dict(sp, eps=1e-30, norm_thresh=1e-30, hang=-1.0, max_iter=k_it, imin=k_it, iter_min=k_it)
+        sync()
+        c0 = G.get_option("residual_in_relax_launches")
+        t0 = time.perf_counter()
+        G.solve(sp_it)
+        sync()
+        extra["solve_iteration"] = {"ms": 1e3 * (time.perf_counter() - t0) / k_it, "iterations": k_it,
+                                    "what": "V-cycle + residual + max norm + read-back per iteration of suhmo_level_solve",
+                                    "residual_left_by_the_last_launch": bool(G.get_option("residual_in_relax_launches") - c0 >= k_it)}
     if args.sweeps_only:
         sync()
         G.profile(True)

@@ -489,7 +489,7 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st,
     g.fres = nullptr; g.frhs = g.flphi = g.fphiold = nullptr;
     g.ortrue = nullptr; g.ores = g.olphi = nullptr;
     if (RM == 2) {
-        if (v.alpha != 0.0 || part) { suhmo_set_error("internal: residual output on a launch that cannot form it"); return -4; }
+        if (v.alpha != 0.0) { suhmo_set_error("internal: residual output on a launch that cannot form it"); return -4; }
         g.ortrue = L->resout_rhs ? L->resout_rhs : D.fp.f[SUHMO_F_RHS];
         g.ores = D.fp.f[SUHMO_F_RES];
         if (L->resout_req & 2) { g.olphi = suhmo_field(L, depth, SUHMO_F_LPHI); if (!g.olphi) return -2; }
@@ -1148,8 +1148,13 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
         } else {
             const int nt = L->fused_nt ? L->fused_nt : ((long)D.v.nx * D.v.ny >= 8000000L ? 256 : 64);   // 0 = by size
             bool rst = may_restrict && nt == 64 && K == 2 && it + K == sweeps;
-            // rank strip: 2K current halo rows, one more when the launch also restricts (one exchange instead of the restriction's own)
-            const int need = 2 * K + (rst && ext ? 1 : 0);
+            // the launch that ends the cycle (armed by the cycle for its last relax of depth 0) also leaves the residual of the final phi
+            // behind (same needs as the restricting launch: one more final row and column around a chunk)
+            bool rout = L->resout_armed && depth == 0 && !restricted && nt == 64 && K == 2 && it + K == sweeps && D.v.alpha == 0.0
+                        && (!(D.v.ext[0] || D.v.ext[1]) || ext) && L->desc.nx_global == 0 && !D.rhs_pending;
+            // rank strip: 2K current halo rows, one more when the launch also restricts / evaluates the residual (one exchange instead of
+            // the one the separate pass would ask for)
+            const int need = 2 * K + ((rst || rout) && ext ? 1 : 0);
             bool flying = false;                                           // the exchange is in flight on the second stream
             if (ext && F < need) {
                 // only the native transport is stream-ordered (its pack / send / recv / unpack are enqueued on the stream the hook is
@@ -1173,14 +1178,10 @@ int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream
             if (D.rhs_pending && ext) want = F;                            // the launch that forms the right-hand side loads (and keeps) all halo rows
             int E = ext ? (F - 2 * K < want ? F - 2 * K : want) : 0;
             int rc = 0;
-            if (rst && ext) {
-                if (F < 2 * K + 1) rst = false;
-                else { E = F - 2 * K - 1 < want ? F - 2 * K - 1 : want; E &= ~1; }
+            if ((rst || rout) && ext) {
+                if (F < 2 * K + 1) rst = rout = false;
+                else { E = F - 2 * K - 1 < want ? F - 2 * K - 1 : want; if (rst) E &= ~1; }
             }
-            // the launch that ends the cycle (armed by the cycle for its last relax of depth 0) also leaves the residual of the final phi
-            // behind: whole levels (same needs as the restricting launch: one more final row and column around a chunk)
-            const bool rout = L->resout_armed && depth == 0 && !restricted && nt == 64 && K == 2 && it + K == sweeps && D.v.alpha == 0.0
-                              && !(D.v.ext[0] || D.v.ext[1]) && L->desc.nx_global == 0 && !D.rhs_pending;
             auto launch = [&](int part) {
                 if (rout) return launch_fused<2, 64, 2>(L, depth, E, st, part);
                 if (rst) return launch_fused<2, 64, 1>(L, depth, E, st, part);

@@ -136,7 +136,8 @@ def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
         G.vcycle(sp)
         p1 = G.get(lv.F_PHI)
         n, hist = G.solve(sp)
-        return p1, G.get(lv.F_PHI), n, hist, G.ndepth, G.get_option("overlapped_launches"), G.get_option("rhs_in_streaming_launches")
+        return (p1, G.get(lv.F_PHI), n, hist, G.ndepth, G.get_option("overlapped_launches"), G.get_option("rhs_in_streaming_launches"),
+                G.get_option("residual_in_relax_launches"), G.get(lv.F_RES))
 
     parts = run_strips(world, f, bc, ph, 0.0, -1.0, body, halo=halo, max_box=64)
     if fused == "overlap":
@@ -147,6 +148,8 @@ def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
         # streaming kernel on the strips of every depth that is wide enough: the first launch of a coarse depth's pre-smoothing forms the
         # depth's FAS right-hand side, in the strip's halo rows too (R phi and RES arrived together)
         assert all(p[6] > 0 for p in parts), [p[6] for p in parts]
+        # ... and the launch that ends each V-cycle of the solve leaves the residual of the strip's rows behind (one more halo row than the sweeps need)
+        assert all(p[7] > 0 for p in parts), [p[7] for p in parts]
     O = oracle.OracleLevel(256, 256, f["dx"], f["dy"], bc, ph, 0.0, -1.0, 64, 4)
     O.set_inputs(f)
     O.build_mg_coefficients()
@@ -157,6 +160,7 @@ def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
     assert all(p[2] == n for p in parts)
     assert np.array_equal(parts[0][3], hist)
     assert np.array_equal(np.vstack([p[1] for p in parts]), O.get(oracle.F_PHI))
+    assert np.array_equal(np.vstack([p[8] for p in parts]), O.get(oracle.F_RES)), "residual of the converged head"
 
 
 @pytest.mark.parametrize("where", ["none", "first-rows-of-rank-1", "inside-rank-1", "last-rows-of-rank-0"])
