@@ -150,7 +150,7 @@ def main():
     # one iteration of the solve loop the time step runs (AMRFASMultiGrid::solve: V-cycle, residual for the stopping rule, its max norm and
     # the read-back the host decides on) -- outside the timed region, a side figure: the launch that ends the V-cycle leaves the residual behind
     # where the streaming kernel runs depth 0
-    if not args.no_side:
+    if not args.no_side and world == 1:                 # (N > 1: the line carries the timed V-cycles and nothing that could cost it)
         k_it = 10
         sp_it = dict(sp, eps=1e-30, norm_thresh=1e-30, hang=-1.0, max_iter=k_it, imin=k_it, iter_min=k_it)
         sync()
