@@ -133,7 +133,7 @@ struct VGraph {                 // a V-cycle captured for one set of solver para
     double *p0[SUHMO_MAXDEPTH], *a0[SUHMO_MAXDEPTH];     // PHI / second canvas of every depth when the cycle starts ...
     double *p1[SUHMO_MAXDEPTH], *a1[SUHMO_MAXDEPTH];     // ... and when it ends (an odd number of out-of-place launches on a depth swaps them)
     double *rhs;                                         // right-hand-side canvas of depth 0 the cycle was captured with
-    int rout_req, rout_done; const double *rout_rhs;     // the residual its last launch was asked to leave behind (resout_req, resout_rhs) and did
+    int rout_req, rout_done, rout_np; const double *rout_rhs;     // the residual its last launch was asked to leave behind (resout_req, resout_rhs) and did
 };
 struct ProfEv { hipEvent_t a, b; long cells; int restricts; };   // restricts: the launch also did the restriction (RST)
 
@@ -172,6 +172,7 @@ struct suhmo_level {
     // too; resout_rhs: the right-hand side it is about (NULL: the level's); resout_armed: set by the cycle around its last relax of depth 0;
     // resout_done: the launch did it (else the caller runs its own pass); read-only option residual_in_relax_launches counts them
     int resout_req, resout_armed, resout_done; const double *resout_rhs; long resout_count;
+    int resout_np;              // resout_req bit 2: the launch also left that many partial maxima of |RES| in scratch + 2 (k_norm_final's input)
     long frhs_stream, frhs_tile;   // launches that formed a coarse depth's FAS right-hand side themselves (streaming / tile kernel); read-only options
     int prof_on;
     std::vector<ProfEv> prof;
@@ -235,6 +236,7 @@ struct SwapGuard {
 int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st);      // suhmo_level.hip
 int suhmo_restrict_both(suhmo_level *L, int depth, hipStream_t st);                 // suhmo_level.hip
 bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps);           // suhmo_gsrb.hip
+int suhmo_level_norm_from_partials(suhmo_level *L, int np, double *out, hipStream_t st);   // suhmo_level.hip
 bool suhmo_gsrb_can_fuse_rhs(suhmo_level *L, int depth, int sweeps, bool rhs_local = false);               // suhmo_gsrb.hip
 int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream_t st, int *restricted = nullptr);   // suhmo_gsrb.hip; tail = halo
                                                     // rows worth keeping valid at exit; restricted: see there

@@ -147,7 +147,7 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
             if (!g.exec) return 0;                                       // known not to be capturable
             HIPCHK(hipGraphLaunch(g.exec, (hipStream_t)s));
             for (int d = 0; d < L->ndepth; d++) { L->d[d].fp.f[SUHMO_F_PHI] = g.p1[d]; L->d[d].phi_alt = g.a1[d]; } suhmo_fp_changed();
-            if (g.rout_done) { L->resout_done = 1; L->resout_count++; }
+            if (g.rout_done) { L->resout_done = 1; L->resout_count++; L->resout_np = g.rout_np; }
             done = true;
             return 0;
         }
@@ -170,6 +170,7 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
         e = hipStreamEndCapture(L->gstream, &graph);
     }
     g.rout_done = L->resout_count != rout_count;                         // (nothing was executed during capture: the flags go back)
+    g.rout_np = L->resout_np;
     L->resout_done = rout_before; L->resout_count = rout_count;
     bool clean = true;                                                   // host-side state the cycle must leave behind: none pending
     for (int d = 0; d < L->ndepth; d++) {
@@ -186,7 +187,7 @@ static int vcycle_graph(suhmo_level *L, const suhmo_solver_params_t *sp, int nd,
     if (!g.exec) return 0;                                               // run eagerly
     HIPCHK(hipGraphLaunch(g.exec, (hipStream_t)s));
     for (int d = 0; d < L->ndepth; d++) { L->d[d].fp.f[SUHMO_F_PHI] = g.p1[d]; L->d[d].phi_alt = g.a1[d]; } suhmo_fp_changed();
-    if (g.rout_done) { L->resout_done = 1; L->resout_count++; }
+    if (g.rout_done) { L->resout_done = 1; L->resout_count++; L->resout_np = g.rout_np; }
     done = true;
     return 0;
 }
@@ -227,13 +228,16 @@ extern "C" int suhmo_level_solve(suhmo_level_t *L, const suhmo_solver_params_t *
     while (goMin || (goIter && goRedu && goHang && goNorm)) {
         norm_last = rnorm;
         // (the launch that ends the cycle leaves rhs - L(phi) of the final phi in RES when it can: the pass below is then not needed)
-        L->resout_req = 1; L->resout_rhs = nullptr; L->resout_done = 0;
+        L->resout_req = 1 | 4; L->resout_rhs = nullptr; L->resout_done = 0; L->resout_np = 0;      // (4: and the partial maxima of its max norm)
         rc = suhmo_level_vcycle(L, sp, s);
         const bool have_res = L->resout_done != 0;
-        L->resout_req = 0; L->resout_done = 0;
+        const int np = have_res ? L->resout_np : 0;
+        L->resout_req = 0; L->resout_done = 0; L->resout_np = 0;
         if (rc) return rc;
         if (!have_res && (rc = suhmo_level_residual(L, 0, s))) return rc;
-        if ((rc = suhmo_level_norm(L, 0, SUHMO_F_RES, 0, &rnorm, s))) return rc;
+        if (np > 0) rc = suhmo_level_norm_from_partials(L, np, &rnorm, (hipStream_t)s);
+        else rc = suhmo_level_norm(L, 0, SUHMO_F_RES, 0, &rnorm, s);
+        if (rc) return rc;
         iter++;
         if (hist) hist[iter] = rnorm;
         goNorm = rnorm > sp->norm_thresh;

@@ -129,6 +129,7 @@ struct FusedGeom {
     // evaluation, k_apply<., 1> / <., 3>): RES = rtrue - L(phi), optionally L(phi) too; rtrue = the right-hand side the CALLER's residual is
     // about (inside an AMR cycle the level relaxes against its FAS right-hand side while the true one waits on the second canvas)
     const double *ortrue; double *ores, *olphi;
+    double *onorm;      // ... and the chunk's max |RES| (one partial per strip x chunk: k_norm_partial's job, for k_norm_final); NULL: not asked for
 };
 
 struct RowCoef {          // per-thread coefficients of its column pair in one row
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
     // cf0 = row r (being prefetched), cfM = row r-M
     RowCoef cf0, cf1, cf2, cf3, cf4, cf5;
     double racc = 0.0, raccp = 0.0;        // RST: the coarse cell's sums after its first fine row
+    double nmax = 0.0;                     // ROUT: max |RES| over this thread's cells of the chunk
     // physical-BC sides this tile can touch (uniform): skip the per-lane boundary tests elsewhere
     const bool xbc = !v.per[0] && (c0 - HX <= 0 || c0 + g.W + HX >= v.nx);
     const bool ybc = !v.per[1] && (jmin <= 0 || jmax >= v.ny - 1);
@@ -364,8 +366,10 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
                 if constexpr (ROUT) {
                     const int idx = cidx(v, i0, jr);
                     const double2 rt = *reinterpret_cast<const double2 *>(g.ortrue + idx);
-                    *reinterpret_cast<double2 *>(g.ores + idx) = make_double2(-1.0 * lo2[0] + 1.0 * rt.x, -1.0 * lo2[1] + 1.0 * rt.y);
+                    const double r0 = -1.0 * lo2[0] + 1.0 * rt.x, r1 = -1.0 * lo2[1] + 1.0 * rt.y;
+                    *reinterpret_cast<double2 *>(g.ores + idx) = make_double2(r0, r1);
                     if (g.olphi) *reinterpret_cast<double2 *>(g.olphi + idx) = make_double2(lo2[0], lo2[1]);
+                    nmax = fmax(nmax, fmax(fabs(r0), fabs(r1)));
                 } else if (jr & 1) {
                     const int ic = ((jr >> 1) + g.rgy) * g.rP + SUHMO_XOFF + (i0 >> 1);
                     g.rres[ic] = acc; g.rphi[ic] = accp;
@@ -389,6 +393,14 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
         else if constexpr (RR) copy_coef<HAS_ALPHA>(cf3, cf2);
         copy_coef<HAS_ALPHA>(cf2, cf1);
         copy_coef<HAS_ALPHA>(cf1, cf0);
+    }
+    if constexpr (ROUT) {
+        if (g.onorm) {                         // (uniform) the chunk's max norm: a maximum, so the order of the lanes does not matter
+            static_assert(!ROUT || NT == 64, "one wave per workgroup");
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nmax = fmax(nmax, __shfl_xor(nmax, o));
+            if (t == 0) g.onorm[strip * g.nchunks + chunk] = nmax;
+        }
     }
 }
 
@@ -493,6 +505,9 @@ static int launch_fused(suhmo_level *L, int depth, int ext_rows, hipStream_t st,
         g.ortrue = L->resout_rhs ? L->resout_rhs : D.fp.f[SUHMO_F_RHS];
         g.ores = D.fp.f[SUHMO_F_RES];
         if (L->resout_req & 2) { g.olphi = suhmo_field(L, depth, SUHMO_F_LPHI); if (!g.olphi) return -2; }
+        g.onorm = nullptr;
+        if ((L->resout_req & 4) && (size_t)g.nstrips * g.nchunks + 4 < L->scratch_elems) { g.onorm = L->scratch + 2; L->resout_np = g.nstrips * g.nchunks; }
+        else L->resout_np = 0;
     }
     if (D.rhs_pending) {
         // (suhmo_gsrb_can_fuse_rhs said yes for exactly this launch: whole level, two sweeps, one-wave workgroups, alpha = 0)

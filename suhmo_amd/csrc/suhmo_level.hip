@@ -169,6 +169,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     L->agg_min_cells = 100000; L->agg_depth = 0; L->agg_world = 1; L->agg_rank = 0; L->agg = nullptr; L->ag = nullptr; L->ag_user = nullptr;
     L->agg_send = L->agg_recv = nullptr; L->agg_cap = 0; L->agg_gathers = 0;
     L->frhs_stream = L->frhs_tile = 0;
+    L->resout_np = 0;
     L->resout_req = L->resout_armed = L->resout_done = 0; L->resout_rhs = nullptr; L->resout_count = 0; L->resid_in_relax = 1;
     if (const char *e = getenv("SUHMO_RESID_IN_RELAX")) L->resid_in_relax = atoi(e);
     if (const char *e = getenv("SUHMO_AGG_MIN_CELLS")) L->agg_min_cells = atol(e);
@@ -1908,6 +1909,17 @@ extern "C" int suhmo_level_norm(suhmo_level_t *L, int depth, int field, int ord,
     // the reference's norm() reduces over the ranks (src/AMRNonLinearPoissonOp.cpp:1222-1264): MAX for the max norm, SUM of the squares for l2
     { int rc = suhmo_reduce_finish(L, st, 1, ord == 0 ? 0 : 1, &r); if (rc) return rc; }
     if (ord == 2) r = sqrt(r);
+    *out = r;
+    return 0;
+}
+
+// max norm of RES at depth 0 from the partial maxima the cycle's last launch left behind (suhmo_gsrb.hip, residual output): the second
+// stage of suhmo_level_norm alone
+int suhmo_level_norm_from_partials(suhmo_level *L, int np, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, st, L->scratch + 2, np, 0, L->scratch, suhmo_reduce_slot(L));
+    double r = 0.0;
+    int rc = suhmo_reduce_finish(L, st, 1, 0, &r); if (rc) return rc;
     *out = r;
     return 0;
 }
