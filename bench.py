@@ -142,7 +142,7 @@ def main():
         # the launch that ends the pre-smoothing also restricts: 2 sweeps (144 B/cell) + RESTRICTRESVCNL2D/RESTRICTVCNL (76 B/cell)
         rl = rst_ms / rst_launches
         rbytes = (BYTES_PER_CELL_SWEEP * rst_cells / rst_launches) + 76.0 * cells
-        extra["gsrb_plus_restrict_launch"] = {"kernel": "k_gsrb_fused<2, false, 64, true> (2 sweeps + restriction in one pass)", "avg_launch_ms": rl,
+        extra["gsrb_plus_restrict_launch"] = {"kernel": "k_gsrb_fused<2, false, 64, 1> (2 sweeps + restriction in one pass)", "avg_launch_ms": rl,
                                               "launches_timed": rst_launches, "algorithmic_bytes_per_launch": rbytes,
                                               "algorithmic_GBs": rbytes / (rl * 1e-3) / 1e9,
                                               "note": "algorithmic bytes of 2 sweeps + a separate restriction pass; the fused launch moves far less, "
