@@ -357,6 +357,47 @@ def test_tile_kernel_random_shapes(hip, seed, monkeypatch):
     assert np.array_equal(out[0][1:-1, :], out[1][1:-1, :]) and np.array_equal(out[0][:, 1:-1], out[1][:, 1:-1])
 
 
+def _random_stream_case(seed):
+    rng = np.random.default_rng(7000 + seed)
+    nx = 4 * int(rng.integers(32, 100))                      # (two streaming depths: nx / 2 even and >= 64 as well)
+    per = [int(rng.integers(0, 2)), int(rng.integers(0, 2))]
+    ny = 4 * int(rng.integers(8, 40))
+    bc = dict(type=[[int(rng.integers(0, 2)), int(rng.integers(0, 2))], [int(rng.integers(0, 2)), int(rng.integers(0, 2))]],
+              value=[[float(rng.uniform(-5, 5)), float(rng.uniform(-0.05, 0.05))], [float(rng.uniform(-0.05, 0.05)), float(rng.uniform(-5, 5))]],
+              periodic=per)
+    return nx, ny, bc, int(rng.choice([0, 6, 10, 14])), bool(rng.integers(0, 2))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_streaming_cycle_random_shapes(oracle, hip, seed, monkeypatch):
+    """the streaming kernel with everything it carries -- prolongation while loading, the FAS right-hand side of a coarse depth in its
+    first launch, restriction and the solve loop's residual + partial norms in its last -- on random shapes, boundary conditions, chunk heights
+    and ice-free patches (so that some V-cycles read the mask array and some skip it): V-cycles, solve history and the residual field are the
+    oracle's, bit for bit"""
+    nx, ny, bc, hc, icefree = _random_stream_case(seed)
+    monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "1")
+    monkeypatch.setenv("SUHMO_GSRB_TILE", "0")
+    monkeypatch.setenv("SUHMO_FUSED_HC", str(hc))
+    f = sy.random_fields(nx, ny, seed=7100 + seed)
+    f.pop("bx", None); f.pop("by", None)
+    if not icefree:
+        f["mask"][:] = 1.0
+    ph = dict(sy.RANDOM_PHYS)
+    O, G = pair(oracle, hip, f, bc, ph, 0.0, -1.0, 64)
+    O.build_mg_coefficients(); G.build_mg_coefficients()
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-12, norm_thresh=1e-14, max_iter=3, imin=6)
+    for k in range(2):
+        O.vcycle(sp); G.vcycle(sp)
+        assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI)), (seed, nx, ny, bc, hc, k)
+    for d in range(1, G.ndepth):
+        assert np.array_equal(G.get(hip.F_RHS, depth=d), O.get(oracle.F_RHS, depth=d)), (seed, "coarse right-hand side", d)
+    no, ho = O.solve(sp)
+    ng, hg = G.solve(sp)
+    assert ng == no and np.array_equal(hg, ho), (seed, nx, ny, bc, hc, hg, ho)
+    assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI)) and np.array_equal(G.get(hip.F_RES), O.get(oracle.F_RES)), (seed, nx, ny, bc, hc)
+    assert G.get_option("residual_in_relax_launches") > 0 and (G.ndepth < 2 or G.get_option("rhs_in_streaming_launches") > 0)
+
+
 def test_full_size_properties(hip):
     """BASELINE size (4096^2): size-independent properties instead of the (slow) oracle:
     GSRB fixed point, residual == rhs - applyOp, restriction of a constant, idempotent
