@@ -208,6 +208,10 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
     const bool usemask = !g.negflag || *g.negflag == g.mask_epoch;
 
     int sr = 0;                            // LDS ring slot of row r
+    // slot of an earlier row: sr - m, m <= R -- a compare instead of a division by 7 (the kernel issues nearly as many scalar as vector
+    // instructions: 290.7 against 294.7 us per launch, profiles/r03_i_ring_index_ab.txt; keeping the seven offsets in rotating scalars
+    // instead: fewer instructions, more spilled scalars, the same time)
+    auto ring = [](int x) { return x < 0 ? x + R : x; };
     for (int r = jmin - 1; r <= jB - 1 + 2 * K + EY; r++) {
         // ---- 1. prefetch: phi of row r+1, coefficients of row r (both first used in step r+1)
         bool lphi = cval && (r + 1 >= jmin) && (r + 1 <= jmax);
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
         if constexpr (FRHS) {
             const int jf = r - 1;
             if (cval && jf >= jmin && jf <= jmax) {
-                const int s0 = (sr - 1 + 2 * R) % R, sN = (s0 + 1) % R;
+                const int s0 = ring(sr - 1), sN = sr;
                 const double *row = lds + s0 * LW;
                 double lo[2], cc[2];
 #pragma unroll
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
             constexpr int a = decltype(a_tag)::value;
             const int j = r - m;
             const int x = xl + a, i = im + a;
-            const int s0 = (sr - m + 2 * R) % R, sN = (s0 + 1) % R, sS = (s0 + R - 1) % R;
+            const int s0 = ring(sr - m), sN = ring(sr - m + 1), sS = ring(sr - m - 1);
             const double *row = lds + s0 * LW;
             double c = row[x];
             double w = row[(a == 0 && xl == 0) ? 0 : x - 1], e = row[(a == 1 && xl == LW - 2) ? LW - 1 : x + 1];
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
             const int jr = r - 2 * K - 1;
             if (own && jr >= jA && jr < jB && jr >= 0 && jr < v.ny) {    // (rank strips: halo rows are advanced, not restricted)
                 const RowCoef &q = (K >= 2) ? cf5 : cf3;
-                const int s0 = (sr - (2 * K + 1) + 2 * R) % R, sN = (s0 + 1) % R, sS = (s0 + R - 1) % R;
+                const int s0 = ring(sr - (2 * K + 1)), sN = ring(sr - 2 * K), sS = ring(sr - (2 * K + 2));
                 const double *row = lds + s0 * LW;
                 double acc = (jr & 1) ? racc : 0.0, accp = (jr & 1) ? raccp : 0.0;
                 double lo2[2] = {0.0, 0.0};
@@ -380,13 +384,13 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
         {
             const int jo = r - 2 * K;
             if (own && jo >= jA && jo < jB) {
-                const int so = (sr - 2 * K + 2 * R) % R;
+                const int so = ring(sr - 2 * K);
                 double2 o = make_double2(lds[so * LW + xl], lds[so * LW + xl + 1]);
                 *reinterpret_cast<double2 *>(pout + cidx(v, i0, jo)) = o;
             }
         }
         // ---- 4. row r+1 enters the ring (its slot held row r-2K-2: no longer read), rotate
-        sr = (sr + 1) % R;
+        sr = sr + 1 == R ? 0 : sr + 1;
         if (in_row) { lds[sr * LW + xl] = pnext.x; lds[sr * LW + xl + 1] = pnext.y; }
         if constexpr (RR && K >= 2) copy_coef<HAS_ALPHA>(cf5, cf4);
         if constexpr (K >= 2) { copy_coef<HAS_ALPHA>(cf4, cf3); copy_coef<HAS_ALPHA>(cf3, cf2); }
