@@ -236,6 +236,7 @@ struct SwapGuard {
 int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st);      // suhmo_level.hip
 int suhmo_restrict_both(suhmo_level *L, int depth, hipStream_t st);                 // suhmo_level.hip
 bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps);           // suhmo_gsrb.hip
+int suhmo_level_residual_and_norm(suhmo_level *L, double *out, hipStream_t st);                   // suhmo_level.hip
 int suhmo_level_norm_from_partials(suhmo_level *L, int np, double *out, hipStream_t st);   // suhmo_level.hip
 bool suhmo_gsrb_can_fuse_rhs(suhmo_level *L, int depth, int sweeps, bool rhs_local = false);               // suhmo_gsrb.hip
 int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream_t st, int *restricted = nullptr);   // suhmo_gsrb.hip; tail = halo

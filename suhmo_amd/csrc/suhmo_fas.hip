@@ -215,8 +215,7 @@ extern "C" int suhmo_level_solve(suhmo_level_t *L, const suhmo_solver_params_t *
     HIPCHK(hipSetDevice(L->device));
     int rc;
     double rnorm = 0.0;
-    if ((rc = suhmo_level_residual(L, 0, s))) return rc;
-    if ((rc = suhmo_level_norm(L, 0, SUHMO_F_RES, 0, &rnorm, s))) return rc;
+    if ((rc = suhmo_level_residual_and_norm(L, &rnorm, (hipStream_t)s))) return rc;
     double initial_rnorm = rnorm, norm_last = 2.0 * initial_rnorm;
     int iter = 0;
     if (hist) hist[0] = rnorm;
@@ -234,8 +233,8 @@ extern "C" int suhmo_level_solve(suhmo_level_t *L, const suhmo_solver_params_t *
         const int np = have_res ? L->resout_np : 0;
         L->resout_req = 0; L->resout_done = 0; L->resout_np = 0;
         if (rc) return rc;
-        if (!have_res && (rc = suhmo_level_residual(L, 0, s))) return rc;
-        if (np > 0) rc = suhmo_level_norm_from_partials(L, np, &rnorm, (hipStream_t)s);
+        if (!have_res) rc = suhmo_level_residual_and_norm(L, &rnorm, (hipStream_t)s);        // (two launches: the pass leaves the partial maxima too)
+        else if (np > 0) rc = suhmo_level_norm_from_partials(L, np, &rnorm, (hipStream_t)s);
         else rc = suhmo_level_norm(L, 0, SUHMO_F_RES, 0, &rnorm, s);
         if (rc) return rc;
         iter++;

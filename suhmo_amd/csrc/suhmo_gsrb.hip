@@ -156,7 +156,7 @@ __global__ __launch_bounds__(NT) void k_gsrb_fused(DV v, FP fp, const double *__
                                                    double *__restrict__ pout, suhmo_phys_t ph, FusedGeom g)
 {
     // RM: what the launch does with the final rows besides storing them: 0 nothing, 1 restricts (RST), 2 stores their residual (ROUT)
-    constexpr bool RST = RM == 1, ROUT = RM == 2, RR = RM != 0;
+    constexpr bool ROUT = RM == 2, RR = RM != 0;
     static_assert(!(FRHS && (RR || HAS_ALPHA)), "the right-hand side is formed in the plain launch of an alpha = 0 operator");
     constexpr int LW = 2 * NT, R = 2 * K + 3 + (RR ? 1 : 0);
     constexpr int HX = 2 * K + (RR ? 2 : 0), EY = RR ? 1 : 0;

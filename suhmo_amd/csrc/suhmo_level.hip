@@ -589,17 +589,18 @@ extern "C" int suhmo_level_fill_ghosts(suhmo_level_t *L, int depth, int field, i
 // VCNLCOMPUTEOP2D / VCNLCOMPUTERES2D with BC, NL fused.  MODE 0: LPHI = L(phi); 1: RES = rhs - L(phi);
 // 2: the FAS right-hand side of a coarse depth in one pass: LPHI = L(phi), RHS = axby(RES, LPHI, 1, 1), PHIOLD = phi
 // 3: LPHI = L(phi) and RES = axby(LPHI, RHS, -1, 1) in one pass (the composite residual of an AMR level, suhmo_hier.hip)
+// (returns what it stored in RES, MODE 1 / 3; 0 for a thread outside the level)
 template <bool HAS_ALPHA, int MODE>
-__device__ __forceinline__ void d_apply_at(const DV &v, const FP &fp, suhmo_phys_t ph, int homog, int halo, int hcomp, int i, int j)
+__device__ __forceinline__ double d_apply_at(const DV &v, const FP &fp, suhmo_phys_t ph, int homog, int halo, int hcomp, int i, int j)
 {
-    if (i >= v.nx || j >= v.ny + halo) return;
+    if (i >= v.nx || j >= v.ny + halo) return 0.0;
     const double *__restrict__ phi = fp.f[SUHMO_F_PHI];
     int idx = cidx(v, i, j);
     if (MODE == 2 && (j < 0 || j >= v.ny)) {
         // rank strip: the first hcomp halo rows beyond a rank boundary get the neighbour's right-hand side computed here (its phi
         // and RES were exchanged together), which saves the exchange of RHS; the rows further out only copy phi
         const bool comp = (j < 0 && v.rk[0] && j >= -hcomp) || (j >= v.ny && v.rk[1] && j < v.ny + hcomp);
-        if (!comp) { fp.f[SUHMO_F_PHIOLD][idx] = phi[idx]; return; }
+        if (!comp) { fp.f[SUHMO_F_PHIOLD][idx] = phi[idx]; return 0.0; }
     }
     double c = phi[idx];
     double e = phiE(v, phi, idx, i, c, homog), w = phiW(v, phi, idx, i, c, homog);
@@ -610,14 +611,16 @@ __device__ __forceinline__ void d_apply_at(const DV &v, const FP &fp, suhmo_phys
     nl_terms(ph, c, fp.f[SUHMO_F_B][idx], fp.f[SUHMO_F_PI][idx], fp.f[SUHMO_F_ZB][idx], fp.f[SUHMO_F_MASK][idx], nl, dnl);
     double aterm = HAS_ALPHA ? v.alpha * fp.f[SUHMO_F_ACOEF][idx] : v.alpha;
     double lofphi = lofphi_cell(v, aterm, c, e, w, n, s, bxE, bxW, byN, byS, nl);
+    double res = 0.0;
     if (MODE == 0) fp.f[SUHMO_F_LPHI][idx] = lofphi;
-    else if (MODE == 1) fp.f[SUHMO_F_RES][idx] = fp.f[SUHMO_F_RHS][idx] - lofphi;
-    else if (MODE == 3) { fp.f[SUHMO_F_LPHI][idx] = lofphi; fp.f[SUHMO_F_RES][idx] = -1.0 * lofphi + 1.0 * fp.f[SUHMO_F_RHS][idx]; }
+    else if (MODE == 1) fp.f[SUHMO_F_RES][idx] = res = fp.f[SUHMO_F_RHS][idx] - lofphi;
+    else if (MODE == 3) { fp.f[SUHMO_F_LPHI][idx] = lofphi; fp.f[SUHMO_F_RES][idx] = res = -1.0 * lofphi + 1.0 * fp.f[SUHMO_F_RHS][idx]; }
     else {
         fp.f[SUHMO_F_LPHI][idx] = lofphi;
         fp.f[SUHMO_F_RHS][idx] = 1.0 * fp.f[SUHMO_F_RES][idx] + 1.0 * lofphi;
         fp.f[SUHMO_F_PHIOLD][idx] = c;
     }
+    return res;
 }
 template <bool HAS_ALPHA, int MODE>
 __device__ __forceinline__ void d_apply(const DV &v, const FP &fp, suhmo_phys_t ph, int homog, int halo, int hcomp)
@@ -630,6 +633,20 @@ template <bool HAS_ALPHA, int MODE>
 __global__ __launch_bounds__(256) void k_apply(DV v, FP fp, suhmo_phys_t ph, int homog, int halo = 0, int hcomp = 0)
 {
     d_apply<HAS_ALPHA, MODE>(v, fp, ph, homog, halo, hcomp);
+}
+// RES = rhs - L(phi) and, in the same pass, the first stage of its max norm (one partial per workgroup, as k_norm_partial leaves them for
+// k_norm_final): the solve loop's residual evaluation on levels whose cycle's last launch cannot leave it behind (the tile-kernel sizes)
+template <bool HAS_ALPHA>
+__global__ __launch_bounds__(256) void k_residual_norm(DV v, FP fp, suhmo_phys_t ph, double *__restrict__ partial)
+{
+    __shared__ double sm[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    double r = fabs(d_apply_at<HAS_ALPHA, 1>(v, fp, ph, 0, 0, 0, i, j));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) r = fmax(r, __shfl_xor(r, o));
+    if (threadIdx.x == 0) sm[threadIdx.y] = r;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
 }
 // LPHI and RES = rhs - LPHI on a list of rectangles (x = first column, y = first row, z = columns, w = rows) of the level: the part of
 // a composite residual that has changed since the whole level was evaluated (suhmo_hier.hip); overlapping rectangles write the same values
@@ -1913,6 +1930,23 @@ extern "C" int suhmo_level_norm(suhmo_level_t *L, int depth, int field, int ord,
     return 0;
 }
 
+// residualI of depth 0 and the max norm of the result in two launches instead of three (levels of up to scratch-many workgroups)
+int suhmo_level_residual_and_norm(suhmo_level *L, double *out, hipStream_t st)
+{
+    Depth &D = L->d[0];
+    const dim3 grd = grid2d(D.v.nx, D.v.ny);
+    const size_t np = (size_t)grd.x * grd.y;
+    int rc;
+    if (np + 4 >= L->scratch_elems) {
+        if ((rc = suhmo_level_residual(L, 0, (suhmo_stream_t)st))) return rc;
+        return suhmo_level_norm(L, 0, SUHMO_F_RES, 0, out, (suhmo_stream_t)st);
+    }
+    if ((rc = suhmo_ensure_phi_halo(L, 0, 1, st))) return rc;
+    if (D.v.alpha != 0.0) hipLaunchKernelGGL(k_residual_norm<true>, grd, BLK2D, 0, st, D.v, D.fp, L->ph, L->scratch + 2);
+    else hipLaunchKernelGGL(k_residual_norm<false>, grd, BLK2D, 0, st, D.v, D.fp, L->ph, L->scratch + 2);
+    HIPCHK(hipGetLastError());
+    return suhmo_level_norm_from_partials(L, (int)np, out, st);
+}
 // max norm of RES at depth 0 from the partial maxima the cycle's last launch left behind (suhmo_gsrb.hip, residual output): the second
 // stage of suhmo_level_norm alone
 int suhmo_level_norm_from_partials(suhmo_level *L, int np, double *out, hipStream_t st)
