@@ -115,6 +115,44 @@ def test_hier_timestep_on_strips_bitwise(case, agg, part, monkeypatch):
                     assert np.array_equal(out[r][3][l][k], mref[l][k]), (name, r, l, k, "msrc")
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("seed,world", [(1, 2), (2, 4), (3, 2), (4, 4)])
+def test_random_box_layouts_partitioned_bitwise(seed, world):
+    """box layouts grown around random points (boxes_around: nested, coarse-aligned, disjoint; some ranks may own no box of a level),
+    every finer level dealt to its owners (partition_min_cells = 1): two time steps with moulins, diffusion and the implicit gap-height
+    solve equal the single-process hierarchy on the device, bit for bit, on every rank"""
+    from suhmo_amd import model
+    rng = np.random.default_rng(4200 + seed)
+    nx0, ny0, lx, ly = 128, 64, 1.0e5, 2.0e4
+    pts = [(float(rng.uniform(0.1, 0.9) * lx), float(rng.uniform(0.1, 0.9) * ly)) for _ in range(int(rng.integers(2, 6)))]
+    boxes = sy.boxes_around(pts, nx0, ny0, 3, lx, ly, radius_cells=(int(rng.integers(3, 7)), int(rng.integers(2, 5))), max_box=int(rng.choice([16, 32])))
+    assert len(boxes) >= 1 and all(len(b) > 0 for b in boxes)
+    m = dict(sy.A3_MODEL, **B5ISH)
+    sts = sy.shmip_amrm_states(nx0, ny0, boxes, rough=0.5)
+    mb = min(MB, ny0 // world)
+    A = model.HipHierModel(nx0, ny0, sts[0][0]["dx"], sts[0][0]["dy"], sy.A3_BC, sy.A3_PHYS, m, boxes, max_box=mb)
+    A.set_states(sts)
+    mou = dict(positions=pts[:2], sigma=[900.0, 700.0], flux=[8.0, 5.0])
+    iref = A.moulin_source(**mou)
+    ref_counts = [A.timestep(m["dt"]) for _ in range(2)]
+    ref = [[{nm: A.get(l, k, nm) for nm in NAMES} for k in range(len(A.level[l]))] for l in range(len(sts))]
+    A.close()
+    out = run_strips(world, nx0, ny0, boxes, sts, m, 2, mou, mb, options="partition_min_cells=1")
+    for l in range(1, len(sts)):
+        assert sum(out[r][6][l - 1][1] for r in range(world)) == len(sts[l]) and all(out[r][6][l - 1][0] == 1 for r in range(world))
+    for r in range(world):
+        assert out[r][0] == ref_counts, (r, out[r][0], ref_counts)
+        assert np.array_equal(out[r][2], iref)
+    for nm in NAMES:
+        got = np.vstack([out[r][1][0][0][nm] for r in range(world)])
+        assert np.array_equal(got, ref[0][0][nm], equal_nan=True), (seed, 0, nm)
+    for l in range(1, len(sts)):
+        for k in range(len(sts[l])):
+            for r in range(world):
+                for nm in NAMES:
+                    assert np.array_equal(out[r][1][l][k][nm], ref[l][k][nm], equal_nan=True), (seed, r, l, k, nm)
+
+
 @pytest.mark.timeout(300)
 def test_hier_solve_on_strips_bitwise():
     """suhmo_hier_solve alone (cfg4 physics, frozen gap height) on 2 strips: iteration count, residual history and head"""
