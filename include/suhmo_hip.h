@@ -393,8 +393,8 @@ int suhmo_amr_moulin_source(suhmo_level_t **levels, int nlev, const int *patch_b
  * ONE PROCESS PER GPU: `base` may describe a rank's STRIP of level 0 (j0 / ny / ny_global as for suhmo_level_create, equal
  * strips, rank = j0 / ny; halo_rows as the strip needs them).  Level 0 -- where the cells are -- is then partitioned as a
  * single level is (halo rows over suhmo_level_attach_rccl / suhmo_level_set_hooks on suhmo_hier_box(H, 0, 0)); the boxes of
- * the levels >= 1 are held and relaxed by EVERY rank (the reference's load balancer spreads them; they are a few per cent
- * of the cells of the configurations the reference ships, exec/AMR_multiMoulins/run_C_3lev).  Level 1 reads level 0 through
+ * the levels >= 1 are held and relaxed by EVERY rank while they are small (a few per cent of the cells of the configurations
+ * the reference ships, exec/AMR_multiMoulins/run_C_3lev) and dealt to the ranks, storage and work, from partition_min_cells on (below).  Level 1 reads level 0 through
  * an all-gather of exactly the coarse cells its stencils touch (suhmo_hier_attach_rccl, or suhmo_hier_set_allgather for a
  * host transport) and writes only this rank's rows.  Results are the single-process bits. */
 typedef struct suhmo_hier suhmo_hier_t;
@@ -406,14 +406,19 @@ int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *base, int nl
  * cycle except in the cells the average from level 1 changed, and level 0's gradient is evaluated only where level 1's coarse-fine
  * interpolation reads it -- the same bits, two passes over level 0 less per cycle).  push_ghosts and incremental_residual can also
  * be changed later (suhmo_hier_set_option).
- * partition_min_cells = n (rank strips; default 500000): a finer level with at least n cells PER RANK is dealt to the ranks, boxes in
- * the order given cut into runs of about equal cell counts (the reference: LoadBalance(procIDs, grids), src/AmrHydro.cpp:4283, 4929).
- * Owner computes: the colour passes, the operator and the residual of such a level run on the owner's boxes only, and the canvases
- * they wrote travel to the other ranks' replicas in one all-gather per pass (the reference's own pattern: exchange() before every
- * colour pass, src/VCAMRNonLinearPoissonOp.cpp:692); the light passes (coefficients, axby, copies, the plans between levels) stay
- * replicated.  Below the threshold a pass over the level is shorter than the message, so every rank relaxes all boxes.  The same
- * bits either way.  Read-only through suhmo_hier_get_option: partitioned_level_<l> (0 / 1), own_boxes_level_<l> (boxes of level l
- * this rank relaxes), partition_gathers (all-gathers of canvases so far). */
+ * partition_min_cells = n (rank strips): when the levels >= 1 together hold at least n cells PER RANK they are dealt to the ranks, the boxes
+ * of a level in the order given cut into runs of about equal cell counts (the reference: LoadBalance(procIDs, grids),
+ * src/AmrHydro.cpp:4283, 4929).  OWNER COMPUTES: every pass over such a level runs on the owner's boxes only and only they (plus mirrors
+ * of the neighbours' boxes a plan of this rank reads) have storage here -- every other box is a stub (suhmo_hier_box_owner);
+ * what a plan reads of another rank's box travels as packed cells in one all-gather: before a colour pass the side cells of the colour
+ * just advanced, one cell deep, of the boxes that have a neighbour on another rank (the reference's Copier: exchange() before every
+ * colour pass, src/VCAMRNonLinearPoissonOp.cpp:692, 912-913), the coarse cells of coarse-fine stencils and correction windows, the
+ * fine cells next to coarse-fine faces for the flux register; averages onto coarse cells another rank holds travel as packed
+ * rectangles.  Below the threshold a pass over the levels is shorter than the messages, so every rank relaxes all boxes.  The same
+ * bits either way.  Read-only through suhmo_hier_get_option: partitioned_level_<l> (0 / 1), own_boxes_level_<l>, held_boxes_level_<l>
+ * (own + mirrors), owned_cells_level_<l>, canvas_bytes_level_<l> (bytes of the level's canvases on this rank),
+ * ghost_exchange_bytes_level_<l> (what this rank sends per colour-pass exchange) and ghost_exchange_bound_bytes_level_<l> (4 sides x 8 B
+ * of its boxes), partition_gathers, partition_bytes (collectives of the partition so far / bytes this rank put into them). */
 int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc_t *base, int nlev, const int *nbox, const int *boxes, const char *options);
 int suhmo_hier_set_option(suhmo_hier_t *H, const char *key, long value);
 int suhmo_hier_get_option(const suhmo_hier_t *H, const char *key, long *value);
@@ -426,6 +431,10 @@ int suhmo_hier_destroy(suhmo_hier_t *H);
 int suhmo_hier_num_levels(const suhmo_hier_t *H);
 int suhmo_hier_num_boxes(const suhmo_hier_t *H, int level);
 suhmo_level_t *suhmo_hier_box(suhmo_hier_t *H, int level, int box);   /* level 0, box 0 = the base level */
+/* the rank that owns box `box` of a level dealt to the ranks (partition_min_cells), -1: every rank holds it (a replicated level, level 0's
+ * strip), -2: no such box; *held (may be NULL): this rank keeps storage for it -- its own box or a mirror; load and read a box where it is
+ * owned (a mirror's cells are overwritten by its owner's; a box that is not held refuses field access with rc -7) */
+int suhmo_hier_box_owner(const suhmo_hier_t *H, int level, int box, int *held);
 int suhmo_hier_exchange(suhmo_hier_t *H, int level, int field, int corners, suhmo_stream_t s);
 int suhmo_hier_cf_interp(suhmo_hier_t *H, int level, int field_f, int field_c, suhmo_stream_t s);   /* from level - 1 */
 int suhmo_hier_pwl_fill(suhmo_hier_t *H, int level, int field_f, int field_c, suhmo_stream_t s);

@@ -35,6 +35,7 @@ __global__ void k_agg_unpack(SegList sl, const double *__restrict__ buf, long st
     const Seg &q = sl.e[e];
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1, r = blockIdx.y * blockDim.y + threadIdx.y;
     if (i > q.nx || r >= q.rows) return;
+    if (r >= q.roff && rk != (int)(gridDim.z / sl.n) - 1) return;        // the row a strip shares with the next one: the next one writes it
     q.dst[(size_t)(rk * q.roff + r + q.dgy) * q.dP + SUHMO_XOFF + i] = buf[(long)rk * stride + q.off + (long)r * (q.nx + 2) + (i + 1)];
 }
 // rows [jlo, jhi) of the strip's depth d_a (halo rows included) <- the rows of A that hold them; two fields per launch
@@ -91,7 +92,8 @@ int seg_of(suhmo_level *L, int d, int f, Seg &q)
     if (!src || !dst) { suhmo_set_error("field allocation failed"); return -2; }
     const DV &sv = L->d[d].v, &av = A->d[k].v;
     q.src = src; q.dst = dst; q.sP = sv.P; q.sgy = sv.gy; q.dP = av.P; q.dgy = av.gy; q.nx = sv.nx;
-    q.rows = sv.ny + (f == SUHMO_F_BY ? 1 : 0);           // y-faces: face row ny of a strip is face row 0 of the next (the same value); the last strip's closes A
+    q.rows = sv.ny + (f == SUHMO_F_BY ? 1 : 0);           // y-faces: face row ny of a strip is face row 0 of the next: every rank sends it (one layout for
+                                                          // all ranks), only the LAST rank's is unpacked (it closes A): one writer per row of A
     q.roff = sv.ny; q.off = 0;
     return 0;
 }
@@ -101,7 +103,7 @@ void suhmo_agg_release(suhmo_level *L)
 {
     if (L->agg) { suhmo_level_destroy(L->agg); L->agg = nullptr; }
     if (L->agg_send) { (void)hipFree(L->agg_send); (void)hipFree(L->agg_recv); L->agg_send = L->agg_recv = nullptr; }
-    L->agg_cap = 0; L->agg_depth = 0;
+    L->agg_cap = 0; L->agg_depth = 0; L->agg_static_stale = 0;
 }
 
 // decide d_a and create A; called when the all-gather transport is attached (and when agg_min_cells changes)
@@ -128,6 +130,7 @@ int suhmo_agg_setup(suhmo_level *L)
     }
     A->graph_max_cells = 0;                                                  // driven depth by depth from the strip's cycle
     L->agg = A; L->agg_depth = da; L->agg_world = v0.nyg / v0.ny; L->agg_rank = v0.j0 / v0.ny;
+    L->agg_static_stale = 1;                                                 // (nothing of the level's coefficients is in A yet: suhmo_agg_gather_static)
     return 0;
 }
 
@@ -148,6 +151,7 @@ int suhmo_agg_gather_static(suhmo_level *L, bool with_faces, hipStream_t st)
         }
     }
     if ((rc = gather(L, segs, st))) return rc;
+    L->agg_static_stale = 0;
     for (int k = 0; k < L->agg->ndepth; k++)
         for (int f : {SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB, SUHMO_F_MASK}) if ((rc = suhmo_copy_ghosts(L->agg, k, f, st))) return rc;
     return 0;

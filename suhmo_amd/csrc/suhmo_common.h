@@ -139,6 +139,7 @@ struct ProfEv { hipEvent_t a, b; long cells; int restricts; };   // restricts: t
 
 struct suhmo_level {
     int ndepth;
+    int stub;                   // geometry only: no canvas, no scratch (a box of a partitioned AMR level held by other ranks; suhmo_hier.hip)
     Depth d[SUHMO_MAXDEPTH];
     suhmo_level_desc_t desc;
     std::vector<int> boxes;     // nbox x 4, global indices, depth 0
@@ -166,6 +167,7 @@ struct suhmo_level {
     long agg_min_cells;         // depths whose strip holds fewer cells are agglomerated (env SUHMO_AGG_MIN_CELLS, default 100000: at 4096^2 cells per strip the two deepest of six depths; 0 = off)
     int agg_depth, agg_world, agg_rank;
     suhmo_level *agg;
+    int agg_static_stale;       // A was (re)created after the last coefficient build: its B / Pi / zb / mask / aCoef / faces are gathered before the cycle enters it
     suhmo_allgather_fn ag; void *ag_user;
     double *agg_send, *agg_recv; size_t agg_cap; long agg_gathers;
     // the solve loops ask the cycle to leave the residual of its final phi behind (suhmo_gsrb.hip, RM = 2): resout_req bit 0 RES, bit 1 LPHI
@@ -219,6 +221,8 @@ struct SuhmoTimer { const char *name; double t0; int mode; explicit SuhmoTimer(c
 #define ARG(cond) do { if (!(cond)) { suhmo_set_error("%s:%d bad argument: %s", __FILE__, __LINE__, #cond); return -1; } } while (0)
 
 double *suhmo_field(suhmo_level *L, int depth, int field);   // lazily allocates
+int suhmo_level_create_(suhmo_level_t **out, const suhmo_level_desc_t *desc, bool stub);   // suhmo_level.hip
+int suhmo_level_materialize_(suhmo_level *L);
 // Two canvases of a level trade places while its FAS problem runs (the level's own right-hand side is set aside): whatever way the
 // scope is left -- an exchange or all-gather hook failing in between included -- they trade back, so a caller that catches the
 // error still holds the problem it posed

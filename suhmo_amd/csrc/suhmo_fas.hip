@@ -66,6 +66,8 @@ static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, i
         // phi and R phi come back, so the prolongation below needs no exchange either
         suhmo_level *A = L->agg;
         const int ndA = nd - L->agg_depth;
+        // A created after the coefficients were built (agg_min_cells set, or the transport attached, later): its copies of them first
+        if (L->agg_static_stale && (rc = suhmo_agg_gather_static(L, true, (hipStream_t)s))) return rc;
         if ((rc = suhmo_agg_gather_state(L, (hipStream_t)s))) return rc;
         const int next_sweeps = ndA == 1 ? sp->num_bottom : S;
         if (suhmo_gsrb_can_fuse_rhs(A, 0, next_sweeps)) A->d[0].rhs_pending = 1;

@@ -97,6 +97,7 @@ int suhmo_gsrb_colour_pass(suhmo_level *L, int depth, int pass, hipStream_t st)
 
 int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int pass, hipStream_t st, bool push)
 {
+    if (m.nbox <= 0) return 0;                       // a rank that owns no box of the level
     dim3 blk(64, 4), grd(((m.maxnx + 1) / 2 + 63) / 64, (m.maxny + 3) / 4, m.nbox);
     const int2 *pp = push ? (const int2 *)m.push : nullptr;
     if (has_alpha) hipLaunchKernelGGL(k_gsrb_pass_simple_m<true>, grd, blk, 0, st, m.dv, m.fp, ph, pass, pp, m.pbase);

@@ -31,4 +31,11 @@ int suhmo_multi_norm_max(const suhmo_multi &m, suhmo_level *slot, int field, dou
 int suhmo_hier_multi_(suhmo_hier *H, int l, hipStream_t st, suhmo_multi *m);       // l >= 1
 int suhmo_hier_ensure_(suhmo_hier *H, int l, int field);                            // allocate a field on every box of a level
 void suhmo_hier_invalidate_(suhmo_hier *H);                                         // an entry point outside suhmo_hier.hip: the caller may have loaded new data
-const double *suhmo_hier_base_cover_(suhmo_hier *H, DV *whole);                     // level 0 cut into rank strips: COVER of the WHOLE level and its view; else NULL
+const double *suhmo_hier_base_cover_(suhmo_hier *H, DV *whole);
+// owner computes (levels >= 1 dealt to the ranks): is it on; the boxes of level l this rank owns (everything suhmo_hier_multi_ launches on);
+// MAX over the ranks of a value each computed on its own boxes; the all-gather of the hierarchy (device buffers, `count` doubles per rank)
+bool suhmo_hier_partitioned_(const suhmo_hier *H);
+void suhmo_hier_owned_(const suhmo_hier *H, int l, int *first, int *n);
+int suhmo_hier_allreduce_max_(suhmo_hier *H, double *v);
+int suhmo_hier_allgather_(suhmo_hier *H, const double *send, long count, double *recv, hipStream_t st);
+int suhmo_hier_world_(const suhmo_hier *H);                     // level 0 cut into rank strips: COVER of the WHOLE level and its view; else NULL

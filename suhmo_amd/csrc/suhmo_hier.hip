@@ -101,7 +101,17 @@ struct BoxIndex {
     }
 };
 
-struct PartEnt { long off; int elems, owner; };
+// ---- levels dealt to the ranks (owner computes).  A cell that a plan executed on one rank reads from a box another rank owns travels
+// as ONE packed value: the owner packs the cells somebody needs (send, in a fixed order), one all-gather moves every rank's segment,
+// the reader scatters what it needs into its MIRROR of the owner's box (recv: mirror cell, owner rank, position in that segment).
+// Mirrors exist only for boxes some plan of this rank reads; every other foreign box is a stub without storage.
+struct SyncRecv { Ref d; int rank, pos; };
+struct Sync {
+    DevVec<Ref> send; DevVec<SyncRecv> recv; long stride = 0;         // stride: longest segment over the ranks (0: nothing travels, no collective)
+    void release() { send.release(); recv.release(); stride = 0; }
+};
+struct Xf { int owner, b, off, reader; };                             // plan building: cell (b, off) of `owner` is read on `reader`
+struct PutEnt { int cb, coff, rank, pos, w, h; };                     // w x h averaged cells arriving in `rank`'s segment at pos -> box cb at coff
 struct HLev {
     int l = 0, nxd = 0, nyd = 0;
     std::vector<suhmo_level *> box;
@@ -124,13 +134,21 @@ struct HLev {
     unsigned long tab_epoch = 0;                                  // suhmo_fp_epoch() the tables were last compared at
     unsigned long long ensured = 0;                               // fields every box is known to have
     double *d_red = nullptr; int maxnx = 0, maxny = 0;            // reduction scratch (64 nbox + 16 doubles), largest box
-    // ---- owner computes (rank strips, option partition_min_cells): boxes own[r] .. own[r+1] belong to rank r.  The passes that carry the
-    // level's arithmetic (colour passes, operator / residual) run on the owner's boxes only; the canvases they wrote then travel to the
-    // other ranks' replicas in one all-gather (segment of rank r = the canvases of its boxes, one after the other: pent[k].off)
+    // ---- owner computes (rank strips, creation option partition_min_cells): boxes own[r] .. own[r+1] belong to rank r (LoadBalance,
+    // src/AmrHydro.cpp:4283, 4929).  EVERY pass over the level runs on the owner's boxes only; plans are executed by the owner of the cell
+    // they write; what they read of other ranks' boxes travels as packed cells (Sync), what they write into them (averages) as packed
+    // rectangles (avg_put / avg_get).  The ghost exchange before a colour pass (Copier::exchange, src/VCAMRNonLinearPoissonOp.cpp:692,
+    // 912-913) moves the side cells of ONE colour of the boxes that have a neighbour on another rank and nothing else.
     bool part = false;
-    std::vector<int> own;
-    DevVec<PartEnt> pent; long part_max = 0; int part_maxelems = 0;
-    double *ps = nullptr, *pr = nullptr;
+    std::vector<int> own, owner;                     // owner[k]
+    std::vector<char> held;                          // this rank keeps storage for box k (its own, or a mirror some plan here reads)
+    int b0 = 0, nown = 0;                            // this rank's boxes: b0 .. b0 + nown
+    Sync sy_side[2], sy_sides, sy_all;               // cells of THIS level: sources of fine-fine side ghosts by colour / both colours / sides + corners
+    Sync sy_cread, sy_win;                           // cells of level l-1 (>= 1) the stencils / the correction windows of this level's plans read here
+    Sync sy_fface;                                   // cells of THIS level the reflux into level l-1 reads on the owners of the coarse cells
+    DevVec<RectEnt> avg_cov; int cov_w = 0, cov_h = 0;       // covered rectangles by the owner of the COARSE cells (zeroing / marking them)
+    DevVec<RectEnt> avg_put; DevVec<PutEnt> avg_get; long put_stride = 0, put_mine = 0; int put_w = 0, put_h = 0, get_w = 0, get_h = 0;
+    long owned_cells = 0, held_boxes = 0;
 };
 }  // namespace
 
@@ -171,9 +189,15 @@ struct suhmo_hier {
     // evaluation then needs no pass over level 0 at all
     unsigned long base_fused_ver = 0;
     bool incremental = true;                               // option incremental_residual
-    long part_min_cells = 500000;                          // creation option partition_min_cells: a level of boxes with at least this many cells
-                                                           // PER RANK is relaxed by its owners (below it a pass is shorter than the message)
-    long part_gathers = 0;
+    long part_min_cells = 500000;                          // creation option partition_min_cells: levels >= 1 that hold at least this many cells
+                                                           // PER RANK (all of them together) are dealt to the ranks (below it a pass is shorter than the message)
+    bool part = false;                                     // ... they are
+    long part_gathers = 0, part_bytes = 0;                 // collectives of the partition; bytes THIS rank contributed to them
+    long side_bytes[8] = {};                               // bytes this rank contributes to ONE colour-pass ghost exchange of level l (the larger colour)
+    double *ps = nullptr, *pr = nullptr; size_t pcap = 0;  // staging of those collectives (pcap doubles per rank)
+    // read-only counters (suhmo_hier_get_option): composite residuals of level 0 evaluated on the dirty rectangles only / not at all (left
+    // behind by the launch that ended level 0's V-cycle), coarse gradients evaluated on the cell list only
+    long n_incr_residual = 0, n_fused_residual = 0, n_sparse_grad = 0;
     DevVec<RectEnt> cover_full;                            // coarsen(boxes of level 1) in the shadow: COVER of the whole level 0
 };
 
@@ -290,6 +314,30 @@ __global__ void k_avg(const RectEnt *__restrict__ e, const FP *__restrict__ ftab
     s = s + f[b]; s = s + f[b + 1]; s = s + f[b + Pf]; s = s + f[b + Pf + 1];
     c[q.coff + J * Pc + I] = s * 0.25;
 }
+// owner computes: the same averages into this rank's segment of an all-gather (q.coff = position, pitch = q.w) ...
+__global__ void k_avg_put(const RectEnt *__restrict__ e, const FP *__restrict__ ftab, const DV *__restrict__ fdv, int ff, double *__restrict__ buf)
+{
+    RectEnt q = e[blockIdx.z];
+    int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y * blockDim.y + threadIdx.y;
+    if (I >= q.w || J >= q.h) return;
+    const int Pf = fdv[q.fb].P;
+    const double *f = ftab[q.fb].f[ff];
+    int b = q.foff + 2 * J * Pf + 2 * I;
+    double s = 0.0;
+    s = s + f[b]; s = s + f[b + 1]; s = s + f[b + Pf]; s = s + f[b + Pf + 1];
+    buf[q.coff + (long)J * q.w + I] = s * 0.25;
+}
+// ... and the holder of the coarse cells takes its rectangles out of the writers' segments
+__global__ void k_put_unpack(const PutEnt *__restrict__ e, const FP *__restrict__ ctab, const DV *__restrict__ cdv, FP cbase, DV cbdv, int use_base, int fc,
+                             const double *__restrict__ buf, long stride)
+{
+    PutEnt q = e[blockIdx.z];
+    int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y * blockDim.y + threadIdx.y;
+    if (I >= q.w || J >= q.h) return;
+    const int Pc = use_base ? cbdv.P : cdv[q.cb].P;
+    double *c = fptr(ctab, cbase, use_base, q.cb, fc);
+    c[q.coff + J * Pc + I] = buf[(long)q.rank * stride + q.pos + (long)J * q.w + I];
+}
 // old != NULL: the window gets c - old (the correction phi - phi_saved, as axby(phi, saved, 1, -1) states it), old being an earlier
 // gather of the same cells
 __global__ void k_win_gather(const WinEnt *__restrict__ e, double *__restrict__ wbuf, const FP *__restrict__ ctab, const DV *__restrict__ cdv,
@@ -385,6 +433,28 @@ __global__ void k_reflux(const Target *__restrict__ tg, int n, const Face *__res
 }
 
 // ------------------------------------------------------------------ plan building (host)
+// transfers (owner, cell, reader) of one kind -> this rank's part of the exchange: the cells it packs (what anybody reads of its boxes, sorted:
+// position = rank in that order), the cells it unpacks into its mirrors of V's boxes (marked as held), the longest segment
+int make_sync(suhmo_hier *H, HLev &V, std::vector<Xf> &x, Sync &S)
+{
+    const int me = H->rank;
+    auto key = [](const Xf &a, const Xf &b) { return a.owner != b.owner ? a.owner < b.owner : a.b != b.b ? a.b < b.b : a.off != b.off ? a.off < b.off : a.reader < b.reader; };
+    std::sort(x.begin(), x.end(), key);
+    x.erase(std::unique(x.begin(), x.end(), [](const Xf &a, const Xf &b) { return a.owner == b.owner && a.b == b.b && a.off == b.off && a.reader == b.reader; }), x.end());
+    std::vector<Ref> send; std::vector<SyncRecv> recv;
+    std::vector<long> cnt(H->world, 0);
+    for (size_t t = 0; t < x.size();) {                     // one cell of one owner, its readers
+        size_t u = t;
+        bool mine = false;
+        while (u < x.size() && x[u].owner == x[t].owner && x[u].b == x[t].b && x[u].off == x[t].off) { mine = mine || x[u].reader == me; u++; }
+        const int pos = (int)cnt[x[t].owner]++;
+        if (x[t].owner == me) send.push_back(Ref{x[t].b, x[t].off});
+        else if (mine) { recv.push_back(SyncRecv{Ref{x[t].b, x[t].off}, x[t].owner, pos}); V.held[x[t].b] = 1; }
+        t = u;
+    }
+    S.stride = *std::max_element(cnt.begin(), cnt.end());
+    return S.send.upload(send) | S.recv.upload(recv);
+}
 int build_plans(suhmo_hier *H, int l)
 {
     HLev &F = H->lev[l], &C = H->lev[l - 1];
@@ -404,6 +474,15 @@ int build_plans(suhmo_hier *H, int l)
     std::vector<int4> dirty0; std::vector<std::pair<int, int>> gcell;        // (level l == 1)
     std::vector<RectEnt> cover_full;
     auto note = [&](const Ref &r) { if (cut && r.b >= 0) needv.push_back(r.off); };
+    // owner computes: who executes what.  ownF / ownC: the rank that holds box k of this level / box o of level l-1 (a replicated level:
+    // every rank, i.e. "me"); a cell of a cut level 0 belongs to the strip its row lies in, and is READ through the shadow
+    const bool P = F.part;
+    const int me = H->rank;
+    auto ownF = [&](int k) { return P ? F.owner[k] : me; };
+    auto ownC = [&](int o) { return (P && C.l >= 1) ? C.owner[o] : me; };
+    std::vector<Xf> x_side[2], x_all, x_cread, x_win, x_fface;
+    std::vector<RectEnt> avg_cov, avg_put; std::vector<PutEnt> avg_get;
+    std::vector<long> putpos(H->world, 0);
     auto good_cell = [&](int I, int J) -> bool {          // coarse cell (I,J) of level l-1 good for tangential stencils?
         if (!wrap_cell(H, C, I, J)) return false;
         return F.index.find(2 * I, 2 * J) < 0;
@@ -418,18 +497,23 @@ int build_plans(suhmo_hier *H, int l)
                 if (!gx && !gy) continue;
                 int iw = i, jw = j;
                 if (!wrap_cell(H, F, iw, jw)) continue;                       // domain ghost
-                const Ref me = local_ref(F, k, i - b[0], j - b[1]);
+                const Ref mine = local_ref(F, k, i - b[0], j - b[1]);
                 const int o = F.index.find(iw, jw);
                 if (o >= 0) {
                     const DV &vo = F.box[o]->d[0].v;
-                    CopyEnt e{me, Ref{o, cidx(vo, iw - vo.i0, jw - vo.j0)}};
-                    (gx && gy ? ffc : ffs).push_back(e);
+                    CopyEnt e{mine, Ref{o, cidx(vo, iw - vo.i0, jw - vo.j0)}};
+                    if (P && F.owner[o] != F.owner[k]) {                      // the source cell travels to the owner of the ghost
+                        const Xf x{F.owner[o], e.s.b, e.s.off, F.owner[k]};
+                        x_all.push_back(x);
+                        if (!(gx && gy)) x_side[(iw + jw) & 1].push_back(x);
+                    }
+                    if (ownF(k) == me) (gx && gy ? ffc : ffs).push_back(e);
                     continue;
                 }
                 // coarse-fine cell
                 {
                     PwlEnt p;
-                    p.f = me; p.par = (iw & 1) | ((jw & 1) << 1);
+                    p.f = mine; p.par = (iw & 1) | ((jw & 1) << 1);
                     const int I = iw >> 1, J = jw >> 1;
                     for (int jj = -1; jj <= 1; jj++)
                         for (int ii = -1; ii <= 1; ii++) {
@@ -441,16 +525,17 @@ int build_plans(suhmo_hier *H, int l)
                             }
                             p.c[(jj + 1) * 3 + (ii + 1)] = r;
                             note(r);
+                            if (P && C.l >= 1 && r.b >= 0 && C.owner[r.b] != F.owner[k]) x_cread.push_back(Xf{C.owner[r.b], r.b, r.off, F.owner[k]});
                         }
                     p.sx = (I - 1 >= 0 && I + 1 <= C.nxd - 1) ? 0 : (I - 1 < 0 ? 1 : 2);
                     p.sy = (J - 1 >= 0 && J + 1 <= C.nyd - 1) ? 0 : (J - 1 < 0 ? 1 : 2);
-                    pwl.push_back(p);
+                    if (ownF(k) == me) pwl.push_back(p);
                 }
                 if (gx && gy) continue;                                       // QuadCFInterp: sides only
                 const int dir = gx ? 0 : 1, side = gx ? (i < b[0] ? 0 : 1) : (j < b[1] ? 0 : 1);
                 const int g = dir == 0 ? i : j, t = dir == 0 ? j : i;
                 CfEnt e;
-                e.f = me; e.step = (side == 0 ? 1 : -1) * (dir == 0 ? 1 : v.P);
+                e.f = mine; e.step = (side == 0 ? 1 : -1) * (dir == 0 ? 1 : v.P);
                 e.xsign = t & 1;
                 const int icn = g >> 1, ict = t >> 1;
                 auto good = [&](int o_) { return dir == 0 ? good_cell(icn, ict + o_) : good_cell(ict + o_, icn); };
@@ -465,13 +550,14 @@ int build_plans(suhmo_hier *H, int l)
                     e.c[m] = m < nneed ? cref(need[m]) : Ref{0, 0};
                     if (m < nneed && e.c[m].b < 0) { suhmo_set_error("hier: level %d is not properly nested in level %d (coarse-fine stencil)", l, l - 1); return -1; }
                     if (m < nneed) note(e.c[m]);
+                    if (m < nneed && P && C.l >= 1 && C.owner[e.c[m].b] != F.owner[k]) x_cread.push_back(Xf{C.owner[e.c[m].b], e.c[m].b, e.c[m].off, F.owner[k]});
                     if (m < nneed && C.l == 0) {                              // the coarse cell, wrapped into the domain (as cell_ref did)
                         int I = dir == 0 ? icn : ict + need[m], J = dir == 0 ? ict + need[m] : icn;
                         (void)wrap_cell(H, C, I, J);
                         gcell.push_back(std::make_pair(J, I));
                     }
                 }
-                cf.push_back(e);
+                if (ownF(k) == me) cf.push_back(e);
             }
         // ---- average / covered rectangles: coarsen(box) split over the boxes of level l-1
         const int ci0 = b[0] / 2, cj0 = b[1] / 2, ci1 = b[2] / 2, cj1 = b[3] / 2;
@@ -496,19 +582,30 @@ int build_plans(suhmo_hier *H, int l)
             return 0;
         };
         int rc = split(ci0, cj0, ci1, cj1, [&](int o, int a0, int c0, int a1, int c1) {
-            if (cut) {                                                  // the rows of this rank's strip
-                cover_full.push_back(RectEnt{k, 0, 0, cidx(H->vglob, a0, c0), a1 - a0 + 1, c1 - c0 + 1});
-                c0 = std::max(c0, sv.j0); c1 = std::min(c1, sv.j0 + sv.ny - 1);
-                if (c0 > c1) return;
-            }
+            if (cut) cover_full.push_back(RectEnt{k, 0, 0, cidx(H->vglob, a0, c0), a1 - a0 + 1, c1 - c0 + 1});
             const DV &vc = C.box[o]->d[0].v;
-            avg.push_back(RectEnt{k, o, cidx(v, 2 * a0 - b[0], 2 * c0 - b[1]), cidx(vc, a0 - vc.i0, c0 - vc.j0), a1 - a0 + 1, c1 - c0 + 1});
+            // the piece by the rank that holds its coarse cells: a strip of a cut level 0 (its rows), the owner of coarse box o, or everybody
+            const int r0 = (C.l == 0 && cut) ? c0 / sv.ny : 0, r1 = (C.l == 0 && cut) ? c1 / sv.ny : 0;
+            for (int r = r0; r <= r1; r++) {
+                int d0 = c0, d1 = c1, dest = ownC(o);
+                if (C.l == 0 && cut) { d0 = std::max(c0, r * sv.ny); d1 = std::min(c1, r * sv.ny + sv.ny - 1); dest = r; }
+                if (d0 > d1) continue;
+                const int w = a1 - a0 + 1, h = d1 - d0 + 1, writer = ownF(k);
+                const int foff = cidx(v, 2 * a0 - b[0], 2 * d0 - b[1]), coff = cidx(vc, a0 - vc.i0, d0 - vc.j0);
+                if (dest == me) avg_cov.push_back(RectEnt{k, o, foff, coff, w, h});
+                if (!P) { if (dest == me) avg.push_back(RectEnt{k, o, foff, coff, w, h}); continue; }      // a replicated level: every rank averages into what it holds
+                if (writer == dest) { if (writer == me) avg.push_back(RectEnt{k, o, foff, coff, w, h}); continue; }
+                // the owner of the fine box averages into its segment of an all-gather, the holder of the coarse cells takes them from there
+                if (writer == me) avg_put.push_back(RectEnt{k, 0, foff, (int)putpos[writer], w, h});
+                if (dest == me) avg_get.push_back(PutEnt{o, coff, writer, (int)putpos[writer], w, h});
+                putpos[writer] += (long)w * h;
+            }
         });
         if (rc) return rc;
         // ---- window: coarsen(box) grown by one cell, gathered from level l-1 (periodic images included)
         Win &w = F.win[k];
         w.i0 = ci0 - 1; w.j0 = cj0 - 1; w.nx = ci1 - ci0 + 3; w.ny = cj1 - cj0 + 3; w.base = wtot;
-        wtot += (size_t)w.nx * w.ny;
+        if (ownF(k) == me) wtot += (size_t)w.nx * w.ny;                      // (only the windows of this rank's boxes exist)
         for (int sy = -1; sy <= 1; sy++)
             for (int sx = -1; sx <= 1; sx++) {
                 if ((sx && !H->bc.periodic[0]) || (sy && !H->bc.periodic[1])) continue;
@@ -523,6 +620,9 @@ int build_plans(suhmo_hier *H, int l)
                         if (d0 <= d1) dirty0.push_back(int4{a0, d0 - sv.j0, a1 - a0 + 1, d1 - d0 + 1});
                     }
                     if (cut) for (int J = c0; J <= c1; J++) for (int I = a0; I <= a1; I++) needv.push_back(cidx(vc, I, J));
+                    if (P && C.l >= 1 && C.owner[o] != F.owner[k])
+                        for (int J = c0; J <= c1; J++) for (int I = a0; I <= a1; I++) x_win.push_back(Xf{C.owner[o], o, cidx(vc, I - vc.i0, J - vc.j0), F.owner[k]});
+                    if (ownF(k) != me) return;
                     wing.push_back(WinEnt{o, cidx(vc, a0 - vc.i0, c0 - vc.j0), (c0 + sy * C.nyd - w.j0) * w.nx + (a0 + sx * C.nxd - w.i0), a1 - a0 + 1, c1 - c0 + 1});
                     wing_box.push_back(k);
                 });
@@ -566,11 +666,27 @@ int build_plans(suhmo_hier *H, int l)
     for (auto &key : order) {
         auto &fv = by_target[key];
         Ref t{key.first, key.second};
-        if (cut) {                                                      // a cell of the shadow -> the same cell of this rank's strip, or none
+        // the register of a coarse cell is added up by the rank that holds the cell: a strip of a cut level 0 (the cell of the shadow -> the
+        // same cell of that strip), the owner of its box, or everybody
+        int exec = me;
+        if (cut) {
             const int J = t.off / H->vglob.P - H->vglob.gy, I = t.off % H->vglob.P - SUHMO_XOFF;
-            if (J < sv.j0 || J >= sv.j0 + sv.ny) continue;
-            t.off = cidx(sv, I, J - sv.j0);
-        }
+            exec = J / sv.ny;
+            if (exec == me) t.off = cidx(sv, I, J - sv.j0);
+        } else if (C.l >= 1) exec = ownC(t.b);
+        if (P)
+            for (const Face &f : fv) {
+                if (F.owner[f.fb] != exec) {                            // the fine cells and faces the register reads (k_reflux)
+                    const int Pf = F.box[f.fb]->d[0].v.P;
+                    for (int kk = 0; kk < 2; kk++) {
+                        const int idx = f.foff + (f.dir == 0 ? kk * Pf : kk);
+                        x_fface.push_back(Xf{F.owner[f.fb], f.fb, idx, exec});
+                        x_fface.push_back(Xf{F.owner[f.fb], f.fb, f.dir == 0 ? idx - 1 : idx - Pf, exec});
+                    }
+                }
+                if (C.l >= 1) for (const Ref &r : {f.hi, f.lo}) if (C.owner[r.b] != exec) x_cread.push_back(Xf{C.owner[r.b], r.b, r.off, exec});
+            }
+        if (exec != me) continue;
         targets.push_back(Target{t, (int)faces.size(), (int)fv.size()});
         faces.insert(faces.end(), fv.begin(), fv.end());
     }
@@ -591,7 +707,7 @@ int build_plans(suhmo_hier *H, int l)
         if (H->need.upload(needv) || H->need_rl.upload(rl) || H->cover_full.upload(cover_full)) { suhmo_set_error("hier: plan upload failed"); return -2; }
     }
     int rc = 0;
-    {   // the side copies by source cell: per box W, E (ny entries each), S, N (nx each)
+    if (!P) {   // the side copies by source cell: per box W, E (ny entries each), S, N (nx each)
         std::vector<int> pbase(nb);
         size_t tot = 0;
         for (int k = 0; k < nb; k++) { const DV &v = F.box[k]->d[0].v; pbase[k] = (int)tot; tot += 2 * (size_t)(v.nx + v.ny); }
@@ -615,6 +731,19 @@ int build_plans(suhmo_hier *H, int l)
     rc |= F.ff_side.upload(ffs);
     { std::vector<CopyEnt> all(ffs); all.insert(all.end(), ffc.begin(), ffc.end()); rc |= F.ff_all.upload(all); } rc |= F.cf.upload(cf); rc |= F.pwl.upload(pwl);
     rc |= F.avg.upload(avg); rc |= F.wing.upload(wing); rc |= F.targets.upload(targets); rc |= F.faces.upload(faces);
+    rc |= F.avg_cov.upload(avg_cov);
+    for (auto &e : avg_cov) { F.cov_w = std::max(F.cov_w, e.w); F.cov_h = std::max(F.cov_h, e.h); }
+    if (P) {
+        rc |= F.avg_put.upload(avg_put); rc |= F.avg_get.upload(avg_get);
+        F.put_stride = *std::max_element(putpos.begin(), putpos.end());
+        for (auto &e : avg_put) { F.put_w = std::max(F.put_w, e.w); F.put_h = std::max(F.put_h, e.h); F.put_mine += (long)e.w * e.h; }
+        for (auto &e : avg_get) { F.get_w = std::max(F.get_w, e.w); F.get_h = std::max(F.get_h, e.h); }
+        std::vector<Xf> x_sides(x_side[0]); x_sides.insert(x_sides.end(), x_side[1].begin(), x_side[1].end());
+        rc |= make_sync(H, F, x_side[0], F.sy_side[0]); rc |= make_sync(H, F, x_side[1], F.sy_side[1]); rc |= make_sync(H, F, x_sides, F.sy_sides);
+        rc |= make_sync(H, F, x_all, F.sy_all); rc |= make_sync(H, F, x_fface, F.sy_fface);
+        if (C.l >= 1) { rc |= make_sync(H, C, x_cread, F.sy_cread); rc |= make_sync(H, C, x_win, F.sy_win); }
+        H->side_bytes[l] = 8 * (long)std::max(F.sy_side[0].send.n, F.sy_side[1].send.n);
+    }
     if (C.l == 0) {
         std::sort(gcell.begin(), gcell.end());
         gcell.erase(std::unique(gcell.begin(), gcell.end()), gcell.end());
@@ -678,7 +807,10 @@ int ensure_field(suhmo_hier *H, int l, int field)
 {
     HLev &V = H->lev[l];
     if (V.ensured >> field & 1ull) return 0;
-    for (suhmo_level *L : V.box) if (!suhmo_field(L, 0, field)) { suhmo_set_error("field allocation failed"); return -2; }
+    for (size_t k = 0; k < V.box.size(); k++) {
+        if (V.part && !V.held[k]) continue;                            // a box other ranks hold: no storage here
+        if (!suhmo_field(V.box[k], 0, field)) { suhmo_set_error("field allocation failed"); return -2; }
+    }
     V.ensured |= 1ull << field;
     return 0;
 }
@@ -749,6 +881,55 @@ int refresh_base(suhmo_hier *H, const int *fields, int nf, hipStream_t st)
 }
 inline int refresh_base1(suhmo_hier *H, int field, hipStream_t st) { return refresh_base(H, &field, 1, st); }
 
+// ---- owner computes: packed cells from their owners to the mirrors of the ranks that read them
+struct FIdx { int f[XF]; int n; };
+__global__ void k_sync_pack(const Ref *__restrict__ e, int n, const FP *__restrict__ tab, FIdx fl, double *__restrict__ buf, long stride)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const Ref q = e[t];
+    for (int f = 0; f < fl.n; f++) buf[f * stride + t] = tab[q.b].f[fl.f[f]][q.off];
+}
+__global__ void k_sync_unpack(const SyncRecv *__restrict__ e, int n, const FP *__restrict__ tab, FIdx fl, const double *__restrict__ buf, long stride)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const SyncRecv q = e[t];
+    for (int f = 0; f < fl.n; f++) tab[q.d.b].f[fl.f[f]][q.d.off] = buf[((long)q.rank * fl.n + f) * stride + q.pos];
+}
+int part_staging(suhmo_hier *H, size_t doubles, hipStream_t st)
+{
+    if (doubles <= H->pcap) return 0;
+    if (H->ps) { HIPCHK(hipStreamSynchronize(st)); (void)hipFree(H->ps); (void)hipFree(H->pr); H->ps = H->pr = nullptr; }
+    H->pcap = doubles + doubles / 4 + 64;
+    HIPCHK(hipMalloc(&H->ps, H->pcap * sizeof(double)));
+    HIPCHK(hipMalloc(&H->pr, H->pcap * H->world * sizeof(double)));
+    HIPCHK(hipMemsetAsync(H->ps, 0, H->pcap * sizeof(double), st));
+    return 0;
+}
+// fields of level lt (the level whose cells S lists) from their owners into this rank's mirrors; collective over the ranks (skipped by all
+// of them alike when nothing of this kind travels anywhere)
+int sync_run(suhmo_hier *H, int lt, Sync &S, const int *fields, int nf, hipStream_t st)
+{
+    if (S.stride == 0) return 0;
+    SUHMO_TIME("hier: exchange of packed cells between the owners of a level's boxes");
+    if (!H->ag) { suhmo_set_error("hier: level %d is partitioned over the ranks and no all-gather is attached (suhmo_hier_attach_rccl / suhmo_hier_set_allgather)", lt); return -1; }
+    ARG(nf >= 1 && nf <= XF);
+    int rc;
+    FIdx fl; fl.n = nf;
+    for (int f = 0; f < nf; f++) { fl.f[f] = fields[f]; if ((rc = ensure_field(H, lt, fields[f]))) return rc; }
+    if ((rc = refresh_tables(H, lt, st)) || (rc = part_staging(H, (size_t)nf * S.stride, st))) return rc;
+    HLev &V = H->lev[lt];
+    if (S.send.n) hipLaunchKernelGGL(k_sync_pack, g1(S.send.n), dim3(256), 0, st, S.send.d, (int)S.send.n, V.d_fp, fl, H->ps, S.stride);
+    HIPCHK(hipGetLastError());
+    if ((rc = H->ag(H->ag_user, H->ps, (long)nf * S.stride, H->pr, (suhmo_stream_t)st))) return rc;
+    H->part_gathers++; H->part_bytes += 8L * nf * (long)S.send.n;
+    if (S.recv.n) hipLaunchKernelGGL(k_sync_unpack, g1(S.recv.n), dim3(256), 0, st, S.recv.d, (int)S.recv.n, V.d_fp, fl, H->pr, S.stride);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+inline int sync1(suhmo_hier *H, int lt, Sync &S, int field, hipStream_t st) { return sync_run(H, lt, S, &field, 1, st); }
+
 // coarse-side arguments of a kernel that reads / writes level l-1.  base / bdv: where the cells of level 0 are READ (the shadow
 // of a cut level 0); dst / ddv: where they are written (the level, or this rank's strip of it)
 struct CoarseArgs { const FP *tab; const DV *dv; FP base; DV bdv; FP dst; DV ddv; int use_base; };
@@ -772,13 +953,15 @@ int multi_of(suhmo_hier *H, int l, hipStream_t st, suhmo_multi &m)
     HLev &V = H->lev[l];
     m.dv = V.d_dv; m.fp = V.d_fp; m.nbox = (int)V.box.size(); m.maxnx = V.maxnx; m.maxny = V.maxny; m.red = V.d_red;
     m.push = V.push.d; m.pbase = V.pbase.d;
+    if (V.part) { m.dv += V.b0; m.fp += V.b0; m.nbox = V.nown; m.push = nullptr; m.pbase = nullptr; }   // owner computes: the tables from this rank's first box
     return 0;
 }
 inline const suhmo_phys_t &phys_of(suhmo_hier *H, int l) { return H->lev[l].box[0]->ph; }
 inline bool has_alpha(suhmo_hier *H, int l) { return H->lev[l].box[0]->d[0].v.alpha != 0.0; }
 
 // Copier::exchange of one or two cell fields of level l
-int hier_ff(suhmo_hier *H, int l, int f0, int f1, bool corners, hipStream_t st)
+// colour >= 0 (owner computes, after a colour pass of the head): only the side cells of that colour have changed and travel
+int hier_ff(suhmo_hier *H, int l, int f0, int f1, bool corners, hipStream_t st, int colour = -1)
 {
     if (l == 0) return 0;                                   // the base canvas: a neighbour's cell IS the ghost
     HLev &V = H->lev[l];
@@ -787,6 +970,11 @@ int hier_ff(suhmo_hier *H, int l, int f0, int f1, bool corners, hipStream_t st)
     const bool head_sides = f0 == SUHMO_F_PHI && f1 < 0 && !corners;
     if (head_sides && H->ff_seen[l] == H->phi_ver[l]) return 0;              // the side ghosts of the head are current
     if (head_sides) H->ff_seen[l] = H->phi_ver[l];
+    if (V.part) {                                           // the source cells other ranks own -> their mirrors here, then the copies below
+        const int fl[2] = {f0, f1};
+        Sync &S = corners ? V.sy_all : (colour >= 0 ? V.sy_side[colour & 1] : V.sy_sides);
+        if ((rc = sync_run(H, l, S, fl, f1 >= 0 ? 2 : 1, st))) return rc;
+    }
     // (a corner ghost's source is a valid cell, never a ghost: sides and corners do not depend on each other)
     const DevVec<CopyEnt> &list = corners ? V.ff_all : V.ff_side;
     if (list.n) hipLaunchKernelGGL(k_ff, g1(list.n), dim3(256), 0, st, list.d, (int)list.n, V.d_fp, f0, f1);
@@ -803,7 +991,9 @@ int hier_cf(suhmo_hier *H, int l, int ff, int fc, hipStream_t st, int ff1 = -1, 
     CoarseArgs ca;
     if ((rc = ensure_field(H, l, ff)) || (rc = ensure_field(H, l - 1, fc)) || (rc = refresh_tables(H, l, st))) return rc;
     if (ff1 >= 0 && ((rc = ensure_field(H, l, ff1)) || (rc = ensure_field(H, l - 1, fc1)) || (rc = refresh_tables(H, l, st)))) return rc;
-    if (l == 1) { const int fl[2] = {fc, fc1}; if ((rc = refresh_base(H, fl, ff1 >= 0 ? 2 : 1, st))) return rc; }
+    { const int fl[2] = {fc, fc1};
+      if (l == 1) rc = refresh_base(H, fl, ff1 >= 0 ? 2 : 1, st); else rc = V.part ? sync_run(H, l - 1, V.sy_cread, fl, ff1 >= 0 ? 2 : 1, st) : 0;
+      if (rc) return rc; }
     if ((rc = coarse_args(H, l - 1, st, ca))) return rc;
     if (V.cf.n) hipLaunchKernelGGL(k_cf, g1(V.cf.n), dim3(256), 0, st, V.cf.d, (int)V.cf.n, V.d_fp, ff, ca.tab, ca.base, ca.use_base, fc, ff1, fc1);
     HIPCHK(hipGetLastError());
@@ -817,6 +1007,7 @@ int hier_pwl(suhmo_hier *H, int l, int ff, int fc, hipStream_t st)
     CoarseArgs ca;
     if ((rc = ensure_field(H, l, ff)) || (rc = ensure_field(H, l - 1, fc)) || (rc = refresh_tables(H, l, st))) return rc;
     if (l == 1 && (rc = refresh_base1(H, fc, st))) return rc;
+    if (l > 1 && V.part && (rc = sync1(H, l - 1, V.sy_cread, fc, st))) return rc;
     if ((rc = coarse_args(H, l - 1, st, ca))) return rc;
     if (V.pwl.n) hipLaunchKernelGGL(k_pwl, g1(V.pwl.n), dim3(256), 0, st, V.pwl.d, (int)V.pwl.n, V.d_fp, ff, ca.tab, ca.base, ca.use_base, fc);
     HIPCHK(hipGetLastError());
@@ -831,11 +1022,39 @@ int hier_avg(suhmo_hier *H, int l, int ff, int fc, int mode, double val, hipStre
     if ((rc = ensure_field(H, l, ff)) || (rc = ensure_field(H, l - 1, fc)) || (rc = refresh_tables(H, l, st)) || (rc = coarse_args(H, l - 1, st, ca))) return rc;
     if (fc == SUHMO_F_PHI) { for (suhmo_level *L : H->lev[l - 1].box) L->d[0].phi_fresh = 0; H->phi_ver[l - 1]++; }
     if (fc == SUHMO_F_PHI && l == 1) H->phi_shadow_fresh = false;
+    if (mode == 1) {                                        // geometry only: every holder of coarse cells marks / zeroes its own
+        if (V.avg_cov.n) {
+            dim3 grd((V.cov_w + 63) / 64, (V.cov_h + 3) / 4, (unsigned)V.avg_cov.n);
+            hipLaunchKernelGGL(k_avg, grd, dim3(64, 4), 0, st, V.avg_cov.d, V.d_fp, V.d_dv, ff, ca.tab, ca.dv, ca.dst, ca.ddv, ca.use_base, fc, mode, val);
+        }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (V.avg.n) {
         dim3 grd((V.avg_w + 63) / 64, (V.avg_h + 3) / 4, (unsigned)V.avg.n);
         hipLaunchKernelGGL(k_avg, grd, dim3(64, 4), 0, st, V.avg.d, V.d_fp, V.d_dv, ff, ca.tab, ca.dv, ca.dst, ca.ddv, ca.use_base, fc, mode, val);
     }
     HIPCHK(hipGetLastError());
+    if (V.part && V.put_stride) {
+        // owner computes: averages of this rank's fine boxes over coarse cells another rank holds travel in this rank's segment of one
+        // all-gather; the holder of the coarse cells takes its rectangles from there (FORT_AVERAGE's sum, the same bits)
+        SUHMO_TIME("hier: averages onto coarse cells other ranks hold");
+        if (!H->ag) { suhmo_set_error("hier: level %d is partitioned over the ranks and no all-gather is attached", l); return -1; }
+        if ((rc = part_staging(H, (size_t)V.put_stride, st))) return rc;
+        if (V.avg_put.n) {
+            dim3 grd((V.put_w + 63) / 64, (V.put_h + 3) / 4, (unsigned)V.avg_put.n);
+            hipLaunchKernelGGL(k_avg_put, grd, dim3(64, 4), 0, st, V.avg_put.d, V.d_fp, V.d_dv, ff, H->ps);
+        }
+        HIPCHK(hipGetLastError());
+        if ((rc = H->ag(H->ag_user, H->ps, V.put_stride, H->pr, (suhmo_stream_t)st))) return rc;
+        H->part_gathers++;
+        H->part_bytes += 8L * V.put_mine;
+        if (V.avg_get.n) {
+            dim3 grd((V.get_w + 63) / 64, (V.get_h + 3) / 4, (unsigned)V.avg_get.n);
+            hipLaunchKernelGGL(k_put_unpack, grd, dim3(64, 4), 0, st, V.avg_get.d, ca.tab, ca.dv, ca.dst, ca.ddv, ca.use_base, fc, H->pr, V.put_stride);
+        }
+        HIPCHK(hipGetLastError());
+    }
     return 0;
 }
 // AMRProlongS_2 (:1143-1206): PHI of level l += PROLONG_2_NL(field_c of level l-1), the coarse field gathered per box with
@@ -849,6 +1068,7 @@ int hier_window_save(suhmo_hier *H, int l, int field_c, hipStream_t st)
     CoarseArgs ca;
     if ((rc = ensure_field(H, l - 1, field_c)) || (rc = refresh_tables(H, l, st))) return rc;
     if (l == 1 && (rc = refresh_base1(H, field_c, st))) return rc;
+    if (l > 1 && V.part && (rc = sync1(H, l - 1, V.sy_win, field_c, st))) return rc;
     if ((rc = coarse_args(H, l - 1, st, ca))) return rc;
     if (!V.winold) {
         HIPCHK(hipMalloc(&V.winold, std::max<size_t>(1, V.winelems) * sizeof(double)));
@@ -868,6 +1088,7 @@ int hier_prolong2(suhmo_hier *H, int l, int field_c, hipStream_t st, bool minus_
     CoarseArgs ca;
     if ((rc = ensure_field(H, l - 1, field_c)) || (rc = refresh_tables(H, l, st))) return rc;
     if (l == 1 && (rc = refresh_base1(H, field_c, st))) return rc;
+    if (l > 1 && V.part && (rc = sync1(H, l - 1, V.sy_win, field_c, st))) return rc;
     if ((rc = coarse_args(H, l - 1, st, ca))) return rc;
     if (V.wing.n) {
         dim3 grd((V.wing_w + 63) / 64, (V.wing_h + 3) / 4, (unsigned)V.wing.n);
@@ -879,8 +1100,11 @@ int hier_prolong2(suhmo_hier *H, int l, int field_c, hipStream_t st, bool minus_
     for (const Win &w : V.win) maxp = std::max(maxp, 2 * (w.nx - 2) + 2 * (w.ny - 2));
     for (suhmo_level *L : V.box) { maxx = std::max(maxx, L->d[0].v.nx); maxy = std::max(maxy, L->d[0].v.ny); L->d[0].phi_fresh = 0; }
     H->phi_ver[l]++;
-    hipLaunchKernelGGL(k_win_bc, dim3((maxp + 255) / 256, nb), dim3(256), 0, st, V.d_win, nb, V.winbuf, ca.bdv);
-    hipLaunchKernelGGL(k_prolong2_win, dim3((maxx + 63) / 64, (maxy + 3) / 4, nb), dim3(64, 4), 0, st, V.d_win, V.winbuf, V.d_fp, V.d_dv);
+    const int k0 = V.part ? V.b0 : 0, nk = V.part ? V.nown : nb;       // (owner computes: the windows of this rank's boxes)
+    if (nk > 0) {
+        hipLaunchKernelGGL(k_win_bc, dim3((maxp + 255) / 256, nk), dim3(256), 0, st, V.d_win + k0, nk, V.winbuf, ca.bdv);
+        hipLaunchKernelGGL(k_prolong2_win, dim3((maxx + 63) / 64, (maxy + 3) / 4, nk), dim3(64, 4), 0, st, V.d_win + k0, V.winbuf, V.d_fp + k0, V.d_dv + k0);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -893,7 +1117,11 @@ int hier_reflux(suhmo_hier *H, int l, int field_c, hipStream_t st, int residual 
     int rc;
     CoarseArgs ca;
     if ((rc = ensure_field(H, l - 1, field_c)) || (rc = refresh_tables(H, l, st))) return rc;
-    if (l == 1) { const int fl[3] = {SUHMO_F_PHI, SUHMO_F_BX, SUHMO_F_BY}; if ((rc = refresh_base(H, fl, 3, st))) return rc; }
+    { const int fl[3] = {SUHMO_F_PHI, SUHMO_F_BX, SUHMO_F_BY};
+      if (l == 1) { if ((rc = refresh_base(H, fl, 3, st))) return rc; }
+      else if (V.part && (rc = sync_run(H, l - 1, V.sy_cread, fl, 3, st))) return rc;
+      // owner computes: the register is added up where the coarse cell lives; the fine cells and faces next to the coarse-fine faces come along
+      if (V.part && (rc = sync_run(H, l, V.sy_fface, fl, 3, st))) return rc; }
     if ((rc = coarse_args(H, l - 1, st, ca))) return rc;
     const DV &vc = H->lev[l - 1].box[0]->d[0].v;
     if (V.targets.n)
@@ -904,94 +1132,34 @@ int hier_reflux(suhmo_hier *H, int l, int field_c, hipStream_t st, int residual 
 }
 
 // ------------------------------------------------------------------ operator methods of a level
-// relax: levelGSRB x sweeps (src/VCAMRNonLinearPoissonOp.cpp:654-760): per colour pass exchange, then the pass on every box
-// ---- owner computes: canvases of the fields f0 (and f1) of the boxes [b0, b0 + gridDim.z) -> this rank's segment; every other rank's
-// segment -> the replicas of its boxes
-__global__ void k_part_pack(const PartEnt *__restrict__ e, int b0, const FP *__restrict__ tab, int f0, int f1, double *__restrict__ send, long stride)
-{
-    const int k = b0 + blockIdx.z;
-    const PartEnt q = e[k];
-    const double *__restrict__ a = tab[k].f[f0];
-    const double *__restrict__ b = f1 >= 0 ? tab[k].f[f1] : nullptr;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < q.elems; i += gridDim.x * blockDim.x) {
-        send[q.off + i] = a[i];
-        if (b) send[stride + q.off + i] = b[i];
-    }
-}
-__global__ void k_part_unpack(const PartEnt *__restrict__ e, int rank, const FP *__restrict__ tab, int f0, int f1, const double *__restrict__ recv, long stride, long rstride)
-{
-    const int k = blockIdx.z;
-    const PartEnt q = e[k];
-    if (q.owner == rank) return;
-    const double *__restrict__ src = recv + (long)q.owner * rstride + q.off;
-    double *__restrict__ a = tab[k].f[f0];
-    double *__restrict__ b = f1 >= 0 ? tab[k].f[f1] : nullptr;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < q.elems; i += gridDim.x * blockDim.x) {
-        a[i] = src[i];
-        if (b) b[i] = src[stride + i];
-    }
-}
-// the boxes of this rank as a table of their own (the kernels index the tables by blockIdx.z)
-inline bool part_mine(const suhmo_hier *H, const HLev &V, const suhmo_multi &m, suhmo_multi &mine)
-{
-    const int b0 = V.own[H->rank], n = V.own[H->rank + 1] - b0;
-    mine = m;
-    mine.dv = m.dv + b0; mine.fp = m.fp + b0; mine.nbox = n;
-    if (m.pbase) mine.pbase = m.pbase + b0;
-    return n > 0;
-}
-// what the owners wrote into the fields f0 (, f1) of level l -> every rank's replica (collective)
-int part_share(suhmo_hier *H, int l, int f0, int f1, hipStream_t st)
-{
-    HLev &V = H->lev[l];
-    SUHMO_TIME("hier: all-gather of the boxes' canvases (owner computes)");
-    if (!H->ag) { suhmo_set_error("hier: level %d is partitioned over the ranks and no all-gather is attached (suhmo_hier_attach_rccl / suhmo_hier_set_allgather)", l); return -1; }
-    const int nf = f1 >= 0 ? 2 : 1;
-    if (!V.ps) {
-        HIPCHK(hipMalloc(&V.ps, (size_t)std::max<long>(1, 2 * V.part_max) * sizeof(double)));
-        HIPCHK(hipMalloc(&V.pr, (size_t)std::max<long>(1, 2 * V.part_max) * H->world * sizeof(double)));
-        HIPCHK(hipMemsetAsync(V.ps, 0, (size_t)std::max<long>(1, 2 * V.part_max) * sizeof(double), st));
-    }
-    const int b0 = V.own[H->rank], mine = V.own[H->rank + 1] - b0;
-    const int gx = std::max(1, std::min(64, (V.part_maxelems + 1023) / 1024));
-    if (mine) hipLaunchKernelGGL(k_part_pack, dim3(gx, 1, mine), dim3(256), 0, st, V.pent.d, b0, V.d_fp, f0, f1, V.ps, V.part_max);
-    HIPCHK(hipGetLastError());
-    int rc = H->ag(H->ag_user, V.ps, (long)nf * V.part_max, V.pr, (suhmo_stream_t)st);
-    if (rc) return rc;
-    H->part_gathers++;
-    hipLaunchKernelGGL(k_part_unpack, dim3(gx, 1, (unsigned)V.box.size()), dim3(256), 0, st, V.pent.d, H->rank, V.d_fp, f0, f1, V.pr, V.part_max, (long)nf * V.part_max);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
 // LoadBalance(procIDs, grids) (src/AmrHydro.cpp:4283, 4929): here the boxes in the order given, cut into `world` runs of about equal cell
-// counts (a box goes to the rank its middle cell falls to): deterministic, contiguous, the same on every rank
+// counts (a box goes to the rank its middle cell falls to): deterministic, contiguous, the same on every rank.  Called BEFORE the plans are
+// built: every plan entry is kept by the rank that executes it
 int part_setup(suhmo_hier *H, int l)
 {
     HLev &V = H->lev[l];
     const int nb = (int)V.box.size(), W = H->world;
+    V.part = H->part;
+    if (!V.part) return 0;
     long total = 0;
     for (int k = 0; k < nb; k++) { const int *b = &V.b4[4 * k]; total += (long)(b[2] - b[0] + 1) * (b[3] - b[1] + 1); }
-    V.part = W > 1 && total >= H->part_min_cells * W;
-    if (!V.part) return 0;
-    std::vector<PartEnt> e(nb);
-    std::vector<int> owner(nb);
-    std::vector<long> seg(W, 0);
+    V.owner.assign(nb, 0);
     long before = 0;
     int prev = 0;
     for (int k = 0; k < nb; k++) {
         const int *b = &V.b4[4 * k];
         const long c = (long)(b[2] - b[0] + 1) * (b[3] - b[1] + 1);
         const int r = std::max(prev, std::min(W - 1, (int)(((before + c / 2) * W) / total)));
-        owner[k] = prev = r;
-        e[k].owner = r; e[k].elems = (int)V.box[k]->d[0].elems; e[k].off = seg[r];
-        seg[r] += e[k].elems;
-        V.part_maxelems = std::max(V.part_maxelems, e[k].elems);
+        V.owner[k] = prev = r;
+        if (r == H->rank) V.owned_cells += c;
         before += c;
     }
     V.own.assign(W + 1, nb);
-    for (int r = 0; r < W; r++) V.own[r] = (int)(std::lower_bound(owner.begin(), owner.end(), r) - owner.begin());
-    V.part_max = *std::max_element(seg.begin(), seg.end());
-    return V.pent.upload(e);
+    for (int r = 0; r < W; r++) V.own[r] = (int)(std::lower_bound(V.owner.begin(), V.owner.end(), r) - V.owner.begin());
+    V.b0 = V.own[H->rank]; V.nown = V.own[H->rank + 1] - V.b0;
+    V.held.assign(nb, 0);
+    for (int k = V.b0; k < V.b0 + V.nown; k++) V.held[k] = 1;
+    return 0;
 }
 
 int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
@@ -1004,18 +1172,15 @@ int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
     // exchange() before every colour pass (:692, :751): once here (unless the side ghosts are current), then every pass pushes
     // its new side cells into the ghost cells they feed
     if (sweeps > 0 && (rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
-    // owner computes: a pass relaxes this rank's boxes, the canvases travel, the exchange launch refreshes every replica's ghosts (a
-    // pushed ghost value would sit in the neighbour's canvas, which its owner sends): the reference's own pattern, exchange() + pass
+    // owner computes: a pass relaxes this rank's boxes, the side cells of the colour it advanced travel to the ranks whose boxes lie across
+    // those sides, and the exchange launch copies them into the ghost cells: the reference's own pattern, exchange() + pass (:692, :751)
     HLev &V = H->lev[l];
     const bool push = H->push_ghosts && !V.part;
-    suhmo_multi mine = m;
-    const bool any = V.part ? part_mine(H, V, m, mine) : true;
     for (int it = 0; it < sweeps; it++)
         for (int pass = 0; pass < 2; pass++) {
-            if (any && (rc = suhmo_multi_colour_pass(mine, phys_of(H, l), has_alpha(H, l), pass, HST(s), push))) return rc;
-            if (V.part && (rc = part_share(H, l, SUHMO_F_PHI, -1, HST(s)))) return rc;
+            if ((rc = suhmo_multi_colour_pass(m, phys_of(H, l), has_alpha(H, l), pass, HST(s), push))) return rc;
             H->phi_ver[l]++;
-            if (!push && (rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
+            if (!push && (rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s), V.part ? pass : -1))) return rc;
         }
     if (sweeps > 0 && (rc = suhmo_multi_fill_ghosts(m, SUHMO_F_PHI, 1, HST(s)))) return rc;                        // :757-759
     if (sweeps > 0 && push) H->ff_seen[l] = H->phi_ver[l];          // every pass pushed its side cells: the ghosts are current
@@ -1027,11 +1192,7 @@ int hier_level_residual(suhmo_hier *H, int l, suhmo_stream_t s)   // residualI: 
     int rc;
     suhmo_multi m;
     if ((rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s))) || (rc = multi_of(H, l, HST(s), m))) return rc;
-    HLev &V = H->lev[l];
-    if (!V.part) return suhmo_multi_apply(m, phys_of(H, l), has_alpha(H, l), 1, HST(s));
-    suhmo_multi mine;
-    if (part_mine(H, V, m, mine) && (rc = suhmo_multi_apply(mine, phys_of(H, l), has_alpha(H, l), 1, HST(s)))) return rc;
-    return part_share(H, l, SUHMO_F_RES, -1, HST(s));
+    return suhmo_multi_apply(m, phys_of(H, l), has_alpha(H, l), 1, HST(s));            // (owner computes: m = this rank's boxes)
 }
 int hier_axby(suhmo_hier *H, int l, int dst, int x, int y, double a, double b, suhmo_stream_t s)
 {
@@ -1086,7 +1247,7 @@ int hier_update_operator(suhmo_hier *H, int l, suhmo_stream_t s)
     if ((rc = hier_grad_cc(H, l, s))) return rc;
     // the coarse gradient is read by the coarse-fine interpolation below and by nothing else: on level 0 only the cells those
     // stencils touch are evaluated (a pass over the whole level otherwise, 86 us at 4096^2)
-    if (l - 1 == 0 && H->incremental) rc = suhmo_grad_cc_list(base_of(H), 0, H->lev[1].gcells.d, (int)H->lev[1].gcells.n, HST(s));
+    if (l - 1 == 0 && H->incremental) { rc = suhmo_grad_cc_list(base_of(H), 0, H->lev[1].gcells.d, (int)H->lev[1].gcells.n, HST(s)); H->n_sparse_grad++; }
     else rc = hier_grad_cc(H, l - 1, s);
     if (rc) return rc;
     if ((rc = hier_cf(H, l, SUHMO_F_GRADX, SUHMO_F_GRADX, HST(s), SUHMO_F_GRADY, SUHMO_F_GRADY))) return rc;
@@ -1108,19 +1269,15 @@ int composite_residual(suhmo_hier *H, int l, suhmo_stream_t s, bool whole_level_
     if (l - 1 == 0) {
         HLev &V1 = H->lev[1];
         if (!whole_level_follows && H->base_fused_ver == H->base_full_ver)
-            rc = 0;                                                           // L(phi) and rhs - L(phi) of the head as it is: written by the cycle's last launch
+            { rc = 0; H->n_fused_residual++; }                                // L(phi) and rhs - L(phi) of the head as it is: written by the cycle's last launch
         else if (H->incremental && whole_level_follows && H->base_res_seen == H->base_full_ver)
-            rc = suhmo_apply_and_residual_rects(base_of(H), 0, V1.dirty0.d, (int)V1.dirty0.n, V1.dirty_w, V1.dirty_h, HST(s));   // only what the average changed
+            { rc = suhmo_apply_and_residual_rects(base_of(H), 0, V1.dirty0.d, (int)V1.dirty0.n, V1.dirty_w, V1.dirty_h, HST(s)); H->n_incr_residual++; }   // only what the average changed
         else rc = suhmo_apply_and_residual(base_of(H), 0, HST(s));
         H->base_res_seen = whole_level_follows ? 0 : H->base_full_ver;       // (the solve loop's evaluation is the one the next cycle can build on)
     } else {
         suhmo_multi m;
         if ((rc = hier_ff(H, l - 1, SUHMO_F_PHI, -1, false, HST(s))) || (rc = ensure_field(H, l - 1, SUHMO_F_LPHI)) || (rc = multi_of(H, l - 1, HST(s), m))) return rc;
-        HLev &Vc = H->lev[l - 1];
-        suhmo_multi mine;
-        if (!Vc.part) rc = suhmo_multi_apply(m, phys_of(H, l - 1), has_alpha(H, l - 1), 3, HST(s));
-        else if (!part_mine(H, Vc, m, mine) || !(rc = suhmo_multi_apply(mine, phys_of(H, l - 1), has_alpha(H, l - 1), 3, HST(s))))
-            rc = part_share(H, l - 1, SUHMO_F_LPHI, SUHMO_F_RES, HST(s));
+        rc = suhmo_multi_apply(m, phys_of(H, l - 1), has_alpha(H, l - 1), 3, HST(s));
     }
     if (rc) return rc;
     if ((rc = cf_phi(H, l, s))) return rc;
@@ -1167,6 +1324,16 @@ int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stre
     if ((rc = cf_phi(H, l, s))) return rc;
     return hier_gsrb(H, l, sp->num_smooth, s);
 }
+}  // namespace
+// MAX over the ranks of a value every rank computed on the boxes it owns (through the all-reduce of the base strip)
+int suhmo_hier_allreduce_max_(suhmo_hier *H, double *v)
+{
+    suhmo_level *B = H->lev[0].box[0];
+    if (H->world <= 1) return 0;
+    if (!B->ar) { suhmo_set_error("hier: the levels are partitioned over the ranks and level 0 has no all-reduce hook"); return -1; }
+    return B->ar(B->user, v);
+}
+namespace {
 int check_hier(suhmo_hier *H)
 {
     ARG(H && H->nlev >= 1);
@@ -1200,10 +1367,11 @@ extern "C" int suhmo_hier_destroy(suhmo_hier_t *H)
         if (V.d_fp) (void)hipFree(V.d_fp);
         if (V.d_dv) (void)hipFree(V.d_dv);
         if (V.d_red) (void)hipFree(V.d_red);
-        V.pent.release();
-        if (V.ps) (void)hipFree(V.ps);
-        if (V.pr) (void)hipFree(V.pr);
+        for (Sync *S : {&V.sy_side[0], &V.sy_side[1], &V.sy_sides, &V.sy_all, &V.sy_cread, &V.sy_win, &V.sy_fface}) S->release();
+        V.avg_cov.release(); V.avg_put.release(); V.avg_get.release();
     }
+    if (H->ps) (void)hipFree(H->ps);
+    if (H->pr) (void)hipFree(H->pr);
     delete H;
     return 0;
 }
@@ -1250,6 +1418,12 @@ extern "C" int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc
         g.ny = g.nyg; g.j0 = 0; g.rows = g.ny + 2 * g.gy;
         g.ext[0] = g.ext[1] = g.rk[0] = g.rk[1] = 0;
         H->shadow_elems = (size_t)g.P * (size_t)(g.rows + 1);
+    }
+    {   // owner computes: the levels >= 1 are dealt to the ranks when together they hold at least partition_min_cells cells per rank
+        long cells = 0;
+        const int *qq = boxes;
+        for (int l = 1; l < nlev; l++) for (int k = 0; k < nbox[l]; k++, qq += 4) cells += (long)(qq[2] - qq[0] + 1) * (qq[3] - qq[1] + 1);
+        H->part = H->world > 1 && nlev > 1 && cells >= H->part_min_cells * H->world;
     }
     const int *q = boxes;
     for (int l = 1; l < nlev; l++) {
@@ -1302,7 +1476,7 @@ extern "C" int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc
             d.nbox = 0; d.boxes = nullptr; d.max_box = std::max(d.nx, d.ny);
             d.halo_rows = 1; d.patch_j0 = 0; d.patch_ny = 0;
             suhmo_level *L = nullptr;
-            rc = suhmo_level_create(&L, &d);
+            rc = suhmo_level_create_(&L, &d, H->part);           // (owner computes: geometry first, storage once the plans say which boxes this rank holds)
             if (rc) { suhmo_hier_destroy(H); return rc; }
             L->gsrb_variant = 0; L->gsrb_tile = 0;               // in-place colour passes: the canvases of a box never move
             V.box.push_back(L);
@@ -1310,14 +1484,17 @@ extern "C" int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc
         (void)cells;
     }
     static const int need[] = {SUHMO_F_LPHI, SUHMO_F_GRADX, SUHMO_F_GRADY, SUHMO_F_RE, SUHMO_F_RHS0, SUHMO_F_PHIOLD, SUHMO_F_CORR};
-    for (int l = 0; l < nlev; l++) for (int f : need) if ((rc = ensure_field(H, l, f))) { suhmo_hier_destroy(H); return rc; }
-    for (int l = 1; l < nlev; l++) {
-        if ((rc = build_plans(H, l))) { suhmo_hier_destroy(H); return rc; }
-        if ((rc = refresh_tables(H, l, nullptr))) { suhmo_hier_destroy(H); return rc; }
-        if ((rc = part_setup(H, l))) { suhmo_hier_destroy(H); return rc; }
+    for (int l = 1; l < nlev; l++) if ((rc = part_setup(H, l))) { suhmo_hier_destroy(H); return rc; }
+    for (int l = 1; l < nlev; l++) if ((rc = build_plans(H, l))) { suhmo_hier_destroy(H); return rc; }
+    for (int l = 1; l < nlev && H->part; l++) {              // storage for the boxes this rank owns or mirrors; every other box stays a stub
+        HLev &V = H->lev[l];
+        for (size_t k = 0; k < V.box.size(); k++)
+            if (V.held[k]) { V.held_boxes++; if ((rc = suhmo_level_materialize_(V.box[k]))) { suhmo_hier_destroy(H); return rc; } }
     }
+    for (int l = 0; l < nlev; l++) for (int f : need) if ((rc = ensure_field(H, l, f))) { suhmo_hier_destroy(H); return rc; }
+    for (int l = 1; l < nlev; l++) if ((rc = refresh_tables(H, l, nullptr))) { suhmo_hier_destroy(H); return rc; }
     // SUHMO_F_COVER: 1 under a finer level, 0 elsewhere
-    for (int l = 0; l < nlev; l++) for (suhmo_level *L : H->lev[l].box) if ((rc = suhmo_level_set_value(L, 0, SUHMO_F_COVER, 0.0, nullptr))) { suhmo_hier_destroy(H); return rc; }
+    for (int l = 0; l < nlev; l++) for (suhmo_level *L : H->lev[l].box) if (!L->stub && (rc = suhmo_level_set_value(L, 0, SUHMO_F_COVER, 0.0, nullptr))) { suhmo_hier_destroy(H); return rc; }
     for (int l = 1; l < nlev; l++) if ((rc = hier_avg(H, l, SUHMO_F_COVER, SUHMO_F_COVER, 1, 1.0, nullptr))) { suhmo_hier_destroy(H); return rc; }
     if (H->shadowed && nlev > 1) {                          // COVER of the whole level 0 (geometry only): the moulin integrals run over all of it
         if (!shadow_field(H, SUHMO_F_COVER)) { suhmo_set_error("field allocation failed"); suhmo_hier_destroy(H); return -2; }
@@ -1355,6 +1532,19 @@ void suhmo_hier_invalidate_(suhmo_hier *H)
     H->base_full_ver++;
     if (H->gap) suhmo_hier_invalidate_(H->gap);
 }
+bool suhmo_hier_partitioned_(const suhmo_hier *H) { return H->part; }
+int suhmo_hier_world_(const suhmo_hier *H) { return H->world; }
+void suhmo_hier_owned_(const suhmo_hier *H, int l, int *first, int *n)
+{
+    const HLev &V = H->lev[l];
+    if (V.part) { *first = V.b0; *n = V.nown; } else { *first = 0; *n = (int)V.box.size(); }
+}
+int suhmo_hier_allgather_(suhmo_hier *H, const double *send, long count, double *recv, hipStream_t st)
+{
+    if (!H->ag) { suhmo_set_error("hier: no all-gather is attached (suhmo_hier_attach_rccl / suhmo_hier_set_allgather)"); return -1; }
+    H->part_gathers++;
+    return H->ag(H->ag_user, send, count, recv, (suhmo_stream_t)st);
+}
 const double *suhmo_hier_base_cover_(suhmo_hier *H, DV *whole)
 {
     if (!dist_base(H)) return nullptr;
@@ -1366,7 +1556,6 @@ int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, su
     if (H->gap && H->gap_dt != dt) {                       // a new time step size: beta = dt diffFactor of every operator; boxes, plans and tables stay
         for (int l = 0; l < H->nlev; l++)
             for (suhmo_level *L : H->gap->lev[l].box) { int rc = suhmo_level_set_alpha_beta(L, 1.0, dt * mp->diffFactor); if (rc) return rc; }
-        if (H->gap->lev[0].box[0]->agg) { int rc = suhmo_level_set_alpha_beta(H->gap->lev[0].box[0]->agg, 1.0, dt * mp->diffFactor); if (rc) return rc; }
         HIPCHK(hipDeviceSynchronize());
         for (int l = 1; l < H->nlev; l++) {                // the device copies of the boxes' views carry beta: uploaded again at the next use
             HLev &V = H->gap->lev[l];
@@ -1422,14 +1611,34 @@ extern "C" int suhmo_hier_get_option(const suhmo_hier_t *H, const char *key, lon
     if (!strcmp(key, "incremental_residual")) { *value = H->incremental; return 0; }
     if (!strcmp(key, "shadow")) { *value = H->shadowed; return 0; }
     if (!strcmp(key, "partition_min_cells")) { *value = H->part_min_cells; return 0; }
+    if (!strcmp(key, "incremental_residual_passes")) { *value = H->n_incr_residual; return 0; }
+    if (!strcmp(key, "residuals_left_by_relax")) { *value = H->n_fused_residual; return 0; }
+    if (!strcmp(key, "sparse_gradient_passes")) { *value = H->n_sparse_grad; return 0; }
     if (!strcmp(key, "partition_gathers")) { *value = H->part_gathers + (H->gap ? H->gap->part_gathers : 0); return 0; }
     if (!strncmp(key, "partitioned_level_", 18) || !strncmp(key, "own_boxes_level_", 16)) {      // e.g. own_boxes_level_2: boxes of level 2 this rank relaxes
         const bool own = key[0] == 'o';
         const int l = atoi(key + (own ? 16 : 18));
         if (l < 0 || l >= H->nlev) { suhmo_set_error("no level %d", l); return -1; }
         const HLev &V = H->lev[l];
-        *value = own ? (V.part ? V.own[H->rank + 1] - V.own[H->rank] : (long)V.box.size()) : (V.part ? 1 : 0);
+        *value = own ? (V.part ? V.nown : (long)V.box.size()) : (V.part ? 1 : 0);
         return 0;
+    }
+    if (!strcmp(key, "partition_bytes")) { *value = H->part_bytes + (H->gap ? H->gap->part_bytes : 0); return 0; }     // bytes this rank contributed to the partition's collectives
+    {   // per level l >= 1: <key>_level_<l>
+        static const char *keys[] = {"ghost_exchange_bytes_level_", "held_boxes_level_", "owned_cells_level_", "canvas_bytes_level_", "ghost_exchange_bound_bytes_level_"};
+        for (int q = 0; q < 5; q++) {
+            const size_t n = strlen(keys[q]);
+            if (strncmp(key, keys[q], n)) continue;
+            const int l = atoi(key + n);
+            if (l < 1 || l >= H->nlev) { suhmo_set_error("no level %d", l); return -1; }
+            const HLev &V = H->lev[l];
+            if (q == 0) *value = H->side_bytes[l];                                   // what this rank sends per colour-pass exchange (the larger colour)
+            else if (q == 1) *value = V.part ? V.held_boxes : (long)V.box.size();
+            else if (q == 2) { long c = 0; if (V.part) c = V.owned_cells; else for (size_t k = 0; k < V.box.size(); k++) { const int *b = &V.b4[4 * k]; c += (long)(b[2] - b[0] + 1) * (b[3] - b[1] + 1); } *value = c; }
+            else if (q == 3) { long c = 0; for (suhmo_level *L : V.box) for (int f = 0; f < SUHMO_F_COUNT; f++) if (L->d[0].fp.f[f]) c += (long)L->d[0].elems * 8; *value = c; }
+            else { long c = 0; for (int k = V.part ? V.b0 : 0; k < (V.part ? V.b0 + V.nown : 0); k++) { const int *b = &V.b4[4 * k]; c += 8L * 2 * ((b[2] - b[0] + 1) + (b[3] - b[1] + 1)); } *value = c; }   // 4 sides x 8 B of the owned boxes
+            return 0;
+        }
     }
     suhmo_set_error("unknown hierarchy option '%s'", key);
     return -1;
@@ -1456,6 +1665,15 @@ extern "C" suhmo_level_t *suhmo_hier_box(suhmo_hier_t *H, int l, int k)
 {
     if (!H || l < 0 || l >= H->nlev || k < 0 || k >= (int)H->lev[l].box.size()) return nullptr;
     return H->lev[l].box[k];
+}
+// which rank holds box k of level l: -1 = every rank (a replicated level, level 0's strip); `held`: this rank keeps storage for it (its own
+// box, or a mirror of a neighbour's whose cells its plans read) -- a box that is neither is a stub: suhmo_level_set_field etc. refuse it
+extern "C" int suhmo_hier_box_owner(const suhmo_hier_t *H, int l, int k, int *held)
+{
+    if (!H || l < 0 || l >= H->nlev || k < 0 || k >= (int)H->lev[l].box.size()) return -2;
+    const HLev &V = H->lev[l];
+    if (held) *held = V.part ? (int)V.held[k] : 1;
+    return V.part ? V.owner[k] : -1;
 }
 extern "C" int suhmo_hier_exchange(suhmo_hier_t *H, int l, int field, int corners, suhmo_stream_t s)
 {
@@ -1514,12 +1732,15 @@ static int hier_residual_(suhmo_hier *H, double *norm, suhmo_stream_t s)
     if (norm) {
         double m = 0.0;
         if ((rc = suhmo_level_norm(base_of(H), 0, SUHMO_F_RES, 0, &m, s))) return rc;
+        double mp = 0.0;
         for (int l = 1; l <= top; l++) {
             double a = 0.0;
             suhmo_multi mv;
             if ((rc = multi_of(H, l, HST(s), mv)) || (rc = suhmo_multi_norm_max(mv, base_of(H), SUHMO_F_RES, &a, HST(s)))) return rc;
-            if (a > m) m = a;
+            if (a > mp) mp = a;
         }
+        if (H->part && (rc = suhmo_hier_allreduce_max_(H, &mp))) return rc;     // owner computes: every rank saw its own boxes only
+        if (mp > m) m = mp;
         *norm = m;
     }
     return 0;

@@ -122,6 +122,7 @@ double *suhmo_field(suhmo_level *L, int depth, int field)
     Depth &D = L->d[depth];
     if (!D.fp.f[field]) {
         double *p = nullptr;
+        if (L->stub) return nullptr;                              // geometry only (a box another rank holds)
         if (hipMalloc(&p, D.elems * sizeof(double)) != hipSuccess) return nullptr;
         (void)hipMemset(p, 0, D.elems * sizeof(double));
         D.fp.f[field] = p;
@@ -130,7 +131,13 @@ double *suhmo_field(suhmo_level *L, int depth, int field)
     return D.fp.f[field];
 }
 
-extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t *desc)
+// stub: geometry, options and boxes only -- no canvas, no scratch: a box of a partitioned AMR level this rank neither owns nor reads
+// (suhmo_hier.hip); suhmo_level_materialize_ turns it into a level with storage
+static int level_storage(suhmo_level *L);
+int suhmo_level_create_(suhmo_level_t **out, const suhmo_level_desc_t *desc, bool stub);
+extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t *desc) { return suhmo_level_create_(out, desc, false); }
+int suhmo_level_materialize_(suhmo_level *L) { return L->stub ? level_storage(L) : 0; }
+int suhmo_level_create_(suhmo_level_t **out, const suhmo_level_desc_t *desc, bool stub)
 {
     ARG(out && desc);
     ARG(desc->nx >= 2 && desc->ny >= 2 && desc->dx > 0 && desc->dy > 0);
@@ -167,7 +174,7 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
     L->fas_rhs_fused = 1;
     if (const char *e = getenv("SUHMO_FAS_RHS_FUSED")) L->fas_rhs_fused = atoi(e) != 0;
     L->agg_min_cells = 100000; L->agg_depth = 0; L->agg_world = 1; L->agg_rank = 0; L->agg = nullptr; L->ag = nullptr; L->ag_user = nullptr;
-    L->agg_send = L->agg_recv = nullptr; L->agg_cap = 0; L->agg_gathers = 0;
+    L->agg_send = L->agg_recv = nullptr; L->agg_cap = 0; L->agg_gathers = 0; L->agg_static_stale = 0;
     L->frhs_stream = L->frhs_tile = 0;
     L->resout_np = 0;
     L->resout_req = L->resout_armed = L->resout_done = 0; L->resout_rhs = nullptr; L->resout_count = 0; L->resid_in_relax = 1;
@@ -221,8 +228,6 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
         if ((desc->i0 % (2 << dep)) || (desc->nx_global % (1 << dep))) break;
         L->ndepth = dep + 1;
     }
-    static const int eager[] = {SUHMO_F_PHI, SUHMO_F_RHS, SUHMO_F_ACOEF, SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB,
-                                SUHMO_F_MASK, SUHMO_F_BX, SUHMO_F_BY, SUHMO_F_RES, SUHMO_F_LPHI};
     for (int dep = 0; dep < L->ndepth; dep++) {
         Depth &D = L->d[dep];
         make_dv(D.v, L->desc, dep);
@@ -230,23 +235,35 @@ extern "C" int suhmo_level_create(suhmo_level_t **out, const suhmo_level_desc_t 
         D.nbox = L->desc.nbox;
         memset(&D.fp, 0, sizeof(D.fp));
         D.phi_alt = nullptr; D.prolong_pending = 0; D.rhs_pending = 0; D.phi_fresh = 0;
+    }
+    L->scratch = nullptr; L->scratch_elems = 0; L->hscratch = nullptr; L->hscratch_dev = nullptr; L->hseq = 0; L->poll_readback = 1;
+    L->mask_epoch = 0; L->maskflag_epoch = 0; L->mask_reported = 0; L->skip_mask = 1; L->coarse_mask_ok = 0;
+    if (const char *e = getenv("SUHMO_SKIP_MASK")) L->skip_mask = atoi(e);
+    if (const char *e = getenv("SUHMO_POLL_READBACK")) L->poll_readback = atoi(e);
+    L->stub = 1;
+    if (!stub) { int rc = level_storage(L); if (rc) { suhmo_level_destroy(L); return rc; } }
+    *out = L;
+    return 0;
+}
+static int level_storage(suhmo_level *L)
+{
+    static const int eager[] = {SUHMO_F_PHI, SUHMO_F_RHS, SUHMO_F_ACOEF, SUHMO_F_B, SUHMO_F_PI, SUHMO_F_ZB,
+                                SUHMO_F_MASK, SUHMO_F_BX, SUHMO_F_BY, SUHMO_F_RES, SUHMO_F_LPHI};
+    HIPCHK(hipSetDevice(L->device));
+    L->stub = 0;
+    for (int dep = 0; dep < L->ndepth; dep++) {
         for (int f : eager) {
             if (dep == 0 && f == SUHMO_F_LPHI) continue;       // lazily (only tests / AMR use it at depth 0)
-            if (!suhmo_field(L, dep, f)) { suhmo_set_error("hipMalloc failed (depth %d field %d)", dep, f); delete L; return -2; }
+            if (!suhmo_field(L, dep, f)) { suhmo_set_error("hipMalloc failed (depth %d field %d)", dep, f); return -2; }
         }
         if (dep > 0) { suhmo_field(L, dep, SUHMO_F_PHIOLD); suhmo_field(L, dep, SUHMO_F_CORR); }
     }
     L->scratch_elems = 16384;
     HIPCHK(hipMalloc(&L->scratch, L->scratch_elems * sizeof(double)));
     HIPCHK(hipMemset(L->scratch, 0, L->scratch_elems * sizeof(double)));                   // (its last word: the negative-mask report of k_bcoef_fused)
-    L->mask_epoch = 0; L->maskflag_epoch = 0; L->mask_reported = 0; L->skip_mask = 1; L->coarse_mask_ok = 0;
-    if (const char *e = getenv("SUHMO_SKIP_MASK")) L->skip_mask = atoi(e);
     HIPCHK(hipHostMalloc(&L->hscratch, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     memset(L->hscratch, 0, 64 * sizeof(double));
-    L->hscratch_dev = nullptr; L->hseq = 0; L->poll_readback = 1;
-    if (const char *e = getenv("SUHMO_POLL_READBACK")) L->poll_readback = atoi(e);
     if (L->poll_readback && hipHostGetDevicePointer((void **)&L->hscratch_dev, L->hscratch, 0) != hipSuccess) { L->hscratch_dev = nullptr; L->poll_readback = 0; (void)hipGetLastError(); }
-    *out = L;
     return 0;
 }
 
@@ -266,8 +283,8 @@ extern "C" int suhmo_level_destroy(suhmo_level_t *L)
         if (L->d[dep].phi_alt) (void)hipFree(L->d[dep].phi_alt);
     for (auto &pe : L->prof) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     if (L->xstream) { (void)hipStreamDestroy(L->xstream); (void)hipEventDestroy(L->xev[0]); (void)hipEventDestroy(L->xev[1]); }
-    (void)hipFree(L->scratch);
-    (void)hipHostFree(L->hscratch);
+    if (L->scratch) (void)hipFree(L->scratch);
+    if (L->hscratch) (void)hipHostFree(L->hscratch);
     delete L;
     return 0;
 }
@@ -285,6 +302,7 @@ extern "C" int suhmo_level_set_alpha_beta(suhmo_level_t *L, double alpha, double
 {
     ARG(L);
     L->desc.alpha = alpha; L->desc.beta = beta;
+    if (L->agg) { int rc = suhmo_level_set_alpha_beta(L->agg, alpha, beta); if (rc) return rc; }   // the agglomerated depths are depths of this operator
     return remake_views(L);
 }
 extern "C" int suhmo_level_set_bc(suhmo_level_t *L, const suhmo_bc_t *bc)
@@ -294,6 +312,7 @@ extern "C" int suhmo_level_set_bc(suhmo_level_t *L, const suhmo_bc_t *bc)
         if ((bc->periodic[d] != 0) != (L->desc.bc.periodic[d] != 0)) { suhmo_set_error("setBC cannot change the periodicity of the domain"); return -1; }
     for (int d = 0; d < 2; d++) for (int s = 0; s < 2; s++) ARG(bc->type[d][s] == 0 || bc->type[d][s] == 1);
     L->desc.bc = *bc;
+    if (L->agg) { int rc = suhmo_level_set_bc(L->agg, bc); if (rc) return rc; }
     return remake_views(L);
 }
 
@@ -406,7 +425,8 @@ static inline void phi_changed(suhmo_level *L, int depth) { L->d[depth].phi_fres
 static bool is_xface(int f) { return f == SUHMO_F_BX || f == SUHMO_F_QWX || f == SUHMO_F_DCX; }
 static bool is_yface(int f) { return f == SUHMO_F_BY || f == SUHMO_F_QWY || f == SUHMO_F_DCY; }
 static bool is_face(int f) { return is_xface(f) || is_yface(f); }
-#define CHECK_DF(L, depth, field) ARG(L); ARG(depth >= 0 && depth < L->ndepth); ARG(field >= 0 && field < SUHMO_F_COUNT)
+#define CHECK_DF(L, depth, field) ARG(L); ARG(depth >= 0 && depth < L->ndepth); ARG(field >= 0 && field < SUHMO_F_COUNT); \
+    if (L->stub) { suhmo_set_error("this box of a partitioned AMR level is held by another rank (suhmo_hier_box_owner)"); return -7; }
 
 extern "C" int suhmo_level_field_view(suhmo_level_t *L, int depth, int field, double **base, long *pitch, long *origin)
 {
@@ -455,7 +475,7 @@ extern "C" int suhmo_level_set_field(suhmo_level_t *L, int depth, int field, con
     CHECK_DF(L, depth, field); ARG(src);
     HIPCHK(hipSetDevice(L->device));
     if (field == SUHMO_F_PHI) phi_changed(L, depth);
-    if (field == SUHMO_F_MASK) L->coarse_mask_ok = 0;
+    if (field == SUHMO_F_MASK) { L->coarse_mask_ok = 0; L->maskflag_epoch = 0; }
     return field_io(L, depth, field, (double *)src, ghosted, on_device, true, (hipStream_t)s);
 }
 extern "C" int suhmo_level_get_field(suhmo_level_t *L, int depth, int field, double *dst, int ghosted,
@@ -485,7 +505,7 @@ extern "C" int suhmo_level_put_box(suhmo_level_t *L, int depth, int field, int i
     hipStream_t st = (hipStream_t)s;
     const DV &v = L->d[depth].v;
     if (field == SUHMO_F_PHI) phi_changed(L, depth);
-    if (field == SUHMO_F_MASK) L->coarse_mask_ok = 0;
+    if (field == SUHMO_F_MASK) { L->coarse_mask_ok = 0; L->maskflag_epoch = 0; }
     int r[4]; box_region(L, depth, field, ibox, r);
     int j0 = v.j0;                         // fab indices are global: local j = global j - j0
     flo0 -= v.i0; fhi0 -= v.i0;            // ... and local i = global i - i0 (AMR patch)
@@ -1771,6 +1791,7 @@ extern "C" int suhmo_level_axby(suhmo_level_t *L, int depth, int dst, int x, int
     Depth &D = L->d[depth];
     double *pd = suhmo_field(L, depth, dst), *px = suhmo_field(L, depth, x), *py = suhmo_field(L, depth, y);
     if (dst == SUHMO_F_PHI) phi_changed(L, depth);
+    if (dst == SUHMO_F_MASK) { L->coarse_mask_ok = 0; L->maskflag_epoch = 0; }      // (the reports about the ice mask end with any write to it)
     hipLaunchKernelGGL(k_axby, grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, pd, px, py, a, b);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1781,6 +1802,7 @@ extern "C" int suhmo_level_set_value(suhmo_level_t *L, int depth, int field, dou
     HIPCHK(hipSetDevice(L->device));
     Depth &D = L->d[depth];
     if (field == SUHMO_F_PHI) phi_changed(L, depth);
+    if (field == SUHMO_F_MASK) { L->coarse_mask_ok = 0; L->maskflag_epoch = 0; }
     hipLaunchKernelGGL(k_setval, grid2d(D.v.nx, D.v.ny), BLK2D, 0, (hipStream_t)s, D.v, suhmo_field(L, depth, field), val);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1994,6 +2016,7 @@ __global__ __launch_bounds__(256) void k_norm_max_partial_m(const DV *__restrict
 static inline dim3 grid_m(const suhmo_multi &m, int ex = 0, int ey = 0) { return dim3((m.maxnx + ex + 63) / 64, (m.maxny + ey + 3) / 4, m.nbox); }
 int suhmo_multi_fill_ghosts(const suhmo_multi &m, int field, int homog, hipStream_t st)
 {
+    if (m.nbox <= 0) return 0;                       // a rank that owns no box of the level
     int n = 2 * m.maxny + 2 * m.maxnx;
     hipLaunchKernelGGL(k_fill_ghosts_m, dim3((n + 255) / 256, 1, m.nbox), dim3(256), 0, st, m.dv, m.fp, field, homog);
     HIPCHK(hipGetLastError());
@@ -2001,6 +2024,7 @@ int suhmo_multi_fill_ghosts(const suhmo_multi &m, int field, int homog, hipStrea
 }
 int suhmo_multi_apply(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int mode, hipStream_t st)
 {
+    if (m.nbox <= 0) return 0;                       // a rank that owns no box of the level
     if (has_alpha) { if (mode == 0) hipLaunchKernelGGL((k_apply_m<true, 0>), grid_m(m), BLK2D, 0, st, m.dv, m.fp, ph, 0);
                      else if (mode == 1) hipLaunchKernelGGL((k_apply_m<true, 1>), grid_m(m), BLK2D, 0, st, m.dv, m.fp, ph, 0);
                      else hipLaunchKernelGGL((k_apply_m<true, 3>), grid_m(m), BLK2D, 0, st, m.dv, m.fp, ph, 0); }
@@ -2012,6 +2036,7 @@ int suhmo_multi_apply(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alp
 }
 int suhmo_multi_grad_cc(const suhmo_multi &m, int hasMask, hipStream_t st)
 {
+    if (m.nbox <= 0) return 0;                       // a rank that owns no box of the level
     hipLaunchKernelGGL(k_gradcc_m, grid_m(m), BLK2D, 0, st, m.dv, m.fp, hasMask);
     int n = 2 * m.maxny + 2 * m.maxnx;
     hipLaunchKernelGGL(k_grad_ghosts_m, dim3((n + 255) / 256, 1, m.nbox), dim3(256), 0, st, m.dv, m.fp);
@@ -2020,18 +2045,21 @@ int suhmo_multi_grad_cc(const suhmo_multi &m, int hasMask, hipStream_t st)
 }
 int suhmo_multi_re(const suhmo_multi &m, const suhmo_phys_t &ph, hipStream_t st)
 {
+    if (m.nbox <= 0) return 0;                       // a rank that owns no box of the level
     hipLaunchKernelGGL(k_re_m, grid_m(m, 2, 2), BLK2D, 0, st, m.dv, m.fp, ph);
     HIPCHK(hipGetLastError());
     return 0;
 }
 int suhmo_multi_bcoef_faces(const suhmo_multi &m, const suhmo_phys_t &ph, hipStream_t st)
 {
+    if (m.nbox <= 0) return 0;                       // a rank that owns no box of the level
     hipLaunchKernelGGL(k_bcoef_faces_m, grid_m(m, 1, 1), BLK2D, 0, st, m.dv, m.fp, ph);
     HIPCHK(hipGetLastError());
     return 0;
 }
 int suhmo_multi_coef_ghosts(const suhmo_multi &m, int field, hipStream_t st)
 {
+    if (m.nbox <= 0) return 0;                       // a rank that owns no box of the level
     int n = 2 * m.maxny + 2 * m.maxnx;
     hipLaunchKernelGGL(k_coef_ghosts_m, dim3((n + 255) / 256, 1, m.nbox), dim3(256), 0, st, m.dv, m.fp, field);
     HIPCHK(hipGetLastError());
@@ -2039,12 +2067,14 @@ int suhmo_multi_coef_ghosts(const suhmo_multi &m, int field, hipStream_t st)
 }
 int suhmo_multi_axby(const suhmo_multi &m, int fd, int fx, int fy, double a, double b, hipStream_t st)
 {
+    if (m.nbox <= 0) return 0;                       // a rank that owns no box of the level
     hipLaunchKernelGGL(k_axby_m, grid_m(m), BLK2D, 0, st, m.dv, m.fp, fd, fx, fy, a, b);
     HIPCHK(hipGetLastError());
     return 0;
 }
 int suhmo_multi_copy(const suhmo_multi &m, int fd, int fs, hipStream_t st)
 {
+    if (m.nbox <= 0) return 0;                       // a rank that owns no box of the level
     hipLaunchKernelGGL(k_copy_m, grid_m(m, 2, 2), BLK2D, 0, st, m.dv, m.fp, fd, fs);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2052,6 +2082,7 @@ int suhmo_multi_copy(const suhmo_multi &m, int fd, int fs, hipStream_t st)
 int suhmo_multi_copy_between(const suhmo_multi &dst, const suhmo_multi &src, const int *fd, const int *fs, int n, hipStream_t st)
 {
     if (n < 1 || n > 4 || dst.nbox != src.nbox) { suhmo_set_error("internal: copy between hierarchies"); return -4; }
+    if (src.nbox <= 0) return 0;
     CopyPairs cp;
     cp.n = n;
     for (int q = 0; q < n; q++) { cp.fd[q] = fd[q]; cp.fs[q] = fs[q]; }
@@ -2061,6 +2092,7 @@ int suhmo_multi_copy_between(const suhmo_multi &dst, const suhmo_multi &src, con
 }
 int suhmo_multi_norm_max(const suhmo_multi &m, suhmo_level *slot, int field, double *out, hipStream_t st)
 {
+    if (m.nbox <= 0) { *out = 0.0; return 0; }
     dim3 grd(std::min((m.maxnx + 63) / 64, 4), std::min((m.maxny + 3) / 4, 16), m.nbox);
     hipLaunchKernelGGL(k_norm_max_partial_m, grd, BLK2D, 0, st, m.dv, m.fp, field, m.red);
     hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, st, m.red, (int)(grd.x * grd.y * grd.z), 0, slot->scratch, suhmo_host_slot(slot));

@@ -348,7 +348,6 @@ static int gap_level_prepare(suhmo_level *L, const suhmo_model_params_t *mp, dou
     Depth &D = L->d[0];
     if (L->gap && L->gap_dt != dt) {                       // a new time step size: only beta = dt diffFactor changes
         int rc = suhmo_level_set_alpha_beta(L->gap, 1.0, dt * mp->diffFactor); if (rc) return rc;
-        if (L->gap->agg && (rc = suhmo_level_set_alpha_beta(L->gap->agg, 1.0, dt * mp->diffFactor))) return rc;
         L->gap_dt = dt;
     }
     if (!L->gap) {
@@ -670,7 +669,7 @@ int hier_chain(suhmo_hier *H, int l, hipStream_t st)
     if ((rc = suhmo_hier_ff_(H, l, SUHMO_F_RE, -1, true, st))) return rc;
     if (t.base) { Depth &D = t.base->d[0];
         hipLaunchKernelGGL(k_qw_faces, dim3((D.v.nx + 1 + 63) / 64, (D.v.ny + 1 + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, ph); }
-    else hipLaunchKernelGGL(k_qw_faces_m, grid_m(t.m, 1, 1), dim3(64, 4), 0, st, t.m.dv, t.m.fp, ph);
+    else if (t.m.nbox > 0) hipLaunchKernelGGL(k_qw_faces_m, grid_m(t.m, 1, 1), dim3(64, 4), 0, st, t.m.dv, t.m.fp, ph);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -700,8 +699,9 @@ int hier_melt(suhmo_hier *H, int l, const suhmo_model_params_t *mp, double dt, i
         else hipLaunchKernelGGL(k_melt<0>, dim3((D.v.nx + 63) / 64, (D.v.ny + 3) / 4), dim3(64, 4), 0, st, D.v, D.fp, ph, *mp, dt);
     } else {
         const suhmo_multi &m = t.m;
+        if (diffusion) for (int f : {SUHMO_F_DCX, SUHMO_F_DCY, SUHMO_F_DTERM}) if ((rc = suhmo_hier_ensure_(H, l, f))) return rc;
+        if (m.nbox <= 0) return 0;                                               // owner computes: none of this level's boxes is this rank's
         if (diffusion) {
-            for (int f : {SUHMO_F_DCX, SUHMO_F_DCY, SUHMO_F_DTERM}) if ((rc = suhmo_hier_ensure_(H, l, f))) return rc;
             if ((rc = lev_target(H, l, st, t))) return rc;                       // the tables after the allocation
             int n = 2 * m.maxny + 2 * m.maxnx;
             hipLaunchKernelGGL(k_extrap_ghosts_m, dim3((n + 255) / 256, 1, m.nbox), dim3(256), 0, st, m.dv, m.fp, (int)SUHMO_F_MR);
@@ -731,11 +731,18 @@ int hier_picard_maxima(suhmo_hier *H, int l, bool covered, double *maxh, double 
         return 0;
     }
     const suhmo_multi &m = t.m;
-    dim3 grd(std::min((m.maxnx + 63) / 64, 4), std::min((m.maxny + 3) / 4, 8), m.nbox);       // 2 values per block: 64 nbox doubles
-    hipLaunchKernelGGL(k_picard2_partial_m, grd, dim3(64, 4), 0, st, m.dv, m.fp, covered ? 1 : 0, m.red);
-    hipLaunchKernelGGL(k_max2_final, dim3(1), dim3(256), 0, st, m.red, (int)(grd.x * grd.y * grd.z), slot->scratch, suhmo_host_slot(slot));
-    HIPCHK(hipGetLastError());
-    return suhmo_readback(slot, st, maxh, maxd);
+    *maxh = -1.0e300; *maxd = 0.0;
+    if (m.nbox > 0) {
+        dim3 grd(std::min((m.maxnx + 63) / 64, 4), std::min((m.maxny + 3) / 4, 8), m.nbox);       // 2 values per block: 64 nbox doubles
+        hipLaunchKernelGGL(k_picard2_partial_m, grd, dim3(64, 4), 0, st, m.dv, m.fp, covered ? 1 : 0, m.red);
+        hipLaunchKernelGGL(k_max2_final, dim3(1), dim3(256), 0, st, m.red, (int)(grd.x * grd.y * grd.z), slot->scratch, suhmo_host_slot(slot));
+        HIPCHK(hipGetLastError());
+        if ((rc = suhmo_readback(slot, st, maxh, maxd))) return rc;
+    }
+    if (suhmo_hier_partitioned_(H)) {                                            // owner computes: computeMax over the ranks
+        if ((rc = suhmo_hier_allreduce_max_(H, maxh)) || (rc = suhmo_hier_allreduce_max_(H, maxd))) return rc;
+    }
+    return 0;
 }
 }  // namespace
 
@@ -753,8 +760,12 @@ extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *
     static const int need[] = {SUHMO_F_MR, SUHMO_F_PW, SUHMO_F_QWX, SUHMO_F_QWY, SUHMO_F_HLAG, SUHMO_F_CD, SUHMO_F_GRADX, SUHMO_F_GRADY, SUHMO_F_RE};
     for (int l = 0; l < nlev; l++) {
         for (int f : need) if ((rc = suhmo_hier_ensure_(H, l, f))) return rc;
-        if (mp->use_moulin_source) for (suhmo_level *L : suhmo_hier_boxes_(H, l))
-            if (!L->d[0].fp.f[SUHMO_F_MSRC]) { suhmo_set_error("use_moulin_source without a moulin source term (suhmo_hier_moulin_source)"); return -1; }
+        if (mp->use_moulin_source) {
+            int k0, nk;
+            suhmo_hier_owned_(H, l, &k0, &nk);
+            for (int k = k0; k < k0 + nk; k++)
+                if (!suhmo_hier_boxes_(H, l)[k]->d[0].fp.f[SUHMO_F_MSRC]) { suhmo_set_error("use_moulin_source without a moulin source term (suhmo_hier_moulin_source)"); return -1; }
+        }
     }
     suhmo_level *base = suhmo_hier_boxes_(H, 0)[0];
     if ((base->d[0].v.rk[0] || base->d[0].v.rk[1]) && !(base->ex && base->ar)) { suhmo_set_error("time step on rank strips needs the exchange hooks on level 0"); return -1; }
@@ -848,7 +859,7 @@ extern "C" int suhmo_hier_timestep(suhmo_hier_t *H, const suhmo_model_params_t *
                 static const int fd[1] = {SUHMO_F_B}, fs[1] = {SUHMO_F_PHI};
                 suhmo_multi mh, mg;
                 if ((rc = suhmo_hier_multi_(H, l, st, &mh)) || (rc = suhmo_hier_multi_(G, l, st, &mg))) return rc;
-                if (mp->freeze_icefree_gap) {
+                if (mp->freeze_icefree_gap && mh.nbox > 0) {
                     hipLaunchKernelGGL(k_keep_icefree_m, grid_m(mh), dim3(64, 4), 0, st, mh.dv, mh.fp, mg.fp);
                     HIPCHK(hipGetLastError());
                 }
@@ -1069,19 +1080,36 @@ extern "C" int suhmo_hier_moulin_source(suhmo_hier_t *H, int n, const double *po
         ARG(sigma[m] > 0.0);
         h[3 * m] = positions[2 * m]; h[3 * m + 1] = positions[2 * m + 1]; h[3 * m + 2] = sigma[m]; h[3 * (size_t)n + m] = flux[m];
     }
-    size_t maxblk = 0;
-    for (int l = 0; l < nlev; l++) for (suhmo_level *L : suhmo_hier_boxes_(H, l)) {
-        if (!suhmo_field(L, 0, SUHMO_F_MSRC)) { suhmo_set_error("field allocation failed"); return -2; }
-        maxblk = std::max(maxblk, (size_t)((L->d[0].v.nx + 15) / 16) * (((l == 0 ? L->d[0].v.nyg : L->d[0].v.ny) + 15) / 16));
+    // owner computes (levels >= 1 dealt to the ranks): a rank integrates and fills the boxes it owns; the per-box integrals of all ranks are
+    // gathered and added up in the single-process order (finest level first, box after box), so every rank gets the same bits
+    const bool parted = suhmo_hier_partitioned_(H);
+    size_t maxblk = 0, nbt = 0;
+    std::vector<size_t> first(nlev + 1, 0);
+    for (int l = 0; l < nlev; l++) {
+        const auto &bx = suhmo_hier_boxes_(H, l);
+        first[l] = nbt; nbt += bx.size();
+        int k0, nk;
+        suhmo_hier_owned_(H, l, &k0, &nk);
+        for (int k = 0; k < (int)bx.size(); k++) {
+            suhmo_level *L = bx[k];
+            if (k >= k0 && k < k0 + nk && !suhmo_field(L, 0, SUHMO_F_MSRC)) { suhmo_set_error("field allocation failed"); return -2; }
+            maxblk = std::max(maxblk, (size_t)((L->d[0].v.nx + 15) / 16) * (((l == 0 ? L->d[0].v.nyg : L->d[0].v.ny) + 15) / 16));
+        }
     }
+    first[nlev] = nbt;
     double *dev = nullptr;
     HIPCHK(hipMalloc(&dev, (5 * (size_t)n + maxblk * n) * sizeof(double)));
     double *mo = dev, *fl = dev + 3 * (size_t)n, *integ = dev + 4 * (size_t)n, *partial = dev + 5 * (size_t)n;
     hipError_t e = hipMemcpyAsync(dev, h.data(), 4 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
     DV whole;
     const double *whole_cover = suhmo_hier_base_cover_(H, &whole);     // level 0 cut into rank strips: every rank integrates all of it (geometry only)
-    for (int l = nlev - 1; l >= 0 && e == hipSuccess; l--)             // finest first (:1891)
-        for (suhmo_level *L : suhmo_hier_boxes_(H, l)) {
+    std::vector<double> perbox(nbt * (size_t)n, 0.0);                  // the integrals over every box (this rank's; the others' after the gather)
+    for (int l = nlev - 1; l >= 0 && e == hipSuccess; l--) {
+        const auto &bx = suhmo_hier_boxes_(H, l);
+        int k0, nk;
+        suhmo_hier_owned_(H, l, &k0, &nk);
+        for (int k = k0; k < k0 + nk; k++) {
+            suhmo_level *L = bx[k];
             const bool cutbase = l == 0 && (L->d[0].v.rk[0] || L->d[0].v.rk[1]);
             DV v = L->d[0].v;
             if (cutbase) { v.ny = v.nyg; v.j0 = 0; }
@@ -1093,11 +1121,39 @@ extern "C" int suhmo_hier_moulin_source(suhmo_hier_t *H, int n, const double *po
             if (e == hipSuccess) e = hipMemcpyAsync(part.data(), integ, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) break;
-            for (int m = 0; m < n; m++) total[m] += part[m];
+            for (int m = 0; m < n; m++) perbox[(first[l] + k) * (size_t)n + m] = part[m];
         }
+    }
+    if (e == hipSuccess && parted) {                                   // every rank's integrals over its boxes -> every rank
+        const int world = suhmo_hier_world_(H);
+        const size_t cnt = nbt * (size_t)n;
+        double *gs = nullptr, *gr = nullptr;
+        std::vector<double> all(cnt * world);
+        e = hipMalloc(&gs, cnt * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc(&gr, cnt * world * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpyAsync(gs, perbox.data(), cnt * sizeof(double), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && (rc = suhmo_hier_allgather_(H, gs, (long)cnt, gr, st))) { (void)hipFree(gs); (void)hipFree(gr); (void)hipFree(dev); return rc; }
+        if (e == hipSuccess) e = hipMemcpyAsync(all.data(), gr, cnt * world * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (gs) (void)hipFree(gs);
+        if (gr) (void)hipFree(gr);
+        if (e == hipSuccess)
+            for (int l = 1; l < nlev; l++)
+                for (size_t k = 0; k < first[l + 1] - first[l]; k++) {
+                    const int o = suhmo_hier_box_owner(H, l, (int)k, nullptr);
+                    if (o >= 0) for (int m = 0; m < n; m++) perbox[(first[l] + k) * (size_t)n + m] = all[(size_t)o * cnt + (first[l] + k) * (size_t)n + m];
+                }
+    }
+    for (int l = nlev - 1; l >= 0; l--)                                // finest first (:1891), box after box
+        for (size_t k = first[l]; k < first[l + 1]; k++)
+            for (int m = 0; m < n; m++) total[m] += perbox[k * (size_t)n + m];
     if (e == hipSuccess) e = hipMemcpyAsync(integ, total.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
-    for (int l = 0; l < nlev && e == hipSuccess; l++)
-        for (suhmo_level *L : suhmo_hier_boxes_(H, l)) {
+    for (int l = 0; l < nlev && e == hipSuccess; l++) {
+        const auto &bx = suhmo_hier_boxes_(H, l);
+        int k0, nk;
+        suhmo_hier_owned_(H, l, &k0, &nk);
+        for (int k = k0; k < k0 + nk; k++) {
+            suhmo_level *L = bx[k];
             const DV &v = L->d[0].v;
             dim3 blk(16, 16), grd((v.nx + 15) / 16, (v.ny + 15) / 16);
             const double *cover = l < nlev - 1 ? L->d[0].fp.f[SUHMO_F_COVER] : nullptr;
@@ -1105,6 +1161,7 @@ extern "C" int suhmo_hier_moulin_source(suhmo_hier_t *H, int n, const double *po
             e = hipGetLastError();
             if (e != hipSuccess) break;
         }
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(dev);
     if (e != hipSuccess) { suhmo_set_error("moulin source: %s", hipGetErrorString(e)); return -2; }

@@ -116,3 +116,70 @@ def test_cfg5_at_the_north_star_size_properties():
             for nm in ("head", "B", "mR"):
                 assert np.all(np.isfinite(G.get(l, k, nm)))
     G.close()
+
+
+def _cfg5_solver_inputs(nb, boxes, mo, m):
+    """cfg5's state (mountain bed, ice, gap height, initial head) as inputs of the head solve on every box: the right-hand side is the
+    distributed input plus the moulins' Gaussians sampled at the cell centres (numpy, the same array for checker and device)"""
+    sts = sy.mountain_amrm_states(nb, nb, boxes)
+    pos, sg, fl = mo["positions"], mo["sigma"], mo["flux"]
+    out = []
+    for l, bl in enumerate([[(0, 0, nb - 1, nb - 1)]] + [list(b) for b in boxes]):
+        lev = []
+        for k, (lo0, lo1, hi0, hi1) in enumerate(bl):
+            st = sts[l][k]
+            nx, ny, dx, dy = hi0 - lo0 + 1, hi1 - lo1 + 1, st["dx"], st["dy"]
+            x = (np.arange(lo0, hi0 + 1) + 0.5) * dx
+            y = (np.arange(lo1, hi1 + 1) + 0.5) * dy
+            rhs = np.full((ny, nx), float(m["distributed_input"]))
+            for (px, py), s, q in zip(pos, sg, fl):
+                if px + 6 * s < x[0] or px - 6 * s > x[-1] or py + 6 * s < y[0] or py - 6 * s > y[-1]:
+                    continue
+                rhs = rhs + (q / (2.0 * np.pi * s * s)) * np.exp(-((x[None, :] - px) ** 2 + (y[:, None] - py) ** 2) / (2.0 * s * s))
+            lev.append(dict(nx=nx, ny=ny, dx=dx, dy=dy, box=(lo0, lo1, hi0, hi1), phi=np.ascontiguousarray(st["head"][1:-1, 1:-1]), rhs=rhs,
+                            aCoef=np.zeros((ny, nx)), B=st["B"], Pi=st["Pi"], zb=st["zb"], mask=st["mask"]))
+        out.append(lev if l else lev[0])
+    return out
+
+
+@pytest.mark.timeout(1500)
+def test_cfg5_north_star_size_amr_vcycles_bitwise(oracle):
+    """BASELINE north_star's own size: 4096^2 base + 3 AMR levels of boxes around the 63 moulins (exec/AMR_multiMoulins/run_C_3lev/input.hydro,
+    src/AmrHydro.cpp:3119-3141: SolveForHead_nl on the hierarchy).  The head solve's loop -- composite residual, two AMR FAS V-cycles, the
+    residual after each -- against oracle/amrm.c on the host's cores: residual history, the head of EVERY box of EVERY level and of the
+    16.8 M cells of level 0, bit for bit.  This is the size where level 0 relaxes on the streaming kernel whose last launch leaves
+    L(phi) and the TRUE rhs - L(phi) behind (resout_rhs), where the cycle's composite residual of level 0 re-evaluates only the rectangles
+    the average from level 1 changed, and where level 0's gradient is evaluated only at the cells level 1's stencils read: the counters
+    say that all three ran."""
+    from suhmo_amd import level as lv
+    bc, ph, m, mo = sy.multimoulins_setup()
+    nb = 4096
+    boxes = sy.boxes_around(mo["positions"], nb, nb, 4, 1.0e5, 1.0e5)
+    fs = _cfg5_solver_inputs(nb, boxes, mo, m)
+    sp = dict(num_smooth=4, num_bottom=16, max_iter=2, iter_min=2, imin=5, eps=1e-10, hang=1e-4, norm_thresh=1e-10, bcoeff_otf=1, max_depth=-1)
+    G = lv.HipHier(nb, nb, fs[0]["dx"], fs[0]["dy"], bc, ph, boxes, max_box=64)
+    G.set_inputs(fs)
+    base = G.coarse
+    c0 = (G.get_option("incremental_residual_passes"), G.get_option("residuals_left_by_relax"), G.get_option("sparse_gradient_passes"),
+          base.get_option("residual_in_relax_launches"))
+    ng, hg = G.solve(sp)
+    c1 = (G.get_option("incremental_residual_passes"), G.get_option("residuals_left_by_relax"), G.get_option("sparse_gradient_passes"),
+          base.get_option("residual_in_relax_launches"))
+    assert ng == 2
+    assert c1[0] - c0[0] >= 1, "the cycle's composite residual of level 0 was not the incremental one"
+    assert c1[1] - c0[1] == 2, "the solve loop's residual of level 0 was not the one the cycle's last launch left behind"
+    assert c1[2] - c0[2] == 2, "level 0's gradient was evaluated over the whole level"
+    assert c1[3] - c0[3] >= 2, "the streaming launch did not write the residual (resout_rhs)"
+    got = [[G.level[l][k].get(lv.F_PHI) for k in range(len(G.level[l]))] for l in range(G.nlev)]
+    G.close()
+    import os
+    O = oracle.OracleAmrM(nb, nb, fs[0]["dx"], fs[0]["dy"], bc, ph, boxes, max_box=64, nthreads=min(16, len(os.sched_getaffinity(0))))
+    O.set_inputs(fs)
+    no, ho = O.solve(sp)
+    assert no == ng and np.array_equal(ho, hg), (no, ng, ho, hg)
+    assert np.array_equal(O.coarse.get(oracle.F_PHI), got[0][0]), "level 0"
+    for l in range(1, O.nlev):
+        for k in range(len(boxes[l - 1])):
+            a = O.box_get(l, k, oracle.F_PHI)
+            assert np.array_equal(a, got[l][k]), (l, k, float(np.max(np.abs(a - got[l][k]))))
+    O.close()

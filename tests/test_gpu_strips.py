@@ -273,3 +273,45 @@ def test_strips_agglomerated_coarse_depths(world, n, agg_min_cells, expect_da, p
     assert all(p[2] == n_ for p in parts)
     assert np.array_equal(parts[0][3], hist)
     assert np.array_equal(np.vstack([p[1] for p in parts]), O.get(oracle.F_PHI))
+
+
+@pytest.mark.parametrize("world,agg_min_cells,expect_da", [(2, 40000, 1), (4, 2000, 2)])
+def test_agglomeration_set_after_the_coefficient_build_and_operator_changes_reach_it(world, agg_min_cells, expect_da, oracle):
+    """the agglomerated copy created AFTER suhmo_build_mg_coefficients (set_option("agg_min_cells") on a level whose environment default is
+    off): the cycle gathers the coarse coefficients before it enters the copy; suhmo_level_set_alpha_beta / set_bc through the C-ABI reach
+    the agglomerated depths too (an operator with beta = -2 and other boundary values equals an oracle level created that way)"""
+    import ctypes as C
+    from suhmo_amd import level as lv, capi
+    n = 256
+    bc, bc2 = sy.A3_BC, dict(sy.A3_BC, value=[[3.0, 0.0], [0.0, 0.0]])
+    f = wrap_ghosts(sy.shmip_fields(n, n, ly=1.0e5), bc)
+    ph = sy.A3_PHYS
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-10, norm_thresh=1e-13, max_iter=3, imin=4)
+
+    def body(G, rank):
+        G.build_mg_coefficients()
+        assert capi.lib().suhmo_level_agglomerated_depth(G.h) == 0
+        G.set_option("agg_min_cells", agg_min_cells)
+        da = capi.lib().suhmo_level_agglomerated_depth(G.h)
+        G.vcycle(sp)
+        p1 = G.get(lv.F_PHI)
+        capi.check(capi.lib().suhmo_level_set_alpha_beta(G.h, 0.0, -2.0))
+        b = lv._bc(bc2)
+        capi.check(capi.lib().suhmo_level_set_bc(G.h, C.byref(b)))
+        G.vcycle(sp)
+        return p1, G.get(lv.F_PHI), da
+
+    parts = run_strips(world, f, bc, ph, 0.0, -1.0, body, halo=24, max_box=64)
+    assert all(p[2] == expect_da for p in parts), [p[2] for p in parts]
+    O = oracle.OracleLevel(n, n, f["dx"], f["dy"], bc, ph, 0.0, -1.0, 64, 4)
+    O.set_inputs(f); O.build_mg_coefficients(); O.vcycle(sp)
+    phi1 = O.get(oracle.F_PHI)
+    assert np.array_equal(np.vstack([p[0] for p in parts]), phi1)
+    O2 = oracle.OracleLevel(n, n, f["dx"], f["dy"], bc2, ph, 0.0, -2.0, 64, 4)
+    f2 = dict(f, phi=phi1)
+    O2.set_inputs(f2); O2.build_mg_coefficients()
+    for k, fid in (("bx", oracle.F_BX), ("by", oracle.F_BY)):
+        O2.set(fid, O.get(fid))                           # the face coefficients the first cycle's UpdateOperator left (bcoeff_otf rebuilds them anyway)
+    O2.vcycle(sp)
+    assert np.array_equal(np.vstack([p[1] for p in parts]), O2.get(oracle.F_PHI))
+    O.close(); O2.close()

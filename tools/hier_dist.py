@@ -59,7 +59,7 @@ def main():
 
         def progress():
             for k in range(2):
-                time.sleep(int(os.environ["SUHMO_DUMP_AFTER"]) - 30 + 20 * k)
+                time.sleep(max(1, int(os.environ["SUHMO_DUMP_AFTER"]) - 30 + 20 * k))
                 print("rank %d after %.0f s: %d all-gathers of coarse cells, %d of owners' boxes, %d halo message groups, %d agglomeration gathers"
                       % (rank, time.perf_counter() - t_start, H.hier.gathers(), H.hier.get_option("partition_gathers"),
                          H.level[0][0].rccl_exchanges() if hasattr(H.level[0][0], "rccl_exchanges") else -1, H.level[0][0].get_option("agg_gathers")), flush=True)

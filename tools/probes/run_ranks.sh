@@ -9,7 +9,7 @@ for r in $(seq 0 $((W - 1))); do
   RANK=$r LOCAL_RANK=$r WORLD_SIZE=$W MASTER_ADDR=127.0.0.1 MASTER_PORT=$PORT SUHMO_DIST_BACKEND=gloo OMP_NUM_THREADS=1 \
   timeout -k 5 $T python3 -c "
 import faulthandler, runpy, sys
-faulthandler.dump_traceback_later($T - 20, exit=False)
+faulthandler.dump_traceback_later(max(1, $T - 20), exit=False)
 sys.argv = ['$TOOL'] + '$*'.split()
 runpy.run_path('$R/tools/$TOOL', run_name='__main__')
 " > $R/gpurun_out/rank_$r.log 2>&1 &
