@@ -24,7 +24,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_PER_CELL_SWEEP = 72.0    # phi r+w, rhs, bx, by, B, Pi, zb, mask
-PMC_FILE = "r03_pmc_traffic_gsrb.json"   # HBM bytes per launch of the depth-0 kernel, from this round's rocprofv3 --pmc passes
+PMC_FILE = "r04_pmc_traffic_gsrb.json"   # HBM bytes per launch of the depth-0 kernel, from this round's rocprofv3 --pmc passes
+PMC_VCYCLE_FILE = "r04_pmc_traffic_vcycle.json"   # HBM bytes of ONE whole V-cycle, every kernel (tools/pmc_vcycle.sh + tools/make_traffic_json.py --vcycle)
+FLOOR_FILE = "r04_other_configs_floor.json"       # ms of the smaller configurations this build is held to (regression guard)
 LX = 1.0e5                     # width of the synthetic domain in metres (SHMIP-A: 100 km)
 
 
@@ -37,6 +39,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--sweeps-only", type=int, default=0, help="also time this many bare GSRB sweeps")
     ap.add_argument("--no-side", action="store_true", help="skip the side figures of the smaller BASELINE configurations")
+    ap.add_argument("--no-guard", action="store_true", help="report a configuration slower than its committed floor without failing")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: every rank holds cells x cells; strong: the level of cells x cells is cut into --gpus row strips")
     args = ap.parse_args()
@@ -134,6 +137,12 @@ def main():
         pj = json.load(open(pmc))
         if pj.get("cells") == cells and abs(sweeps_timed / gsrb_launches - pj.get("sweeps_per_launch", 0)) < 1e-9:
             traffic, traffic_src = pj["hbm_bytes_per_launch"], "profiles/" + PMC_FILE
+    vtraffic, vtraffic_src = None, None
+    pmcv = os.path.join(ROOT, "profiles", PMC_VCYCLE_FILE)
+    if os.path.exists(pmcv) and world == 1:
+        pv = json.load(open(pmcv))
+        if pv.get("cells") == cells:
+            vtraffic, vtraffic_src = pv["hbm_bytes_per_vcycle"], "profiles/" + PMC_VCYCLE_FILE
     launch_ms = gsrb_ms / max(gsrb_launches, 1)
     alg_bytes_launch = BYTES_PER_CELL_SWEEP * cells * sweeps_timed / max(gsrb_launches, 1)
 
@@ -161,6 +170,8 @@ def main():
         extra["solve_iteration"] = {"ms": 1e3 * (time.perf_counter() - t0) / k_it, "iterations": k_it,
                                     "what": "V-cycle + residual + max norm + read-back per iteration of suhmo_level_solve",
                                     "residual_left_by_the_last_launch": bool(G.get_option("residual_in_relax_launches") - c0 >= k_it)}
+    if not args.no_side and world == 1:
+        extra["converged_solve"] = converged_solve(sy, level, G, f, n, rows)
     if args.sweeps_only:
         sync()
         G.profile(True)
@@ -177,8 +188,11 @@ def main():
     # the other configurations of BASELINE.json that fit this run, as side figures (not `value`): configs[1] =
     # SHMIP A3 on 1024^2 single-level (cache-resident: 9 arrays x 8 MB, so it is not an HBM-roofline case),
     # configs[2] = 2-level AMR (64 x 16 base + refined box), and the time step of SHMIP A3 (320 x 64)
+    guard = None
     if world == 1 and not args.no_side:
         extra["other_configs"] = side_configs(sy, level, sp, args)
+        guard = regression_guard(extra["other_configs"], lambda: side_configs(sy, level, sp, args))
+        extra["regression_guard"] = guard
 
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -207,6 +221,9 @@ def main():
                                    "%d MG depths, 4+4 GSRB sweeps per depth, %d bottom (BASELINE north_star: 4096^2 single-level)"
                                    % (n, rows, LX / n, ndepth, sp["num_bottom"]),
                        "global_cells": [n, ny_global], "partition": "row strips, 1 per GPU" if world > 1 else "none",
+                       # N > 1: the halo transport in use and the number of ranks its communicator reports (ncclCommCount), so that N can be verified
+                       "transport": transport_name(G) if world > 1 else None,
+                       "ranks_in_communicator": int(capi.lib().suhmo_level_rccl_comm_count(G.h)) if world > 1 else None,
                        "unit_of_value": "V-cycles over %dx%d cells (%s; the level of %dx%d cells completes %.4g V-cycles/s)"
                                         % (n, n, "the whole level, cut into strips" if strong else "one per GPU per step", n, ny_global, vps),
                        "halo_message_groups_per_vcycle_per_rank": msgs if world > 1 else None,
@@ -227,6 +244,9 @@ def main():
                          "physical_frac": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "blocked_bound_frac": (BYTES_PER_CELL_SWEEP * cells / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if gsrb_launches else None,
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
+                         # the whole cycle: PMC bytes of EVERY kernel of one V-cycle / the measured time of a V-cycle / peak
+                         "vcycle_hbm_bytes": vtraffic, "vcycle_hbm_bytes_source": vtraffic_src,
+                         "vcycle_physical_frac": (vtraffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if vtraffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": launch_ms,
                          "algorithmic_bytes_per_cell_sweep": BYTES_PER_CELL_SWEEP,
                          "avg_sweep_ms": sweep_ms, "sweeps_timed": sweeps_timed, "launches_timed": gsrb_launches},
@@ -238,6 +258,69 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if guard is not None and not guard["ok"] and not args.no_guard:
+        sys.exit("bench.py: regression guard: %s" % "; ".join(guard["slower_than_floor"]))
+
+
+def transport_name(G):
+    ex = getattr(G, "_exchanger", None)
+    if ex == "rccl":
+        return os.environ.get("SUHMO_TRANSPORT", "rccl") if os.environ.get("SUHMO_TRANSPORT") in ("ipc",) else "rccl (ncclSend / ncclRecv on the kernels' stream)"
+    return "torch.distributed P2P (%s)" % type(getattr(ex, "tr", ex)).__name__
+
+
+def converged_solve(sy, level, G, f, n, rows):
+    """Time to solution, not V-cycles per second: suhmo_level_solve from SHMIP-A's initial head to the reference's tolerances of a
+    step >= 50 (src/AmrHydro.cpp:737-762: eps 1e-7, hang 0.01, normThresh 1e-7, iterMin 2, <= 100 cycles, 4 + 4 sweeps, 16 bottom) on the
+    bench level with the 64^2 boxes of the headline (the cycle bottoms out at 128^2 cells) and with max_box_size = the level (an ordinary
+    input of the reference, exec/A_SHMIP/A3/input.hydro:71-72: the cycle goes down to 2^2 cells).  Both bitwise against the oracle at
+    1024^2 (tests/test_gpu_parity.py::test_converged_solve_bitwise)."""
+    out = {}
+    sp = dict(sy.SOLVER_DEFAULT)
+    for tag, mb in (("max_box_64", 64), ("max_box_is_the_level", n)):
+        if mb == 64:
+            L = G
+        else:
+            L = level.HipLevel(n, rows, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=mb)
+        L.set_inputs(f); L.build_mg_coefficients()
+        L.synchronize()
+        t0 = time.perf_counter()
+        it, hist = L.solve(sp)
+        L.synchronize()
+        dt = time.perf_counter() - t0
+        out[tag] = {"ms": 1e3 * dt, "vcycles": int(it), "mg_depths": L.ndepth, "residual_first": float(hist[0]), "residual_last": float(hist[-1]),
+                    "converged": bool(hist[-1] <= sp["norm_thresh"] or hist[-1] <= sp["eps"] * hist[0])}
+        if L is not G:
+            L.close()
+    out["tolerances"] = "eps %g, hang %g, normThresh %g, iterMin %d, max %d cycles (src/AmrHydro.cpp:737-762, step >= 50)" % (
+        sp["eps"], sp["hang"], sp["norm_thresh"], sp["iter_min"], sp["max_iter"])
+    return out
+
+
+def regression_guard(configs, remeasure):
+    """every entry of other_configs against the committed floor (profiles/FLOOR_FILE: ms this build is held to): > 10 % slower fails the run
+    (non-zero exit after the JSON line) -- once re-measured, so that one disturbed measurement does not"""
+    path = os.path.join(ROOT, "profiles", FLOOR_FILE)
+    if not os.path.exists(path):
+        return {"ok": True, "floor": None}
+    floor = json.load(open(path))["ms"]
+
+    def ms_of(e):
+        return e.get("ms_per_vcycle", e.get("ms_per_step"))
+
+    def slow(cfgs):
+        return [k for k, v in floor.items() if k in cfgs and ms_of(cfgs[k]) > 1.10 * v]
+    bad = slow(configs)
+    retried = False
+    if bad:
+        retried = True
+        again = remeasure()
+        for k in bad:
+            if k in again and ms_of(again[k]) < ms_of(configs[k]):
+                configs[k] = again[k]
+        bad = slow(configs)
+    return {"ok": not bad, "floor": "profiles/" + FLOOR_FILE, "threshold": "1.10 x floor ms", "remeasured": retried,
+            "slower_than_floor": ["%s: %.3f ms against a floor of %.3f" % (k, ms_of(configs[k]), floor[k]) for k in bad]}
 
 
 def spawn_ranks(args):

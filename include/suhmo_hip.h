@@ -323,6 +323,7 @@ int suhmo_level_attach_rccl(suhmo_level_t *L, const void *id128, int rank, int w
                             suhmo_stream_t s);
 int suhmo_level_detach_rccl(suhmo_level_t *L);
 long suhmo_level_rccl_exchanges(const suhmo_level_t *L);
+int suhmo_level_rccl_comm_count(const suhmo_level_t *L);   /* ranks the level's communicator reports (ncclCommCount); -1: not attached */
 
 /* ---- two AMR levels: base level `coarse` (spans the domain) + one patch `fine` refined by 2, created with
  * desc.i0 / nx_global / j0 / ny_global = its place in the refined domain (coarse-aligned), dx = coarse dx / 2.

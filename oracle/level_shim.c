@@ -659,11 +659,29 @@ double or_level_norm(OrLevel *L, int depth, int field, int ord)
 /* ---------------- FAS multigrid cycle ----------------
  * The cycle driver (AMRFASMultiGrid) lives in the un-vendored Chombo fork; this is the
  * reconstruction documented in SURVEY.md Appendix D / DESIGN.md ("unpinned"). */
+/* Test-only variants of what the un-vendored fork may do differently (tools/stopping_rule_sweep.py; never set in a parity run):
+ *   SUHMO_ORACLE_STOP    bit 0: no exit on normThresh (only eps x the initial norm, the hang test and maxIter end a solve)
+ *                        bit 1: imin is a hard minimum number of cycles (upstream: it only postpones the hang test)
+ *   SUHMO_ORACLE_BOTTOM  1: the bottom relaxes are followed by Chombo's RelaxSolver::solve as the fork's three-argument preCond
+ *                        (src/VCAMRNonLinearPoissonOp.cpp:233-271 = relax(phi, rhs, 2)) would run it: up to imax = 40 rounds of two
+ *                        sweeps, ended by an l2 residual below 1e-6 x its first value or reduced by less than 10 % */
+static int or_variant(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
 static void fas_cycle(OrLevel *L, int dep, const OrSolverParams *sp, int ndepth)
 {
     Depth *D = &L->d[dep];
     if (dep == ndepth - 1) {                       /* coarsest: bottom relaxes */
         or_level_gsrb(L, dep, sp->num_bottom);
+        if (or_variant("SUHMO_ORACLE_BOTTOM") == 1) {
+            or_level_residual(L, dep);
+            double norm = or_level_norm(L, dep, OR_F_RES, 2), first = norm;
+            for (int it = 0; it < 40 && norm > 1.0e-20; it++) {
+                or_level_gsrb(L, dep, 2);
+                or_level_residual(L, dep);
+                double old = norm;
+                norm = or_level_norm(L, dep, OR_F_RES, 2);
+                if (norm < 1.0e-6 * first || norm > old * (1.0 - 0.1)) break;
+            }
+        }
         return;
     }
     Depth *C = &L->d[dep + 1];
@@ -719,6 +737,9 @@ int or_level_solve(OrLevel *L, const OrSolverParams *sp, double *hist)
     int goIter = iter < sp->max_iter;
     int goHang = iter < sp->imin || rnorm < (1.0 - sp->hang) * norm_last;
     int goMin = iter < sp->iter_min;
+    const int variant = or_variant("SUHMO_ORACLE_STOP");           /* test-only, see fas_cycle */
+    if (variant & 1) goNorm = 1;
+    if (variant & 2) goMin = goMin || iter < sp->imin;
     while (goMin || (goIter && goRedu && goHang && goNorm)) {
         norm_last = rnorm;
         or_level_vcycle(L, sp);
@@ -731,6 +752,8 @@ int or_level_solve(OrLevel *L, const OrSolverParams *sp, double *hist)
         goIter = iter < sp->max_iter;
         goHang = iter < sp->imin || rnorm < (1.0 - sp->hang) * norm_last;
         goMin = iter < sp->iter_min;
+        if (variant & 1) goNorm = 1;
+        if (variant & 2) goMin = goMin || iter < sp->imin;
     }
     return iter;
 }

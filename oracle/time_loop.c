@@ -452,6 +452,8 @@ int or_model_timestep(OrModel *M, double dt, int *picard_iters, int *vcycles_tot
             free(bx); free(by);
         }
         or_level_build_mg_coefficients(M->L);
+        if (cur_picard > 0 && getenv("SUHMO_ORACLE_MIN_FIRST_SOLVE_ONLY")) { sp.iter_min = 0; sp.imin = 0; }   /* test-only variant (tools/stopping_rule_sweep.py):
+                                                                                    iterMin / imin held per time step, not per solve */
         nv += or_level_solve(M->L, &sp, NULL);
         or_level_get(M->L, 0, OR_F_PHI, tmp, 0);
         for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) CC(h, i, j) = tmp[(size_t)j * nx + i];

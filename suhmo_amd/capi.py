@@ -70,12 +70,12 @@ SYMBOLS = [
     "suhmo_level_unpack_rows", "suhmo_level_set_hooks", "suhmo_level_exchange", "suhmo_level_halo_info", "suhmo_level_profile_reset",
     "suhmo_level_profile_enable", "suhmo_level_profile_read", "suhmo_level_profile_read_restricting", "suhmo_level_timestep",
     "suhmo_rccl_load", "suhmo_rccl_unique_id", "suhmo_level_attach_rccl", "suhmo_level_detach_rccl",
-    "suhmo_level_rccl_exchanges",
+    "suhmo_level_rccl_exchanges", "suhmo_level_rccl_comm_count",
     "suhmo_amr2_cf_interp", "suhmo_amr2_average", "suhmo_amr2_fine_update_operator", "suhmo_amr2_residual",
     "suhmo_amr2_vcycle", "suhmo_amr2_solve", "suhmo_level_moulin_source", "suhmo_amr2_prolong2", "suhmo_amr2_set_covered",
     "suhmo_amr_residual", "suhmo_amr_vcycle", "suhmo_amr_solve", "suhmo_level_postproc_table", "suhmo_level_postproc_partial", "suhmo_postproc_finish", "suhmo_postproc_temporal", "suhmo_level_postproc_temporal",
     "suhmo_level_set_alpha_beta", "suhmo_level_set_bc", "suhmo_amr2_reflux", "suhmo_amr2_pwl_fill", "suhmo_amr_timestep", "suhmo_level_time_varying_recharge", "suhmo_amr_moulin_source", "suhmo_amr2_prolong_pc", "suhmo_amr2_finer_operator_changed",
-    "suhmo_hier_create", "suhmo_hier_destroy", "suhmo_hier_num_levels", "suhmo_hier_num_boxes", "suhmo_hier_box", "suhmo_hier_exchange",
+    "suhmo_hier_create", "suhmo_hier_destroy", "suhmo_hier_num_levels", "suhmo_hier_num_boxes", "suhmo_hier_box", "suhmo_hier_box_owner", "suhmo_hier_exchange",
     "suhmo_hier_cf_interp", "suhmo_hier_pwl_fill", "suhmo_hier_average", "suhmo_hier_gsrb", "suhmo_hier_update_operator",
     "suhmo_hier_residual", "suhmo_hier_vcycle", "suhmo_hier_solve", "suhmo_hier_timestep", "suhmo_hier_moulin_source",
     "suhmo_hier_set_allgather", "suhmo_hier_attach_rccl", "suhmo_hier_gathers", "suhmo_level_set_option", "suhmo_level_get_option", "suhmo_timers_enable", "suhmo_timers_reset", "suhmo_timers_report",
@@ -183,6 +183,7 @@ def lib():
     L.suhmo_hier_num_boxes.argtypes = [vp, ci]
     L.suhmo_hier_box.argtypes = [vp, ci, ci]
     L.suhmo_hier_box.restype = vp
+    L.suhmo_hier_box_owner.argtypes = [vp, ci, ci, ip]
     L.suhmo_hier_exchange.argtypes = [vp, ci, ci, ci, vp]
     L.suhmo_hier_cf_interp.argtypes = [vp, ci, ci, ci, vp]
     L.suhmo_hier_pwl_fill.argtypes = [vp, ci, ci, ci, vp]

@@ -168,9 +168,10 @@ struct suhmo_hier {
     bool shadowed = false;                                 // world > 1, or creation option shadow = 1 (tests: the whole path on one rank)
     std::string options;                                   // as given to suhmo_hier_create_opts (the gap hierarchy is created with the same)
     DV vglob;                                              // level 0 as one canvas (= the base view when it is not cut)
-    FP shadow{};
-    size_t shadow_elems = 0;
-    DevVec<int> need; DevVec<int2> need_rl;                // offsets in vglob; (owner rank, position in the owner's segment)
+    FP shadow{};                                           // COMPACT: only the rows of level 0 that hold a cell some plan reads (shadow_rows of them, pitch
+    size_t shadow_elems = 0; int shadow_rows = 0;          // vglob.P; a plan's offset = compact row * P + column); fields allocated on first use
+    double *cover_whole = nullptr;                         // SUHMO_F_COVER of the WHOLE level 0 (geometry only; the moulin integrals run over all of it)
+    DevVec<int> need, need_c; DevVec<int2> need_rl;        // offsets in vglob (what the owner packs) / in the compact shadow; (owner rank, position in its segment)
     std::vector<int> seg;                                  // need[seg[r] .. seg[r+1]) are rows of rank r
     long cnt_max = 0;                                      // longest segment: every rank contributes cnt_max doubles per field
     double *xs = nullptr, *xr = nullptr; size_t xcap = 0;  // staging of the all-gather
@@ -694,6 +695,22 @@ int build_plans(suhmo_hier *H, int l)
         std::sort(needv.begin(), needv.end());
         needv.erase(std::unique(needv.begin(), needv.end()), needv.end());
         const int N = (int)needv.size();
+        // the shadow keeps only the rows that hold a needed cell, in ascending order (rows next to each other stay next to each other: the
+        // window rectangles, whose every cell is needed, remain rectangles): every offset into level 0 the plans carry is mapped over
+        const int Pg = H->vglob.P, gyg = H->vglob.gy;
+        std::vector<int> rowc(H->vglob.nyg, -1);
+        for (int t = 0; t < N; t++) rowc[needv[t] / Pg - gyg] = 0;
+        int nrow = 0;
+        for (int J = 0; J < H->vglob.nyg; J++) if (rowc[J] == 0) rowc[J] = nrow++;
+        auto remap = [&](int off) { return rowc[off / Pg - gyg] * Pg + off % Pg; };
+        for (CfEnt &e : cf) { const int nn = e.kind == 0 || e.kind == 1 || e.kind == 3 ? 3 : (e.kind == 5 ? 1 : 2); for (int m = 0; m < nn; m++) e.c[m].off = remap(e.c[m].off); }
+        for (PwlEnt &q : pwl) for (int m = 0; m < 9; m++) if (q.c[m].b >= 0) q.c[m].off = remap(q.c[m].off);
+        for (WinEnt &w : wing) w.coff = remap(w.coff);
+        for (Face &f : faces) { f.hi.off = remap(f.hi.off); f.lo.off = remap(f.lo.off); f.bq.off = remap(f.bq.off); }
+        std::vector<int> needc(N);
+        for (int t = 0; t < N; t++) needc[t] = remap(needv[t]);
+        H->shadow_rows = nrow; H->shadow_elems = (size_t)Pg * (size_t)(nrow + 1);
+        if (H->need_c.upload(needc)) { suhmo_set_error("hier: plan upload failed"); return -2; }
         std::vector<int2> rl(N);
         H->seg.assign(H->world + 1, 0);
         for (int t = 0; t < N; t++) {
@@ -824,7 +841,7 @@ __global__ void k_need_pack(const int *__restrict__ need, int first, int n, int 
     const int off = need[first + t] - shift;             // the cell in this rank's strip canvas (same pitch, same ghost rows)
     for (int f = 0; f < fl.n; f++) buf[f * stride + t] = fl.src[f][off];
 }
-__global__ void k_need_unpack(const int *__restrict__ need, const int2 *__restrict__ rl, int n, FList fl, const double *__restrict__ buf, long stride)
+__global__ void k_need_unpack(const int *__restrict__ need /* offsets in the compact shadow */, const int2 *__restrict__ rl, int n, FList fl, const double *__restrict__ buf, long stride)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -874,7 +891,7 @@ int refresh_base(suhmo_hier *H, const int *fields, int nf, hipStream_t st)
     int rc = H->ag(H->ag_user, H->xs, count, H->xr, (suhmo_stream_t)st);
     if (rc) return rc;
     H->gathers++;
-    if (H->need.n) hipLaunchKernelGGL(k_need_unpack, g1(H->need.n), dim3(256), 0, st, H->need.d, H->need_rl.d, (int)H->need.n, fl, H->xr, stride);
+    if (H->need.n) hipLaunchKernelGGL(k_need_unpack, g1(H->need.n), dim3(256), 0, st, H->need_c.d, H->need_rl.d, (int)H->need.n, fl, H->xr, stride);
     HIPCHK(hipGetLastError());
     for (int f = 0; f < nf; f++) if (fields[f] == SUHMO_F_PHI) H->phi_shadow_fresh = true;
     return 0;
@@ -1352,7 +1369,8 @@ extern "C" int suhmo_hier_destroy(suhmo_hier_t *H)
     (void)hipDeviceSynchronize();
     if (H->gap) { (void)suhmo_hier_destroy(H->gap); H->gap = nullptr; }
     for (int f = 0; f < SUHMO_F_COUNT; f++) if (H->shadow.f[f]) (void)hipFree(H->shadow.f[f]);
-    H->need.release(); H->need_rl.release(); H->cover_full.release();
+    H->need.release(); H->need_c.release(); H->need_rl.release(); H->cover_full.release();
+    if (H->cover_whole) (void)hipFree(H->cover_whole);
     if (H->xs) (void)hipFree(H->xs);
     if (H->xr) (void)hipFree(H->xr);
     for (int l = 0; l < 8; l++) {
@@ -1417,7 +1435,6 @@ extern "C" int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc
         DV &g = H->vglob;
         g.ny = g.nyg; g.j0 = 0; g.rows = g.ny + 2 * g.gy;
         g.ext[0] = g.ext[1] = g.rk[0] = g.rk[1] = 0;
-        H->shadow_elems = (size_t)g.P * (size_t)(g.rows + 1);
     }
     {   // owner computes: the levels >= 1 are dealt to the ranks when together they hold at least partition_min_cells cells per rank
         long cells = 0;
@@ -1497,7 +1514,10 @@ extern "C" int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc
     for (int l = 0; l < nlev; l++) for (suhmo_level *L : H->lev[l].box) if (!L->stub && (rc = suhmo_level_set_value(L, 0, SUHMO_F_COVER, 0.0, nullptr))) { suhmo_hier_destroy(H); return rc; }
     for (int l = 1; l < nlev; l++) if ((rc = hier_avg(H, l, SUHMO_F_COVER, SUHMO_F_COVER, 1, 1.0, nullptr))) { suhmo_hier_destroy(H); return rc; }
     if (H->shadowed && nlev > 1) {                          // COVER of the whole level 0 (geometry only): the moulin integrals run over all of it
-        if (!shadow_field(H, SUHMO_F_COVER)) { suhmo_set_error("field allocation failed"); suhmo_hier_destroy(H); return -2; }
+        const size_t welems = (size_t)H->vglob.P * (size_t)(H->vglob.rows + 1);
+        if (hipMalloc(&H->cover_whole, welems * sizeof(double)) != hipSuccess) { suhmo_set_error("field allocation failed"); suhmo_hier_destroy(H); return -2; }
+        HIPCHK(hipMemset(H->cover_whole, 0, welems * sizeof(double)));
+        FP whole{}; whole.f[SUHMO_F_COVER] = H->cover_whole;
         HLev &V = H->lev[1];
         if (H->cover_full.n) {
             int w = 0, h = 0;
@@ -1506,7 +1526,7 @@ extern "C" int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc
             for (auto &e : tmp) { w = std::max(w, e.w); h = std::max(h, e.h); }
             dim3 grd((w + 63) / 64, (h + 3) / 4, (unsigned)H->cover_full.n);
             hipLaunchKernelGGL(k_avg, grd, dim3(64, 4), 0, nullptr, H->cover_full.d, V.d_fp, V.d_dv, (int)SUHMO_F_COVER, (const FP *)nullptr, (const DV *)nullptr,
-                               H->shadow, H->vglob, 1, (int)SUHMO_F_COVER, 1, 1.0);
+                               whole, H->vglob, 1, (int)SUHMO_F_COVER, 1, 1.0);
             HIPCHK(hipGetLastError());
         }
     }
@@ -1549,7 +1569,7 @@ const double *suhmo_hier_base_cover_(suhmo_hier *H, DV *whole)
 {
     if (!dist_base(H)) return nullptr;
     *whole = H->vglob;
-    return H->shadow.f[SUHMO_F_COVER];
+    return H->cover_whole;
 }
 int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, suhmo_hier **gap)
 {
@@ -1580,7 +1600,7 @@ int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, su
         { suhmo_level *G0 = H->gap->lev[0].box[0]; G0->ex = B->ex; G0->ar = B->ar; G0->ar2 = B->ar2; G0->ard = B->ard; G0->user = B->user; G0->ex_begin = B->ex_begin; G0->ex_end = B->ex_end;
           G0->ag = B->ag; G0->ag_user = B->ag_user; G0->agg_min_cells = B->agg_min_cells; if ((rc = suhmo_agg_setup(G0))) return rc; }
         for (int l = 0; l < H->nlev; l++)
-            for (suhmo_level *L : H->gap->lev[l].box) if ((rc = suhmo_level_set_value(L, 0, SUHMO_F_ACOEF, 1.0, nullptr))) return rc;   // aCoeff_GH :1820-1828
+            for (suhmo_level *L : H->gap->lev[l].box) if (!L->stub && (rc = suhmo_level_set_value(L, 0, SUHMO_F_ACOEF, 1.0, nullptr))) return rc;   // aCoeff_GH :1820-1828
     }
     *gap = H->gap;
     return 0;

@@ -27,6 +27,7 @@ struct Fns {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
 } g;
 
 constexpr int MAXF = 8;           // fields per message
@@ -257,6 +258,7 @@ extern "C" int suhmo_rccl_load(const char *path)
     SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
     SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
     SYM(AllReduce, "ncclAllReduce"); SYM(AllGather, "ncclAllGather"); SYM(GetErrorString, "ncclGetErrorString");
+    g.CommCount = (decltype(g.CommCount))dlsym(dl, "ncclCommCount");      // (optional: reporting only)
 #undef SYM
     g.dl = dl;
     return 0;
@@ -352,6 +354,14 @@ extern "C" int suhmo_level_attach_rccl(suhmo_level_t *L, const void *id128, int 
     return 0;
 }
 
+// the number of ranks the level's communicator reports (ncclCommCount): what a run over N GPUs prints so that N can be verified; -1: not attached
+extern "C" int suhmo_level_rccl_comm_count(const suhmo_level_t *L)
+{
+    if (!L || !L->rccl || !g.CommCount) return -1;
+    int n = -1;
+    if (g.CommCount(((Strip *)L->rccl)->comm, &n) != ncclSuccess) return -1;
+    return n;
+}
 extern "C" long suhmo_level_rccl_exchanges(const suhmo_level_t *L)
 {
     return (L && L->rccl) ? ((Strip *)L->rccl)->exchanges : -1;

@@ -317,6 +317,21 @@ class HipHier:
             self.level.append([_BoxView(capi.lib().suhmo_hier_box(h, l, k), b[2] - b[0] + 1, b[3] - b[1] + 1, dx0 / 2 ** l, dy0 / 2 ** l,
                                         self.stream) for k, b in enumerate(bl)])
         self.coarse = self.level[0][0]
+        # levels dealt to the ranks (option partition_min_cells): owner[l][k] = the rank that owns box k (-1: every rank), held[l][k]: this
+        # rank keeps storage for it (its own boxes and mirrors of neighbours'); a box that is not held is a stub without fields
+        self.owner, self.held = [[-1]], [[True]]
+        for l, bl in enumerate(self.boxes, start=1):
+            ow, he = [], []
+            for k in range(len(bl)):
+                hf = C.c_int()
+                ow.append(int(capi.lib().suhmo_hier_box_owner(h, l, k, C.byref(hf))))
+                he.append(bool(hf.value))
+            self.owner.append(ow); self.held.append(he)
+        self.rank = (j0 // ny0) if ny_global is not None and ny_global != ny0 else 0
+
+    def owns(self, l, k):
+        """this rank computes box k of level l (every box of a replicated level; on a level dealt to the ranks: its own boxes)"""
+        return self.owner[l][k] in (-1, self.rank)
 
     def set_inputs(self, fs):
         """fs as suhmo_amd.synthetic.amrm_fields returns it"""
@@ -324,7 +339,8 @@ class HipHier:
         self.coarse.build_mg_coefficients()
         for l in range(1, self.nlev):
             for k, f in enumerate(fs[l]):
-                self.level[l][k].set_inputs(f)
+                if self.held[l][k]:
+                    self.level[l][k].set_inputs(f)
 
     def level_array(self, l, field):
         nx, ny = self.coarse.nx << l, self.ny_global << l

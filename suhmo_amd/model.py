@@ -163,7 +163,10 @@ class HipHierModel:
         self.cur_step = 0
 
     def set_state(self, l, k, f):
-        """f: dict with ghosted arrays head, B, Pi, zb, mask of box k of level l (fine-fine / coarse-fine ghost cells: anything)"""
+        """f: dict with ghosted arrays head, B, Pi, zb, mask of box k of level l (fine-fine / coarse-fine ghost cells: anything).  On a level dealt
+        to the ranks a box this rank does not hold is skipped (its owner loads it); loading a mirror is harmless"""
+        if not self.hier.held[l][k]:
+            return
         L = self.level[l][k]
         L.set(lv.F_PHI, f["head"][1:-1, 1:-1])
         L.set(lv.F_ACOEF, np.zeros((L.ny, L.nx)))
@@ -191,6 +194,9 @@ class HipHierModel:
         return integ
 
     def get(self, l, k, name, ghosted=False):
+        """a field of box k of level l; None where another rank owns the box (levels dealt to the ranks: hier.owns(l, k))"""
+        if not self.hier.owns(l, k):
+            return None
         return self.level[l][k].get(self.FIELDS[name], ghosted=ghosted)
 
     def postproc_table_device(self):

@@ -47,7 +47,9 @@ def run_strips(world, nx0, ny0, boxes, sts, m, nsteps, mou, mb, halo_rows=4, opt
             counts = [G.timestep(m["dt"]) for _ in range(nsteps)]
             res = [[{nm: G.get(l, k, nm) for nm in NAMES} for k in range(len(G.level[l]))] for l in range(len(sts))]
             part = [(G.hier.get_option("partitioned_level_%d" % l), G.hier.get_option("own_boxes_level_%d" % l)) for l in range(1, len(sts))]
-            out[rank] = (counts, res, integ, msrc, ag.calls, G.hier.gathers() + G.hier.get_option("partition_gathers"), part, G.hier.get_option("partition_gathers"))
+            stats = [{k: G.hier.get_option("%s_level_%d" % (k, l)) for k in ("ghost_exchange_bytes", "ghost_exchange_bound_bytes", "held_boxes", "owned_cells", "canvas_bytes")}
+                     for l in range(1, len(sts))]
+            out[rank] = (counts, res, integ, msrc, ag.calls, G.hier.gathers() + G.hier.get_option("partition_gathers"), part, G.hier.get_option("partition_gathers"), stats)
             G.close()
         except Exception as e:  # pragma: no cover
             import traceback
@@ -60,6 +62,18 @@ def run_strips(world, nx0, ny0, boxes, sts, m, nsteps, mou, mb, halo_rows=4, opt
     [t.join() for t in th]
     assert not err, err
     return out
+
+
+def check_partition_stats(out, sts, world):
+    """owner computes: a colour-pass ghost exchange moves at most the side cells of the rank's boxes (4 sides x 8 B, in fact one colour of the
+    sides that face another rank's box); every cell of a level has one owner; a rank keeps canvases for its boxes and the neighbours' it reads"""
+    for l in range(1, len(sts)):
+        cells = sum(st["head"][1:-1, 1:-1].size for st in sts[l])
+        assert sum(out[r][8][l - 1]["owned_cells"] for r in range(world)) == cells
+        for r in range(world):
+            q = out[r][8][l - 1]
+            assert q["ghost_exchange_bytes"] <= q["ghost_exchange_bound_bytes"] // 2 + 8, (l, r, q)     # one colour of the sides
+            assert q["held_boxes"] <= len(sts[l]) and (q["owned_cells"] == 0) == (out[r][6][l - 1][1] == 0)
 
 
 CASES = [("union-2-ranks", 2, UNION, dict(), 2), ("union-4-ranks", 4, UNION, dict(), 2),
@@ -107,12 +121,16 @@ def test_hier_timestep_on_strips_bitwise(case, agg, part, monkeypatch):
         assert np.array_equal(got, mref[0][0]), (name, "msrc level 0")
     for l in range(1, len(sts)):
         for k in range(len(sts[l])):
-            for r in range(world):
+            holders = [r for r in range(world) if out[r][1][l][k]["head"] is not None]
+            assert len(holders) == (1 if part else world), (name, l, k, holders)          # dealt to the ranks: exactly the owner answers for a box
+            for r in holders:
                 for nm in NAMES:
                     a, b = out[r][1][l][k][nm], ref[l][k][nm]
                     assert np.array_equal(a, b, equal_nan=True), (name, r, l, k, nm, float(np.nanmax(np.abs(a - b))))
                 if mou:
                     assert np.array_equal(out[r][3][l][k], mref[l][k]), (name, r, l, k, "msrc")
+    if part:
+        check_partition_stats(out, sts, world)
 
 
 @pytest.mark.timeout(600)
@@ -148,9 +166,11 @@ def test_random_box_layouts_partitioned_bitwise(seed, world):
         assert np.array_equal(got, ref[0][0][nm], equal_nan=True), (seed, 0, nm)
     for l in range(1, len(sts)):
         for k in range(len(sts[l])):
-            for r in range(world):
-                for nm in NAMES:
-                    assert np.array_equal(out[r][1][l][k][nm], ref[l][k][nm], equal_nan=True), (seed, r, l, k, nm)
+            holders = [r for r in range(world) if out[r][1][l][k]["head"] is not None]
+            assert len(holders) == 1, (seed, l, k, holders)
+            for nm in NAMES:
+                assert np.array_equal(out[holders[0]][1][l][k][nm], ref[l][k][nm], equal_nan=True), (seed, holders[0], l, k, nm)
+    check_partition_stats(out, sts, world)
 
 
 @pytest.mark.timeout(300)

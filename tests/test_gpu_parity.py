@@ -449,6 +449,30 @@ def test_bench_size_vcycle_bitwise(oracle, hip):
     O.close(); G.close()
 
 
+@pytest.mark.parametrize("max_box", [64, 1024], ids=["max-box-64", "max-box-is-the-level"])
+def test_converged_solve_bitwise(oracle, hip, max_box):
+    """bench.py's `converged_solve` at 1024^2: suhmo_level_solve from SHMIP-A's initial head to the reference's tolerances of a step >= 50
+    (src/AmrHydro.cpp:737-762) with the headline's 64^2 boxes (6 depths, the cycle bottoms out at 32^2 cells) and with max_box_size = the
+    level (exec/A_SHMIP/A3/input.hydro:71-72 is an ordinary input: 10 depths down to 2^2 cells) -- cycle count, residual history and head
+    against the oracle, bit for bit"""
+    n = 1024
+    f = sy.shmip_fields(n, n, ly=1.0e5)
+    f.pop("bx", None); f.pop("by", None)
+    O = oracle.OracleLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=max_box, nthreads=min(16, os.cpu_count() or 1))
+    G = hip.HipLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, max_box=max_box)
+    O.set_inputs(f); G.set_inputs(f)
+    O.build_mg_coefficients(); G.build_mg_coefficients()
+    assert G.ndepth == O.ndepth == (6 if max_box == 64 else 10)
+    sp = dict(sy.SOLVER_DEFAULT)
+    no, ho = O.solve(sp)
+    ng, hg = G.solve(sp)
+    assert no == ng and np.array_equal(ho, hg), (no, ng, ho[-3:], hg[-3:])
+    assert np.array_equal(G.get(hip.F_PHI), O.get(oracle.F_PHI))
+    if max_box == n:
+        assert hg[-1] <= sp["norm_thresh"] and ng < 40, (ng, hg[-1])     # the deep cycle converges; with 64^2 boxes it contracts slowly (DESIGN section 3)
+    O.close(); G.close()
+
+
 @pytest.mark.parametrize("case", FUSED_VCYCLE_CASES[:4], ids=[c[0] for c in FUSED_VCYCLE_CASES[:4]])
 def test_residual_left_behind_by_the_last_launch_equals_the_residual_pass(oracle, hip, case, monkeypatch):
     """suhmo_level_solve with the residual riding on the cycle's last launch (level option resid_in_relax, default 1) and with the

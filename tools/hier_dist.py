@@ -2,7 +2,7 @@
 """cfg5 shape on several GPUs: the time step (moulins, diffusion, implicit gap-height solve) on a hierarchy whose levels are unions of
 boxes, level 0 cut into rank strips, one process per GPU:
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/hier_dist.py --base 256 --steps 5
-Every rank holds its rows of level 0 and all boxes of the finer levels (suhmo_amd.multigpu.attach_hier: halo rows and the all-gather
+Every rank holds its rows of level 0 and all boxes of the finer levels (or, from --partition-min-cells on, the boxes it owns and mirrors of their neighbours) (suhmo_amd.multigpu.attach_hier: halo rows and the all-gather
 of the coarse cells level 1 reads, native RCCL on the "nccl" backend; SUHMO_DIST_BACKEND=gloo rehearses several ranks on one GPU).
 --check: rank 0 also runs the whole hierarchy alone and compares bit for bit."""
 import argparse, os, sys, time
@@ -75,6 +75,19 @@ def main():
     parted = [H.hier.get_option("partitioned_level_%d" % l) for l in range(1, len(sts))]
     owned_all = [None] * world
     dist.all_gather_object(owned_all, owned)
+    # owner computes: what a rank sends per colour-pass ghost exchange against 4 sides x 8 B of its boxes, the canvases it keeps against the level's
+    stats = [{k: H.hier.get_option("%s_level_%d" % (k, l)) for k in ("ghost_exchange_bytes", "ghost_exchange_bound_bytes", "held_boxes", "owned_cells", "canvas_bytes")}
+             for l in range(1, len(sts))]
+    stats_all = [None] * world
+    dist.all_gather_object(stats_all, stats)
+    if rank == 0 and any(parted):
+        for l in range(1, len(sts)):
+            tot = sum(q[l - 1]["canvas_bytes"] for q in stats_all)
+            print("  level %d dealt to the ranks: per rank, bytes sent per colour-pass ghost exchange %s (bound 4 x side x 8 B of the owned boxes: %s); boxes held %s of %d; "
+                  "canvas bytes %s (shares %s of what all ranks hold)"
+                  % (l, [q[l - 1]["ghost_exchange_bytes"] for q in stats_all], [q[l - 1]["ghost_exchange_bound_bytes"] for q in stats_all],
+                     [q[l - 1]["held_boxes"] for q in stats_all], len(sts[l]), [q[l - 1]["canvas_bytes"] for q in stats_all],
+                     ["%.2f" % (q[l - 1]["canvas_bytes"] / max(tot, 1)) for q in stats_all]), flush=True)
     if a.check:
         mine = [[{nm: H.get(l, k, nm) for nm in NAMES} for k in range(len(H.level[l]))] for l in range(len(sts))]
         allv = [None] * world
@@ -90,7 +103,10 @@ def main():
                 ok = ok and eq
                 print("  level 0 %-4s %s" % (nm, "bitwise equal" if eq else "DIFFERS"), flush=True)
             for l in range(1, len(sts)):
-                eq = all(np.array_equal(allv[r][l][k][nm], A.get(l, k, nm), equal_nan=True) for r in range(world) for k in range(len(sts[l])) for nm in NAMES)
+                # a level dealt to the ranks: the owner of a box answers for it (the other ranks hold no storage for it, or a mirror)
+                eq = all(any(allv[r][l][k][nm] is not None for r in range(world)) and
+                         all(np.array_equal(allv[r][l][k][nm], A.get(l, k, nm), equal_nan=True) for r in range(world) if allv[r][l][k][nm] is not None)
+                         for k in range(len(sts[l])) for nm in NAMES)
                 ok = ok and eq
                 print("  level %d (%d boxes, %s) %s" % (l, len(sts[l]), "boxes relaxed per rank %s" % [o[l - 1] for o in owned_all] if parted[l - 1] else "relaxed on every rank",
                                                       "bitwise equal" if eq else "DIFFERS"), flush=True)
