@@ -263,9 +263,11 @@ def main():
 
 
 def transport_name(G):
+    if getattr(G, "_transport", None):
+        return G._transport
     ex = getattr(G, "_exchanger", None)
     if ex == "rccl":
-        return os.environ.get("SUHMO_TRANSPORT", "rccl") if os.environ.get("SUHMO_TRANSPORT") in ("ipc",) else "rccl (ncclSend / ncclRecv on the kernels' stream)"
+        return "rccl (ncclSend / ncclRecv on the kernels' stream)"
     return "torch.distributed P2P (%s)" % type(getattr(ex, "tr", ex)).__name__
 
 

@@ -324,6 +324,19 @@ int suhmo_level_attach_rccl(suhmo_level_t *L, const void *id128, int rank, int w
 int suhmo_level_detach_rccl(suhmo_level_t *L);
 long suhmo_level_rccl_exchanges(const suhmo_level_t *L);
 int suhmo_level_rccl_comm_count(const suhmo_level_t *L);   /* ranks the level's communicator reports (ncclCommCount); -1: not attached */
+/* ---- peer-direct halo transport (suhmo_amd/csrc/suhmo_ipc.hip; SUHMO_TRANSPORT=ipc in suhmo_amd.multigpu): a rank's pack kernel stores its
+ * edge rows straight into the neighbour's receive slots -- device memory of the neighbouring GPU mapped with hipIpcOpenMemHandle, peer
+ * stores over xGMI -- and publishes a sequence number there; the neighbour's unpack kernel polls it locally and acknowledges.  What the
+ * reference does with MPI point-to-point inside LevelData::exchange (src/VCAMRNonLinearPoissonOp.cpp:692, 912-913) without a
+ * communication kernel in between.  Two steps, both per rank: suhmo_level_ipc_export lays out and allocates the rank's arena and fills
+ * `blob128` (128 bytes: the IPC handle, the process id, the address); the host carries the blobs to the neighbours (MPI_Sendrecv /
+ * torch.distributed all_gather); suhmo_level_attach_ipc maps the arenas of rank - 1 and rank + 1 (periodic_y: the ends are neighbours;
+ * NULL where there is none; ranks that are threads of one process, or a rank that is its own neighbour, need no mapping) and routes the
+ * level's halo exchanges through them.  Reductions and all-gathers keep the transport the level is attached to (suhmo_level_attach_rccl,
+ * suhmo_level_set_hooks): attach that first.  Every wait on a neighbour is bounded (about 3 s): the next exchange then fails with rc -7. */
+int suhmo_level_ipc_export(suhmo_level_t *L, void *blob128);
+int suhmo_level_attach_ipc(suhmo_level_t *L, int rank, int world, int periodic_y, const void *blob_lo, const void *blob_hi);
+long suhmo_level_ipc_exchanges(const suhmo_level_t *L);   /* halo messages sent so far; -1: not attached */
 
 /* ---- two AMR levels: base level `coarse` (spans the domain) + one patch `fine` refined by 2, created with
  * desc.i0 / nx_global / j0 / ny_global = its place in the refined domain (coarse-aligned), dx = coarse dx / 2.
@@ -407,7 +420,7 @@ int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *base, int nl
  * cycle except in the cells the average from level 1 changed, and level 0's gradient is evaluated only where level 1's coarse-fine
  * interpolation reads it -- the same bits, two passes over level 0 less per cycle).  push_ghosts and incremental_residual can also
  * be changed later (suhmo_hier_set_option).
- * partition_min_cells = n (rank strips): when the levels >= 1 together hold at least n cells PER RANK they are dealt to the ranks, the boxes
+ * partition_min_cells = n (rank strips; default 350000): when the largest level >= 1 holds at least n cells PER RANK the levels >= 1 are dealt to the ranks, the boxes
  * of a level in the order given cut into runs of about equal cell counts (the reference: LoadBalance(procIDs, grids),
  * src/AmrHydro.cpp:4283, 4929).  OWNER COMPUTES: every pass over such a level runs on the owner's boxes only and only they (plus mirrors
  * of the neighbours' boxes a plan of this rank reads) have storage here -- every other box is a stub (suhmo_hier_box_owner);

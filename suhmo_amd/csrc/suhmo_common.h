@@ -162,6 +162,7 @@ struct suhmo_level {
     std::vector<VGraph> vgraphs; int vgraph_seen[4]; hipStream_t gstream;
     suhmo_level *gap; double gap_dt;   // implicit gap-height operator of the time step (suhmo_step.hip), owned
     void *rccl;                 // native transport state (suhmo_rccl.hip), owned by the level
+    void *ipc; int ipc_owner;   // peer-direct halo transport (suhmo_ipc.hip): arena and neighbours' mappings; a gap-height handle borrows its level's
     // agglomeration of the coarse depths of a rank strip (suhmo_agg.hip): from depth agg_depth on (0 = none) the cycle runs on `agg`, a
     // handle of the WHOLE level at that depth held by every rank; all-gather transport ag (suhmo_level_set_allgather / attach_rccl)
     long agg_min_cells;         // depths whose strip holds fewer cells are agglomerated (env SUHMO_AGG_MIN_CELLS, default 100000: at 4096^2 cells per strip the two deepest of six depths; 0 = off)
@@ -265,6 +266,7 @@ __device__ __forceinline__ void suhmo_publish(const HostSlot &h, double v)
 }
 int suhmo_build_mg_coefficients(suhmo_level *L, bool with_faces, hipStream_t st);   // suhmo_level.hip
 // suhmo_agg.hip: agglomeration of the coarse multigrid depths of a rank strip
+void suhmo_ipc_release(suhmo_level *L);   // suhmo_ipc.hip
 int suhmo_agg_setup(suhmo_level *L);
 void suhmo_agg_release(suhmo_level *L);
 int suhmo_agg_gather_static(suhmo_level *L, bool with_faces, hipStream_t st);

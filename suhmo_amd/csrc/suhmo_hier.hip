@@ -190,8 +190,8 @@ struct suhmo_hier {
     // evaluation then needs no pass over level 0 at all
     unsigned long base_fused_ver = 0;
     bool incremental = true;                               // option incremental_residual
-    long part_min_cells = 500000;                          // creation option partition_min_cells: levels >= 1 that hold at least this many cells
-                                                           // PER RANK (all of them together) are dealt to the ranks (below it a pass is shorter than the message)
+    long part_min_cells = 350000;                          // creation option partition_min_cells: when the largest level >= 1 holds at least this many cells
+                                                           // PER RANK, the levels >= 1 are dealt to the ranks (below it a pass is shorter than the messages it needs)
     bool part = false;                                     // ... they are
     long part_gathers = 0, part_bytes = 0;                 // collectives of the partition; bytes THIS rank contributed to them
     long side_bytes[8] = {};                               // bytes this rank contributes to ONE colour-pass ghost exchange of level l (the larger colour)
@@ -1436,11 +1436,17 @@ extern "C" int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc
         g.ny = g.nyg; g.j0 = 0; g.rows = g.ny + 2 * g.gy;
         g.ext[0] = g.ext[1] = g.rk[0] = g.rk[1] = 0;
     }
-    {   // owner computes: the levels >= 1 are dealt to the ranks when together they hold at least partition_min_cells cells per rank
-        long cells = 0;
+    {   // owner computes: the levels >= 1 are dealt to the ranks -- all of them or none -- when the largest holds at least partition_min_cells
+        // cells per rank (per AMR cycle a level's ~26 passes shrink by (1 - 1/W) x 14 us per million cells each and ~28
+        // collectives of ~30 us + 8 B x W x the packed cells / the link rate are added: even at ~2.6 M cells per level on 8 ranks)
+        long most = 0;
         const int *qq = boxes;
-        for (int l = 1; l < nlev; l++) for (int k = 0; k < nbox[l]; k++, qq += 4) cells += (long)(qq[2] - qq[0] + 1) * (qq[3] - qq[1] + 1);
-        H->part = H->world > 1 && nlev > 1 && cells >= H->part_min_cells * H->world;
+        for (int l = 1; l < nlev; l++) {
+            long cells = 0;
+            for (int k = 0; k < nbox[l]; k++, qq += 4) cells += (long)(qq[2] - qq[0] + 1) * (qq[3] - qq[1] + 1);
+            most = std::max(most, cells);
+        }
+        H->part = H->world > 1 && nlev > 1 && most >= H->part_min_cells * H->world;
     }
     const int *q = boxes;
     for (int l = 1; l < nlev; l++) {
@@ -1597,7 +1603,7 @@ int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, su
         int rc = suhmo_hier_create_opts(&H->gap, &d, H->nlev, nbox.data(), flat.data(), H->options.c_str()); if (rc) return rc;
         H->gap_dt = dt;
         H->gap->ag = H->ag; H->gap->ag_user = H->ag_user;                                  // same strips, same ranks
-        { suhmo_level *G0 = H->gap->lev[0].box[0]; G0->ex = B->ex; G0->ar = B->ar; G0->ar2 = B->ar2; G0->ard = B->ard; G0->user = B->user; G0->ex_begin = B->ex_begin; G0->ex_end = B->ex_end;
+        { suhmo_level *G0 = H->gap->lev[0].box[0]; G0->ex = B->ex; G0->ar = B->ar; G0->ar2 = B->ar2; G0->ard = B->ard; G0->user = B->user; G0->ex_begin = B->ex_begin; G0->ex_end = B->ex_end; G0->ipc = B->ipc;
           G0->ag = B->ag; G0->ag_user = B->ag_user; G0->agg_min_cells = B->agg_min_cells; if ((rc = suhmo_agg_setup(G0))) return rc; }
         for (int l = 0; l < H->nlev; l++)
             for (suhmo_level *L : H->gap->lev[l].box) if (!L->stub && (rc = suhmo_level_set_value(L, 0, SUHMO_F_ACOEF, 1.0, nullptr))) return rc;   // aCoeff_GH :1820-1828

@@ -13,7 +13,9 @@
 // All polling is local; everything remote is a store.  Message n of a depth uses slot n & 1 and may be packed once the neighbour has
 // acknowledged message n - 2.  Every wait is bounded (about 3 s): a neighbour that never answers raises an error word the next
 // exchange reports, instead of hanging the queue.  Kernels that wait are at most 128 workgroups, so the neighbour's kernels find room
-// even when two ranks share one GPU (the test harness).
+// even when two ranks share one GPU (the test harness).  One process per GPU is the deployment; ranks that are THREADS of one process work as
+// long as every rank's stream has a hardware queue of its own (HIP multiplexes streams onto a few: with more than two thread ranks a waiting
+// kernel can sit in front of the kernel it waits for -- the test suite keeps thread ranks at two and runs more ranks as processes).
 #include "suhmo_common.h"
 #include <unistd.h>
 
@@ -35,6 +37,8 @@ struct IpcStrip {
 __device__ __forceinline__ void wait_ge(const unsigned long long *p, unsigned long long v, unsigned long long *err)
 {
     const long long t0 = wall_clock64();
+    if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= v) return;
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;       // a wait has run out before: what is queued behind it drains at once
     while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < v) {
         __builtin_amdgcn_s_sleep(4);
         if (wall_clock64() - t0 > 300000000LL) { __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }   // ~3 s at 100 MHz

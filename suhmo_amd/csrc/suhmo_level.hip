@@ -153,7 +153,7 @@ int suhmo_level_create_(suhmo_level_t **out, const suhmo_level_desc_t *desc, boo
     HIPCHK(hipSetDevice(desc->device));
     suhmo_level *L = new suhmo_level();
     L->desc = *desc; L->ph = desc->phys; L->device = desc->device;
-    L->ex = nullptr; L->ar = nullptr; L->ar2 = nullptr; L->ard = nullptr; L->user = nullptr; L->ex_begin = nullptr; L->ex_end = nullptr; L->rccl = nullptr; L->gap = nullptr; L->gap_dt = 0.0; L->prof_on = 0; L->gsrb_variant = -1; L->fused_hc = 0;
+    L->ex = nullptr; L->ar = nullptr; L->ar2 = nullptr; L->ard = nullptr; L->user = nullptr; L->ex_begin = nullptr; L->ex_end = nullptr; L->rccl = nullptr; L->ipc = nullptr; L->ipc_owner = 0; L->gap = nullptr; L->gap_dt = 0.0; L->prof_on = 0; L->gsrb_variant = -1; L->fused_hc = 0;
     if (const char *e = getenv("SUHMO_GSRB_VARIANT")) L->gsrb_variant = atoi(e);
     if (const char *e = getenv("SUHMO_FUSED_HC")) L->fused_hc = atoi(e);
     L->bcoef_fused = 1;
@@ -274,6 +274,7 @@ extern "C" int suhmo_level_destroy(suhmo_level_t *L)
     (void)hipDeviceSynchronize();
     if (L->rccl) (void)suhmo_level_detach_rccl(L);
     if (L->gap) { (void)suhmo_level_destroy(L->gap); L->gap = nullptr; }
+    suhmo_ipc_release(L);
     suhmo_agg_release(L);
     suhmo_level_drop_graphs(L);
     for (int dep = 0; dep < L->ndepth; dep++)

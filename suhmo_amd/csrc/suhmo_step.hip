@@ -360,7 +360,7 @@ static int gap_level_prepare(suhmo_level *L, const suhmo_model_params_t *mp, dou
         if ((rc = suhmo_level_set_value(L->gap, 0, SUHMO_F_ACOEF, 1.0, (suhmo_stream_t)st))) return rc;       // aCoeff_GH :1820-1828
     }
     suhmo_level *G = L->gap;
-    G->ex = L->ex; G->ar = L->ar; G->ar2 = L->ar2; G->ard = L->ard; G->user = L->user; G->ex_begin = L->ex_begin; G->ex_end = L->ex_end;
+    G->ex = L->ex; G->ar = L->ar; G->ar2 = L->ar2; G->ard = L->ard; G->user = L->user; G->ex_begin = L->ex_begin; G->ex_end = L->ex_end; G->ipc = L->ipc;
     if (G->ag != L->ag || G->ag_user != L->ag_user || G->agg_min_cells != L->agg_min_cells) {                // ... and the same agglomeration
         G->ag = L->ag; G->ag_user = L->ag_user; G->agg_min_cells = L->agg_min_cells;
         int rca = suhmo_agg_setup(G); if (rca) return rca;

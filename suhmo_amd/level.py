@@ -184,8 +184,9 @@ class HipLevel:
     def rccl_exchanges(self):
         """halo message groups this strip has sent so far (native transport), or the calls of the Python exchanger"""
         n = capi.lib().suhmo_level_rccl_exchanges(self.h)
-        if n >= 0:
-            return n
+        m = capi.lib().suhmo_level_ipc_exchanges(self.h)           # peer-direct halo messages (suhmo_ipc.hip); RCCL then carries the all-gathers only
+        if n >= 0 or m >= 0:
+            return max(n, 0) + max(m, 0)
         ex = getattr(self, "_exchanger", None)
         return getattr(ex, "calls", 0)
 

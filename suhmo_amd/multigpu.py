@@ -309,6 +309,40 @@ def attach_rccl(level, rank, world, periodic_y=False, dist=None, unique_id=None)
     return level
 
 
+def ipc_export(level):
+    """step 1 of the peer-direct transport: this rank's arena; returns the 128-byte blob its neighbours need"""
+    blob = (C.c_char * 128)()
+    check(capi.lib().suhmo_level_ipc_export(level.h, C.cast(blob, C.c_void_p)))
+    return bytes(blob)
+
+
+def ipc_attach(level, rank, world, periodic_y, blobs):
+    """step 2: blobs[r] = the blob of rank r (all ranks, or at least this rank's neighbours); halo exchanges from here on are peer-direct
+    stores + flag words (suhmo_amd/csrc/suhmo_ipc.hip); reductions and all-gathers keep the hooks the level already has"""
+    lo = rank - 1 if rank > 0 else (world - 1 if periodic_y else None)
+    hi = rank + 1 if rank < world - 1 else (0 if periodic_y else None)
+    keep = [(C.c_char * 128).from_buffer_copy(blobs[q]) if q is not None else None for q in (lo, hi)]
+    check(capi.lib().suhmo_level_attach_ipc(level.h, rank, world, int(periodic_y),
+                                            C.cast(keep[0], C.c_void_p) if keep[0] is not None else None,
+                                            C.cast(keep[1], C.c_void_p) if keep[1] is not None else None))
+    level._transport = "ipc (peer-direct stores into the neighbour's halo slots, hipIpcOpenMemHandle; reductions: %s)" % (
+        "rccl" if getattr(level, "_exchanger", None) == "rccl" else "host hooks")
+
+
+def attach_ipc(level, dist, rank, world, periodic_y=False):
+    """COLLECTIVE: every rank exports its arena, the blobs travel by torch.distributed all_gather, every rank maps its neighbours'"""
+    import torch
+    mine = ipc_export(level)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor(list(mine), dtype=torch.uint8, device=dev)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    blobs = [bytes(o.cpu().tolist()) for o in out]
+    ipc_attach(level, rank, world, periodic_y, blobs)
+    dist.barrier()                        # every arena is mapped before anybody stores into one
+    return level
+
+
 def attach(level, dist, rank, world, periodic_y=False):
     """bench.py / production entry: couple this rank's strip to its neighbours.  Backend "nccl":
     the native RCCL transport (SUHMO_TRANSPORT=torch forces the torch.distributed P2P one);
@@ -326,7 +360,10 @@ def attach(level, dist, rank, world, periodic_y=False):
         flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
-            return attach_rccl(level, rank, world, periodic_y, dist)
+            attach_rccl(level, rank, world, periodic_y, dist)
+            if os.environ.get("SUHMO_TRANSPORT") == "ipc":         # halo rows peer-direct; RCCL stays for reductions and all-gathers
+                attach_ipc(level, dist, rank, world, periodic_y)
+            return level
         import sys
         print("suhmo_amd.multigpu: native RCCL transport unavailable (%s); falling back to torch.distributed P2P"
               % (err if err is not None else "another rank failed"), file=sys.stderr, flush=True)
@@ -334,6 +371,8 @@ def attach(level, dist, rank, world, periodic_y=False):
     ex = StripExchanger(level, tr, rank, world, periodic_y)
     level._exchanger = ex
     ex.exchange_static()
+    if os.environ.get("SUHMO_TRANSPORT") == "ipc":                 # (gloo rehearsal: the halo rows peer-direct, reductions through the host hooks)
+        attach_ipc(level, dist, rank, world, periodic_y)
     return ex
 
 

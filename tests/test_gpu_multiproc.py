@@ -57,7 +57,9 @@ def test_two_ranks_over_nccl_bitwise(tool, args):
     assert "BITWISE EQUAL" in logs[0]
 
 
-@pytest.mark.parametrize("tool,args,world,agg", [("amr_shmip_dist.py", ["--case", "B5", "--steps", "6", "--check"], 2, 0),
+@pytest.mark.parametrize("tool,args,world,agg", [("shmip_dist.py", ["--case", "A3", "--scale", "2", "--steps", "6", "--check", "--ipc"], 2, 0),
+                                                 ("shmip_dist.py", ["--case", "B3", "--scale", "1", "--steps", "4", "--check", "--ipc"], 3, 3000),
+                                                 ("amr_shmip_dist.py", ["--case", "B5", "--steps", "6", "--check"], 2, 0),
                                                  ("shmip_dist.py", ["--case", "B3", "--scale", "1", "--steps", "6", "--check"], 4, 0),
                                                  ("hier_dist.py", ["--base", "256", "--steps", "2", "--check"], 2, 0),
                                                  ("shmip_dist.py", ["--case", "B3", "--scale", "1", "--steps", "6", "--check"], 4, 3000),
@@ -82,7 +84,9 @@ def test_rank_strips_as_processes(tool, args, world, agg):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    SUHMO_DIST_BACKEND="gloo", OMP_NUM_THREADS="1", SUHMO_AGG_MIN_CELLS=str(agg),    # agg > 0: coarse depths agglomerated (all-gather over gloo)
                    SUHMO_DUMP_AFTER="240", GLOO_SOCKET_IFNAME="lo")                                                            # a rank that hangs says where before it is killed
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", tool)] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        if "--ipc" in args:            # the halo rows peer-direct between the PROCESSES (hipIpcGetMemHandle / hipIpcOpenMemHandle of each other's arenas on
+            env["SUHMO_TRANSPORT"] = "ipc"     # the one GPU of the test box), reductions and all-gathers over gloo
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", tool)] + [a for a in args if a != "--ipc"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     import time
     deadline = time.time() + 300

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--partition-min-cells", type=int, default=0,
                     help="> 0: hierarchy option partition_min_cells (levels of boxes with at least that many cells per rank are relaxed by their owners; "
-                         "default: the library's 500000, i.e. cfg5's small levels stay replicated)")
+                         "default: the library's 350000 for the largest level, i.e. cfg5's small levels stay replicated)")
     a = ap.parse_args()
     for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29536")):
         os.environ.setdefault(k, v)

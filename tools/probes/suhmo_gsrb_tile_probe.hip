@@ -1,3 +1,6 @@
+// PROBE COPY of suhmo_amd/csrc/suhmo_gsrb.hip as of round 4 (tools/probes/tile_probe.sh builds it into a library of its own under /tmp):
+// with -DSUHMO_TILE_PROBE the environment variable SUHMO_TILE_DBG switches parts of k_gsrb_tile off.  RESULTS OF SUCH RUNS ARE WRONG ON
+// PURPOSE; the product kernel carries none of these branches.
 // suhmo_gsrb.hip -- nonlinear variable-coefficient Gauss-Seidel red-black relaxation.
 //
 // Replaces VCAMRNonLinearPoissonOp::levelGSRB (src/VCAMRNonLinearPoissonOp.cpp:654-760):
@@ -550,9 +553,13 @@ struct TileGeom {
     int jbeg, jend;                          // rows written: the level's, plus on a rank strip the halo rows that stay current for the next launch
     int chunks;                              // level = one tile: this many times S sweeps in the launch (halo images refreshed in LDS)
     int order;                               // workgroup -> tile: 0 as launched, 1 / 2 XCD-aware (see k_gsrb_tile)
+    int dbg;                                 // timing probes (builds with -DSUHMO_TILE_PROBE only, env SUHMO_TILE_DBG; tools/probes/tile_probe.sh): results are wrong on purpose
 };
-// (the timing probes that switch parts of the tile kernel off -- wrong results on purpose -- live in a copy of this file:
-//  tools/probes/suhmo_gsrb_tile_probe.hip, built by tools/probes/tile_probe.sh; nothing of them is in the product kernel)
+#ifdef SUHMO_TILE_PROBE
+#define TILE_DBG(bit) (g.dbg & (bit))
+#else
+#define TILE_DBG(bit) false
+#endif
 // (of the ice mask COMPUTENONLINEARTERMS uses the sign only: mneg bit 0 / 1 = the first / second cell of the pair is without ice)
 struct PairCoef { double rhs0, rhs1, B0, B1, Pi0, Pi1, zb0, zb1, a0, a1, byS0, byS1, byN0, byN1, bx0, bx1, bx2; int mneg; };
 
@@ -627,7 +634,7 @@ __global__ __launch_bounds__((TileThreads<S, T, RST>::NT)) __attribute__((amdgpu
     bool special = false;                                     // a pair of this thread has a cell without ice or in a cut-off range of the gap height
     // most tiles of a large level: the whole region lies in the level's own cells (uniform) -- the index logic of the general case
     // (validity of every pair, periodic images, stored ghosts, halo rows) is 250 instructions per pair, 19 % of the launch at 2048^2
-    const bool inner = gx0 >= 0 && gx0 + LX <= v.nx && gy0 >= 0 && gy0 + LY <= v.ny;
+    const bool inner = gx0 >= 0 && gx0 + LX <= v.nx && gy0 >= 0 && gy0 + LY <= v.ny && !TILE_DBG(1);
     // the coefficients of a pair in the domain (and the FAS correction added to its phi, PROLONGNL)
     auto ldcoef = [&](PairCoef &c, double2 &p2, const int idx, const int i, const int j) {
         if (g.pc) {
@@ -667,6 +674,8 @@ __global__ __launch_bounds__((TileThreads<S, T, RST>::NT)) __attribute__((amdgpu
             const bool exi = inx || (i == -2 && v.cfx[0]) || (i == v.nx && v.cfx[1]);
             const bool exj = iny || (j == -1 && v.ext[0] && !v.rk[0]) || (j == v.ny && v.ext[1] && !v.rk[1]);
             double2 p2 = make_double2(0.0, 0.0);
+            if (exi && exj && TILE_DBG(1)) { live = inx && iny; p2 = make_double2(900.0 + 1.0e-3 * lx, 900.0 + 1.0e-3 * ly); }
+            else
             if (exi && exj) {
                 live = inx && iny;
                 if (perx) i = wrap(i, v.nx);
@@ -674,6 +683,10 @@ __global__ __launch_bounds__((TileThreads<S, T, RST>::NT)) __attribute__((amdgpu
                 const int idx = cidx(v, i, j);
                 p2 = ld2(pin, idx);
             }
+            if (live && TILE_DBG(1)) {                        // probe: no global loads of the coefficients
+                c.rhs0 = c.rhs1 = 1.0e-9; c.B0 = c.B1 = 0.01; c.Pi0 = c.Pi1 = 9.0e6; c.zb0 = c.zb1 = 0.0; c.mneg = 0; c.a0 = c.a1 = 0.0;
+                c.byS0 = c.byS1 = c.byN0 = c.byN1 = c.bx0 = c.bx1 = c.bx2 = -1.0e-3;
+            } else
             if (live) ldcoef(c, p2, cidx(v, i, j), i, j);
             lds[ly * LX + lx] = p2.x; lds[ly * LX + lx + 1] = p2.y;
         }
@@ -757,7 +770,7 @@ __global__ __launch_bounds__((TileThreads<S, T, RST>::NT)) __attribute__((amdgpu
         TILE_EACH(refresh);
         __syncthreads();
     }
-    if constexpr (PLAIN_OK) { if (plain) {
+    if constexpr (PLAIN_OK) { if (plain && !TILE_DBG(2)) {
         // ---- the passes as straight-line code: every pair of the thread is evaluated (edge cells and idle slots too: their results
         // land in the margin), all LDS reads of a pass come before its writes (a pass reads the other colour and its own
         // centres only), nothing branches per lane: five independent updates the scheduler can interleave.  The expressions are
@@ -782,7 +795,8 @@ __global__ __launch_bounds__((TileThreads<S, T, RST>::NT)) __attribute__((amdgpu
                 const int x = lx + A;
                 const double *row = lds + ly * LX;
                 double2 pr; double wl, er, s, n;
-                pr = *reinterpret_cast<const double2 *>(row + lx); wl = row[lx - 1]; er = row[lx + 2]; s = row[x - LX]; n = row[x + LX];
+                if (TILE_DBG(32)) { pr = make_double2(q_.rhs0 + 900.0, q_.rhs1 + 900.0); wl = q_.Pi0 * 1.0e-4; er = q_.Pi1 * 1.0e-4; s = q_.zb0 + 900.0; n = q_.zb1 + 900.0; }   // probe: passes without LDS reads
+                else { pr = *reinterpret_cast<const double2 *>(row + lx); wl = row[lx - 1]; er = row[lx + 2]; s = row[x - LX]; n = row[x + LX]; }
                 const double c = A ? pr.y : pr.x;
                 const double w = A ? pr.x : wl, e = A ? er : pr.y;
                 const double B = A ? q_.B1 : q_.B0;
@@ -811,12 +825,15 @@ __global__ __launch_bounds__((TileThreads<S, T, RST>::NT)) __attribute__((amdgpu
                 upd(0, cf0, A0(), nv0, ad0); if constexpr (NK > 1) upd(1, cf1, A0(), nv1, ad1); if constexpr (NK > 2) upd(2, cf2, A0(), nv2, ad2);
                 if constexpr (NK > 3) upd(3, cf3, A0(), nv3, ad3); if constexpr (NK > 4) upd(4, cf4, A0(), nv4, ad4);
             }
+            if (TILE_DBG(64)) { cf0.rhs0 += nv0 * 1e-30; if constexpr (NK > 1) cf1.rhs0 += nv1 * 1e-30; if constexpr (NK > 2) cf2.rhs0 += nv2 * 1e-30;
+                                if constexpr (NK > 3) cf3.rhs0 += nv3 * 1e-30; if constexpr (NK > 4) cf4.rhs0 += nv4 * 1e-30; }   // probe: no LDS writes (results kept alive)
+            else {
             lds[ad0] = nv0; if constexpr (NK > 1) lds[ad1] = nv1; if constexpr (NK > 2) lds[ad2] = nv2;
-            if constexpr (NK > 3) lds[ad3] = nv3; if constexpr (NK > 4) lds[ad4] = nv4;
-            __syncthreads();
+            if constexpr (NK > 3) lds[ad3] = nv3; if constexpr (NK > 4) lds[ad4] = nv4; }
+            if (!TILE_DBG(4)) __syncthreads();
         }
     } }
-    if (!(PLAIN_OK && plain))
+    if (!(PLAIN_OK && plain) && !TILE_DBG(2))
 #pragma unroll 1
     for (int p = 0; p < 2 * S; p++) {
         const int xlo = openW ? 0 : p + 1, xhi = openE ? LX - 1 : LX - 2 - p;
@@ -862,7 +879,7 @@ __global__ __launch_bounds__((TileThreads<S, T, RST>::NT)) __attribute__((amdgpu
     const int wj0 = tj0 - ((ty == 0 && v.ext[0] && !v.rk[0]) ? 1 : 0), wj1 = oj1 + ((oj1 == v.ny && v.ext[1] && !v.rk[1]) ? 1 : 0);
     auto store = [&](const int k, const PairCoef &q_, const bool) {
         int ly, lx;
-        if (pair_pos(k, ly, lx)) {
+        if (pair_pos(k, ly, lx) && !(TILE_DBG(8) && ly != 7)) {
             const int i = gx0 + lx, j = gy0 + ly;
             if (inner && !RST) {                              // (the tile itself lies in the level too)
                 if (lx >= HX && lx < HX + TX && ly >= HY && ly < HY + TY)
@@ -963,6 +980,10 @@ static int launch_tile(suhmo_level *L, int depth, int chunks, int ext_rows, hipS
     }
     g.chunks = chunks;
     g.order = L->tile_order;
+    g.dbg = 0;
+#ifdef SUHMO_TILE_PROBE
+    if (const char *e = getenv("SUHMO_TILE_DBG")) g.dbg = atoi(e);
+#endif
     g.frhs = 0;
     if (D.rhs_pending) {
         if (!suhmo_field(L, depth, SUHMO_F_LPHI) || !suhmo_field(L, depth, SUHMO_F_PHIOLD)) return -2;

@@ -2,6 +2,8 @@
 """Cost of the halo exchanges of a V-cycle: an n x n periodic level whole, and the same level as ONE rank strip that is its own
 neighbour over the native RCCL transport (ncclSend / ncclRecv to itself on the kernels' stream).  Under
 `rocprofv3 --kernel-trace --stats -- python3 tools/strip_probe.py strip` the pack / transport / unpack kernels of the 14 exchanges.
+SUHMO_TRANSPORT=ipc: the strip's halo rows go peer-direct (suhmo_ipc.hip: the pack kernel stores into the receive slots -- its own, being
+its own neighbour -- and the unpack kernel waits on a flag word), RCCL keeps the reductions.
 usage: strip_probe.py [whole|strip|both] [n] [cycles]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,16 +26,18 @@ for name in ("whole", "strip"):
                            halo_rows=int(os.environ.get("SUHMO_HALO_ROWS", "24")))
         L.set_inputs(f)
         multigpu.attach_rccl(L, 0, 1, periodic_y=True)
+        if os.environ.get("SUHMO_TRANSPORT") == "ipc":
+            multigpu.ipc_attach(L, 0, 1, True, [multigpu.ipc_export(L)])
     L.build_mg_coefficients()
     for _ in range(3):
         L.vcycle(sp)
     L.synchronize()
-    e0 = capi.lib().suhmo_level_rccl_exchanges(L.h) if name == "strip" else 0
+    e0 = L.rccl_exchanges() if name == "strip" else 0
     t0 = time.perf_counter()
     for _ in range(cycles):
         L.vcycle(sp)
     L.synchronize()
     dt = (time.perf_counter() - t0) / cycles
-    ex = (capi.lib().suhmo_level_rccl_exchanges(L.h) - e0) / cycles if name == "strip" else 0
-    print("%s %dx%d: %.3f ms per V-cycle, %.1f exchanges per V-cycle" % (name, n, n, dt * 1e3, ex), flush=True)
+    ex = (L.rccl_exchanges() - e0) / cycles if name == "strip" else 0
+    print("%s %dx%d%s: %.3f ms per V-cycle, %.1f exchanges per V-cycle" % (name, n, n, " [%s]" % getattr(L, "_transport", "rccl") if name == "strip" else "", dt * 1e3, ex), flush=True)
     L.close()
