@@ -92,6 +92,7 @@ enum {
     SUHMO_F_DCX, SUHMO_F_DCY, SUHMO_F_DTERM,   /* diffusion coefficient of the gap height on x / y faces, div(D grad b) */
     SUHMO_F_ZS,          /* ice surface height (m_iceheight), input of suhmo_level_time_varying_recharge */
     SUHMO_F_COVER,       /* hierarchies of box unions: 1 where a finer level covers the cell, else 0 (norms, Picard test, moulin integrals) */
+    SUHMO_F_PHI2,        /* hierarchies of box unions: second canvas of the head (the several-sweeps-per-launch relaxation writes out of place) */
     SUHMO_F_COUNT
 };
 

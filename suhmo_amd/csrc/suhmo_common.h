@@ -162,6 +162,7 @@ struct suhmo_level {
     std::vector<VGraph> vgraphs; int vgraph_seen[4]; hipStream_t gstream;
     suhmo_level *gap; double gap_dt;   // implicit gap-height operator of the time step (suhmo_step.hip), owned
     void *rccl;                 // native transport state (suhmo_rccl.hip), owned by the level
+    int faces_deferred;         // rank strips: UpdateOperator left the halo rows of the depth-0 faces to the message that carries the coarse depths' (suhmo_average_operator_all)
     void *ipc; int ipc_owner;   // peer-direct halo transport (suhmo_ipc.hip): arena and neighbours' mappings; a gap-height handle borrows its level's
     // agglomeration of the coarse depths of a rank strip (suhmo_agg.hip): from depth agg_depth on (0 = none) the cycle runs on `agg`, a
     // handle of the WHOLE level at that depth held by every rank; all-gather transport ag (suhmo_level_set_allgather / attach_rccl)
@@ -182,6 +183,7 @@ struct suhmo_level {
     int gsrb_variant;           // kernel selection (see suhmo_gsrb.hip); env SUHMO_GSRB_VARIANT
     long fused_min_cells;       // auto mode: use the fused kernel from this many cells (env SUHMO_FUSED_MIN_CELLS)
     int bcoef_fused;            // single-kernel WFlx_level (env SUHMO_BCOEF_FUSED, default 1)
+    int bcoef_tile_x;           // its tile width: 62 (64 x 4 threads) or 126 (128 x 2 threads); env SUHMO_BCOEF_TILE_X
     int fused_nt;               // threads per workgroup of the fused kernel: 256 or 64 (env SUHMO_FUSED_NT)
     int fused_restrict;         // the last pre-smoothing launch also restricts (env SUHMO_FUSED_RESTRICT, default 1)
     int fused_hc;               // rows per chunk of the fused kernel (0 = auto); env SUHMO_FUSED_HC
@@ -267,6 +269,7 @@ __device__ __forceinline__ void suhmo_publish(const HostSlot &h, double v)
 int suhmo_build_mg_coefficients(suhmo_level *L, bool with_faces, hipStream_t st);   // suhmo_level.hip
 // suhmo_agg.hip: agglomeration of the coarse multigrid depths of a rank strip
 void suhmo_ipc_release(suhmo_level *L);   // suhmo_ipc.hip
+int suhmo_ipc_batch(suhmo_level *L, int open, hipStream_t st);
 int suhmo_agg_setup(suhmo_level *L);
 void suhmo_agg_release(suhmo_level *L);
 int suhmo_agg_gather_static(suhmo_level *L, bool with_faces, hipStream_t st);

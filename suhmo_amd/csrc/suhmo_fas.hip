@@ -112,7 +112,9 @@ static int vcycle_body(suhmo_level *L, const suhmo_solver_params_t *sp, int nd, 
 {
     int rc;
     if (sp->bcoeff_otf) {
-        if ((rc = suhmo_level_update_operator(L, 0, s))) return rc;
+        L->faces_deferred = 1;              // rank strips: the halo rows of the depth-0 faces travel with those of the coarse depths, one message
+        rc = suhmo_level_update_operator(L, 0, s);
+        if (rc) { L->faces_deferred = 0; return rc; }
         if (L->mask_reported) L->maskflag_epoch = L->mask_epoch;                   // the relaxations of THIS cycle may rely on the report
         if ((rc = suhmo_average_operator_all(L, nd, (hipStream_t)s))) return rc;   // AverageOperator on every depth > 0
     } else L->maskflag_epoch = 0;

@@ -106,6 +106,103 @@ int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool h
     return 0;
 }
 
+// ---- levels that are UNIONS OF BOXES: several sweeps per launch (relaxNF, src/AMRNonLinearPoissonOp.cpp:690-750; levelGSRB :654-760).
+// A workgroup owns a box and loads it with a halo of BOXG = 4 cells -- the cells of the neighbouring boxes, taken from THEIR canvases (plan
+// `halo`: for every position of the extended box the box that holds the cell and its canvas offset, or none) -- into LDS, advances the halo
+// cells redundantly (pass m keeps what lies within 3 - m cells of the box current) and after 2 sweeps = 4 colour passes writes the box to the
+// second canvas of the head.  What a cell reads beyond the cells of the level is what its OWN box's ghost ring says: the stored coarse-fine
+// ghost (interpolated before the relaxation, constant during it) or the physical boundary condition of its side, evaluated with that box's
+// view -- at a re-entrant corner of the union a position is the x-ghost of one box and the y-ghost of another, and each reader gets its own.
+// Every update is d_gsrb_pass_simple's expression on the same operands in the same order, so the result is the colour passes' with an
+// exchange before each, bit for bit; a launch reads canvases no workgroup of the launch writes (PHI -> PHI2, then PHI2 -> PHI).
+#define BOXG 4
+#define BOXT 16            // a workgroup takes a 16 x 16 tile of its box (24 x 24 with the halo: the redundant updates buy 16 times the workgroups of one per box)
+template <bool HAS_ALPHA>
+__global__ __launch_bounds__(256) void k_gsrb_box_m(const DV *__restrict__ vt, const FP *__restrict__ ft, const int2 *__restrict__ halo, const int *__restrict__ hbase,
+                                                    suhmo_phys_t ph, int fsrc, int fdst, int npass)
+{
+    constexpr int LWmax = BOXT + 2 * BOXG;
+    __shared__ double pl[LWmax * LWmax];
+    __shared__ int own[LWmax * LWmax], offs[LWmax * LWmax];
+    const int k = blockIdx.y, tid = threadIdx.x;
+    const DV v = vt[k];
+    const int tiles_x = (v.nx + BOXT - 1) / BOXT, tiles_y = (v.ny + BOXT - 1) / BOXT;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int tj = blockIdx.x / tiles_x, ti = blockIdx.x - tj * tiles_x;
+    const int x0 = ti * BOXT, y0 = tj * BOXT;                          // the tile's first cell in the box = its halo's first position in the extended box
+    const int tw = min(BOXT, v.nx - x0), th = min(BOXT, v.ny - y0);
+    const int LW = tw + 2 * BOXG, LH = th + 2 * BOXG, EW = v.nx + 2 * BOXG;
+    const int2 *__restrict__ hk = halo + hbase[k];
+    for (int q = tid; q < LW * LH; q += 256) {
+        const int lj = q / LW, li = q - lj * LW;
+        const int2 h = hk[(y0 + lj) * EW + x0 + li];
+        own[q] = h.x; offs[q] = h.y;
+        pl[q] = h.x >= 0 ? ft[h.x].f[fsrc][h.y] : 0.0;
+    }
+    __syncthreads();
+    const FP &fk = ft[k];
+    for (int m = 0; m < npass; m++) {
+        const int pass = m & 1, reach = npass - 1 - m;                   // cells within `reach` of the tile are advanced by this pass
+        const int RW = tw + 2 * reach, RH = th + 2 * reach, o0 = BOXG - reach;
+        for (int r = tid; r < RW * RH; r += 256) {
+            const int rj = r / RW, ri = r - rj * RW;
+            const int q = (o0 + rj) * LW + (o0 + ri);
+            const int b = own[q];
+            if (b < 0) continue;
+            const int off = offs[q];
+            const DV &vb = b == k ? v : vt[b];
+            const int j = off / vb.P - vb.gy, i = off - (j + vb.gy) * vb.P - SUHMO_XOFF;
+            if ((i + vb.i0 + j + vb.j0 + pass) & 1) continue;          // the colour of this pass (global indices; a periodic image keeps its parity)
+            const FP &fb = b == k ? fk : ft[b];
+            const double *__restrict__ psrc = fb.f[fsrc];
+            const double c = pl[q];
+            // a neighbour that is a cell of the level: its current value; else what the cell's own box holds there (coarse-fine ghost / physical BC)
+            const double w = own[q - 1] >= 0 ? pl[q - 1] : phiW(vb, psrc, off, i, c, false);
+            const double e = own[q + 1] >= 0 ? pl[q + 1] : phiE(vb, psrc, off, i, c, false);
+            const double s = own[q - LW] >= 0 ? pl[q - LW] : phiS(vb, psrc, off, j, c, false);
+            const double n = own[q + LW] >= 0 ? pl[q + LW] : phiN(vb, psrc, off, j, c, false);
+            const double bxW = fb.f[SUHMO_F_BX][off], bxE = fb.f[SUHMO_F_BX][off + 1];
+            const double byS = fb.f[SUHMO_F_BY][off], byN = fb.f[SUHMO_F_BY][off + vb.P];
+            double nl, dnl;
+            nl_terms(ph, c, fb.f[SUHMO_F_B][off], fb.f[SUHMO_F_PI][off], fb.f[SUHMO_F_ZB][off], fb.f[SUHMO_F_MASK][off], nl, dnl);
+            const double aterm = HAS_ALPHA ? vb.alpha * fb.f[SUHMO_F_ACOEF][off] : vb.alpha;
+            const double lofphi = lofphi_cell(vb, aterm, c, e, w, n, s, bxE, bxW, byN, byS, nl);
+            const double lam = lambda_cell(vb, aterm, bxE, bxW, byN, byS);
+            const double denom = 1.0e-16 + lam + dnl;                      // ...OpF.ChF:154
+            pl[q] = c + (fb.f[SUHMO_F_RHS][off] - lofphi) / denom;         // :156 (a cell of one colour reads cells of the other only: in place)
+        }
+        __syncthreads();
+    }
+    // the tile to the second canvas; the box's ghost ring goes along unchanged (first tile): the coarse-fine ghosts stay what they are, the
+    // fine-fine ones are not read by this kernel and are refreshed by the next exchange
+    const double *__restrict__ psrc = fk.f[fsrc];
+    double *__restrict__ pdst = fk.f[fdst];
+    for (int q = tid; q < tw * th; q += 256) {
+        const int jj = q / tw, ii = q - jj * tw;
+        pdst[cidx(v, x0 + ii, y0 + jj)] = pl[(BOXG + jj) * LW + BOXG + ii];
+    }
+    if (blockIdx.x == 0)
+        for (int q = tid; q < 2 * (v.nx + 2) + 2 * v.ny; q += 256) {
+            int ii, jj;
+            if (q < v.nx + 2) { ii = q - 1; jj = -1; }
+            else if (q < 2 * (v.nx + 2)) { ii = q - (v.nx + 2) - 1; jj = v.ny; }
+            else if (q < 2 * (v.nx + 2) + v.ny) { ii = -1; jj = q - 2 * (v.nx + 2); }
+            else { ii = v.nx; jj = q - 2 * (v.nx + 2) - v.ny; }
+            const int idx = cidx(v, ii, jj);
+            pdst[idx] = psrc[idx];
+        }
+}
+// 2 sweeps (4 colour passes, or `npass` of them) of every box of the level in one launch, fsrc -> fdst
+int suhmo_multi_gsrb_box(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, const void *halo, const int *hbase, int fsrc, int fdst, int npass, hipStream_t st)
+{
+    if (m.nbox <= 0) return 0;
+    const dim3 grd(((m.maxnx + BOXT - 1) / BOXT) * ((m.maxny + BOXT - 1) / BOXT), m.nbox);
+    if (has_alpha) hipLaunchKernelGGL(k_gsrb_box_m<true>, grd, dim3(256), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass);
+    else hipLaunchKernelGGL(k_gsrb_box_m<false>, grd, dim3(256), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ---- variant 1: K sweeps fused, streaming over rows ----
 struct FusedGeom {
     int W;        // owned columns per strip (even)

@@ -17,6 +17,7 @@ int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, su
 struct suhmo_multi { const DV *dv; const FP *fp; int nbox, maxnx, maxny; double *red; /* reduction scratch, 64 nbox + 16 doubles */
                      const void *push; const int *pbase; /* fine-fine ghost cells a side cell feeds (int2 {box, offset}), first entry of every box */ };
 int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int pass, hipStream_t st, bool push = false);      // suhmo_gsrb.hip
+int suhmo_multi_gsrb_box(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, const void *halo, const int *hbase, int fsrc, int fdst, int npass, hipStream_t st);   // suhmo_gsrb.hip: 2 sweeps per launch
 int suhmo_multi_fill_ghosts(const suhmo_multi &m, int field, int homog, hipStream_t st);                                  // suhmo_level.hip ...
 int suhmo_multi_apply(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int mode, hipStream_t st);            // mode 0: LPHI, 1: RES, 3: both
 int suhmo_apply_and_residual(suhmo_level *L, int depth, hipStream_t st);                                                  // LPHI and RES = rhs - LPHI in one pass
@@ -25,6 +26,8 @@ int suhmo_multi_re(const suhmo_multi &m, const suhmo_phys_t &ph, hipStream_t st)
 int suhmo_multi_bcoef_faces(const suhmo_multi &m, const suhmo_phys_t &ph, hipStream_t st);
 int suhmo_multi_coef_ghosts(const suhmo_multi &m, int field, hipStream_t st);
 int suhmo_multi_axby(const suhmo_multi &m, int fd, int fx, int fy, double a, double b, hipStream_t st);
+int suhmo_multi_fas_enter(const suhmo_multi &m, hipStream_t st);   // RHS0 <- RHS, RHS <- RES + LPHI, PHIOLD <- PHI in one launch
+int suhmo_multi_fas_leave(const suhmo_multi &m, hipStream_t st);   // RHS <- RHS0, CORR <- PHI - PHIOLD in one launch
 int suhmo_multi_copy(const suhmo_multi &m, int fd, int fs, hipStream_t st);                                               // valid cells + ghost ring
 int suhmo_multi_copy_between(const suhmo_multi &dst, const suhmo_multi &src, const int *fd, const int *fs, int n, hipStream_t st);   // same boxes, two hierarchies
 int suhmo_multi_norm_max(const suhmo_multi &m, suhmo_level *slot, int field, double *out, hipStream_t st);                // max |x| over the valid cells of all boxes

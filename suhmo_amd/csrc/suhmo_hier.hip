@@ -120,10 +120,11 @@ struct HLev {
     // plans (device)
     DevVec<CopyEnt> ff_side, ff_all;                 // ff_all = sides, then corners (the default copier's exchange in one launch)
     DevVec<int2> push; DevVec<int> pbase;            // ff_side seen from the source cell (the colour passes push, suhmo_gsrb.hip)
+    DevVec<int2> halo; DevVec<int> hbase; bool halo_ok = false;   // per box the cells of its 4-cell surroundings (box, canvas offset; -1: no cell of the level): two sweeps per launch
     DevVec<CfEnt> cf;
     DevVec<PwlEnt> pwl;
     DevVec<RectEnt> avg; int avg_w = 0, avg_h = 0;
-    DevVec<WinEnt> wing; int wing_w = 0, wing_h = 0;
+    DevVec<WinEnt> wing; int wing_w = 0, wing_h = 0; DevVec<int> wstart; int win_max = 0;   // wstart[k] .. wstart[k + 1]: the pieces of box k's window
     DevVec<Target> targets; DevVec<Face> faces;
     // level 1 only, in the cells of this rank's part of level 0: the rectangles whose L(phi) / residual change when level 1's head is
     // averaged down (coarsen(box) grown by one cell, periodic images included), and the cells its gradient interpolation reads
@@ -189,6 +190,9 @@ struct suhmo_hier {
     // ... or were left behind by the launch that ended level 0's own V-cycle (suhmo_gsrb.hip, residual output): the solve loop's residual
     // evaluation then needs no pass over level 0 at all
     unsigned long base_fused_ver = 0;
+    bool fused_relax = true;                               // option fused_relax: two sweeps per launch on levels of boxes (0: a launch per colour pass)
+    long n_fused_relax = 0;                                // launches of that kind (read-only option fused_relax_launches)
+    bool fused_prolong = true;                             // option fused_prolong: AMRProlongS_2 of a box in one workgroup (0: gather, BC, prolongation as three launches)
     bool incremental = true;                               // option incremental_residual
     long part_min_cells = 350000;                          // creation option partition_min_cells: when the largest level >= 1 holds at least this many cells
                                                            // PER RANK, the levels >= 1 are dealt to the ranks (below it a pass is shorter than the messages it needs)
@@ -398,6 +402,67 @@ __global__ void k_prolong2_win(const Win *__restrict__ wins, const double *__res
     p = p + fx2 * c[cc] + f0 * c[cc + o1 + o2 * w.nx];
     p = p + fx1 * (c[cc + o1] + c[cc + o2 * w.nx]);
     phi[idx] = p;
+}
+// AMRProlongS_2 of one box per workgroup: the three steps above (gather of the coarse correction into the box's window, physical BC on the
+// window, PROLONG_2_NL) with the window in LDS instead of three launches over a buffer in HBM; the same expressions on the same operands.
+// wstart[k] .. wstart[k + 1]: the gather pieces of box k.  old != NULL: the window gets c - old (see k_win_gather)
+__global__ __launch_bounds__(256) void k_prolong2_fused(const WinEnt *__restrict__ e, const int *__restrict__ wstart, const Win *__restrict__ wins, int k0,
+                                                        const FP *__restrict__ ctab, const DV *__restrict__ cdv, FP cbase, DV cbdv, int use_base, int fc,
+                                                        const double *__restrict__ old, const FP *__restrict__ ftab, const DV *__restrict__ fdv)
+{
+    extern __shared__ double win[];
+    const int k = k0 + blockIdx.x, tid = threadIdx.x;
+    const Win w = wins[k];
+    const int nw = w.nx * w.ny;
+    for (int t = tid; t < nw; t += 256) win[t] = 0.0;                       // (cells no piece and no BC writes: the corners, value 0)
+    __syncthreads();
+    for (int p = wstart[k]; p < wstart[k + 1]; p++) {
+        const WinEnt q = e[p];
+        const int Pc = use_base ? cbdv.P : cdv[q.cb].P;
+        const double *c = fptr(ctab, cbase, use_base, q.cb, fc);
+        for (int t = tid; t < q.w * q.h; t += 256) {
+            const int J = t / q.w, I = t - J * q.w;
+            const int o = q.woff + J * w.nx + I;
+            const double cv = c[q.coff + J * Pc + I];
+            win[o] = old ? 1.0 * cv + -1.0 * old[w.base + o] : cv;
+        }
+    }
+    __syncthreads();
+    {   // k_win_bc
+        const int inx = w.nx - 2, iny = w.ny - 2;
+        for (int t0 = tid; t0 < 2 * iny + 2 * inx; t0 += 256) {
+            int t = t0, dir, side, tt;
+            if (t < 2 * iny) { dir = 0; side = t / iny; tt = t % iny; }
+            else { t -= 2 * iny; dir = 1; side = t / inx; tt = t % inx; }
+            if (cbdv.per[dir]) continue;
+            const int ndom = dir == 0 ? cbdv.nxg : cbdv.nyg;
+            const int g = dir == 0 ? (side ? w.i0 + w.nx - 1 : w.i0) : (side ? w.j0 + w.ny - 1 : w.j0);
+            if (g >= 0 && g <= ndom - 1) continue;
+            const int il = dir == 0 ? (side ? w.nx - 1 : 0) : tt + 1, jl = dir == 0 ? tt + 1 : (side ? w.ny - 1 : 0);
+            const int in_ = dir == 0 ? (side ? w.nx - 2 : 1) : il, jn_ = dir == 0 ? jl : (side ? w.ny - 2 : 1);
+            const double nearv = win[jn_ * w.nx + in_];
+            double gv;
+            if (cbdv.bct[dir][side] == 0) gv = cbdv.two_v[dir][side] - nearv; else gv = nearv + cbdv.neu[dir][side];
+            win[jl * w.nx + il] = gv;
+        }
+    }
+    __syncthreads();
+    {   // k_prolong2_win
+        const DV v = fdv[k];
+        const double den = 1.0 / 16.0, fx1 = 3.0 * den, fx2 = 9.0 * den, f0 = 1.0 * den;
+        double *phi = ftab[k].f[SUHMO_F_PHI];
+        for (int t = tid; t < v.nx * v.ny; t += 256) {
+            const int j = t / v.nx, i = t - j * v.nx;
+            const int gi = i + v.i0, gj = j + v.j0;
+            const int ic = gi / 2, jc = gj / 2, o1 = 2 * (gi % 2) - 1, o2 = 2 * (gj % 2) - 1;
+            const int cc = (jc - w.j0) * w.nx + (ic - w.i0);
+            const int idx = cidx(v, i, j);
+            double p = phi[idx];
+            p = p + fx2 * win[cc] + f0 * win[cc + o1 + o2 * w.nx];
+            p = p + fx1 * (win[cc + o1] + win[cc + o2 * w.nx]);
+            phi[idx] = p;
+        }
+    }
 }
 // [Chombo] LevelFluxRegister (oracle/amrm.c:reflux): one thread per coarse cell next to coarse-fine faces
 __global__ void k_reflux(const Target *__restrict__ tg, int n, const Face *__restrict__ faces, const FP *__restrict__ ftab, const DV *__restrict__ fdv,
@@ -745,6 +810,34 @@ int build_plans(suhmo_hier *H, int l)
         }
         rc |= F.push.upload(push); rc |= F.pbase.upload(pbase);
     }
+    if (!P) {   // two sweeps per launch (suhmo_gsrb.hip:k_gsrb_box_m): for every position of a box grown by 4 cells the box that holds the cell
+        constexpr int G = 4;
+        size_t tot = 0;
+        std::vector<int> hb(nb);
+        bool fits = true;
+        for (int k = 0; k < nb; k++) { const DV &v = F.box[k]->d[0].v; hb[k] = (int)tot; tot += (size_t)(v.nx + 2 * G) * (v.ny + 2 * G);
+                                       fits = fits && v.nx >= 2 && v.ny >= 2; }
+        if (fits && tot < (1u << 30)) {
+            std::vector<int2> hv(tot);
+            for (int k = 0; k < nb; k++) {
+                const int *b = &F.b4[4 * k];
+                const DV &v = F.box[k]->d[0].v;
+                const int EW = v.nx + 2 * G;
+                for (int ej = 0; ej < v.ny + 2 * G; ej++)
+                    for (int ei = 0; ei < EW; ei++) {
+                        int iw = b[0] - G + ei, jw = b[1] - G + ej;
+                        int2 h = int2{-1, 0};
+                        if (wrap_cell(H, F, iw, jw)) {
+                            const int o = F.index.find(iw, jw);
+                            if (o >= 0) { const DV &vo = F.box[o]->d[0].v; h = int2{o, cidx(vo, iw - vo.i0, jw - vo.j0)}; }
+                        }
+                        hv[hb[k] + (size_t)ej * EW + ei] = h;
+                    }
+            }
+            rc |= F.halo.upload(hv); rc |= F.hbase.upload(hb);
+            F.halo_ok = true;
+        }
+    }
     rc |= F.ff_side.upload(ffs);
     { std::vector<CopyEnt> all(ffs); all.insert(all.end(), ffc.begin(), ffc.end()); rc |= F.ff_all.upload(all); } rc |= F.cf.upload(cf); rc |= F.pwl.upload(pwl);
     rc |= F.avg.upload(avg); rc |= F.wing.upload(wing); rc |= F.targets.upload(targets); rc |= F.faces.upload(faces);
@@ -774,6 +867,14 @@ int build_plans(suhmo_hier *H, int l)
     F.avg_w = F.avg_h = F.wing_w = F.wing_h = 0;
     for (auto &e : avg) { F.avg_w = std::max(F.avg_w, e.w); F.avg_h = std::max(F.avg_h, e.h); }
     for (auto &e : wing) { F.wing_w = std::max(F.wing_w, e.w); F.wing_h = std::max(F.wing_h, e.h); }
+    {   // the pieces of a box's window are consecutive (the boxes were visited in order)
+        std::vector<int> ws(nb + 1, 0);
+        for (int b : wing_box) ws[b + 1]++;
+        for (int k = 0; k < nb; k++) ws[k + 1] += ws[k];
+        for (size_t t = 1; t < wing_box.size(); t++) if (wing_box[t] < wing_box[t - 1]) { suhmo_set_error("hier: internal: window pieces out of order"); return -4; }
+        if (F.wstart.upload(ws)) { suhmo_set_error("hier: plan upload failed"); return -2; }
+        for (const Win &w : F.win) F.win_max = std::max(F.win_max, w.nx * w.ny);
+    }
     F.winelems = wtot;
     if (hipMalloc(&F.winbuf, std::max<size_t>(1, wtot) * sizeof(double)) != hipSuccess) { suhmo_set_error("hier: window allocation failed"); return -2; }
     (void)hipMemset(F.winbuf, 0, std::max<size_t>(1, wtot) * sizeof(double));
@@ -1107,21 +1208,27 @@ int hier_prolong2(suhmo_hier *H, int l, int field_c, hipStream_t st, bool minus_
     if (l == 1 && (rc = refresh_base1(H, field_c, st))) return rc;
     if (l > 1 && V.part && (rc = sync1(H, l - 1, V.sy_win, field_c, st))) return rc;
     if ((rc = coarse_args(H, l - 1, st, ca))) return rc;
+    const int nb = (int)V.box.size();
+    for (suhmo_level *L : V.box) L->d[0].phi_fresh = 0;
+    H->phi_ver[l]++;
+    const int k0 = V.part ? V.b0 : 0, nk = V.part ? V.nown : nb;       // (owner computes: the windows of this rank's boxes)
+    if (nk <= 0) return 0;
+    if (H->fused_prolong && V.win_max <= 6144) {                       // gather + BC + PROLONG_2_NL of a box in one workgroup, the window in LDS
+        hipLaunchKernelGGL(k_prolong2_fused, dim3(nk), dim3(256), (size_t)V.win_max * sizeof(double), st, V.wing.d, V.wstart.d, V.d_win, k0,
+                           ca.tab, ca.dv, ca.base, ca.bdv, ca.use_base, field_c, minus_saved ? V.winold : nullptr, V.d_fp, V.d_dv);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (V.wing.n) {
         dim3 grd((V.wing_w + 63) / 64, (V.wing_h + 3) / 4, (unsigned)V.wing.n);
         hipLaunchKernelGGL(k_win_gather, grd, dim3(64, 4), 0, st, V.wing.d, V.winbuf, ca.tab, ca.dv, ca.base, ca.bdv, ca.use_base, field_c, V.d_win, V.d_wing_box,
                            minus_saved ? V.winold : nullptr);
     }
-    const int nb = (int)V.box.size();
     int maxp = 0, maxx = 0, maxy = 0;
     for (const Win &w : V.win) maxp = std::max(maxp, 2 * (w.nx - 2) + 2 * (w.ny - 2));
-    for (suhmo_level *L : V.box) { maxx = std::max(maxx, L->d[0].v.nx); maxy = std::max(maxy, L->d[0].v.ny); L->d[0].phi_fresh = 0; }
-    H->phi_ver[l]++;
-    const int k0 = V.part ? V.b0 : 0, nk = V.part ? V.nown : nb;       // (owner computes: the windows of this rank's boxes)
-    if (nk > 0) {
-        hipLaunchKernelGGL(k_win_bc, dim3((maxp + 255) / 256, nk), dim3(256), 0, st, V.d_win + k0, nk, V.winbuf, ca.bdv);
-        hipLaunchKernelGGL(k_prolong2_win, dim3((maxx + 63) / 64, (maxy + 3) / 4, nk), dim3(64, 4), 0, st, V.d_win + k0, V.winbuf, V.d_fp + k0, V.d_dv + k0);
-    }
+    for (suhmo_level *L : V.box) { maxx = std::max(maxx, L->d[0].v.nx); maxy = std::max(maxy, L->d[0].v.ny); }
+    hipLaunchKernelGGL(k_win_bc, dim3((maxp + 255) / 256, nk), dim3(256), 0, st, V.d_win + k0, nk, V.winbuf, ca.bdv);
+    hipLaunchKernelGGL(k_prolong2_win, dim3((maxx + 63) / 64, (maxy + 3) / 4, nk), dim3(64, 4), 0, st, V.d_win + k0, V.winbuf, V.d_fp + k0, V.d_dv + k0);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1186,6 +1293,21 @@ int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
     int rc;
     suhmo_multi m;
     if ((rc = multi_of(H, l, HST(s), m))) return rc;
+    HLev &Vf = H->lev[l];
+    if (sweeps > 0 && H->fused_relax && Vf.halo_ok && !Vf.part) {
+        // two sweeps per launch: a box's workgroup relaxes the box and, redundantly, the 4 cells around it that belong to its neighbours,
+        // reading their canvases directly -- no exchange between the colour passes, a quarter of the launches (suhmo_gsrb.hip:k_gsrb_box_m)
+        if ((rc = ensure_field(H, l, SUHMO_F_PHI2)) || (rc = multi_of(H, l, HST(s), m))) return rc;
+        int src = SUHMO_F_PHI, dst = SUHMO_F_PHI2;
+        for (int done = 0; done < sweeps; done += 2) {
+            const int npass = 2 * std::min(2, sweeps - done);
+            if ((rc = suhmo_multi_gsrb_box(m, phys_of(H, l), has_alpha(H, l), Vf.halo.d, Vf.hbase.d, src, dst, npass, HST(s)))) return rc;
+            std::swap(src, dst);
+            H->phi_ver[l]++; H->n_fused_relax++;
+        }
+        if (src != SUHMO_F_PHI && (rc = suhmo_multi_copy(m, SUHMO_F_PHI, SUHMO_F_PHI2, HST(s)))) return rc;     // (an odd number of launches)
+        return suhmo_multi_fill_ghosts(m, SUHMO_F_PHI, 1, HST(s));                                            // :757-759
+    }
     // exchange() before every colour pass (:692, :751): once here (unless the side ghosts are current), then every pass pushes
     // its new side cells into the ghost cells they feed
     if (sweeps > 0 && (rc = hier_ff(H, l, SUHMO_F_PHI, -1, false, HST(s)))) return rc;
@@ -1315,14 +1437,20 @@ int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stre
     // the right-hand side of level l-1 is set aside while its FAS problem runs: two canvases trade places on level 0 (its
     // pointers travel by value), a copy on a level of boxes (their pointers sit in a device table)
     SwapGuard rhs_aside;                                   // (trades back on every way out of this scope)
-    if (l - 1 == 0) rhs_aside.arm(&base_of(H)->d[0].fp.f[SUHMO_F_RHS], &base_of(H)->d[0].fp.f[SUHMO_F_RHS0]);
-    else if ((rc = hier_copy(H, l - 1, SUHMO_F_RHS0, SUHMO_F_RHS, s))) return rc;
-    if ((rc = hier_axby(H, l - 1, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
-    if (l == 1 && dist_base(H) && (rc = suhmo_level_exchange(base_of(H), 0, SUHMO_F_RHS, s))) return rc;      // rank strips: rhs halo rows (relaxed redundantly)
-    // the head of level l-1 before its FAS problem: level 1 reads the correction of level 0 only through the windows of its boxes,
-    // so only those cells are kept (and only their differences formed); a level of boxes keeps a copy
-    if (l - 1 == 0) rc = hier_window_save(H, l, SUHMO_F_PHI, HST(s)); else rc = hier_copy(H, l - 1, SUHMO_F_PHIOLD, SUHMO_F_PHI, s);
-    if (rc) return rc;
+    if (l - 1 == 0) {
+        rhs_aside.arm(&base_of(H)->d[0].fp.f[SUHMO_F_RHS], &base_of(H)->d[0].fp.f[SUHMO_F_RHS0]);
+        if ((rc = hier_axby(H, 0, SUHMO_F_RHS, SUHMO_F_RES, SUHMO_F_LPHI, 1.0, 1.0, s))) return rc;
+        if (dist_base(H) && (rc = suhmo_level_exchange(base_of(H), 0, SUHMO_F_RHS, s))) return rc;      // rank strips: rhs halo rows (relaxed redundantly)
+        // the head of level 0 before its FAS problem: level 1 reads the correction of level 0 only through the windows of its boxes,
+        // so only those cells are kept (and only their differences formed)
+        if ((rc = hier_window_save(H, l, SUHMO_F_PHI, HST(s)))) return rc;
+    } else {
+        // a level of boxes: its right-hand side set aside, the FAS right-hand side formed, a copy of its head kept -- one launch
+        // (copy RHS0 <- RHS, axby RHS <- RES + LPHI, copy PHIOLD <- PHI: the same expressions on the same operands)
+        suhmo_multi mc;
+        for (int f : {SUHMO_F_RHS0, SUHMO_F_PHIOLD, SUHMO_F_LPHI}) if ((rc = ensure_field(H, l - 1, f))) return rc;
+        if ((rc = multi_of(H, l - 1, HST(s), mc)) || (rc = suhmo_multi_fas_enter(mc, HST(s)))) return rc;
+    }
     if (l - 1 == 0) {
         // level 0's own V-cycle runs against the FAS right-hand side; its last launch is asked to leave L(phi) and TRUE rhs - L(phi) behind
         // (the true right-hand side waits on the second canvas): what the solve loop's residual evaluation computes next
@@ -1333,10 +1461,12 @@ int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stre
         B->resout_req = 0; B->resout_rhs = nullptr; B->resout_done = 0;
         if (rc) return rc;
     } else if ((rc = vcycle_amr(H, l - 1, sp, s))) return rc;
-    if (l - 1 == 0) rhs_aside.back();
-    else if ((rc = hier_copy(H, l - 1, SUHMO_F_RHS, SUHMO_F_RHS0, s))) return rc;
-    if (l - 1 == 0) rc = hier_prolong2(H, l, SUHMO_F_PHI, HST(s), true);                      // AMRProlongS_2 of phi - phi_saved
-    else if (!(rc = hier_axby(H, l - 1, SUHMO_F_CORR, SUHMO_F_PHI, SUHMO_F_PHIOLD, 1.0, -1.0, s))) rc = hier_prolong2(H, l, SUHMO_F_CORR, HST(s));
+    if (l - 1 == 0) { rhs_aside.back(); rc = hier_prolong2(H, l, SUHMO_F_PHI, HST(s), true); }                // AMRProlongS_2 of phi - phi_saved
+    else {                                                                                    // RHS <- RHS0, CORR <- PHI - PHIOLD: one launch
+        suhmo_multi mc;
+        if ((rc = ensure_field(H, l - 1, SUHMO_F_CORR)) || (rc = multi_of(H, l - 1, HST(s), mc)) || (rc = suhmo_multi_fas_leave(mc, HST(s)))) return rc;
+        rc = hier_prolong2(H, l, SUHMO_F_CORR, HST(s));
+    }
     if (rc) return rc;
     if ((rc = cf_phi(H, l, s))) return rc;
     return hier_gsrb(H, l, sp->num_smooth, s);
@@ -1376,7 +1506,7 @@ extern "C" int suhmo_hier_destroy(suhmo_hier_t *H)
     for (int l = 0; l < 8; l++) {
         HLev &V = H->lev[l];
         for (suhmo_level *L : V.box) (void)suhmo_level_destroy(L);
-        V.ff_side.release(); V.ff_all.release(); V.push.release(); V.pbase.release(); V.cf.release(); V.pwl.release(); V.avg.release(); V.wing.release();
+        V.ff_side.release(); V.ff_all.release(); V.push.release(); V.pbase.release(); V.cf.release(); V.pwl.release(); V.avg.release(); V.wing.release(); V.wstart.release(); V.halo.release(); V.hbase.release();
         V.targets.release(); V.faces.release(); V.dirty0.release(); V.gcells.release();
         if (V.winbuf) (void)hipFree(V.winbuf);
         if (V.winold) (void)hipFree(V.winold);
@@ -1423,6 +1553,8 @@ extern "C" int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc
     if (hier_opt(options, "shadow", 0) != 0) H->shadowed = true;          // an uncut level 0 read through the shadow path all the same (tests)
     H->push_ghosts = hier_opt(options, "push_ghosts", 1) != 0;
     H->incremental = hier_opt(options, "incremental_residual", 1) != 0;
+    H->fused_prolong = hier_opt(options, "fused_prolong", 1) != 0;
+    H->fused_relax = hier_opt(options, "fused_relax", 1) != 0;
     H->part_min_cells = std::max(1L, hier_opt(options, "partition_min_cells", H->part_min_cells));
     H->nlev = nlev; H->device = base->device; H->bc = base->bc; H->base_desc = *base; H->base_desc.boxes = nullptr; H->base_desc.nbox = 0;
     if (options) H->options = options;
@@ -1621,6 +1753,8 @@ extern "C" int suhmo_hier_set_option(suhmo_hier_t *H, const char *key, long valu
         if (H->gap) return suhmo_hier_set_option(H->gap, key, value);
         return 0;
     }
+    if (!strcmp(key, "fused_prolong")) { H->fused_prolong = value != 0; if (H->gap) return suhmo_hier_set_option(H->gap, key, value); return 0; }
+    if (!strcmp(key, "fused_relax")) { H->fused_relax = value != 0; if (H->gap) return suhmo_hier_set_option(H->gap, key, value); return 0; }
     if (!strcmp(key, "push_ghosts")) {
         H->push_ghosts = value != 0;
         for (int l = 0; l < 8; l++) H->ff_seen[l] = 0;
@@ -1634,6 +1768,9 @@ extern "C" int suhmo_hier_get_option(const suhmo_hier_t *H, const char *key, lon
 {
     ARG(H && key && value);
     if (!strcmp(key, "push_ghosts")) { *value = H->push_ghosts; return 0; }
+    if (!strcmp(key, "fused_prolong")) { *value = H->fused_prolong; return 0; }
+    if (!strcmp(key, "fused_relax")) { *value = H->fused_relax; return 0; }
+    if (!strcmp(key, "fused_relax_launches")) { *value = H->n_fused_relax + (H->gap ? H->gap->n_fused_relax : 0); return 0; }
     if (!strcmp(key, "incremental_residual")) { *value = H->incremental; return 0; }
     if (!strcmp(key, "shadow")) { *value = H->shadowed; return 0; }
     if (!strcmp(key, "partition_min_cells")) { *value = H->part_min_cells; return 0; }

@@ -22,54 +22,96 @@
 namespace {
 constexpr int MAXF = 8;
 struct IpcFlags { unsigned long long arrive[2], ack[2]; unsigned int count[2]; unsigned int pad[2]; };
-struct PackList { double *p[MAXF]; int pack_lo[MAXF], pack_hi[MAXF], unpack_lo[MAXF], unpack_hi[MAXF]; int n; };
+constexpr int MAXSEG = 24;
+struct Seg { double *p; int w, P, rows, pack_lo, pack_hi, unpack_lo, unpack_hi, row0; long off; };   // p: canvas address of (i = 0, j = 0); row0: first row of the list
+struct SegList { Seg e[MAXSEG]; int n, nrow, nch; };                                                 // nrow: rows of all segments; nch: 1024-double chunks of the widest row
 struct IpcBlob { hipIpcMemHandle_t handle; long long pid; unsigned long long ptr; unsigned long long bytes; };    // 64 + 24 bytes <= 128
 struct IpcStrip {
     int rank = 0, world = 1, lo = -1, hi = -1, ndepth = 0;
     char *arena = nullptr; size_t bytes = 0;
     char *remote[2] = {nullptr, nullptr}; bool mapped[2] = {false, false};     // the arenas of the lo / hi neighbour
-    size_t slot[SUHMO_MAXDEPTH][2][2] = {}, slot_cap[SUHMO_MAXDEPTH] = {}, flags[SUHMO_MAXDEPTH] = {};   // offsets: [depth][side][slot & 1]
-    unsigned long long seq[SUHMO_MAXDEPTH] = {};
+    // channels: one per depth, and the batch channel (index ndepth) for the exchanges between ex_begin and ex_end
+    size_t slot[SUHMO_MAXDEPTH + 1][2][2] = {}, slot_cap[SUHMO_MAXDEPTH + 1] = {}, flags[SUHMO_MAXDEPTH + 1] = {};   // offsets: [channel][side][slot & 1]; slot_cap in doubles
+    unsigned long long seq[SUHMO_MAXDEPTH + 1] = {};
+    bool batching = false; SegList batch;
     unsigned long long *herr = nullptr, *herr_dev = nullptr;                   // pinned: a kernel whose wait ran out says so here
     long exchanges = 0;
 };
 
-__device__ __forceinline__ void wait_ge(const unsigned long long *p, unsigned long long v, unsigned long long *err)
+// err[0]: a wait ran out; err[1..4]: which one (1 / 2 acknowledgement from lo / hi, 3 / 4 arrival from lo / hi), the number waited for, the number
+// seen, the depth
+__device__ __forceinline__ void wait_ge(const unsigned long long *p, unsigned long long v, unsigned long long *err, int what, int depth)
 {
     const long long t0 = wall_clock64();
     if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= v) return;
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;       // a wait has run out before: what is queued behind it drains at once
     while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < v) {
         __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > 300000000LL) { __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }   // ~3 s at 100 MHz
+        if (wall_clock64() - t0 > 300000000LL) {                                           // ~3 s at 100 MHz
+            if (!__hip_atomic_exchange(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+                err[1] = (unsigned long long)what; err[2] = v; err[3] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); err[4] = (unsigned long long)depth;
+            }
+            return;
+        }
     }
 }
-// message `seq` of a depth: rows travel (nx + 1) wide (x-face rows whole), field after field; to the hi neighbour's lo slot and to the lo
-// neighbour's hi slot (NULL: no neighbour on that side)
-__global__ __launch_bounds__(256) void k_ipc_pack(DV v, PackList pl, int rows, unsigned long long seq, double *__restrict__ to_lo, double *__restrict__ to_hi,
-                                                  IpcFlags *mine, IpcFlags *flo, IpcFlags *fhi, unsigned long long *err)
+// A message = a list of segments (one field of one depth each: `rows` canvas rows of w = nx + 1 doubles -- x-face rows whole -- next to the lo
+// and hi side), laid out one after the other in a slot.  A single exchange is the list of its fields, on the channel of its depth; the
+// exchanges between ex_begin and ex_end (the face coefficients of all depths) are ONE list on the batch channel: one pack and one unpack launch.
+// the segment table from the kernel arguments into LDS (statically indexed copies: a dynamically indexed by-value argument lands in scratch)
+__device__ __forceinline__ void seg_table(const SegList &sl, Seg *segs)
+{
+#pragma unroll
+    for (int k = 0; k < MAXSEG; k++) if ((int)threadIdx.x == k && k < sl.n) segs[k] = sl.e[k];
+    __syncthreads();
+}
+__device__ __forceinline__ const Seg &seg_of(const Seg *segs, int n, int row, int &r)
+{
+    int k = 0;
+    while (k + 1 < n && row >= segs[k + 1].row0) k++;
+    r = row - segs[k].row0;
+    return segs[k];
+}
+// halo data crosses GPUs (or, in the test harness, the XCDs of one): stores that go through to memory, loads that do not stop at a cache
+__device__ __forceinline__ void st_sys(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double ld_sys(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// workgroup = (side, row, chunk of 1024 doubles): four loads in flight per thread, then the stores -- into the neighbour's slot when packing
+__global__ __launch_bounds__(256) void k_ipc_pack(SegList sl, unsigned long long seq, double *__restrict__ to_lo, double *__restrict__ to_hi,
+                                                  IpcFlags *mine, IpcFlags *flo, IpcFlags *fhi, unsigned long long *err, int chan)
 {
     __shared__ int last;
+    __shared__ Seg segs[MAXSEG];
+    seg_table(sl, segs);
     if (threadIdx.x == 0 && seq > 2) {                       // the slot is free once the neighbour has copied message seq - 2 out of it
-        if (to_lo) wait_ge(&mine->ack[0], seq - 2, err);
-        if (to_hi) wait_ge(&mine->ack[1], seq - 2, err);
+        if (to_lo) wait_ge(&mine->ack[0], seq - 2, err, 1, chan);
+        if (to_hi) wait_ge(&mine->ack[1], seq - 2, err, 2, chan);
     }
     __syncthreads();
-    const int w = v.nx + 1;
-    const long per = (long)rows * w, total = per * pl.n * 2;
-    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int side = (int)(t / (per * pl.n));
-        long u = t - (long)side * per * pl.n;
-        const int q = (int)(u / per); u -= (long)q * per;
-        const int r = (int)(u / w), i = (int)(u - (long)r * w);
+    const int per_side = sl.nrow * sl.nch;
+    for (int t = blockIdx.x; t < 2 * per_side; t += gridDim.x) {
+        const int side = t / per_side, u = t - side * per_side, row = u / sl.nch, c = u - row * sl.nch;
         double *b = side ? to_hi : to_lo;
         if (!b) continue;
-        const int j = (side ? pl.pack_hi[q] : pl.pack_lo[q]) + r;
-        b[(long)q * per + u] = pl.p[q][cidx(v, i, j)];
+        int r;
+        const Seg &q = seg_of(segs, sl.n, row, r);
+        const double *__restrict__ src = q.p + (long)((side ? q.pack_hi : q.pack_lo) + r) * q.P;
+        double *dst = b + q.off + (long)r * q.w;
+        const int i0 = c * 1024 + threadIdx.x;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        if (i0 < q.w) v0 = src[i0];
+        if (i0 + 256 < q.w) v1 = src[i0 + 256];
+        if (i0 + 512 < q.w) v2 = src[i0 + 512];
+        if (i0 + 768 < q.w) v3 = src[i0 + 768];
+        if (i0 < q.w) st_sys(dst + i0, v0);
+        if (i0 + 256 < q.w) st_sys(dst + i0 + 256, v1);
+        if (i0 + 512 < q.w) st_sys(dst + i0 + 512, v2);
+        if (i0 + 768 < q.w) st_sys(dst + i0 + 768, v3);
     }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(&mine->count[0], 1u) == gridDim.x - 1;
+    __syncthreads();                                         // (the workgroup's stores are ordered before lane 0's fence by the barrier; the data
+    if (threadIdx.x == 0) {                                  //  stores themselves go through to memory: st_sys)
+        __threadfence_system();
+        last = atomicAdd(&mine->count[0], 1u) == gridDim.x - 1;
+    }
     __syncthreads();
     if (last && threadIdx.x == 0) {
         mine->count[0] = 0;
@@ -78,26 +120,36 @@ __global__ __launch_bounds__(256) void k_ipc_pack(DV v, PackList pl, int rows, u
         if (to_hi) __hip_atomic_store(&fhi->arrive[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-__global__ __launch_bounds__(256) void k_ipc_unpack(DV v, PackList pl, int rows, unsigned long long seq, const double *__restrict__ from_lo, const double *__restrict__ from_hi,
-                                                    IpcFlags *mine, IpcFlags *flo, IpcFlags *fhi, unsigned long long *err)
+__global__ __launch_bounds__(256) void k_ipc_unpack(SegList sl, unsigned long long seq, const double *__restrict__ from_lo, const double *__restrict__ from_hi,
+                                                    IpcFlags *mine, IpcFlags *flo, IpcFlags *fhi, unsigned long long *err, int chan)
 {
     __shared__ int last;
+    __shared__ Seg segs[MAXSEG];
+    seg_table(sl, segs);
     if (threadIdx.x == 0) {
-        if (from_lo) wait_ge(&mine->arrive[0], seq, err);
-        if (from_hi) wait_ge(&mine->arrive[1], seq, err);
+        if (from_lo) wait_ge(&mine->arrive[0], seq, err, 3, chan);
+        if (from_hi) wait_ge(&mine->arrive[1], seq, err, 4, chan);
     }
     __syncthreads();
-    const int w = v.nx + 1;
-    const long per = (long)rows * w, total = per * pl.n * 2;
-    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int side = (int)(t / (per * pl.n));
-        long u = t - (long)side * per * pl.n;
-        const int q = (int)(u / per); u -= (long)q * per;
-        const int r = (int)(u / w), i = (int)(u - (long)r * w);
+    const int per_side = sl.nrow * sl.nch;
+    for (int t = blockIdx.x; t < 2 * per_side; t += gridDim.x) {
+        const int side = t / per_side, u = t - side * per_side, row = u / sl.nch, c = u - row * sl.nch;
         const double *b = side ? from_hi : from_lo;
         if (!b) continue;
-        const int j = (side ? pl.unpack_hi[q] : pl.unpack_lo[q]) + r;
-        pl.p[q][cidx(v, i, j)] = __builtin_nontemporal_load(&b[(long)q * per + u]);
+        int r;
+        const Seg &q = seg_of(segs, sl.n, row, r);
+        double *__restrict__ dst = q.p + (long)((side ? q.unpack_hi : q.unpack_lo) + r) * q.P;
+        const double *src = b + q.off + (long)r * q.w;
+        const int i0 = c * 1024 + threadIdx.x;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        if (i0 < q.w) v0 = ld_sys(src + i0);
+        if (i0 + 256 < q.w) v1 = ld_sys(src + i0 + 256);
+        if (i0 + 512 < q.w) v2 = ld_sys(src + i0 + 512);
+        if (i0 + 768 < q.w) v3 = ld_sys(src + i0 + 768);
+        if (i0 < q.w) dst[i0] = v0;
+        if (i0 + 256 < q.w) dst[i0 + 256] = v1;
+        if (i0 + 512 < q.w) dst[i0 + 512] = v2;
+        if (i0 + 768 < q.w) dst[i0 + 768] = v3;
     }
     __syncthreads();
     if (threadIdx.x == 0) last = atomicAdd(&mine->count[1], 1u) == gridDim.x - 1;
@@ -109,47 +161,82 @@ __global__ __launch_bounds__(256) void k_ipc_unpack(DV v, PackList pl, int rows,
     }
 }
 
+// one message: the segments of `sl` on channel `chan` (a depth, or the batch channel = ndepth)
+int ipc_send(IpcStrip *S, SegList &sl, int chan, hipStream_t st)
+{
+    long off = 0;
+    int row0 = 0, wmax = 1;
+    for (int k = 0; k < sl.n; k++) { sl.e[k].off = off; sl.e[k].row0 = row0; off += (long)sl.e[k].rows * sl.e[k].w; row0 += sl.e[k].rows; wmax = std::max(wmax, sl.e[k].w); }
+    sl.nrow = row0; sl.nch = (wmax + 1023) / 1024;
+    if ((size_t)off > S->slot_cap[chan]) { suhmo_set_error("ipc transport: a message larger than the slots the arena was laid out with"); return -7; }
+    const unsigned long long seq = ++S->seq[chan];
+    const int q = (int)(seq & 1);
+    IpcFlags *mine = (IpcFlags *)(S->arena + S->flags[chan]);
+    IpcFlags *flo = S->lo >= 0 ? (IpcFlags *)(S->remote[0] + S->flags[chan]) : nullptr, *fhi = S->hi >= 0 ? (IpcFlags *)(S->remote[1] + S->flags[chan]) : nullptr;
+    double *to_lo = S->lo >= 0 ? (double *)(S->remote[0] + S->slot[chan][1][q]) : nullptr;      // my rows next to my lo side are the lo neighbour's hi halo
+    double *to_hi = S->hi >= 0 ? (double *)(S->remote[1] + S->slot[chan][0][q]) : nullptr;
+    const double *from_lo = S->lo >= 0 ? (const double *)(S->arena + S->slot[chan][0][q]) : nullptr;
+    const double *from_hi = S->hi >= 0 ? (const double *)(S->arena + S->slot[chan][1][q]) : nullptr;
+    const int nblk = std::max(1, std::min(1024, 2 * sl.nrow * sl.nch));      // bounded: a neighbour that shares the GPU (test harness) must find room while these wait
+    hipLaunchKernelGGL(k_ipc_pack, dim3(nblk), dim3(256), 0, st, sl, seq, to_lo, to_hi, mine, flo, fhi, S->herr_dev, chan);
+    hipLaunchKernelGGL(k_ipc_unpack, dim3(nblk), dim3(256), 0, st, sl, seq, from_lo, from_hi, mine, flo, fhi, S->herr_dev, chan);
+    HIPCHK(hipGetLastError());
+    S->exchanges++;
+    return 0;
+}
+int ipc_check(IpcStrip *S)
+{
+    if (!*S->herr) return 0;
+    static const char *what[] = {"?", "the acknowledgement of the lower neighbour", "the acknowledgement of the upper neighbour", "the message of the lower neighbour", "the message of the upper neighbour"};
+    suhmo_set_error("ipc transport (rank %d of %d): %s did not come within 3 s: waited for number %llu on channel %llu, saw %llu (a neighbour rank stopped, or the ranks disagree on "
+                    "the sequence of exchanges); this rank has sent %llu messages on that channel", S->rank, S->world, what[S->herr[1] <= 4 ? S->herr[1] : 0], S->herr[2], S->herr[4], S->herr[3],
+                    S->herr[4] <= SUHMO_MAXDEPTH ? S->seq[S->herr[4]] : 0ull);
+    return -7;
+}
 int ipc_exchange_hook(void *user, suhmo_level_t *L, int depth, const int *fields, int nfields, suhmo_stream_t s)
 {
     (void)user;
     IpcStrip *S = (IpcStrip *)L->ipc;
     if (!S) { suhmo_set_error("ipc transport: the level is not attached"); return -7; }
-    if (*S->herr) { suhmo_set_error("ipc transport: a halo message did not arrive within 3 s (a neighbour rank stopped?)"); return -7; }
-    hipStream_t st = (hipStream_t)s;
+    int rc = ipc_check(S); if (rc) return rc;
+    if (depth >= S->ndepth) { suhmo_set_error("ipc transport: depth %d beyond the arena's %d", depth, S->ndepth); return -7; }
     const DV &v = L->d[depth].v;
     const int rows = v.gy < v.ny ? v.gy : v.ny;
-    const size_t n = (size_t)rows * (v.nx + 1);
-    if (depth >= S->ndepth || n * (size_t)(nfields < MAXF ? nfields : MAXF) > S->slot_cap[depth]) { suhmo_set_error("ipc transport: a message larger than the slots the arena was laid out with"); return -7; }
-    for (int f0 = 0; f0 < nfields; f0 += MAXF) {
-        PackList pl;
-        pl.n = nfields - f0 < MAXF ? nfields - f0 : MAXF;
-        for (int q = 0; q < pl.n; q++) {
-            const int f = fields[f0 + q];
-            pl.p[q] = suhmo_field(L, depth, f);
-            if (!pl.p[q]) { suhmo_set_error("field allocation failed"); return -2; }
-            pl.pack_lo[q] = f == SUHMO_F_BY ? 1 : 0;         // (as suhmo_rccl.hip: face row 0 of a strip IS face row ny of the lower neighbour)
-            pl.pack_hi[q] = v.ny - rows;
-            pl.unpack_lo[q] = -rows;
-            pl.unpack_hi[q] = f == SUHMO_F_BY ? v.ny + 1 : v.ny;
+    SegList one;
+    SegList &sl = S->batching ? S->batch : one;
+    if (!S->batching) sl.n = 0;
+    for (int q = 0; q < nfields; q++) {
+        const int f = fields[q];
+        double *p = suhmo_field(L, depth, f);
+        if (!p) { suhmo_set_error("field allocation failed"); return -2; }
+        if (sl.n == MAXSEG) {                                // (a list is full: send what there is; both neighbours fill theirs alike)
+            if ((rc = ipc_send(S, sl, S->batching ? S->ndepth : depth, (hipStream_t)s))) return rc;
+            sl.n = 0;
         }
-        const unsigned long long seq = ++S->seq[depth];
-        const int sl = (int)(seq & 1);
-        IpcFlags *mine = (IpcFlags *)(S->arena + S->flags[depth]);
-        IpcFlags *flo = S->lo >= 0 ? (IpcFlags *)(S->remote[0] + S->flags[depth]) : nullptr, *fhi = S->hi >= 0 ? (IpcFlags *)(S->remote[1] + S->flags[depth]) : nullptr;
-        double *to_lo = S->lo >= 0 ? (double *)(S->remote[0] + S->slot[depth][1][sl]) : nullptr;      // my rows next to my lo side are the lo neighbour's hi halo
-        double *to_hi = S->hi >= 0 ? (double *)(S->remote[1] + S->slot[depth][0][sl]) : nullptr;
-        const double *from_lo = S->lo >= 0 ? (const double *)(S->arena + S->slot[depth][0][sl]) : nullptr;
-        const double *from_hi = S->hi >= 0 ? (const double *)(S->arena + S->slot[depth][1][sl]) : nullptr;
-        const long total = 2L * (long)n * pl.n;
-        const int nblk = (int)std::max(1L, std::min(128L, (total + 1023) / 1024));
-        hipLaunchKernelGGL(k_ipc_pack, dim3(nblk), dim3(256), 0, st, v, pl, rows, seq, to_lo, to_hi, mine, flo, fhi, S->herr_dev);
-        hipLaunchKernelGGL(k_ipc_unpack, dim3(nblk), dim3(256), 0, st, v, pl, rows, seq, from_lo, from_hi, mine, flo, fhi, S->herr_dev);
-        HIPCHK(hipGetLastError());
-        S->exchanges++;
+        Seg &e = sl.e[sl.n++];
+        e.p = p + cidx(v, 0, 0); e.w = v.nx + 1; e.P = v.P; e.rows = rows;
+        e.pack_lo = f == SUHMO_F_BY ? 1 : 0;                 // (as suhmo_rccl.hip: face row 0 of a strip IS face row ny of the lower neighbour)
+        e.pack_hi = v.ny - rows;
+        e.unpack_lo = -rows;
+        e.unpack_hi = f == SUHMO_F_BY ? v.ny + 1 : v.ny;
     }
-    return 0;
+    if (S->batching) return 0;
+    return ipc_send(S, sl, depth, (hipStream_t)s);
 }
 }  // namespace
+
+// the exchanges between open and close travel as ONE message (suhmo_average_operator_all: the face coefficients of every depth)
+int suhmo_ipc_batch(suhmo_level *L, int open, hipStream_t st)
+{
+    IpcStrip *S = (IpcStrip *)L->ipc;
+    if (!S) return 0;
+    if (open) { S->batching = true; S->batch.n = 0; return 0; }
+    S->batching = false;
+    if (S->batch.n == 0) return 0;
+    int rc = ipc_send(S, S->batch, S->ndepth, st);
+    S->batch.n = 0;
+    return rc;
+}
 
 static void ipc_release(suhmo_level *L)
 {
@@ -180,7 +267,13 @@ extern "C" int suhmo_level_ipc_export(suhmo_level_t *L, void *blob128)
         S->slot_cap[d] = (size_t)MAXF * rows * (v.nx + 1);
         for (int side = 0; side < 2; side++) for (int sl = 0; sl < 2; sl++) { S->slot[d][side][sl] = off; off += (S->slot_cap[d] * sizeof(double) + 255) & ~(size_t)255; }
     }
-    for (int d = 0; d < L->ndepth; d++) { S->flags[d] = off; off += 256; }
+    {   // the batch channel: up to four fields of every depth in one message
+        size_t cap = 0;
+        for (int d = 0; d < L->ndepth; d++) cap += S->slot_cap[d] / MAXF * 4;
+        S->slot_cap[L->ndepth] = cap;
+        for (int side = 0; side < 2; side++) for (int sl = 0; sl < 2; sl++) { S->slot[L->ndepth][side][sl] = off; off += (cap * sizeof(double) + 255) & ~(size_t)255; }
+    }
+    for (int d = 0; d <= L->ndepth; d++) { S->flags[d] = off; off += 256; }
     S->bytes = off;
     // fine-grained: stores of a peer and the flag words behind them must be visible to a running kernel of the owner
     if (hipExtMallocWithFlags((void **)&S->arena, S->bytes, hipDeviceMallocFinegrained) != hipSuccess) {
@@ -189,7 +282,7 @@ extern "C" int suhmo_level_ipc_export(suhmo_level_t *L, void *blob128)
     }
     HIPCHK(hipMemset(S->arena, 0, S->bytes));
     HIPCHK(hipHostMalloc((void **)&S->herr, 64, hipHostMallocMapped | hipHostMallocCoherent));
-    *S->herr = 0;
+    memset(S->herr, 0, 64);
     HIPCHK(hipHostGetDevicePointer((void **)&S->herr_dev, S->herr, 0));
     HIPCHK(hipDeviceSynchronize());
     IpcBlob b;

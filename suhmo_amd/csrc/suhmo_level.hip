@@ -153,11 +153,13 @@ int suhmo_level_create_(suhmo_level_t **out, const suhmo_level_desc_t *desc, boo
     HIPCHK(hipSetDevice(desc->device));
     suhmo_level *L = new suhmo_level();
     L->desc = *desc; L->ph = desc->phys; L->device = desc->device;
-    L->ex = nullptr; L->ar = nullptr; L->ar2 = nullptr; L->ard = nullptr; L->user = nullptr; L->ex_begin = nullptr; L->ex_end = nullptr; L->rccl = nullptr; L->ipc = nullptr; L->ipc_owner = 0; L->gap = nullptr; L->gap_dt = 0.0; L->prof_on = 0; L->gsrb_variant = -1; L->fused_hc = 0;
+    L->ex = nullptr; L->ar = nullptr; L->ar2 = nullptr; L->ard = nullptr; L->user = nullptr; L->ex_begin = nullptr; L->ex_end = nullptr; L->rccl = nullptr; L->ipc = nullptr; L->ipc_owner = 0; L->faces_deferred = 0; L->gap = nullptr; L->gap_dt = 0.0; L->prof_on = 0; L->gsrb_variant = -1; L->fused_hc = 0;
     if (const char *e = getenv("SUHMO_GSRB_VARIANT")) L->gsrb_variant = atoi(e);
     if (const char *e = getenv("SUHMO_FUSED_HC")) L->fused_hc = atoi(e);
     L->bcoef_fused = 1;
     if (const char *e = getenv("SUHMO_BCOEF_FUSED")) L->bcoef_fused = atoi(e);
+    L->bcoef_tile_x = 62;
+    if (const char *e = getenv("SUHMO_BCOEF_TILE_X")) L->bcoef_tile_x = atoi(e);
     L->fused_nt = 64;                        // one wave per workgroup: 316 vs 308 V-cycles/s at 4096^2 (profiles/r01_i_nt_ab.txt)
     if (const char *e = getenv("SUHMO_FUSED_NT")) L->fused_nt = atoi(e);
     L->fused_restrict = 1;
@@ -331,7 +333,7 @@ static long *option_slot_long(suhmo_level *L, const char *key)
 static int *option_slot_int(suhmo_level *L, const char *key)
 {
     static const struct { const char *k; int suhmo_level::*m; } tab[] = {
-        {"gsrb_variant", &suhmo_level::gsrb_variant}, {"fused_hc", &suhmo_level::fused_hc}, {"bcoef_fused", &suhmo_level::bcoef_fused},
+        {"gsrb_variant", &suhmo_level::gsrb_variant}, {"fused_hc", &suhmo_level::fused_hc}, {"bcoef_fused", &suhmo_level::bcoef_fused}, {"bcoef_tile_x", &suhmo_level::bcoef_tile_x},
         {"fused_nt", &suhmo_level::fused_nt}, {"fused_restrict", &suhmo_level::fused_restrict}, {"strips_rhs_local", &suhmo_level::strips_rhs_local},
         {"tile_strips", &suhmo_level::tile_strips}, {"overlap_halo", &suhmo_level::overlap_halo}, {"skip_mask", &suhmo_level::skip_mask}, {"tile_chunks", &suhmo_level::tile_chunks}, {"tile_order", &suhmo_level::tile_order}, {"tile_restrict", &suhmo_level::tile_restrict}, {"fas_rhs_in_relax", &suhmo_level::fas_rhs_in_relax}, {"resid_in_relax", &suhmo_level::resid_in_relax}, {"fas_rhs_fused", &suhmo_level::fas_rhs_fused},
         {"tile_s", &suhmo_level::tile_s}, {"gsrb_tile", &suhmo_level::gsrb_tile}, {"tile_t", &suhmo_level::tile_t}, {"poll_readback", &suhmo_level::poll_readback}};
@@ -1160,17 +1162,19 @@ __global__ __launch_bounds__(256) void k_bcoef_faces_m(const DV *__restrict__ vt
 // tile's W and S faces (+ the domain's E / N faces in the last tile column / row).
 // Every value comes from the same expressions as the four-kernel path (bitwise equal); halo
 // cells are recomputed instead of stored, so HBM sees phi, B, mask once and bx, by once.
-#define BT_X 62
-#define BT_Y 14
+// Tile shapes: 62 x 14 on 64 x 4 threads, or 126 x 14 on 128 x 2 threads (BT_X + 2 lanes per row; level option bcoef_tile_x): the wider tile's
+// rows are 1040 instead of 528 bytes, so the 128-byte lines its unaligned ends drag in weigh half as much.
 // INTERIOR: the tile and its two-cell halo lie inside the level -- no boundary condition, no wrap, no missing cell: the
 // same expressions without the case distinctions (most tiles; uniform per workgroup)
-template <bool INTERIOR>
+template <bool INTERIOR, int BT_X, int BT_Y>
 __device__ __forceinline__ void bcoef_tile(const DV &v, const FP &fp, const suhmo_phys_t &ph, int hasMask, double *sphi, double *sB, double *sM,
                                            unsigned *negflag, unsigned epoch)
 {
     constexpr int PW = BT_X + 4, PH = BT_Y + 4;     // phi tile: cells [i0-2, i0+BT_X+1] x [j0-2, j0+BT_Y+1]
     constexpr int RW = BT_X + 2, RH = BT_Y + 2;     // Re tile:  cells [i0-1, i0+BT_X]   x [j0-1, j0+BT_Y]
-    constexpr int NK = RH / 4;
+    constexpr int TX = BT_X + 2, TY = 256 / TX;     // threads of the workgroup: TX lanes along a row, TY rows at a time
+    constexpr int NK = RH / TY;
+    static_assert(TX * TY == 256 && RH % TY == 0, "tile shape");
     double *sre = sphi;                              // phi is dead once the gradients exist
     const int i0 = blockIdx.x * BT_X, j0 = blockIdx.y * BT_Y;
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -1185,10 +1189,10 @@ __device__ __forceinline__ void bcoef_tile(const DV &v, const FP &fp, const suhm
 
     // ---- phi tile.  Cells that do not exist get the physical-BC ghost of their interior
     // neighbour (only the first ghost layer is used: face gradient of the boundary cell).
-    for (int lj = ty; lj < PH; lj += 4) {
+    for (int lj = ty; lj < PH; lj += TY) {
         const int j = j0 - 2 + lj;
         const bool yi = yin(j);
-        for (int li = tx; li < PW; li += 64) {
+        for (int li = tx; li < PW; li += TX) {
             const int i = i0 - 2 + li;
             const bool xi = xin(i);
             double val = 0.0;
@@ -1213,7 +1217,7 @@ __device__ __forceinline__ void bcoef_tile(const DV &v, const FP &fp, const suhm
     bool neg = false;
 #pragma unroll
     for (int k = 0; k < NK; k++) {
-        const int lj = ty + 4 * k, j = j0 - 1 + lj;
+        const int lj = ty + TY * k, j = j0 - 1 + lj;
         hasB[k] = INTERIOR || (i >= -1 && i <= v.nx && j >= -v.gy && j <= v.ny + v.gy - 1 && !((i < 0 || i >= v.nx) && (j < 0 || j >= v.ny)));
         double b = 0.0, m = 0.0;
         if (hasB[k]) { int idx = cidx(v, i, j); b = Bf[idx]; m = mk[idx]; }
@@ -1242,7 +1246,7 @@ __device__ __forceinline__ void bcoef_tile(const DV &v, const FP &fp, const suhm
     double rer[NK];
 #pragma unroll
     for (int k = 0; k < NK; k++) {
-        const int lj = ty + 4 * k, j = j0 - 1 + lj;
+        const int lj = ty + TY * k, j = j0 - 1 + lj;
         const bool yi = yin(j);
         const int p = (lj + 1) * PW + (tx + 1);
         double gx = 0.0, gy = 0.0;
@@ -1273,14 +1277,14 @@ __device__ __forceinline__ void bcoef_tile(const DV &v, const FP &fp, const suhm
     }
     __syncthreads();                                 // every lane is done reading the phi tile
 #pragma unroll
-    for (int k = 0; k < NK; k++) sre[(ty + 4 * k) * RW + tx] = rer[k];
+    for (int k = 0; k < NK; k++) sre[(ty + TY * k) * RW + tx] = rer[k];
     __syncthreads();
     // ---- faces (k_bcoef_faces): lane tx >= 1 owns cell column i (its W and S faces); the last tile
     // column / row also owns the domain's E / N faces
     const int nxt = (!INTERIOR && i0 + BT_X >= v.nx) ? v.nx - i0 + 1 : BT_X, nyt = (!INTERIOR && j0 + BT_Y >= v.ny) ? v.ny - j0 + 1 : BT_Y;
     const int fx = tx - 1;                           // face column index inside the tile
     if (fx >= 0 && fx < nxt) {
-        for (int fy = ty; fy < nyt; fy += 4) {
+        for (int fy = ty; fy < nyt; fy += TY) {
             const int j = j0 + fy, idx = cidx(v, i, j), r = (fy + 1) * RW + tx;
             if (INTERIOR || j < v.ny)
                 bxo[idx] = bcoef_face(ph, sre[r], sre[r - 1], sB[r], sB[r - 1], sM[r], sM[r - 1], !INTERIOR && (i == 0 || i == v.nx));
@@ -1308,13 +1312,14 @@ __global__ __launch_bounds__(256) void k_mask_halo_report(MaskHalo h, unsigned *
     }
     if (neg) *negflag = epoch;
 }
+template <int BT_X, int BT_Y>
 __global__ __launch_bounds__(256) void k_bcoef_fused(DV v, FP fp, suhmo_phys_t ph, int hasMask, unsigned *negflag, unsigned epoch)
 {
     __shared__ double sphi[(BT_X + 4) * (BT_Y + 4)], sB[(BT_X + 2) * (BT_Y + 2)], sM[(BT_X + 2) * (BT_Y + 2)];
     const int i0 = blockIdx.x * BT_X, j0 = blockIdx.y * BT_Y;
     const bool interior = i0 - 2 >= 0 && i0 + BT_X + 1 <= v.nx - 1 && j0 - 2 >= 0 && j0 + BT_Y + 1 <= v.ny - 1;
-    if (interior) bcoef_tile<true>(v, fp, ph, hasMask, sphi, sB, sM, negflag, epoch);
-    else bcoef_tile<false>(v, fp, ph, hasMask, sphi, sB, sM, negflag, epoch);
+    if (interior) bcoef_tile<true, BT_X, BT_Y>(v, fp, ph, hasMask, sphi, sB, sM, negflag, epoch);
+    else bcoef_tile<false, BT_X, BT_Y>(v, fp, ph, hasMask, sphi, sB, sM, negflag, epoch);
 }
 
 extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_stream_t s)
@@ -1330,7 +1335,9 @@ extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_st
                  && L->desc.nx_global == 0;      // AMR patches: un-fused kernels (coarse-fine ghosts are stored data)
     int rc = suhmo_ensure_phi_halo(L, depth, fused ? 2 : 1, st); if (rc) return rc;
     if (fused) {
-        dim3 grd((D.v.nx + BT_X - 1) / BT_X, (D.v.ny + BT_Y - 1) / BT_Y);   // the last tile column / row also owns the E / N faces
+        const bool wide = L->bcoef_tile_x == 126 && D.v.nx >= 256;          // tiles of 126 x 14 cells on 128 x 2 threads (else 62 x 14 on 64 x 4)
+        const int BX = wide ? 126 : 62, BY = 14;
+        dim3 grd((D.v.nx + BX - 1) / BX, (D.v.ny + BY - 1) / BY);   // the last tile column / row also owns the E / N faces
         // depth 0 of a whole level: the kernel also reports (device word = this call's number) whether the ice mask has a negative cell
         // (the V-cycle that called takes the report up, suhmo_fas.hip: it holds until that cycle ends, not across calls of this entry point)
         unsigned *flag = nullptr;
@@ -1340,7 +1347,8 @@ extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_st
             if (++L->mask_epoch == 0) L->mask_epoch = 1;
             L->mask_reported = 1;
         }
-        hipLaunchKernelGGL(k_bcoef_fused, grd, dim3(64, 4), 0, st, D.v, D.fp, L->ph, L->ph.use_mask_gradients, flag, L->mask_epoch);
+        if (wide) hipLaunchKernelGGL((k_bcoef_fused<126, 14>), grd, dim3(128, 2), 0, st, D.v, D.fp, L->ph, L->ph.use_mask_gradients, flag, L->mask_epoch);
+        else hipLaunchKernelGGL((k_bcoef_fused<62, 14>), grd, dim3(64, 4), 0, st, D.v, D.fp, L->ph, L->ph.use_mask_gradients, flag, L->mask_epoch);
         if (flag && (D.v.ext[0] || D.v.ext[1])) {
             MaskHalo h;
             h.nd = 0; h.lo = D.v.ext[0]; h.hi = D.v.ext[1];
@@ -1365,7 +1373,9 @@ extern "C" int suhmo_level_update_operator(suhmo_level_t *L, int depth, suhmo_st
         hipLaunchKernelGGL(k_bcoef_faces, grid2d(D.v.nx + 1, D.v.ny + 1), BLK2D, 0, st, D.v, D.fp, L->ph);
     }
     HIPCHK(hipGetLastError());
-    // strips: the fused relaxation recomputes halo rows, so it needs the coefficients there too
+    // strips: the fused relaxation recomputes halo rows, so it needs the coefficients there too (faces_deferred: the V-cycle sends them
+    // with the coarse depths' faces, one message for all depths: suhmo_average_operator_all)
+    if (depth == 0 && L->faces_deferred) return 0;
     rc = exchange_fields(L, depth, {SUHMO_F_BX, SUHMO_F_BY}, st); if (rc) return rc;
     return 0;
 }
@@ -1538,8 +1548,11 @@ extern "C" int suhmo_level_average_operator(suhmo_level_t *L, int depth, suhmo_s
 int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st)
 {
     Depth &F = L->d[0];
-    if (nd < 2) return 0;
+    const bool d0 = L->faces_deferred != 0;          // the halo rows of the depth-0 faces are still to travel
+    L->faces_deferred = 0;
+    if (nd < 2) return d0 ? exchange_fields(L, 0, {SUHMO_F_BX, SUHMO_F_BY}, st) : 0;
     if (nd > 7 || F.v.nx % (1 << (nd - 1)) || F.v.ny % (1 << (nd - 1))) {     // generic fallback
+        if (d0) { int rc = exchange_fields(L, 0, {SUHMO_F_BX, SUHMO_F_BY}, st); if (rc) return rc; }
         for (int k = 1; k < nd; k++) { int rc = suhmo_level_average_operator(L, k, (suhmo_stream_t)st); if (rc) return rc; }
         return suhmo_agg_gather_faces(L, nd, st);
     }
@@ -1552,11 +1565,13 @@ int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st)
     hipLaunchKernelGGL(k_average_faces_y_all, gy, dim3(256), 0, st, F.v, F.fp.f[SUHMO_F_BY], o, nd);
     HIPCHK(hipGetLastError());
     // strips: the coarse face coefficients of all depths travel as one message group when the transport can batch
-    if (L->ex_begin && L->ex) { int rc = L->ex_begin(L->user); if (rc) return rc; }
-    for (int k = 1; k < nd && !(L->agg && k >= L->agg_depth); k++) {
+    if (L->ipc) { int rc = suhmo_ipc_batch(L, 1, st); if (rc) return rc; }
+    else if (L->ex_begin && L->ex) { int rc = L->ex_begin(L->user); if (rc) return rc; }
+    for (int k = d0 ? 0 : 1; k < nd && !(L->agg && k >= L->agg_depth); k++) {
         int rc = exchange_fields(L, k, {SUHMO_F_BX, SUHMO_F_BY}, st); if (rc) return rc;
     }
-    if (L->ex_end && L->ex) { int rc = L->ex_end(L->user, L, (suhmo_stream_t)st); if (rc) return rc; }
+    if (L->ipc) { int rc = suhmo_ipc_batch(L, 0, st); if (rc) return rc; }
+    else if (L->ex_end && L->ex) { int rc = L->ex_end(L->user, L, (suhmo_stream_t)st); if (rc) return rc; }
     return suhmo_agg_gather_faces(L, nd, st);       // agglomerated depths: every rank's rows of the coarse faces -> the whole-level copy
 }
 
@@ -1990,6 +2005,30 @@ __global__ void k_copy_m(const DV *__restrict__ vt, const FP *__restrict__ ft, i
     int idx = cidx(v, i, j);
     ft[blockIdx.z].f[fd][idx] = ft[blockIdx.z].f[fs][idx];
 }
+// A level of boxes entering / leaving its FAS problem in an AMR V-cycle (suhmo_hier.hip:vcycle_amr), one launch each instead of three / two:
+//   enter: RHS0 <- RHS (copy, ghost ring included), RHS <- 1 RES + 1 LPHI (axby, valid cells), PHIOLD <- PHI (copy)
+//   leave: RHS <- RHS0 (copy), CORR <- 1 PHI + (-1) PHIOLD (axby)               -- the expressions of k_copy_m / k_axby_m on the same operands
+__global__ void k_fas_enter_m(const DV *__restrict__ vt, const FP *__restrict__ ft)
+{
+    const DV &v = vt[blockIdx.z];
+    const FP &f = ft[blockIdx.z];
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1, j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+    if (i > v.nx || j > v.ny) return;
+    int idx = cidx(v, i, j);
+    f.f[SUHMO_F_RHS0][idx] = f.f[SUHMO_F_RHS][idx];
+    f.f[SUHMO_F_PHIOLD][idx] = f.f[SUHMO_F_PHI][idx];
+    if (i >= 0 && i < v.nx && j >= 0 && j < v.ny) f.f[SUHMO_F_RHS][idx] = 1.0 * f.f[SUHMO_F_RES][idx] + 1.0 * f.f[SUHMO_F_LPHI][idx];
+}
+__global__ void k_fas_leave_m(const DV *__restrict__ vt, const FP *__restrict__ ft)
+{
+    const DV &v = vt[blockIdx.z];
+    const FP &f = ft[blockIdx.z];
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1, j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+    if (i > v.nx || j > v.ny) return;
+    int idx = cidx(v, i, j);
+    f.f[SUHMO_F_RHS][idx] = f.f[SUHMO_F_RHS0][idx];
+    if (i >= 0 && i < v.nx && j >= 0 && j < v.ny) f.f[SUHMO_F_CORR][idx] = 1.0 * f.f[SUHMO_F_PHI][idx] + -1.0 * f.f[SUHMO_F_PHIOLD][idx];
+}
 // fields of the boxes of one hierarchy <- fields of the same boxes of another (the implicit gap-height operator's copy of a level)
 struct CopyPairs { int n, fd[4], fs[4]; };
 __global__ void k_copy_between_m(const DV *__restrict__ vt, const FP *__restrict__ fdst, const FP *__restrict__ fsrc, CopyPairs cp)
@@ -2077,6 +2116,20 @@ int suhmo_multi_copy(const suhmo_multi &m, int fd, int fs, hipStream_t st)
 {
     if (m.nbox <= 0) return 0;                       // a rank that owns no box of the level
     hipLaunchKernelGGL(k_copy_m, grid_m(m, 2, 2), BLK2D, 0, st, m.dv, m.fp, fd, fs);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int suhmo_multi_fas_enter(const suhmo_multi &m, hipStream_t st)
+{
+    if (m.nbox <= 0) return 0;
+    hipLaunchKernelGGL(k_fas_enter_m, grid_m(m, 2, 2), BLK2D, 0, st, m.dv, m.fp);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int suhmo_multi_fas_leave(const suhmo_multi &m, hipStream_t st)
+{
+    if (m.nbox <= 0) return 0;
+    hipLaunchKernelGGL(k_fas_leave_m, grid_m(m, 2, 2), BLK2D, 0, st, m.dv, m.fp);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -12,7 +12,7 @@ from . import capi
 from .capi import check
 
 F_PHI, F_RHS, F_ACOEF, F_B, F_PI, F_ZB, F_MASK, F_BX, F_BY, F_LAMBDA, F_RES, F_LPHI, F_NL, F_DNL, \
-    F_PHIOLD, F_CORR, F_GRADX, F_GRADY, F_RE, F_MR, F_PW, F_QWX, F_QWY, F_HLAG, F_CD, F_RHS0, F_MSRC, F_DCX, F_DCY, F_DTERM, F_ZS, F_COVER = range(32)
+    F_PHIOLD, F_CORR, F_GRADX, F_GRADY, F_RE, F_MR, F_PW, F_QWX, F_QWY, F_HLAG, F_CD, F_RHS0, F_MSRC, F_DCX, F_DCY, F_DTERM, F_ZS, F_COVER, F_PHI2 = range(33)
 
 
 def _phys(p):

@@ -85,6 +85,7 @@ def test_hier_pieces_bitwise(oracle, bc, ph):
 @pytest.mark.parametrize("name,boxes,bc,ph", [("union-4lev", UNION, BC_NP, sy.CFG3_PHYS), ("union-4lev-values-mask", UNION, BC_V, MASKPH),
                                               ("cut-periodic", CUT, BC, sy.CFG3_PHYS), ("union-4lev-exchange-per-pass", UNION, BC_NP, sy.CFG3_PHYS),
                                               ("union-4lev-whole-level-residuals", UNION, BC_NP, sy.CFG3_PHYS),
+                                              ("union-4lev-a-launch-per-colour-pass", UNION, BC_V, MASKPH),
                                               ("union-4lev-base-on-the-streaming-kernel", UNION, BC_NP, sy.CFG3_PHYS),
                                               ("union-4lev-values-mask-base-on-the-streaming-kernel", UNION, BC_V, MASKPH),
                                               ("union-4lev-base-on-the-streaming-kernel-own-residual-pass", UNION, BC_NP, sy.CFG3_PHYS)],
@@ -102,7 +103,11 @@ def test_hier_vcycle_and_solve_bitwise(oracle, name, boxes, bc, ph, monkeypatch)
     sp = dict(sy.SOLVER_DEFAULT, eps=1e-9, norm_thresh=1e-14, max_iter=6, imin=30)
     # whole-level-residuals: every composite residual and coarse gradient over all of level 0 (default: the solve loop's evaluation is
     # reused by the next cycle except where level 1 was averaged down; the coarse gradient only where the interpolation reads it)
-    O, G, fs = pair(oracle, boxes, bc, ph, options="push_ghosts=0" if name.endswith("exchange-per-pass") else "incremental_residual=0" if name.endswith("whole-level-residuals") else None)
+    # default: two sweeps per launch on the box levels (suhmo_gsrb.hip:k_gsrb_box_m) and AMRProlongS_2 of a box in one workgroup;
+    # a-launch-per-colour-pass: the paths they replace (a launch per colour pass that pushes its side cells; gather, BC and prolongation as three launches)
+    opts = {"exchange-per-pass": "push_ghosts=0,fused_relax=0", "whole-level-residuals": "incremental_residual=0", "a-launch-per-colour-pass": "fused_relax=0,fused_prolong=0"}
+    options = next((v for k, v in opts.items() if name.endswith(k)), None)
+    O, G, fs = pair(oracle, boxes, bc, ph, options=options)
     O.vcycle(sp); G.vcycle(sp)
     same_levels(O, G, oracle, ((oracle.F_PHI, F_PHI), (oracle.F_BX, F_BX)), "vcycle")
     no, ho = O.solve(sp)
@@ -112,6 +117,7 @@ def test_hier_vcycle_and_solve_bitwise(oracle, name, boxes, bc, ph, monkeypatch)
     same_levels(O, G, oracle, ((oracle.F_RES, F_RES),), "solve residual", skip_covered=True)
     if streams:
         assert (G.coarse.get_option("residual_in_relax_launches") > 0) == (not name.endswith("own-residual-pass"))
+    assert (G.get_option("fused_relax_launches") > 0) == (options is None or "fused_relax=0" not in options)
     O.close(); G.close()
 
 

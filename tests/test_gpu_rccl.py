@@ -13,7 +13,9 @@ from suhmo_amd import synthetic as sy
 pytestmark = pytest.mark.gpu
 
 
-def make_pair(nx, ny, f, ph, halo):
+def make_pair(nx, ny, f, ph, halo, transport="rccl"):
+    """transport "ipc": the strip's halo rows go through the peer-direct transport (suhmo_ipc.hip: the pack kernel stores into the receive
+    slots -- the strip's own, being its own neighbour -- and publishes a number the unpack kernel waits for), reductions through RCCL"""
     from suhmo_amd import level, multigpu
     bc = sy.CONV_BC
     W = level.HipLevel(nx, ny, f["dx"], f["dy"], bc, ph, 0.0, -1.0, 32)
@@ -21,25 +23,28 @@ def make_pair(nx, ny, f, ph, halo):
     S = level.HipLevel(nx, ny, f["dx"], f["dy"], bc, ph, 0.0, -1.0, 32, j0=0, ny_global=2 * ny, halo_rows=halo)
     S.set_inputs(f)
     multigpu.attach_rccl(S, 0, 1, periodic_y=True)
+    if transport == "ipc":
+        multigpu.ipc_attach(S, 0, 1, True, [multigpu.ipc_export(S)])
     return W, S
 
 
 @pytest.mark.parametrize("nx,ny,variant,halo", [(64, 32, "simple", 4), (2048, 1024, "fused", 4), (128, 64, "simple", 16), (2048, 1024, "fused", 16), (256, 128, "simple", 24), (2048, 1024, "fused", 24)])
-def test_self_neighbour_vcycle_bitwise(nx, ny, variant, halo, monkeypatch):
+@pytest.mark.parametrize("transport", ["rccl", "ipc"])
+def test_self_neighbour_vcycle_bitwise(nx, ny, variant, halo, transport, monkeypatch):
     from suhmo_amd import capi
     from suhmo_amd.level import F_PHI, F_RES, F_BX, F_BY
     from test_gpu_strips import wrap_ghosts
     if variant == "fused":
         monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "100000")
     f = wrap_ghosts(sy.shmip_fields(nx, ny, ly=2.0e4 * ny / nx * 5), sy.CONV_BC)
-    W, S = make_pair(nx, ny, f, sy.A3_PHYS, halo)
+    W, S = make_pair(nx, ny, f, sy.A3_PHYS, halo, transport)
     sp = dict(sy.SOLVER_DEFAULT)
     for L in (W, S):
         L.build_mg_coefficients()
         L.vcycle(sp)
         L.vcycle(sp)
         L.residual()
-    assert capi.lib().suhmo_level_rccl_exchanges(S.h) > 10
+    assert (capi.lib().suhmo_level_ipc_exchanges(S.h) if transport == "ipc" else capi.lib().suhmo_level_rccl_exchanges(S.h)) > 10
     for fid in (F_PHI, F_RES, F_BX):
         assert np.array_equal(W.get(fid), S.get(fid)), fid
     assert np.array_equal(W.get(F_BY)[:-1], S.get(F_BY)[:-1])
@@ -54,12 +59,13 @@ def test_self_neighbour_vcycle_bitwise(nx, ny, variant, halo, monkeypatch):
 
 
 @pytest.mark.parametrize("impl", [0, 1])
-@pytest.mark.parametrize("direct", [0, 1])
+@pytest.mark.parametrize("direct", [0, 1, "ipc"])
 def test_self_neighbour_timestep_bitwise(impl, direct, monkeypatch):
     """suhmo_level_timestep on a strip coupled through the native RCCL hooks (its own periodic neighbour): gap-height,
     melt-rate, gradient and RHS halos, the MAX all-reduced Picard test and -- impl = 1 -- the implicit gap-height solver
     sharing the strip's communicator; must equal the whole periodic level bit for bit."""
-    monkeypatch.setenv("SUHMO_RCCL_DIRECT", str(direct))      # 1: halo rows sent from / received into the canvas itself
+    ipc = direct == "ipc"                                     # the halo rows peer-direct (suhmo_ipc.hip), the implicit gap solver's handle sharing the arena
+    monkeypatch.setenv("SUHMO_RCCL_DIRECT", "0" if ipc else str(direct))      # 1: halo rows sent from / received into the canvas itself
     from suhmo_amd import model, multigpu
     from test_gpu_timestep import perturbed_state
     from test_gpu_timestep_strips import wrap, NAMES
@@ -73,6 +79,8 @@ def test_self_neighbour_timestep_bitwise(impl, direct, monkeypatch):
     for G in (W, S):
         G.set_state(st)
     multigpu.attach_rccl(S.level, 0, 1, periodic_y=True)
+    if ipc:
+        multigpu.ipc_attach(S.level, 0, 1, True, [multigpu.ipc_export(S.level)])
     # the strip believes the level has 2 ny rows, so its own moulin integrals would differ: it gets W's source term
     W.moulin_source(pos, sg, fl, 1.0)
     from suhmo_amd import level as lv

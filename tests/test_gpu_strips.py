@@ -27,45 +27,25 @@ def split_fields(f, j0, ny):
 wrap_ghosts = sy.wrap_ghosts
 
 
-def new_stream():
-    """a HIP stream of its own for a thread rank (the peer-direct transport waits inside kernels: two ranks must not share the NULL stream)"""
-    import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
-    st = C.c_void_p()
-    assert hip.hipStreamCreateWithFlags(C.byref(st), 1) == 0          # hipStreamNonBlocking
-    return st.value
-
-
-def run_strips(world, f, bc, ph, alpha, beta, body, halo=4, max_box=32, ipc=False):
-    """body(level, rank) runs on every rank-thread; returns list of per-rank results.  ipc: the halo rows travel peer-direct
-    (suhmo_amd/csrc/suhmo_ipc.hip: stores into the neighbour's slots + flag words; threads of one process need no mapping), reductions through
-    the thread transport's hooks"""
+def run_strips(world, f, bc, ph, alpha, beta, body, halo=4, max_box=32):
+    """body(level, rank) runs on every rank-thread; returns list of per-rank results"""
     from suhmo_amd import level, multigpu
     ny_tot = f["ny"]
     assert ny_tot % world == 0
     ny = ny_tot // world
     tr = multigpu.ThreadTransport(world)
     out, err = [None] * world, []
-    blobs = [None] * world
 
     def worker(rank):
         try:
             j0 = rank * ny
             G = level.HipLevel(f["nx"], ny, f["dx"], f["dy"], bc, ph, alpha, beta, max_box, j0=j0,
-                               ny_global=ny_tot, halo_rows=halo, stream=new_stream() if ipc else None)
+                               ny_global=ny_tot, halo_rows=halo)
             G.set_inputs(split_fields(f, j0, ny))
             ex = multigpu.StripExchanger(G, tr, rank, world, bool(bc["periodic"][1]))
             ex.exchange_static()
-            if ipc:
-                blobs[rank] = multigpu.ipc_export(G)
-                tr.barrier.wait()
-                multigpu.ipc_attach(G, rank, world, bool(bc["periodic"][1]), blobs)
-                tr.barrier.wait()
             out[rank] = body(G, rank)
             G.synchronize()
-            if ipc:
-                assert G.rccl_exchanges() > 0               # the halo rows went peer-direct
-                tr.barrier.wait()                           # nobody frees its arena while a neighbour may still store into it
         except Exception as e:  # pragma: no cover
             import traceback
             traceback.print_exc()
@@ -123,28 +103,16 @@ def test_strips_gsrb_and_operators(case, variant, halo, monkeypatch):
 
 @pytest.mark.parametrize("world,halo,fused", [(2, 4, 0), (4, 4, 0), (2, 16, 0), (4, 9, 0), (2, 16, 1), (4, 12, 1), (2, 24, 0), (2, 24, 1), (4, 24, 1), (2, 1, 0),
                                               (2, 24, "no-tile"), (4, 12, "no-tile"), (2, 24, "rhs-exchanged"), (2, 24, "copy-readback"),
-                                              (2, 16, "overlap"), (4, 12, "overlap"), (2, 16, "no-overlap"), (2, 24, "fused-restriction"), (4, 12, "fused-restriction"),
-                                              (2, 24, "ipc"), (2, 4, "ipc"), (2, 24, "ipc-streaming"), (2, 16, "ipc-overlap")])
+                                              (2, 16, "overlap"), (4, 12, "overlap"), (2, 16, "no-overlap"), (2, 24, "fused-restriction"), (4, 12, "fused-restriction")])
 def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
     """strips of 2 / 4 ranks against the oracle's whole level, bitwise.  Halo >= 10 rows: the tile kernel relaxes the strips
     (halo rows advanced redundantly), R phi + RES travel together and the halo rows' right-hand side is computed locally; the
     named variants keep the paths they replace covered (colour passes, exchanged RHS, copy + synchronise read-back).
     "overlap": streaming kernel with chunks tall enough that the halo exchange travels on the second stream while the inner
     chunks relax, the two end chunks after it (what a 4096^2 strip does); "no-overlap": the same launches, exchange first.
-    "ipc...": the halo rows travel peer-direct (suhmo_ipc.hip: the pack kernel stores into the neighbour's receive slots, the unpack kernel
-    waits on a flag word; every rank on a stream of its own), on the tile kernel, on the streaming kernel, and overlapped with the
-    relaxation of the inner chunks (overlap_halo = 1: a stream-ordered transport).  Two thread ranks only: HIP multiplexes the streams of ONE
-    process onto a few hardware queues, and a kernel that waits for another rank's kernel must not share a queue with it; three and four
-    ranks run as processes (tests/test_gpu_multiproc.py)"""
+    (The peer-direct transport, whose kernels wait for the neighbour's kernels, is tested where ranks have queues of their own: as a strip that
+    is its own neighbour, tests/test_gpu_rccl.py, and as processes, tests/test_gpu_multiproc.py.)"""
     from suhmo_amd import level as lv
-    ipc = isinstance(fused, str) and fused.startswith("ipc")
-    if fused == "ipc-streaming":
-        fused = 1
-    elif fused == "ipc-overlap":
-        monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "4000")
-        monkeypatch.setenv("SUHMO_GSRB_TILE", "0")
-        monkeypatch.setenv("SUHMO_FUSED_HC", "32")
-        monkeypatch.setenv("SUHMO_OVERLAP_HALO", "1")
     if fused == 1:
         monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "4000")     # fused K=2 launches down to 64 x 64 strips
         monkeypatch.setenv("SUHMO_GSRB_TILE", "0")
@@ -173,8 +141,8 @@ def test_strips_vcycle_and_solve(world, halo, fused, oracle, monkeypatch):
         return (p1, G.get(lv.F_PHI), n, hist, G.ndepth, G.get_option("overlapped_launches"), G.get_option("rhs_in_streaming_launches"),
                 G.get_option("residual_in_relax_launches"), G.get(lv.F_RES))
 
-    parts = run_strips(world, f, bc, ph, 0.0, -1.0, body, halo=halo, max_box=64, ipc=ipc)
-    if fused in ("overlap", "ipc-overlap"):
+    parts = run_strips(world, f, bc, ph, 0.0, -1.0, body, halo=halo, max_box=64)
+    if fused == "overlap":
         assert all(p[5] > 0 for p in parts), [p[5] for p in parts]
     elif fused == "no-overlap":
         assert all(p[5] == 0 for p in parts)

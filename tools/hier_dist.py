@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--partition-min-cells", type=int, default=0,
                     help="> 0: hierarchy option partition_min_cells (levels of boxes with at least that many cells per rank are relaxed by their owners; "
                          "default: the library's 350000 for the largest level, i.e. cfg5's small levels stay replicated)")
+    ap.add_argument("--dense", action="store_true",
+                    help="level 1 = the middle half of the domain tiled with 64^2 boxes (a LARGE level of boxes: what the owner-computes partition is for), "
+                         "the finer levels around the moulins inside it")
     a = ap.parse_args()
     for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29536")):
         os.environ.setdefault(k, v)
@@ -43,6 +46,17 @@ def main():
     n0 = nb // world
     bc, ph, mm, mo = sy.multimoulins_setup()
     boxes = sy.boxes_around(mo["positions"], nb, nb, a.levels, 1.0e5, 1.0e5)
+    if a.dense:                                     # level-1 cells [nb/2, 3 nb/2)^2 in boxes of 64^2; deeper levels: the moulins' boxes that lie properly inside
+        lo, hi = nb // 2, 3 * nb // 2
+        dense = [(i, j, i + 63, j + 63) for j in range(lo, hi, 64) for i in range(lo, hi, 64)]
+        keep = [dense]
+        for l, bl in enumerate(boxes[1:], start=2):
+            f = 1 << (l - 1)
+            keep.append([b for b in bl if b[0] >= (lo + 4) * f and b[1] >= (lo + 4) * f and b[2] < (hi - 4) * f and b[3] < (hi - 4) * f])
+            if not keep[-1]:
+                keep.pop()
+                break
+        boxes = keep
     sts = sy.mountain_amrm_states(nb, nb, boxes)
     dx, dy = sts[0][0]["dx"], sts[0][0]["dy"]
     H = model.HipHierModel(nb, n0, dx, dy, bc, ph, mm, boxes, max_box=MB, device=dev, j0=rank * n0, ny_global=nb, halo_rows=4 if world > 1 else 1,
