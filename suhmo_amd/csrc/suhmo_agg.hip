@@ -15,7 +15,7 @@
 #include "suhmo_common.h"
 #include <algorithm>
 
-int suhmo_copy_ghosts(suhmo_level *L, int depth, int field, hipStream_t st);      // suhmo_level.hip
+int suhmo_copy_ghosts(suhmo_level *L, int depth, int field, hipStream_t st);      // suhmo_bcoef.hip
 
 namespace {
 constexpr int MAXE = 40;

@@ -222,8 +222,8 @@ __global__ void k_amr_average_faces(DV vf, const double *__restrict__ bxf, const
 }
 }  // namespace
 
-int suhmo_grad_cc(suhmo_level *L, int depth, hipStream_t st);          // suhmo_level.hip: k_gradcc (+ k_grad_ghosts)
-int suhmo_re_bcoef_unfused(suhmo_level *L, int depth, hipStream_t st);  // suhmo_level.hip: k_grad_ghosts, k_re, k_bcoef_faces
+int suhmo_grad_cc(suhmo_level *L, int depth, hipStream_t st);          // suhmo_bcoef.hip: k_gradcc (+ k_grad_ghosts)
+int suhmo_re_bcoef_unfused(suhmo_level *L, int depth, hipStream_t st);  // suhmo_bcoef.hip: k_grad_ghosts, k_re, k_bcoef_faces
 
 extern "C" int suhmo_amr2_cf_interp(suhmo_level_t *C, suhmo_level_t *F, int field_f, int field_c, suhmo_stream_t s)
 {
@@ -462,7 +462,7 @@ extern "C" int suhmo_amr2_solve(suhmo_level_t *C, suhmo_level_t *F, const suhmo_
 // Rank strips: a rank holds of every level the rows of its own physical slab, so levels[l] may be NULL on a rank the
 // patch of level l does not reach.  Such a rank still runs the coarse half of every pair it has a coarse strip of (the
 // FAS right-hand side res' + L(phi) replaces rhs on the WHOLE coarse level) and every base-level collective.
-int suhmo_apply_and_residual(suhmo_level *L, int depth, hipStream_t st);      // suhmo_level.hip: LPHI and RES = rhs - LPHI in one pass
+int suhmo_apply_and_residual(suhmo_level *L, int depth, hipStream_t st);      // suhmo_ops.hip: LPHI and RES = rhs - LPHI in one pass
 namespace {
 // head of level l: coarse-fine ghosts from level l-1.  A rank with a strip of level l-1 but none of level l MIRRORS the
 // halo demand the interpolation puts on level l-1, so that every rank of that level's communicator runs the same sequence

@@ -240,20 +240,20 @@ struct SwapGuard {
     void back() { if (armed) { std::swap(*a, *b); armed = false; suhmo_fp_changed(); } }
     ~SwapGuard() { back(); }
 };
-int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st);      // suhmo_level.hip
-int suhmo_restrict_both(suhmo_level *L, int depth, hipStream_t st);                 // suhmo_level.hip
+int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st);      // suhmo_bcoef.hip
+int suhmo_restrict_both(suhmo_level *L, int depth, hipStream_t st);                 // suhmo_ops.hip
 bool suhmo_gsrb_can_fuse_prolong(suhmo_level *L, int depth, int sweeps);           // suhmo_gsrb.hip
-int suhmo_level_residual_and_norm(suhmo_level *L, double *out, hipStream_t st);                   // suhmo_level.hip
-int suhmo_level_norm_from_partials(suhmo_level *L, int np, double *out, hipStream_t st);   // suhmo_level.hip
+int suhmo_level_residual_and_norm(suhmo_level *L, double *out, hipStream_t st);                   // suhmo_ops.hip
+int suhmo_level_norm_from_partials(suhmo_level *L, int np, double *out, hipStream_t st);   // suhmo_ops.hip
 bool suhmo_gsrb_can_fuse_rhs(suhmo_level *L, int depth, int sweeps, bool rhs_local = false);               // suhmo_gsrb.hip
 int suhmo_launch_gsrb(suhmo_level *L, int depth, int sweeps, int tail, hipStream_t st, int *restricted = nullptr);   // suhmo_gsrb.hip; tail = halo
                                                     // rows worth keeping valid at exit; restricted: see there
 void suhmo_level_drop_graphs(suhmo_level *L);                                     // suhmo_fas.hip
-int suhmo_ensure_phi_halo(suhmo_level *L, int depth, int need, hipStream_t st);      // suhmo_level.hip
-int suhmo_fas_coarse_rhs(suhmo_level *L, int depth, hipStream_t st, int hcomp = 0);  // suhmo_level.hip; hcomp: halo rows that get rhs computed too
+int suhmo_ensure_phi_halo(suhmo_level *L, int depth, int need, hipStream_t st);      // suhmo_ops.hip
+int suhmo_fas_coarse_rhs(suhmo_level *L, int depth, hipStream_t st, int hcomp = 0);  // suhmo_ops.hip; hcomp: halo rows that get rhs computed too
 // Result of a reduction whose last kernel was launched with suhmo_host_slot(L): 8 bytes back on the host.
 struct HostSlot { double *val; unsigned long long *flag; unsigned long long seq; };
-HostSlot suhmo_host_slot(suhmo_level *L);                                           // suhmo_level.hip; call right before the launch
+HostSlot suhmo_host_slot(suhmo_level *L);                                           // suhmo_ops.hip; call right before the launch
 int suhmo_readback(suhmo_level *L, hipStream_t st, double *out, double *out2 = nullptr);   // after the launch; out2: a second value (scratch[1] / val[1])
 // n = 1 or 2 values a reduction's last kernel left in L->scratch[0..n-1] (launched with suhmo_reduce_slot(L)): combined over the ranks of a
 // strip partition (op 0 MAX, 1 SUM) and brought to the host.  On a strip with the native transport the all-reduce runs on the device, on
@@ -266,7 +266,7 @@ __device__ __forceinline__ void suhmo_publish(const HostSlot &h, double v)
     h.val[0] = v;
     __hip_atomic_store(h.flag, h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-int suhmo_build_mg_coefficients(suhmo_level *L, bool with_faces, hipStream_t st);   // suhmo_level.hip
+int suhmo_build_mg_coefficients(suhmo_level *L, bool with_faces, hipStream_t st);   // suhmo_bcoef.hip
 // suhmo_agg.hip: agglomeration of the coarse multigrid depths of a rank strip
 void suhmo_ipc_release(suhmo_level *L);   // suhmo_ipc.hip
 int suhmo_ipc_batch(suhmo_level *L, int open, hipStream_t st);

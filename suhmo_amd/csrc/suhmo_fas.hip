@@ -46,7 +46,7 @@ static int rows_after_prolong(int dep, int num_smooth)
     for (int d = 1; d <= dep; d++) tail_post = (2 * num_smooth + tail_post + 1) / 2;
     return 2 * num_smooth + tail_post;
 }
-int suhmo_prolong_with_halo(suhmo_level *L, int depth, hipStream_t st);     // suhmo_level.hip
+int suhmo_prolong_with_halo(suhmo_level *L, int depth, hipStream_t st);     // suhmo_ops.hip
 
 static int fas_cycle(suhmo_level *L, int dep, const suhmo_solver_params_t *sp, int nd, suhmo_stream_t s)
 {

@@ -117,13 +117,14 @@ int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool h
 // exchange before each, bit for bit; a launch reads canvases no workgroup of the launch writes (PHI -> PHI2, then PHI2 -> PHI).
 #define BOXG 4
 #define BOXT 16            // a workgroup takes a 16 x 16 tile of its box (24 x 24 with the halo: the redundant updates buy 16 times the workgroups of one per box)
+#define BOXNT 320          // threads: one cell of EACH colour per thread (288 of the 576 positions of a full image per colour)
 template <bool HAS_ALPHA>
-__global__ __launch_bounds__(256) void k_gsrb_box_m(const DV *__restrict__ vt, const FP *__restrict__ ft, const int2 *__restrict__ halo, const int *__restrict__ hbase,
-                                                    suhmo_phys_t ph, int fsrc, int fdst, int npass)
+__global__ __launch_bounds__(BOXNT) void k_gsrb_box_m(const DV *__restrict__ vt, const FP *__restrict__ ft, const int2 *__restrict__ halo, const int *__restrict__ hbase,
+                                                      suhmo_phys_t ph, int fsrc, int fdst, int npass)
 {
     constexpr int LWmax = BOXT + 2 * BOXG;
     __shared__ double pl[LWmax * LWmax];
-    __shared__ int own[LWmax * LWmax], offs[LWmax * LWmax];
+    __shared__ int own[LWmax * LWmax];
     const int k = blockIdx.y, tid = threadIdx.x;
     const DV v = vt[k];
     const int tiles_x = (v.nx + BOXT - 1) / BOXT, tiles_y = (v.ny + BOXT - 1) / BOXT;
@@ -131,45 +132,75 @@ __global__ __launch_bounds__(256) void k_gsrb_box_m(const DV *__restrict__ vt, c
     const int tj = blockIdx.x / tiles_x, ti = blockIdx.x - tj * tiles_x;
     const int x0 = ti * BOXT, y0 = tj * BOXT;                          // the tile's first cell in the box = its halo's first position in the extended box
     const int tw = min(BOXT, v.nx - x0), th = min(BOXT, v.ny - y0);
-    const int LW = tw + 2 * BOXG, LH = th + 2 * BOXG, EW = v.nx + 2 * BOXG;
+    const int LW = tw + 2 * BOXG, LH = th + 2 * BOXG, EW = v.nx + 2 * BOXG, HW = (LW + 1) / 2;
     const int2 *__restrict__ hk = halo + hbase[k];
-    for (int q = tid; q < LW * LH; q += 256) {
+    const FP &fk = ft[k];
+    // A thread keeps ONE position of each colour of the tile's image through all passes (slot c: (i + j) & 1 == c, global indices; the colour
+    // of a position follows from where the image lies, a periodic image keeps its parity), with everything about it that does not change: the
+    // cell's box and offset, its coefficients, how far from the tile it lies.  A pass runs the slot of its colour: no lane idles for its colour.
+    // One load phase of three dependent steps: the plan entry -> the box's view and field pointers (its own box: none) -> head and coefficients.
+    const int par0 = (v.i0 + x0 - BOXG + v.j0 + y0 - BOXG) & 1;          // colour of the image's position (0, 0)
+    int cq[2], cb[2], co[2], cd[2];                // position in the image (-1: none), box (-1: not advanced), canvas offset, distance from the tile
+    double c_rhs[2], c_bxW[2], c_bxE[2], c_byS[2], c_byN[2], c_B[2], c_Pi[2], c_zb[2], c_mk[2], c_at[2];
+    int2 hq[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        cq[c] = -1; hq[c] = int2{-1, 0};
+        if (tid < LH * HW) {
+            const int lj = tid / HW, li = 2 * (tid - lj * HW) + ((lj + par0 + c) & 1);
+            if (li < LW) { cq[c] = lj * LW + li; hq[c] = hk[(y0 + lj) * EW + x0 + li]; }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int q = cq[c];
+        cb[c] = -1; co[c] = 0; cd[c] = 0;
+        c_rhs[c] = c_bxW[c] = c_bxE[c] = c_byS[c] = c_byN[c] = c_B[c] = c_Pi[c] = c_zb[c] = c_mk[c] = c_at[c] = 0.0;
+        if (q < 0) continue;
+        const int b = hq[c].x, off = hq[c].y;
+        own[q] = b;
+        if (b < 0) { pl[q] = 0.0; continue; }
         const int lj = q / LW, li = q - lj * LW;
-        const int2 h = hk[(y0 + lj) * EW + x0 + li];
-        own[q] = h.x; offs[q] = h.y;
-        pl[q] = h.x >= 0 ? ft[h.x].f[fsrc][h.y] : 0.0;
+        const int dx = li < BOXG ? BOXG - li : (li >= BOXG + tw ? li - (BOXG + tw - 1) : 0), dy = lj < BOXG ? BOXG - lj : (lj >= BOXG + th ? lj - (BOXG + th - 1) : 0);
+        const int d = max(dx, dy);
+        const FP &fb = b == k ? fk : ft[b];
+        if (d >= BOXG) { pl[q] = fb.f[fsrc][off]; continue; }        // (the outermost ring is only read)
+        const int Pb = b == k ? v.P : vt[b].P;
+        cb[c] = b; co[c] = off; cd[c] = d;
+        pl[q] = fb.f[fsrc][off];
+        c_rhs[c] = fb.f[SUHMO_F_RHS][off];
+        c_bxW[c] = fb.f[SUHMO_F_BX][off]; c_bxE[c] = fb.f[SUHMO_F_BX][off + 1];
+        c_byS[c] = fb.f[SUHMO_F_BY][off]; c_byN[c] = fb.f[SUHMO_F_BY][off + Pb];
+        c_B[c] = fb.f[SUHMO_F_B][off]; c_Pi[c] = fb.f[SUHMO_F_PI][off]; c_zb[c] = fb.f[SUHMO_F_ZB][off]; c_mk[c] = fb.f[SUHMO_F_MASK][off];
+        c_at[c] = HAS_ALPHA ? v.alpha * fb.f[SUHMO_F_ACOEF][off] : v.alpha;      // (alpha, beta, the cell sizes and the BC data are the level's: every box's view has them)
     }
     __syncthreads();
-    const FP &fk = ft[k];
     for (int m = 0; m < npass; m++) {
-        const int pass = m & 1, reach = npass - 1 - m;                   // cells within `reach` of the tile are advanced by this pass
-        const int RW = tw + 2 * reach, RH = th + 2 * reach, o0 = BOXG - reach;
-        for (int r = tid; r < RW * RH; r += 256) {
-            const int rj = r / RW, ri = r - rj * RW;
-            const int q = (o0 + rj) * LW + (o0 + ri);
-            const int b = own[q];
-            if (b < 0) continue;
-            const int off = offs[q];
-            const DV &vb = b == k ? v : vt[b];
-            const int j = off / vb.P - vb.gy, i = off - (j + vb.gy) * vb.P - SUHMO_XOFF;
-            if ((i + vb.i0 + j + vb.j0 + pass) & 1) continue;          // the colour of this pass (global indices; a periodic image keeps its parity)
-            const FP &fb = b == k ? fk : ft[b];
-            const double *__restrict__ psrc = fb.f[fsrc];
+        const int u = m & 1, reach = npass - 1 - m;                      // the pass advances the cells of colour u within `reach` of the tile
+        const int b = u ? cb[1] : cb[0];
+        if (b >= 0 && (u ? cd[1] : cd[0]) <= reach) {
+            const int q = u ? cq[1] : cq[0], off = u ? co[1] : co[0];
             const double c = pl[q];
             // a neighbour that is a cell of the level: its current value; else what the cell's own box holds there (coarse-fine ghost / physical BC)
-            const double w = own[q - 1] >= 0 ? pl[q - 1] : phiW(vb, psrc, off, i, c, false);
-            const double e = own[q + 1] >= 0 ? pl[q + 1] : phiE(vb, psrc, off, i, c, false);
-            const double s = own[q - LW] >= 0 ? pl[q - LW] : phiS(vb, psrc, off, j, c, false);
-            const double n = own[q + LW] >= 0 ? pl[q + LW] : phiN(vb, psrc, off, j, c, false);
-            const double bxW = fb.f[SUHMO_F_BX][off], bxE = fb.f[SUHMO_F_BX][off + 1];
-            const double byS = fb.f[SUHMO_F_BY][off], byN = fb.f[SUHMO_F_BY][off + vb.P];
+            double w, e, s, n;
+            if (own[q - 1] >= 0 && own[q + 1] >= 0 && own[q - LW] >= 0 && own[q + LW] >= 0) { w = pl[q - 1]; e = pl[q + 1]; s = pl[q - LW]; n = pl[q + LW]; }
+            else {
+                const DV &vb = b == k ? v : vt[b];
+                const double *__restrict__ psrc = (b == k ? fk : ft[b]).f[fsrc];
+                const int j = off / vb.P - vb.gy, i = off - (j + vb.gy) * vb.P - SUHMO_XOFF;
+                w = own[q - 1] >= 0 ? pl[q - 1] : phiW(vb, psrc, off, i, c, false);
+                e = own[q + 1] >= 0 ? pl[q + 1] : phiE(vb, psrc, off, i, c, false);
+                s = own[q - LW] >= 0 ? pl[q - LW] : phiS(vb, psrc, off, j, c, false);
+                n = own[q + LW] >= 0 ? pl[q + LW] : phiN(vb, psrc, off, j, c, false);
+            }
+            const double rhs = u ? c_rhs[1] : c_rhs[0], bxW = u ? c_bxW[1] : c_bxW[0], bxE = u ? c_bxE[1] : c_bxE[0], byS = u ? c_byS[1] : c_byS[0], byN = u ? c_byN[1] : c_byN[0];
+            const double at = u ? c_at[1] : c_at[0];
             double nl, dnl;
-            nl_terms(ph, c, fb.f[SUHMO_F_B][off], fb.f[SUHMO_F_PI][off], fb.f[SUHMO_F_ZB][off], fb.f[SUHMO_F_MASK][off], nl, dnl);
-            const double aterm = HAS_ALPHA ? vb.alpha * fb.f[SUHMO_F_ACOEF][off] : vb.alpha;
-            const double lofphi = lofphi_cell(vb, aterm, c, e, w, n, s, bxE, bxW, byN, byS, nl);
-            const double lam = lambda_cell(vb, aterm, bxE, bxW, byN, byS);
+            nl_terms(ph, c, u ? c_B[1] : c_B[0], u ? c_Pi[1] : c_Pi[0], u ? c_zb[1] : c_zb[0], u ? c_mk[1] : c_mk[0], nl, dnl);
+            const double lofphi = lofphi_cell(v, at, c, e, w, n, s, bxE, bxW, byN, byS, nl);
+            const double lam = lambda_cell(v, at, bxE, bxW, byN, byS);
             const double denom = 1.0e-16 + lam + dnl;                      // ...OpF.ChF:154
-            pl[q] = c + (fb.f[SUHMO_F_RHS][off] - lofphi) / denom;         // :156 (a cell of one colour reads cells of the other only: in place)
+            pl[q] = c + (rhs - lofphi) / denom;                            // :156 (a cell of one colour reads cells of the other only: in place)
         }
         __syncthreads();
     }
@@ -177,12 +208,12 @@ __global__ __launch_bounds__(256) void k_gsrb_box_m(const DV *__restrict__ vt, c
     // fine-fine ones are not read by this kernel and are refreshed by the next exchange
     const double *__restrict__ psrc = fk.f[fsrc];
     double *__restrict__ pdst = fk.f[fdst];
-    for (int q = tid; q < tw * th; q += 256) {
+    for (int q = tid; q < tw * th; q += BOXNT) {
         const int jj = q / tw, ii = q - jj * tw;
         pdst[cidx(v, x0 + ii, y0 + jj)] = pl[(BOXG + jj) * LW + BOXG + ii];
     }
     if (blockIdx.x == 0)
-        for (int q = tid; q < 2 * (v.nx + 2) + 2 * v.ny; q += 256) {
+        for (int q = tid; q < 2 * (v.nx + 2) + 2 * v.ny; q += BOXNT) {
             int ii, jj;
             if (q < v.nx + 2) { ii = q - 1; jj = -1; }
             else if (q < 2 * (v.nx + 2)) { ii = q - (v.nx + 2) - 1; jj = v.ny; }
@@ -197,8 +228,8 @@ int suhmo_multi_gsrb_box(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_
 {
     if (m.nbox <= 0) return 0;
     const dim3 grd(((m.maxnx + BOXT - 1) / BOXT) * ((m.maxny + BOXT - 1) / BOXT), m.nbox);
-    if (has_alpha) hipLaunchKernelGGL(k_gsrb_box_m<true>, grd, dim3(256), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass);
-    else hipLaunchKernelGGL(k_gsrb_box_m<false>, grd, dim3(256), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass);
+    if (has_alpha) hipLaunchKernelGGL(k_gsrb_box_m<true>, grd, dim3(BOXNT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass);
+    else hipLaunchKernelGGL(k_gsrb_box_m<false>, grd, dim3(BOXNT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -28,12 +28,12 @@
 #include <map>
 #include <string>
 
-int suhmo_grad_cc(suhmo_level *L, int depth, hipStream_t st);          // suhmo_level.hip
+int suhmo_grad_cc(suhmo_level *L, int depth, hipStream_t st);          // suhmo_bcoef.hip
 int suhmo_re_bcoef_unfused(suhmo_level *L, int depth, hipStream_t st);
 int suhmo_re_cells(suhmo_level *L, int depth, hipStream_t st);
 int suhmo_copy_ghosts(suhmo_level *L, int depth, int field, hipStream_t st);
 int suhmo_gsrb_colour_pass(suhmo_level *L, int depth, int pass, hipStream_t st);   // suhmo_gsrb.hip
-int suhmo_apply_and_residual_rects(suhmo_level *L, int depth, const int4 *d_rects, int n, int maxw, int maxh, hipStream_t st);   // suhmo_level.hip
+int suhmo_apply_and_residual_rects(suhmo_level *L, int depth, const int4 *d_rects, int n, int maxw, int maxh, hipStream_t st);   // suhmo_ops.hip
 int suhmo_grad_cc_list(suhmo_level *L, int depth, const int2 *d_cells, int n, hipStream_t st);
 
 namespace {

@@ -35,7 +35,9 @@ struct IpcStrip {
     unsigned long long seq[SUHMO_MAXDEPTH + 1] = {};
     bool batching = false; SegList batch;
     unsigned long long *herr = nullptr, *herr_dev = nullptr;                   // pinned: a kernel whose wait ran out says so here
+    unsigned int *counters = nullptr;                                          // last-workgroup elections (ordinary device memory: two words per channel)
     long exchanges = 0;
+    int max_blocks = 192;                                                      // workgroups per pack / unpack launch at most (env SUHMO_IPC_BLOCKS: A/B runs)
 };
 
 // err[0]: a wait ran out; err[1..4]: which one (1 / 2 acknowledgement from lo / hi, 3 / 4 arrival from lo / hi), the number waited for, the number
@@ -77,7 +79,7 @@ __device__ __forceinline__ void st_sys(double *p, double v) { __hip_atomic_store
 __device__ __forceinline__ double ld_sys(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 // workgroup = (side, row, chunk of 1024 doubles): four loads in flight per thread, then the stores -- into the neighbour's slot when packing
 __global__ __launch_bounds__(256) void k_ipc_pack(SegList sl, unsigned long long seq, double *__restrict__ to_lo, double *__restrict__ to_hi,
-                                                  IpcFlags *mine, IpcFlags *flo, IpcFlags *fhi, unsigned long long *err, int chan)
+                                                  IpcFlags *mine, IpcFlags *flo, IpcFlags *fhi, unsigned long long *err, int chan, unsigned int *count)
 {
     __shared__ int last;
     __shared__ Seg segs[MAXSEG];
@@ -110,18 +112,18 @@ __global__ __launch_bounds__(256) void k_ipc_pack(SegList sl, unsigned long long
     __syncthreads();                                         // (the workgroup's stores are ordered before lane 0's fence by the barrier; the data
     if (threadIdx.x == 0) {                                  //  stores themselves go through to memory: st_sys)
         __threadfence_system();
-        last = atomicAdd(&mine->count[0], 1u) == gridDim.x - 1;
+        last = atomicAdd(count, 1u) == gridDim.x - 1;
     }
     __syncthreads();
     if (last && threadIdx.x == 0) {
-        mine->count[0] = 0;
+        *count = 0;
         __threadfence_system();
         if (to_lo) __hip_atomic_store(&flo->arrive[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);     // I am my lo neighbour's hi side
         if (to_hi) __hip_atomic_store(&fhi->arrive[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 __global__ __launch_bounds__(256) void k_ipc_unpack(SegList sl, unsigned long long seq, const double *__restrict__ from_lo, const double *__restrict__ from_hi,
-                                                    IpcFlags *mine, IpcFlags *flo, IpcFlags *fhi, unsigned long long *err, int chan)
+                                                    IpcFlags *mine, IpcFlags *flo, IpcFlags *fhi, unsigned long long *err, int chan, unsigned int *count)
 {
     __shared__ int last;
     __shared__ Seg segs[MAXSEG];
@@ -152,10 +154,10 @@ __global__ __launch_bounds__(256) void k_ipc_unpack(SegList sl, unsigned long lo
         if (i0 + 768 < q.w) dst[i0 + 768] = v3;
     }
     __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(&mine->count[1], 1u) == gridDim.x - 1;
+    if (threadIdx.x == 0) last = atomicAdd(count, 1u) == gridDim.x - 1;
     __syncthreads();
     if (last && threadIdx.x == 0) {
-        mine->count[1] = 0;
+        *count = 0;
         if (from_lo) __hip_atomic_store(&flo->ack[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         if (from_hi) __hip_atomic_store(&fhi->ack[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -177,9 +179,11 @@ int ipc_send(IpcStrip *S, SegList &sl, int chan, hipStream_t st)
     double *to_hi = S->hi >= 0 ? (double *)(S->remote[1] + S->slot[chan][0][q]) : nullptr;
     const double *from_lo = S->lo >= 0 ? (const double *)(S->arena + S->slot[chan][0][q]) : nullptr;
     const double *from_hi = S->hi >= 0 ? (const double *)(S->arena + S->slot[chan][1][q]) : nullptr;
-    const int nblk = std::max(1, std::min(1024, 2 * sl.nrow * sl.nch));      // bounded: a neighbour that shares the GPU (test harness) must find room while these wait
-    hipLaunchKernelGGL(k_ipc_pack, dim3(nblk), dim3(256), 0, st, sl, seq, to_lo, to_hi, mine, flo, fhi, S->herr_dev, chan);
-    hipLaunchKernelGGL(k_ipc_unpack, dim3(nblk), dim3(256), 0, st, sl, seq, from_lo, from_hi, mine, flo, fhi, S->herr_dev, chan);
+    // a bounded number of workgroups: every one ends with a fence and a vote (on a counter in ordinary device memory: votes on the fine-grained
+    // arena cost ten times as much), and a neighbour that shares the GPU (test harness) must find room while these wait
+    const int nblk = std::max(1, std::min(S->max_blocks, 2 * sl.nrow * sl.nch));
+    hipLaunchKernelGGL(k_ipc_pack, dim3(nblk), dim3(256), 0, st, sl, seq, to_lo, to_hi, mine, flo, fhi, S->herr_dev, chan, S->counters + 2 * chan);
+    hipLaunchKernelGGL(k_ipc_unpack, dim3(nblk), dim3(256), 0, st, sl, seq, from_lo, from_hi, mine, flo, fhi, S->herr_dev, chan, S->counters + 2 * chan + 1);
     HIPCHK(hipGetLastError());
     S->exchanges++;
     return 0;
@@ -246,6 +250,7 @@ static void ipc_release(suhmo_level *L)
     (void)hipDeviceSynchronize();
     for (int k = 0; k < 2; k++) if (S->mapped[k] && S->remote[k] && !(k == 1 && S->remote[1] == S->remote[0] && S->mapped[0])) (void)hipIpcCloseMemHandle(S->remote[k]);
     if (S->arena) (void)hipFree(S->arena);
+    if (S->counters) (void)hipFree(S->counters);
     if (S->herr) (void)hipHostFree(S->herr);
     delete S;
     L->ipc = nullptr; L->ipc_owner = 0;
@@ -260,6 +265,7 @@ extern "C" int suhmo_level_ipc_export(suhmo_level_t *L, void *blob128)
     if (L->ipc) { suhmo_set_error("ipc transport: already exported / attached"); return -1; }
     IpcStrip *S = new IpcStrip;
     S->ndepth = L->ndepth;
+    if (const char *e = getenv("SUHMO_IPC_BLOCKS")) S->max_blocks = std::max(1, atoi(e));
     size_t off = 0;
     for (int d = 0; d < L->ndepth; d++) {
         const DV &v = L->d[d].v;
@@ -281,6 +287,8 @@ extern "C" int suhmo_level_ipc_export(suhmo_level_t *L, void *blob128)
         if (hipMalloc((void **)&S->arena, S->bytes) != hipSuccess) { delete S; suhmo_set_error("ipc transport: arena allocation failed"); return -2; }
     }
     HIPCHK(hipMemset(S->arena, 0, S->bytes));
+    HIPCHK(hipMalloc((void **)&S->counters, 2 * (SUHMO_MAXDEPTH + 1) * sizeof(unsigned int)));
+    HIPCHK(hipMemset(S->counters, 0, 2 * (SUHMO_MAXDEPTH + 1) * sizeof(unsigned int)));
     HIPCHK(hipHostMalloc((void **)&S->herr, 64, hipHostMallocMapped | hipHostMallocCoherent));
     memset(S->herr, 0, 64);
     HIPCHK(hipHostGetDevicePointer((void **)&S->herr_dev, S->herr, 0));

@@ -232,8 +232,8 @@ static int picard_maxima(suhmo_level *L, const double *h, const double *hl, doub
 static inline double picard_quotient(double maxd, double maxHead) { return maxd == 0.0 ? 0.0 : maxd / fabs(maxHead); }
 
 // grad h (cell centred, ghosted) and Re on the ghosted level: reuses the WFlx_level kernels of
-// suhmo_level.hip (identical arithmetic: NEWMACGRAD + EdgeToCell + ExtrapGhostCells + COMPUTERE)
-int suhmo_grad_re(suhmo_level *L, int depth, hipStream_t st);      // suhmo_level.hip
+// suhmo_bcoef.hip (identical arithmetic: NEWMACGRAD + EdgeToCell + ExtrapGhostCells + COMPUTERE)
+int suhmo_grad_re(suhmo_level *L, int depth, hipStream_t st);      // suhmo_bcoef.hip
 int suhmo_grad_cc(suhmo_level *L, int depth, hipStream_t st);
 int suhmo_re_cells(suhmo_level *L, int depth, hipStream_t st);
 int suhmo_bcoef_faces(suhmo_level *L, int depth, hipStream_t st);

@@ -79,6 +79,14 @@ def test_hier_pieces_bitwise(oracle, bc, ph):
     for l in (1, 2, 3):
         O.gsrb(l, 2); G.gsrb(l, 2)
     same_levels(O, G, oracle, ((oracle.F_PHI, F_PHI),), "gsrb")
+    # sweep counts that are not a multiple of two launches of two: one launch of two passes (1 sweep), two launches + one of two passes (5 sweeps),
+    # an odd number of launches (the head comes back from the second canvas by a copy)
+    for n in (1, 5, 3):
+        for l in (1, 2, 3):
+            O.cf_interp_phi(l); G.cf_interp(l)
+            O.gsrb(l, n); G.gsrb(l, n)
+        same_levels(O, G, oracle, ((oracle.F_PHI, F_PHI),), "gsrb %d sweeps" % n)
+    assert G.get_option("fused_relax_launches") > 0
     O.close(); G.close()
 
 

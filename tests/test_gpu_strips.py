@@ -277,6 +277,31 @@ def test_strips_agglomerated_coarse_depths(world, n, agg_min_cells, expect_da, p
     assert np.array_equal(np.vstack([p[1] for p in parts]), O.get(oracle.F_PHI))
 
 
+def test_strips_agglomerate_at_the_library_default_threshold(oracle, monkeypatch):
+    """the suite switches the agglomeration off by default (tests/conftest.py); here the shipped default (agg_min_cells = 100000) decides: strips of
+    512 x 256 cells keep depth 0 (131 k cells) and run every coarser depth on the whole-level copy -- V-cycle and solve equal the oracle bit for bit"""
+    from suhmo_amd import level as lv, capi
+    monkeypatch.delenv("SUHMO_AGG_MIN_CELLS", raising=False)
+    n, world = 512, 2
+    f = wrap_ghosts(sy.shmip_fields(n, n, ly=1.0e5), sy.A3_BC)
+    sp = dict(sy.SOLVER_DEFAULT, eps=1e-10, norm_thresh=1e-13, max_iter=3, imin=4)
+
+    def body(G, rank):
+        da = capi.lib().suhmo_level_agglomerated_depth(G.h)
+        G.build_mg_coefficients()
+        n_, hist = G.solve(sp)
+        return G.get(lv.F_PHI), n_, hist, da, G.get_option("agg_min_cells")
+
+    parts = run_strips(world, f, sy.A3_BC, sy.A3_PHYS, 0.0, -1.0, body, halo=24, max_box=64)
+    assert all(p[4] == 100000 and p[3] == 1 for p in parts), [(p[3], p[4]) for p in parts]
+    O = oracle.OracleLevel(n, n, f["dx"], f["dy"], sy.A3_BC, sy.A3_PHYS, 0.0, -1.0, 64, 4)
+    O.set_inputs(f); O.build_mg_coefficients()
+    n_, hist = O.solve(sp)
+    assert all(p[1] == n_ for p in parts) and np.array_equal(parts[0][2], hist)
+    assert np.array_equal(np.vstack([p[0] for p in parts]), O.get(oracle.F_PHI))
+    O.close()
+
+
 @pytest.mark.parametrize("world,agg_min_cells,expect_da", [(2, 40000, 1), (4, 2000, 2)])
 def test_agglomeration_set_after_the_coefficient_build_and_operator_changes_reach_it(world, agg_min_cells, expect_da, oracle):
     """the agglomerated copy created AFTER suhmo_build_mg_coefficients (set_option("agg_min_cells") on a level whose environment default is

@@ -7,7 +7,7 @@ TAG=${1:-x}
 R=$GRAFT_REPO_ROOT
 mkdir -p /tmp/probe && cp -r $R/suhmo_amd $R/include $R/tools /tmp/probe/ && cd /tmp/probe/suhmo_amd/csrc || exit 1
 cp /tmp/probe/tools/probes/suhmo_gsrb_tile_probe.hip suhmo_gsrb.hip || exit 1     # (the copy may lag behind the product kernel: it is a probe, not a mirror)
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -DSUHMO_TILE_PROBE -shared suhmo_level.hip suhmo_gsrb.hip suhmo_fas.hip suhmo_step.hip suhmo_rccl.hip suhmo_amr.hip suhmo_hier.hip suhmo_b2.hip suhmo_agg.hip suhmo_ipc.hip -o libsuhmo_hip.so -ldl || exit 1
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -DSUHMO_TILE_PROBE -shared suhmo_level.hip suhmo_ops.hip suhmo_bcoef.hip suhmo_gsrb.hip suhmo_fas.hip suhmo_step.hip suhmo_rccl.hip suhmo_amr.hip suhmo_hier.hip suhmo_b2.hip suhmo_agg.hip suhmo_ipc.hip -o libsuhmo_hip.so -ldl || exit 1
 cd /tmp/probe
 for dbg in 0 2 1 9 11 13 41 105; do
   echo "SUHMO_TILE_DBG=$dbg"
