@@ -11,6 +11,22 @@ if HERE not in sys.path:
     sys.path.insert(1, HERE)          # test modules share helpers (wrap_ghosts, check_against_reference)
 
 
+def free_port():
+    """a rendezvous port OUTSIDE the kernel's ephemeral range (32768-60999): a port picked by bind(0) can be taken by an outgoing connection of
+    another process between this probe and the store's listen() (seen once: EADDRINUSE on rank 0, the other ranks waiting for it)"""
+    import random
+    import socket
+    for _ in range(200):
+        p = random.randint(20000, 29999)
+        with socket.socket() as so:
+            try:
+                so.bind(("127.0.0.1", p))
+            except OSError:
+                continue
+            return p
+    raise RuntimeError("no free rendezvous port found")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

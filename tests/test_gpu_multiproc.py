@@ -43,10 +43,8 @@ def test_two_ranks_over_nccl_bitwise(tool, args):
     from suhmo_amd import capi
     if capi.lib().suhmo_device_count() < 2:
         pytest.skip("needs two GPUs (ncclSend / ncclRecv between distinct devices)")
-    import socket
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
+    from conftest import free_port
+    port = free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
@@ -66,19 +64,20 @@ def test_two_ranks_over_nccl_bitwise(tool, args):
                                                  ("amr_shmip_dist.py", ["--case", "B5", "--steps", "6", "--check"], 2, 100000),
                                                  ("hier_dist.py", ["--base", "256", "--steps", "2", "--check"], 2, 10000),
                                                  ("hier_dist.py", ["--base", "256", "--steps", "2", "--check", "--partition-min-cells", "1"], 2, 0),
-                                                 ("hier_dist.py", ["--base", "192", "--levels", "3", "--steps", "1", "--check", "--partition-min-cells", "1"], 3, 10000)])
+                                                 ("hier_dist.py", ["--base", "192", "--levels", "3", "--steps", "1", "--check", "--partition-min-cells", "1"], 3, 10000),
+                                                 ("hier_dist.py", ["--base", "512", "--levels", "3", "--steps", "1", "--check", "--partition-min-cells", "1", "--dense"], 2, 0)])
 def test_rank_strips_as_processes(tool, args, world, agg):
     """cfg4: SHMIP B5 (100 moulins, diffusion, implicit gap-height solve) on a 3-level AMR hierarchy cut into the strips of 2
     processes, B3 single-level on 4 processes, and cfg5 (base 256^2 + 3 levels of ~65 boxes each, 63 moulins) with level 0 cut into
-    the strips of 2 processes and the boxes on both, or (--partition-min-cells 1) dealt to their owners on 2 and 3 processes (a job
+    the strips of 2 processes and the boxes on both, or (--partition-min-cells 1) dealt to their owners on 2 and 3 processes; --dense: level 1 =
+    64 boxes of 64^2 tiling the middle of a 512^2 base, so that neighbouring boxes, and fine boxes and the coarse boxes under them, have
+    different owners (ghost cells, coarse-fine stencils, windows, flux registers and averages all cross ranks) (a job
     with thousands of small collectives stays at 3 ranks: with this process, which holds a GPU context of its own by then, a fifth
     process on the card makes every synchronisation of every rank wait for its turn -- measured: 7 s alone, > 300 s inside the suite)
     (gloo, all ranks on the one GPU of the test box): every level's head, gap height and melt rate equal the single-process
     run bit for bit (the tool's --check)"""
-    import socket
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
+    from conftest import free_port
+    port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
@@ -90,13 +89,16 @@ def test_rank_strips_as_processes(tool, args, world, agg):
     logs = []
     import time
     deadline = time.time() + 300
-    for p in procs:
-        try:
-            logs.append(p.communicate(timeout=max(1.0, deadline - time.time()))[0].decode())
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            tails = [q.communicate()[0].decode()[-3000:] for q in procs]
-            pytest.fail("timed out; the ranks' output:\n" + "\n-----\n".join(tails))
+    while time.time() < deadline and any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):      # a rank died: the others would wait for it until they time out
+            time.sleep(2.0)
+            break
+        time.sleep(0.2)
+    if any(p.poll() is None for p in procs):
+        for q in procs:
+            q.kill()
+        tails = [q.communicate()[0].decode()[-3000:] for q in procs]
+        pytest.fail(("a rank failed" if any(q.returncode not in (None, 0, -9) for q in procs) else "timed out") + "; the ranks' output:\n" + "\n-----\n".join(tails))
+    logs = [p.communicate()[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-2000:] for l in logs)
     assert "BITWISE EQUAL" in logs[0]

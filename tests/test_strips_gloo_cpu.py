@@ -10,12 +10,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+from conftest import free_port  # noqa: E402
 
 
 @pytest.mark.parametrize("world,periodic", [(2, 0), (2, 1), (3, 1)])
