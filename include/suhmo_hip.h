@@ -325,9 +325,10 @@ int suhmo_level_attach_rccl(suhmo_level_t *L, const void *id128, int rank, int w
 int suhmo_level_detach_rccl(suhmo_level_t *L);
 long suhmo_level_rccl_exchanges(const suhmo_level_t *L);
 int suhmo_level_rccl_comm_count(const suhmo_level_t *L);   /* ranks the level's communicator reports (ncclCommCount); -1: not attached */
-/* ---- peer-direct halo transport (suhmo_amd/csrc/suhmo_ipc.hip; SUHMO_TRANSPORT=ipc in suhmo_amd.multigpu): a rank's pack kernel stores its
+/* ---- peer-direct halo transport (suhmo_amd/csrc/suhmo_ipc.hip; SUHMO_TRANSPORT=ipc in suhmo_amd.multigpu): a rank's exchange kernel stores its
  * edge rows straight into the neighbour's receive slots -- device memory of the neighbouring GPU mapped with hipIpcOpenMemHandle, peer
- * stores over xGMI -- and publishes a sequence number there; the neighbour's unpack kernel polls it locally and acknowledges.  What the
+ * stores over xGMI -- and publishes a sequence number there; the same launch polls the neighbour's number locally, copies its own slots
+ * into the halo rows and acknowledges (one launch per message, a flag pair per workgroup, no grid-wide step).  What the
  * reference does with MPI point-to-point inside LevelData::exchange (src/VCAMRNonLinearPoissonOp.cpp:692, 912-913) without a
  * communication kernel in between.  Two steps, both per rank: suhmo_level_ipc_export lays out and allocates the rank's arena and fills
  * `blob128` (128 bytes: the IPC handle, the process id, the address); the host carries the blobs to the neighbours (MPI_Sendrecv /

@@ -1,30 +1,32 @@
-// suhmo_ipc.hip -- peer-direct strip-halo transport: the pack kernel of a rank stores its edge rows STRAIGHT INTO THE NEIGHBOUR'S
+// suhmo_ipc.hip -- peer-direct strip-halo transport: the exchange kernel of a rank stores its edge rows STRAIGHT INTO THE NEIGHBOUR'S
 // receive slots (device memory of the neighbouring GPU mapped with hipIpcOpenMemHandle, peer stores over xGMI) and publishes a sequence
-// number there; the neighbour's unpack kernel polls that number in its own memory, copies the slot into its halo rows and acknowledges.
+// number there; the same launch then polls the neighbour's number in its own memory, copies its slots into its halo rows and acknowledges.
 // Replaces, for the halo rows, what the reference does with MPI point-to-point inside LevelData::exchange
 // (src/VCAMRNonLinearPoissonOp.cpp:692, 912-913) and what suhmo_rccl.hip does with pack -> ncclGroup{Send, Recv} -> unpack: no
-// communication kernel, none of RCCL's own memsets and copies, two launches per exchange instead of three and a dozen small operations.
+// communication kernel, none of RCCL's own memsets and copies, ONE launch per exchange instead of three and a dozen small operations.
 // Reductions and all-gathers stay with whatever transport the level is attached to (RCCL natively).
 //
 // Per rank ONE arena (fine-grained device memory, one IPC handle): per multigrid depth two receive slots (double buffering) for each
-// side, and a block of flag words:
-//   arrive[side]   written by the neighbour on that side: number of its last message that is complete in my slot
-//   ack[side]      written by the neighbour on that side: number of MY last message it has copied out of ITS slot (frees the slot)
-// All polling is local; everything remote is a store.  Message n of a depth uses slot n & 1 and may be packed once the neighbour has
+// side, and a block of flag words, one PER WORKGROUP of the exchange launch (k_ipc_exchange, below):
+//   arrive[side][b]   written by workgroup b of the neighbour on that side: number of its last message whose pieces b are complete in my slot
+//   ack[side][b]      written by workgroup b of the neighbour on that side: number of MY last message whose pieces b it has copied out of ITS
+//                     slot (frees them)
+// All polling is local; everything remote is a store.  Message n of a depth uses slot n & 1 and may be stored once the neighbour has
 // acknowledged message n - 2.  Every wait is bounded (about 3 s): a neighbour that never answers raises an error word the next
-// exchange reports, instead of hanging the queue.  Kernels that wait are at most 128 workgroups, so the neighbour's kernels find room
-// even when two ranks share one GPU (the test harness).  One process per GPU is the deployment; ranks that are THREADS of one process work as
+// exchange reports, instead of hanging the queue.  Launches that wait are at most 512 workgroups of 256 threads, so the neighbour's kernels
+// find room even when two ranks share one GPU (the test harness).  One process per GPU is the deployment; ranks that are THREADS of one process work as
 // long as every rank's stream has a hardware queue of its own (HIP multiplexes streams onto a few: with more than two thread ranks a waiting
-// kernel can sit in front of the kernel it waits for -- the test suite keeps thread ranks at two and runs more ranks as processes).
+// kernel can sit in front of the kernel it waits for -- the test suite runs ranks that share a GPU as processes).
 #include "suhmo_common.h"
 #include <unistd.h>
 
 namespace {
 constexpr int MAXF = 8;
-struct IpcFlags { unsigned long long arrive[2], ack[2]; unsigned int count[2]; unsigned int pad[2]; };
+constexpr int GMAX = 512;                                   // workgroups of an exchange launch at most: one arrive and one ack word per workgroup and side
+struct IpcFlags { unsigned long long arrive[2][GMAX], ack[2][GMAX]; };
 constexpr int MAXSEG = 24;
-struct Seg { double *p; int w, P, rows, pack_lo, pack_hi, unpack_lo, unpack_hi, row0; long off; };   // p: canvas address of (i = 0, j = 0); row0: first row of the list
-struct SegList { Seg e[MAXSEG]; int n, nrow, nch; };                                                 // nrow: rows of all segments; nch: 1024-double chunks of the widest row
+struct Seg { double *p; int w, P, rows, pack_lo, pack_hi, unpack_lo, unpack_hi, piece0, nch; long off; };   // p: canvas address of (i = 0, j = 0); piece0: first piece of the list; nch: pieces per row
+struct SegList { Seg e[MAXSEG]; int n, npiece; };                                                    // npiece: pieces (a row x a chunk of CHUNK doubles) of all segments, per side
 struct IpcBlob { hipIpcMemHandle_t handle; long long pid; unsigned long long ptr; unsigned long long bytes; };    // 64 + 24 bytes <= 128
 struct IpcStrip {
     int rank = 0, world = 1, lo = -1, hi = -1, ndepth = 0;
@@ -35,9 +37,9 @@ struct IpcStrip {
     unsigned long long seq[SUHMO_MAXDEPTH + 1] = {};
     bool batching = false; SegList batch;
     unsigned long long *herr = nullptr, *herr_dev = nullptr;                   // pinned: a kernel whose wait ran out says so here
-    unsigned int *counters = nullptr;                                          // last-workgroup elections (ordinary device memory: two words per channel)
+    int nblk[SUHMO_MAXDEPTH + 1][2] = {};                                      // workgroups of the last message on each slot of a channel
     long exchanges = 0;
-    int max_blocks = 192;                                                      // workgroups per pack / unpack launch at most (env SUHMO_IPC_BLOCKS: A/B runs)
+    int max_blocks = GMAX;                                                     // workgroups per exchange launch at most (env SUHMO_IPC_BLOCKS: A/B runs)
 };
 
 // err[0]: a wait ran out; err[1..4]: which one (1 / 2 acknowledgement from lo / hi, 3 / 4 arrival from lo / hi), the number waited for, the number
@@ -45,9 +47,9 @@ struct IpcStrip {
 __device__ __forceinline__ void wait_ge(const unsigned long long *p, unsigned long long v, unsigned long long *err, int what, int depth)
 {
     const long long t0 = wall_clock64();
-    if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= v) return;
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= v) return;
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;       // a wait has run out before: what is queued behind it drains at once
-    while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < v) {
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < v) {
         __builtin_amdgcn_s_sleep(4);
         if (wall_clock64() - t0 > 300000000LL) {                                           // ~3 s at 100 MHz
             if (!__hip_atomic_exchange(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
@@ -59,7 +61,7 @@ __device__ __forceinline__ void wait_ge(const unsigned long long *p, unsigned lo
 }
 // A message = a list of segments (one field of one depth each: `rows` canvas rows of w = nx + 1 doubles -- x-face rows whole -- next to the lo
 // and hi side), laid out one after the other in a slot.  A single exchange is the list of its fields, on the channel of its depth; the
-// exchanges between ex_begin and ex_end (the face coefficients of all depths) are ONE list on the batch channel: one pack and one unpack launch.
+// exchanges between ex_begin and ex_end (the face coefficients of all depths) are ONE list on the batch channel: one launch.
 // the segment table from the kernel arguments into LDS (statically indexed copies: a dynamically indexed by-value argument lands in scratch)
 __device__ __forceinline__ void seg_table(const SegList &sl, Seg *segs)
 {
@@ -67,99 +69,102 @@ __device__ __forceinline__ void seg_table(const SegList &sl, Seg *segs)
     for (int k = 0; k < MAXSEG; k++) if ((int)threadIdx.x == k && k < sl.n) segs[k] = sl.e[k];
     __syncthreads();
 }
-__device__ __forceinline__ const Seg &seg_of(const Seg *segs, int n, int row, int &r)
+__device__ __forceinline__ const Seg &seg_of(const Seg *segs, int n, int u, int &r, int &c)
 {
     int k = 0;
-    while (k + 1 < n && row >= segs[k + 1].row0) k++;
-    r = row - segs[k].row0;
+    while (k + 1 < n && u >= segs[k + 1].piece0) k++;
+    const int v = u - segs[k].piece0;
+    r = v / segs[k].nch; c = v - r * segs[k].nch;
     return segs[k];
 }
 // halo data crosses GPUs (or, in the test harness, the XCDs of one): stores that go through to memory, loads that do not stop at a cache
 __device__ __forceinline__ void st_sys(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ double ld_sys(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-// workgroup = (side, row, chunk of 1024 doubles): four loads in flight per thread, then the stores -- into the neighbour's slot when packing
-__global__ __launch_bounds__(256) void k_ipc_pack(SegList sl, unsigned long long seq, double *__restrict__ to_lo, double *__restrict__ to_hi,
-                                                  IpcFlags *mine, IpcFlags *flo, IpcFlags *fhi, unsigned long long *err, int chan, unsigned int *count)
+// ONE launch per message and NO grid-wide step in it.  Workgroup b owns the pieces u = b, b + G, ... of the message (piece = a row of a
+// segment x a chunk of CHUNK doubles) on BOTH sides, and so does workgroup b of either neighbour (the messages of two neighbours are laid
+// out alike and launched with the same G): it stores its pieces of this rank's edge rows into the neighbours' slots, waits for its own
+// stores, and publishes the message number in the neighbours' arrive[.][b]; then it polls ITS OWN arrive[.][b], copies the same pieces
+// of its own slots into the halo rows and acknowledges in the neighbours' ack[.][b] (which is what frees those pieces of the slot two
+// messages later).  A workgroup's wait depends on the neighbour's workgroup b having stored, and that one waits for nothing but an
+// acknowledgement given two messages earlier: no cycle, whatever the order workgroups are scheduled in.  The serial chain of a message is
+// load, store, flag, poll, load, store -- six memory latencies -- instead of a vote of all workgroups in each direction.
+constexpr int CHUNK = 1280, PER = CHUNK / 256;
+__device__ __forceinline__ void wait_own_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__global__ __launch_bounds__(256) void k_ipc_exchange(SegList sl, unsigned long long seq, double *__restrict__ to_lo, double *__restrict__ to_hi,
+                                                      const double *__restrict__ from_lo, const double *__restrict__ from_hi,
+                                                      IpcFlags *mine, IpcFlags *flo, IpcFlags *fhi, unsigned long long *err, int chan, int gprev)
 {
-    __shared__ int last;
     __shared__ Seg segs[MAXSEG];
     seg_table(sl, segs);
-    if (threadIdx.x == 0 && seq > 2) {                       // the slot is free once the neighbour has copied message seq - 2 out of it
-        if (to_lo) wait_ge(&mine->ack[0], seq - 2, err, 1, chan);
-        if (to_hi) wait_ge(&mine->ack[1], seq - 2, err, 2, chan);
+    const int per_side = sl.npiece, b = blockIdx.x;
+    bool first = true;
+    for (int u = b; u < per_side; u += gridDim.x) {
+        int r, c;
+        const Seg &q = seg_of(segs, sl.n, u, r, c);
+        const int i0 = c * CHUNK + threadIdx.x;
+        double v[2][PER];
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            if (!(side ? to_hi : to_lo)) continue;
+            const double *__restrict__ src = q.p + (long)((side ? q.pack_hi : q.pack_lo) + r) * q.P;
+#pragma unroll
+            for (int k = 0; k < PER; k++) v[side][k] = i0 + 256 * k < q.w ? src[i0 + 256 * k] : 0.0;
+        }
+        if (first) {                                         // the slot is free once the neighbour has copied message seq - 2 out of it: every one of the gprev
+            if (seq > 2)                                     // workgroups of THAT message (its fields, and so its pieces, may have been others)
+                for (int t = threadIdx.x; t < gprev; t += 256) {         // (both words on their way before either is looked at; normally both are there)
+                    const unsigned long long a0 = to_lo ? __hip_atomic_load(&mine->ack[0][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ~0ull;
+                    const unsigned long long a1 = to_hi ? __hip_atomic_load(&mine->ack[1][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ~0ull;
+                    if (a0 < seq - 2) wait_ge(&mine->ack[0][t], seq - 2, err, 1, chan);
+                    if (a1 < seq - 2) wait_ge(&mine->ack[1][t], seq - 2, err, 2, chan);
+                }
+            __syncthreads();
+            first = false;
+        }
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            double *slot = side ? to_hi : to_lo;
+            if (!slot) continue;
+            slot += q.off + (long)r * q.w;
+#pragma unroll
+            for (int k = 0; k < PER; k++) if (i0 + 256 * k < q.w) st_sys(slot + i0 + 256 * k, v[side][k]);
+        }
     }
-    __syncthreads();
-    const int per_side = sl.nrow * sl.nch;
-    for (int t = blockIdx.x; t < 2 * per_side; t += gridDim.x) {
-        const int side = t / per_side, u = t - side * per_side, row = u / sl.nch, c = u - row * sl.nch;
-        double *b = side ? to_hi : to_lo;
-        if (!b) continue;
-        int r;
-        const Seg &q = seg_of(segs, sl.n, row, r);
-        const double *__restrict__ src = q.p + (long)((side ? q.pack_hi : q.pack_lo) + r) * q.P;
-        double *dst = b + q.off + (long)r * q.w;
-        const int i0 = c * 1024 + threadIdx.x;
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-        if (i0 < q.w) v0 = src[i0];
-        if (i0 + 256 < q.w) v1 = src[i0 + 256];
-        if (i0 + 512 < q.w) v2 = src[i0 + 512];
-        if (i0 + 768 < q.w) v3 = src[i0 + 768];
-        if (i0 < q.w) st_sys(dst + i0, v0);
-        if (i0 + 256 < q.w) st_sys(dst + i0 + 256, v1);
-        if (i0 + 512 < q.w) st_sys(dst + i0 + 512, v2);
-        if (i0 + 768 < q.w) st_sys(dst + i0 + 768, v3);
-    }
-    __syncthreads();                                         // (the workgroup's stores are ordered before lane 0's fence by the barrier; the data
-    if (threadIdx.x == 0) {                                  //  stores themselves go through to memory: st_sys)
-        __threadfence_system();
-        last = atomicAdd(count, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (last && threadIdx.x == 0) {
-        *count = 0;
-        __threadfence_system();
-        if (to_lo) __hip_atomic_store(&flo->arrive[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);     // I am my lo neighbour's hi side
-        if (to_hi) __hip_atomic_store(&fhi->arrive[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-__global__ __launch_bounds__(256) void k_ipc_unpack(SegList sl, unsigned long long seq, const double *__restrict__ from_lo, const double *__restrict__ from_hi,
-                                                    IpcFlags *mine, IpcFlags *flo, IpcFlags *fhi, unsigned long long *err, int chan, unsigned int *count)
-{
-    __shared__ int last;
-    __shared__ Seg segs[MAXSEG];
-    seg_table(sl, segs);
+    wait_own_stores();                                       // every wave: its stores (write-through, st_sys) have been acknowledged by the memory they went to ...
+    __syncthreads();                                         // ... before lane 0 says so.  No acquire / release operations anywhere in this kernel: each one writes back or
+                                                             // invalidates a whole L2, and 512 workgroups doing that cost 100 us; what crosses ranks bypasses the caches instead
     if (threadIdx.x == 0) {
-        if (from_lo) wait_ge(&mine->arrive[0], seq, err, 3, chan);
-        if (from_hi) wait_ge(&mine->arrive[1], seq, err, 4, chan);
+        if (to_lo) __hip_atomic_store(&flo->arrive[1][b], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // I am my lo neighbour's hi side
+        if (to_hi) __hip_atomic_store(&fhi->arrive[0][b], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (from_lo) wait_ge(&mine->arrive[0][b], seq, err, 3, chan);
+        if (from_hi) wait_ge(&mine->arrive[1][b], seq, err, 4, chan);
     }
     __syncthreads();
-    const int per_side = sl.nrow * sl.nch;
-    for (int t = blockIdx.x; t < 2 * per_side; t += gridDim.x) {
-        const int side = t / per_side, u = t - side * per_side, row = u / sl.nch, c = u - row * sl.nch;
-        const double *b = side ? from_hi : from_lo;
-        if (!b) continue;
-        int r;
-        const Seg &q = seg_of(segs, sl.n, row, r);
-        double *__restrict__ dst = q.p + (long)((side ? q.unpack_hi : q.unpack_lo) + r) * q.P;
-        const double *src = b + q.off + (long)r * q.w;
-        const int i0 = c * 1024 + threadIdx.x;
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-        if (i0 < q.w) v0 = ld_sys(src + i0);
-        if (i0 + 256 < q.w) v1 = ld_sys(src + i0 + 256);
-        if (i0 + 512 < q.w) v2 = ld_sys(src + i0 + 512);
-        if (i0 + 768 < q.w) v3 = ld_sys(src + i0 + 768);
-        if (i0 < q.w) dst[i0] = v0;
-        if (i0 + 256 < q.w) dst[i0 + 256] = v1;
-        if (i0 + 512 < q.w) dst[i0 + 512] = v2;
-        if (i0 + 768 < q.w) dst[i0 + 768] = v3;
+    for (int u = b; u < per_side; u += gridDim.x) {
+        int r, c;
+        const Seg &q = seg_of(segs, sl.n, u, r, c);
+        const int i0 = c * CHUNK + threadIdx.x;
+        double v[2][PER];
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const double *slot = side ? from_hi : from_lo;
+            if (!slot) continue;
+            slot += q.off + (long)r * q.w;
+#pragma unroll
+            for (int k = 0; k < PER; k++) v[side][k] = i0 + 256 * k < q.w ? ld_sys(slot + i0 + 256 * k) : 0.0;
+        }
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            if (!(side ? from_hi : from_lo)) continue;
+            double *__restrict__ dst = q.p + (long)((side ? q.unpack_hi : q.unpack_lo) + r) * q.P;
+#pragma unroll
+            for (int k = 0; k < PER; k++) if (i0 + 256 * k < q.w) dst[i0 + 256 * k] = v[side][k];
+        }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(count, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (last && threadIdx.x == 0) {
-        *count = 0;
-        if (from_lo) __hip_atomic_store(&flo->ack[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (from_hi) __hip_atomic_store(&fhi->ack[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();                                         // (every load of the slots has returned: its value went into a store)
+    if (threadIdx.x == 0) {
+        if (from_lo) __hip_atomic_store(&flo->ack[1][b], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (from_hi) __hip_atomic_store(&fhi->ack[0][b], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -167,9 +172,13 @@ __global__ __launch_bounds__(256) void k_ipc_unpack(SegList sl, unsigned long lo
 int ipc_send(IpcStrip *S, SegList &sl, int chan, hipStream_t st)
 {
     long off = 0;
-    int row0 = 0, wmax = 1;
-    for (int k = 0; k < sl.n; k++) { sl.e[k].off = off; sl.e[k].row0 = row0; off += (long)sl.e[k].rows * sl.e[k].w; row0 += sl.e[k].rows; wmax = std::max(wmax, sl.e[k].w); }
-    sl.nrow = row0; sl.nch = (wmax + 1023) / 1024;
+    int piece0 = 0;
+    for (int k = 0; k < sl.n; k++) {
+        Seg &e = sl.e[k];
+        e.off = off; e.piece0 = piece0; e.nch = (e.w + CHUNK - 1) / CHUNK;
+        off += (long)e.rows * e.w; piece0 += e.rows * e.nch;
+    }
+    sl.npiece = piece0;
     if ((size_t)off > S->slot_cap[chan]) { suhmo_set_error("ipc transport: a message larger than the slots the arena was laid out with"); return -7; }
     const unsigned long long seq = ++S->seq[chan];
     const int q = (int)(seq & 1);
@@ -181,9 +190,10 @@ int ipc_send(IpcStrip *S, SegList &sl, int chan, hipStream_t st)
     const double *from_hi = S->hi >= 0 ? (const double *)(S->arena + S->slot[chan][1][q]) : nullptr;
     // a bounded number of workgroups: every one ends with a fence and a vote (on a counter in ordinary device memory: votes on the fine-grained
     // arena cost ten times as much), and a neighbour that shares the GPU (test harness) must find room while these wait
-    const int nblk = std::max(1, std::min(S->max_blocks, 2 * sl.nrow * sl.nch));
-    hipLaunchKernelGGL(k_ipc_pack, dim3(nblk), dim3(256), 0, st, sl, seq, to_lo, to_hi, mine, flo, fhi, S->herr_dev, chan, S->counters + 2 * chan);
-    hipLaunchKernelGGL(k_ipc_unpack, dim3(nblk), dim3(256), 0, st, sl, seq, from_lo, from_hi, mine, flo, fhi, S->herr_dev, chan, S->counters + 2 * chan + 1);
+    const int nblk = std::max(1, std::min(S->max_blocks, sl.npiece));
+    const int gprev = S->nblk[chan][q];                      // workgroups of message seq - 2 (same slot)
+    S->nblk[chan][q] = nblk;
+    hipLaunchKernelGGL(k_ipc_exchange, dim3(nblk), dim3(256), 0, st, sl, seq, to_lo, to_hi, from_lo, from_hi, mine, flo, fhi, S->herr_dev, chan, gprev);
     HIPCHK(hipGetLastError());
     S->exchanges++;
     return 0;
@@ -250,7 +260,6 @@ static void ipc_release(suhmo_level *L)
     (void)hipDeviceSynchronize();
     for (int k = 0; k < 2; k++) if (S->mapped[k] && S->remote[k] && !(k == 1 && S->remote[1] == S->remote[0] && S->mapped[0])) (void)hipIpcCloseMemHandle(S->remote[k]);
     if (S->arena) (void)hipFree(S->arena);
-    if (S->counters) (void)hipFree(S->counters);
     if (S->herr) (void)hipHostFree(S->herr);
     delete S;
     L->ipc = nullptr; L->ipc_owner = 0;
@@ -265,7 +274,7 @@ extern "C" int suhmo_level_ipc_export(suhmo_level_t *L, void *blob128)
     if (L->ipc) { suhmo_set_error("ipc transport: already exported / attached"); return -1; }
     IpcStrip *S = new IpcStrip;
     S->ndepth = L->ndepth;
-    if (const char *e = getenv("SUHMO_IPC_BLOCKS")) S->max_blocks = std::max(1, atoi(e));
+    if (const char *e = getenv("SUHMO_IPC_BLOCKS")) S->max_blocks = std::max(1, std::min(GMAX, atoi(e)));
     size_t off = 0;
     for (int d = 0; d < L->ndepth; d++) {
         const DV &v = L->d[d].v;
@@ -279,7 +288,7 @@ extern "C" int suhmo_level_ipc_export(suhmo_level_t *L, void *blob128)
         S->slot_cap[L->ndepth] = cap;
         for (int side = 0; side < 2; side++) for (int sl = 0; sl < 2; sl++) { S->slot[L->ndepth][side][sl] = off; off += (cap * sizeof(double) + 255) & ~(size_t)255; }
     }
-    for (int d = 0; d <= L->ndepth; d++) { S->flags[d] = off; off += 256; }
+    for (int d = 0; d <= L->ndepth; d++) { S->flags[d] = off; off += (sizeof(IpcFlags) + 255) & ~(size_t)255; }
     S->bytes = off;
     // fine-grained: stores of a peer and the flag words behind them must be visible to a running kernel of the owner
     if (hipExtMallocWithFlags((void **)&S->arena, S->bytes, hipDeviceMallocFinegrained) != hipSuccess) {
@@ -287,8 +296,6 @@ extern "C" int suhmo_level_ipc_export(suhmo_level_t *L, void *blob128)
         if (hipMalloc((void **)&S->arena, S->bytes) != hipSuccess) { delete S; suhmo_set_error("ipc transport: arena allocation failed"); return -2; }
     }
     HIPCHK(hipMemset(S->arena, 0, S->bytes));
-    HIPCHK(hipMalloc((void **)&S->counters, 2 * (SUHMO_MAXDEPTH + 1) * sizeof(unsigned int)));
-    HIPCHK(hipMemset(S->counters, 0, 2 * (SUHMO_MAXDEPTH + 1) * sizeof(unsigned int)));
     HIPCHK(hipHostMalloc((void **)&S->herr, 64, hipHostMallocMapped | hipHostMallocCoherent));
     memset(S->herr, 0, 64);
     HIPCHK(hipHostGetDevicePointer((void **)&S->herr_dev, S->herr, 0));
