@@ -8,9 +8,8 @@
 // ------------------------------------------------------------------ bCoef update (WFlx_level)
 // step 1: cell-centred gradient = EdgeToCell(NEWMACGRAD) (util/Gradient.cpp:96-127, :623;
 // util/GradientF.ChF:57-70)
-__device__ __forceinline__ void d_gradcc_at(const DV &v, const FP &fp, int hasMask, int i, int j)
+__device__ __forceinline__ void d_gradcc_val(const DV &v, const FP &fp, int hasMask, int i, int j, double &gx, double &gy)
 {
-    if (i >= v.nx || j >= v.ny) return;
     const double *__restrict__ phi = fp.f[SUHMO_F_PHI];
     int idx = cidx(v, i, j);
     double c = phi[idx];
@@ -25,8 +24,17 @@ __device__ __forceinline__ void d_gradcc_at(const DV &v, const FP &fp, int hasMa
         if (mc || m[idx - v.P] < 1e-6) gS = 0.0;
         if (mc || m[idx + v.P] < 1e-6) gN = 0.0;
     }
-    fp.f[SUHMO_F_GRADX][idx] = 0.5 * (gW + gE);
-    fp.f[SUHMO_F_GRADY][idx] = 0.5 * (gS + gN);
+    gx = 0.5 * (gW + gE);
+    gy = 0.5 * (gS + gN);
+}
+__device__ __forceinline__ void d_gradcc_at(const DV &v, const FP &fp, int hasMask, int i, int j)
+{
+    if (i >= v.nx || j >= v.ny) return;
+    double gx, gy;
+    d_gradcc_val(v, fp, hasMask, i, j, gx, gy);
+    const int idx = cidx(v, i, j);
+    fp.f[SUHMO_F_GRADX][idx] = gx;
+    fp.f[SUHMO_F_GRADY][idx] = gy;
 }
 __device__ __forceinline__ void d_gradcc(const DV &v, const FP &fp, int hasMask)
 {
@@ -84,7 +92,45 @@ __global__ void k_grad_ghosts_m(const DV *__restrict__ vt, const FP *__restrict_
 {
     d_grad_ghosts(vt[blockIdx.z], ft[blockIdx.z].f[SUHMO_F_GRADX], ft[blockIdx.z].f[SUHMO_F_GRADY]);
 }
+// steps 1 + 2 of every box of a level in ONE launch: the thread of a cell on a physical side of its box also writes the ghost cell beyond it,
+// from the gradient of the neighbour the extrapolation (or the periodic wrap) reads, evaluated a second time: d_grad_ghosts' expressions on the
+// same values (boxes of AMR levels are at least two cells wide: block_factor 2)
+__global__ __launch_bounds__(256) void k_gradcc_ghosts_m(const DV *__restrict__ vt, const FP *__restrict__ ft, int hasMask)
+{
+    const DV &v = vt[blockIdx.z];
+    const FP &fp = ft[blockIdx.z];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= v.nx || j >= v.ny) return;
+    double gx, gy, ox, oy;
+    d_gradcc_val(v, fp, hasMask, i, j, gx, gy);
+    const int idx = cidx(v, i, j);
+    double *__restrict__ GX = fp.f[SUHMO_F_GRADX], *__restrict__ GY = fp.f[SUHMO_F_GRADY];
+    GX[idx] = gx; GY[idx] = gy;
+    if (i == 0 && !v.cfx[0]) {
+        d_gradcc_val(v, fp, hasMask, v.per[0] ? v.nx - 1 : 1, j, ox, oy);
+        GX[idx - 1] = v.per[0] ? ox : 2.0 * gx - ox; GY[idx - 1] = v.per[0] ? oy : 2.0 * gy - oy;
+    }
+    if (i == v.nx - 1 && !v.cfx[1]) {
+        d_gradcc_val(v, fp, hasMask, v.per[0] ? 0 : v.nx - 2, j, ox, oy);
+        GX[idx + 1] = v.per[0] ? ox : 2.0 * gx - ox; GY[idx + 1] = v.per[0] ? oy : 2.0 * gy - oy;
+    }
+    if (j == 0 && !v.ext[0]) {
+        d_gradcc_val(v, fp, hasMask, i, v.per[1] ? v.ny - 1 : 1, ox, oy);
+        GX[idx - v.P] = v.per[1] ? ox : 2.0 * gx - ox; GY[idx - v.P] = v.per[1] ? oy : 2.0 * gy - oy;
+    }
+    if (j == v.ny - 1 && !v.ext[1]) {
+        d_gradcc_val(v, fp, hasMask, i, v.per[1] ? 0 : v.ny - 2, ox, oy);
+        GX[idx + v.P] = v.per[1] ? ox : 2.0 * gx - ox; GY[idx + v.P] = v.per[1] ? oy : 2.0 * gy - oy;
+    }
+}
 // step 3: COMPUTERE on the ghosted box (src/AmrHydro.cpp:1495-1505, src/AmrHydroF.ChF:92-109)
+__device__ __forceinline__ double d_re_val(const FP &fp, const suhmo_phys_t &ph, int idx)
+{
+    double gx = fp.f[SUHMO_F_GRADX][idx], gy = fp.f[SUHMO_F_GRADY][idx], B = fp.f[SUHMO_F_B][idx];
+    double sg = sqrt(gx * gx + gy * gy);
+    double discr = 1.0 + 4.0 * ph.omega * (B * B * B * ph.grav * sg) / (12.0 * ph.nu * ph.nu);
+    return (-1.0 + sqrt(discr)) / (2.0 * ph.omega);
+}
 __device__ __forceinline__ void d_re(const DV &v, const FP &fp, suhmo_phys_t ph)
 {
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1, j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
@@ -92,10 +138,7 @@ __device__ __forceinline__ void d_re(const DV &v, const FP &fp, suhmo_phys_t ph)
     bool xo = (i < 0 || i >= v.nx), yo = (j < 0 || j >= v.ny);
     if (xo && yo) return;                                      // corner ghosts are never read
     int idx = cidx(v, i, j);
-    double gx = fp.f[SUHMO_F_GRADX][idx], gy = fp.f[SUHMO_F_GRADY][idx], B = fp.f[SUHMO_F_B][idx];
-    double sg = sqrt(gx * gx + gy * gy);
-    double discr = 1.0 + 4.0 * ph.omega * (B * B * B * ph.grav * sg) / (12.0 * ph.nu * ph.nu);
-    fp.f[SUHMO_F_RE][idx] = (-1.0 + sqrt(discr)) / (2.0 * ph.omega);
+    fp.f[SUHMO_F_RE][idx] = d_re_val(fp, ph, idx);
 }
 __global__ __launch_bounds__(256) void k_re(DV v, FP fp, suhmo_phys_t ph)
 {
@@ -141,6 +184,28 @@ __global__ __launch_bounds__(256) void k_bcoef_faces(DV v, FP fp, suhmo_phys_t p
 __global__ __launch_bounds__(256) void k_bcoef_faces_m(const DV *__restrict__ vt, const FP *__restrict__ ft, suhmo_phys_t ph)
 {
     d_bcoef_faces(vt[blockIdx.z], ft[blockIdx.z], ph);
+}
+// steps 3 + 4 of every box of a level in ONE launch: the thread of a position of the ghosted box stores Re there (d_re) and the two faces on
+// its low sides (d_bcoef_faces), with the Re of the two cells across those faces evaluated a second time from the same gradient and gap height
+__global__ __launch_bounds__(256) void k_re_bcoef_m(const DV *__restrict__ vt, const FP *__restrict__ ft, suhmo_phys_t ph)
+{
+    const DV &v = vt[blockIdx.z];
+    const FP &fp = ft[blockIdx.z];
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1, j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+    if (i > v.nx || j > v.ny) return;
+    const bool xo = (i < 0 || i >= v.nx), yo = (j < 0 || j >= v.ny);
+    if (xo && yo) return;                                      // corner ghosts are never read
+    const int idx = cidx(v, i, j);
+    const double Rc = d_re_val(fp, ph, idx);
+    fp.f[SUHMO_F_RE][idx] = Rc;
+    if (i < 0 || j < 0) return;                                // (faces (i, j), 0 <= i <= nx, 0 <= j <= ny)
+    const double *__restrict__ B = fp.f[SUHMO_F_B], *__restrict__ m = fp.f[SUHMO_F_MASK];
+    if (j < v.ny)
+        fp.f[SUHMO_F_BX][idx] = bcoef_face(ph, Rc, d_re_val(fp, ph, idx - 1), B[idx], B[idx - 1], m[idx], m[idx - 1], i + v.i0 == 0 || i + v.i0 == v.nxg);
+    if (i < v.nx) {
+        const int jg = j + v.j0;
+        fp.f[SUHMO_F_BY][idx] = bcoef_face(ph, Rc, d_re_val(fp, ph, idx - v.P), B[idx], B[idx - v.P], m[idx], m[idx - v.P], jg == 0 || jg == v.nyg);
+    }
 }
 
 // ---- fused WFlx_level: one kernel = steps 1-4 above on a tile staged in LDS.
@@ -719,6 +784,11 @@ extern "C" int suhmo_level_build_mg_coefficients(suhmo_level_t *L, suhmo_stream_
 int suhmo_multi_grad_cc(const suhmo_multi &m, int hasMask, hipStream_t st)
 {
     if (m.nbox <= 0) return 0;                       // a rank that owns no box of the level
+    if (m.merged) {
+        hipLaunchKernelGGL(k_gradcc_ghosts_m, grid_m(m), BLK2D, 0, st, m.dv, m.fp, hasMask);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k_gradcc_m, grid_m(m), BLK2D, 0, st, m.dv, m.fp, hasMask);
     int n = 2 * m.maxny + 2 * m.maxnx;
     hipLaunchKernelGGL(k_grad_ghosts_m, dim3((n + 255) / 256, 1, m.nbox), dim3(256), 0, st, m.dv, m.fp);
@@ -738,6 +808,15 @@ int suhmo_multi_bcoef_faces(const suhmo_multi &m, const suhmo_phys_t &ph, hipStr
 {
     if (m.nbox <= 0) return 0;                       // a rank that owns no box of the level
     hipLaunchKernelGGL(k_bcoef_faces_m, grid_m(m, 1, 1), BLK2D, 0, st, m.dv, m.fp, ph);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int suhmo_multi_re_bcoef(const suhmo_multi &m, const suhmo_phys_t &ph, hipStream_t st)
+{
+    if (m.nbox <= 0) return 0;
+    if (!m.merged) { int rc = suhmo_multi_re(m, ph, st); return rc ? rc : suhmo_multi_bcoef_faces(m, ph, st); }
+    hipLaunchKernelGGL(k_re_bcoef_m, grid_m(m, 2, 2), BLK2D, 0, st, m.dv, m.fp, ph);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -120,7 +120,7 @@ int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool h
 #define BOXNT 320          // threads: one cell of EACH colour per thread (288 of the 576 positions of a full image per colour)
 template <bool HAS_ALPHA>
 __global__ __launch_bounds__(BOXNT) void k_gsrb_box_m(const DV *__restrict__ vt, const FP *__restrict__ ft, const int2 *__restrict__ halo, const int *__restrict__ hbase,
-                                                      suhmo_phys_t ph, int fsrc, int fdst, int npass)
+                                                      suhmo_phys_t ph, int fsrc, int fdst, int npass, int bcg)
 {
     constexpr int LWmax = BOXT + 2 * BOXG;
     __shared__ double pl[LWmax * LWmax];
@@ -208,28 +208,39 @@ __global__ __launch_bounds__(BOXNT) void k_gsrb_box_m(const DV *__restrict__ vt,
     // fine-fine ones are not read by this kernel and are refreshed by the next exchange
     const double *__restrict__ psrc = fk.f[fsrc];
     double *__restrict__ pdst = fk.f[fdst];
+    // bcg: the ghost cells beyond the box's PHYSICAL sides get the homogeneous boundary condition of the final values as well (levelGSRB's closing
+    // fill, src/AMRNonLinearPoissonOp.cpp:757-759; d_fill_ghosts' expression on the same operand) instead of a launch of their own; the caller sets
+    // it only when no box of the level is its own periodic neighbour (that ghost would be another tile's cell)
+    const bool gW = bcg && !v.cfx[0] && !v.per[0], gE = bcg && !v.cfx[1] && !v.per[0], gS = bcg && !v.ext[0] && !v.per[1], gN = bcg && !v.ext[1] && !v.per[1];
     for (int q = tid; q < tw * th; q += BOXNT) {
-        const int jj = q / tw, ii = q - jj * tw;
-        pdst[cidx(v, x0 + ii, y0 + jj)] = pl[(BOXG + jj) * LW + BOXG + ii];
+        const int jj = q / tw, ii = q - jj * tw, gi = x0 + ii, gj = y0 + jj, idx = cidx(v, gi, gj);
+        const double c = pl[(BOXG + jj) * LW + BOXG + ii];
+        pdst[idx] = c;
+        if (gW && gi == 0) pdst[idx - 1] = phiW(v, pdst, idx, gi, c, true);
+        if (gE && gi == v.nx - 1) pdst[idx + 1] = phiE(v, pdst, idx, gi, c, true);
+        if (gS && gj == 0) pdst[idx - v.P] = phiS(v, pdst, idx, gj, c, true);
+        if (gN && gj == v.ny - 1) pdst[idx + v.P] = phiN(v, pdst, idx, gj, c, true);
     }
     if (blockIdx.x == 0)
         for (int q = tid; q < 2 * (v.nx + 2) + 2 * v.ny; q += BOXNT) {
             int ii, jj;
-            if (q < v.nx + 2) { ii = q - 1; jj = -1; }
-            else if (q < 2 * (v.nx + 2)) { ii = q - (v.nx + 2) - 1; jj = v.ny; }
-            else if (q < 2 * (v.nx + 2) + v.ny) { ii = -1; jj = q - 2 * (v.nx + 2); }
-            else { ii = v.nx; jj = q - 2 * (v.nx + 2) - v.ny; }
+            bool filled;                                                // (a side cell the loop above writes)
+            if (q < v.nx + 2) { ii = q - 1; jj = -1; filled = gS && ii >= 0 && ii < v.nx; }
+            else if (q < 2 * (v.nx + 2)) { ii = q - (v.nx + 2) - 1; jj = v.ny; filled = gN && ii >= 0 && ii < v.nx; }
+            else if (q < 2 * (v.nx + 2) + v.ny) { ii = -1; jj = q - 2 * (v.nx + 2); filled = gW; }
+            else { ii = v.nx; jj = q - 2 * (v.nx + 2) - v.ny; filled = gE; }
+            if (filled) continue;
             const int idx = cidx(v, ii, jj);
             pdst[idx] = psrc[idx];
         }
 }
 // 2 sweeps (4 colour passes, or `npass` of them) of every box of the level in one launch, fsrc -> fdst
-int suhmo_multi_gsrb_box(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, const void *halo, const int *hbase, int fsrc, int fdst, int npass, hipStream_t st)
+int suhmo_multi_gsrb_box(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, const void *halo, const int *hbase, int fsrc, int fdst, int npass, int bc_ghosts, hipStream_t st)
 {
     if (m.nbox <= 0) return 0;
     const dim3 grd(((m.maxnx + BOXT - 1) / BOXT) * ((m.maxny + BOXT - 1) / BOXT), m.nbox);
-    if (has_alpha) hipLaunchKernelGGL(k_gsrb_box_m<true>, grd, dim3(BOXNT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass);
-    else hipLaunchKernelGGL(k_gsrb_box_m<false>, grd, dim3(BOXNT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass);
+    if (has_alpha) hipLaunchKernelGGL(k_gsrb_box_m<true>, grd, dim3(BOXNT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass, bc_ghosts);
+    else hipLaunchKernelGGL(k_gsrb_box_m<false>, grd, dim3(BOXNT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass, bc_ghosts);
     HIPCHK(hipGetLastError());
     return 0;
 }

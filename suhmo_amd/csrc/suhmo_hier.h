@@ -15,15 +15,17 @@ int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, su
 
 // every box of a level in ONE launch (blockIdx.z = box): device tables of the boxes' views and field pointers
 struct suhmo_multi { const DV *dv; const FP *fp; int nbox, maxnx, maxny; double *red; /* reduction scratch, 64 nbox + 16 doubles */
+                     int merged; /* hierarchy option merged_launches: gradient + its ghosts, Re + bCoef in one launch each */
                      const void *push; const int *pbase; /* fine-fine ghost cells a side cell feeds (int2 {box, offset}), first entry of every box */ };
 int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int pass, hipStream_t st, bool push = false);      // suhmo_gsrb.hip
-int suhmo_multi_gsrb_box(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, const void *halo, const int *hbase, int fsrc, int fdst, int npass, hipStream_t st);   // suhmo_gsrb.hip: 2 sweeps per launch
+int suhmo_multi_gsrb_box(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, const void *halo, const int *hbase, int fsrc, int fdst, int npass, int bc_ghosts, hipStream_t st);   // suhmo_gsrb.hip: 2 sweeps per launch (bc_ghosts: + the closing homogeneous ghost fill)
 int suhmo_multi_fill_ghosts(const suhmo_multi &m, int field, int homog, hipStream_t st);                                  // suhmo_ops.hip ...
 int suhmo_multi_apply(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int mode, hipStream_t st);            // mode 0: LPHI, 1: RES, 3: both
 int suhmo_apply_and_residual(suhmo_level *L, int depth, hipStream_t st);                                                  // LPHI and RES = rhs - LPHI in one pass
 int suhmo_multi_grad_cc(const suhmo_multi &m, int hasMask, hipStream_t st);
 int suhmo_multi_re(const suhmo_multi &m, const suhmo_phys_t &ph, hipStream_t st);
 int suhmo_multi_bcoef_faces(const suhmo_multi &m, const suhmo_phys_t &ph, hipStream_t st);
+int suhmo_multi_re_bcoef(const suhmo_multi &m, const suhmo_phys_t &ph, hipStream_t st);          // the two above, one launch when m.merged
 int suhmo_multi_coef_ghosts(const suhmo_multi &m, int field, hipStream_t st);
 int suhmo_multi_axby(const suhmo_multi &m, int fd, int fx, int fy, double a, double b, hipStream_t st);
 int suhmo_multi_fas_enter(const suhmo_multi &m, hipStream_t st);   // RHS0 <- RHS, RHS <- RES + LPHI, PHIOLD <- PHI in one launch
@@ -31,6 +33,10 @@ int suhmo_multi_fas_leave(const suhmo_multi &m, hipStream_t st);   // RHS <- RHS
 int suhmo_multi_copy(const suhmo_multi &m, int fd, int fs, hipStream_t st);                                               // valid cells + ghost ring
 int suhmo_multi_copy_between(const suhmo_multi &dst, const suhmo_multi &src, const int *fd, const int *fs, int n, hipStream_t st);   // same boxes, two hierarchies
 int suhmo_multi_norm_max(const suhmo_multi &m, suhmo_level *slot, int field, double *out, hipStream_t st);                // max |x| over the valid cells of all boxes
+// the same in pieces, for one read-back over a whole hierarchy: first stages (partial maxima of level 0 / of a level of boxes), then one launch over all lists
+int suhmo_level_norm_max_partials(suhmo_level *L, int field, const double **partials, int *np, hipStream_t st);
+int suhmo_multi_norm_max_partials(const suhmo_multi &m, int field, const double **partials, int *np, hipStream_t st);
+int suhmo_norm_max_of_lists(suhmo_level *slot, const double *const *partials, const int *np, int cnt, double *out, hipStream_t st);
 int suhmo_hier_multi_(suhmo_hier *H, int l, hipStream_t st, suhmo_multi *m);       // l >= 1
 int suhmo_hier_ensure_(suhmo_hier *H, int l, int field);                            // allocate a field on every box of a level
 void suhmo_hier_invalidate_(suhmo_hier *H);                                         // an entry point outside suhmo_hier.hip: the caller may have loaded new data

@@ -134,6 +134,7 @@ struct HLev {
     std::vector<FP> h_fp; FP *d_fp = nullptr; DV *d_dv = nullptr;
     unsigned long tab_epoch = 0;                                  // suhmo_fp_epoch() the tables were last compared at
     unsigned long long ensured = 0;                               // fields every box is known to have
+    int self_wrap = -1;                                            // some box of the level is its own periodic neighbour (-1: not looked at yet)
     double *d_red = nullptr; int maxnx = 0, maxny = 0;            // reduction scratch (64 nbox + 16 doubles), largest box
     // ---- owner computes (rank strips, creation option partition_min_cells): boxes own[r] .. own[r+1] belong to rank r (LoadBalance,
     // src/AmrHydro.cpp:4283, 4929).  EVERY pass over the level runs on the owner's boxes only; plans are executed by the owner of the cell
@@ -192,6 +193,7 @@ struct suhmo_hier {
     unsigned long base_fused_ver = 0;
     bool fused_relax = true;                               // option fused_relax: two sweeps per launch on levels of boxes (0: a launch per colour pass)
     long n_fused_relax = 0;                                // launches of that kind (read-only option fused_relax_launches)
+    bool merged_launches = true;                           // option merged_launches: both kinds of ghost cell in one launch, one norm read-back per hierarchy, ... (0: a launch each)
     bool fused_prolong = true;                             // option fused_prolong: AMRProlongS_2 of a box in one workgroup (0: gather, BC, prolongation as three launches)
     bool incremental = true;                               // option incremental_residual
     long part_min_cells = 350000;                          // creation option partition_min_cells: when the largest level >= 1 holds at least this many cells
@@ -239,21 +241,21 @@ __device__ __forceinline__ double *fptr(const FP *tab, const FP &base, int use_b
 {
     return use_base ? base.f[field] : tab[b].f[field];
 }
+__device__ __forceinline__ void d_ff(const CopyEnt &c, const FP *__restrict__ tab, int f0, int f1)
+{
+    tab[c.d.b].f[f0][c.d.off] = tab[c.s.b].f[f0][c.s.off];
+    if (f1 >= 0) tab[c.d.b].f[f1][c.d.off] = tab[c.s.b].f[f1][c.s.off];
+}
 __global__ void k_ff(const CopyEnt *__restrict__ e, int n, const FP *__restrict__ tab, int f0, int f1)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    CopyEnt c = e[t];
-    tab[c.d.b].f[f0][c.d.off] = tab[c.s.b].f[f0][c.s.off];
-    if (f1 >= 0) tab[c.d.b].f[f1][c.d.off] = tab[c.s.b].f[f1][c.s.off];
+    d_ff(e[t], tab, f0, f1);
 }
 // [Chombo] QuadCFInterp (oracle/amrm.c:cf_interp)
-__global__ void k_cf(const CfEnt *__restrict__ e, int n, const FP *__restrict__ ftab, int ff0, const FP *__restrict__ ctab, FP cbase,
-                     int use_base, int fc0, int ff1, int fc1)
+__device__ __forceinline__ void d_cf(const CfEnt &q, const FP *__restrict__ ftab, int ff0, const FP *__restrict__ ctab, const FP &cbase,
+                                     int use_base, int fc0, int ff1, int fc1)
 {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    CfEnt q = e[t];
     const double c_s = 8.0 / 15.0, c_b = 2.0 / 3.0, c_a = -0.2;
     const double xt = q.xsign ? 0.25 : -0.25;
   for (int pass = 0; pass < (ff1 >= 0 ? 2 : 1); pass++) {          // one or two fields over the same stencils (the two gradient components)
@@ -271,6 +273,27 @@ __global__ void k_cf(const CfEnt *__restrict__ e, int n, const FP *__restrict__ 
     double *f = ftab[q.f.b].f[ff];
     f[q.f.off] = c_s * phistar + c_b * f[q.f.off + q.step] + c_a * f[q.f.off + 2 * q.step];
   }
+}
+__global__ void k_cf(const CfEnt *__restrict__ e, int n, const FP *__restrict__ ftab, int ff0, const FP *__restrict__ ctab, FP cbase,
+                     int use_base, int fc0, int ff1, int fc1)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    d_cf(e[t], ftab, ff0, ctab, cbase, use_base, fc0, ff1, fc1);
+}
+// both kinds of ghost cell of one or two fields of a level in ONE launch: the coarse-fine ghosts are interpolated from the level below and two
+// VALID cells of their own box, the fine-fine ghosts are copies of VALID cells of the neighbouring boxes -- neither reads what the other
+// writes (workgroups [0, nbcf): the cf plan, the rest: the ff plan)
+__global__ void k_cf_ff(const CfEnt *__restrict__ ce, int ncf, int nbcf, const CopyEnt *__restrict__ fe, int nff, const FP *__restrict__ ftab, int ff0,
+                        const FP *__restrict__ ctab, FP cbase, int use_base, int fc0, int ff1, int fc1)
+{
+    if ((int)blockIdx.x < nbcf) {
+        int t = blockIdx.x * blockDim.x + threadIdx.x;
+        if (t < ncf) d_cf(ce[t], ftab, ff0, ctab, cbase, use_base, fc0, ff1, fc1);
+    } else {
+        int t = (blockIdx.x - nbcf) * blockDim.x + threadIdx.x;
+        if (t < nff) d_ff(fe[t], ftab, ff0, ff1);
+    }
 }
 // [Chombo] PiecewiseLinearFillPatch (oracle/amr_step.c:or_pwl_fill)
 __global__ void k_pwl(const PwlEnt *__restrict__ e, int n, const FP *__restrict__ ftab, int ff, const FP *__restrict__ ctab, FP cbase,
@@ -1070,7 +1093,7 @@ int multi_of(suhmo_hier *H, int l, hipStream_t st, suhmo_multi &m)
     int rc = refresh_tables(H, l, st); if (rc) return rc;
     HLev &V = H->lev[l];
     m.dv = V.d_dv; m.fp = V.d_fp; m.nbox = (int)V.box.size(); m.maxnx = V.maxnx; m.maxny = V.maxny; m.red = V.d_red;
-    m.push = V.push.d; m.pbase = V.pbase.d;
+    m.push = V.push.d; m.pbase = V.pbase.d; m.merged = H->merged_launches;
     if (V.part) { m.dv += V.b0; m.fp += V.b0; m.nbox = V.nown; m.push = nullptr; m.pbase = nullptr; }   // owner computes: the tables from this rank's first box
     return 0;
 }
@@ -1114,6 +1137,25 @@ int hier_cf(suhmo_hier *H, int l, int ff, int fc, hipStream_t st, int ff1 = -1, 
       if (rc) return rc; }
     if ((rc = coarse_args(H, l - 1, st, ca))) return rc;
     if (V.cf.n) hipLaunchKernelGGL(k_cf, g1(V.cf.n), dim3(256), 0, st, V.cf.d, (int)V.cf.n, V.d_fp, ff, ca.tab, ca.base, ca.use_base, fc, ff1, fc1);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// hier_cf + hier_ff of the same field(s) in one launch (levels held whole by this process)
+int hier_cf_ff(suhmo_hier *H, int l, int ff, int fc, int ff1, int fc1, bool corners, hipStream_t st)
+{
+    SUHMO_TIME("QuadCFInterp::coarseFineInterp + exchange");
+    HLev &V = H->lev[l];
+    int rc;
+    CoarseArgs ca;
+    if ((rc = ensure_field(H, l, ff)) || (rc = ensure_field(H, l - 1, fc)) || (rc = refresh_tables(H, l, st))) return rc;
+    if (ff1 >= 0 && ((rc = ensure_field(H, l, ff1)) || (rc = ensure_field(H, l - 1, fc1)) || (rc = refresh_tables(H, l, st)))) return rc;
+    { const int fl[2] = {fc, fc1};
+      if (l == 1 && (rc = refresh_base(H, fl, ff1 >= 0 ? 2 : 1, st))) return rc; }
+    if ((rc = coarse_args(H, l - 1, st, ca))) return rc;
+    const DevVec<CopyEnt> &list = corners ? V.ff_all : V.ff_side;
+    const int nbcf = (int)g1(V.cf.n).x, nbff = (int)g1(list.n).x;
+    if (nbcf + nbff > 0)
+        hipLaunchKernelGGL(k_cf_ff, dim3(nbcf + nbff), dim3(256), 0, st, V.cf.d, (int)V.cf.n, nbcf, list.d, (int)list.n, V.d_fp, ff, ca.tab, ca.base, ca.use_base, fc, ff1, fc1);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1298,15 +1340,20 @@ int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
         // two sweeps per launch: a box's workgroup relaxes the box and, redundantly, the 4 cells around it that belong to its neighbours,
         // reading their canvases directly -- no exchange between the colour passes, a quarter of the launches (suhmo_gsrb.hip:k_gsrb_box_m)
         if ((rc = ensure_field(H, l, SUHMO_F_PHI2)) || (rc = multi_of(H, l, HST(s), m))) return rc;
+        if (Vf.self_wrap < 0) {                            // a box that is its own periodic neighbour: its physical ghost is another tile's cell
+            Vf.self_wrap = 0;
+            for (suhmo_level *L : Vf.box) { const DV &v = L->d[0].v; if ((v.per[0] && !v.cfx[0]) || (v.per[1] && !v.ext[0])) Vf.self_wrap = 1; }
+        }
+        const int bcg = H->merged_launches && !Vf.self_wrap;             // the closing ghost fill (:757-759) rides in the relaxation launches
         int src = SUHMO_F_PHI, dst = SUHMO_F_PHI2;
         for (int done = 0; done < sweeps; done += 2) {
             const int npass = 2 * std::min(2, sweeps - done);
-            if ((rc = suhmo_multi_gsrb_box(m, phys_of(H, l), has_alpha(H, l), Vf.halo.d, Vf.hbase.d, src, dst, npass, HST(s)))) return rc;
+            if ((rc = suhmo_multi_gsrb_box(m, phys_of(H, l), has_alpha(H, l), Vf.halo.d, Vf.hbase.d, src, dst, npass, bcg, HST(s)))) return rc;
             std::swap(src, dst);
             H->phi_ver[l]++; H->n_fused_relax++;
         }
         if (src != SUHMO_F_PHI && (rc = suhmo_multi_copy(m, SUHMO_F_PHI, SUHMO_F_PHI2, HST(s)))) return rc;     // (an odd number of launches)
-        return suhmo_multi_fill_ghosts(m, SUHMO_F_PHI, 1, HST(s));                                            // :757-759
+        return bcg ? 0 : suhmo_multi_fill_ghosts(m, SUHMO_F_PHI, 1, HST(s));                                  // :757-759
     }
     // exchange() before every colour pass (:692, :751): once here (unless the side ghosts are current), then every pass pushes
     // its new side cells into the ghost cells they feed
@@ -1362,6 +1409,12 @@ int cf_phi(suhmo_hier *H, int l, suhmo_stream_t s)
 {
     if (l == 0) return 0;
     if (H->cf_seen[l][0] == H->phi_ver[l] && H->cf_seen[l][1] == H->phi_ver[l - 1]) return 0;       // the ghosts are current
+    if (H->merged_launches && !H->lev[l].part && H->ff_seen[l] != H->phi_ver[l]) {
+        // the side ghosts between the boxes are stale as well (whoever reads the head next asks for them): both in one launch
+        int rc = hier_cf_ff(H, l, SUHMO_F_PHI, SUHMO_F_PHI, -1, -1, false, HST(s));
+        if (!rc) { H->cf_seen[l][0] = H->phi_ver[l]; H->cf_seen[l][1] = H->phi_ver[l - 1]; H->ff_seen[l] = H->phi_ver[l]; }
+        return rc;
+    }
     int rc = hier_cf(H, l, SUHMO_F_PHI, SUHMO_F_PHI, HST(s));
     if (!rc) { H->cf_seen[l][0] = H->phi_ver[l]; H->cf_seen[l][1] = H->phi_ver[l - 1]; }
     return rc;
@@ -1389,12 +1442,15 @@ int hier_update_operator(suhmo_hier *H, int l, suhmo_stream_t s)
     if (l - 1 == 0 && H->incremental) { rc = suhmo_grad_cc_list(base_of(H), 0, H->lev[1].gcells.d, (int)H->lev[1].gcells.n, HST(s)); H->n_sparse_grad++; }
     else rc = hier_grad_cc(H, l - 1, s);
     if (rc) return rc;
-    if ((rc = hier_cf(H, l, SUHMO_F_GRADX, SUHMO_F_GRADX, HST(s), SUHMO_F_GRADY, SUHMO_F_GRADY))) return rc;
-    if ((rc = hier_ff(H, l, SUHMO_F_GRADX, SUHMO_F_GRADY, true, HST(s)))) return rc;  // lvlgradH.exchange() src/AmrHydro.cpp:1490
+    if (H->merged_launches && !H->lev[l].part) {
+        if ((rc = hier_cf_ff(H, l, SUHMO_F_GRADX, SUHMO_F_GRADX, SUHMO_F_GRADY, SUHMO_F_GRADY, true, HST(s)))) return rc;
+    } else {
+        if ((rc = hier_cf(H, l, SUHMO_F_GRADX, SUHMO_F_GRADX, HST(s), SUHMO_F_GRADY, SUHMO_F_GRADY))) return rc;
+        if ((rc = hier_ff(H, l, SUHMO_F_GRADX, SUHMO_F_GRADY, true, HST(s)))) return rc;  // lvlgradH.exchange() src/AmrHydro.cpp:1490
+    }
     suhmo_multi m;
     if ((rc = multi_of(H, l, HST(s), m))) return rc;
-    if ((rc = suhmo_multi_re(m, phys_of(H, l), HST(s)))) return rc;
-    return suhmo_multi_bcoef_faces(m, phys_of(H, l), HST(s));
+    return suhmo_multi_re_bcoef(m, phys_of(H, l), HST(s));
 }
 // RES of level l-1 = rhs - [applyOpI(phi) + reflux from level l]; LPHI of level l-1 keeps the plain L(phi)
 // whole_level_follows: called from inside a V-cycle (what follows turns RES of level l-1 into a FAS right-hand side); false: the
@@ -1554,6 +1610,7 @@ extern "C" int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc
     H->push_ghosts = hier_opt(options, "push_ghosts", 1) != 0;
     H->incremental = hier_opt(options, "incremental_residual", 1) != 0;
     H->fused_prolong = hier_opt(options, "fused_prolong", 1) != 0;
+    H->merged_launches = hier_opt(options, "merged_launches", 1) != 0;
     H->fused_relax = hier_opt(options, "fused_relax", 1) != 0;
     H->part_min_cells = std::max(1L, hier_opt(options, "partition_min_cells", H->part_min_cells));
     H->nlev = nlev; H->device = base->device; H->bc = base->bc; H->base_desc = *base; H->base_desc.boxes = nullptr; H->base_desc.nbox = 0;
@@ -1754,6 +1811,7 @@ extern "C" int suhmo_hier_set_option(suhmo_hier_t *H, const char *key, long valu
         return 0;
     }
     if (!strcmp(key, "fused_prolong")) { H->fused_prolong = value != 0; if (H->gap) return suhmo_hier_set_option(H->gap, key, value); return 0; }
+    if (!strcmp(key, "merged_launches")) { H->merged_launches = value != 0; if (H->gap) return suhmo_hier_set_option(H->gap, key, value); return 0; }
     if (!strcmp(key, "fused_relax")) { H->fused_relax = value != 0; if (H->gap) return suhmo_hier_set_option(H->gap, key, value); return 0; }
     if (!strcmp(key, "push_ghosts")) {
         H->push_ghosts = value != 0;
@@ -1769,6 +1827,7 @@ extern "C" int suhmo_hier_get_option(const suhmo_hier_t *H, const char *key, lon
     ARG(H && key && value);
     if (!strcmp(key, "push_ghosts")) { *value = H->push_ghosts; return 0; }
     if (!strcmp(key, "fused_prolong")) { *value = H->fused_prolong; return 0; }
+    if (!strcmp(key, "merged_launches")) { *value = H->merged_launches; return 0; }
     if (!strcmp(key, "fused_relax")) { *value = H->fused_relax; return 0; }
     if (!strcmp(key, "fused_relax_launches")) { *value = H->n_fused_relax + (H->gap ? H->gap->n_fused_relax : 0); return 0; }
     if (!strcmp(key, "incremental_residual")) { *value = H->incremental; return 0; }
@@ -1892,6 +1951,18 @@ static int hier_residual_(suhmo_hier *H, double *norm, suhmo_stream_t s)
     if ((rc = hier_level_residual(H, top, s))) return rc;                                  // AMRResidualNF on the finest level
     for (int l = top; l >= 1; l--) if ((rc = composite_residual(H, l, s, false))) return rc;
     for (int l = top; l >= 1; l--) if ((rc = hier_avg(H, l, SUHMO_F_RES, SUHMO_F_RES, 1, 0.0, HST(s)))) return rc;
+    if (norm && H->merged_launches && !H->part && !dist_base(H)) {
+        // one process holds everything: the first stages of every level's max norm, then ONE launch over their partial maxima and one read-back
+        // (a maximum is the same in any order) instead of a reduction and a read-back per level
+        const double *lists[8];
+        int np[8];
+        if ((rc = suhmo_level_norm_max_partials(base_of(H), SUHMO_F_RES, &lists[0], &np[0], HST(s)))) return rc;
+        for (int l = 1; l <= top; l++) {
+            suhmo_multi mv;
+            if ((rc = multi_of(H, l, HST(s), mv)) || (rc = suhmo_multi_norm_max_partials(mv, SUHMO_F_RES, &lists[l], &np[l], HST(s)))) return rc;
+        }
+        return suhmo_norm_max_of_lists(base_of(H), lists, np, top + 1, norm, HST(s));
+    }
     if (norm) {
         double m = 0.0;
         if ((rc = suhmo_level_norm(base_of(H), 0, SUHMO_F_RES, 0, &m, s))) return rc;

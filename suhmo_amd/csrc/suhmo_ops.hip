@@ -845,6 +845,52 @@ int suhmo_multi_copy_between(const suhmo_multi &dst, const suhmo_multi &src, con
     HIPCHK(hipGetLastError());
     return 0;
 }
+// AMRNorm over a hierarchy in ONE read-back: the first stages of level 0 (suhmo_level_norm_partials) and of every level of boxes
+// (suhmo_multi_norm_max_partials) leave their partial maxima where they always do; one launch takes the maximum of all the lists
+// (a maximum does not care about the order) and publishes it
+constexpr int NORM_LISTS = 8;                        // levels of a hierarchy at most (suhmo_hier_create)
+struct NormLists { const double *p[NORM_LISTS]; int n[NORM_LISTS]; int cnt; };
+__global__ void k_norm_max_final_lists(NormLists nl, double *__restrict__ out, HostSlot hs)
+{
+    __shared__ double sm[256];
+    int tid = threadIdx.x;
+    double acc = 0.0;
+    for (int q = 0; q < nl.cnt; q++)
+        for (int k = tid; k < nl.n[q]; k += 256) acc = fmax(acc, nl.p[q][k]);
+    sm[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = fmax(sm[tid], sm[tid + s]); __syncthreads(); }
+    if (tid == 0) { out[0] = sm[0]; suhmo_publish(hs, sm[0]); }
+}
+int suhmo_level_norm_max_partials(suhmo_level *L, int field, const double **partials, int *np, hipStream_t st)
+{
+    Depth &D = L->d[0];
+    dim3 grd(std::min((D.v.nx + 63) / 64, 32), std::min((D.v.ny + 3) / 4, 128));
+    hipLaunchKernelGGL(k_norm_partial, grd, BLK2D, 0, st, D.v, suhmo_field(L, 0, field), 0, L->scratch + 2);
+    HIPCHK(hipGetLastError());
+    *partials = L->scratch + 2; *np = grd.x * grd.y;
+    return 0;
+}
+int suhmo_multi_norm_max_partials(const suhmo_multi &m, int field, const double **partials, int *np, hipStream_t st)
+{
+    *partials = m.red; *np = 0;
+    if (m.nbox <= 0) return 0;
+    dim3 grd(std::min((m.maxnx + 63) / 64, 4), std::min((m.maxny + 3) / 4, 16), m.nbox);
+    hipLaunchKernelGGL(k_norm_max_partial_m, grd, BLK2D, 0, st, m.dv, m.fp, field, m.red);
+    HIPCHK(hipGetLastError());
+    *np = (int)(grd.x * grd.y * grd.z);
+    return 0;
+}
+int suhmo_norm_max_of_lists(suhmo_level *slot, const double *const *partials, const int *np, int cnt, double *out, hipStream_t st)
+{
+    if (cnt > NORM_LISTS) { suhmo_set_error("internal: norm over more lists than levels"); return -4; }
+    NormLists nl;
+    nl.cnt = cnt;
+    for (int q = 0; q < cnt; q++) { nl.p[q] = partials[q]; nl.n[q] = np[q]; }
+    hipLaunchKernelGGL(k_norm_max_final_lists, dim3(1), dim3(256), 0, st, nl, slot->scratch, suhmo_host_slot(slot));
+    HIPCHK(hipGetLastError());
+    return suhmo_readback(slot, st, out);
+}
 int suhmo_multi_norm_max(const suhmo_multi &m, suhmo_level *slot, int field, double *out, hipStream_t st)
 {
     if (m.nbox <= 0) { *out = 0.0; return 0; }

@@ -94,6 +94,7 @@ def test_hier_pieces_bitwise(oracle, bc, ph):
                                               ("cut-periodic", CUT, BC, sy.CFG3_PHYS), ("union-4lev-exchange-per-pass", UNION, BC_NP, sy.CFG3_PHYS),
                                               ("union-4lev-whole-level-residuals", UNION, BC_NP, sy.CFG3_PHYS),
                                               ("union-4lev-a-launch-per-colour-pass", UNION, BC_V, MASKPH),
+                                              ("union-4lev-a-launch-per-ghost-kind", UNION, BC_NP, sy.CFG3_PHYS),
                                               ("union-4lev-base-on-the-streaming-kernel", UNION, BC_NP, sy.CFG3_PHYS),
                                               ("union-4lev-values-mask-base-on-the-streaming-kernel", UNION, BC_V, MASKPH),
                                               ("union-4lev-base-on-the-streaming-kernel-own-residual-pass", UNION, BC_NP, sy.CFG3_PHYS)],
@@ -112,8 +113,10 @@ def test_hier_vcycle_and_solve_bitwise(oracle, name, boxes, bc, ph, monkeypatch)
     # whole-level-residuals: every composite residual and coarse gradient over all of level 0 (default: the solve loop's evaluation is
     # reused by the next cycle except where level 1 was averaged down; the coarse gradient only where the interpolation reads it)
     # default: two sweeps per launch on the box levels (suhmo_gsrb.hip:k_gsrb_box_m) and AMRProlongS_2 of a box in one workgroup;
-    # a-launch-per-colour-pass: the paths they replace (a launch per colour pass that pushes its side cells; gather, BC and prolongation as three launches)
-    opts = {"exchange-per-pass": "push_ghosts=0,fused_relax=0", "whole-level-residuals": "incremental_residual=0", "a-launch-per-colour-pass": "fused_relax=0,fused_prolong=0"}
+    # a-launch-per-colour-pass: the paths they replace (a launch per colour pass that pushes its side cells; gather, BC and prolongation as three launches;
+    # merged_launches=0: a launch for either kind of ghost cell, a norm and a read-back per level, the closing ghost fill on its own)
+    opts = {"exchange-per-pass": "push_ghosts=0,fused_relax=0", "whole-level-residuals": "incremental_residual=0", "a-launch-per-colour-pass": "fused_relax=0,fused_prolong=0,merged_launches=0",
+            "a-launch-per-ghost-kind": "merged_launches=0"}
     options = next((v for k, v in opts.items() if name.endswith(k)), None)
     O, G, fs = pair(oracle, boxes, bc, ph, options=options)
     O.vcycle(sp); G.vcycle(sp)
