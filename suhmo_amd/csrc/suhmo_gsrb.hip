@@ -107,7 +107,7 @@ int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool h
 }
 
 // ---- levels that are UNIONS OF BOXES: several sweeps per launch (relaxNF, src/AMRNonLinearPoissonOp.cpp:690-750; levelGSRB :654-760).
-// A workgroup owns a box and loads it with a halo of BOXG = 4 cells -- the cells of the neighbouring boxes, taken from THEIR canvases (plan
+// A workgroup owns a tile of a box and loads it with a halo of G = 4 or 8 cells -- the cells of the neighbouring boxes, taken from THEIR canvases (plan
 // `halo`: for every position of the extended box the box that holds the cell and its canvas offset, or none) -- into LDS, advances the halo
 // cells redundantly (pass m keeps what lies within 3 - m cells of the box current) and after 2 sweeps = 4 colour passes writes the box to the
 // second canvas of the head.  What a cell reads beyond the cells of the level is what its OWN box's ghost ring says: the stored coarse-fine
@@ -115,13 +115,16 @@ int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool h
 // view -- at a re-entrant corner of the union a position is the x-ghost of one box and the y-ghost of another, and each reader gets its own.
 // Every update is d_gsrb_pass_simple's expression on the same operands in the same order, so the result is the colour passes' with an
 // exchange before each, bit for bit; a launch reads canvases no workgroup of the launch writes (PHI -> PHI2, then PHI2 -> PHI).
-#define BOXG 4
-#define BOXT 16            // a workgroup takes a 16 x 16 tile of its box (24 x 24 with the halo: the redundant updates buy 16 times the workgroups of one per box)
-#define BOXNT 320          // threads: one cell of EACH colour per thread (288 of the 576 positions of a full image per colour)
-template <bool HAS_ALPHA>
-__global__ __launch_bounds__(BOXNT) void k_gsrb_box_m(const DV *__restrict__ vt, const FP *__restrict__ ft, const int2 *__restrict__ halo, const int *__restrict__ hbase,
+#define BOXT 16            // a workgroup takes a 16 x 16 tile of its box (24 x 24 with a halo of 4: the redundant updates buy 16 times the workgroups of one per box)
+// G: the halo the launch advances through = the sweeps it can do (G = 4: two sweeps, 24 x 24 image on 320 threads; G = 8: FOUR sweeps -- a whole
+// pre- or post-smoothing of the reference's num_smooth = 4 -- on a 32 x 32 image and 512 threads: the eight passes cost less than two launches'
+// fixed parts).  Threads: one cell of EACH colour per thread.  The plan `halo` is laid out for SUHMO_BOX_HALO = 8 cells around every box.
+template <int G> struct BoxGeom { static constexpr int LW = BOXT + 2 * G, NT = ((LW * LW / 2 + 63) / 64) * 64; };
+template <bool HAS_ALPHA, int G>
+__global__ __launch_bounds__(BoxGeom<G>::NT) void k_gsrb_box_m(const DV *__restrict__ vt, const FP *__restrict__ ft, const int2 *__restrict__ halo, const int *__restrict__ hbase,
                                                       suhmo_phys_t ph, int fsrc, int fdst, int npass, int bcg)
 {
+    constexpr int BOXG = G, BOXNT = BoxGeom<G>::NT, HG = SUHMO_BOX_HALO;
     constexpr int LWmax = BOXT + 2 * BOXG;
     __shared__ double pl[LWmax * LWmax];
     __shared__ int own[LWmax * LWmax];
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(BOXNT) void k_gsrb_box_m(const DV *__restrict__ vt,
     const int tj = blockIdx.x / tiles_x, ti = blockIdx.x - tj * tiles_x;
     const int x0 = ti * BOXT, y0 = tj * BOXT;                          // the tile's first cell in the box = its halo's first position in the extended box
     const int tw = min(BOXT, v.nx - x0), th = min(BOXT, v.ny - y0);
-    const int LW = tw + 2 * BOXG, LH = th + 2 * BOXG, EW = v.nx + 2 * BOXG, HW = (LW + 1) / 2;
+    const int LW = tw + 2 * BOXG, LH = th + 2 * BOXG, EW = v.nx + 2 * HG, HW = (LW + 1) / 2;
     const int2 *__restrict__ hk = halo + hbase[k];
     const FP &fk = ft[k];
     // A thread keeps ONE position of each colour of the tile's image through all passes (slot c: (i + j) & 1 == c, global indices; the colour
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(BOXNT) void k_gsrb_box_m(const DV *__restrict__ vt,
         cq[c] = -1; hq[c] = int2{-1, 0};
         if (tid < LH * HW) {
             const int lj = tid / HW, li = 2 * (tid - lj * HW) + ((lj + par0 + c) & 1);
-            if (li < LW) { cq[c] = lj * LW + li; hq[c] = hk[(y0 + lj) * EW + x0 + li]; }
+            if (li < LW) { cq[c] = lj * LW + li; hq[c] = hk[(y0 + lj + HG - BOXG) * EW + x0 + li + HG - BOXG]; }
         }
     }
 #pragma unroll
@@ -234,13 +237,19 @@ __global__ __launch_bounds__(BOXNT) void k_gsrb_box_m(const DV *__restrict__ vt,
             pdst[idx] = psrc[idx];
         }
 }
-// 2 sweeps (4 colour passes, or `npass` of them) of every box of the level in one launch, fsrc -> fdst
+// `npass` colour passes (up to 8 = 4 sweeps) of every box of the level in one launch, fsrc -> fdst
 int suhmo_multi_gsrb_box(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, const void *halo, const int *hbase, int fsrc, int fdst, int npass, int bc_ghosts, hipStream_t st)
 {
     if (m.nbox <= 0) return 0;
     const dim3 grd(((m.maxnx + BOXT - 1) / BOXT) * ((m.maxny + BOXT - 1) / BOXT), m.nbox);
-    if (has_alpha) hipLaunchKernelGGL(k_gsrb_box_m<true>, grd, dim3(BOXNT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass, bc_ghosts);
-    else hipLaunchKernelGGL(k_gsrb_box_m<false>, grd, dim3(BOXNT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass, bc_ghosts);
+    if (npass < 1 || npass > 2 * SUHMO_BOX_HALO) { suhmo_set_error("internal: %d colour passes in one box launch", npass); return -4; }
+    if (npass > 4) {
+        if (has_alpha) hipLaunchKernelGGL((k_gsrb_box_m<true, 8>), grd, dim3(BoxGeom<8>::NT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass, bc_ghosts);
+        else hipLaunchKernelGGL((k_gsrb_box_m<false, 8>), grd, dim3(BoxGeom<8>::NT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass, bc_ghosts);
+    } else {
+        if (has_alpha) hipLaunchKernelGGL((k_gsrb_box_m<true, 4>), grd, dim3(BoxGeom<4>::NT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass, bc_ghosts);
+        else hipLaunchKernelGGL((k_gsrb_box_m<false, 4>), grd, dim3(BoxGeom<4>::NT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass, bc_ghosts);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

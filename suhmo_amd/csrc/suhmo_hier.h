@@ -14,6 +14,7 @@ int suhmo_hier_avg_(suhmo_hier *H, int l, int ff, int fc, hipStream_t st);      
 int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, suhmo_hier **gap);
 
 // every box of a level in ONE launch (blockIdx.z = box): device tables of the boxes' views and field pointers
+constexpr int SUHMO_BOX_HALO = 8;    // cells around a box the plan `halo` of a level covers (k_gsrb_box_m advances through up to that many: 4 sweeps per launch)
 struct suhmo_multi { const DV *dv; const FP *fp; int nbox, maxnx, maxny; double *red; /* reduction scratch, 64 nbox + 16 doubles */
                      int merged; /* hierarchy option merged_launches: gradient + its ghosts, Re + bCoef in one launch each */
                      const void *push; const int *pbase; /* fine-fine ghost cells a side cell feeds (int2 {box, offset}), first entry of every box */ };

@@ -193,6 +193,7 @@ struct suhmo_hier {
     unsigned long base_fused_ver = 0;
     bool fused_relax = true;                               // option fused_relax: two sweeps per launch on levels of boxes (0: a launch per colour pass)
     long n_fused_relax = 0;                                // launches of that kind (read-only option fused_relax_launches)
+    int box_sweeps = 4;                                    // option box_sweeps: sweeps per launch of k_gsrb_box_m (4 or 2)
     bool merged_launches = true;                           // option merged_launches: both kinds of ghost cell in one launch, one norm read-back per hierarchy, ... (0: a launch each)
     bool fused_prolong = true;                             // option fused_prolong: AMRProlongS_2 of a box in one workgroup (0: gather, BC, prolongation as three launches)
     bool incremental = true;                               // option incremental_residual
@@ -833,8 +834,8 @@ int build_plans(suhmo_hier *H, int l)
         }
         rc |= F.push.upload(push); rc |= F.pbase.upload(pbase);
     }
-    if (!P) {   // two sweeps per launch (suhmo_gsrb.hip:k_gsrb_box_m): for every position of a box grown by 4 cells the box that holds the cell
-        constexpr int G = 4;
+    if (!P) {   // several sweeps per launch (suhmo_gsrb.hip:k_gsrb_box_m): for every position of a box grown by 8 cells the box that holds the cell
+        constexpr int G = SUHMO_BOX_HALO;
         size_t tot = 0;
         std::vector<int> hb(nb);
         bool fits = true;
@@ -1346,8 +1347,9 @@ int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
         }
         const int bcg = H->merged_launches && !Vf.self_wrap;             // the closing ghost fill (:757-759) rides in the relaxation launches
         int src = SUHMO_F_PHI, dst = SUHMO_F_PHI2;
-        for (int done = 0; done < sweeps; done += 2) {
-            const int npass = 2 * std::min(2, sweeps - done);
+        const int per = H->box_sweeps;                      // sweeps per launch: 4 (the whole smoothing of num_smooth = 4) or 2
+        for (int done = 0; done < sweeps; done += per) {
+            const int npass = 2 * std::min(per, sweeps - done);
             if ((rc = suhmo_multi_gsrb_box(m, phys_of(H, l), has_alpha(H, l), Vf.halo.d, Vf.hbase.d, src, dst, npass, bcg, HST(s)))) return rc;
             std::swap(src, dst);
             H->phi_ver[l]++; H->n_fused_relax++;
@@ -1611,6 +1613,7 @@ extern "C" int suhmo_hier_create_opts(suhmo_hier_t **out, const suhmo_level_desc
     H->incremental = hier_opt(options, "incremental_residual", 1) != 0;
     H->fused_prolong = hier_opt(options, "fused_prolong", 1) != 0;
     H->merged_launches = hier_opt(options, "merged_launches", 1) != 0;
+    H->box_sweeps = hier_opt(options, "box_sweeps", 4) >= 4 ? 4 : 2;
     H->fused_relax = hier_opt(options, "fused_relax", 1) != 0;
     H->part_min_cells = std::max(1L, hier_opt(options, "partition_min_cells", H->part_min_cells));
     H->nlev = nlev; H->device = base->device; H->bc = base->bc; H->base_desc = *base; H->base_desc.boxes = nullptr; H->base_desc.nbox = 0;
@@ -1812,6 +1815,7 @@ extern "C" int suhmo_hier_set_option(suhmo_hier_t *H, const char *key, long valu
     }
     if (!strcmp(key, "fused_prolong")) { H->fused_prolong = value != 0; if (H->gap) return suhmo_hier_set_option(H->gap, key, value); return 0; }
     if (!strcmp(key, "merged_launches")) { H->merged_launches = value != 0; if (H->gap) return suhmo_hier_set_option(H->gap, key, value); return 0; }
+    if (!strcmp(key, "box_sweeps")) { H->box_sweeps = value >= 4 ? 4 : 2; if (H->gap) return suhmo_hier_set_option(H->gap, key, value); return 0; }
     if (!strcmp(key, "fused_relax")) { H->fused_relax = value != 0; if (H->gap) return suhmo_hier_set_option(H->gap, key, value); return 0; }
     if (!strcmp(key, "push_ghosts")) {
         H->push_ghosts = value != 0;
@@ -1828,6 +1832,7 @@ extern "C" int suhmo_hier_get_option(const suhmo_hier_t *H, const char *key, lon
     if (!strcmp(key, "push_ghosts")) { *value = H->push_ghosts; return 0; }
     if (!strcmp(key, "fused_prolong")) { *value = H->fused_prolong; return 0; }
     if (!strcmp(key, "merged_launches")) { *value = H->merged_launches; return 0; }
+    if (!strcmp(key, "box_sweeps")) { *value = H->box_sweeps; return 0; }
     if (!strcmp(key, "fused_relax")) { *value = H->fused_relax; return 0; }
     if (!strcmp(key, "fused_relax_launches")) { *value = H->n_fused_relax + (H->gap ? H->gap->n_fused_relax : 0); return 0; }
     if (!strcmp(key, "incremental_residual")) { *value = H->incremental; return 0; }

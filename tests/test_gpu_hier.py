@@ -116,7 +116,7 @@ def test_hier_vcycle_and_solve_bitwise(oracle, name, boxes, bc, ph, monkeypatch)
     # a-launch-per-colour-pass: the paths they replace (a launch per colour pass that pushes its side cells; gather, BC and prolongation as three launches;
     # merged_launches=0: a launch for either kind of ghost cell, a norm and a read-back per level, the closing ghost fill on its own)
     opts = {"exchange-per-pass": "push_ghosts=0,fused_relax=0", "whole-level-residuals": "incremental_residual=0", "a-launch-per-colour-pass": "fused_relax=0,fused_prolong=0,merged_launches=0",
-            "a-launch-per-ghost-kind": "merged_launches=0"}
+            "a-launch-per-ghost-kind": "merged_launches=0,box_sweeps=2"}
     options = next((v for k, v in opts.items() if name.endswith(k)), None)
     O, G, fs = pair(oracle, boxes, bc, ph, options=options)
     O.vcycle(sp); G.vcycle(sp)
