@@ -95,10 +95,8 @@ __global__ void k_grad_ghosts_m(const DV *__restrict__ vt, const FP *__restrict_
 // steps 1 + 2 of every box of a level in ONE launch: the thread of a cell on a physical side of its box also writes the ghost cell beyond it,
 // from the gradient of the neighbour the extrapolation (or the periodic wrap) reads, evaluated a second time: d_grad_ghosts' expressions on the
 // same values (boxes of AMR levels are at least two cells wide: block_factor 2)
-__global__ __launch_bounds__(256) void k_gradcc_ghosts_m(const DV *__restrict__ vt, const FP *__restrict__ ft, int hasMask)
+__device__ __forceinline__ void d_gradcc_ghosts(const DV &v, const FP &fp, int hasMask)
 {
-    const DV &v = vt[blockIdx.z];
-    const FP &fp = ft[blockIdx.z];
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
     if (i >= v.nx || j >= v.ny) return;
     double gx, gy, ox, oy;
@@ -122,6 +120,23 @@ __global__ __launch_bounds__(256) void k_gradcc_ghosts_m(const DV *__restrict__ 
         d_gradcc_val(v, fp, hasMask, i, v.per[1] ? 0 : v.ny - 2, ox, oy);
         GX[idx + v.P] = v.per[1] ? ox : 2.0 * gx - ox; GY[idx + v.P] = v.per[1] ? oy : 2.0 * gy - oy;
     }
+}
+__global__ __launch_bounds__(256) void k_gradcc_ghosts_m(const DV *__restrict__ vt, const FP *__restrict__ ft, int hasMask)
+{
+    d_gradcc_ghosts(vt[blockIdx.z], ft[blockIdx.z], hasMask);
+}
+// ... of SEVERAL levels (UpdateOperator of an AMR level evaluates the gradient of its own and of the coarser level)
+__global__ __launch_bounds__(256) void k_gradcc_ghosts_lv(suhmo_lvboxes lv, int hasMask)
+{
+    int z = blockIdx.z, q = -1;
+#pragma unroll
+    for (int t = 0; t < SUHMO_LVMAX; t++)
+        if (t < lv.n && q < 0) { if (z < lv.nbox[t]) q = t; else z -= lv.nbox[t]; }
+    if (q < 0) return;
+    const DV *dv = nullptr; const FP *fp = nullptr;
+#pragma unroll
+    for (int t = 0; t < SUHMO_LVMAX; t++) if (t == q) { dv = lv.dv[t]; fp = lv.fp[t]; }
+    d_gradcc_ghosts(dv[z], fp[z], hasMask);
 }
 // step 3: COMPUTERE on the ghosted box (src/AmrHydro.cpp:1495-1505, src/AmrHydroF.ChF:92-109)
 __device__ __forceinline__ double d_re_val(const FP &fp, const suhmo_phys_t &ph, int idx)
@@ -792,6 +807,16 @@ int suhmo_multi_grad_cc(const suhmo_multi &m, int hasMask, hipStream_t st)
     hipLaunchKernelGGL(k_gradcc_m, grid_m(m), BLK2D, 0, st, m.dv, m.fp, hasMask);
     int n = 2 * m.maxny + 2 * m.maxnx;
     hipLaunchKernelGGL(k_grad_ghosts_m, dim3((n + 255) / 256, 1, m.nbox), dim3(256), 0, st, m.dv, m.fp);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int suhmo_levels_grad_cc(const suhmo_lvboxes &lv, int hasMask, hipStream_t st)
+{
+    int nz = 0;
+    for (int q = 0; q < lv.n; q++) nz += lv.nbox[q];
+    if (nz <= 0) return 0;
+    hipLaunchKernelGGL(k_gradcc_ghosts_lv, dim3((lv.maxnx + 63) / 64, (lv.maxny + 3) / 4, nz), BLK2D, 0, st, lv, hasMask);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -38,6 +38,15 @@ int suhmo_multi_norm_max(const suhmo_multi &m, suhmo_level *slot, int field, dou
 int suhmo_level_norm_max_partials(suhmo_level *L, int field, const double **partials, int *np, hipStream_t st);
 int suhmo_multi_norm_max_partials(const suhmo_multi &m, int field, const double **partials, int *np, hipStream_t st);
 int suhmo_norm_max_of_lists(suhmo_level *slot, const double *const *partials, const int *np, int cnt, double *out, hipStream_t st);
+// SEVERAL levels of boxes in one launch (blockIdx.z runs over the boxes of the listed levels, one after the other): by value, indexed with
+// constants only (an unrolled search), so that the tables stay in scalar registers
+constexpr int SUHMO_LVMAX = 7;
+struct suhmo_lvboxes { const DV *dv[SUHMO_LVMAX]; const FP *fp[SUHMO_LVMAX]; int nbox[SUHMO_LVMAX], mode[SUHMO_LVMAX]; int n, maxnx, maxny; };
+int suhmo_levels_apply(const suhmo_lvboxes &lv, const suhmo_phys_t &ph, bool has_alpha, hipStream_t st);   // mode[q]: 1 RES = rhs - L(phi), 3: LPHI as well (suhmo_multi_apply)
+// field <- 0 where SUHMO_F_COVER is set, and the first stage of max |field| over the rest, of the listed levels / of a whole level; one partial per workgroup
+int suhmo_levels_norm_max_cover_partials(const suhmo_lvboxes &lv, int field, double *partial, int *np, hipStream_t st);
+int suhmo_level_norm_max_cover_partials(suhmo_level *L, int field, const double **partials, int *np, hipStream_t st);
+int suhmo_levels_grad_cc(const suhmo_lvboxes &lv, int hasMask, hipStream_t st);                              // suhmo_multi_grad_cc (merged form) of several levels
 int suhmo_hier_multi_(suhmo_hier *H, int l, hipStream_t st, suhmo_multi *m);       // l >= 1
 int suhmo_hier_ensure_(suhmo_hier *H, int l, int field);                            // allocate a field on every box of a level
 void suhmo_hier_invalidate_(suhmo_hier *H);                                         // an entry point outside suhmo_hier.hip: the caller may have loaded new data

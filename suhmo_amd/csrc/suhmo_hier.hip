@@ -206,6 +206,7 @@ struct suhmo_hier {
     // read-only counters (suhmo_hier_get_option): composite residuals of level 0 evaluated on the dirty rectangles only / not at all (left
     // behind by the launch that ended level 0's V-cycle), coarse gradients evaluated on the cell list only
     long n_incr_residual = 0, n_fused_residual = 0, n_sparse_grad = 0;
+    double *red_all = nullptr;                             // partial maxima of a norm over all levels of boxes (64 per box + 16)
     DevVec<RectEnt> cover_full;                            // coarsen(boxes of level 1) in the shadow: COVER of the whole level 0
 };
 
@@ -294,6 +295,29 @@ __global__ void k_cf_ff(const CfEnt *__restrict__ ce, int ncf, int nbcf, const C
     } else {
         int t = (blockIdx.x - nbcf) * blockDim.x + threadIdx.x;
         if (t < nff) d_ff(fe[t], ftab, ff0, ff1);
+    }
+}
+// ... of the head of SEVERAL levels (their ghosts depend on valid cells only, of the level itself and of the one below: no order among them).
+// By value, indexed with constants only (unrolled search), so that the tables stay in scalar registers.
+struct LvGhosts { const CfEnt *cf[SUHMO_LVMAX]; const CopyEnt *ff[SUHMO_LVMAX]; const FP *ftab[SUHMO_LVMAX], *ctab[SUHMO_LVMAX];
+                  int ncf[SUHMO_LVMAX], nbcf[SUHMO_LVMAX], nff[SUHMO_LVMAX], nb[SUHMO_LVMAX], use_base[SUHMO_LVMAX]; int n; };
+__global__ void k_cf_ff_lv(LvGhosts lv, FP cbase, int field)
+{
+    int b = blockIdx.x, q = -1;
+#pragma unroll
+    for (int t = 0; t < SUHMO_LVMAX; t++)
+        if (t < lv.n && q < 0) { if (b < lv.nb[t]) q = t; else b -= lv.nb[t]; }
+    if (q < 0) return;
+    const CfEnt *ce = nullptr; const CopyEnt *fe = nullptr; const FP *ftab = nullptr, *ctab = nullptr; int ncf = 0, nbcf = 0, nff = 0, use_base = 0;
+#pragma unroll
+    for (int t = 0; t < SUHMO_LVMAX; t++)
+        if (t == q) { ce = lv.cf[t]; fe = lv.ff[t]; ftab = lv.ftab[t]; ctab = lv.ctab[t]; ncf = lv.ncf[t]; nbcf = lv.nbcf[t]; nff = lv.nff[t]; use_base = lv.use_base[t]; }
+    if (b < nbcf) {
+        int t = b * blockDim.x + threadIdx.x;
+        if (t < ncf) d_cf(ce[t], ftab, field, ctab, cbase, use_base, field, -1, -1);
+    } else {
+        int t = (b - nbcf) * blockDim.x + threadIdx.x;
+        if (t < nff) d_ff(fe[t], ftab, field, -1);
     }
 }
 // [Chombo] PiecewiseLinearFillPatch (oracle/amr_step.c:or_pwl_fill)
@@ -489,12 +513,9 @@ __global__ __launch_bounds__(256) void k_prolong2_fused(const WinEnt *__restrict
     }
 }
 // [Chombo] LevelFluxRegister (oracle/amrm.c:reflux): one thread per coarse cell next to coarse-fine faces
-__global__ void k_reflux(const Target *__restrict__ tg, int n, const Face *__restrict__ faces, const FP *__restrict__ ftab, const DV *__restrict__ fdv,
-                         const FP *__restrict__ ctab, FP cbase, FP cdst, int use_base, int field_c, double dxc, double dyc, double beta, int residual)
+__device__ __forceinline__ void d_reflux(const Target &T, const Face *__restrict__ faces, const FP *__restrict__ ftab, const DV *__restrict__ fdv,
+                                         const FP *__restrict__ ctab, const FP &cbase, const FP &cdst, int use_base, int field_c, double dxc, double dyc, double beta, int residual)
 {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    Target T = tg[t];
     // cdst: the level itself; cbase: where its cells are read (the shadow of a cut level 0).  residual: the register is added to
     // LPHI's value and field_c <- rhs - that (the axby of the composite residual, for the cells the reflux reaches)
     double *lof = fptr(ctab, cdst, use_base, T.t.b, field_c);
@@ -520,6 +541,32 @@ __global__ void k_reflux(const Target *__restrict__ tg, int n, const Face *__res
         acc = acc + sign * rscale * reg;
     }
     lof[T.t.off] = residual ? -1.0 * acc + 1.0 * fptr(ctab, cdst, use_base, T.t.b, SUHMO_F_RHS)[T.t.off] : acc;
+}
+__global__ void k_reflux(const Target *__restrict__ tg, int n, const Face *__restrict__ faces, const FP *__restrict__ ftab, const DV *__restrict__ fdv,
+                         const FP *__restrict__ ctab, FP cbase, FP cdst, int use_base, int field_c, double dxc, double dyc, double beta, int residual)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    d_reflux(tg[t], faces, ftab, fdv, ctab, cbase, cdst, use_base, field_c, dxc, dyc, beta, residual);
+}
+// the refluxes of SEVERAL levels (level l's adds to cells of level l-1 from fluxes of levels l and l-1: no order among them)
+struct LvReflux { const Target *tg[SUHMO_LVMAX]; const Face *faces[SUHMO_LVMAX]; const FP *ftab[SUHMO_LVMAX], *ctab[SUHMO_LVMAX]; const DV *fdv[SUHMO_LVMAX];
+                  int ntg[SUHMO_LVMAX], nb[SUHMO_LVMAX], use_base[SUHMO_LVMAX]; double dxc[SUHMO_LVMAX], dyc[SUHMO_LVMAX], beta[SUHMO_LVMAX]; int n; };
+__global__ void k_reflux_lv(LvReflux lv, FP cbase, FP cdst, int field_c, int residual)
+{
+    int b = blockIdx.x, q = -1;
+#pragma unroll
+    for (int t = 0; t < SUHMO_LVMAX; t++)
+        if (t < lv.n && q < 0) { if (b < lv.nb[t]) q = t; else b -= lv.nb[t]; }
+    if (q < 0) return;
+    const Target *tg = nullptr; const Face *faces = nullptr; const FP *ftab = nullptr, *ctab = nullptr; const DV *fdv = nullptr;
+    int ntg = 0, use_base = 0; double dxc = 0.0, dyc = 0.0, beta = 0.0;
+#pragma unroll
+    for (int t = 0; t < SUHMO_LVMAX; t++)
+        if (t == q) { tg = lv.tg[t]; faces = lv.faces[t]; ftab = lv.ftab[t]; ctab = lv.ctab[t]; fdv = lv.fdv[t]; ntg = lv.ntg[t]; use_base = lv.use_base[t];
+                      dxc = lv.dxc[t]; dyc = lv.dyc[t]; beta = lv.beta[t]; }
+    const int t = b * blockDim.x + threadIdx.x;
+    if (t < ntg) d_reflux(tg[t], faces, ftab, fdv, ctab, cbase, cdst, use_base, field_c, dxc, dyc, beta, residual);
 }
 
 // ------------------------------------------------------------------ plan building (host)
@@ -1422,6 +1469,95 @@ int cf_phi(suhmo_hier *H, int l, suhmo_stream_t s)
     return rc;
 }
 
+// ---- several levels per launch (option merged_launches; this process holds every box and the whole of level 0)
+inline bool levels_mergeable(const suhmo_hier *H) { return H->merged_launches && !H->part && !dist_base(H) && H->nlev <= SUHMO_LVMAX + 1; }
+// coarse-fine and fine-fine side ghosts of the head of the levels llo .. lhi (>= 1) that are stale: ONE launch
+int ghosts_levels(suhmo_hier *H, int llo, int lhi, suhmo_stream_t s)
+{
+    LvGhosts g;
+    memset(&g, 0, sizeof(g));
+    int rc, nb = 0;
+    for (int l = std::max(1, llo); l <= lhi; l++) {
+        HLev &V = H->lev[l];
+        const bool cf_ok = H->cf_seen[l][0] == H->phi_ver[l] && H->cf_seen[l][1] == H->phi_ver[l - 1], ff_ok = H->ff_seen[l] == H->phi_ver[l];
+        if (cf_ok && ff_ok) continue;
+        if ((rc = ensure_field(H, l, SUHMO_F_PHI)) || (rc = ensure_field(H, l - 1, SUHMO_F_PHI)) || (rc = refresh_tables(H, l, HST(s)))) return rc;
+        if (l - 1 >= 1 && (rc = refresh_tables(H, l - 1, HST(s)))) return rc;
+        const int q = g.n++;
+        g.cf[q] = V.cf.d; g.ncf[q] = (int)V.cf.n; g.nbcf[q] = (int)g1(V.cf.n).x;
+        g.ff[q] = V.ff_side.d; g.nff[q] = (int)V.ff_side.n;
+        g.nb[q] = g.nbcf[q] + (int)g1(V.ff_side.n).x;
+        g.ftab[q] = V.d_fp; g.ctab[q] = l - 1 >= 1 ? H->lev[l - 1].d_fp : nullptr; g.use_base[q] = l - 1 == 0;
+        nb += g.nb[q];
+        H->cf_seen[l][0] = H->phi_ver[l]; H->cf_seen[l][1] = H->phi_ver[l - 1]; H->ff_seen[l] = H->phi_ver[l];
+    }
+    if (nb > 0) {
+        SUHMO_TIME("QuadCFInterp::coarseFineInterp + exchange");
+        hipLaunchKernelGGL(k_cf_ff_lv, dim3(nb), dim3(256), 0, HST(s), g, base_of(H)->d[0].fp, (int)SUHMO_F_PHI);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// the boxes of the levels lhi, lhi - 1, .. llo (>= 1) as one launch's table; mode_top for lhi, mode_rest for the others
+int levels_boxes(suhmo_hier *H, int llo, int lhi, int mode_top, int mode_rest, suhmo_stream_t s, suhmo_lvboxes &lv)
+{
+    memset(&lv, 0, sizeof(lv));
+    int rc;
+    for (int l = lhi; l >= std::max(1, llo); l--) {
+        suhmo_multi m;
+        if ((rc = multi_of(H, l, HST(s), m))) return rc;
+        const int q = lv.n++;
+        lv.dv[q] = m.dv; lv.fp[q] = m.fp; lv.nbox[q] = m.nbox; lv.mode[q] = l == lhi ? mode_top : mode_rest;
+        lv.maxnx = std::max(lv.maxnx, m.maxnx); lv.maxny = std::max(lv.maxny, m.maxny);
+    }
+    return 0;
+}
+// L(phi) and the residual of level 0 inside a composite residual: as it is (left behind by the cycle's last launch), on the rectangles the
+// average from level 1 changed, or over the whole level
+int base_apply_residual(suhmo_hier *H, bool whole_level_follows, suhmo_stream_t s)
+{
+    int rc;
+    HLev &V1 = H->lev[1];
+    if (!whole_level_follows && H->base_fused_ver == H->base_full_ver)
+        { rc = 0; H->n_fused_residual++; }                                // L(phi) and rhs - L(phi) of the head as it is: written by the cycle's last launch
+    else if (H->incremental && whole_level_follows && H->base_res_seen == H->base_full_ver)
+        { rc = suhmo_apply_and_residual_rects(base_of(H), 0, V1.dirty0.d, (int)V1.dirty0.n, V1.dirty_w, V1.dirty_h, HST(s)); H->n_incr_residual++; }   // only what the average changed
+    else rc = suhmo_apply_and_residual(base_of(H), 0, HST(s));
+    H->base_res_seen = whole_level_follows ? 0 : H->base_full_ver;       // (the solve loop's evaluation is the one the next cycle can build on)
+    return rc;
+}
+// RES of the levels llo .. lhi: level lhi's own residual (residualI), the composite residual with the reflux from the level above on the others
+// (what hier_level_residual(lhi) and composite_residual(lhi), .., composite_residual(llo + 1) leave) in ONE launch per kind: ghosts, operator on
+// the levels of boxes, [level 0], refluxes.  Nothing of one level's part reads what another's writes (ghosts from valid cells; L(phi) from the
+// level's own head; a reflux adds fluxes of two heads to L(phi) of its coarse cells).
+int levels_residual(suhmo_hier *H, int lhi, int llo, bool whole_level_follows, suhmo_stream_t s)
+{
+    int rc;
+    if ((rc = ghosts_levels(H, llo, lhi, s))) return rc;
+    for (int l = std::max(1, llo); l < lhi; l++) if ((rc = ensure_field(H, l, SUHMO_F_LPHI))) return rc;
+    suhmo_lvboxes lv;
+    if ((rc = levels_boxes(H, llo, lhi, 1, 3, s, lv)) || (rc = suhmo_levels_apply(lv, phys_of(H, lhi), has_alpha(H, lhi), HST(s)))) return rc;
+    if (llo == 0 && (rc = base_apply_residual(H, whole_level_follows, s))) return rc;
+    SUHMO_TIME("VCAMRNonLinearPoissonOp::reflux");
+    LvReflux r;
+    memset(&r, 0, sizeof(r));
+    int nb = 0;
+    for (int l = lhi; l > llo; l--) {
+        HLev &V = H->lev[l];
+        if (!V.targets.n) continue;
+        if ((rc = refresh_tables(H, l, HST(s))) || (l - 1 >= 1 && (rc = refresh_tables(H, l - 1, HST(s))))) return rc;
+        const DV &vc = H->lev[l - 1].box[0]->d[0].v;
+        const int q = r.n++;
+        r.tg[q] = V.targets.d; r.ntg[q] = (int)V.targets.n; r.nb[q] = (int)g1(V.targets.n).x; r.faces[q] = V.faces.d;
+        r.ftab[q] = V.d_fp; r.fdv[q] = V.d_dv; r.ctab[q] = l - 1 >= 1 ? H->lev[l - 1].d_fp : nullptr; r.use_base[q] = l - 1 == 0;
+        r.dxc[q] = vc.dx; r.dyc[q] = vc.dy; r.beta[q] = vc.beta;
+        nb += r.nb[q];
+    }
+    if (nb > 0) hipLaunchKernelGGL(k_reflux_lv, dim3(nb), dim3(256), 0, HST(s), r, base_of(H)->d[0].fp, base_of(H)->d[0].fp, (int)SUHMO_F_RES, 1);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // cell-centred gradient of level l (compGradientCC) with its domain-side ghosts
 int hier_grad_cc(suhmo_hier *H, int l, suhmo_stream_t s)
 {
@@ -1437,6 +1573,17 @@ int hier_update_operator(suhmo_hier *H, int l, suhmo_stream_t s)
 {
     SUHMO_TIME("VCAMRNonLinearPoissonOp::UpdateOperator(AMR)");
     int rc;
+    if (l - 1 >= 1 && levels_mergeable(H)) {
+        // the gradients of this level and of the coarser one: their ghosts in one launch, the two gradients in one launch
+        suhmo_lvboxes lv;
+        if ((rc = ghosts_levels(H, l - 1, l, s))) return rc;
+        for (int q = l - 1; q <= l; q++) for (int f : {SUHMO_F_GRADX, SUHMO_F_GRADY, SUHMO_F_RE}) if ((rc = ensure_field(H, q, f))) return rc;
+        if ((rc = levels_boxes(H, l - 1, l, 0, 0, s, lv)) || (rc = suhmo_levels_grad_cc(lv, phys_of(H, l).use_mask_gradients, HST(s)))) return rc;
+        if ((rc = hier_cf_ff(H, l, SUHMO_F_GRADX, SUHMO_F_GRADX, SUHMO_F_GRADY, SUHMO_F_GRADY, true, HST(s)))) return rc;
+        suhmo_multi m;
+        if ((rc = multi_of(H, l, HST(s), m))) return rc;
+        return suhmo_multi_re_bcoef(m, phys_of(H, l), HST(s));
+    }
     if ((rc = cf_phi(H, l - 1, s))) return rc;                    // the coarser level's own coarse-fine ghosts (its gradient reads them)
     if ((rc = hier_grad_cc(H, l, s))) return rc;
     // the coarse gradient is read by the coarse-fine interpolation below and by nothing else: on level 0 only the cells those
@@ -1463,15 +1610,8 @@ int composite_residual(suhmo_hier *H, int l, suhmo_stream_t s, bool whole_level_
     // one pass writes LPHI and rhs - LPHI; the cells next to the coarse-fine faces then get rhs - (LPHI + flux mismatch): the
     // values of copy, reflux, axby(RES, RHS, -1, 1) over the whole level, without two of its three passes
     if ((rc = cf_phi(H, l - 1, s))) return rc;
-    if (l - 1 == 0) {
-        HLev &V1 = H->lev[1];
-        if (!whole_level_follows && H->base_fused_ver == H->base_full_ver)
-            { rc = 0; H->n_fused_residual++; }                                // L(phi) and rhs - L(phi) of the head as it is: written by the cycle's last launch
-        else if (H->incremental && whole_level_follows && H->base_res_seen == H->base_full_ver)
-            { rc = suhmo_apply_and_residual_rects(base_of(H), 0, V1.dirty0.d, (int)V1.dirty0.n, V1.dirty_w, V1.dirty_h, HST(s)); H->n_incr_residual++; }   // only what the average changed
-        else rc = suhmo_apply_and_residual(base_of(H), 0, HST(s));
-        H->base_res_seen = whole_level_follows ? 0 : H->base_full_ver;       // (the solve loop's evaluation is the one the next cycle can build on)
-    } else {
+    if (l - 1 == 0) rc = base_apply_residual(H, whole_level_follows, s);
+    else {
         suhmo_multi m;
         if ((rc = hier_ff(H, l - 1, SUHMO_F_PHI, -1, false, HST(s))) || (rc = ensure_field(H, l - 1, SUHMO_F_LPHI)) || (rc = multi_of(H, l - 1, HST(s), m))) return rc;
         rc = suhmo_multi_apply(m, phys_of(H, l - 1), has_alpha(H, l - 1), 3, HST(s));
@@ -1488,9 +1628,12 @@ int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stre
     if (sp->bcoeff_otf && (rc = hier_update_operator(H, l, s))) return rc;
     if ((rc = hier_gsrb(H, l, sp->num_smooth, s))) return rc;                                 // relaxNF
     if ((rc = hier_avg(H, l, SUHMO_F_PHI, SUHMO_F_PHI, 0, 0.0, HST(s)))) return rc;           // AMRRestrictS(skip_res)
-    if ((rc = cf_phi(H, l, s))) return rc;
-    if ((rc = hier_level_residual(H, l, s))) return rc;
-    if ((rc = composite_residual(H, l, s))) return rc;
+    if (levels_mergeable(H)) { if ((rc = levels_residual(H, l, l - 1, true, s))) return rc; }
+    else {
+        if ((rc = cf_phi(H, l, s))) return rc;
+        if ((rc = hier_level_residual(H, l, s))) return rc;
+        if ((rc = composite_residual(H, l, s))) return rc;
+    }
     if ((rc = hier_avg(H, l, SUHMO_F_RES, SUHMO_F_RES, 0, 0.0, HST(s)))) return rc;
     // the right-hand side of level l-1 is set aside while its FAS problem runs: two canvases trade places on level 0 (its
     // pointers travel by value), a copy on a level of boxes (their pointers sit in a device table)
@@ -1559,6 +1702,7 @@ extern "C" int suhmo_hier_destroy(suhmo_hier_t *H)
     for (int f = 0; f < SUHMO_F_COUNT; f++) if (H->shadow.f[f]) (void)hipFree(H->shadow.f[f]);
     H->need.release(); H->need_c.release(); H->need_rl.release(); H->cover_full.release();
     if (H->cover_whole) (void)hipFree(H->cover_whole);
+    if (H->red_all) (void)hipFree(H->red_all);
     if (H->xs) (void)hipFree(H->xs);
     if (H->xr) (void)hipFree(H->xr);
     for (int l = 0; l < 8; l++) {
@@ -1952,6 +2096,23 @@ static int hier_residual_(suhmo_hier *H, double *norm, suhmo_stream_t s)
     SUHMO_TIME("AMRNonLinearPoissonOp::AMRResidual");
     int rc;
     const int top = H->nlev - 1;
+    if (levels_mergeable(H)) {
+        // every level's ghosts, operator and reflux in one launch per kind; the covered cells are zeroed by the pass that takes the first stage
+        // of the max norm; ONE launch over all partial maxima and one read-back (a maximum is the same in any order)
+        if ((rc = levels_residual(H, top, 0, false, s))) return rc;
+        if (!H->red_all) {
+            size_t nb = 0;
+            for (int l = 1; l <= top; l++) nb += H->lev[l].box.size();
+            HIPCHK(hipMalloc(&H->red_all, (64 * nb + 16) * sizeof(double)));
+        }
+        const double *lists[2];
+        int np[2];
+        suhmo_lvboxes lv;
+        if ((rc = suhmo_level_norm_max_cover_partials(base_of(H), SUHMO_F_RES, &lists[0], &np[0], HST(s)))) return rc;
+        if ((rc = levels_boxes(H, 1, top, 0, 1, s, lv)) || (rc = suhmo_levels_norm_max_cover_partials(lv, SUHMO_F_RES, H->red_all, &np[1], HST(s)))) return rc;
+        lists[1] = H->red_all;
+        return norm ? suhmo_norm_max_of_lists(base_of(H), lists, np, 2, norm, HST(s)) : 0;
+    }
     if ((rc = cf_phi(H, top, s))) return rc;
     if ((rc = hier_level_residual(H, top, s))) return rc;                                  // AMRResidualNF on the finest level
     for (int l = top; l >= 1; l--) if ((rc = composite_residual(H, l, s, false))) return rc;

@@ -132,6 +132,39 @@ __global__ __launch_bounds__(256) void k_apply_m(const DV *__restrict__ vt, cons
     d_apply<HAS_ALPHA, MODE>(vt[blockIdx.z], ft[blockIdx.z], ph, homog, 0, 0);
 }
 
+// the box of blockIdx.z among the boxes of several levels: its level's slot q (unrolled: constant indices only), its index in that level
+__device__ __forceinline__ bool lv_find(const suhmo_lvboxes &lv, int &q, int &k)
+{
+    int z = blockIdx.z;
+    q = -1; k = 0;
+#pragma unroll
+    for (int t = 0; t < SUHMO_LVMAX; t++)
+        if (t < lv.n && q < 0) { if (z < lv.nbox[t]) { q = t; k = z; } else z -= lv.nbox[t]; }
+    return q >= 0;
+}
+#define LV_PICK(lv, q, member, out) do { _Pragma("unroll") for (int t_ = 0; t_ < SUHMO_LVMAX; t_++) if (t_ == (q)) (out) = (lv).member[t_]; } while (0)
+template <bool HAS_ALPHA>
+__global__ __launch_bounds__(256) void k_apply_lv(suhmo_lvboxes lv, suhmo_phys_t ph)
+{
+    int q, k;
+    if (!lv_find(lv, q, k)) return;
+    const DV *dv = nullptr; const FP *fp = nullptr; int mode = 1;
+    LV_PICK(lv, q, dv, dv); LV_PICK(lv, q, fp, fp); LV_PICK(lv, q, mode, mode);
+    if (mode == 1) d_apply<HAS_ALPHA, 1>(dv[k], fp[k], ph, 0, 0, 0);
+    else d_apply<HAS_ALPHA, 3>(dv[k], fp[k], ph, 0, 0, 0);
+}
+int suhmo_levels_apply(const suhmo_lvboxes &lv, const suhmo_phys_t &ph, bool has_alpha, hipStream_t st)
+{
+    int nz = 0;
+    for (int q = 0; q < lv.n; q++) nz += lv.nbox[q];
+    if (nz <= 0) return 0;
+    const dim3 grd((lv.maxnx + 63) / 64, (lv.maxny + 3) / 4, nz);
+    if (has_alpha) hipLaunchKernelGGL(k_apply_lv<true>, grd, BLK2D, 0, st, lv, ph);
+    else hipLaunchKernelGGL(k_apply_lv<false>, grd, BLK2D, 0, st, lv, ph);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int suhmo_exchange_fields(suhmo_level *L, int depth, std::initializer_list<int> fields, hipStream_t st)
 {
     const DV &v = L->d[depth].v;
@@ -890,6 +923,59 @@ int suhmo_norm_max_of_lists(suhmo_level *slot, const double *const *partials, co
     hipLaunchKernelGGL(k_norm_max_final_lists, dim3(1), dim3(256), 0, st, nl, slot->scratch, suhmo_host_slot(slot));
     HIPCHK(hipGetLastError());
     return suhmo_readback(slot, st, out);
+}
+// the composite norm's covered cells (AMRNorm zeroes them, src/AMRNonLinearPoissonOp.cpp:1241-1258) and its first stage in one pass
+__device__ __forceinline__ void d_norm_max_cover(const DV &v, double *__restrict__ x, const double *__restrict__ cover, double *__restrict__ partial, int slot)
+{
+    __shared__ double sm[256];
+    int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    double acc = 0.0;
+    for (int j = blockIdx.y * blockDim.y + threadIdx.y; j < v.ny; j += gridDim.y * blockDim.y)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.nx; i += gridDim.x * blockDim.x) {
+            const int idx = cidx(v, i, j);
+            if (cover && cover[idx] != 0.0) x[idx] = 0.0; else acc = fmax(acc, fabs(x[idx]));
+        }
+    sm[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = fmax(sm[tid], sm[tid + s]); __syncthreads(); }
+    if (tid == 0) partial[slot] = sm[0];
+}
+__global__ __launch_bounds__(256) void k_norm_max_cover(DV v, double *__restrict__ x, const double *__restrict__ cover, double *__restrict__ partial)
+{
+    d_norm_max_cover(v, x, cover, partial, blockIdx.y * gridDim.x + blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_norm_max_cover_lv(suhmo_lvboxes lv, int field, double *__restrict__ partial)
+{
+    int q, k;
+    const int slot = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (!lv_find(lv, q, k)) { if (threadIdx.x == 0 && threadIdx.y == 0) partial[slot] = 0.0; return; }
+    const DV *dv = nullptr; const FP *fp = nullptr; int covered = 0;
+    LV_PICK(lv, q, dv, dv); LV_PICK(lv, q, fp, fp); LV_PICK(lv, q, mode, covered);
+    d_norm_max_cover(dv[k], fp[k].f[field], covered ? fp[k].f[SUHMO_F_COVER] : nullptr, partial, slot);
+}
+// lv.mode[q] != 0: the level has cells under a finer one (every level but the finest)
+int suhmo_levels_norm_max_cover_partials(const suhmo_lvboxes &lv, int field, double *partial, int *np, hipStream_t st)
+{
+    int nz = 0;
+    for (int q = 0; q < lv.n; q++) nz += lv.nbox[q];
+    *np = 0;
+    if (nz <= 0) return 0;
+    dim3 grd(std::min((lv.maxnx + 63) / 64, 4), std::min((lv.maxny + 3) / 4, 16), nz);
+    hipLaunchKernelGGL(k_norm_max_cover_lv, grd, BLK2D, 0, st, lv, field, partial);
+    HIPCHK(hipGetLastError());
+    *np = (int)(grd.x * grd.y * grd.z);
+    return 0;
+}
+int suhmo_level_norm_max_cover_partials(suhmo_level *L, int field, const double **partials, int *np, hipStream_t st)
+{
+    Depth &D = L->d[0];
+    double *x = suhmo_field(L, 0, field), *cover = suhmo_field(L, 0, SUHMO_F_COVER);
+    if (!x || !cover) { suhmo_set_error("field allocation failed"); return -2; }
+    dim3 grd(std::min((D.v.nx + 63) / 64, 32), std::min((D.v.ny + 3) / 4, 128));
+    hipLaunchKernelGGL(k_norm_max_cover, grd, BLK2D, 0, st, D.v, x, cover, L->scratch + 2);
+    HIPCHK(hipGetLastError());
+    *partials = L->scratch + 2; *np = grd.x * grd.y;
+    return 0;
 }
 int suhmo_multi_norm_max(const suhmo_multi &m, suhmo_level *slot, int field, double *out, hipStream_t st)
 {
