@@ -537,11 +537,11 @@ __global__ void k_average_faces(DV vf, const double *__restrict__ bxf, const dou
 // the (unscaled) depth d-1 sum, so one walk over 2^(nd-1) faces yields every depth bit for bit.
 struct AvgOut { double *bx[SUHMO_MAXDEPTH], *by[SUHMO_MAXDEPTH]; int P[SUHMO_MAXDEPTH]; int gy[SUHMO_MAXDEPTH]; };
 // x-faces: thread = (even fine column i, block of R = 2^(nd-1) rows); walks the rows
-__global__ __launch_bounds__(256) void k_average_faces_x_all(DV vf, const double *__restrict__ bxf, AvgOut o, int nd)
+__device__ __forceinline__ void d_average_faces_x_all(const DV &vf, const double *__restrict__ bxf, const AvgOut &o, int nd, int bix, int biy, int tx, int ty)
 {
     const int R = 1 << (nd - 1);
-    int ih = blockIdx.x * blockDim.x + threadIdx.x;      // i = 2 * ih
-    int jb = blockIdx.y * blockDim.y + threadIdx.y;
+    int ih = bix * 64 + tx;                              // i = 2 * ih
+    int jb = biy * 4 + ty;
     int i = 2 * ih;
     if (i > vf.nx || jb * R >= vf.ny) return;
     double sum[SUHMO_MAXDEPTH];
@@ -571,11 +571,11 @@ __global__ __launch_bounds__(256) void k_average_faces_x_all(DV vf, const double
 }
 // y-faces: one wave walks 64 consecutive columns of YR even fine rows (their loads in flight together); lane l = column
 #define AVG_YR 8
-__global__ __launch_bounds__(256) void k_average_faces_y_all(DV vf, const double *__restrict__ byf, AvgOut o, int nd)
+__device__ __forceinline__ void d_average_faces_y_all(const DV &vf, const double *__restrict__ byf, const AvgOut &o, int nd, int bix, int biy, int tid)
 {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 64 + lane;
-    const int jb = 2 * AVG_YR * (blockIdx.y * (blockDim.x / 64) + (threadIdx.x >> 6));
+    const int lane = tid & 63;
+    const int i = bix * 64 + lane;
+    const int jb = 2 * AVG_YR * (biy * 4 + (tid >> 6));
     if (jb > vf.ny) return;                               // whole wave leaves together
     double fr[AVG_YR];
 #pragma unroll
@@ -600,6 +600,15 @@ __global__ __launch_bounds__(256) void k_average_faces_y_all(DV vf, const double
                 o.by[d][(j / r + o.gy[d]) * o.P[d] + SUHMO_XOFF + i / r] = run / (double)r;
         }
     }
+}
+
+// both directions in ONE launch of 256-thread workgroups: the first gxx * gxy of them are the x-face walkers (64 x 4 threads), the rest the
+// y-face walkers (four waves): nothing of one reads what the other writes
+__global__ __launch_bounds__(256) void k_average_faces_all(DV vf, const double *__restrict__ bxf, const double *__restrict__ byf, AvgOut o, int nd, int gxx, int gxy, int gyx)
+{
+    const int b = blockIdx.x, nbx = gxx * gxy;
+    if (b < nbx) d_average_faces_x_all(vf, bxf, o, nd, b % gxx, b / gxx, threadIdx.x & 63, threadIdx.x >> 6);
+    else d_average_faces_y_all(vf, byf, o, nd, (b - nbx) % gyx, (b - nbx) / gyx, threadIdx.x);
 }
 
 extern "C" int suhmo_level_average_operator(suhmo_level_t *L, int depth, suhmo_stream_t s)
@@ -631,9 +640,8 @@ int suhmo_average_operator_all(suhmo_level *L, int nd, hipStream_t st)
     for (int d = 0; d < nd; d++) { o.bx[d] = L->d[d].fp.f[SUHMO_F_BX]; o.by[d] = L->d[d].fp.f[SUHMO_F_BY]; o.P[d] = L->d[d].v.P; o.gy[d] = L->d[d].v.gy; }
     const int R = 1 << (nd - 1);
     dim3 gx((F.v.nx / 2 + 1 + 63) / 64, (F.v.ny / R + 3) / 4);
-    hipLaunchKernelGGL(k_average_faces_x_all, gx, dim3(64, 4), 0, st, F.v, F.fp.f[SUHMO_F_BX], o, nd);
     dim3 gy((F.v.nx + 63) / 64, ((F.v.ny / 2 + 1 + AVG_YR - 1) / AVG_YR + 3) / 4);
-    hipLaunchKernelGGL(k_average_faces_y_all, gy, dim3(256), 0, st, F.v, F.fp.f[SUHMO_F_BY], o, nd);
+    hipLaunchKernelGGL(k_average_faces_all, dim3(gx.x * gx.y + gy.x * gy.y), dim3(256), 0, st, F.v, F.fp.f[SUHMO_F_BX], F.fp.f[SUHMO_F_BY], o, nd, (int)gx.x, (int)gx.y, (int)gy.x);
     HIPCHK(hipGetLastError());
     // strips: the coarse face coefficients of all depths travel as one message group when the transport can batch
     if (L->ipc) { int rc = suhmo_ipc_batch(L, 1, st); if (rc) return rc; }

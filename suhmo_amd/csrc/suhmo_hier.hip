@@ -132,6 +132,9 @@ struct HLev {
     std::vector<Win> win; double *winbuf = nullptr, *winold = nullptr; size_t winelems = 0; Win *d_win = nullptr; int *d_wing_box = nullptr;
     // field pointer / view tables of the boxes
     std::vector<FP> h_fp; FP *d_fp = nullptr; DV *d_dv = nullptr;
+    // the same table with the two canvases of the head trading places: a relaxation of an odd number of launches inside a V-cycle leaves its
+    // result on the second canvas and makes THAT the head (swap_head) instead of copying it back; the post-smoothing undoes it
+    std::vector<FP> h_fp_alt; FP *d_fp_alt = nullptr; bool swapped = false;
     unsigned long tab_epoch = 0;                                  // suhmo_fp_epoch() the tables were last compared at
     unsigned long long ensured = 0;                               // fields every box is known to have
     int self_wrap = -1;                                            // some box of the level is its own periodic neighbour (-1: not looked at yet)
@@ -454,11 +457,26 @@ __global__ void k_prolong2_win(const Win *__restrict__ wins, const double *__res
 // AMRProlongS_2 of one box per workgroup: the three steps above (gather of the coarse correction into the box's window, physical BC on the
 // window, PROLONG_2_NL) with the window in LDS instead of three launches over a buffer in HBM; the same expressions on the same operands.
 // wstart[k] .. wstart[k + 1]: the gather pieces of box k.  old != NULL: the window gets c - old (see k_win_gather)
+// fc_minus >= 0: the coarse field is 1 fc + (-1) fc_minus formed on the fly (the correction PHI - PHIOLD of a level of boxes leaving its FAS problem),
+// and the workgroups from nk on ARE that leaving (k_fas_leave_m's RHS <- RHS0, CORR <- PHI - PHIOLD on the coarse level's boxes: they write
+// neither PHI nor PHIOLD): one launch instead of two
 __global__ __launch_bounds__(256) void k_prolong2_fused(const WinEnt *__restrict__ e, const int *__restrict__ wstart, const Win *__restrict__ wins, int k0,
                                                         const FP *__restrict__ ctab, const DV *__restrict__ cdv, FP cbase, DV cbdv, int use_base, int fc,
-                                                        const double *__restrict__ old, const FP *__restrict__ ftab, const DV *__restrict__ fdv)
+                                                        const double *__restrict__ old, const FP *__restrict__ ftab, const DV *__restrict__ fdv,
+                                                        int fc_minus, int nk, int cgx, int cgy)
 {
     extern __shared__ double win[];
+    if (fc_minus >= 0 && (int)blockIdx.x >= nk) {
+        const int b = blockIdx.x - nk, bx = b % cgx, by = (b / cgx) % cgy, bz = b / (cgx * cgy);
+        const DV &v = cdv[bz];
+        const FP &f = ctab[bz];
+        const int i = bx * 64 + (int)(threadIdx.x & 63) - 1, j = by * 4 + (int)(threadIdx.x >> 6) - 1;
+        if (i > v.nx || j > v.ny) return;
+        const int idx = cidx(v, i, j);
+        f.f[SUHMO_F_RHS][idx] = f.f[SUHMO_F_RHS0][idx];
+        if (i >= 0 && i < v.nx && j >= 0 && j < v.ny) f.f[SUHMO_F_CORR][idx] = 1.0 * f.f[SUHMO_F_PHI][idx] + -1.0 * f.f[SUHMO_F_PHIOLD][idx];
+        return;
+    }
     const int k = k0 + blockIdx.x, tid = threadIdx.x;
     const Win w = wins[k];
     const int nw = w.nx * w.ny;
@@ -468,10 +486,12 @@ __global__ __launch_bounds__(256) void k_prolong2_fused(const WinEnt *__restrict
         const WinEnt q = e[p];
         const int Pc = use_base ? cbdv.P : cdv[q.cb].P;
         const double *c = fptr(ctab, cbase, use_base, q.cb, fc);
+        const double *cm = fc_minus >= 0 ? fptr(ctab, cbase, use_base, q.cb, fc_minus) : nullptr;
         for (int t = tid; t < q.w * q.h; t += 256) {
             const int J = t / q.w, I = t - J * q.w;
             const int o = q.woff + J * w.nx + I;
-            const double cv = c[q.coff + J * Pc + I];
+            double cv = c[q.coff + J * Pc + I];
+            if (cm) cv = 1.0 * cv + -1.0 * cm[q.coff + J * Pc + I];
             win[o] = old ? 1.0 * cv + -1.0 * old[w.base + o] : cv;
         }
     }
@@ -980,8 +1000,11 @@ int refresh_tables(suhmo_hier *H, int l, hipStream_t st)
         if (memcmp(&V.h_fp[k], &V.box[k]->d[0].fp, sizeof(FP))) { V.h_fp[k] = V.box[k]->d[0].fp; dirty = true; }
     if (!dirty) return 0;
     HIPCHK(hipStreamSynchronize(st));
-    if (!V.d_fp) HIPCHK(hipMalloc(&V.d_fp, nb * sizeof(FP)));
+    if (!V.d_fp) { HIPCHK(hipMalloc(&V.d_fp, nb * sizeof(FP))); HIPCHK(hipMalloc(&V.d_fp_alt, nb * sizeof(FP))); }
     HIPCHK(hipMemcpy(V.d_fp, V.h_fp.data(), nb * sizeof(FP), hipMemcpyHostToDevice));
+    V.h_fp_alt = V.h_fp;
+    for (FP &f : V.h_fp_alt) std::swap(f.f[SUHMO_F_PHI], f.f[SUHMO_F_PHI2]);
+    HIPCHK(hipMemcpy(V.d_fp_alt, V.h_fp_alt.data(), nb * sizeof(FP), hipMemcpyHostToDevice));
     if (!V.d_dv) {
         std::vector<DV> dv(nb);
         for (size_t k = 0; k < nb; k++) dv[k] = V.box[k]->d[0].v;
@@ -991,6 +1014,16 @@ int refresh_tables(suhmo_hier *H, int l, hipStream_t st)
         for (size_t k = 0; k < nb; k++) { V.maxnx = std::max(V.maxnx, dv[k].nx); V.maxny = std::max(V.maxny, dv[k].ny); }
     }
     return 0;
+}
+// the two canvases of the head of a level of boxes trade places: in the boxes' handles and by switching to the table that lists them the other way
+// round (no copy, nothing uploaded; requires SUHMO_F_PHI2 on every box and current tables)
+void swap_head(suhmo_hier *H, int l)
+{
+    HLev &V = H->lev[l];
+    for (suhmo_level *L : V.box) std::swap(L->d[0].fp.f[SUHMO_F_PHI], L->d[0].fp.f[SUHMO_F_PHI2]);
+    std::swap(V.d_fp, V.d_fp_alt);
+    V.h_fp.swap(V.h_fp_alt);
+    V.swapped = !V.swapped;
 }
 int ensure_field(suhmo_hier *H, int l, int field)
 {
@@ -1289,11 +1322,17 @@ int hier_window_save(suhmo_hier *H, int l, int field_c, hipStream_t st)
     HIPCHK(hipGetLastError());
     return 0;
 }
-int hier_prolong2(suhmo_hier *H, int l, int field_c, hipStream_t st, bool minus_saved = false)
+// leave_below (l - 1 >= 1): the level below leaves its FAS problem in the same launch, field_c = PHI minus PHIOLD formed on the fly
+int hier_prolong2(suhmo_hier *H, int l, int field_c, hipStream_t st, bool minus_saved = false, bool leave_below = false)
 {
     HLev &V = H->lev[l];
     int rc;
     CoarseArgs ca;
+    if (leave_below && !(H->fused_prolong && V.win_max <= 6144 && !V.part && !H->lev[l - 1].part && l - 1 >= 1)) {     // two launches after all
+        suhmo_multi mc;
+        if ((rc = multi_of(H, l - 1, st, mc)) || (rc = suhmo_multi_fas_leave(mc, st))) return rc;
+        return hier_prolong2(H, l, SUHMO_F_CORR, st);
+    }
     if ((rc = ensure_field(H, l - 1, field_c)) || (rc = refresh_tables(H, l, st))) return rc;
     if (l == 1 && (rc = refresh_base1(H, field_c, st))) return rc;
     if (l > 1 && V.part && (rc = sync1(H, l - 1, V.sy_win, field_c, st))) return rc;
@@ -1303,9 +1342,18 @@ int hier_prolong2(suhmo_hier *H, int l, int field_c, hipStream_t st, bool minus_
     H->phi_ver[l]++;
     const int k0 = V.part ? V.b0 : 0, nk = V.part ? V.nown : nb;       // (owner computes: the windows of this rank's boxes)
     if (nk <= 0) return 0;
+    if (leave_below) {
+        suhmo_multi mc;
+        if ((rc = multi_of(H, l - 1, st, mc))) return rc;
+        const int cgx = (mc.maxnx + 2 + 63) / 64, cgy = (mc.maxny + 2 + 3) / 4;
+        hipLaunchKernelGGL(k_prolong2_fused, dim3(nk + cgx * cgy * mc.nbox), dim3(256), (size_t)V.win_max * sizeof(double), st, V.wing.d, V.wstart.d, V.d_win, k0,
+                           ca.tab, ca.dv, ca.base, ca.bdv, ca.use_base, (int)SUHMO_F_PHI, (const double *)nullptr, V.d_fp, V.d_dv, (int)SUHMO_F_PHIOLD, nk, cgx, cgy);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (H->fused_prolong && V.win_max <= 6144) {                       // gather + BC + PROLONG_2_NL of a box in one workgroup, the window in LDS
         hipLaunchKernelGGL(k_prolong2_fused, dim3(nk), dim3(256), (size_t)V.win_max * sizeof(double), st, V.wing.d, V.wstart.d, V.d_win, k0,
-                           ca.tab, ca.dv, ca.base, ca.bdv, ca.use_base, field_c, minus_saved ? V.winold : nullptr, V.d_fp, V.d_dv);
+                           ca.tab, ca.dv, ca.base, ca.bdv, ca.use_base, field_c, minus_saved ? V.winold : nullptr, V.d_fp, V.d_dv, -1, nk, 1, 1);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -1376,7 +1424,7 @@ int part_setup(suhmo_hier *H, int l)
     return 0;
 }
 
-int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
+int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s, bool may_swap = false)
 {
     SUHMO_TIME("AMRNonLinearPoissonOp::relaxNF");
     if (l == 0) { H->phi_shadow_fresh = false; H->phi_ver[0]++; H->base_full_ver++; return suhmo_level_gsrb(base_of(H), 0, sweeps, s); }
@@ -1401,7 +1449,10 @@ int hier_gsrb(suhmo_hier *H, int l, int sweeps, suhmo_stream_t s)
             std::swap(src, dst);
             H->phi_ver[l]++; H->n_fused_relax++;
         }
-        if (src != SUHMO_F_PHI && (rc = suhmo_multi_copy(m, SUHMO_F_PHI, SUHMO_F_PHI2, HST(s)))) return rc;     // (an odd number of launches)
+        if (src != SUHMO_F_PHI) {                          // an odd number of launches: the result is on the second canvas
+            if (may_swap && Vf.d_fp_alt) swap_head(H, l);  // (inside a V-cycle: that canvas becomes the head; vcycle_amr puts things back)
+            else if ((rc = suhmo_multi_copy(m, SUHMO_F_PHI, SUHMO_F_PHI2, HST(s)))) return rc;
+        }
         return bcg ? 0 : suhmo_multi_fill_ghosts(m, SUHMO_F_PHI, 1, HST(s));                                  // :757-759
     }
     // exchange() before every colour pass (:692, :751): once here (unless the side ghosts are current), then every pass pushes
@@ -1626,7 +1677,7 @@ int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stre
     int rc;
     if ((rc = cf_phi(H, l, s))) return rc;
     if (sp->bcoeff_otf && (rc = hier_update_operator(H, l, s))) return rc;
-    if ((rc = hier_gsrb(H, l, sp->num_smooth, s))) return rc;                                 // relaxNF
+    if ((rc = hier_gsrb(H, l, sp->num_smooth, s, true))) return rc;                           // relaxNF
     if ((rc = hier_avg(H, l, SUHMO_F_PHI, SUHMO_F_PHI, 0, 0.0, HST(s)))) return rc;           // AMRRestrictS(skip_res)
     if (levels_mergeable(H)) { if ((rc = levels_residual(H, l, l - 1, true, s))) return rc; }
     else {
@@ -1664,13 +1715,23 @@ int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stre
     } else if ((rc = vcycle_amr(H, l - 1, sp, s))) return rc;
     if (l - 1 == 0) { rhs_aside.back(); rc = hier_prolong2(H, l, SUHMO_F_PHI, HST(s), true); }                // AMRProlongS_2 of phi - phi_saved
     else {                                                                                    // RHS <- RHS0, CORR <- PHI - PHIOLD: one launch
-        suhmo_multi mc;
-        if ((rc = ensure_field(H, l - 1, SUHMO_F_CORR)) || (rc = multi_of(H, l - 1, HST(s), mc)) || (rc = suhmo_multi_fas_leave(mc, HST(s)))) return rc;
-        rc = hier_prolong2(H, l, SUHMO_F_CORR, HST(s));
+        if ((rc = ensure_field(H, l - 1, SUHMO_F_CORR))) return rc;
+        if (H->merged_launches) rc = hier_prolong2(H, l, SUHMO_F_PHI, HST(s), false, true);      // leaving and prolongation in one launch
+        else {
+            suhmo_multi mc;
+            if ((rc = multi_of(H, l - 1, HST(s), mc)) || (rc = suhmo_multi_fas_leave(mc, HST(s)))) return rc;
+            rc = hier_prolong2(H, l, SUHMO_F_CORR, HST(s));
+        }
     }
     if (rc) return rc;
     if ((rc = cf_phi(H, l, s))) return rc;
-    return hier_gsrb(H, l, sp->num_smooth, s);
+    if ((rc = hier_gsrb(H, l, sp->num_smooth, s, true))) return rc;
+    if (H->lev[l].swapped) {                               // (an odd number of odd relaxations: the head goes back to its own canvas by a copy after all)
+        suhmo_multi m;
+        if ((rc = multi_of(H, l, HST(s), m)) || (rc = suhmo_multi_copy(m, SUHMO_F_PHI2, SUHMO_F_PHI, HST(s)))) return rc;
+        swap_head(H, l);
+    }
+    return 0;
 }
 }  // namespace
 // MAX over the ranks of a value every rank computed on the boxes it owns (through the all-reduce of the base strip)
@@ -1715,6 +1776,7 @@ extern "C" int suhmo_hier_destroy(suhmo_hier_t *H)
         if (V.d_win) (void)hipFree(V.d_win);
         if (V.d_wing_box) (void)hipFree(V.d_wing_box);
         if (V.d_fp) (void)hipFree(V.d_fp);
+        if (V.d_fp_alt) (void)hipFree(V.d_fp_alt);
         if (V.d_dv) (void)hipFree(V.d_dv);
         if (V.d_red) (void)hipFree(V.d_red);
         for (Sync *S : {&V.sy_side[0], &V.sy_side[1], &V.sy_sides, &V.sy_all, &V.sy_cread, &V.sy_win, &V.sy_fface}) S->release();

@@ -2,7 +2,7 @@ cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 python3 tools/hier_bench.py 256 20 > gpurun_out/r04_n_hier256.txt 2>&1; cat gpurun_out/r04_n_hier256.txt
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r04_n_prof -o h -- python3 $R/tools/hier_bench.py 256 10 > $R/gpurun_out/r04_n_prof.log 2>&1
+SUHMO_GRAPH_MAX_CELLS=0 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r04_n_prof -o h -- python3 $R/tools/hier_bench.py 256 10 > $R/gpurun_out/r04_n_prof.log 2>&1
 cd $R
 T=$(ls gpurun_out/r04_n_prof/*kernel_trace.csv gpurun_out/r04_n_prof/*/*kernel_trace.csv 2>/dev/null | head -1)
 python3 tools/trace_busy.py $T 0.4 > gpurun_out/r04_n_busy.txt 2>&1
