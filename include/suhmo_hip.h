@@ -421,9 +421,12 @@ int suhmo_hier_create(suhmo_hier_t **out, const suhmo_level_desc_t *base, int nl
  * a cycle over the whole of level 0 (default 1: inside suhmo_hier_solve the residual evaluated for the stopping rule serves the next
  * cycle except in the cells the average from level 1 changed, and level 0's gradient is evaluated only where level 1's coarse-fine
  * interpolation reads it -- the same bits, two passes over level 0 less per cycle).  fused_relax = 0: a launch per colour pass on the levels
- * of boxes (default 1: two sweeps per launch, a box's 16 x 16 tiles advancing the 4 cells around them from the neighbours' canvases;
- * read-only counter fused_relax_launches); fused_prolong = 0: AMRProlongS_2 as three launches (default: one workgroup per box).  These four
- * can also be changed later (suhmo_hier_set_option).
+ * of boxes (default 1: up to four sweeps per launch, a box's 16 x 16 tiles advancing the 8 cells around them from the neighbours' canvases;
+ * box_sweeps = 2: two sweeps per launch on 4 cells; read-only counter fused_relax_launches); fused_prolong = 0: AMRProlongS_2 as three
+ * launches (default: one workgroup per box); merged_launches = 0: a launch for either kind of ghost cell, for the gradient and its ghosts, for Re
+ * and bCoef, per level for ghosts / operator / reflux / norm, a read-back per level's norm, the closing ghost fill and the leaving of a FAS problem on
+ * their own (default 1: one launch each, several levels per launch where nothing orders them -- the same bits).  These can also be changed later
+ * (suhmo_hier_set_option).
  * partition_min_cells = n (rank strips; default 350000): when the largest level >= 1 holds at least n cells PER RANK the levels >= 1 are dealt to the ranks, the boxes
  * of a level in the order given cut into runs of about equal cell counts (the reference: LoadBalance(procIDs, grids),
  * src/AmrHydro.cpp:4283, 4929).  OWNER COMPUTES: every pass over such a level runs on the owner's boxes only and only they (plus mirrors
