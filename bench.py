@@ -223,6 +223,7 @@ def main():
                        "global_cells": [n, ny_global], "partition": "row strips, 1 per GPU" if world > 1 else "none",
                        # N > 1: the halo transport in use and the number of ranks its communicator reports (ncclCommCount), so that N can be verified
                        "transport": transport_name(G) if world > 1 else None,
+                       "transport_probe": getattr(G, "_ipc_probe", None) if world > 1 else None,
                        "ranks_in_communicator": int(capi.lib().suhmo_level_rccl_comm_count(G.h)) if world > 1 else None,
                        "unit_of_value": "V-cycles over %dx%d cells (%s; the level of %dx%d cells completes %.4g V-cycles/s)"
                                         % (n, n, "the whole level, cut into strips" if strong else "one per GPU per step", n, ny_global, vps),

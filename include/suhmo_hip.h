@@ -339,6 +339,7 @@ int suhmo_level_rccl_comm_count(const suhmo_level_t *L);   /* ranks the level's 
 int suhmo_level_ipc_export(suhmo_level_t *L, void *blob128);
 int suhmo_level_attach_ipc(suhmo_level_t *L, int rank, int world, int periodic_y, const void *blob_lo, const void *blob_hi);
 long suhmo_level_ipc_exchanges(const suhmo_level_t *L);   /* halo messages sent so far; -1: not attached */
+int suhmo_level_detach_ipc(suhmo_level_t *L);               /* back to the transport the level had before suhmo_level_attach_ipc; the arena is unmapped and freed */
 
 /* ---- two AMR levels: base level `coarse` (spans the domain) + one patch `fine` refined by 2, created with
  * desc.i0 / nx_global / j0 / ny_global = its place in the refined domain (coarse-aligned), dx = coarse dx / 2.

@@ -70,7 +70,7 @@ SYMBOLS = [
     "suhmo_level_unpack_rows", "suhmo_level_set_hooks", "suhmo_level_exchange", "suhmo_level_halo_info", "suhmo_level_profile_reset",
     "suhmo_level_profile_enable", "suhmo_level_profile_read", "suhmo_level_profile_read_restricting", "suhmo_level_timestep",
     "suhmo_rccl_load", "suhmo_rccl_unique_id", "suhmo_level_attach_rccl", "suhmo_level_detach_rccl",
-    "suhmo_level_rccl_exchanges", "suhmo_level_rccl_comm_count", "suhmo_level_ipc_export", "suhmo_level_attach_ipc", "suhmo_level_ipc_exchanges",
+    "suhmo_level_rccl_exchanges", "suhmo_level_rccl_comm_count", "suhmo_level_ipc_export", "suhmo_level_attach_ipc", "suhmo_level_ipc_exchanges", "suhmo_level_detach_ipc",
     "suhmo_amr2_cf_interp", "suhmo_amr2_average", "suhmo_amr2_fine_update_operator", "suhmo_amr2_residual",
     "suhmo_amr2_vcycle", "suhmo_amr2_solve", "suhmo_level_moulin_source", "suhmo_amr2_prolong2", "suhmo_amr2_set_covered",
     "suhmo_amr_residual", "suhmo_amr_vcycle", "suhmo_amr_solve", "suhmo_level_postproc_table", "suhmo_level_postproc_partial", "suhmo_postproc_finish", "suhmo_postproc_temporal", "suhmo_level_postproc_temporal",
@@ -150,6 +150,7 @@ def lib():
     L.suhmo_level_ipc_export.argtypes = [vp, vp]
     L.suhmo_level_attach_ipc.argtypes = [vp, ci, ci, ci, vp, vp]
     L.suhmo_level_ipc_exchanges.argtypes = [vp]
+    L.suhmo_level_detach_ipc.argtypes = [vp]
     L.suhmo_level_ipc_exchanges.restype = C.c_long
     L.suhmo_level_moulin_source.argtypes = [vp, ci, dp, dp, dp, C.c_double, dp, vp]
     L.suhmo_level_postproc_table.argtypes = [vp, C.POINTER(ModelParams), dp, vp]

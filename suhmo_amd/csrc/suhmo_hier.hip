@@ -2170,7 +2170,11 @@ static int hier_residual_(suhmo_hier *H, double *norm, suhmo_stream_t s)
         const double *lists[2];
         int np[2];
         suhmo_lvboxes lv;
-        if ((rc = suhmo_level_norm_max_cover_partials(base_of(H), SUHMO_F_RES, &lists[0], &np[0], HST(s)))) return rc;
+        // level 0: a large one is not read a second time for its cover -- its covered rectangles are zeroed by their list (one small launch), then the
+        // plain first stage; a small one zeroes as it reduces, like the levels of boxes
+        if (base_of(H)->d[0].elems > (1 << 20)) {
+            if ((rc = hier_avg(H, 1, SUHMO_F_RES, SUHMO_F_RES, 1, 0.0, HST(s))) || (rc = suhmo_level_norm_max_partials(base_of(H), SUHMO_F_RES, &lists[0], &np[0], HST(s)))) return rc;
+        } else if ((rc = suhmo_level_norm_max_cover_partials(base_of(H), SUHMO_F_RES, &lists[0], &np[0], HST(s)))) return rc;
         if ((rc = levels_boxes(H, 1, top, 0, 1, s, lv)) || (rc = suhmo_levels_norm_max_cover_partials(lv, SUHMO_F_RES, H->red_all, &np[1], HST(s)))) return rc;
         lists[1] = H->red_all;
         return norm ? suhmo_norm_max_of_lists(base_of(H), lists, np, 2, norm, HST(s)) : 0;

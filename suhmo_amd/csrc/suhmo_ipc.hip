@@ -39,6 +39,7 @@ struct IpcStrip {
     unsigned long long *herr = nullptr, *herr_dev = nullptr;                   // pinned: a kernel whose wait ran out says so here
     int nblk[SUHMO_MAXDEPTH + 1][2] = {};                                      // workgroups of the last message on each slot of a channel
     long exchanges = 0;
+    suhmo_exchange_fn prev_ex = nullptr; int (*prev_begin)(void *) = nullptr; int (*prev_end)(void *, suhmo_level *, suhmo_stream_t) = nullptr; bool hooked = false;   // what suhmo_level_attach_ipc replaced
     int max_blocks = GMAX;                                                     // workgroups per exchange launch at most (env SUHMO_IPC_BLOCKS: A/B runs)
 };
 
@@ -336,7 +337,19 @@ extern "C" int suhmo_level_attach_ipc(suhmo_level_t *L, int rank, int world, int
         if (e != hipSuccess) { (void)hipGetLastError(); suhmo_set_error("ipc transport: hipIpcOpenMemHandle -> %s", hipGetErrorString(e)); return -7; }
         S->remote[k] = (char *)p; S->mapped[k] = true;
     }
+    if (!S->hooked) { S->prev_ex = L->ex; S->prev_begin = L->ex_begin; S->prev_end = L->ex_end; S->hooked = true; }
     L->ex = ipc_exchange_hook; L->ex_begin = nullptr; L->ex_end = nullptr;
+    return 0;
+}
+// back to the transport the level had before suhmo_level_attach_ipc (a host that probes the peer-direct path and finds it wanting on some rank:
+// suhmo_amd.multigpu.attach); the arena is unmapped and freed.  Not while a gap-height operator or another handle shares the attachment.
+extern "C" int suhmo_level_detach_ipc(suhmo_level_t *L)
+{
+    ARG(L);
+    IpcStrip *S = (IpcStrip *)L->ipc;
+    if (!S) return 0;
+    if (S->hooked) { L->ex = S->prev_ex; L->ex_begin = S->prev_begin; L->ex_end = S->prev_end; }
+    ipc_release(L);
     return 0;
 }
 extern "C" long suhmo_level_ipc_exchanges(const suhmo_level_t *L) { return (L && L->ipc) ? ((IpcStrip *)L->ipc)->exchanges : -1; }

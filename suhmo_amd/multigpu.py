@@ -329,18 +329,73 @@ def ipc_attach(level, rank, world, periodic_y, blobs):
         "rccl" if getattr(level, "_exchanger", None) == "rccl" else "host hooks")
 
 
-def attach_ipc(level, dist, rank, world, periodic_y=False):
-    """COLLECTIVE: every rank exports its arena, the blobs travel by torch.distributed all_gather, every rank maps its neighbours'"""
+def _all_ok(dist, ok, dev):
     import torch
-    mine = ipc_export(level)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return int(flag.item()) == 1
+
+
+def attach_ipc(level, dist, rank, world, periodic_y=False, probe=False):
+    """COLLECTIVE: every rank exports its arena, the blobs travel by torch.distributed all_gather, every rank maps its neighbours'.
+    probe: do not raise when a step fails on some rank or the first messages do not arrive intact -- every rank then goes back to the
+    transport it had (suhmo_level_detach_ipc) and False is returned; three single-field messages of rank-coded values are checked row by row."""
+    import torch
+    import numpy as np
+    from .level import F_CORR
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    err = None
+    try:
+        if probe and os.environ.get("SUHMO_IPC_PROBE_FAIL_RANK") == str(rank):      # fault injection (tests of the fallback)
+            raise RuntimeError("failure injected on rank %d" % rank)
+        mine = ipc_export(level)
+    except Exception as e:
+        if not probe:
+            raise
+        mine, err = bytes(128), e
     t = torch.tensor(list(mine), dtype=torch.uint8, device=dev)
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t)
     blobs = [bytes(o.cpu().tolist()) for o in out]
-    ipc_attach(level, rank, world, periodic_y, blobs)
+    if err is None:
+        try:
+            ipc_attach(level, rank, world, periodic_y, blobs)
+        except Exception as e:
+            if not probe:
+                raise
+            err = e
+    if probe and not _all_ok(dist, err is None, dev):
+        check(capi.lib().suhmo_level_detach_ipc(level.h))
+        level._transport = None
+        level._ipc_probe = "peer-direct transport not available: %s" % (err if err is not None else "another rank could not map its neighbours")
+        dist.barrier()
+        return False
     dist.barrier()                        # every arena is mapped before anybody stores into one
-    return level
+    if probe:
+        lo = rank - 1 if rank > 0 else (world - 1 if periodic_y else None)
+        hi = rank + 1 if rank < world - 1 else (0 if periodic_y else None)
+        good = True
+        try:
+            for rnd in range(3):          # (three messages: both slots of the channel and the first acknowledgement are exercised)
+                level.set_value(F_CORR, 1000.0 * (rnd + 1) + rank)
+                check(capi.lib().suhmo_level_exchange(level.h, 0, F_CORR, level.stream))
+                a = level.get(F_CORR, ghosted=True)
+                if lo is not None:
+                    good = good and bool(np.all(a[0, 1:-1] == 1000.0 * (rnd + 1) + lo))
+                if hi is not None:
+                    good = good and bool(np.all(a[-1, 1:-1] == 1000.0 * (rnd + 1) + hi))
+        except Exception as e:
+            good, err = False, e
+        if not _all_ok(dist, good, dev):
+            dist.barrier()                # nobody unmaps while a neighbour may still store
+            check(capi.lib().suhmo_level_detach_ipc(level.h))
+            level._transport = None
+            level._ipc_probe = "peer-direct messages did not arrive intact on some rank (%s)" % (err if err is not None else "values differ")
+            dist.barrier()
+            return False
+        level.set_value(F_CORR, 0.0)
+        level._ipc_probe = "three probe messages arrived intact on every rank"
+    return True
 
 
 def attach(level, dist, rank, world, periodic_y=False):
@@ -348,7 +403,7 @@ def attach(level, dist, rank, world, periodic_y=False):
     the native RCCL transport (SUHMO_TRANSPORT=torch forces the torch.distributed P2P one);
     other backends (gloo in CPU-side tests): torch.distributed P2P.  Returns the exchanger."""
     import torch
-    if dist.get_backend() == "nccl" and os.environ.get("SUHMO_TRANSPORT", "rccl") != "torch":
+    if dist.get_backend() == "nccl" and os.environ.get("SUHMO_TRANSPORT", "auto") != "torch":
         # every rank must end up on the same transport: agree that librccl could be loaded everywhere BEFORE the
         # collective part (id broadcast, ncclCommInitRank) starts
         ok, err = 1, None
@@ -361,8 +416,13 @@ def attach(level, dist, rank, world, periodic_y=False):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
             attach_rccl(level, rank, world, periodic_y, dist)
-            if os.environ.get("SUHMO_TRANSPORT") == "ipc":         # halo rows peer-direct; RCCL stays for reductions and all-gathers
+            # halo rows peer-direct, RCCL stays for reductions and all-gathers.  "ipc": insist; default ("auto"): probe -- map the neighbours,
+            # send three checked messages -- and stay on RCCL's send / recv when any rank reports a failure; "rccl": do not try
+            how = os.environ.get("SUHMO_TRANSPORT", "auto")
+            if how == "ipc":
                 attach_ipc(level, dist, rank, world, periodic_y)
+            elif how == "auto":
+                attach_ipc(level, dist, rank, world, periodic_y, probe=True)
             return level
         import sys
         print("suhmo_amd.multigpu: native RCCL transport unavailable (%s); falling back to torch.distributed P2P"
@@ -371,8 +431,9 @@ def attach(level, dist, rank, world, periodic_y=False):
     ex = StripExchanger(level, tr, rank, world, periodic_y)
     level._exchanger = ex
     ex.exchange_static()
-    if os.environ.get("SUHMO_TRANSPORT") == "ipc":                 # (gloo rehearsal: the halo rows peer-direct, reductions through the host hooks)
-        attach_ipc(level, dist, rank, world, periodic_y)
+    how = os.environ.get("SUHMO_TRANSPORT")                        # (gloo rehearsal: the halo rows peer-direct, reductions through the host hooks;
+    if how in ("ipc", "ipc-probe"):                                #  ipc-probe: as the default on the nccl backend, with the fallback)
+        attach_ipc(level, dist, rank, world, periodic_y, probe=how == "ipc-probe")
     return ex
 
 

@@ -57,6 +57,8 @@ def test_two_ranks_over_nccl_bitwise(tool, args):
 
 @pytest.mark.parametrize("tool,args,world,agg", [("shmip_dist.py", ["--case", "A3", "--scale", "2", "--steps", "6", "--check", "--ipc"], 2, 0),
                                                  ("shmip_dist.py", ["--case", "B3", "--scale", "1", "--steps", "4", "--check", "--ipc"], 4, 3000),
+                                                 ("shmip_dist.py", ["--case", "A3", "--scale", "2", "--steps", "4", "--check", "--ipc-probe"], 2, 0),
+                                                 ("shmip_dist.py", ["--case", "A3", "--scale", "2", "--steps", "4", "--check", "--ipc-probe-fails"], 2, 0),
                                                  ("amr_shmip_dist.py", ["--case", "B5", "--steps", "6", "--check"], 2, 0),
                                                  ("shmip_dist.py", ["--case", "B3", "--scale", "1", "--steps", "6", "--check"], 4, 0),
                                                  ("hier_dist.py", ["--base", "256", "--steps", "2", "--check"], 2, 0),
@@ -85,7 +87,13 @@ def test_rank_strips_as_processes(tool, args, world, agg):
                    SUHMO_DUMP_AFTER="240", GLOO_SOCKET_IFNAME="lo")                                                            # a rank that hangs says where before it is killed
         if "--ipc" in args:            # the halo rows peer-direct between the PROCESSES (hipIpcGetMemHandle / hipIpcOpenMemHandle of each other's arenas on
             env["SUHMO_TRANSPORT"] = "ipc"     # the one GPU of the test box), reductions and all-gathers over gloo
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", tool)] + [a for a in args if a != "--ipc"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        # --ipc-probe: what multigpu.attach does by default on the nccl backend: map, send three checked messages, keep the peer-direct path only if
+        # every rank saw them intact; --ipc-probe-fails: rank 1 reports a failure, every rank goes back to the transport it had (and the run is still bitwise)
+        if "--ipc-probe" in args or "--ipc-probe-fails" in args:
+            env["SUHMO_TRANSPORT"] = "ipc-probe"
+            if "--ipc-probe-fails" in args:
+                env["SUHMO_IPC_PROBE_FAIL_RANK"] = "1"
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", tool)] + [a for a in args if not a.startswith("--ipc")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     import time
     deadline = time.time() + 300
@@ -102,3 +110,7 @@ def test_rank_strips_as_processes(tool, args, world, agg):
     logs = [p.communicate()[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-2000:] for l in logs)
     assert "BITWISE EQUAL" in logs[0]
+    if "--ipc-probe" in args:
+        assert "three probe messages arrived intact on every rank -> ipc" in logs[0], logs[0][-1500:]
+    if "--ipc-probe-fails" in args:
+        assert "peer-direct transport not available" in logs[0] and "-> the transport it had" in logs[0], logs[0][-1500:]

@@ -58,6 +58,8 @@ def main():
     G.set_state({k: (v[j0:j0 + nyl + 2] if isinstance(v, np.ndarray) else v) for k, v in st.items()})
     if world > 1:
         multigpu.attach(G.level, dist, rank, world, periodic_y=False)
+        if rank == 0 and getattr(G.level, "_ipc_probe", None):
+            print("transport probe: %s -> %s" % (G.level._ipc_probe, getattr(G.level, "_transport", None) or "the transport it had"), flush=True)
     if m.get("use_moulin_source"):
         G.moulin_source(m["moulin_position"], m["moulin_sigma"], m["moulin_flux"], 1.0)
     dist.barrier()
