@@ -115,95 +115,115 @@ int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool h
 // view -- at a re-entrant corner of the union a position is the x-ghost of one box and the y-ghost of another, and each reader gets its own.
 // Every update is d_gsrb_pass_simple's expression on the same operands in the same order, so the result is the colour passes' with an
 // exchange before each, bit for bit; a launch reads canvases no workgroup of the launch writes (PHI -> PHI2, then PHI2 -> PHI).
-#define BOXT 16            // a workgroup takes a 16 x 16 tile of its box (24 x 24 with a halo of 4: the redundant updates buy 16 times the workgroups of one per box)
-// G: the halo the launch advances through = the sweeps it can do (G = 4: two sweeps, 24 x 24 image on 320 threads; G = 8: FOUR sweeps -- a whole
-// pre- or post-smoothing of the reference's num_smooth = 4 -- on a 32 x 32 image and 512 threads: the eight passes cost less than two launches'
-// fixed parts).  Threads: one cell of EACH colour per thread.  The plan `halo` is laid out for SUHMO_BOX_HALO = 8 cells around every box.
-template <int G> struct BoxGeom { static constexpr int LW = BOXT + 2 * G, NT = ((LW * LW / 2 + 63) / 64) * 64; };
-template <bool HAS_ALPHA, int G>
-__global__ __launch_bounds__(BoxGeom<G>::NT) void k_gsrb_box_m(const DV *__restrict__ vt, const FP *__restrict__ ft, const int2 *__restrict__ halo, const int *__restrict__ hbase,
-                                                      suhmo_phys_t ph, int fsrc, int fdst, int npass, int bcg)
+// G: the halo the launch advances through = the sweeps it can do (G = 4: two sweeps; G = 8: FOUR sweeps -- a whole pre- or post-smoothing of the
+// reference's num_smooth = 4 -- in one launch: the eight passes cost less than two launches' fixed parts).  T: the tile edge at most (a box is cut
+// into ceil(n / T) tiles of equal width per direction).  Threads keep S positions of EACH colour of the tile's image.  T = 16, S = 1 (320 / 512
+// threads): many small workgroups -- what levels of small boxes want (cfg5, ~28 x 28 cells per box: 16.8 ms per step against 20.5 with T = 32,
+// although a 28 x 28 box as four tiles with their halos is 3600 positions and as one tile 1936: the ~200 boxes of a level do not fill 256 CUs with
+// one workgroup each, and a wave with two updates per pass has twice the dependent chain).  T = 32, S = 2 (48 x 48 image on 576 threads): levels
+// with a thousand tiles and more, where the redundant halo updates are what the launch spends its time on (one box of 1024 x 256: 3.22 against 3.32
+// ms per step; `profiles/r04_w_box_tile_ab.txt`).  The plan `halo` is laid out for SUHMO_BOX_HALO = 8 cells around every box.
+template <int G, int T, int S> struct BoxGeom { static constexpr int LW = T + 2 * G, NT = (((LW * LW / 2 + S - 1) / S + 63) / 64) * 64; };
+template <bool HAS_ALPHA, int G, int T, int S>
+__global__ __launch_bounds__((BoxGeom<G, T, S>::NT)) __attribute__((amdgpu_waves_per_eu(1, 3))) void k_gsrb_box_m(const DV *__restrict__ vt, const FP *__restrict__ ft, const int2 *__restrict__ halo, const int *__restrict__ hbase,
+                                                                     suhmo_phys_t ph, int fsrc, int fdst, int npass, int bcg)
 {
-    constexpr int BOXG = G, BOXNT = BoxGeom<G>::NT, HG = SUHMO_BOX_HALO;
-    constexpr int LWmax = BOXT + 2 * BOXG;
+    constexpr int BOXG = G, BOXNT = BoxGeom<G, T, S>::NT, HG = SUHMO_BOX_HALO;
+    constexpr int LWmax = T + 2 * BOXG;
     __shared__ double pl[LWmax * LWmax];
     __shared__ int own[LWmax * LWmax];
     const int k = blockIdx.y, tid = threadIdx.x;
-    const DV v = vt[k];
-    const int tiles_x = (v.nx + BOXT - 1) / BOXT, tiles_y = (v.ny + BOXT - 1) / BOXT;
+    const DV &v = vt[k];                                               // (uniform: scalar loads, not a copy per lane)
+    const int tiles_x = (v.nx + T - 1) / T, tiles_y = (v.ny + T - 1) / T;
     if ((int)blockIdx.x >= tiles_x * tiles_y) return;
     const int tj = blockIdx.x / tiles_x, ti = blockIdx.x - tj * tiles_x;
-    const int x0 = ti * BOXT, y0 = tj * BOXT;                          // the tile's first cell in the box = its halo's first position in the extended box
-    const int tw = min(BOXT, v.nx - x0), th = min(BOXT, v.ny - y0);
+    const int twb = (v.nx + tiles_x - 1) / tiles_x, thb = (v.ny + tiles_y - 1) / tiles_y;      // tiles of equal size (the last one may be smaller)
+    const int x0 = ti * twb, y0 = tj * thb;                            // the tile's first cell in the box = its halo's first position in the extended box
+    const int tw = min(twb, v.nx - x0), th = min(thb, v.ny - y0);
+    if (tw <= 0 || th <= 0) return;
     const int LW = tw + 2 * BOXG, LH = th + 2 * BOXG, EW = v.nx + 2 * HG, HW = (LW + 1) / 2;
     const int2 *__restrict__ hk = halo + hbase[k];
     const FP &fk = ft[k];
-    // A thread keeps ONE position of each colour of the tile's image through all passes (slot c: (i + j) & 1 == c, global indices; the colour
+    // A thread keeps S positions of each colour of the tile's image through all passes (slot [s][c]: (i + j) & 1 == c, global indices; the colour
     // of a position follows from where the image lies, a periodic image keeps its parity), with everything about it that does not change: the
-    // cell's box and offset, its coefficients, how far from the tile it lies.  A pass runs the slot of its colour: no lane idles for its colour.
+    // cell's box and offset, its coefficients, how far from the tile it lies.  A pass runs the slots of its colour: no lane idles for its colour.
     // One load phase of three dependent steps: the plan entry -> the box's view and field pointers (its own box: none) -> head and coefficients.
     const int par0 = (v.i0 + x0 - BOXG + v.j0 + y0 - BOXG) & 1;          // colour of the image's position (0, 0)
-    int cq[2], cb[2], co[2], cd[2];                // position in the image (-1: none), box (-1: not advanced), canvas offset, distance from the tile
-    double c_rhs[2], c_bxW[2], c_bxE[2], c_byS[2], c_byN[2], c_B[2], c_Pi[2], c_zb[2], c_mk[2], c_at[2];
-    int2 hq[2];
+    int cq[S][2], cb[S][2], co[S][2], cd[S][2];    // position in the image (-1: none), box (-1: not advanced), canvas offset, distance from the tile
+    double c_rhs[S][2], c_bxW[S][2], c_bxE[S][2], c_byS[S][2], c_byN[S][2], c_B[S][2], c_Pi[S][2], c_zb[S][2], c_mk[S][2], c_at[S][2];
+    int2 hq[S][2];
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        cq[c] = -1; hq[c] = int2{-1, 0};
-        if (tid < LH * HW) {
-            const int lj = tid / HW, li = 2 * (tid - lj * HW) + ((lj + par0 + c) & 1);
-            if (li < LW) { cq[c] = lj * LW + li; hq[c] = hk[(y0 + lj + HG - BOXG) * EW + x0 + li + HG - BOXG]; }
-        }
-    }
+    for (int s = 0; s < S; s++)
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const int q = cq[c];
-        cb[c] = -1; co[c] = 0; cd[c] = 0;
-        c_rhs[c] = c_bxW[c] = c_bxE[c] = c_byS[c] = c_byN[c] = c_B[c] = c_Pi[c] = c_zb[c] = c_mk[c] = c_at[c] = 0.0;
-        if (q < 0) continue;
-        const int b = hq[c].x, off = hq[c].y;
-        own[q] = b;
-        if (b < 0) { pl[q] = 0.0; continue; }
-        const int lj = q / LW, li = q - lj * LW;
-        const int dx = li < BOXG ? BOXG - li : (li >= BOXG + tw ? li - (BOXG + tw - 1) : 0), dy = lj < BOXG ? BOXG - lj : (lj >= BOXG + th ? lj - (BOXG + th - 1) : 0);
-        const int d = max(dx, dy);
-        const FP &fb = b == k ? fk : ft[b];
-        if (d >= BOXG) { pl[q] = fb.f[fsrc][off]; continue; }        // (the outermost ring is only read)
-        const int Pb = b == k ? v.P : vt[b].P;
-        cb[c] = b; co[c] = off; cd[c] = d;
-        pl[q] = fb.f[fsrc][off];
-        c_rhs[c] = fb.f[SUHMO_F_RHS][off];
-        c_bxW[c] = fb.f[SUHMO_F_BX][off]; c_bxE[c] = fb.f[SUHMO_F_BX][off + 1];
-        c_byS[c] = fb.f[SUHMO_F_BY][off]; c_byN[c] = fb.f[SUHMO_F_BY][off + Pb];
-        c_B[c] = fb.f[SUHMO_F_B][off]; c_Pi[c] = fb.f[SUHMO_F_PI][off]; c_zb[c] = fb.f[SUHMO_F_ZB][off]; c_mk[c] = fb.f[SUHMO_F_MASK][off];
-        c_at[c] = HAS_ALPHA ? v.alpha * fb.f[SUHMO_F_ACOEF][off] : v.alpha;      // (alpha, beta, the cell sizes and the BC data are the level's: every box's view has them)
-    }
-    __syncthreads();
-    for (int m = 0; m < npass; m++) {
-        const int u = m & 1, reach = npass - 1 - m;                      // the pass advances the cells of colour u within `reach` of the tile
-        const int b = u ? cb[1] : cb[0];
-        if (b >= 0 && (u ? cd[1] : cd[0]) <= reach) {
-            const int q = u ? cq[1] : cq[0], off = u ? co[1] : co[0];
-            const double c = pl[q];
-            // a neighbour that is a cell of the level: its current value; else what the cell's own box holds there (coarse-fine ghost / physical BC)
-            double w, e, s, n;
-            if (own[q - 1] >= 0 && own[q + 1] >= 0 && own[q - LW] >= 0 && own[q + LW] >= 0) { w = pl[q - 1]; e = pl[q + 1]; s = pl[q - LW]; n = pl[q + LW]; }
-            else {
-                const DV &vb = b == k ? v : vt[b];
-                const double *__restrict__ psrc = (b == k ? fk : ft[b]).f[fsrc];
-                const int j = off / vb.P - vb.gy, i = off - (j + vb.gy) * vb.P - SUHMO_XOFF;
-                w = own[q - 1] >= 0 ? pl[q - 1] : phiW(vb, psrc, off, i, c, false);
-                e = own[q + 1] >= 0 ? pl[q + 1] : phiE(vb, psrc, off, i, c, false);
-                s = own[q - LW] >= 0 ? pl[q - LW] : phiS(vb, psrc, off, j, c, false);
-                n = own[q + LW] >= 0 ? pl[q + LW] : phiN(vb, psrc, off, j, c, false);
+        for (int c = 0; c < 2; c++) {
+            cq[s][c] = -1; hq[s][c] = int2{-1, 0};
+            const int p = tid + s * BOXNT;
+            if (p < LH * HW) {
+                const int lj = p / HW, li = 2 * (p - lj * HW) + ((lj + par0 + c) & 1);
+                if (li < LW) { cq[s][c] = lj * LW + li; hq[s][c] = hk[(y0 + lj + HG - BOXG) * EW + x0 + li + HG - BOXG]; }
             }
-            const double rhs = u ? c_rhs[1] : c_rhs[0], bxW = u ? c_bxW[1] : c_bxW[0], bxE = u ? c_bxE[1] : c_bxE[0], byS = u ? c_byS[1] : c_byS[0], byN = u ? c_byN[1] : c_byN[0];
-            const double at = u ? c_at[1] : c_at[0];
-            double nl, dnl;
-            nl_terms(ph, c, u ? c_B[1] : c_B[0], u ? c_Pi[1] : c_Pi[0], u ? c_zb[1] : c_zb[0], u ? c_mk[1] : c_mk[0], nl, dnl);
-            const double lofphi = lofphi_cell(v, at, c, e, w, n, s, bxE, bxW, byN, byS, nl);
-            const double lam = lambda_cell(v, at, bxE, bxW, byN, byS);
-            const double denom = 1.0e-16 + lam + dnl;                      // ...OpF.ChF:154
-            pl[q] = c + (rhs - lofphi) / denom;                            // :156 (a cell of one colour reads cells of the other only: in place)
+        }
+#pragma unroll
+    for (int s = 0; s < S; s++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int q = cq[s][c];
+            cb[s][c] = -1; co[s][c] = 0; cd[s][c] = 0;
+            c_rhs[s][c] = c_bxW[s][c] = c_bxE[s][c] = c_byS[s][c] = c_byN[s][c] = c_B[s][c] = c_Pi[s][c] = c_zb[s][c] = c_mk[s][c] = c_at[s][c] = 0.0;
+            if (q < 0) continue;
+            const int b = hq[s][c].x, off = hq[s][c].y;
+            own[q] = b;
+            if (b < 0) { pl[q] = 0.0; continue; }
+            const int lj = q / LW, li = q - lj * LW;
+            const int dx = li < BOXG ? BOXG - li : (li >= BOXG + tw ? li - (BOXG + tw - 1) : 0), dy = lj < BOXG ? BOXG - lj : (lj >= BOXG + th ? lj - (BOXG + th - 1) : 0);
+            const int d = max(dx, dy);
+            const FP &fb = b == k ? fk : ft[b];
+            if (d >= BOXG) { pl[q] = fb.f[fsrc][off]; continue; }        // (the outermost ring is only read)
+            const int Pb = b == k ? v.P : vt[b].P;
+            cb[s][c] = b; co[s][c] = off; cd[s][c] = d;
+            pl[q] = fb.f[fsrc][off];
+            c_rhs[s][c] = fb.f[SUHMO_F_RHS][off];
+            c_bxW[s][c] = fb.f[SUHMO_F_BX][off]; c_bxE[s][c] = fb.f[SUHMO_F_BX][off + 1];
+            c_byS[s][c] = fb.f[SUHMO_F_BY][off]; c_byN[s][c] = fb.f[SUHMO_F_BY][off + Pb];
+            c_B[s][c] = fb.f[SUHMO_F_B][off]; c_Pi[s][c] = fb.f[SUHMO_F_PI][off]; c_zb[s][c] = fb.f[SUHMO_F_ZB][off]; c_mk[s][c] = fb.f[SUHMO_F_MASK][off];
+            c_at[s][c] = HAS_ALPHA ? v.alpha * fb.f[SUHMO_F_ACOEF][off] : v.alpha;      // (alpha, beta, the cell sizes and the BC data are the level's: every box's view has them)
+        }
+    __syncthreads();
+    // one update: d_gsrb_pass_simple's expression.  Called with CONSTANT slot indices from either branch of the (uniform) colour test below: a
+    // `u ? x[1] : x[0]` on the slot arrays is turned into a variably indexed load by the optimiser, which keeps all of them in scratch
+    auto update = [&](int q, int b, int off, double rhs, double bxW, double bxE, double byS, double byN, double B, double Pi, double zb, double mk, double at) {
+        const double c = pl[q];
+        // a neighbour that is a cell of the level: its current value; else what the cell's own box holds there (coarse-fine ghost / physical BC)
+        double w, e, sv, n;
+        if (own[q - 1] >= 0 && own[q + 1] >= 0 && own[q - LW] >= 0 && own[q + LW] >= 0) { w = pl[q - 1]; e = pl[q + 1]; sv = pl[q - LW]; n = pl[q + LW]; }
+        else {
+            const DV &vb = b == k ? v : vt[b];
+            const double *__restrict__ psrc = (b == k ? fk : ft[b]).f[fsrc];
+            const int j = off / vb.P - vb.gy, i = off - (j + vb.gy) * vb.P - SUHMO_XOFF;
+            w = own[q - 1] >= 0 ? pl[q - 1] : phiW(vb, psrc, off, i, c, false);
+            e = own[q + 1] >= 0 ? pl[q + 1] : phiE(vb, psrc, off, i, c, false);
+            sv = own[q - LW] >= 0 ? pl[q - LW] : phiS(vb, psrc, off, j, c, false);
+            n = own[q + LW] >= 0 ? pl[q + LW] : phiN(vb, psrc, off, j, c, false);
+        }
+        double nl, dnl;
+        nl_terms(ph, c, B, Pi, zb, mk, nl, dnl);
+        const double lofphi = lofphi_cell(v, at, c, e, w, n, sv, bxE, bxW, byN, byS, nl);
+        const double lam = lambda_cell(v, at, bxE, bxW, byN, byS);
+        const double denom = 1.0e-16 + lam + dnl;                      // ...OpF.ChF:154
+        pl[q] = c + (rhs - lofphi) / denom;                            // :156 (a cell of one colour reads cells of the other only: in place)
+    };
+    for (int m = 0; m < npass; m++) {
+        const int reach = npass - 1 - m;                               // the pass advances the cells of colour m & 1 within `reach` of the tile
+        if ((m & 1) == 0) {
+#pragma unroll
+            for (int s = 0; s < S; s++)
+                if (cb[s][0] >= 0 && cd[s][0] <= reach)
+                    update(cq[s][0], cb[s][0], co[s][0], c_rhs[s][0], c_bxW[s][0], c_bxE[s][0], c_byS[s][0], c_byN[s][0], c_B[s][0], c_Pi[s][0], c_zb[s][0], c_mk[s][0], c_at[s][0]);
+        } else {
+#pragma unroll
+            for (int s = 0; s < S; s++)
+                if (cb[s][1] >= 0 && cd[s][1] <= reach)
+                    update(cq[s][1], cb[s][1], co[s][1], c_rhs[s][1], c_bxW[s][1], c_bxE[s][1], c_byS[s][1], c_byN[s][1], c_B[s][1], c_Pi[s][1], c_zb[s][1], c_mk[s][1], c_at[s][1]);
         }
         __syncthreads();
     }
@@ -238,18 +258,24 @@ __global__ __launch_bounds__(BoxGeom<G>::NT) void k_gsrb_box_m(const DV *__restr
         }
 }
 // `npass` colour passes (up to 8 = 4 sweeps) of every box of the level in one launch, fsrc -> fdst
+template <int G, int T, int S>
+static void launch_box(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, const void *halo, const int *hbase, int fsrc, int fdst, int npass, int bc_ghosts, hipStream_t st)
+{
+    const dim3 grd(((m.maxnx + T - 1) / T) * ((m.maxny + T - 1) / T), m.nbox);
+    if (has_alpha) hipLaunchKernelGGL((k_gsrb_box_m<true, G, T, S>), grd, dim3(BoxGeom<G, T, S>::NT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass, bc_ghosts);
+    else hipLaunchKernelGGL((k_gsrb_box_m<false, G, T, S>), grd, dim3(BoxGeom<G, T, S>::NT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass, bc_ghosts);
+}
 int suhmo_multi_gsrb_box(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, const void *halo, const int *hbase, int fsrc, int fdst, int npass, int bc_ghosts, hipStream_t st)
 {
     if (m.nbox <= 0) return 0;
-    const dim3 grd(((m.maxnx + BOXT - 1) / BOXT) * ((m.maxny + BOXT - 1) / BOXT), m.nbox);
     if (npass < 1 || npass > 2 * SUHMO_BOX_HALO) { suhmo_set_error("internal: %d colour passes in one box launch", npass); return -4; }
-    if (npass > 4) {
-        if (has_alpha) hipLaunchKernelGGL((k_gsrb_box_m<true, 8>), grd, dim3(BoxGeom<8>::NT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass, bc_ghosts);
-        else hipLaunchKernelGGL((k_gsrb_box_m<false, 8>), grd, dim3(BoxGeom<8>::NT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass, bc_ghosts);
-    } else {
-        if (has_alpha) hipLaunchKernelGGL((k_gsrb_box_m<true, 4>), grd, dim3(BoxGeom<4>::NT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass, bc_ghosts);
-        else hipLaunchKernelGGL((k_gsrb_box_m<false, 4>), grd, dim3(BoxGeom<4>::NT), 0, st, m.dv, m.fp, (const int2 *)halo, hbase, ph, fsrc, fdst, npass, bc_ghosts);
-    }
+    static const int forced = [] { const char *e = getenv("SUHMO_BOX_TILE"); return e ? atoi(e) : 0; }();        // (A/B runs)
+    const int tiles16 = ((m.maxnx + 15) / 16) * ((m.maxny + 15) / 16) * m.nbox;
+    const int tile = forced ? forced : (tiles16 >= 1024 ? 32 : 16);
+    if (tile == 16) { if (npass > 4) launch_box<8, 16, 1>(m, ph, has_alpha, halo, hbase, fsrc, fdst, npass, bc_ghosts, st);
+                      else launch_box<4, 16, 1>(m, ph, has_alpha, halo, hbase, fsrc, fdst, npass, bc_ghosts, st); }
+    else { if (npass > 4) launch_box<8, 32, 2>(m, ph, has_alpha, halo, hbase, fsrc, fdst, npass, bc_ghosts, st);
+           else launch_box<4, 32, 2>(m, ph, has_alpha, halo, hbase, fsrc, fdst, npass, bc_ghosts, st); }
     HIPCHK(hipGetLastError());
     return 0;
 }
