@@ -117,12 +117,11 @@ int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool h
 // exchange before each, bit for bit; a launch reads canvases no workgroup of the launch writes (PHI -> PHI2, then PHI2 -> PHI).
 // G: the halo the launch advances through = the sweeps it can do (G = 4: two sweeps; G = 8: FOUR sweeps -- a whole pre- or post-smoothing of the
 // reference's num_smooth = 4 -- in one launch: the eight passes cost less than two launches' fixed parts).  T: the tile edge at most (a box is cut
-// into ceil(n / T) tiles of equal width per direction).  Threads keep S positions of EACH colour of the tile's image.  T = 16, S = 1 (320 / 512
-// threads): many small workgroups -- what levels of small boxes want (cfg5, ~28 x 28 cells per box: 16.8 ms per step against 20.5 with T = 32,
-// although a 28 x 28 box as four tiles with their halos is 3600 positions and as one tile 1936: the ~200 boxes of a level do not fill 256 CUs with
-// one workgroup each, and a wave with two updates per pass has twice the dependent chain).  T = 32, S = 2 (48 x 48 image on 576 threads): levels
-// with a thousand tiles and more, where the redundant halo updates are what the launch spends its time on (one box of 1024 x 256: 3.22 against 3.32
-// ms per step; `profiles/r04_w_box_tile_ab.txt`).  The plan `halo` is laid out for SUHMO_BOX_HALO = 8 cells around every box.
+// into ceil(n / T) tiles of equal width per direction).  Threads keep S positions of EACH colour of the tile's image.  What runs is T = 16, S = 1
+// (320 / 512 threads): many small workgroups.  Measured and not kept: T = 32, S = 2 (48 x 48 image on 576 threads, 168 VGPRs) -- a 28 x 28 box as
+// four tiles with their halos is 3600 positions and as one tile 1936, but cfg5's ~200 boxes per level do not fill 256 CUs with one workgroup each
+// and a wave with two updates per pass has twice the dependent chain: 20.5 against 16.8 ms per step; on one box of 1024 x 256 cells 3.22 against
+// 3.32 ms per step, within the box-to-box noise (`profiles/r04_w_box_tile_ab.txt`).  The plan `halo` is laid out for SUHMO_BOX_HALO = 8 cells around every box.
 template <int G, int T, int S> struct BoxGeom { static constexpr int LW = T + 2 * G, NT = (((LW * LW / 2 + S - 1) / S + 63) / 64) * 64; };
 template <bool HAS_ALPHA, int G, int T, int S>
 __global__ __launch_bounds__((BoxGeom<G, T, S>::NT)) __attribute__((amdgpu_waves_per_eu(1, 3))) void k_gsrb_box_m(const DV *__restrict__ vt, const FP *__restrict__ ft, const int2 *__restrict__ halo, const int *__restrict__ hbase,
@@ -269,13 +268,8 @@ int suhmo_multi_gsrb_box(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_
 {
     if (m.nbox <= 0) return 0;
     if (npass < 1 || npass > 2 * SUHMO_BOX_HALO) { suhmo_set_error("internal: %d colour passes in one box launch", npass); return -4; }
-    static const int forced = [] { const char *e = getenv("SUHMO_BOX_TILE"); return e ? atoi(e) : 0; }();        // (A/B runs)
-    const int tiles16 = ((m.maxnx + 15) / 16) * ((m.maxny + 15) / 16) * m.nbox;
-    const int tile = forced ? forced : (tiles16 >= 1024 ? 32 : 16);
-    if (tile == 16) { if (npass > 4) launch_box<8, 16, 1>(m, ph, has_alpha, halo, hbase, fsrc, fdst, npass, bc_ghosts, st);
-                      else launch_box<4, 16, 1>(m, ph, has_alpha, halo, hbase, fsrc, fdst, npass, bc_ghosts, st); }
-    else { if (npass > 4) launch_box<8, 32, 2>(m, ph, has_alpha, halo, hbase, fsrc, fdst, npass, bc_ghosts, st);
-           else launch_box<4, 32, 2>(m, ph, has_alpha, halo, hbase, fsrc, fdst, npass, bc_ghosts, st); }
+    if (npass > 4) launch_box<8, 16, 1>(m, ph, has_alpha, halo, hbase, fsrc, fdst, npass, bc_ghosts, st);
+    else launch_box<4, 16, 1>(m, ph, has_alpha, halo, hbase, fsrc, fdst, npass, bc_ghosts, st);
     HIPCHK(hipGetLastError());
     return 0;
 }
