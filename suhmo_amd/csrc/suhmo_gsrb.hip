@@ -188,21 +188,45 @@ __global__ __launch_bounds__((BoxGeom<G, T, S>::NT)) __attribute__((amdgpu_waves
             c_at[s][c] = HAS_ALPHA ? v.alpha * fb.f[SUHMO_F_ACOEF][off] : v.alpha;      // (alpha, beta, the cell sizes and the BC data are the level's: every box's view has them)
         }
     __syncthreads();
+    // What a cell reads beyond the cells of the level does not change during the launch: its own box's stored ghost (coarse-fine: interpolated before
+    // the relaxation) or a physical boundary condition of its own value.  Worked out ONCE per position -- the box's view, the cell's indices, the ghost
+    // value: global loads and an index computation that used to sit in every pass of every wave with a cell next to the level's edge -- as a kind per
+    // direction (2 bits each: 0 a cell of the level, read from LDS; 1 the constant g; 2 g - c, Dirichlet: g = 2 x value; 3 c + g, Neumann: g = +-dx x
+    // value: phiW / phiE / phiS / phiN's expressions) and the four g.
+    int nk[S][2];
+    double hW[S][2], hE[S][2], hS[S][2], hN[S][2];
+#pragma unroll
+    for (int s = 0; s < S; s++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            nk[s][c] = 0; hW[s][c] = hE[s][c] = hS[s][c] = hN[s][c] = 0.0;
+            const int q = cq[s][c], b = cb[s][c];
+            if (b < 0) continue;
+            const bool oW = own[q - 1] < 0, oE = own[q + 1] < 0, oS = own[q - LW] < 0, oN = own[q + LW] < 0;
+            if (!(oW || oE || oS || oN)) continue;
+            const DV &vb = b == k ? v : vt[b];
+            const double *__restrict__ psrc = (b == k ? fk : ft[b]).f[fsrc];
+            const int off = co[s][c];
+            // (a neighbour that is not a cell of the level lies outside the cell's own box: i == 0 / nx - 1 / j == 0 / ny - 1 there; a box that is its own
+            //  periodic neighbour has its images in the plan as cells of the level)
+            if (oW) { if (vb.cfx[0]) { nk[s][c] |= 1; hW[s][c] = psrc[off - 1]; } else if (vb.bct[0][0] == 0) { nk[s][c] |= 2; hW[s][c] = vb.two_v[0][0]; } else { nk[s][c] |= 3; hW[s][c] = vb.neu[0][0]; } }
+            if (oE) { if (vb.cfx[1]) { nk[s][c] |= 1 << 2; hE[s][c] = psrc[off + 1]; } else if (vb.bct[0][1] == 0) { nk[s][c] |= 2 << 2; hE[s][c] = vb.two_v[0][1]; } else { nk[s][c] |= 3 << 2; hE[s][c] = vb.neu[0][1]; } }
+            if (oS) { if (vb.ext[0]) { nk[s][c] |= 1 << 4; hS[s][c] = psrc[off - vb.P]; } else if (vb.bct[1][0] == 0) { nk[s][c] |= 2 << 4; hS[s][c] = vb.two_v[1][0]; } else { nk[s][c] |= 3 << 4; hS[s][c] = vb.neu[1][0]; } }
+            if (oN) { if (vb.ext[1]) { nk[s][c] |= 1 << 6; hN[s][c] = psrc[off + vb.P]; } else if (vb.bct[1][1] == 0) { nk[s][c] |= 2 << 6; hN[s][c] = vb.two_v[1][1]; } else { nk[s][c] |= 3 << 6; hN[s][c] = vb.neu[1][1]; } }
+        }
+    auto outside = [](int kind, double g, double c) { return kind == 1 ? g : (kind == 2 ? g - c : c + g); };
     // one update: d_gsrb_pass_simple's expression.  Called with CONSTANT slot indices from either branch of the (uniform) colour test below: a
     // `u ? x[1] : x[0]` on the slot arrays is turned into a variably indexed load by the optimiser, which keeps all of them in scratch
-    auto update = [&](int q, int b, int off, double rhs, double bxW, double bxE, double byS, double byN, double B, double Pi, double zb, double mk, double at) {
+    auto update = [&](int q, int kinds, double g_w, double g_e, double g_s, double g_n, double rhs, double bxW, double bxE, double byS, double byN, double B, double Pi, double zb, double mk, double at) {
         const double c = pl[q];
         // a neighbour that is a cell of the level: its current value; else what the cell's own box holds there (coarse-fine ghost / physical BC)
         double w, e, sv, n;
-        if (own[q - 1] >= 0 && own[q + 1] >= 0 && own[q - LW] >= 0 && own[q + LW] >= 0) { w = pl[q - 1]; e = pl[q + 1]; sv = pl[q - LW]; n = pl[q + LW]; }
+        if (kinds == 0) { w = pl[q - 1]; e = pl[q + 1]; sv = pl[q - LW]; n = pl[q + LW]; }
         else {
-            const DV &vb = b == k ? v : vt[b];
-            const double *__restrict__ psrc = (b == k ? fk : ft[b]).f[fsrc];
-            const int j = off / vb.P - vb.gy, i = off - (j + vb.gy) * vb.P - SUHMO_XOFF;
-            w = own[q - 1] >= 0 ? pl[q - 1] : phiW(vb, psrc, off, i, c, false);
-            e = own[q + 1] >= 0 ? pl[q + 1] : phiE(vb, psrc, off, i, c, false);
-            sv = own[q - LW] >= 0 ? pl[q - LW] : phiS(vb, psrc, off, j, c, false);
-            n = own[q + LW] >= 0 ? pl[q + LW] : phiN(vb, psrc, off, j, c, false);
+            w = (kinds & 3) ? outside(kinds & 3, g_w, c) : pl[q - 1];
+            e = ((kinds >> 2) & 3) ? outside((kinds >> 2) & 3, g_e, c) : pl[q + 1];
+            sv = ((kinds >> 4) & 3) ? outside((kinds >> 4) & 3, g_s, c) : pl[q - LW];
+            n = ((kinds >> 6) & 3) ? outside((kinds >> 6) & 3, g_n, c) : pl[q + LW];
         }
         double nl, dnl;
         nl_terms(ph, c, B, Pi, zb, mk, nl, dnl);
@@ -217,12 +241,12 @@ __global__ __launch_bounds__((BoxGeom<G, T, S>::NT)) __attribute__((amdgpu_waves
 #pragma unroll
             for (int s = 0; s < S; s++)
                 if (cb[s][0] >= 0 && cd[s][0] <= reach)
-                    update(cq[s][0], cb[s][0], co[s][0], c_rhs[s][0], c_bxW[s][0], c_bxE[s][0], c_byS[s][0], c_byN[s][0], c_B[s][0], c_Pi[s][0], c_zb[s][0], c_mk[s][0], c_at[s][0]);
+                    update(cq[s][0], nk[s][0], hW[s][0], hE[s][0], hS[s][0], hN[s][0], c_rhs[s][0], c_bxW[s][0], c_bxE[s][0], c_byS[s][0], c_byN[s][0], c_B[s][0], c_Pi[s][0], c_zb[s][0], c_mk[s][0], c_at[s][0]);
         } else {
 #pragma unroll
             for (int s = 0; s < S; s++)
                 if (cb[s][1] >= 0 && cd[s][1] <= reach)
-                    update(cq[s][1], cb[s][1], co[s][1], c_rhs[s][1], c_bxW[s][1], c_bxE[s][1], c_byS[s][1], c_byN[s][1], c_B[s][1], c_Pi[s][1], c_zb[s][1], c_mk[s][1], c_at[s][1]);
+                    update(cq[s][1], nk[s][1], hW[s][1], hE[s][1], hS[s][1], hN[s][1], c_rhs[s][1], c_bxW[s][1], c_bxE[s][1], c_byS[s][1], c_byN[s][1], c_B[s][1], c_Pi[s][1], c_zb[s][1], c_mk[s][1], c_at[s][1]);
         }
         __syncthreads();
     }
