@@ -354,11 +354,9 @@ __global__ void k_pwl(const PwlEnt *__restrict__ e, int n, const FP *__restrict_
     ftab[q.f.b].f[ff][q.f.off] = v;
 }
 // [Chombo] FORT_AVERAGE (mode 0) / covered cells <- val (mode 1)
-__global__ void k_avg(const RectEnt *__restrict__ e, const FP *__restrict__ ftab, const DV *__restrict__ fdv, int ff,
-                      const FP *__restrict__ ctab, const DV *__restrict__ cdv, FP cbase, DV cbdv, int use_base, int fc, int mode, double val)
+__device__ __forceinline__ void d_avg(const RectEnt &q, int I, int J, const FP *__restrict__ ftab, const DV *__restrict__ fdv, int ff,
+                                      const FP *__restrict__ ctab, const DV *__restrict__ cdv, const FP &cbase, const DV &cbdv, int use_base, int fc, int mode, double val)
 {
-    RectEnt q = e[blockIdx.z];
-    int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y * blockDim.y + threadIdx.y;
     if (I >= q.w || J >= q.h) return;
     const int Pc = use_base ? cbdv.P : cdv[q.cb].P;
     double *c = fptr(ctab, cbase, use_base, q.cb, fc);
@@ -369,6 +367,11 @@ __global__ void k_avg(const RectEnt *__restrict__ e, const FP *__restrict__ ftab
     double s = 0.0;
     s = s + f[b]; s = s + f[b + 1]; s = s + f[b + Pf]; s = s + f[b + Pf + 1];
     c[q.coff + J * Pc + I] = s * 0.25;
+}
+__global__ void k_avg(const RectEnt *__restrict__ e, const FP *__restrict__ ftab, const DV *__restrict__ fdv, int ff,
+                      const FP *__restrict__ ctab, const DV *__restrict__ cdv, FP cbase, DV cbdv, int use_base, int fc, int mode, double val)
+{
+    d_avg(e[blockIdx.z], blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y * blockDim.y + threadIdx.y, ftab, fdv, ff, ctab, cdv, cbase, cbdv, use_base, fc, mode, val);
 }
 // owner computes: the same averages into this rank's segment of an all-gather (q.coff = position, pitch = q.w) ...
 __global__ void k_avg_put(const RectEnt *__restrict__ e, const FP *__restrict__ ftab, const DV *__restrict__ fdv, int ff, double *__restrict__ buf)
@@ -572,8 +575,16 @@ __global__ void k_reflux(const Target *__restrict__ tg, int n, const Face *__res
 // the refluxes of SEVERAL levels (level l's adds to cells of level l-1 from fluxes of levels l and l-1: no order among them)
 struct LvReflux { const Target *tg[SUHMO_LVMAX]; const Face *faces[SUHMO_LVMAX]; const FP *ftab[SUHMO_LVMAX], *ctab[SUHMO_LVMAX]; const DV *fdv[SUHMO_LVMAX];
                   int ntg[SUHMO_LVMAX], nb[SUHMO_LVMAX], use_base[SUHMO_LVMAX]; double dxc[SUHMO_LVMAX], dyc[SUHMO_LVMAX], beta[SUHMO_LVMAX]; int n; };
-__global__ void k_reflux_lv(LvReflux lv, FP cbase, FP cdst, int field_c, int residual)
+// ... and, in the workgroups from nb0 on, ONE level's FORT_AVERAGE of the same field onto the cells it covers (the step that follows the reflux in a
+// V-cycle's down-leg: it reads the fine residual and writes COVERED coarse cells, the reflux writes uncovered ones next to the coarse-fine faces)
+struct AvgPart { const RectEnt *e; const FP *ftab, *ctab; const DV *fdv, *cdv; int use_base, n, gx, gy, nb0; };
+__global__ void k_reflux_lv(LvReflux lv, FP cbase, FP cdst, int field_c, int residual, AvgPart av, DV cbdv)
 {
+    if (av.n > 0 && (int)blockIdx.x >= av.nb0) {
+        const int b = blockIdx.x - av.nb0, bx = b % av.gx, by = (b / av.gx) % av.gy, bz = b / (av.gx * av.gy);
+        d_avg(av.e[bz], bx * 64 + (int)(threadIdx.x & 63), by * 4 + (int)(threadIdx.x >> 6), av.ftab, av.fdv, field_c, av.ctab, av.cdv, cdst, cbdv, av.use_base, field_c, 0, 0.0);
+        return;
+    }
     int b = blockIdx.x, q = -1;
 #pragma unroll
     for (int t = 0; t < SUHMO_LVMAX; t++)
@@ -1581,7 +1592,7 @@ int base_apply_residual(suhmo_hier *H, bool whole_level_follows, suhmo_stream_t 
 // (what hier_level_residual(lhi) and composite_residual(lhi), .., composite_residual(llo + 1) leave) in ONE launch per kind: ghosts, operator on
 // the levels of boxes, [level 0], refluxes.  Nothing of one level's part reads what another's writes (ghosts from valid cells; L(phi) from the
 // level's own head; a reflux adds fluxes of two heads to L(phi) of its coarse cells).
-int levels_residual(suhmo_hier *H, int lhi, int llo, bool whole_level_follows, suhmo_stream_t s)
+int levels_residual(suhmo_hier *H, int lhi, int llo, bool whole_level_follows, suhmo_stream_t s, bool average_down = false)
 {
     int rc;
     if ((rc = ghosts_levels(H, llo, lhi, s))) return rc;
@@ -1604,7 +1615,17 @@ int levels_residual(suhmo_hier *H, int lhi, int llo, bool whole_level_follows, s
         r.dxc[q] = vc.dx; r.dyc[q] = vc.dy; r.beta[q] = vc.beta;
         nb += r.nb[q];
     }
-    if (nb > 0) hipLaunchKernelGGL(k_reflux_lv, dim3(nb), dim3(256), 0, HST(s), r, base_of(H)->d[0].fp, base_of(H)->d[0].fp, (int)SUHMO_F_RES, 1);
+    AvgPart av;
+    memset(&av, 0, sizeof(av));
+    if (average_down) {                                    // AMRRestrictS of the residual of level lhi rides along (hier_avg(H, lhi, RES, RES, 0))
+        HLev &V = H->lev[lhi];
+        CoarseArgs ca;
+        if ((rc = refresh_tables(H, lhi, HST(s))) || (rc = coarse_args(H, lhi - 1, HST(s), ca))) return rc;
+        av.e = V.avg.d; av.n = (int)V.avg.n; av.ftab = V.d_fp; av.fdv = V.d_dv; av.ctab = ca.tab; av.cdv = ca.dv; av.use_base = ca.use_base;
+        av.gx = (V.avg_w + 63) / 64; av.gy = (V.avg_h + 3) / 4; av.nb0 = nb;
+        nb += av.gx * av.gy * av.n;
+    }
+    if (nb > 0) hipLaunchKernelGGL(k_reflux_lv, dim3(nb), dim3(256), 0, HST(s), r, base_of(H)->d[0].fp, base_of(H)->d[0].fp, (int)SUHMO_F_RES, 1, av, base_of(H)->d[0].v);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1679,13 +1700,13 @@ int vcycle_amr(suhmo_hier *H, int l, const suhmo_solver_params_t *sp, suhmo_stre
     if (sp->bcoeff_otf && (rc = hier_update_operator(H, l, s))) return rc;
     if ((rc = hier_gsrb(H, l, sp->num_smooth, s, true))) return rc;                           // relaxNF
     if ((rc = hier_avg(H, l, SUHMO_F_PHI, SUHMO_F_PHI, 0, 0.0, HST(s)))) return rc;           // AMRRestrictS(skip_res)
-    if (levels_mergeable(H)) { if ((rc = levels_residual(H, l, l - 1, true, s))) return rc; }
+    if (levels_mergeable(H)) { if ((rc = levels_residual(H, l, l - 1, true, s, true))) return rc; }      // (the average of the residual rides in the reflux launch)
     else {
         if ((rc = cf_phi(H, l, s))) return rc;
         if ((rc = hier_level_residual(H, l, s))) return rc;
         if ((rc = composite_residual(H, l, s))) return rc;
+        if ((rc = hier_avg(H, l, SUHMO_F_RES, SUHMO_F_RES, 0, 0.0, HST(s)))) return rc;
     }
-    if ((rc = hier_avg(H, l, SUHMO_F_RES, SUHMO_F_RES, 0, 0.0, HST(s)))) return rc;
     // the right-hand side of level l-1 is set aside while its FAS problem runs: two canvases trade places on level 0 (its
     // pointers travel by value), a copy on a level of boxes (their pointers sit in a device table)
     SwapGuard rhs_aside;                                   // (trades back on every way out of this scope)
