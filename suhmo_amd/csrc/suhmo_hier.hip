@@ -1767,6 +1767,18 @@ namespace {
 int check_hier(suhmo_hier *H)
 {
     ARG(H && H->nlev >= 1);
+    // a V-cycle that failed half way may have left a level with the canvases of its head trading places (swap_head): the head goes back to its
+    // own canvas before anything else looks at the level
+    for (int l = 1; l < H->nlev; l++)
+        if (H->lev[l].swapped) {
+            suhmo_multi m;
+            int rc;
+            HIPCHK(hipSetDevice(H->device));
+            HIPCHK(hipDeviceSynchronize());
+            if ((rc = multi_of(H, l, nullptr, m)) || (rc = suhmo_multi_copy(m, SUHMO_F_PHI2, SUHMO_F_PHI, nullptr))) return rc;
+            HIPCHK(hipDeviceSynchronize());
+            swap_head(H, l);
+        }
     H->phi_shadow_fresh = false;
     for (int l = 0; l < 8; l++) H->phi_ver[l]++;
     H->base_full_ver++;
