@@ -57,6 +57,7 @@ def test_two_ranks_over_nccl_bitwise(tool, args):
 
 @pytest.mark.parametrize("tool,args,world,agg", [("shmip_dist.py", ["--case", "A3", "--scale", "2", "--steps", "6", "--check", "--ipc"], 2, 0),
                                                  ("shmip_dist.py", ["--case", "B3", "--scale", "1", "--steps", "4", "--check", "--ipc"], 4, 3000),
+                                                 ("hier_dist.py", ["--base", "256", "--steps", "2", "--check", "--ipc"], 2, 0),
                                                  ("shmip_dist.py", ["--case", "A3", "--scale", "2", "--steps", "4", "--check", "--ipc-probe"], 2, 0),
                                                  ("shmip_dist.py", ["--case", "A3", "--scale", "2", "--steps", "4", "--check", "--ipc-probe-fails"], 2, 0),
                                                  ("amr_shmip_dist.py", ["--case", "B5", "--steps", "6", "--check"], 2, 0),
