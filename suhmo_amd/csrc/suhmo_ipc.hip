@@ -292,9 +292,13 @@ extern "C" int suhmo_level_ipc_export(suhmo_level_t *L, void *blob128)
     for (int d = 0; d <= L->ndepth; d++) { S->flags[d] = off; off += (sizeof(IpcFlags) + 255) & ~(size_t)255; }
     S->bytes = off;
     // fine-grained: stores of a peer and the flag words behind them must be visible to a running kernel of the owner
+    // (and nothing else will do: the exchange kernel orders its stores and flags without acquire / release operations, which holds for memory no
+    //  cache keeps a private copy of)
     if (hipExtMallocWithFlags((void **)&S->arena, S->bytes, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
-        if (hipMalloc((void **)&S->arena, S->bytes) != hipSuccess) { delete S; suhmo_set_error("ipc transport: arena allocation failed"); return -2; }
+        delete S;
+        suhmo_set_error("ipc transport: no fine-grained device memory for the arena (hipExtMallocWithFlags)");
+        return -2;
     }
     HIPCHK(hipMemset(S->arena, 0, S->bytes));
     HIPCHK(hipHostMalloc((void **)&S->herr, 64, hipHostMallocMapped | hipHostMallocCoherent));
