@@ -335,7 +335,9 @@ int suhmo_level_rccl_comm_count(const suhmo_level_t *L);   /* ranks the level's 
  * torch.distributed all_gather); suhmo_level_attach_ipc maps the arenas of rank - 1 and rank + 1 (periodic_y: the ends are neighbours;
  * NULL where there is none; ranks that are threads of one process, or a rank that is its own neighbour, need no mapping) and routes the
  * level's halo exchanges through them.  Reductions and all-gathers keep the transport the level is attached to (suhmo_level_attach_rccl,
- * suhmo_level_set_hooks): attach that first.  Every wait on a neighbour is bounded (about 3 s): the next exchange then fails with rc -7. */
+ * suhmo_level_set_hooks): attach that first.  Every wait on a neighbour is bounded (about 3 s): the next exchange then fails with rc -7.
+ * Destroy or detach a level only after something that synchronises the ranks has followed its last exchange (a norm, a barrier): a neighbour's
+ * last acknowledgement is a store into this rank's arena. */
 int suhmo_level_ipc_export(suhmo_level_t *L, void *blob128);
 int suhmo_level_attach_ipc(suhmo_level_t *L, int rank, int world, int periodic_y, const void *blob_lo, const void *blob_hi);
 long suhmo_level_ipc_exchanges(const suhmo_level_t *L);   /* halo messages sent so far; -1: not attached */
