@@ -14,6 +14,9 @@ BC_NP = dict(type=[[0, 1], [1, 0]], value=[[0.0, 0.0], [0.0, 0.0]], periodic=[0,
 BC_V = dict(type=[[0, 1], [1, 0]], value=[[3.0, 0.01], [-0.02, 7.0]], periodic=[0, 0])
 ONE = ([(16, 8, 47, 23)], [(44, 22, 75, 41)])
 CUT = ([(16, 8, 31, 23), (32, 8, 47, 15), (32, 16, 47, 23)], [(44, 22, 59, 41), (60, 22, 75, 41)])
+# periodic in y: two boxes that are neighbours THROUGH the wrap (rows 0-7 and 24-31 of a level of 32 rows), one that spans the period and is its own
+# neighbour, and a finer box on the wrap inside it
+WRAP = ([(16, 0, 31, 7), (16, 24, 31, 31), (40, 0, 55, 31)], [(84, 0, 99, 11), (84, 52, 99, 63)])
 UNION = ([(16, 8, 31, 23), (32, 8, 47, 15), (0, 2, 11, 13)],
          [(36, 20, 59, 27), (36, 28, 51, 43), (4, 8, 15, 19)],
          [(80, 44, 103, 51), (12, 20, 23, 31)])
@@ -91,7 +94,8 @@ def test_hier_pieces_bitwise(oracle, bc, ph):
 
 
 @pytest.mark.parametrize("name,boxes,bc,ph", [("union-4lev", UNION, BC_NP, sy.CFG3_PHYS), ("union-4lev-values-mask", UNION, BC_V, MASKPH),
-                                              ("cut-periodic", CUT, BC, sy.CFG3_PHYS), ("union-4lev-exchange-per-pass", UNION, BC_NP, sy.CFG3_PHYS),
+                                              ("cut-periodic", CUT, BC, sy.CFG3_PHYS), ("wrap-periodic", WRAP, BC, sy.CFG3_PHYS),
+                                              ("wrap-periodic-a-launch-per-colour-pass", WRAP, BC, sy.CFG3_PHYS), ("union-4lev-exchange-per-pass", UNION, BC_NP, sy.CFG3_PHYS),
                                               ("union-4lev-whole-level-residuals", UNION, BC_NP, sy.CFG3_PHYS),
                                               ("union-4lev-a-launch-per-colour-pass", UNION, BC_V, MASKPH),
                                               ("union-4lev-a-launch-per-ghost-kind", UNION, BC_NP, sy.CFG3_PHYS),

@@ -14,18 +14,23 @@ CUT = ([(32, 16, 63, 47), (64, 16, 95, 31), (64, 32, 95, 47)], [(80, 44, 119, 83
 UNION = ([(32, 16, 63, 47), (64, 16, 95, 31), (0, 4, 23, 27)],
          [(72, 40, 119, 55), (72, 56, 103, 87), (8, 16, 31, 39)],
          [(160, 88, 207, 103), (24, 40, 47, 63)])
+# two boxes on opposite domain sides in y, one that spans the domain's height, a finer box on either side: with SHMIP-A's Neumann sides, and
+# ("periodic-") with sy.CONV_BC, periodic in y -- then the first two are neighbours THROUGH the wrap and the third is its own neighbour
+WRAP = ([(32, 0, 63, 15), (32, 48, 63, 63), (80, 0, 111, 63)], [(176, 0, 207, 23), (176, 104, 207, 127)])
 MOULINS = dict(positions=[(30.0e3, 9.0e3), (42.0e3, 5.5e3), (8.0e3, 4.0e3)], sigma=[900.0, 700.0, 800.0], flux=[8.0, 5.0, 3.0])
 B5ISH = dict(diffFactor=1.0, use_impl_diff=1, use_moulin_source=1, distributed_input=7.93e-11)
 
 CASES = [("union-explicit", UNION, dict(), 3), ("union-diffusion", UNION, dict(diffFactor=1.0), 2),
-         ("union-moulins-implicit", UNION, B5ISH, 3), ("cut-moulins-implicit", CUT, B5ISH, 2)]
+         ("union-moulins-implicit", UNION, B5ISH, 3), ("cut-moulins-implicit", CUT, B5ISH, 2),
+         ("wrap-explicit", WRAP, dict(), 2), ("wrap-moulins-implicit", WRAP, B5ISH, 2),
+         ("periodic-wrap-explicit", WRAP, dict(), 2), ("periodic-wrap-moulins-implicit", WRAP, B5ISH, 2)]
 
 
-def make(oracle, boxes, m, nx0=64, ny0=32):
+def make(oracle, boxes, m, nx0=64, ny0=32, bc=sy.A3_BC):
     from suhmo_amd import model
     sts = sy.shmip_amrm_states(nx0, ny0, boxes, rough=0.5)
-    O = oracle.OracleAmrMModel(nx0, ny0, sts[0][0]["dx"], sts[0][0]["dy"], sy.A3_BC, sy.A3_PHYS, m, boxes, max_box=16, nthreads=2)
-    G = model.HipHierModel(nx0, ny0, sts[0][0]["dx"], sts[0][0]["dy"], sy.A3_BC, sy.A3_PHYS, m, boxes, max_box=16)
+    O = oracle.OracleAmrMModel(nx0, ny0, sts[0][0]["dx"], sts[0][0]["dy"], bc, sy.A3_PHYS, m, boxes, max_box=16, nthreads=2)
+    G = model.HipHierModel(nx0, ny0, sts[0][0]["dx"], sts[0][0]["dy"], bc, sy.A3_PHYS, m, boxes, max_box=16)
     O.set_states(sts); G.set_states(sts)
     return O, G, sts
 
@@ -34,7 +39,7 @@ def make(oracle, boxes, m, nx0=64, ny0=32):
 def test_hier_timestep_bitwise(oracle, name, boxes, mpo, nsteps):
     from suhmo_amd import level as lv
     m = dict(sy.A3_MODEL, **mpo)
-    O, G, sts = make(oracle, boxes, m)
+    O, G, sts = make(oracle, boxes, m, bc=sy.CONV_BC if name.startswith("periodic-") else sy.A3_BC)
     if m.get("use_moulin_source"):
         io, ig = O.moulin_source(**MOULINS), G.moulin_source(**MOULINS)
         assert np.max(np.abs(io - ig)) <= 1e-13 * np.max(io)
