@@ -95,7 +95,9 @@ def test_hier_pieces_bitwise(oracle, bc, ph):
 
 @pytest.mark.parametrize("name,boxes,bc,ph", [("union-4lev", UNION, BC_NP, sy.CFG3_PHYS), ("union-4lev-values-mask", UNION, BC_V, MASKPH),
                                               ("cut-periodic", CUT, BC, sy.CFG3_PHYS), ("wrap-periodic", WRAP, BC, sy.CFG3_PHYS),
-                                              ("wrap-periodic-a-launch-per-colour-pass", WRAP, BC, sy.CFG3_PHYS), ("union-4lev-exchange-per-pass", UNION, BC_NP, sy.CFG3_PHYS),
+                                              ("wrap-periodic-a-launch-per-colour-pass", WRAP, BC, sy.CFG3_PHYS),
+                                              ("union-4lev-three-sweeps", UNION, BC_NP, sy.CFG3_PHYS), ("union-4lev-values-mask-two-sweeps", UNION, BC_V, MASKPH),
+                                              ("union-4lev-six-sweeps", UNION, BC_NP, sy.CFG3_PHYS), ("union-4lev-exchange-per-pass", UNION, BC_NP, sy.CFG3_PHYS),
                                               ("union-4lev-whole-level-residuals", UNION, BC_NP, sy.CFG3_PHYS),
                                               ("union-4lev-a-launch-per-colour-pass", UNION, BC_V, MASKPH),
                                               ("union-4lev-a-launch-per-ghost-kind", UNION, BC_NP, sy.CFG3_PHYS),
@@ -114,6 +116,11 @@ def test_hier_vcycle_and_solve_bitwise(oracle, name, boxes, bc, ph, monkeypatch)
         monkeypatch.setenv("SUHMO_RESID_IN_RELAX", "0" if name.endswith("own-residual-pass") else "1")
     # exchange-per-pass: an exchange launch before every colour pass instead of the pushed side cells (creation option of the hierarchy)
     sp = dict(sy.SOLVER_DEFAULT, eps=1e-9, norm_thresh=1e-14, max_iter=6, imin=30)
+    # -N-sweeps: num_smooth other than the reference's 4 (one launch of 8 passes per smoothing): 3 -> one launch of 6 passes, 2 -> one of 4 (the two-sweep
+    # form of the kernel), 6 -> 8 + 4 passes; an odd number of launches leaves the head on its second canvas between pre- and post-smoothing
+    for word, n in (("three", 3), ("two", 2), ("six", 6)):
+        if name.endswith("-%s-sweeps" % word):
+            sp["num_smooth"] = n
     # whole-level-residuals: every composite residual and coarse gradient over all of level 0 (default: the solve loop's evaluation is
     # reused by the next cycle except where level 1 was averaged down; the coarse gradient only where the interpolation reads it)
     # default: two sweeps per launch on the box levels (suhmo_gsrb.hip:k_gsrb_box_m) and AMRProlongS_2 of a box in one workgroup;
