@@ -23,19 +23,21 @@ def make_pair(nx, ny, f, ph, halo, transport="rccl"):
     S = level.HipLevel(nx, ny, f["dx"], f["dy"], bc, ph, 0.0, -1.0, 32, j0=0, ny_global=2 * ny, halo_rows=halo)
     S.set_inputs(f)
     multigpu.attach_rccl(S, 0, 1, periodic_y=True)
-    if transport == "ipc":
+    if transport.startswith("ipc"):
         multigpu.ipc_attach(S, 0, 1, True, [multigpu.ipc_export(S)])
     return W, S
 
 
 @pytest.mark.parametrize("nx,ny,variant,halo", [(64, 32, "simple", 4), (2048, 1024, "fused", 4), (128, 64, "simple", 16), (2048, 1024, "fused", 16), (256, 128, "simple", 24), (2048, 1024, "fused", 24)])
-@pytest.mark.parametrize("transport", ["rccl", "ipc"])
+@pytest.mark.parametrize("transport", ["rccl", "ipc", "ipc-eight-workgroups"])
 def test_self_neighbour_vcycle_bitwise(nx, ny, variant, halo, transport, monkeypatch):
     from suhmo_amd import capi
     from suhmo_amd.level import F_PHI, F_RES, F_BX, F_BY
     from test_gpu_strips import wrap_ghosts
     if variant == "fused":
         monkeypatch.setenv("SUHMO_FUSED_MIN_CELLS", "100000")
+    if transport == "ipc-eight-workgroups":           # exchange launches of at most 8 workgroups: every workgroup owns several pieces of a message, and messages
+        monkeypatch.setenv("SUHMO_IPC_BLOCKS", "8")   # of fewer pieces than that alternate with fuller ones on a channel (the acknowledgements of BOTH counts are waited for)
     f = wrap_ghosts(sy.shmip_fields(nx, ny, ly=2.0e4 * ny / nx * 5), sy.CONV_BC)
     W, S = make_pair(nx, ny, f, sy.A3_PHYS, halo, transport)
     sp = dict(sy.SOLVER_DEFAULT)
@@ -44,7 +46,7 @@ def test_self_neighbour_vcycle_bitwise(nx, ny, variant, halo, transport, monkeyp
         L.vcycle(sp)
         L.vcycle(sp)
         L.residual()
-    assert (capi.lib().suhmo_level_ipc_exchanges(S.h) if transport == "ipc" else capi.lib().suhmo_level_rccl_exchanges(S.h)) > 10
+    assert (capi.lib().suhmo_level_ipc_exchanges(S.h) if transport.startswith("ipc") else capi.lib().suhmo_level_rccl_exchanges(S.h)) > 10
     for fid in (F_PHI, F_RES, F_BX):
         assert np.array_equal(W.get(fid), S.get(fid)), fid
     assert np.array_equal(W.get(F_BY)[:-1], S.get(F_BY)[:-1])
