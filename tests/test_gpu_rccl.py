@@ -60,6 +60,32 @@ def test_self_neighbour_vcycle_bitwise(nx, ny, variant, halo, transport, monkeyp
     S.close()
 
 
+def test_detaching_the_peer_direct_transport_gives_the_level_back_to_rccl():
+    """suhmo_level_detach_ipc (what multigpu.attach's probe does when a rank reports a failure): the halo rows travel over RCCL again, the cycles stay
+    the single level's bit for bit, and the level can be attached once more"""
+    from suhmo_amd import capi, multigpu
+    from suhmo_amd.level import F_PHI
+    from test_gpu_strips import wrap_ghosts
+    f = wrap_ghosts(sy.shmip_fields(256, 128, ly=2.0e4 * 128 / 256 * 5), sy.CONV_BC)
+    W, S = make_pair(256, 128, f, sy.A3_PHYS, 8, "ipc")
+    sp = dict(sy.SOLVER_DEFAULT)
+    lib = capi.lib()
+    for L in (W, S):
+        L.build_mg_coefficients()
+        L.vcycle(sp)
+    n_ipc, n_rccl = lib.suhmo_level_ipc_exchanges(S.h), lib.suhmo_level_rccl_exchanges(S.h)
+    assert n_ipc > 0
+    S.synchronize()
+    assert lib.suhmo_level_detach_ipc(S.h) == 0 and lib.suhmo_level_ipc_exchanges(S.h) == -1
+    W.vcycle(sp); S.vcycle(sp)
+    assert lib.suhmo_level_rccl_exchanges(S.h) > n_rccl
+    assert np.array_equal(W.get(F_PHI), S.get(F_PHI))
+    multigpu.ipc_attach(S, 0, 1, True, [multigpu.ipc_export(S)])
+    W.vcycle(sp); S.vcycle(sp)
+    assert lib.suhmo_level_ipc_exchanges(S.h) > 0 and np.array_equal(W.get(F_PHI), S.get(F_PHI))
+    W.close(); S.close()
+
+
 @pytest.mark.parametrize("impl", [0, 1])
 @pytest.mark.parametrize("direct", [0, 1, "ipc"])
 def test_self_neighbour_timestep_bitwise(impl, direct, monkeypatch):
