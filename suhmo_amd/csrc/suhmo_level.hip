@@ -156,14 +156,10 @@ int suhmo_level_create_(suhmo_level_t **out, const suhmo_level_desc_t *desc, boo
     suhmo_level *L = new suhmo_level();
     L->desc = *desc; L->ph = desc->phys; L->device = desc->device;
     L->ex = nullptr; L->ar = nullptr; L->ar2 = nullptr; L->ard = nullptr; L->user = nullptr; L->ex_begin = nullptr; L->ex_end = nullptr; L->rccl = nullptr; L->ipc = nullptr; L->ipc_owner = 0; L->faces_deferred = 0; L->gap = nullptr; L->gap_dt = 0.0; L->prof_on = 0; L->gsrb_variant = -1; L->fused_hc = 0;
-    if (const char *e = getenv("SUHMO_GSRB_VARIANT")) L->gsrb_variant = atoi(e);
-    if (const char *e = getenv("SUHMO_FUSED_HC")) L->fused_hc = atoi(e);
+    // defaults of the kernel-selection knobs (each with the measurement it comes from where it is declared, suhmo_common.h) ...
     L->bcoef_fused = 1;
-    if (const char *e = getenv("SUHMO_BCOEF_FUSED")) L->bcoef_fused = atoi(e);
     L->bcoef_tile_x = 62;
-    if (const char *e = getenv("SUHMO_BCOEF_TILE_X")) L->bcoef_tile_x = atoi(e);
     L->fused_nt = 64;                        // one wave per workgroup: 316 vs 308 V-cycles/s at 4096^2 (profiles/r01_i_nt_ab.txt)
-    if (const char *e = getenv("SUHMO_FUSED_NT")) L->fused_nt = atoi(e);
     L->fused_restrict = 1;
     L->gsrb_tile = 1; L->tile_t = 0; L->tile_s = 4;
     L->tile_max_cells = 3000000;     // 2048^2 (4.2 M cells) streams: 45 us per sweep at its one-round chunk height against 51 on tiles (profiles/r03_stream2048.txt)
@@ -172,32 +168,38 @@ int suhmo_level_create_(suhmo_level_t **out, const suhmo_level_desc_t *desc, boo
     L->tile_order = 2; L->tile_restrict = 0;
     L->tile_strips = 1;
     L->overlap_halo = 1; L->xstream = nullptr; L->xev[0] = L->xev[1] = nullptr; L->overlapped = 0;
-    if (const char *e = getenv("SUHMO_OVERLAP_HALO")) L->overlap_halo = atoi(e);
     L->strips_rhs_local = 1;
-    if (const char *e = getenv("SUHMO_STRIPS_RHS_LOCAL")) L->strips_rhs_local = atoi(e);
     L->fas_rhs_fused = 1;
-    if (const char *e = getenv("SUHMO_FAS_RHS_FUSED")) L->fas_rhs_fused = atoi(e) != 0;
     L->agg_min_cells = 100000; L->agg_depth = 0; L->agg_world = 1; L->agg_rank = 0; L->agg = nullptr; L->ag = nullptr; L->ag_user = nullptr;
     L->agg_send = L->agg_recv = nullptr; L->agg_cap = 0; L->agg_gathers = 0; L->agg_static_stale = 0;
     L->frhs_stream = L->frhs_tile = 0;
     L->resout_np = 0;
     L->resout_req = L->resout_armed = L->resout_done = 0; L->resout_rhs = nullptr; L->resout_count = 0; L->resid_in_relax = 1;
-    if (const char *e = getenv("SUHMO_RESID_IN_RELAX")) L->resid_in_relax = atoi(e);
-    if (const char *e = getenv("SUHMO_AGG_MIN_CELLS")) L->agg_min_cells = atol(e);
-    if (const char *e = getenv("SUHMO_TILE_STRIPS")) L->tile_strips = atoi(e);
-    if (const char *e = getenv("SUHMO_TILE_CHUNKS")) L->tile_chunks = atoi(e);
-    if (const char *e = getenv("SUHMO_TILE_RESTRICT")) L->tile_restrict = atoi(e);
-    if (const char *e = getenv("SUHMO_TILE_ORDER")) { L->tile_order = atoi(e); if (L->tile_order < 0 || L->tile_order > 2) L->tile_order = 0; }
-    if (const char *e = getenv("SUHMO_FAS_RHS_IN_RELAX")) L->fas_rhs_in_relax = atoi(e);
-    if (const char *e = getenv("SUHMO_TILE_MAX_CELLS")) L->tile_max_cells = atol(e);
-    if (const char *e = getenv("SUHMO_TILE_S")) L->tile_s = atoi(e);        // most sweeps per tile launch (4, 2, 1)
-    if (const char *e = getenv("SUHMO_GSRB_TILE")) L->gsrb_tile = atoi(e);
-    if (const char *e = getenv("SUHMO_TILE_T")) { L->tile_t = atoi(e); if (L->tile_t != 16 && L->tile_t != 32) L->tile_t = 0; }
-    if (const char *e = getenv("SUHMO_FUSED_RESTRICT")) L->fused_restrict = atoi(e);
     L->graph_max_cells = 1500000; L->gstream = nullptr; memset(L->vgraph_seen, 0, sizeof(L->vgraph_seen));
-    if (const char *e = getenv("SUHMO_GRAPH_MAX_CELLS")) L->graph_max_cells = atol(e);
     L->fused_min_cells = 1000000;
-    if (const char *e = getenv("SUHMO_FUSED_MIN_CELLS")) L->fused_min_cells = atol(e);
+    L->skip_mask = 1; L->poll_readback = 1;
+    // ... and ONE place where the environment may override them, read when a level is created: the A/B runs DESIGN.md quotes and the tests that
+    // force a kernel onto a small level.  Nothing else of a level is taken from the environment.
+    {
+        struct IntKnob { const char *env; int suhmo_level::*field; };
+        struct LongKnob { const char *env; long suhmo_level::*field; };
+        static const IntKnob ints[] = {
+            {"SUHMO_GSRB_VARIANT", &suhmo_level::gsrb_variant}, {"SUHMO_FUSED_HC", &suhmo_level::fused_hc}, {"SUHMO_BCOEF_FUSED", &suhmo_level::bcoef_fused},
+            {"SUHMO_BCOEF_TILE_X", &suhmo_level::bcoef_tile_x}, {"SUHMO_FUSED_NT", &suhmo_level::fused_nt}, {"SUHMO_OVERLAP_HALO", &suhmo_level::overlap_halo},
+            {"SUHMO_STRIPS_RHS_LOCAL", &suhmo_level::strips_rhs_local}, {"SUHMO_FAS_RHS_FUSED", &suhmo_level::fas_rhs_fused},
+            {"SUHMO_RESID_IN_RELAX", &suhmo_level::resid_in_relax}, {"SUHMO_TILE_STRIPS", &suhmo_level::tile_strips}, {"SUHMO_TILE_CHUNKS", &suhmo_level::tile_chunks},
+            {"SUHMO_TILE_RESTRICT", &suhmo_level::tile_restrict}, {"SUHMO_TILE_ORDER", &suhmo_level::tile_order}, {"SUHMO_FAS_RHS_IN_RELAX", &suhmo_level::fas_rhs_in_relax},
+            {"SUHMO_TILE_S", &suhmo_level::tile_s}, {"SUHMO_GSRB_TILE", &suhmo_level::gsrb_tile}, {"SUHMO_TILE_T", &suhmo_level::tile_t},
+            {"SUHMO_FUSED_RESTRICT", &suhmo_level::fused_restrict}, {"SUHMO_SKIP_MASK", &suhmo_level::skip_mask}, {"SUHMO_POLL_READBACK", &suhmo_level::poll_readback}};
+        static const LongKnob longs[] = {
+            {"SUHMO_AGG_MIN_CELLS", &suhmo_level::agg_min_cells}, {"SUHMO_TILE_MAX_CELLS", &suhmo_level::tile_max_cells},
+            {"SUHMO_GRAPH_MAX_CELLS", &suhmo_level::graph_max_cells}, {"SUHMO_FUSED_MIN_CELLS", &suhmo_level::fused_min_cells}};
+        for (const IntKnob &k : ints) if (const char *e = getenv(k.env)) L->*(k.field) = atoi(e);
+        for (const LongKnob &k : longs) if (const char *e = getenv(k.env)) L->*(k.field) = atol(e);
+        L->fas_rhs_fused = L->fas_rhs_fused != 0;
+        if (L->tile_order < 0 || L->tile_order > 2) L->tile_order = 0;
+        if (L->tile_t != 16 && L->tile_t != 32) L->tile_t = 0;          // (most sweeps per tile launch tile_s: 4, 2, 1)
+    }
     if (desc->boxes && desc->nbox > 0) {
         L->boxes.assign(desc->boxes, desc->boxes + 4 * (size_t)desc->nbox);
     } else {
@@ -240,10 +242,8 @@ int suhmo_level_create_(suhmo_level_t **out, const suhmo_level_desc_t *desc, boo
         memset(&D.fp, 0, sizeof(D.fp));
         D.phi_alt = nullptr; D.prolong_pending = 0; D.rhs_pending = 0; D.phi_fresh = 0;
     }
-    L->scratch = nullptr; L->scratch_elems = 0; L->hscratch = nullptr; L->hscratch_dev = nullptr; L->hseq = 0; L->poll_readback = 1;
-    L->mask_epoch = 0; L->maskflag_epoch = 0; L->mask_reported = 0; L->skip_mask = 1; L->coarse_mask_ok = 0;
-    if (const char *e = getenv("SUHMO_SKIP_MASK")) L->skip_mask = atoi(e);
-    if (const char *e = getenv("SUHMO_POLL_READBACK")) L->poll_readback = atoi(e);
+    L->scratch = nullptr; L->scratch_elems = 0; L->hscratch = nullptr; L->hscratch_dev = nullptr; L->hseq = 0;
+    L->mask_epoch = 0; L->maskflag_epoch = 0; L->mask_reported = 0; L->coarse_mask_ok = 0;
     L->stub = 1;
     if (!stub) { int rc = level_storage(L); if (rc) { suhmo_level_destroy(L); return rc; } }
     *out = L;
