@@ -131,7 +131,8 @@ static int vcycle_body(suhmo_level *L, const suhmo_solver_params_t *sp, int nd, 
 // after every replay.  Not used on rank strips (the exchange hooks are host calls), while profiling, or above SUHMO_GRAPH_MAX_CELLS.
 void suhmo_level_drop_graphs(suhmo_level *L)
 {
-    if (getenv("SUHMO_GRAPH_DEBUG")) { int ok = 0; for (VGraph &g : L->vgraphs) ok += g.exec != nullptr; fprintf(stderr, "[suhmo] level %dx%d: %zu V-cycle graphs, %d executable\n", L->d[0].v.nx, L->d[0].v.ny, L->vgraphs.size(), ok); }
+    if (getenv("SUHMO_GRAPH_DEBUG")) { int ok = 0; for (VGraph &g : L->vgraphs) ok += g.exec != nullptr; fprintf(stderr,
+        "[suhmo] level %dx%d: %zu V-cycle graphs, %d executable\n", L->d[0].v.nx, L->d[0].v.ny, L->vgraphs.size(), ok); }
     for (VGraph &g : L->vgraphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     L->vgraphs.clear();
     if (L->gstream) { (void)hipStreamDestroy(L->gstream); L->gstream = nullptr; }

@@ -124,7 +124,8 @@ int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool h
 // 3.32 ms per step, within the box-to-box noise (`profiles/r04_w_box_tile_ab.txt`).  The plan `halo` is laid out for SUHMO_BOX_HALO = 8 cells around every box.
 template <int G, int T, int S> struct BoxGeom { static constexpr int LW = T + 2 * G, NT = (((LW * LW / 2 + S - 1) / S + 63) / 64) * 64; };
 template <bool HAS_ALPHA, int G, int T, int S>
-__global__ __launch_bounds__((BoxGeom<G, T, S>::NT)) __attribute__((amdgpu_waves_per_eu(1, 3))) void k_gsrb_box_m(const DV *__restrict__ vt, const FP *__restrict__ ft, const int2 *__restrict__ halo, const int *__restrict__ hbase,
+__global__ __launch_bounds__((BoxGeom<G, T, S>::NT)) __attribute__((amdgpu_waves_per_eu(1, 3))) void k_gsrb_box_m(const DV *__restrict__ vt,
+    const FP *__restrict__ ft, const int2 *__restrict__ halo, const int *__restrict__ hbase,
                                                                      suhmo_phys_t ph, int fsrc, int fdst, int npass, int bcg)
 {
     constexpr int BOXG = G, BOXNT = BoxGeom<G, T, S>::NT, HG = SUHMO_BOX_HALO;
@@ -209,15 +210,20 @@ __global__ __launch_bounds__((BoxGeom<G, T, S>::NT)) __attribute__((amdgpu_waves
             const int off = co[s][c];
             // (a neighbour that is not a cell of the level lies outside the cell's own box: i == 0 / nx - 1 / j == 0 / ny - 1 there; a box that is its own
             //  periodic neighbour has its images in the plan as cells of the level)
-            if (oW) { if (vb.cfx[0]) { nk[s][c] |= 1; hW[s][c] = psrc[off - 1]; } else if (vb.bct[0][0] == 0) { nk[s][c] |= 2; hW[s][c] = vb.two_v[0][0]; } else { nk[s][c] |= 3; hW[s][c] = vb.neu[0][0]; } }
-            if (oE) { if (vb.cfx[1]) { nk[s][c] |= 1 << 2; hE[s][c] = psrc[off + 1]; } else if (vb.bct[0][1] == 0) { nk[s][c] |= 2 << 2; hE[s][c] = vb.two_v[0][1]; } else { nk[s][c] |= 3 << 2; hE[s][c] = vb.neu[0][1]; } }
-            if (oS) { if (vb.ext[0]) { nk[s][c] |= 1 << 4; hS[s][c] = psrc[off - vb.P]; } else if (vb.bct[1][0] == 0) { nk[s][c] |= 2 << 4; hS[s][c] = vb.two_v[1][0]; } else { nk[s][c] |= 3 << 4; hS[s][c] = vb.neu[1][0]; } }
-            if (oN) { if (vb.ext[1]) { nk[s][c] |= 1 << 6; hN[s][c] = psrc[off + vb.P]; } else if (vb.bct[1][1] == 0) { nk[s][c] |= 2 << 6; hN[s][c] = vb.two_v[1][1]; } else { nk[s][c] |= 3 << 6; hN[s][c] = vb.neu[1][1]; } }
+            if (oW) { if (vb.cfx[0]) { nk[s][c] |= 1; hW[s][c] = psrc[off - 1]; } else if (vb.bct[0][0] == 0) { nk[s][c] |= 2; hW[s][c] = vb.two_v[0][0];
+                } else { nk[s][c] |= 3; hW[s][c] = vb.neu[0][0]; } }
+            if (oE) { if (vb.cfx[1]) { nk[s][c] |= 1 << 2; hE[s][c] = psrc[off + 1]; } else if (vb.bct[0][1] == 0) { nk[s][c] |= 2 << 2; hE[s][c] = vb.two_v[0][1];
+                } else { nk[s][c] |= 3 << 2; hE[s][c] = vb.neu[0][1]; } }
+            if (oS) { if (vb.ext[0]) { nk[s][c] |= 1 << 4; hS[s][c] = psrc[off - vb.P]; } else if (vb.bct[1][0] == 0) { nk[s][c] |= 2 << 4;
+                hS[s][c] = vb.two_v[1][0]; } else { nk[s][c] |= 3 << 4; hS[s][c] = vb.neu[1][0]; } }
+            if (oN) { if (vb.ext[1]) { nk[s][c] |= 1 << 6; hN[s][c] = psrc[off + vb.P]; } else if (vb.bct[1][1] == 0) { nk[s][c] |= 2 << 6;
+                hN[s][c] = vb.two_v[1][1]; } else { nk[s][c] |= 3 << 6; hN[s][c] = vb.neu[1][1]; } }
         }
     auto outside = [](int kind, double g, double c) { return kind == 1 ? g : (kind == 2 ? g - c : c + g); };
     // one update: d_gsrb_pass_simple's expression.  Called with CONSTANT slot indices from either branch of the (uniform) colour test below: a
     // `u ? x[1] : x[0]` on the slot arrays is turned into a variably indexed load by the optimiser, which keeps all of them in scratch
-    auto update = [&](int q, int kinds, double g_w, double g_e, double g_s, double g_n, double rhs, double bxW, double bxE, double byS, double byN, double B, double Pi, double zb, double mk, double at) {
+    auto update = [&](int q, int kinds, double g_w, double g_e, double g_s, double g_n, double rhs, double bxW, double bxE, double byS, double byN, double B,
+        double Pi, double zb, double mk, double at) {
         const double c = pl[q];
         // a neighbour that is a cell of the level: its current value; else what the cell's own box holds there (coarse-fine ghost / physical BC)
         double w, e, sv, n;
@@ -241,12 +247,14 @@ __global__ __launch_bounds__((BoxGeom<G, T, S>::NT)) __attribute__((amdgpu_waves
 #pragma unroll
             for (int s = 0; s < S; s++)
                 if (cb[s][0] >= 0 && cd[s][0] <= reach)
-                    update(cq[s][0], nk[s][0], hW[s][0], hE[s][0], hS[s][0], hN[s][0], c_rhs[s][0], c_bxW[s][0], c_bxE[s][0], c_byS[s][0], c_byN[s][0], c_B[s][0], c_Pi[s][0], c_zb[s][0], c_mk[s][0], c_at[s][0]);
+                    update(cq[s][0], nk[s][0], hW[s][0], hE[s][0], hS[s][0], hN[s][0], c_rhs[s][0], c_bxW[s][0], c_bxE[s][0], c_byS[s][0], c_byN[s][0], c_B[s][0],
+                        c_Pi[s][0], c_zb[s][0], c_mk[s][0], c_at[s][0]);
         } else {
 #pragma unroll
             for (int s = 0; s < S; s++)
                 if (cb[s][1] >= 0 && cd[s][1] <= reach)
-                    update(cq[s][1], nk[s][1], hW[s][1], hE[s][1], hS[s][1], hN[s][1], c_rhs[s][1], c_bxW[s][1], c_bxE[s][1], c_byS[s][1], c_byN[s][1], c_B[s][1], c_Pi[s][1], c_zb[s][1], c_mk[s][1], c_at[s][1]);
+                    update(cq[s][1], nk[s][1], hW[s][1], hE[s][1], hS[s][1], hN[s][1], c_rhs[s][1], c_bxW[s][1], c_bxE[s][1], c_byS[s][1], c_byN[s][1], c_B[s][1],
+                        c_Pi[s][1], c_zb[s][1], c_mk[s][1], c_at[s][1]);
         }
         __syncthreads();
     }
@@ -758,7 +766,8 @@ template <int T, bool RST> struct TileShape { static constexpr int TX = T, TY = 
 // four SIMDs, a second workgroup no longer fits beside the first, and the 2048^2 launch takes 266 us instead of 203.
 template <int S, int T, bool RST> struct TileThreads { static constexpr int NT = 256; };
 template <int S, int T, bool HAS_ALPHA, bool RST = false, bool CHUNKED = false>
-__global__ __launch_bounds__((TileThreads<S, T, RST>::NT)) __attribute__((amdgpu_waves_per_eu((TileThreads<S, T, RST>::NT == 384 ? 3 : 2)))) void k_gsrb_tile(DV v, FP fp, const double *__restrict__ pin, double *__restrict__ pout,
+__global__ __launch_bounds__((TileThreads<S, T, RST>::NT)) __attribute__((amdgpu_waves_per_eu((TileThreads<S, T, RST>::NT == 384 ? 3 : 2)))) void k_gsrb_tile(DV v,
+    FP fp, const double *__restrict__ pin, double *__restrict__ pout,
                                                    suhmo_phys_t ph, TileGeom g)
 {
     constexpr int TX = TileShape<T, RST>::TX, TY = TileShape<T, RST>::TY;
@@ -854,7 +863,9 @@ __global__ __launch_bounds__((TileThreads<S, T, RST>::NT)) __attribute__((amdgpu
             }
             // (rank boundary of a strip: the rows beyond are the neighbour's cells, held in the canvas' halo rows with their
             //  coefficients; they are advanced redundantly like periodic images, without the wrap)
-            const bool inx = perx || (i >= 0 && i < v.nx), iny = pery || (j >= 0 && j < v.ny) || (j < 0 && v.rk[0] && j >= g.jbeg - HY) || (j >= v.ny && v.rk[1] && j < g.jend + HY);   // (only the halo rows the written rows depend on: the canvas ends at gy)
+            // (only the halo rows the written rows depend on: the canvas ends at gy)
+            const bool inx = perx || (i >= 0 && i < v.nx), iny = pery || (j >= 0 && j < v.ny) || (j < 0 && v.rk[0] && j >= g.jbeg - HY) || (j >= v.ny && v.rk[1]
+                && j < g.jend + HY);
             // AMR patch: the ghost column / row beyond a coarse-fine side holds interpolated data: loaded, never advanced
             const bool exi = inx || (i == -2 && v.cfx[0]) || (i == v.nx && v.cfx[1]);
             const bool exj = iny || (j == -1 && v.ext[0] && !v.rk[0]) || (j == v.ny && v.ext[1] && !v.rk[1]);
@@ -1198,8 +1209,10 @@ static int launch_tile_any(suhmo_level *L, int depth, int S, int chunks, bool rs
 {
     const int T = chunks > 1 ? single_tile(L, L->d[depth].v) : tile_edge(L, L->d[depth].v);
     if (rst) {
-        if (T == 32) return S == 4 ? launch_tile<4, 32, true>(L, depth, chunks, ext_rows, st) : S == 2 ? launch_tile<2, 32, true>(L, depth, chunks, ext_rows, st) : launch_tile<1, 32, true>(L, depth, chunks, ext_rows, st);
-        return S == 4 ? launch_tile<4, 16, true>(L, depth, chunks, ext_rows, st) : S == 2 ? launch_tile<2, 16, true>(L, depth, chunks, ext_rows, st) : launch_tile<1, 16, true>(L, depth, chunks, ext_rows, st);
+        if (T == 32) return S == 4 ? launch_tile<4, 32, true>(L, depth, chunks, ext_rows, st) : S == 2 ? launch_tile<2, 32, true>(L, depth, chunks, ext_rows,
+            st) : launch_tile<1, 32, true>(L, depth, chunks, ext_rows, st);
+        return S == 4 ? launch_tile<4, 16, true>(L, depth, chunks, ext_rows, st) : S == 2 ? launch_tile<2, 16, true>(L, depth, chunks, ext_rows, st) : launch_tile<1,
+            16, true>(L, depth, chunks, ext_rows, st);
     }
     if (T == 32) return S == 4 ? launch_tile<4, 32>(L, depth, chunks, ext_rows, st) : S == 2 ? launch_tile<2, 32>(L, depth, chunks, ext_rows, st) : launch_tile<1, 32>(L, depth, chunks, ext_rows, st);
     return S == 4 ? launch_tile<4, 16>(L, depth, chunks, ext_rows, st) : S == 2 ? launch_tile<2, 16>(L, depth, chunks, ext_rows, st) : launch_tile<1, 16>(L, depth, chunks, ext_rows, st);

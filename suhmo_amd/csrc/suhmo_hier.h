@@ -19,7 +19,9 @@ struct suhmo_multi { const DV *dv; const FP *fp; int nbox, maxnx, maxny; double 
                      int merged; /* hierarchy option merged_launches: gradient + its ghosts, Re + bCoef in one launch each */
                      const void *push; const int *pbase; /* fine-fine ghost cells a side cell feeds (int2 {box, offset}), first entry of every box */ };
 int suhmo_multi_colour_pass(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int pass, hipStream_t st, bool push = false);      // suhmo_gsrb.hip
-int suhmo_multi_gsrb_box(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, const void *halo, const int *hbase, int fsrc, int fdst, int npass, int bc_ghosts, hipStream_t st);   // suhmo_gsrb.hip: 2 sweeps per launch (bc_ghosts: + the closing homogeneous ghost fill)
+// suhmo_gsrb.hip: 2 sweeps per launch (bc_ghosts: + the closing homogeneous ghost fill)
+int suhmo_multi_gsrb_box(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, const void *halo, const int *hbase, int fsrc, int fdst, int npass,
+    int bc_ghosts, hipStream_t st);
 int suhmo_multi_fill_ghosts(const suhmo_multi &m, int field, int homog, hipStream_t st);                                  // suhmo_ops.hip ...
 int suhmo_multi_apply(const suhmo_multi &m, const suhmo_phys_t &ph, bool has_alpha, int mode, hipStream_t st);            // mode 0: LPHI, 1: RES, 3: both
 int suhmo_apply_and_residual(suhmo_level *L, int depth, hipStream_t st);                                                  // LPHI and RES = rhs - LPHI in one pass

@@ -1802,7 +1802,8 @@ extern "C" int suhmo_hier_destroy(suhmo_hier_t *H)
     for (int l = 0; l < 8; l++) {
         HLev &V = H->lev[l];
         for (suhmo_level *L : V.box) (void)suhmo_level_destroy(L);
-        V.ff_side.release(); V.ff_all.release(); V.push.release(); V.pbase.release(); V.cf.release(); V.pwl.release(); V.avg.release(); V.wing.release(); V.wstart.release(); V.halo.release(); V.hbase.release();
+        V.ff_side.release(); V.ff_all.release(); V.push.release(); V.pbase.release(); V.cf.release(); V.pwl.release(); V.avg.release(); V.wing.release();
+            V.wstart.release(); V.halo.release(); V.hbase.release();
         V.targets.release(); V.faces.release(); V.dirty0.release(); V.gcells.release();
         if (V.winbuf) (void)hipFree(V.winbuf);
         if (V.winold) (void)hipFree(V.winold);
@@ -2034,7 +2035,8 @@ int suhmo_hier_gap_(suhmo_hier *H, const suhmo_model_params_t *mp, double dt, su
         int rc = suhmo_hier_create_opts(&H->gap, &d, H->nlev, nbox.data(), flat.data(), H->options.c_str()); if (rc) return rc;
         H->gap_dt = dt;
         H->gap->ag = H->ag; H->gap->ag_user = H->ag_user;                                  // same strips, same ranks
-        { suhmo_level *G0 = H->gap->lev[0].box[0]; G0->ex = B->ex; G0->ar = B->ar; G0->ar2 = B->ar2; G0->ard = B->ard; G0->user = B->user; G0->ex_begin = B->ex_begin; G0->ex_end = B->ex_end; G0->ipc = B->ipc;
+        { suhmo_level *G0 = H->gap->lev[0].box[0]; G0->ex = B->ex; G0->ar = B->ar; G0->ar2 = B->ar2; G0->ard = B->ard; G0->user = B->user;
+            G0->ex_begin = B->ex_begin; G0->ex_end = B->ex_end; G0->ipc = B->ipc;
           G0->ag = B->ag; G0->ag_user = B->ag_user; G0->agg_min_cells = B->agg_min_cells; if ((rc = suhmo_agg_setup(G0))) return rc; }
         for (int l = 0; l < H->nlev; l++)
             for (suhmo_level *L : H->gap->lev[l].box) if (!L->stub && (rc = suhmo_level_set_value(L, 0, SUHMO_F_ACOEF, 1.0, nullptr))) return rc;   // aCoeff_GH :1820-1828
@@ -2100,9 +2102,12 @@ extern "C" int suhmo_hier_get_option(const suhmo_hier_t *H, const char *key, lon
             const HLev &V = H->lev[l];
             if (q == 0) *value = H->side_bytes[l];                                   // what this rank sends per colour-pass exchange (the larger colour)
             else if (q == 1) *value = V.part ? V.held_boxes : (long)V.box.size();
-            else if (q == 2) { long c = 0; if (V.part) c = V.owned_cells; else for (size_t k = 0; k < V.box.size(); k++) { const int *b = &V.b4[4 * k]; c += (long)(b[2] - b[0] + 1) * (b[3] - b[1] + 1); } *value = c; }
+            else if (q == 2) { long c = 0; if (V.part) c = V.owned_cells; else for (size_t k = 0; k < V.box.size(); k++) { const int *b = &V.b4[4 * k];
+                c += (long)(b[2] - b[0] + 1) * (b[3] - b[1] + 1); } *value = c; }
             else if (q == 3) { long c = 0; for (suhmo_level *L : V.box) for (int f = 0; f < SUHMO_F_COUNT; f++) if (L->d[0].fp.f[f]) c += (long)L->d[0].elems * 8; *value = c; }
-            else { long c = 0; for (int k = V.part ? V.b0 : 0; k < (V.part ? V.b0 + V.nown : 0); k++) { const int *b = &V.b4[4 * k]; c += 8L * 2 * ((b[2] - b[0] + 1) + (b[3] - b[1] + 1)); } *value = c; }   // 4 sides x 8 B of the owned boxes
+            // 4 sides x 8 B of the owned boxes
+            else { long c = 0; for (int k = V.part ? V.b0 : 0; k < (V.part ? V.b0 + V.nown : 0); k++) { const int *b = &V.b4[4 * k];
+                c += 8L * 2 * ((b[2] - b[0] + 1) + (b[3] - b[1] + 1)); } *value = c; }
             return 0;
         }
     }

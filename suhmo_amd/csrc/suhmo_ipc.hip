@@ -39,7 +39,8 @@ struct IpcStrip {
     unsigned long long *herr = nullptr, *herr_dev = nullptr;                   // pinned: a kernel whose wait ran out says so here
     int nblk[SUHMO_MAXDEPTH + 1][2] = {};                                      // workgroups of the last message on each slot of a channel
     long exchanges = 0;
-    suhmo_exchange_fn prev_ex = nullptr; int (*prev_begin)(void *) = nullptr; int (*prev_end)(void *, suhmo_level *, suhmo_stream_t) = nullptr; bool hooked = false;   // what suhmo_level_attach_ipc replaced
+    // what suhmo_level_attach_ipc replaced
+    suhmo_exchange_fn prev_ex = nullptr; int (*prev_begin)(void *) = nullptr; int (*prev_end)(void *, suhmo_level *, suhmo_stream_t) = nullptr; bool hooked = false;
     int max_blocks = GMAX;                                                     // workgroups per exchange launch at most (env SUHMO_IPC_BLOCKS: A/B runs)
 };
 
@@ -202,7 +203,8 @@ int ipc_send(IpcStrip *S, SegList &sl, int chan, hipStream_t st)
 int ipc_check(IpcStrip *S)
 {
     if (!*S->herr) return 0;
-    static const char *what[] = {"?", "the acknowledgement of the lower neighbour", "the acknowledgement of the upper neighbour", "the message of the lower neighbour", "the message of the upper neighbour"};
+    static const char *what[] = {"?", "the acknowledgement of the lower neighbour", "the acknowledgement of the upper neighbour",
+        "the message of the lower neighbour", "the message of the upper neighbour"};
     suhmo_set_error("ipc transport (rank %d of %d): %s did not come within 3 s: waited for number %llu on channel %llu, saw %llu (a neighbour rank stopped, or the ranks disagree on "
                     "the sequence of exchanges); this rank has sent %llu messages on that channel", S->rank, S->world, what[S->herr[1] <= 4 ? S->herr[1] : 0], S->herr[2], S->herr[4], S->herr[3],
                     S->herr[4] <= SUHMO_MAXDEPTH ? S->seq[S->herr[4]] : 0ull);

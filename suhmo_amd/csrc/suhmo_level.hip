@@ -155,7 +155,8 @@ int suhmo_level_create_(suhmo_level_t **out, const suhmo_level_desc_t *desc, boo
     HIPCHK(hipSetDevice(desc->device));
     suhmo_level *L = new suhmo_level();
     L->desc = *desc; L->ph = desc->phys; L->device = desc->device;
-    L->ex = nullptr; L->ar = nullptr; L->ar2 = nullptr; L->ard = nullptr; L->user = nullptr; L->ex_begin = nullptr; L->ex_end = nullptr; L->rccl = nullptr; L->ipc = nullptr; L->ipc_owner = 0; L->faces_deferred = 0; L->gap = nullptr; L->gap_dt = 0.0; L->prof_on = 0; L->gsrb_variant = -1; L->fused_hc = 0;
+    L->ex = nullptr; L->ar = nullptr; L->ar2 = nullptr; L->ard = nullptr; L->user = nullptr; L->ex_begin = nullptr; L->ex_end = nullptr; L->rccl = nullptr;
+        L->ipc = nullptr; L->ipc_owner = 0; L->faces_deferred = 0; L->gap = nullptr; L->gap_dt = 0.0; L->prof_on = 0; L->gsrb_variant = -1; L->fused_hc = 0;
     // defaults of the kernel-selection knobs (each with the measurement it comes from where it is declared, suhmo_common.h) ...
     L->bcoef_fused = 1;
     L->bcoef_tile_x = 62;
@@ -337,7 +338,9 @@ static int *option_slot_int(suhmo_level *L, const char *key)
     static const struct { const char *k; int suhmo_level::*m; } tab[] = {
         {"gsrb_variant", &suhmo_level::gsrb_variant}, {"fused_hc", &suhmo_level::fused_hc}, {"bcoef_fused", &suhmo_level::bcoef_fused}, {"bcoef_tile_x", &suhmo_level::bcoef_tile_x},
         {"fused_nt", &suhmo_level::fused_nt}, {"fused_restrict", &suhmo_level::fused_restrict}, {"strips_rhs_local", &suhmo_level::strips_rhs_local},
-        {"tile_strips", &suhmo_level::tile_strips}, {"overlap_halo", &suhmo_level::overlap_halo}, {"skip_mask", &suhmo_level::skip_mask}, {"tile_chunks", &suhmo_level::tile_chunks}, {"tile_order", &suhmo_level::tile_order}, {"tile_restrict", &suhmo_level::tile_restrict}, {"fas_rhs_in_relax", &suhmo_level::fas_rhs_in_relax}, {"resid_in_relax", &suhmo_level::resid_in_relax}, {"fas_rhs_fused", &suhmo_level::fas_rhs_fused},
+        {"tile_strips", &suhmo_level::tile_strips}, {"overlap_halo", &suhmo_level::overlap_halo}, {"skip_mask", &suhmo_level::skip_mask}, {"tile_chunks",
+            &suhmo_level::tile_chunks}, {"tile_order", &suhmo_level::tile_order}, {"tile_restrict", &suhmo_level::tile_restrict}, {"fas_rhs_in_relax",
+            &suhmo_level::fas_rhs_in_relax}, {"resid_in_relax", &suhmo_level::resid_in_relax}, {"fas_rhs_fused", &suhmo_level::fas_rhs_fused},
         {"tile_s", &suhmo_level::tile_s}, {"gsrb_tile", &suhmo_level::gsrb_tile}, {"tile_t", &suhmo_level::tile_t}, {"poll_readback", &suhmo_level::poll_readback}};
     for (const auto &e : tab) if (!strcmp(key, e.k)) return &(L->*(e.m));
     return nullptr;

@@ -330,7 +330,8 @@ extern "C" int suhmo_level_attach_rccl(suhmo_level_t *L, const void *id128, int 
         static const char *names[] = {"nx", "ny (rows per strip: the level must be cut into EQUAL strips)", "halo_rows", "multigrid depths", "SUHMO_GSRB_VARIANT",
                                       "SUHMO_FUSED_MIN_CELLS", "SUHMO_TILE_MAX_CELLS", "SUHMO_GSRB_TILE", "SUHMO_TILE_T", "SUHMO_TILE_S", "SUHMO_FUSED_NT",
                                       "SUHMO_FUSED_HC", "SUHMO_FUSED_RESTRICT", "SUHMO_TILE_STRIPS", "SUHMO_TILE_CHUNKS", "SUHMO_FAS_RHS_IN_RELAX",
-                                      "SUHMO_STRIPS_RHS_LOCAL", "SUHMO_BCOEF_FUSED", "nx_global", "ny_global", "SUHMO_TILE_RESTRICT", "SUHMO_OVERLAP_HALO", "SUHMO_AGG_MIN_CELLS", "SUHMO_FAS_RHS_FUSED"};
+                                      "SUHMO_STRIPS_RHS_LOCAL", "SUHMO_BCOEF_FUSED", "nx_global", "ny_global", "SUHMO_TILE_RESTRICT", "SUHMO_OVERLAP_HALO",
+                                          "SUHMO_AGG_MIN_CELLS", "SUHMO_FAS_RHS_FUSED"};
         double h[2 * 32], *dbuf = nullptr;
         for (int k = 0; k < K; k++) { h[2 * k] = desc[k]; h[2 * k + 1] = -desc[k]; }
         bool ok = hipMalloc(&dbuf, 2 * K * sizeof(double)) == hipSuccess
